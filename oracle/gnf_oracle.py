@@ -1,0 +1,296 @@
+"""CPU oracle for the GRevNet forward / inverse + log-det hot path.  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED at the TensorFlow / Sonnet / graph_nets / TFP boundary: the reference cannot be
+imported here (tensorflow 1.x, dm-sonnet 1.34, graph_nets, tensorflow-probability 0.7.0 are absent,
+`requirements.txt:1-7`; `grevnet.py` is missing from the tree) and it ships no tests or golden
+vectors.  This file is therefore a *restatement* of the algorithm in
+`/root/reference/gnn.py`, pinned by (1) agreement of two independent formulations below,
+(2) analytic known-answer tests (closed-form micro case, Jacobian log-det, round trip, additivity,
+permutation equivariance, scipy Gaussian) in tests/test_oracle.py, (3) the committed fixtures in
+tests/golden/ generated from it by tests/golden/make_golden.py.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  The
+product (graph-normalizing-flows_amd/) never does; it fails loudly without its HIP library.
+
+Two formulations of the same maths:
+  * `Fp64Dense`  - numpy float64, dense block adjacency matmul  (the numerical ground truth)
+  * `Fp32Gather` - torch-CPU float32, gather + index_add_ in the reference's op order and
+                   granularity (un-fused, s-net and t-net each redo gather+segment-reduce, exactly
+                   like the TF graph of gnn.py:317-323).  This is also the timed CPU baseline
+                   ("CPU restatement of reference (TensorFlow unavailable)").
+
+Upstream semantics restated (all third-party, not under /root/reference):
+  EdgeBlock(use_sender_nodes only) + IdentityModule      -> edges[e] = nodes[senders[e]]      (gnn.py:130-156)
+  ReceivedEdgesToNodesAggregator(reducer)                 -> reducer(edges, receivers, sum(n_node))  (gnn.py:103,117)
+  tf.unsorted_segment_sum / _mean                         -> sum ; sum / max(count, 1)          (gnn.py:239,245,251,256)
+  snt.nets.MLP(activate_final=False), snt.Linear          -> x @ W + b, W:[in,out]              (gnn.py:159-180)
+  tf.nn.leaky_relu default alpha = 0.2 ; tf.nn.relu                                             (run_grevnet.py:158,179,205)
+  tfd.MultivariateNormalDiag(0,1).log_prob(z)             -> -0.5*sum(z^2) - D/2*ln(2*pi)       (run_grevnet.py:292-294)
+
+Parameter container used everywhere in tests (plain python, no framework):
+  mlp    := list of (W[in,out], b[out]) pairs, one per Linear layer
+  params := {"s": [[mlp]*T, [mlp]*T], "t": [[mlp]*T, [mlp]*T]}      weight_sharing=False  (gnn.py:288-296)
+            {"s": [mlp, mlp],          "t": [mlp, mlp]}              weight_sharing=True   (gnn.py:284-286)
+  index [half][i]: half 0 nets read x0 and update x1, half 1 nets read x1 and update x0 (gnn.py:320-338).
+"""
+import math
+
+import numpy as np
+
+LN_2PI = math.log(2.0 * math.pi)
+
+
+# ----------------------------------------------------------------------------------------------
+# shared helpers
+# ----------------------------------------------------------------------------------------------
+def _net(params, kind, half, i, weight_sharing):
+    """gnn.py:314-321 / 329-336: self.s[half] (shared) or self.s[half][i]."""
+    return params[kind][half] if weight_sharing else params[kind][half][i]
+
+
+def gaussian_log_prob_sum(z):
+    """run_grevnet.py:292-294: sum_n MultivariateNormalDiag(0_D, 1_D).log_prob(z_n), in float64."""
+    z = np.asarray(z, dtype=np.float64)
+    n, d = z.shape
+    return float(-0.5 * np.sum(z * z) - 0.5 * d * LN_2PI * n)
+
+
+def assemble_log_prob(log_prob_zs, logdet, n_total):
+    """run_grevnet.py:294-302: the scalars the reference logs, incl. the per-node forms."""
+    log_prob_xs = log_prob_zs + logdet
+    n = float(n_total)
+    return {
+        "log_prob_zs": log_prob_zs,
+        "log_det_jacobian": logdet,
+        "log_prob_xs": log_prob_xs,
+        "total_loss": -log_prob_xs,
+        "num_nodes": n,
+        "loss_per_node": -log_prob_xs / n,
+        "log_prob_xs_per_node": log_prob_xs / n,
+        "log_prob_zs_per_node": log_prob_zs / n,
+        "log_det_jacobian_per_node": logdet / n,
+    }
+
+
+# ----------------------------------------------------------------------------------------------
+# formulation (i): numpy float64, dense adjacency
+# ----------------------------------------------------------------------------------------------
+class Fp64Dense:
+    """Ground truth.  agg = A @ x with A[r, s] = number of edges s->r (a dense [N,N] matrix)."""
+
+    def __init__(self, senders, receivers, n_total, agg="mean", combine="agg", epsilon=1.0,
+                 activation="leaky_relu", alpha=0.2):
+        assert agg in ("sum", "mean") and combine in ("agg", "concat")
+        assert activation in ("leaky_relu", "relu")
+        self.n = int(n_total)
+        a = np.zeros((self.n, self.n), dtype=np.float64)
+        np.add.at(a, (np.asarray(receivers, np.int64), np.asarray(senders, np.int64)), 1.0)
+        self.adj = a
+        self.deg = np.maximum(a.sum(axis=1, keepdims=True), 1.0)  # unsorted_segment_mean: max(count,1)
+        self.agg, self.combine, self.eps = agg, combine, float(epsilon)
+        self.activation, self.alpha = activation, float(alpha)
+
+    def act(self, h):
+        if self.activation == "relu":
+            return np.maximum(h, 0.0)
+        return np.maximum(h, self.alpha * h)  # tf.nn.leaky_relu = max(alpha*x, x)
+
+    def mlp(self, h, layers):
+        """gnn.py:159-180: (K-1) x [Linear + act] then Linear, activate_final=False."""
+        k = len(layers)
+        for j, (w, b) in enumerate(layers):
+            h = h @ np.asarray(w, np.float64) + np.asarray(b, np.float64)
+            if j < k - 1:
+                h = self.act(h)
+        return h
+
+    def gnn(self, x, layers):
+        """gnn.py:155-156 NodeBlockGNN -> gnn.py:122-126 AggThenMLPBlock / 107-111 ConcatThenMLPBlock."""
+        agg = self.adj @ x
+        if self.agg == "mean":
+            agg = agg / self.deg
+        h = np.concatenate([x, agg], axis=1) if self.combine == "concat" else self.eps * x + agg
+        return self.mlp(h, layers)
+
+    def f(self, x, params, num_timesteps, weight_sharing=False):
+        """gnn.py:304-341 (use_batch_norm=False).  Returns (z[N,D], logdet scalar)."""
+        x = np.asarray(x, np.float64)
+        hdim = x.shape[1] // 2
+        x0, x1 = x[:, :hdim].copy(), x[:, hdim:].copy()
+        logdet = 0.0
+        for i in range(num_timesteps):
+            s = self.gnn(x0, _net(params, "s", 0, i, weight_sharing))
+            t = self.gnn(x0, _net(params, "t", 0, i, weight_sharing))
+            logdet += float(np.sum(s))
+            x1 = x1 * np.exp(s) + t
+            s = self.gnn(x1, _net(params, "s", 1, i, weight_sharing))
+            t = self.gnn(x1, _net(params, "t", 1, i, weight_sharing))
+            logdet += float(np.sum(s))
+            x0 = x0 * np.exp(s) + t
+        return np.concatenate([x0, x1], axis=1), logdet
+
+    def g(self, z, params, num_timesteps, weight_sharing=False):
+        """gnn.py:343-373 (use_batch_norm=False).  Returns x[N,D]."""
+        z = np.asarray(z, np.float64)
+        hdim = z.shape[1] // 2
+        z0, z1 = z[:, :hdim].copy(), z[:, hdim:].copy()
+        for i in reversed(range(num_timesteps)):
+            s = self.gnn(z1, _net(params, "s", 1, i, weight_sharing))
+            t = self.gnn(z1, _net(params, "t", 1, i, weight_sharing))
+            z0 = (z0 - t) * np.exp(-s)
+            s = self.gnn(z0, _net(params, "s", 0, i, weight_sharing))
+            t = self.gnn(z0, _net(params, "t", 0, i, weight_sharing))
+            z1 = (z1 - t) * np.exp(-s)
+        return np.concatenate([z0, z1], axis=1)
+
+    def log_prob(self, x, params, num_timesteps, weight_sharing=False):
+        """run_grevnet.py:290-302 on top of f."""
+        z, logdet = self.f(x, params, num_timesteps, weight_sharing)
+        out = assemble_log_prob(gaussian_log_prob_sum(z), logdet, self.n)
+        out["z"] = z
+        return out
+
+
+# ----------------------------------------------------------------------------------------------
+# formulation (ii): torch-CPU float32, gather + index_add_, reference op order (also the CPU baseline)
+# ----------------------------------------------------------------------------------------------
+class Fp32Gather:
+    """Un-fused fp32 restatement in the op order of the TF graph the reference builds."""
+
+    def __init__(self, senders, receivers, n_total, agg="mean", combine="agg", epsilon=1.0,
+                 activation="leaky_relu", alpha=0.2, dtype=None):
+        import torch
+        self.torch = torch
+        self.dtype = dtype or torch.float32
+        self.n = int(n_total)
+        self.senders = torch.as_tensor(np.asarray(senders, np.int64))
+        self.receivers = torch.as_tensor(np.asarray(receivers, np.int64))
+        self.agg, self.combine, self.eps = agg, combine, float(epsilon)
+        self.activation, self.alpha = activation, float(alpha)
+        cnt = torch.zeros(self.n, dtype=self.dtype).index_add_(
+            0, self.receivers, torch.ones(len(self.receivers), dtype=self.dtype))
+        self.cnt = torch.clamp(cnt, min=1.0).unsqueeze(1)
+
+    def to_t(self, a):
+        return self.torch.as_tensor(np.asarray(a), dtype=self.dtype)
+
+    def prep_params(self, params):
+        """numpy -> torch once, outside any timed region."""
+        def conv(m):
+            if isinstance(m, list) and m and isinstance(m[0], tuple):
+                return [(self.to_t(w), self.to_t(b)) for (w, b) in m]
+            return [conv(q) for q in m]
+        return {k: conv(v) for k, v in params.items()}
+
+    def act(self, h):
+        torch = self.torch
+        if self.activation == "relu":
+            return torch.relu(h)
+        return torch.maximum(h, self.alpha * h)
+
+    def mlp(self, h, layers):
+        k = len(layers)
+        for j, (w, b) in enumerate(layers):
+            h = h @ w + b                       # snt.Linear: MatMul + Add
+            if j < k - 1:
+                h = self.act(h)
+        return h
+
+    def gnn(self, x, layers):
+        torch = self.torch
+        edges = x.index_select(0, self.senders)                       # GatherV2 (gnn.py:151-156), materialised [E,H]
+        agg = torch.zeros_like(x).index_add_(0, self.receivers, edges)  # UnsortedSegmentSum
+        if self.agg == "mean":
+            agg = agg / self.cnt
+        h = torch.cat([x, agg], dim=1) if self.combine == "concat" else self.eps * x + agg
+        return self.mlp(h, layers)
+
+    def f(self, x, params, num_timesteps, weight_sharing=False):
+        torch = self.torch
+        hdim = x.shape[1] // 2
+        x0, x1 = x[:, :hdim], x[:, hdim:]                             # tf.split
+        logdet = torch.zeros((), dtype=self.dtype)
+        for i in range(num_timesteps):
+            s = self.gnn(x0, _net(params, "s", 0, i, weight_sharing))
+            t = self.gnn(x0, _net(params, "t", 0, i, weight_sharing))
+            logdet = logdet + s.sum()
+            x1 = x1 * torch.exp(s) + t
+            s = self.gnn(x1, _net(params, "s", 1, i, weight_sharing))
+            t = self.gnn(x1, _net(params, "t", 1, i, weight_sharing))
+            logdet = logdet + s.sum()
+            x0 = x0 * torch.exp(s) + t
+        return torch.cat([x0, x1], dim=1), logdet
+
+    def g(self, z, params, num_timesteps, weight_sharing=False):
+        torch = self.torch
+        hdim = z.shape[1] // 2
+        z0, z1 = z[:, :hdim], z[:, hdim:]
+        for i in reversed(range(num_timesteps)):
+            s = self.gnn(z1, _net(params, "s", 1, i, weight_sharing))
+            t = self.gnn(z1, _net(params, "t", 1, i, weight_sharing))
+            z0 = (z0 - t) * torch.exp(-s)
+            s = self.gnn(z0, _net(params, "s", 0, i, weight_sharing))
+            t = self.gnn(z0, _net(params, "t", 0, i, weight_sharing))
+            z1 = (z1 - t) * torch.exp(-s)
+        return torch.cat([z0, z1], dim=1)
+
+    def log_prob(self, x, params, num_timesteps, weight_sharing=False):
+        """f + run_grevnet.py:292-302 entirely in the working dtype (what the TF graph does)."""
+        torch = self.torch
+        z, logdet = self.f(x, params, num_timesteps, weight_sharing)
+        d = z.shape[1]
+        lp = (-0.5 * (z * z).sum(dim=1) - 0.5 * d * LN_2PI).sum()
+        out = assemble_log_prob(float(lp), float(logdet), self.n)
+        out["z"] = z
+        return out
+
+
+# ----------------------------------------------------------------------------------------------
+# deterministic test-parameter generator (NOT the reference's initializer; just reproducible weights)
+# ----------------------------------------------------------------------------------------------
+def make_mlp_params(rng, in_dim, latent, out_dim, num_layers, bias_std=0.1, final_scale=1.0,
+                    dtype=np.float32):
+    """K Linear layers sized [latent]*(K-1)+[out] (gnn.py:165-166).  W ~ N(0, 2/(fan_in+fan_out))
+    (glorot-style variance, gnn.py:171-172), b ~ N(0, bias_std) clipped at 2 sigma (gnn.py:173).
+    `final_scale` multiplies the last layer (W and b) so |s| stays O(1) over many coupling steps."""
+    sizes = [latent] * (num_layers - 1) + [out_dim]
+    layers, fan_in = [], in_dim
+    for j, fan_out in enumerate(sizes):
+        std = math.sqrt(2.0 / (fan_in + fan_out))
+        w = rng.standard_normal((fan_in, fan_out)) * std
+        b = np.clip(rng.standard_normal(fan_out), -2.0, 2.0) * bias_std
+        if j == len(sizes) - 1:
+            w, b = w * final_scale, b * final_scale
+        layers.append((w.astype(dtype), b.astype(dtype)))
+        fan_in = fan_out
+    return layers
+
+
+def make_grevnet_params(seed, hdim, latent, num_layers, num_timesteps, combine="agg",
+                        weight_sharing=False, bias_std=0.1, final_scale=1.0, dtype=np.float32):
+    rng = np.random.default_rng(seed)
+    in_dim = 2 * hdim if combine == "concat" else hdim
+
+    def one():
+        return make_mlp_params(rng, in_dim, latent, hdim, num_layers, bias_std, final_scale, dtype)
+
+    if weight_sharing:
+        return {"s": [one(), one()], "t": [one(), one()]}
+    return {"s": [[one() for _ in range(num_timesteps)] for _ in range(2)],
+            "t": [[one() for _ in range(num_timesteps)] for _ in range(2)]}
+
+
+def batch_graphs(n_node, n_edge, senders_local, receivers_local, graph_ids):
+    """Concatenate the chosen graphs with node-id offsets (what gn.utils_np.*_to_graphs_tuple does;
+    graph_data.py:122, grevnet_synthetic_data.py:45-47).  Returns (n_node[B], n_edge[B], senders, receivers)."""
+    eoff = np.concatenate([[0], np.cumsum(n_edge)])
+    nn, ne, ss, rr, off = [], [], [], [], 0
+    for gid in graph_ids:
+        lo, hi = eoff[gid], eoff[gid + 1]
+        ss.append(senders_local[lo:hi].astype(np.int64) + off)
+        rr.append(receivers_local[lo:hi].astype(np.int64) + off)
+        nn.append(int(n_node[gid]))
+        ne.append(int(n_edge[gid]))
+        off += int(n_node[gid])
+    return (np.array(nn, np.int32), np.array(ne, np.int32),
+            np.concatenate(ss).astype(np.int32), np.concatenate(rr).astype(np.int32))

@@ -1,0 +1,172 @@
+"""Pins for the oracle itself.  CPU only.
+
+The reference has no tests / golden vectors and cannot be imported, so these analytic known-answer
+tests are what anchors oracle/gnf_oracle.py to the maths of /root/reference/gnn.py:304-373.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gnf_oracle as O
+
+
+def tiny_graph():
+    # 5 nodes, ring + chord, directed both ways + self loops (graph_data.py:33-50 shape of data)
+    und = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 0), (1, 3)]
+    s = [i for i in range(5)] + [a for a, b in und] + [b for a, b in und]
+    r = [i for i in range(5)] + [b for a, b in und] + [a for a, b in und]
+    return np.array(s, np.int32), np.array(r, np.int32), 5
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean"])
+@pytest.mark.parametrize("combine", ["agg", "concat"])
+def test_dual_restatement_agreement(grid_small, agg, combine):
+    """(1) fp64 dense-adjacency form vs fp32 gather/index_add form."""
+    n_node, n_edge, sl, rl = grid_small
+    nn, ne, s, r = O.batch_graphs(n_node, n_edge, sl, rl, [6, 0, 3])
+    n = int(nn.sum())
+    rng = np.random.default_rng(12345)
+    for d, latent, k, t in [(2, 16, 3, 1), (8, 32, 5, 3)]:
+        x = rng.standard_normal((n, d)).astype(np.float32)
+        p = O.make_grevnet_params(7, d // 2, latent, k, t, combine=combine, final_scale=0.5)
+        a = O.Fp64Dense(s, r, n, agg=agg, combine=combine)
+        b = O.Fp32Gather(s, r, n, agg=agg, combine=combine)
+        ra = a.log_prob(x, p, t)
+        rb = b.log_prob(b.to_t(x), b.prep_params(p), t)
+        assert abs(ra["log_prob_xs_per_node"] - rb["log_prob_xs_per_node"]) < 1e-5
+        np.testing.assert_allclose(rb["z"].numpy(), ra["z"], atol=2e-5, rtol=2e-5)
+
+
+def test_hand_computed_micro_case():
+    """(4) 2-node graph, H=1, one Linear layer per net: closed form.
+    edges: 0->0, 1->1, 0->1 (node 1 receives from 0 and itself).  sum aggregation, eps=1.
+      agg(x)[0] = x[0],  agg(x)[1] = x[0]+x[1];  h = x + agg
+      step half 0: s = ws*h(x0)+bs, t = wt*h(x0)+bt ; x1 <- x1*exp(s)+t
+    """
+    s_idx = np.array([0, 1, 0], np.int32)
+    r_idx = np.array([0, 1, 1], np.int32)
+    x = np.array([[1.0, 2.0], [3.0, -1.0]])
+    ws0, bs0, wt0, bt0 = 0.1, 0.05, -0.3, 0.2
+    ws1, bs1, wt1, bt1 = -0.2, 0.0, 0.5, -0.1
+    mk = lambda w, b: [(np.array([[w]]), np.array([b]))]
+    p = {"s": [[mk(ws0, bs0)], [mk(ws1, bs1)]], "t": [[mk(wt0, bt0)], [mk(wt1, bt1)]]}
+    o = O.Fp64Dense(s_idx, r_idx, 2, agg="sum", combine="agg", epsilon=1.0)
+    z, ld = o.f(x, p, 1)
+    # by hand
+    h0 = np.array([1.0 + 1.0, 3.0 + (1.0 + 3.0)])          # x0 = [1,3]
+    s = ws0 * h0 + bs0
+    t = wt0 * h0 + bt0
+    x1 = np.array([2.0, -1.0]) * np.exp(s) + t
+    ld_hand = s.sum()
+    h1 = np.array([x1[0] + x1[0], x1[1] + (x1[0] + x1[1])])
+    s2 = ws1 * h1 + bs1
+    t2 = wt1 * h1 + bt1
+    x0 = np.array([1.0, 3.0]) * np.exp(s2) + t2
+    ld_hand += s2.sum()
+    np.testing.assert_allclose(z, np.stack([x0, x1], axis=1), rtol=1e-14)
+    assert abs(ld - ld_hand) < 1e-14
+
+
+@pytest.mark.parametrize("agg,combine", [("mean", "agg"), ("sum", "concat")])
+def test_logdet_equals_jacobian_logdet(agg, combine):
+    """(2) logdet from f == log|det d vec(z)/d vec(x)| of the whole [N*D]->[N*D] map (autograd, fp64).
+    Pins sign and the 'sum over all nodes and features' convention of gnn.py:322,337."""
+    s, r, n = tiny_graph()
+    d, t = 4, 2
+    p = O.make_grevnet_params(3, d // 2, 8, 3, t, combine=combine, final_scale=0.7, dtype=np.float64)
+    o = O.Fp32Gather(s, r, n, agg=agg, combine=combine, dtype=torch.float64)
+    pt = o.prep_params(p)
+    x = torch.as_tensor(np.random.default_rng(0).standard_normal((n, d)))
+    z, ld = o.f(x, pt, t)
+    jac = torch.autograd.functional.jacobian(lambda v: o.f(v.reshape(n, d), pt, t)[0].reshape(-1),
+                                             x.reshape(-1))
+    sign, logabs = torch.linalg.slogdet(jac)
+    assert abs(float(logabs) - float(ld)) < 1e-9
+    # cross-check the fp64 dense formulation on the same input
+    z2, ld2 = O.Fp64Dense(s, r, n, agg=agg, combine=combine).f(x.numpy(), p, t)
+    assert abs(ld2 - float(ld)) < 1e-10
+    np.testing.assert_allclose(z2, z.numpy(), atol=1e-11)
+
+
+@pytest.mark.parametrize("weight_sharing", [False, True])
+def test_round_trip(grid_small, weight_sharing):
+    """(3) g(f(x)) = x and f(g(z)) = z (gnn.py:343-373 undoes gnn.py:304-341 in reverse order)."""
+    n_node, n_edge, sl, rl = grid_small
+    nn, ne, s, r = O.batch_graphs(n_node, n_edge, sl, rl, [6, 7])
+    n = int(nn.sum())
+    d, t = 8, 4
+    p = O.make_grevnet_params(11, d // 2, 32, 4, t, weight_sharing=weight_sharing, final_scale=0.5)
+    x = np.random.default_rng(1).standard_normal((n, d))
+    o = O.Fp64Dense(s, r, n)
+    z, _ = o.f(x, p, t, weight_sharing)
+    np.testing.assert_allclose(o.g(z, p, t, weight_sharing), x, atol=1e-11)
+    np.testing.assert_allclose(o.f(o.g(x, p, t, weight_sharing), p, t, weight_sharing)[0], x, atol=1e-11)
+    o32 = O.Fp32Gather(s, r, n)
+    p32 = o32.prep_params(p)
+    x32 = o32.to_t(x)
+    z32, _ = o32.f(x32, p32, t, weight_sharing)
+    assert float((o32.g(z32, p32, t, weight_sharing) - x32).abs().max()) < 1e-4
+
+
+def test_additivity_and_permutation(community_medium):
+    """(5) log-prob of a batch = sum over single-graph runs (block-diagonal batching: the property
+    multi-GPU sharding relies on); relabelling nodes leaves it unchanged."""
+    n_node, n_edge, sl, rl = community_medium
+    ids = [3, 50, 120]
+    nn, ne, s, r = O.batch_graphs(n_node, n_edge, sl, rl, ids)
+    n = int(nn.sum())
+    d, t = 8, 2
+    p = O.make_grevnet_params(5, d // 2, 16, 3, t, final_scale=0.5)
+    x = np.random.default_rng(2).standard_normal((n, d))
+    full = O.Fp64Dense(s, r, n).log_prob(x, p, t)
+    acc, off = 0.0, 0
+    for gid in ids:
+        n1, e1, s1, r1 = O.batch_graphs(n_node, n_edge, sl, rl, [gid])
+        k = int(n1.sum())
+        acc += O.Fp64Dense(s1, r1, k).log_prob(x[off:off + k], p, t)["log_prob_xs"]
+        off += k
+    assert abs(acc - full["log_prob_xs"]) < 1e-8
+    perm = np.random.default_rng(3).permutation(n)
+    inv = np.empty(n, np.int64)
+    inv[perm] = np.arange(n)          # old id v -> new id inv[v]; new node j holds old node perm[j]
+    pr = O.Fp64Dense(inv[s], inv[r], n).log_prob(x[perm], p, t)
+    assert abs(pr["log_prob_xs"] - full["log_prob_xs"]) < 1e-8
+    np.testing.assert_allclose(pr["z"], full["z"][perm], atol=1e-11)
+
+
+def test_aggregator_semantics():
+    """(6) mean = sum / in-degree; sum on a fully connected graph (+self loops) = per-graph column sum
+    (grevnet_synthetic_data.py:17-21, utils.py:164-183)."""
+    n = 6
+    s = np.repeat(np.arange(n), n).astype(np.int32)   # sender-major all ordered pairs incl. self
+    r = np.tile(np.arange(n), n).astype(np.int32)
+    x = np.random.default_rng(4).standard_normal((n, 3))
+    ident = [(np.eye(3), np.zeros(3))]
+    o_sum = O.Fp64Dense(s, r, n, agg="sum", epsilon=0.0)
+    np.testing.assert_allclose(o_sum.gnn(x, ident), np.tile(x.sum(0), (n, 1)), atol=1e-13)
+    o_mean = O.Fp64Dense(s, r, n, agg="mean", epsilon=0.0)
+    np.testing.assert_allclose(o_mean.gnn(x, ident), np.tile(x.mean(0), (n, 1)), atol=1e-13)
+    # isolated node (no incoming edge): empty segment -> 0 for both sum and mean (max(count,1))
+    o_iso = O.Fp64Dense(np.array([0], np.int32), np.array([0], np.int32), 2, agg="mean", epsilon=0.0)
+    out = o_iso.gnn(np.array([[2.0], [5.0]]), [(np.eye(1), np.zeros(1))])
+    np.testing.assert_allclose(out, [[2.0], [0.0]])
+    o_iso32 = O.Fp32Gather(np.array([0], np.int32), np.array([0], np.int32), 2, agg="mean", epsilon=0.0)
+    out32 = o_iso32.gnn(o_iso32.to_t([[2.0], [5.0]]), o_iso32.prep_params({"m": [(np.eye(1), np.zeros(1))]})["m"])
+    np.testing.assert_allclose(out32.numpy(), [[2.0], [0.0]])
+
+
+def test_gaussian_term_vs_scipy():
+    """(7) -0.5*sum z^2 - D/2 ln 2pi  vs scipy.stats.multivariate_normal."""
+    from scipy.stats import multivariate_normal
+    z = np.random.default_rng(5).standard_normal((7, 6))
+    ref = multivariate_normal(mean=np.zeros(6), cov=np.eye(6)).logpdf(z).sum()
+    assert abs(O.gaussian_log_prob_sum(z) - ref) < 1e-10
+
+
+def test_activation_semantics():
+    o = O.Fp64Dense(np.array([0], np.int32), np.array([0], np.int32), 1)
+    np.testing.assert_allclose(o.act(np.array([-2.0, 0.0, 3.0])), [-0.4, 0.0, 3.0])
+    o.activation = "relu"
+    np.testing.assert_allclose(o.act(np.array([-2.0, 0.0, 3.0])), [0.0, 0.0, 3.0])
