@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py - GRevNet forward + log-det throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+One "step" = one pass of the hot path over one batch: GRevNet.f (gnn.py:304-341) + the log-prob
+reductions (run_grevnet.py:290-302) on a synthetic community_medium batch, inputs (node features,
+edge list -> CSR, weights) already resident in HBM, the two batch scalars landing in host memory
+before the timed region closes.  Workload = BASELINE.json configs[1]: community_medium batch=64
+graphs per GPU, 8-step GRevNet; hyper-parameters frozen in BASELINE.md section 4 (D=64, L=256, K=5,
+avg_then_mlp eps=1, leaky_relu 0.2, sparse dataset topology + self loops, no batch norm).  With N
+GPUs the batch is 64*N graphs sharded N ways (weak scaling, configs[2] at N=8) and every step ends
+with the path's single collective: one all-reduce of [logdet, sum z^2, num_nodes] (3 x fp64).
+
+Prints ONE JSON line (rank 0).  `value` = node-updates/s over all GPUs, one node-update = one node
+through one GRevNet timestep (both half couplings), SURVEY.md 8d.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HP = dict(D=64, latent=256, K=5, T=8, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu",
+          weight_sharing=False)
+GRAPHS_PER_GPU = 64
+WEIGHT_SEED = 99
+FINAL_SCALE = 0.25     # last Linear layer of every net scaled by this so |s| stays O(1) over 16 half-steps
+PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_half_step(n, e, hp):
+    """flops and minimum HBM bytes of ONE fused coupling half-step launch."""
+    h, l, k = hp["D"] // 2, hp["latent"], hp["K"]
+    in0 = 2 * h if hp["combine"] == "concat" else h
+    if k == 1:
+        p_w, p_b = in0 * h, h
+    else:
+        p_w = in0 * l + (k - 2) * l * l + l * h
+        p_b = (k - 1) * l + h
+    flops = n * 4 * p_w + e * h + 6 * n * h
+    bytes_ = 12 * n * h + 4 * e + 4 * n + 8 * (p_w + p_b)
+    return flops, bytes_
+
+
+def make_params(seed, hp, final_scale):
+    """Bench weights (same layout as tests' fixtures): W ~ N(0, 2/(fan_in+fan_out)) (glorot variance,
+    gnn.py:171-172), b ~ N(0, 0.1) clipped at 2 sigma (gnn.py:173), last layer x final_scale."""
+    rng = np.random.default_rng(seed)
+    h, l, k, t = hp["D"] // 2, hp["latent"], hp["K"], hp["T"]
+    in0 = 2 * h if hp["combine"] == "concat" else h
+
+    def mlp():
+        layers, fan_in = [], in0
+        sizes = [l] * (k - 1) + [h]
+        for j, fan_out in enumerate(sizes):
+            w = rng.standard_normal((fan_in, fan_out)) * np.sqrt(2.0 / (fan_in + fan_out))
+            b = np.clip(rng.standard_normal(fan_out), -2.0, 2.0) * 0.1
+            if j == len(sizes) - 1:
+                w, b = w * final_scale, b * final_scale
+            layers.append((w.astype(np.float32), b.astype(np.float32)))
+            fan_in = fan_out
+        return layers
+
+    return {"s": [[mlp() for _ in range(t)] for _ in range(2)], "t": [[mlp() for _ in range(t)] for _ in range(2)]}
+
+
+def make_batch(n_gpus, rank, seed=12345):
+    """Global batch = 64*n_gpus graphs drawn with replacement from the 80% train split
+    (graph_data.py:77-78,112-122), sharded by greedy balance on nodes+edges; returns this rank's shard."""
+    from gnf_amd.datasets import GraphDataset
+    from gnf_amd.sharding import shard_graph_ids
+    ds = GraphDataset("graph_rnn_community_medium", HP["D"], seed=seed)
+    ids = ds.sample_ids(GRAPHS_PER_GPU * n_gpus)
+    nn, ne = ds.all.n_node[ids], ds.all.n_edge[ids]
+    mine = ids[shard_graph_ids(nn, ne, n_gpus)[rank]]
+    rng = np.random.default_rng(seed + 1000 + rank)
+    dicts = ds.all.data_dicts(mine, lambda n: rng.standard_normal((n, HP["D"])).astype(np.float32))
+    return dicts, int(nn.sum()), int(ne.sum())
+
+
+def cpu_baseline(dicts, params, budget_s=20.0, min_iters=3, warm=1):
+    """The oracle's fp32 gather/index_add restatement (reference op order, un-fused) timed on this
+    box's host cores: 'CPU restatement of reference (TensorFlow unavailable)', BASELINE.md section 3."""
+    from oracle import gnf_oracle as O
+    from gnf_amd.graphs import data_dicts_to_graphs_tuple
+    g = data_dicts_to_graphs_tuple(dicts)
+    n = g.nodes.shape[0]
+    o = O.Fp32Gather(g.senders.numpy(), g.receivers.numpy(), n, agg=HP["agg"], combine=HP["combine"],
+                     epsilon=HP["epsilon"], activation=HP["activation"])
+    pt = o.prep_params(params)
+    x = g.nodes.clone()
+    res = None
+    for _ in range(warm):
+        res = o.log_prob(x, pt, HP["T"])
+    iters, t0 = 0, time.perf_counter()
+    while True:
+        res = o.log_prob(x, pt, HP["T"])
+        iters += 1
+        dt = time.perf_counter() - t0
+        if iters >= min_iters and (dt >= budget_s or iters >= 200):
+            break
+    return {"value": n * HP["T"] * iters / dt, "unit": "node-updates/s", "cores": torch.get_num_threads(),
+            "kind": "port", "ms_per_step": 1e3 * dt / iters,
+            "sample": f"{iters} forwards of the same rank-0 batch (N={n} nodes, T={HP['T']}) in {dt:.1f}s, "
+                      f"torch-CPU fp32 restatement of gnn.py in reference op order, os.cpu_count()={os.cpu_count()}"}, res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--layered", action="store_true", help="run the generic layered kernels instead of the fused one")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-each-step", action="store_true", help="latency mode: host waits for every step's scalar")
+    ap.add_argument("--kernel-timing-steps", type=int, default=10)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+
+    from helpers import make_product_grevnet
+    from gnf_amd import _abi
+    from gnf_amd.flow import forward_shard_sums, log_prob_from_sums
+    from gnf_amd.graphs import csr_of, data_dicts_to_graphs_tuple
+    from gnf_amd.sharding import all_reduce_shard_sums
+    _abi.lib()
+
+    dicts, n_global, e_global = make_batch(world, rank)
+    params = make_params(WEIGHT_SEED, HP, FINAL_SCALE)
+    graph = data_dicts_to_graphs_tuple(dicts, dev)
+    n_local, e_local = int(graph.nodes.shape[0]), int(graph.senders.shape[0])
+    net = make_product_grevnet(HP, params)
+    net.fused = not args.layered
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    csr = csr_of(graph)                      # device CSR build (gnf_build_csr), cached afterwards
+    torch.cuda.synchronize()
+    csr_ms = 1e3 * (time.perf_counter() - t0)
+
+    sums3 = torch.zeros(3, dtype=torch.float64, device=dev)
+    sums3[2] = float(n_local)
+    host = torch.zeros(args.steps + args.warmup + 1, 3, dtype=torch.float64).pin_memory()
+
+    def step(i):
+        _, s3 = forward_shard_sums(net, graph, sums3)
+        if world > 1:
+            s3[2] = float(n_local)           # all-reduce sums in place: restore this rank's count first
+            all_reduce_shard_sums(s3)
+        host[i].copy_(s3, non_blocking=True)
+        if args.sync_each_step:
+            torch.cuda.current_stream().synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    ms_per_step = 1e3 * elapsed / args.steps
+    last = log_prob_from_sums(host[args.warmup + args.steps - 1].tolist(), HP["D"])
+    value = n_global * HP["T"] * args.steps / elapsed
+
+    # ---- dominant-kernel timing with HIP events on the launch stream (one event pair per launch) ----
+    import ctypes as C
+    lib = _abi.lib()
+    flow = net._flow(HP["D"] // 2, dev)
+    ws_bytes = lib.gnf_workspace_bytes(n_local, HP["D"], C.byref(flow))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    buf = graph.nodes.clone()
+    h = HP["D"] // 2
+    evs = []
+    st = _abi.stream_ptr(dev)
+    for it in range(args.kernel_timing_steps + 2):
+        buf.copy_(graph.nodes)
+        for i in range(HP["T"]):
+            for half in range(2):
+                q = half * HP["T"] + i
+                cond = buf.data_ptr() + (0 if half == 0 else 4 * h)
+                upd = buf.data_ptr() + (4 * h if half == 0 else 0)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                _abi.check(lib.gnf_coupling_half_f32(C.byref(csr.desc), C.byref(flow.s_nets[q]),
+                                                     C.byref(flow.t_nets[q]), C.byref(flow.gnn), C.c_void_p(cond),
+                                                     C.c_void_p(upd), buf.stride(0), h, 0, None, _abi.ptr(ws),
+                                                     ws_bytes, st), "gnf_coupling_half_f32")
+                b.record()
+                if it >= 2:
+                    evs.append((a, b))
+    torch.cuda.synchronize()
+    kernel_us = 1e3 * float(np.mean([a.elapsed_time(b) for a, b in evs])) if evs else float("nan")
+    flops, abytes = algorithmic_half_step(n_local, e_local, HP)
+    achieved_tflops = flops / (kernel_us * 1e-6) / 1e12
+    roofline = {"bound": "mfma", "achieved": round(achieved_tflops, 3), "peak": PEAK_FP32_MATRIX_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+                "kernel": "k_half_fused<1>" if net.fused else "layered (aggregate + 2K x k_linear + k_coupling)",
+                "kernel_us": round(kernel_us, 2), "launches_per_step": 2 * HP["T"],
+                "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": abytes,
+                "hbm_floor_us": round(abytes / (PEAK_HBM_GBS * 1e3), 3)}
+
+    out = {
+        "metric": "node-updates/sec (fwd+logdet) on community_medium batch", "value": round(value, 1),
+        "unit": "node-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"community_medium batch={GRAPHS_PER_GPU}/GPU ({GRAPHS_PER_GPU * world} graphs total), "
+                               f"{HP['T']}-step GRevNet fwd+logdet, D={HP['D']} L={HP['latent']} K={HP['K']} "
+                               f"avg_then_mlp eps=1 leaky_relu(0.2), sparse topology+self loops",
+                   "nodes_total": n_global, "edges_total": e_global, "nodes_rank0": n_local, "edges_rank0": e_local,
+                   "weights": f"N(0,2/(fan_in+fan_out)), seed {WEIGHT_SEED}, last layer x{FINAL_SCALE}",
+                   "parallelism": f"graph-shard dp{world}, 1 all-reduce of 3xfp64 per step" if world > 1 else "single GPU",
+                   "path": "fused MFMA half-step kernel" if net.fused else "layered kernels",
+                   "csr": f"prebuilt on device once (gnf_build_csr {csr_ms:.3f} ms incl. first-call overhead), cached",
+                   "host_sync": "every step" if args.sync_each_step else "results copied to pinned host memory each step; one sync at end"},
+        "log_prob_xs_per_node": last["log_prob_xs_per_node"],
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cb, ref = cpu_baseline(dicts, params)
+        out["cpu_baseline"] = cb
+        out["speedup_vs_cpu_baseline"] = round(value / cb["value"], 2)
+        out["log_prob_delta_vs_cpu_fp32"] = abs(last["log_prob_xs_per_node"] - ref["log_prob_xs_per_node"])
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,109 @@
+"""ctypes binding of libgnf_hip.so (the C ABI declared in include/gnf.h).
+
+This is the whole FFI surface: plain pointers and sizes, PyTorch tensors only as the owners of
+device memory (`tensor.data_ptr()`) and of the stream (`torch.cuda.current_stream().cuda_stream`).
+There is NO fallback: if the HIP library is missing or a call fails, we raise.
+"""
+import ctypes as C
+import os
+
+GNF_MAX_LAYERS = 8
+GNF_ABI_VERSION = 1
+
+GNF_AGG_SUM, GNF_AGG_MEAN = 0, 1
+GNF_COMBINE_EPS, GNF_COMBINE_CONCAT = 0, 1
+GNF_ACT_RELU, GNF_ACT_LEAKY_RELU = 0, 1
+GNF_FORWARD, GNF_INVERSE = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgnf_hip.so")
+
+
+class GnfError(RuntimeError):
+    pass
+
+
+class GnfCsr(C.Structure):
+    _fields_ = [("rowptr", C.c_void_p), ("col", C.c_void_p), ("n_nodes", C.c_int64),
+                ("n_edges", C.c_int64)]
+
+
+class GnfMlp(C.Structure):
+    _fields_ = [("num_layers", C.c_int32), ("dims", C.c_int32 * (GNF_MAX_LAYERS + 1)),
+                ("W", C.c_void_p * GNF_MAX_LAYERS), ("b", C.c_void_p * GNF_MAX_LAYERS),
+                ("packed", C.c_void_p)]
+
+
+class GnfGnnSpec(C.Structure):
+    _fields_ = [("agg", C.c_int32), ("combine", C.c_int32), ("epsilon", C.c_float),
+                ("activation", C.c_int32), ("alpha", C.c_float)]
+
+
+class GnfFlow(C.Structure):
+    _fields_ = [("num_timesteps", C.c_int32), ("weight_sharing", C.c_int32),
+                ("s_nets", C.POINTER(GnfMlp)), ("t_nets", C.POINTER(GnfMlp)), ("gnn", GnfGnnSpec)]
+
+
+_SIGNATURES = {
+    "gnf_abi_version": (C.c_int, []),
+    "gnf_last_error": (C.c_char_p, []),
+    "gnf_packed_floats": (C.c_int64, [C.POINTER(GnfMlp)]),
+    "gnf_pack_mlp": (C.c_int, [C.POINTER(GnfMlp), C.c_void_p, C.c_void_p]),
+    "gnf_csr_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "gnf_build_csr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gnf_aggregate_f32": (C.c_int, [C.POINTER(GnfCsr), C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                    C.c_void_p, C.c_int64, C.c_void_p]),
+    "gnf_gnn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.POINTER(GnfMlp), C.c_int32]),
+    "gnf_gnn_apply_f32": (C.c_int, [C.POINTER(GnfCsr), C.POINTER(GnfMlp), C.POINTER(GnfGnnSpec),
+                                    C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
+                                    C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gnf_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.POINTER(GnfFlow)]),
+    "gnf_coupling_half_f32": (C.c_int, [C.POINTER(GnfCsr), C.POINTER(GnfMlp), C.POINTER(GnfMlp),
+                                        C.POINTER(GnfGnnSpec), C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
+                                        C.c_void_p]),
+    "gnf_grevnet_f32": (C.c_int, [C.POINTER(GnfCsr), C.POINTER(GnfFlow), C.c_void_p, C.c_int64,
+                                  C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gnf_gauss_sumsq_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p,
+                                      C.c_void_p, C.c_size_t, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    """Load libgnf_hip.so once.  Raises GnfError (never falls back) if it is absent or stale."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GnfError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if handle.gnf_abi_version() != GNF_ABI_VERSION:
+            raise GnfError(f"libgnf_hip.so ABI {handle.gnf_abi_version()} != binding {GNF_ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().gnf_last_error()
+        raise GnfError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def stream_ptr(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())

@@ -1,0 +1,380 @@
+// extern "C" entry points of libgnf_hip.so (declared in include/gnf.h): host-side validation,
+// workspace planning and dispatch onto the gfx950 kernels.  No torch types, no allocation, no
+// host synchronisation; every launch goes to the caller's stream.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "gnf_common.h"
+
+namespace gnf {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int validate_mlp(const GnfMlp* m, const char* what) {
+    if (!m) {
+        set_error("%s: null GnfMlp", what);
+        return GNF_EINVAL;
+    }
+    if (m->num_layers < 1 || m->num_layers > GNF_MAX_LAYERS) {
+        set_error("%s: num_layers=%d outside [1,%d]", what, m->num_layers, GNF_MAX_LAYERS);
+        return GNF_ESHAPE;
+    }
+    for (int j = 0; j <= m->num_layers; ++j)
+        if (m->dims[j] < 1) {
+            set_error("%s: dims[%d]=%d must be >= 1", what, j, m->dims[j]);
+            return GNF_ESHAPE;
+        }
+    for (int j = 0; j < m->num_layers; ++j)
+        if (!m->W[j] || !m->b[j]) {
+            set_error("%s: layer %d has a null W or b pointer", what, j);
+            return GNF_EINVAL;
+        }
+    return GNF_OK;
+}
+
+static int validate_spec(const GnfGnnSpec* g) {
+    if (!g) {
+        set_error("null GnfGnnSpec");
+        return GNF_EINVAL;
+    }
+    if (g->agg != GNF_AGG_SUM && g->agg != GNF_AGG_MEAN) {
+        set_error("GnfGnnSpec.agg=%d is not GNF_AGG_SUM/GNF_AGG_MEAN", g->agg);
+        return GNF_EINVAL;
+    }
+    if (g->combine != GNF_COMBINE_EPS && g->combine != GNF_COMBINE_CONCAT) {
+        set_error("GnfGnnSpec.combine=%d is not GNF_COMBINE_EPS/GNF_COMBINE_CONCAT", g->combine);
+        return GNF_EINVAL;
+    }
+    if (g->activation != GNF_ACT_RELU && g->activation != GNF_ACT_LEAKY_RELU) {
+        set_error("GnfGnnSpec.activation=%d is not GNF_ACT_RELU/GNF_ACT_LEAKY_RELU", g->activation);
+        return GNF_EINVAL;
+    }
+    return GNF_OK;
+}
+
+static int validate_csr(const GnfCsr* c) {
+    if (!c) {
+        set_error("null GnfCsr");
+        return GNF_EINVAL;
+    }
+    if (c->n_nodes < 0 || c->n_edges < 0 || c->n_nodes > INT32_MAX || c->n_edges > INT32_MAX) {
+        set_error("GnfCsr: n_nodes=%lld n_edges=%lld out of int32 range", (long long)c->n_nodes,
+                  (long long)c->n_edges);
+        return GNF_ESHAPE;
+    }
+    if (c->n_nodes > 0 && (!c->rowptr || (c->n_edges > 0 && !c->col))) {
+        set_error("GnfCsr: null rowptr/col");
+        return GNF_EINVAL;
+    }
+    return GNF_OK;
+}
+
+// s/t nets of one half-step must agree with H and the combine mode (gnn.py:107-126: the MLP input
+// is [x|agg] (2H) or eps*x+agg (H); its output feeds exp(s) / +t on an H-wide half, gnn.py:323).
+static int validate_pair(const GnfMlp* s, const GnfMlp* t, const GnfGnnSpec* g, int32_t H) {
+    int rc = validate_mlp(s, "s_net");
+    if (rc) return rc;
+    rc = validate_mlp(t, "t_net");
+    if (rc) return rc;
+    const int in0 = (g->combine == GNF_COMBINE_CONCAT) ? 2 * H : H;
+    const GnfMlp* nets[2] = {s, t};
+    for (int q = 0; q < 2; ++q) {
+        const GnfMlp* m = nets[q];
+        if (m->dims[0] != in0 || m->dims[m->num_layers] != H) {
+            set_error("%s: MLP maps %d -> %d but the coupling needs %d -> %d (H=%d, combine=%d)",
+                      q ? "t_net" : "s_net", m->dims[0], m->dims[m->num_layers], in0, H, H, g->combine);
+            return GNF_ESHAPE;
+        }
+    }
+    return GNF_OK;
+}
+
+WorkspacePlan plan_workspace(int64_t n_nodes, int32_t H, const GnfMlp* net, int32_t combine,
+                             int64_t n_halfsteps) {
+    WorkspacePlan p;
+    p.partial_stride = coupling_blocks_max(n_nodes);
+    p.n_halfsteps = n_halfsteps;
+    size_t pb = (size_t)(n_halfsteps * p.partial_stride + kMaxGaussBlocks) * sizeof(double);
+    p.partial_bytes = (pb + 255) / 256 * 256;
+    int lmax = 1;
+    if (net)
+        for (int j = 1; j < net->num_layers; ++j) lmax = lmax > net->dims[j] ? lmax : net->dims[j];
+    const int in0 = (combine == GNF_COMBINE_CONCAT) ? 2 * H : H;
+    p.scratch_floats = (size_t)n_nodes * (size_t)(in0 + 2 * lmax + 2 * H);
+    p.total_bytes = p.partial_bytes + p.scratch_floats * sizeof(float);
+    return p;
+}
+
+static int run_half(const HalfStep& hs, float* scratch, hipStream_t st) {
+    if (fused_supported(hs)) return launch_half_fused(hs, st);
+    return launch_half_layered(hs, scratch, st);
+}
+
+static const GnfMlp* pick(const GnfFlow* f, const GnfMlp* nets, int half, int i) {
+    return f->weight_sharing ? &nets[half] : &nets[half * f->num_timesteps + i];
+}
+
+}  // namespace gnf
+
+using namespace gnf;
+
+extern "C" {
+
+int gnf_abi_version(void) { return GNF_ABI_VERSION; }
+
+const char* gnf_last_error(void) { return g_err; }
+
+int64_t gnf_packed_floats(const GnfMlp* mlp) {
+    if (!mlp || mlp->num_layers < 1 || mlp->num_layers > GNF_MAX_LAYERS) {
+        set_error("gnf_packed_floats: bad GnfMlp");
+        return GNF_EINVAL;
+    }
+    return packed_floats(mlp);
+}
+
+int gnf_pack_mlp(const GnfMlp* mlp, float* packed, gnf_stream_t stream) {
+    int rc = validate_mlp(mlp, "gnf_pack_mlp");
+    if (rc) return rc;
+    if (!packed) {
+        set_error("gnf_pack_mlp: null output buffer");
+        return GNF_EINVAL;
+    }
+    return launch_pack_mlp(mlp, packed, (hipStream_t)stream);
+}
+
+int gnf_aggregate_f32(const GnfCsr* csr, const float* x, int64_t ldx, int32_t H, int32_t agg,
+                      float* out, int64_t ldo, gnf_stream_t stream) {
+    int rc = validate_csr(csr);
+    if (rc) return rc;
+    if (agg != GNF_AGG_SUM && agg != GNF_AGG_MEAN) {
+        set_error("gnf_aggregate_f32: agg=%d", agg);
+        return GNF_EINVAL;
+    }
+    if (H < 1 || ldx < H || ldo < H) {
+        set_error("gnf_aggregate_f32: H=%d ldx=%lld ldo=%lld", H, (long long)ldx, (long long)ldo);
+        return GNF_ESHAPE;
+    }
+    if (csr->n_nodes > 0 && (!x || !out)) {
+        set_error("gnf_aggregate_f32: null x/out");
+        return GNF_EINVAL;
+    }
+    return launch_aggregate(csr->rowptr, csr->col, csr->n_nodes, x, ldx, H, agg == GNF_AGG_MEAN, 2,
+                            0.f, out, ldo, (hipStream_t)stream);
+}
+
+size_t gnf_gnn_workspace_bytes(int64_t n_nodes, int32_t H, const GnfMlp* mlp, int32_t combine) {
+    if (n_nodes < 0 || H < 1 || !mlp) return 0;
+    return plan_workspace(n_nodes, H, mlp, combine, 0).scratch_floats * sizeof(float);
+}
+
+int gnf_gnn_apply_f32(const GnfCsr* csr, const GnfMlp* mlp, const GnfGnnSpec* gnn, const float* x,
+                      int64_t ldx, int32_t H, float* out, int64_t ldo, void* ws, size_t ws_bytes,
+                      gnf_stream_t stream) {
+    int rc = validate_csr(csr);
+    if (rc) return rc;
+    rc = validate_spec(gnn);
+    if (rc) return rc;
+    rc = validate_mlp(mlp, "gnf_gnn_apply_f32");
+    if (rc) return rc;
+    const int in0 = (gnn->combine == GNF_COMBINE_CONCAT) ? 2 * H : H;
+    const int od = mlp->dims[mlp->num_layers];
+    if (H < 1 || ldx < H || ldo < od || mlp->dims[0] != in0) {
+        set_error("gnf_gnn_apply_f32: H=%d ldx=%lld ldo=%lld, MLP maps %d -> %d, needs input %d", H,
+                  (long long)ldx, (long long)ldo, mlp->dims[0], od, in0);
+        return GNF_ESHAPE;
+    }
+    if (csr->n_nodes == 0) return GNF_OK;
+    if (!x || !out || !ws) {
+        set_error("gnf_gnn_apply_f32: null x/out/ws");
+        return GNF_EINVAL;
+    }
+    if (ws_bytes < gnf_gnn_workspace_bytes(csr->n_nodes, H, mlp, gnn->combine)) {
+        set_error("gnf_gnn_apply_f32: workspace %zu < %zu bytes", ws_bytes,
+                  gnf_gnn_workspace_bytes(csr->n_nodes, H, mlp, gnn->combine));
+        return GNF_EWORKSPACE;
+    }
+    return launch_gnn_layered(csr->rowptr, csr->col, csr->n_nodes, x, ldx, H, *gnn, mlp, out, ldo,
+                              (float*)ws, (hipStream_t)stream);
+}
+
+size_t gnf_workspace_bytes(int64_t n_nodes, int32_t D, const GnfFlow* flow) {
+    if (n_nodes < 0 || D < 2 || !flow || !flow->s_nets) return 0;
+    return plan_workspace(n_nodes, D / 2, &flow->s_nets[0], flow->gnn.combine,
+                          2 * (int64_t)(flow->num_timesteps > 0 ? flow->num_timesteps : 1))
+        .total_bytes;
+}
+
+int gnf_coupling_half_f32(const GnfCsr* csr, const GnfMlp* s_net, const GnfMlp* t_net,
+                          const GnfGnnSpec* gnn, const float* x_cond, float* x_upd, int64_t ld,
+                          int32_t H, int32_t direction, double* logdet_accum, void* ws,
+                          size_t ws_bytes, gnf_stream_t stream) {
+    int rc = validate_csr(csr);
+    if (rc) return rc;
+    rc = validate_spec(gnn);
+    if (rc) return rc;
+    if (H < 1 || ld < 2 * (int64_t)H) {
+        set_error("gnf_coupling_half_f32: H=%d ld=%lld (need ld >= 2H)", H, (long long)ld);
+        return GNF_ESHAPE;
+    }
+    rc = validate_pair(s_net, t_net, gnn, H);
+    if (rc) return rc;
+    if (direction != GNF_FORWARD && direction != GNF_INVERSE) {
+        set_error("gnf_coupling_half_f32: direction=%d", direction);
+        return GNF_EINVAL;
+    }
+    if (csr->n_nodes == 0) return GNF_OK;
+    if (!x_cond || !x_upd || !ws) {
+        set_error("gnf_coupling_half_f32: null x_cond/x_upd/ws");
+        return GNF_EINVAL;
+    }
+    const WorkspacePlan p = plan_workspace(csr->n_nodes, H, s_net, gnn->combine, 1);
+    if (ws_bytes < p.total_bytes) {
+        set_error("gnf_coupling_half_f32: workspace %zu < %zu bytes", ws_bytes, p.total_bytes);
+        return GNF_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int32_t nparts = 0;
+    HalfStep hs{csr->rowptr, csr->col, csr->n_nodes, x_cond, x_upd, ld, H, direction, *gnn,
+                s_net, t_net, (double*)ws, &nparts};
+    rc = run_half(hs, (float*)((char*)ws + p.partial_bytes), st);
+    if (rc) return rc;
+    if (logdet_accum)
+        return launch_finalize((const double*)ws, nparts, nullptr, 0, logdet_accum, 1, 0, st);
+    return GNF_OK;
+}
+
+int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld, int32_t D,
+                    int32_t direction, double* sums, void* ws, size_t ws_bytes, gnf_stream_t stream) {
+    int rc = validate_csr(csr);
+    if (rc) return rc;
+    if (!flow || !flow->s_nets || !flow->t_nets) {
+        set_error("gnf_grevnet_f32: null flow / nets");
+        return GNF_EINVAL;
+    }
+    rc = validate_spec(&flow->gnn);
+    if (rc) return rc;
+    if (flow->num_timesteps < 0) {
+        set_error("gnf_grevnet_f32: num_timesteps=%d", flow->num_timesteps);
+        return GNF_ESHAPE;
+    }
+    if (D < 2 || (D & 1) || ld < D) {
+        // tf.split(x, 2, axis=1) (gnn.py:306) requires an even feature width
+        set_error("gnf_grevnet_f32: D=%d must be even and >= 2, ld=%lld >= D", D, (long long)ld);
+        return GNF_ESHAPE;
+    }
+    if (direction != GNF_FORWARD && direction != GNF_INVERSE) {
+        set_error("gnf_grevnet_f32: direction=%d", direction);
+        return GNF_EINVAL;
+    }
+    const int H = D / 2;
+    const int T = flow->num_timesteps;
+    const int n_nets = flow->weight_sharing ? 2 : 2 * T;
+    for (int q = 0; q < n_nets; ++q) {
+        rc = validate_pair(&flow->s_nets[q], &flow->t_nets[q], &flow->gnn, H);
+        if (rc) return rc;
+        // one make_gnn_fn builds every net (gnn.py:266-267): identical layer widths
+        if (memcmp(flow->s_nets[q].dims, flow->s_nets[0].dims, sizeof(int32_t) * (GNF_MAX_LAYERS + 1)) ||
+            flow->s_nets[q].num_layers != flow->s_nets[0].num_layers ||
+            memcmp(flow->t_nets[q].dims, flow->s_nets[0].dims, sizeof(int32_t) * (GNF_MAX_LAYERS + 1)) ||
+            flow->t_nets[q].num_layers != flow->s_nets[0].num_layers) {
+            set_error("gnf_grevnet_f32: net %d has different layer widths than net 0", q);
+            return GNF_ESHAPE;
+        }
+    }
+    if (direction == GNF_FORWARD && !sums) {
+        set_error("gnf_grevnet_f32: FORWARD needs a device sums[2] buffer");
+        return GNF_EINVAL;
+    }
+    const int64_t n = csr->n_nodes;
+    if (n > 0 && (!x || !ws)) {
+        set_error("gnf_grevnet_f32: null x/ws");
+        return GNF_EINVAL;
+    }
+    const WorkspacePlan p = plan_workspace(n, H, n_nets ? &flow->s_nets[0] : nullptr,
+                                           flow->gnn.combine, 2 * (int64_t)(T > 0 ? T : 1));
+    if (n > 0 && ws_bytes < p.total_bytes) {
+        set_error("gnf_grevnet_f32: workspace %zu < %zu bytes", ws_bytes, p.total_bytes);
+        return GNF_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    double* partials = (double*)ws;
+    float* scratch = (float*)((char*)ws + p.partial_bytes);
+    float* half0 = x;       // columns [0, H)
+    float* half1 = x + H;   // columns [H, D)
+    int64_t used = 0;       // partial slots written so far (packed densely, fixed order)
+
+    if (n > 0) {
+        if (direction == GNF_FORWARD) {
+            for (int i = 0; i < T; ++i) {  // gnn.py:309-338
+                for (int half = 0; half < 2; ++half) {
+                    int32_t np_ = 0;
+                    HalfStep hs{csr->rowptr, csr->col, n, half == 0 ? half0 : half1,
+                                half == 0 ? half1 : half0, ld, H, GNF_FORWARD, flow->gnn,
+                                pick(flow, flow->s_nets, half, i), pick(flow, flow->t_nets, half, i),
+                                partials + used, &np_};
+                    rc = run_half(hs, scratch, st);
+                    if (rc) return rc;
+                    used += np_;
+                }
+            }
+        } else {
+            for (int i = T - 1; i >= 0; --i) {  // gnn.py:347-372
+                for (int half = 1; half >= 0; --half) {
+                    int32_t np_ = 0;
+                    HalfStep hs{csr->rowptr, csr->col, n, half == 0 ? half0 : half1,
+                                half == 0 ? half1 : half0, ld, H, GNF_INVERSE, flow->gnn,
+                                pick(flow, flow->s_nets, half, i), pick(flow, flow->t_nets, half, i),
+                                partials + used, &np_};
+                    rc = run_half(hs, scratch, st);
+                    if (rc) return rc;
+                    // partial slots are reused: the inverse pass has no log-det (gnn.py:343-373)
+                }
+            }
+        }
+    }
+    if (direction == GNF_FORWARD) {
+        double* gpart = partials + 2 * (int64_t)(T > 0 ? T : 1) * p.partial_stride;
+        int32_t ng = 0;
+        if (n > 0) {
+            rc = launch_gauss_partials(x, n, D, ld, gpart, &ng, st);
+            if (rc) return rc;
+        }
+        return launch_finalize(partials, used, gpart, ng, sums, 0, 1, st);
+    }
+    return GNF_OK;
+}
+
+int gnf_gauss_sumsq_f32(const float* z, int64_t n_nodes, int32_t D, int64_t ld, double* out,
+                        void* ws, size_t ws_bytes, gnf_stream_t stream) {
+    if (n_nodes < 0 || D < 1 || ld < D) {
+        set_error("gnf_gauss_sumsq_f32: N=%lld D=%d ld=%lld", (long long)n_nodes, D, (long long)ld);
+        return GNF_ESHAPE;
+    }
+    if (!out || !ws || (n_nodes > 0 && !z)) {
+        set_error("gnf_gauss_sumsq_f32: null z/out/ws");
+        return GNF_EINVAL;
+    }
+    if (ws_bytes < kMaxGaussBlocks * sizeof(double)) {
+        set_error("gnf_gauss_sumsq_f32: workspace %zu < %zu bytes", ws_bytes,
+                  kMaxGaussBlocks * sizeof(double));
+        return GNF_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int32_t ng = 0;
+    if (n_nodes > 0) {
+        int rc = launch_gauss_partials(z, n_nodes, D, ld, (double*)ws, &ng, st);
+        if (rc) return rc;
+    }
+    // a == b trick: write out[0] from the partials (no accumulate)
+    return launch_finalize((const double*)ws, ng, nullptr, 0, out, 0, 0, st);
+}
+
+}  // extern "C"

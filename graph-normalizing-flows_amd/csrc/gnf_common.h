@@ -1,0 +1,86 @@
+// Internal declarations shared by the HIP translation units of libgnf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gnf.h"
+
+namespace gnf {
+
+void set_error(const char* fmt, ...);
+
+#define GNF_HIP_TRY(expr)                                                                     \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            gnf::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,   \
+                           __LINE__);                                                         \
+            return GNF_EHIP;                                                                  \
+        }                                                                                     \
+    } while (0)
+
+#define GNF_LAUNCH_CHECK(name)                                                                \
+    do {                                                                                      \
+        hipError_t _e = hipGetLastError();                                                    \
+        if (_e != hipSuccess) {                                                               \
+            gnf::set_error("launch of %s failed: %s", name, hipGetErrorString(_e));           \
+            return GNF_EHIP;                                                                  \
+        }                                                                                     \
+    } while (0)
+
+// Everything one coupling half-step needs, resolved to raw pointers (host struct, passed by value
+// to the launchers).
+struct HalfStep {
+    const int32_t* rowptr;
+    const int32_t* col;
+    int64_t n_nodes;
+    const float* x_cond;  // first column of the conditioning half
+    float* x_upd;         // first column of the half being updated
+    int64_t ld;
+    int32_t H;
+    int32_t direction;
+    GnfGnnSpec gnn;
+    const GnfMlp* s_net;  // host
+    const GnfMlp* t_net;  // host
+    double* partials;     // device: one fp64 partial sum(s) per workgroup of the epilogue kernel
+    int32_t* n_partials;  // host out: how many partials this launch writes
+};
+
+// ---- layout of the caller-provided workspace --------------------------------------------------
+// [ fp64 partial sums | float scratch of the layered path ]
+static constexpr int kFinalizeBlock = 256;
+static constexpr int kMaxGaussBlocks = 1024;
+
+inline int64_t coupling_blocks_max(int64_t n_nodes) { return (n_nodes + 15) / 16 + 1; }
+
+struct WorkspacePlan {
+    int64_t partial_stride;  // doubles per half-step
+    int64_t n_halfsteps;
+    size_t partial_bytes;    // (n_halfsteps * stride + kMaxGaussBlocks) * 8, 256-aligned
+    size_t scratch_floats;   // layered path activations
+    size_t total_bytes;
+};
+WorkspacePlan plan_workspace(int64_t n_nodes, int32_t H, const GnfMlp* net, int32_t combine,
+                             int64_t n_halfsteps);
+
+// ---- launchers (each returns GNF_OK / GNF_E*) --------------------------------------------------
+bool fused_supported(const HalfStep& hs);
+int launch_half_fused(const HalfStep& hs, hipStream_t st);
+int launch_half_layered(const HalfStep& hs, float* scratch, hipStream_t st);
+int launch_gnn_layered(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, const float* x,
+                       int64_t ldx, int32_t H, const GnfGnnSpec& g, const GnfMlp* mlp, float* out,
+                       int64_t ldo, float* scratch, hipStream_t st);
+int launch_aggregate(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, const float* x,
+                     int64_t ldx, int32_t H, int32_t mean, int32_t mode, float eps, float* out,
+                     int64_t ldo, hipStream_t st);
+int launch_gauss_partials(const float* z, int64_t n_nodes, int32_t D, int64_t ld, double* partials,
+                          int32_t* n_partials, hipStream_t st);
+// out[0] (+)= sum of a[0..na) ; out[1] = sum of b[0..nb)   (fixed order, fp64, single workgroup)
+int launch_finalize(const double* a, int64_t na, const double* b, int64_t nb, double* out,
+                    int accumulate_a, int write_b, hipStream_t st);
+int launch_pack_mlp(const GnfMlp* mlp, float* packed, hipStream_t st);
+int64_t packed_floats(const GnfMlp* mlp);
+
+int validate_mlp(const GnfMlp* m, const char* what);
+
+}  // namespace gnf

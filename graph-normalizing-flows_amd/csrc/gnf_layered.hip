@@ -1,0 +1,301 @@
+// Layer-by-layer ("layered") HIP path for gfx950: shape-generic kernels that run one coupling
+// half-step as aggregate -> K x linear -> coupling epilogue through a global-memory scratch.
+// It serves every shape the LDS-resident fused kernel (gnf_fused.hip) cannot hold, and the
+// stand-alone kernel-A / kernel-D entry points.  Everything here is fp32 FMA in k order.
+//
+// Reference arithmetic being replaced (see include/gnf.h for the per-entry citations):
+//   aggregate : gnn.py:103-104,117-118,151-156 (gather senders + unsorted_segment_{sum,mean})
+//   combine   : gnn.py:108-109 (concat) / gnn.py:123 (eps*x + agg)
+//   linear    : gnn.py:159-180 (snt.nets.MLP)
+//   coupling  : gnn.py:322-323,337-338 (forward) / gnn.py:359,372 (inverse)
+//   gauss     : run_grevnet.py:292-294
+#include "gnf_common.h"
+
+namespace gnf {
+
+// ------------------------------------------------------------------------------------------------
+// Kernel A: CSR segmented reduce of neighbour rows.  Lanes run along the feature axis so that each
+// neighbour row is one coalesced read; several rows per workgroup when H is small.
+//   mode 0: out[r, f] = eps * x[r, f] + agg        (AggThenMLPBlock)
+//   mode 1: out[r, f] = x[r, f]; out[r, H+f] = agg (ConcatThenMLPBlock)
+//   mode 2: out[r, f] = agg                        (aggregator alone)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_aggregate(const int32_t* __restrict__ rowptr,
+                                                   const int32_t* __restrict__ col, int64_t n_nodes,
+                                                   const float* __restrict__ x, int64_t ldx, int H,
+                                                   int mean, int mode, float eps,
+                                                   float* __restrict__ out, int64_t ldo,
+                                                   int rows_per_block) {
+    const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+    const int total = rows_per_block * H;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const int rl = idx / H;
+        const int f = idx - rl * H;
+        const int64_t r = row0 + rl;
+        if (r >= n_nodes) continue;
+        const int beg = rowptr[r], end = rowptr[r + 1];
+        float acc = 0.f;
+        for (int e = beg; e < end; ++e) acc += x[(int64_t)col[e] * ldx + f];
+        if (mean) {
+            const int cnt = end - beg;
+            acc = acc / (float)(cnt > 1 ? cnt : 1);  // unsorted_segment_mean: sum / max(count, 1)
+        }
+        if (mode == 0) {
+            out[r * ldo + f] = eps * x[r * ldx + f] + acc;
+        } else if (mode == 1) {
+            out[r * ldo + f] = x[r * ldx + f];
+            out[r * ldo + H + f] = acc;
+        } else {
+            out[r * ldo + f] = acc;
+        }
+    }
+}
+
+int launch_aggregate(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, const float* x,
+                     int64_t ldx, int32_t H, int32_t mean, int32_t mode, float eps, float* out,
+                     int64_t ldo, hipStream_t st) {
+    if (n_nodes == 0) return GNF_OK;
+    int rows = 256 / H;
+    if (rows < 1) rows = 1;
+    if (rows > 64) rows = 64;
+    const int64_t blocks = (n_nodes + rows - 1) / rows;
+    hipLaunchKernelGGL(k_aggregate, dim3((unsigned)blocks), dim3(256), 0, st, rowptr, col, n_nodes, x,
+                       ldx, H, mean, mode, eps, out, ldo, rows);
+    GNF_LAUNCH_CHECK("k_aggregate");
+    return GNF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Linear layer Y[N,O] = act(X[N,I] @ W[I,O] + b): 64x64 output tile, BK = 16, 4x4 micro-tile per
+// thread, operands staged through LDS; k accumulated in order with fmaf.
+// ------------------------------------------------------------------------------------------------
+static constexpr int LT = 64;
+static constexpr int LK = 16;
+
+__global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, int64_t ldx,
+                                                const float* __restrict__ W,
+                                                const float* __restrict__ bias,
+                                                float* __restrict__ Y, int64_t ldy, int64_t n_rows,
+                                                int I, int O, int act, float alpha, int apply_act) {
+    __shared__ float Xs[LK][LT + 4];  // transposed: Xs[k][row]
+    __shared__ float Ws[LK][LT + 4];  // Ws[k][col]
+    const int64_t row0 = (int64_t)blockIdx.y * LT;
+    const int col0 = blockIdx.x * LT;
+    const int tx = threadIdx.x & 15;   // column group
+    const int ty = threadIdx.x >> 4;   // row group
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < I; k0 += LK) {
+        // stage X tile (64 rows x 16 k): 1024 elements, 4 per thread
+        for (int i = threadIdx.x; i < LT * LK; i += 256) {
+            const int r = i >> 4, k = i & 15;
+            const int64_t gr = row0 + r;
+            Xs[k][r] = (gr < n_rows && k0 + k < I) ? X[gr * ldx + k0 + k] : 0.f;
+        }
+        for (int i = threadIdx.x; i < LT * LK; i += 256) {
+            const int k = i >> 6, c = i & 63;
+            Ws[k][c] = (k0 + k < I && col0 + c < O) ? W[(int64_t)(k0 + k) * O + col0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LK; ++k) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = Xs[k][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Ws[k][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t gr = row0 + ty * 4 + i;
+        if (gr >= n_rows) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gc = col0 + tx * 4 + j;
+            if (gc >= O) continue;
+            float v = acc[i][j] + bias[gc];
+            if (apply_act) v = (act == GNF_ACT_RELU) ? fmaxf(v, 0.f) : fmaxf(v, alpha * v);
+            Y[gr * ldy + gc] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Coupling epilogue: x_upd <- x_upd*exp(s)+t  or  (x_upd-t)*exp(-s); one fp64 partial of sum(s)
+// per workgroup (fixed in-block order -> bitwise reproducible).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_256(double v, double* sh) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    double tot = 0.0;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) tot += sh[i];
+    }
+    return tot;  // valid on thread 0
+}
+
+__global__ __launch_bounds__(256) void k_coupling(const float* __restrict__ s,
+                                                  const float* __restrict__ t, int64_t lds_,
+                                                  float* __restrict__ x_upd, int64_t ld,
+                                                  int64_t n_nodes, int H, int inverse,
+                                                  double* __restrict__ partials) {
+    __shared__ double sh[4];
+    const int64_t total = n_nodes * H;
+    const int64_t per_block = ((total + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const int64_t beg = (int64_t)blockIdx.x * per_block;
+    int64_t end = beg + per_block;
+    if (end > total) end = total;
+    double local = 0.0;
+    for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
+        const int64_t r = i / H;
+        const int f = (int)(i - r * H);
+        const float sv = s[r * lds_ + f], tv = t[r * lds_ + f];
+        const float xv = x_upd[r * ld + f];
+        x_upd[r * ld + f] = inverse ? (xv - tv) * expf(-sv) : xv * expf(sv) + tv;
+        local += (double)sv;
+    }
+    const double tot = block_sum_256(local, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+// Kernel D: per-workgroup fp64 partials of sum(z^2).
+__global__ __launch_bounds__(256) void k_gauss(const float* __restrict__ z, int64_t n_nodes, int D,
+                                               int64_t ld, double* __restrict__ partials) {
+    __shared__ double sh[4];
+    const int64_t total = n_nodes * D;
+    const int64_t per_block = ((total + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const int64_t beg = (int64_t)blockIdx.x * per_block;
+    int64_t end = beg + per_block;
+    if (end > total) end = total;
+    double local = 0.0;
+    for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
+        const int64_t r = i / D;
+        const int f = (int)(i - r * D);
+        const double v = (double)z[r * ld + f];
+        local += v * v;
+    }
+    const double tot = block_sum_256(local, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+int launch_gauss_partials(const float* z, int64_t n_nodes, int32_t D, int64_t ld, double* partials,
+                          int32_t* n_partials, hipStream_t st) {
+    const int64_t total = n_nodes * D;
+    int64_t blocks = (total + 256 * 8 - 1) / (256 * 8);
+    if (blocks < 1) blocks = 1;
+    if (blocks > kMaxGaussBlocks) blocks = kMaxGaussBlocks;
+    hipLaunchKernelGGL(k_gauss, dim3((unsigned)blocks), dim3(256), 0, st, z, n_nodes, D, ld, partials);
+    GNF_LAUNCH_CHECK("k_gauss");
+    *n_partials = (int32_t)blocks;
+    return GNF_OK;
+}
+
+// Final fixed-order fp64 reduction of the per-workgroup partials (single workgroup).
+__global__ __launch_bounds__(kFinalizeBlock) void k_finalize(const double* __restrict__ a, int64_t na,
+                                                            const double* __restrict__ b, int64_t nb,
+                                                            double* __restrict__ out,
+                                                            int accumulate_a, int write_b) {
+    __shared__ double sh[4];
+    double la = 0.0;
+    for (int64_t i = threadIdx.x; i < na; i += kFinalizeBlock) la += a[i];
+    const double ta = block_sum_256(la, sh);
+    __syncthreads();
+    double lb = 0.0;
+    if (write_b)
+        for (int64_t i = threadIdx.x; i < nb; i += kFinalizeBlock) lb += b[i];
+    const double tb = block_sum_256(lb, sh);
+    if (threadIdx.x == 0) {
+        if (a != nullptr) out[0] = accumulate_a ? out[0] + ta : ta;
+        if (write_b) out[1] = tb;
+    }
+}
+
+int launch_finalize(const double* a, int64_t na, const double* b, int64_t nb, double* out,
+                    int accumulate_a, int write_b, hipStream_t st) {
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinalizeBlock), 0, st, a, na, b, nb, out,
+                       accumulate_a, write_b);
+    GNF_LAUNCH_CHECK("k_finalize");
+    return GNF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// One half-step through the scratch buffer.
+// scratch layout (floats): h0 [N, in0] | bufA [N, Lmax] | bufB [N, Lmax] | s [N, H] | t [N, H]
+// ------------------------------------------------------------------------------------------------
+static int run_mlp(const GnfMlp* m, const float* h0, int64_t ld0, float* bufA, float* bufB,
+                   int64_t ldbuf, float* outp, int64_t ldout, int64_t n, const GnfGnnSpec& g,
+                   hipStream_t st) {
+    const float* in = h0;
+    int64_t ldin = ld0;
+    for (int j = 0; j < m->num_layers; ++j) {
+        const bool last = (j == m->num_layers - 1);
+        float* dst = last ? outp : ((j & 1) ? bufB : bufA);
+        const int64_t lddst = last ? ldout : ldbuf;
+        const int I = m->dims[j], O = m->dims[j + 1];
+        dim3 grid((O + LT - 1) / LT, (unsigned)((n + LT - 1) / LT));
+        hipLaunchKernelGGL(k_linear, grid, dim3(256), 0, st, in, ldin, m->W[j], m->b[j], dst, lddst, n,
+                           I, O, g.activation, g.alpha, last ? 0 : 1);
+        GNF_LAUNCH_CHECK("k_linear");
+        in = dst;
+        ldin = lddst;
+    }
+    return GNF_OK;
+}
+
+// One GNN module call: scratch = h0 [N, in0] | bufA [N, Lmax] | bufB [N, Lmax]
+int launch_gnn_layered(const int32_t* rowptr, const int32_t* col, int64_t n, const float* x,
+                       int64_t ldx, int32_t H, const GnfGnnSpec& g, const GnfMlp* mlp, float* out,
+                       int64_t ldo, float* scratch, hipStream_t st) {
+    const int in0 = mlp->dims[0];
+    int lmax = 1;
+    for (int j = 1; j < mlp->num_layers; ++j) lmax = lmax > mlp->dims[j] ? lmax : mlp->dims[j];
+    float* h0 = scratch;
+    float* bufA = h0 + n * in0;
+    float* bufB = bufA + n * lmax;
+    int rc = launch_aggregate(rowptr, col, n, x, ldx, H, g.agg == GNF_AGG_MEAN,
+                              g.combine == GNF_COMBINE_CONCAT ? 1 : 0, g.epsilon, h0, in0, st);
+    if (rc) return rc;
+    return run_mlp(mlp, h0, in0, bufA, bufB, lmax, out, ldo, n, g, st);
+}
+
+int launch_half_layered(const HalfStep& hs, float* scratch, hipStream_t st) {
+    const int64_t n = hs.n_nodes;
+    *hs.n_partials = 0;
+    if (n == 0) return GNF_OK;
+    const int H = hs.H;
+    const int in0 = hs.s_net->dims[0];
+    int lmax = 1;
+    for (int j = 1; j < hs.s_net->num_layers; ++j) lmax = lmax > hs.s_net->dims[j] ? lmax : hs.s_net->dims[j];
+    for (int j = 1; j < hs.t_net->num_layers; ++j) lmax = lmax > hs.t_net->dims[j] ? lmax : hs.t_net->dims[j];
+    float* h0 = scratch;
+    float* bufA = h0 + n * in0;
+    float* bufB = bufA + n * lmax;
+    float* sbuf = bufB + n * lmax;
+    float* tbuf = sbuf + n * H;
+    int rc = launch_aggregate(hs.rowptr, hs.col, n, hs.x_cond, hs.ld, H, hs.gnn.agg == GNF_AGG_MEAN,
+                              hs.gnn.combine == GNF_COMBINE_CONCAT ? 1 : 0, hs.gnn.epsilon, h0, in0, st);
+    if (rc) return rc;
+    rc = run_mlp(hs.s_net, h0, in0, bufA, bufB, lmax, sbuf, H, n, hs.gnn, st);
+    if (rc) return rc;
+    rc = run_mlp(hs.t_net, h0, in0, bufA, bufB, lmax, tbuf, H, n, hs.gnn, st);
+    if (rc) return rc;
+    int64_t blocks = (n * H + 256 * 4 - 1) / (256 * 4);
+    const int64_t cap = coupling_blocks_max(n);
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_coupling, dim3((unsigned)blocks), dim3(256), 0, st, sbuf, tbuf, (int64_t)H,
+                       hs.x_upd, hs.ld, n, H, hs.direction == GNF_INVERSE ? 1 : 0, hs.partials);
+    GNF_LAUNCH_CHECK("k_coupling");
+    *hs.n_partials = (int32_t)blocks;
+    return GNF_OK;
+}
+
+}  // namespace gnf

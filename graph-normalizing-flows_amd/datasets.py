@@ -1,0 +1,170 @@
+"""Harness-side data for the hot path (no arithmetic of the path itself):
+
+  * GraphDataset       - the reference's GraphRNN-pickle datasets after graph_data.py:33-50 preprocessing
+                         (to_directed + one self loop per node first), read from the committed
+                         data/*.npz edge lists (tools/convert_datasets.py), with the reference's batch
+                         semantics (graph_data.py:61-122): train split = first int(0.8*G) graphs,
+                         graphs drawn uniformly WITH replacement (the `self.index` quirk at
+                         graph_data.py:119 leaves train_index at 0), fresh N(0, scale^2) node features
+                         per batch (graph_data.py:24-27).
+  * fully_connected_edges / senders_receivers - the complete-graph + self-loop topology of
+                         grevnet_synthetic_data.py:17-21 and utils.py:164-183 (sender-major order).
+  * synthetic stand-ins - protein / citeseer(ego) datasets are absent from the reference
+                         (.MISSING_LARGE_BLOBS); BASELINE.md section 4 fixes the generators used instead.
+"""
+import os
+
+import numpy as np
+
+from .graphs import data_dicts_to_graphs_tuple
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
+
+# reference name (graph_data.py:283-300 FILENAME_MAP key) -> committed edge-list file
+FILENAME_MAP = {
+    "graph_rnn_grid": "grid.npz",
+    "graph_rnn_ego_small": "citeseer_small.npz",
+    "graph_rnn_community_small": "caveman_small.npz",
+    "graph_rnn_community_medium": "community_medium.npz",
+    "graph_rnn_grid_small": "grid_small.npz",   # no key in the reference map; BASELINE config 1
+}
+
+
+class EdgeListDataset:
+    """A list of graphs as concatenated local edge lists."""
+
+    def __init__(self, n_node, n_edge, senders, receivers):
+        self.n_node = np.asarray(n_node, np.int32)
+        self.n_edge = np.asarray(n_edge, np.int32)
+        self.senders = np.asarray(senders, np.int32)
+        self.receivers = np.asarray(receivers, np.int32)
+        self.eoff = np.concatenate([[0], np.cumsum(self.n_edge)]).astype(np.int64)
+
+    def __len__(self):
+        return len(self.n_node)
+
+    def graph(self, gid):
+        lo, hi = self.eoff[gid], self.eoff[gid + 1]
+        return int(self.n_node[gid]), self.senders[lo:hi], self.receivers[lo:hi]
+
+    def data_dicts(self, graph_ids, nodes_fn):
+        out = []
+        for gid in graph_ids:
+            n, s, r = self.graph(gid)
+            out.append({"nodes": nodes_fn(n), "senders": s, "receivers": r, "n_node": n})
+        return out
+
+    @staticmethod
+    def load(path):
+        d = np.load(path)
+        return EdgeListDataset(d["n_node"], d["n_edge"], d["senders"], d["receivers"])
+
+
+class GraphDataset:
+    def __init__(self, dataset_name, node_embedding_dim, gaussian_scale=1.0, seed=12345):
+        self.all = EdgeListDataset.load(os.path.join(DATA_DIR, FILENAME_MAP[dataset_name]))
+        g = len(self.all)
+        self.train_ids = np.arange(0, int(0.8 * g))        # graph_data.py:77-78
+        self.test_ids = np.arange(int(0.8 * g), g)
+        self.dim = int(node_embedding_dim)
+        self.scale = float(gaussian_scale)
+        self.rng = np.random.default_rng(seed)              # run_grevnet.py:108 default seed
+
+    def _features(self, n):
+        return self.rng.normal(scale=self.scale, size=(n, self.dim)).astype(np.float32)
+
+    def sample_ids(self, batch_size, split="train"):
+        ids = self.train_ids if split == "train" else self.test_ids
+        return self.rng.choice(ids, size=batch_size, replace=True)
+
+    def get_next_train_batch(self, batch_size, device=None):
+        return data_dicts_to_graphs_tuple(self.all.data_dicts(self.sample_ids(batch_size), self._features), device)
+
+    def get_next_test_batch(self, batch_size, device=None):
+        return data_dicts_to_graphs_tuple(self.all.data_dicts(self.sample_ids(batch_size, "test"), self._features),
+                                          device)
+
+    def train_n_nodes(self):
+        return [int(self.all.n_node[i]) for i in self.train_ids]
+
+
+def fully_connected_edges(n):
+    """All ordered pairs (a, b) incl. self, sender-major (utils.py:138-143 order; same edge SET as
+    grevnet_synthetic_data.py:17-21)."""
+    a = np.repeat(np.arange(n, dtype=np.int32), n)
+    b = np.tile(np.arange(n, dtype=np.int32), n)
+    return a, b
+
+
+def senders_receivers(n_node):
+    """utils.py:164-183 for a whole batch: returns (senders, receivers, n_edge = n_node**2) with global ids."""
+    s, r, off = [], [], 0
+    for n in n_node:
+        a, b = fully_connected_edges(int(n))
+        s.append(a + off)
+        r.append(b + off)
+        off += int(n)
+    return np.concatenate(s), np.concatenate(r), np.asarray(n_node, np.int32) ** 2
+
+
+def with_fully_connected_topology(ds):
+    """Same node counts, complete-graph topology (train_grevnet_with_data.py:237-244 transform_example)."""
+    S, R = [], []
+    for n in ds.n_node:
+        a, b = fully_connected_edges(int(n))
+        S.append(a)
+        R.append(b)
+    return EdgeListDataset(ds.n_node, ds.n_node.astype(np.int64) ** 2, np.concatenate(S), np.concatenate(R))
+
+
+def _knn_graph(rng, n, k):
+    """Random geometric k-NN graph in the unit square, symmetrised, + self loops first
+    (the data shape of graph_data.py:33-50)."""
+    pts = rng.random((n, 2))
+    d2 = ((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1)
+    np.fill_diagonal(d2, np.inf)
+    nbr = np.argsort(d2, axis=1)[:, :k]
+    adj = np.zeros((n, n), bool)
+    adj[np.repeat(np.arange(n), k), nbr.ravel()] = True
+    adj |= adj.T
+    s, r = np.nonzero(adj)
+    idx = np.arange(n)
+    return np.concatenate([idx, s]).astype(np.int32), np.concatenate([idx, r]).astype(np.int32)
+
+
+def synthetic_protein(num_graphs, seed=12345):
+    """Stand-in for the absent protein dataset: n ~ U{100..500}, geometric k-NN
+    graph with mean degree about 5, + self loops."""
+    rng = np.random.default_rng(seed)
+    nn, ne, S, R = [], [], [], []
+    for _ in range(num_graphs):
+        n = int(rng.integers(100, 501))
+        s, r = _knn_graph(rng, n, 3)
+        nn.append(n); ne.append(len(s)); S.append(s); R.append(r)
+    return EdgeListDataset(nn, ne, np.concatenate(S), np.concatenate(R))
+
+
+def synthetic_ego(num_graphs, seed=12345):
+    """Stand-in for the absent citeseer (ego) dataset: n ~ U{50..399}; node 0 is
+    the ego hub (linked to a third of the nodes), the rest grows by preferential attachment with 2
+    links per new node (mean degree about 5-6), + self loops first."""
+    rng = np.random.default_rng(seed)
+    nn, ne, S, R = [], [], [], []
+    for _ in range(num_graphs):
+        n = int(rng.integers(50, 400))
+        deg = np.zeros(n)
+        edges = set()
+        for v in range(1, n):
+            if v % 3 == 1:
+                edges.add((0, v)); deg[0] += 1; deg[v] += 1
+            w = deg[:v] + 1.0
+            for u in rng.choice(v, size=min(2, v), replace=False, p=w / w.sum()):
+                e = (int(u), v)
+                if e not in edges:
+                    edges.add(e); deg[u] += 1; deg[v] += 1
+        und = np.array(sorted(edges), dtype=np.int32).reshape(-1, 2)
+        idx = np.arange(n, dtype=np.int32)
+        s = np.concatenate([idx, und[:, 0], und[:, 1]])
+        r = np.concatenate([idx, und[:, 1], und[:, 0]])
+        nn.append(n); ne.append(len(s)); S.append(s); R.append(r)
+    return EdgeListDataset(nn, ne, np.concatenate(S), np.concatenate(R))

@@ -1,0 +1,432 @@
+"""Host-side mirror of the GRevNet / GNN call surface of /root/reference/gnn.py for the hot path
+(gnn.py:100-180, 238-257, 266-267, 273-381): same class and function names, argument order and
+return conventions, with PyTorch-ROCm tensors as containers and every bit of arithmetic executed by
+the hand-written gfx950 kernels behind the C ABI (include/gnf.h).  Eager instead of TF graph mode.
+
+Differences a reference user will notice (all deliberate):
+  * `aggn_fn` / `activation` are tokens: pass this module's `unsorted_segment_sum`,
+    `unsorted_segment_mean`, `relu`, `leaky_relu` (or the strings "sum" / "mean" / "relu" /
+    "leaky_relu") where the reference passes `tf.unsorted_segment_*` / `tf.nn.*`.
+  * parameters are explicit: `mlp.get_params()` / `mlp.set_params([(W, b), ...])`, `W` is [in, out]
+    like snt.Linear; call `grevnet.repack()` after mutating weight tensors in place.
+  * `use_batch_norm=True` raises (deferred).
+  * there is no CPU fallback: without libgnf_hip.so / a HIP device every call raises GnfError.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _abi
+from .graphs import GraphsTuple, csr_of
+
+# ----------------------------------------------------------------------------------------------
+# tokens standing in for tf.unsorted_segment_{sum,mean} (gnn.py:239,245,251,256) and tf.nn.*
+# ----------------------------------------------------------------------------------------------
+def unsorted_segment_sum(*_a, **_k):
+    raise NotImplementedError("token only: pass it as aggn_fn; the reduction runs inside the HIP kernels")
+
+
+def unsorted_segment_mean(*_a, **_k):
+    raise NotImplementedError("token only: pass it as aggn_fn; the reduction runs inside the HIP kernels")
+
+
+def relu(*_a, **_k):
+    raise NotImplementedError("token only: pass it as activation; it runs inside the HIP kernels")
+
+
+def leaky_relu(*_a, **_k):
+    raise NotImplementedError("token only: pass it as activation; it runs inside the HIP kernels")
+
+
+unsorted_segment_sum.gnf_agg = _abi.GNF_AGG_SUM
+unsorted_segment_mean.gnf_agg = _abi.GNF_AGG_MEAN
+relu.gnf_act = (_abi.GNF_ACT_RELU, 0.0)
+leaky_relu.gnf_act = (_abi.GNF_ACT_LEAKY_RELU, 0.2)  # tf.nn.leaky_relu default alpha
+
+
+def _agg_code(aggn_fn):
+    if hasattr(aggn_fn, "gnf_agg"):
+        return aggn_fn.gnf_agg
+    name = aggn_fn if isinstance(aggn_fn, str) else getattr(aggn_fn, "__name__", "")
+    if name in ("sum", "unsorted_segment_sum"):
+        return _abi.GNF_AGG_SUM
+    if name in ("mean", "avg", "unsorted_segment_mean"):
+        return _abi.GNF_AGG_MEAN
+    raise ValueError(f"unsupported aggn_fn {aggn_fn!r}: use unsorted_segment_sum / unsorted_segment_mean")
+
+
+def _act_code(activation):
+    if hasattr(activation, "gnf_act"):
+        return activation.gnf_act
+    name = activation if isinstance(activation, str) else getattr(activation, "__name__", "")
+    if name == "relu":
+        return (_abi.GNF_ACT_RELU, 0.0)
+    if name == "leaky_relu":
+        return (_abi.GNF_ACT_LEAKY_RELU, 0.2)
+    raise ValueError(f"unsupported activation {activation!r}: use relu / leaky_relu")
+
+
+_GEN = torch.Generator().manual_seed(12345)  # run_grevnet.py:108 default random_seed
+
+
+def set_random_seed(seed):
+    """Seed of the weight initialisers (the reference seeds TF at graph construction)."""
+    _GEN.manual_seed(int(seed))
+
+
+# ----------------------------------------------------------------------------------------------
+# MLP  (gnn.py:159-180: snt.nets.MLP([latent]*(K-1)+[out], activate_final=False))
+# ----------------------------------------------------------------------------------------------
+class MLP:
+    def __init__(self, layer_sizes, activation=relu, bias_init_stddev=0.1, name="mlp"):
+        if not 1 <= len(layer_sizes) <= _abi.GNF_MAX_LAYERS:
+            raise ValueError(f"num_layers must be in [1, {_abi.GNF_MAX_LAYERS}]")
+        self.layer_sizes = [int(v) for v in layer_sizes]
+        self.activation = activation
+        self.act_code, self.alpha = _act_code(activation)
+        self.bias_init_stddev = float(bias_init_stddev)
+        self.name = name
+        self.params = None      # list of (W[in,out], b[out]) fp32 tensors, created at first connect
+        self.in_dim = None
+        self.version = 0
+
+    def ensure_built(self, in_dim, device):
+        """Sonnet creates variables at first connection, inferring the input width; so do we.
+        W ~ glorot_normal (truncated, fan_avg), b ~ truncated_normal(stddev) (gnn.py:171-174)."""
+        if self.params is None:
+            params, fan_in = [], int(in_dim)
+            for fan_out in self.layer_sizes:
+                std = math.sqrt(2.0 / (fan_in + fan_out)) / 0.87962566103423978
+                w = torch.empty(fan_in, fan_out)
+                torch.nn.init.trunc_normal_(w, 0.0, std, -2 * std, 2 * std, generator=_GEN)
+                b = torch.empty(fan_out)
+                bs = self.bias_init_stddev
+                if bs > 0:
+                    torch.nn.init.trunc_normal_(b, 0.0, bs, -2 * bs, 2 * bs, generator=_GEN)
+                else:
+                    b.zero_()
+                params.append((w, b))
+                fan_in = fan_out
+            self.in_dim = int(in_dim)
+            self.params = params
+            self.version += 1
+        if self.in_dim != int(in_dim):
+            raise ValueError(f"{self.name}: built for input width {self.in_dim}, connected to {in_dim}")
+        if self.params[0][0].device != torch.device(device):
+            self.params = [(w.to(device), b.to(device)) for (w, b) in self.params]
+            self.version += 1
+        return self
+
+    def set_params(self, layers):
+        """layers: [(W[in,out], b[out]), ...] numpy or torch; shapes must chain and match layer_sizes."""
+        if len(layers) != len(self.layer_sizes):
+            raise ValueError(f"{self.name}: expected {len(self.layer_sizes)} layers, got {len(layers)}")
+        params, fan_in = [], None
+        for j, (w, b) in enumerate(layers):
+            w = torch.as_tensor(np.asarray(w) if not isinstance(w, torch.Tensor) else w).to(torch.float32).contiguous()
+            b = torch.as_tensor(np.asarray(b) if not isinstance(b, torch.Tensor) else b).to(torch.float32).contiguous()
+            if w.ndim != 2 or b.ndim != 1 or w.shape[1] != self.layer_sizes[j] or b.shape[0] != self.layer_sizes[j]:
+                raise ValueError(f"{self.name}: layer {j} has W{tuple(w.shape)} b{tuple(b.shape)}, "
+                                 f"expected out width {self.layer_sizes[j]}")
+            if fan_in is not None and w.shape[0] != fan_in:
+                raise ValueError(f"{self.name}: layer {j} input width {w.shape[0]} != previous output {fan_in}")
+            fan_in = w.shape[1]
+            params.append((w, b))
+        self.in_dim = int(params[0][0].shape[0])
+        self.params = params
+        self.version += 1
+        return self
+
+    def get_params(self):
+        return None if self.params is None else [(w.detach().cpu().numpy().copy(), b.detach().cpu().numpy().copy())
+                                                 for (w, b) in self.params]
+
+    def dims(self):
+        return [self.in_dim] + self.layer_sizes
+
+    def packed_floats(self):
+        return sum(_pad16(i) * _pad16(o) + _pad16(o) for i, o in zip(self.dims()[:-1], self.dims()[1:]))
+
+    def fill_desc(self, desc, packed_ptr):
+        desc.num_layers = len(self.layer_sizes)
+        for j, d in enumerate(self.dims()):
+            desc.dims[j] = d
+        for j, (w, b) in enumerate(self.params):
+            desc.W[j] = w.data_ptr()
+            desc.b[j] = b.data_ptr()
+        desc.packed = packed_ptr
+
+    def __call__(self, *_a, **_k):
+        raise NotImplementedError("the MLP is evaluated inside the fused coupling kernels; call the GNN block / GRevNet")
+
+
+def _pad16(v):
+    return (int(v) + 15) // 16 * 16
+
+
+def make_mlp_model(latent_dim, output_dim, num_layers, activation=relu, l2_regularizer_weight=0.01,
+                   bias_init_stddev=0.1):
+    """gnn.py:159-180.  `l2_regularizer_weight` is accepted and ignored exactly as in the reference
+    (its regularizers are commented out, gnn.py:175-178).  output_dim may arrive as a float
+    (run_grevnet.py:157 passes node_embedding_dim / 2)."""
+    layers = [int(latent_dim)] * (int(num_layers) - 1)
+    layers.append(int(output_dim))
+    return MLP(layers, activation=activation, bias_init_stddev=bias_init_stddev)
+
+
+# ----------------------------------------------------------------------------------------------
+# node blocks (gnn.py:100-156)
+# ----------------------------------------------------------------------------------------------
+class _NodeBlock:
+    combine = None
+
+    def spec(self):
+        return _abi.GnfGnnSpec(self._agg, self.combine, float(getattr(self, "epsilon", 0.0)),
+                               self._mlp.act_code, float(self._mlp.alpha))
+
+    def in_dim(self, h):
+        return 2 * h if self.combine == _abi.GNF_COMBINE_CONCAT else h
+
+    def _build(self, graph):
+        """One GNN evaluation outside a coupling: gnf_gnn_apply_f32."""
+        lib = _abi.lib()
+        x = graph.nodes
+        if x.device.type != "cuda":
+            raise _abi.GnfError("GNN blocks run on a HIP device only (no CPU path)")
+        x = x.to(torch.float32).contiguous()
+        n, h = x.shape
+        mlp = self._mlp.ensure_built(self.in_dim(h), x.device)
+        desc = _abi.GnfMlp()
+        mlp.fill_desc(desc, 0)
+        spec = self.spec()
+        csr = csr_of(graph)
+        out = torch.empty(n, mlp.layer_sizes[-1], dtype=torch.float32, device=x.device)
+        ws_bytes = lib.gnf_gnn_workspace_bytes(n, h, C.byref(desc), spec.combine)
+        ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            _abi.check(lib.gnf_gnn_apply_f32(C.byref(csr.desc), C.byref(desc), C.byref(spec), _abi.ptr(x),
+                                             x.stride(0), h, _abi.ptr(out), out.stride(0), _abi.ptr(ws),
+                                             ws_bytes, _abi.stream_ptr(x.device)), "gnf_gnn_apply_f32")
+        return graph.replace(nodes=out)
+
+    __call__ = _build
+
+
+class ConcatThenMLPBlock(_NodeBlock):
+    """gnn.py:100-111: MLP(concat[nodes, aggregate(received edges)])."""
+    combine = _abi.GNF_COMBINE_CONCAT
+
+    def __init__(self, aggn_fn, make_mlp_fn, name="AggThenMLPBlock"):
+        self._agg = _agg_code(aggn_fn)
+        self._mlp = make_mlp_fn()
+        self.name = name
+
+
+class AggThenMLPBlock(_NodeBlock):
+    """gnn.py:114-126: MLP(epsilon * nodes + aggregate(received edges))."""
+    combine = _abi.GNF_COMBINE_EPS
+
+    def __init__(self, aggn_fn, make_mlp_fn, epsilon, name="AggThenMLPBlock"):
+        self._agg = _agg_code(aggn_fn)
+        self._mlp = make_mlp_fn()
+        self.epsilon = epsilon
+        self.name = name
+
+
+class IdentityModule:
+    """gnn.py:130-132: the edge model (edges[e] = nodes[senders[e]]); fused away in the kernels."""
+
+    def __call__(self, inputs):
+        return inputs
+
+
+EDGE_BLOCK_OPT = {
+    "use_edges": False,
+    "use_receiver_nodes": False,
+    "use_sender_nodes": True,
+    "use_globals": False,
+}
+
+
+class NodeBlockGNN:
+    """gnn.py:143-156: node_block(edge_block(graph)); the edge block only broadcasts sender nodes
+    to edges, which the CSR gather inside the kernels does without materialising [E, H]."""
+
+    def __init__(self, node_block, edge_block_opt=EDGE_BLOCK_OPT, name="NodeBlockGNN"):
+        if not isinstance(node_block, _NodeBlock):
+            raise TypeError("NodeBlockGNN supports AggThenMLPBlock / ConcatThenMLPBlock node blocks "
+                            "(GRU / attention blocks are outside the hot path, SURVEY.md 8f)")
+        if dict(edge_block_opt) != EDGE_BLOCK_OPT:
+            raise ValueError("only the reference's EDGE_BLOCK_OPT (sender nodes only) is supported")
+        self._node_block = node_block
+        self.name = name
+
+    def _build(self, graph):
+        return self._node_block(graph)
+
+    __call__ = _build
+
+
+def avg_then_mlp_gnn(make_mlp_fn, epsilon):          # gnn.py:238-241
+    return NodeBlockGNN(AggThenMLPBlock(unsorted_segment_mean, make_mlp_fn, epsilon))
+
+
+def sum_then_mlp_gnn(make_mlp_fn, epsilon):          # gnn.py:244-247
+    return NodeBlockGNN(AggThenMLPBlock(unsorted_segment_sum, make_mlp_fn, epsilon))
+
+
+def sum_concat_then_mlp_gnn(make_mlp_fn):            # gnn.py:250-252
+    return NodeBlockGNN(ConcatThenMLPBlock(unsorted_segment_sum, make_mlp_fn))
+
+
+def avg_concat_then_mlp_gnn(make_mlp_fn):            # gnn.py:255-257
+    return NodeBlockGNN(ConcatThenMLPBlock(unsorted_segment_mean, make_mlp_fn))
+
+
+def get_gnns(num_timesteps, make_gnn_fn):            # gnn.py:266-267
+    return [make_gnn_fn() for _ in range(num_timesteps)]
+
+
+# ----------------------------------------------------------------------------------------------
+# GRevNet (gnn.py:273-381)
+# ----------------------------------------------------------------------------------------------
+class GRevNet:
+    def __init__(self, make_gnn_fn, num_timesteps, node_embedding_dim, use_batch_norm=False,
+                 weight_sharing=False, name="GRevNet"):
+        self.num_timesteps = int(num_timesteps)
+        self.weight_sharing = bool(weight_sharing)
+        self.node_embedding_dim = node_embedding_dim  # accepted and unused, as in gnn.py:277
+        if weight_sharing:                            # gnn.py:284-286
+            self.s = [make_gnn_fn(), make_gnn_fn()]
+            self.t = [make_gnn_fn(), make_gnn_fn()]
+        else:                                         # gnn.py:288-296
+            self.s = [get_gnns(num_timesteps, make_gnn_fn), get_gnns(num_timesteps, make_gnn_fn)]
+            self.t = [get_gnns(num_timesteps, make_gnn_fn), get_gnns(num_timesteps, make_gnn_fn)]
+        if use_batch_norm:
+            raise NotImplementedError("use_batch_norm=True (tfb.BatchNormalization, gnn.py:260-263) is not "
+                                      "part of the MI355X hot path yet (SURVEY.md 8f #2)")
+        self.use_batch_norm = False
+        self.name = name
+        self._cache = None       # (key, flow desc, keep-alive objects)
+        self.fused = True        # False: hide the packed weights -> the layered (generic) kernels run
+        self.last_sums = None    # device fp64 [2]: log_det_jacobian, sum(z^2) of the last f()
+
+    # ---- parameter plumbing ------------------------------------------------------------------
+    def _gnns(self, kind):
+        nets = self.s if kind == "s" else self.t
+        return [nets[0], nets[1]] if self.weight_sharing else list(nets[0]) + list(nets[1])
+
+    def _blocks(self):
+        return [g._node_block for g in self._gnns("s") + self._gnns("t")]
+
+    def mlps(self, kind):
+        """Flat list of MLPs in ABI order: index half*T + i (or half with weight sharing)."""
+        return [g._node_block._mlp for g in self._gnns(kind)]
+
+    def set_params(self, params):
+        """params in the oracle / fixture layout: {"s": [[mlp]*T, [mlp]*T], "t": ...} or, with weight
+        sharing, {"s": [mlp, mlp], "t": [mlp, mlp]}; mlp = [(W[in,out], b[out]), ...]."""
+        for kind in ("s", "t"):
+            flat = list(params[kind]) if self.weight_sharing else list(params[kind][0]) + list(params[kind][1])
+            for mlp, layers in zip(self.mlps(kind), flat):
+                mlp.set_params(layers)
+        self._cache = None
+        return self
+
+    def get_params(self):
+        out = {}
+        for kind in ("s", "t"):
+            flat = [m.get_params() for m in self.mlps(kind)]
+            t = self.num_timesteps
+            out[kind] = flat if self.weight_sharing else [flat[:t], flat[t:]]
+        return out
+
+    def repack(self):
+        """Call after mutating weight tensors in place (the packed MFMA copies are stale otherwise)."""
+        self._cache = None
+
+    def _flow(self, hdim, device):
+        lib = _abi.lib()
+        blocks = self._blocks()
+        b0 = blocks[0]
+        for b in blocks:
+            if (b.combine, b._agg, float(getattr(b, "epsilon", 0.0)), b._mlp.act_code, b._mlp.alpha) != \
+               (b0.combine, b0._agg, float(getattr(b0, "epsilon", 0.0)), b0._mlp.act_code, b0._mlp.alpha):
+                raise ValueError("all s/t GNNs of a GRevNet must come from the same make_gnn_fn")
+        s_mlps = [m.ensure_built(b0.in_dim(hdim), device) for m in self.mlps("s")]
+        t_mlps = [m.ensure_built(b0.in_dim(hdim), device) for m in self.mlps("t")]
+        key = (str(device), hdim, bool(self.fused), tuple(m.version for m in s_mlps + t_mlps))
+        if self._cache is not None and self._cache[0] == key:
+            return self._cache[1]
+        n = len(s_mlps)
+        s_arr, t_arr = (_abi.GnfMlp * n)(), (_abi.GnfMlp * n)()
+        sizes = [m.packed_floats() for m in s_mlps + t_mlps]
+        packed = torch.empty(max(sum(sizes), 1), dtype=torch.float32, device=device)
+        off = 0
+        with torch.cuda.device(device):
+            st = _abi.stream_ptr(device)
+            for arr, mlps in ((s_arr, s_mlps), (t_arr, t_mlps)):
+                for q, m in enumerate(mlps):
+                    m.fill_desc(arr[q], packed.data_ptr() + 4 * off if self.fused else 0)
+                    if lib.gnf_packed_floats(C.byref(arr[q])) != m.packed_floats():
+                        raise _abi.GnfError("packed size mismatch between binding and library")
+                    if self.fused:
+                        _abi.check(lib.gnf_pack_mlp(C.byref(arr[q]), C.c_void_p(packed.data_ptr() + 4 * off), st),
+                                   "gnf_pack_mlp")
+                    off += m.packed_floats()
+        flow = _abi.GnfFlow(self.num_timesteps, int(self.weight_sharing),
+                            C.cast(s_arr, C.POINTER(_abi.GnfMlp)), C.cast(t_arr, C.POINTER(_abi.GnfMlp)),
+                            b0.spec())
+        self._cache = (key, flow, (s_arr, t_arr, packed, s_mlps, t_mlps))
+        return flow
+
+    def _run(self, graph, direction, sums_out=None):
+        lib = _abi.lib()
+        x = graph.nodes
+        if x.device.type != "cuda":
+            raise _abi.GnfError("GRevNet runs on a HIP device only (no CPU path)")
+        if x.ndim != 2 or x.shape[1] % 2:
+            raise ValueError(f"nodes must be [N, D] with even D (tf.split, gnn.py:306); got {tuple(x.shape)}")
+        n, d = x.shape
+        dev = x.device
+        out = x.to(torch.float32).clone(memory_format=torch.contiguous_format)  # TF ops are functional
+        flow = self._flow(d // 2, dev)
+        csr = csr_of(graph)
+        ws_bytes = lib.gnf_workspace_bytes(n, d, C.byref(flow))
+        ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
+        sums = None
+        if direction == _abi.GNF_FORWARD:
+            # sums_out: caller-owned fp64 buffer whose first two slots receive [logdet, sum z^2]
+            sums = sums_out if sums_out is not None else torch.empty(2, dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _abi.check(lib.gnf_grevnet_f32(C.byref(csr.desc), C.byref(flow), _abi.ptr(out), out.stride(0), d,
+                                           direction, _abi.ptr(sums), _abi.ptr(ws), ws_bytes,
+                                           _abi.stream_ptr(dev)), "gnf_grevnet_f32")
+        return out, sums
+
+    # ---- the reference's methods --------------------------------------------------------------
+    def f(self, x, sums_out=None):
+        """gnn.py:304-341: data -> latent.  Returns (GraphsTuple with nodes = z, log_det_jacobian)."""
+        z, sums = self._run(x, _abi.GNF_FORWARD, sums_out)
+        self.last_sums = sums
+        self._last_z = z
+        return x.replace(nodes=z), sums[0].to(torch.float32)
+
+    def g(self, z):
+        """gnn.py:343-373: latent -> data (sampling direction)."""
+        x, _ = self._run(z, _abi.GNF_INVERSE)
+        return z.replace(nodes=x)
+
+    def log_prob(self, x):
+        """gnn.py:375-377 with the prior the drivers use (standard normal, run_grevnet.py:292-294)."""
+        from .flow import log_prob_terms
+        return log_prob_terms(self, x)["log_prob_xs"]
+
+    def _build(self, input, inverse=True):
+        """gnn.py:379-381: inverse=True is the NORMALISING direction f; inverse=False is g."""
+        func = self.f if inverse else self.g
+        return func(input)
+
+    __call__ = _build

@@ -1,0 +1,159 @@
+/*
+ * gnf.h - C ABI of libgnf_hip.so: the MI355X (gfx950) implementation of the GRevNet affine-coupling
+ * forward / inverse + log-det hot path of jliu/graph-normalizing-flows.
+ *
+ * The reference has no FFI: its "operator API" for this path is the Sonnet-module call surface of
+ * /root/reference/gnn.py, executed by TensorFlow kernels.  Each entry point below names the
+ * reference interface (file:line) whose arithmetic it replaces.  A maintainer binds them with
+ * ctypes; graph-normalizing-flows_amd/_abi.py is that binding.
+ *
+ * Conventions
+ *   - plain C types only; every pointer that is not marked "host" is a DEVICE pointer into memory
+ *     owned by the caller (torch tensors' data_ptr()).  The library allocates nothing persistent and
+ *     keeps no global state besides a thread-local error string.
+ *   - every entry point is asynchronous on the caller's stream (hipStream_t passed as void*), does
+ *     no host synchronisation, and is legal inside hipGraph stream capture.
+ *   - return 0 on success, a negative GNF_E* code on failure; gnf_last_error() gives the message.
+ *     Nothing throws across the boundary.
+ *   - node features live in ONE row-major [N, D] fp32 buffer with leading dimension ld >= D; the two
+ *     coupling halves are the column ranges [0, D/2) and [D/2, D), so tf.split / tf.concat
+ *     (gnn.py:306,340,344,373) are zero-copy views.
+ *   - the graph is given as CSR sorted by RECEIVER: for node r, col[rowptr[r] .. rowptr[r+1]) are
+ *     the SENDERS of its incoming edges in original edge order (stable), which is the summation
+ *     order of tf.unsorted_segment_sum on the reference's edge list.
+ */
+#ifndef GNF_H
+#define GNF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNF_ABI_VERSION 1
+#define GNF_MAX_LAYERS 8 /* Linear layers per MLP (gnn.py:165-166 builds num_layers of them) */
+
+typedef void* gnf_stream_t; /* hipStream_t */
+
+enum GnfStatus {
+    GNF_OK = 0,
+    GNF_EINVAL = -1,      /* null pointer / bad enum / bad flag */
+    GNF_ESHAPE = -2,      /* dimension mismatch (odd D, ld < D, MLP in/out dims inconsistent ...) */
+    GNF_EWORKSPACE = -3,  /* workspace too small: call gnf_workspace_bytes */
+    GNF_EHIP = -4,        /* a HIP runtime call / kernel launch failed */
+    GNF_EUNSUPPORTED = -5 /* valid request outside what this build implements */
+};
+
+enum GnfAgg { GNF_AGG_SUM = 0, GNF_AGG_MEAN = 1 };             /* tf.unsorted_segment_sum / _mean (gnn.py:239,245,251,256) */
+enum GnfCombine { GNF_COMBINE_EPS = 0, GNF_COMBINE_CONCAT = 1 }; /* AggThenMLPBlock gnn.py:122-126 / ConcatThenMLPBlock gnn.py:107-111 */
+enum GnfAct { GNF_ACT_RELU = 0, GNF_ACT_LEAKY_RELU = 1 };       /* tf.nn.relu / tf.nn.leaky_relu(alpha) (run_grevnet.py:158,179,205) */
+enum GnfDirection { GNF_FORWARD = 0, GNF_INVERSE = 1 };          /* x*exp(s)+t (gnn.py:323,338) / (z-t)*exp(-s) (gnn.py:359,372) */
+
+/* Graph topology of the whole batch (block-diagonal union of graphs), receiver-sorted CSR. */
+typedef struct GnfCsr {
+    const int32_t* rowptr; /* [n_nodes + 1] */
+    const int32_t* col;    /* [n_edges] sender node ids */
+    int64_t n_nodes;       /* N = sum(n_node)  (run_grevnet.py:298) */
+    int64_t n_edges;       /* E = sum(n_edge), self loops included */
+} GnfCsr;
+
+/* One snt.nets.MLP (gnn.py:159-180): num_layers Linear layers, y = x @ W + b, W row-major [in,out];
+ * activation between layers, none after the last (activate_final=False, gnn.py:179). */
+typedef struct GnfMlp {
+    int32_t num_layers;               /* K >= 1 */
+    int32_t dims[GNF_MAX_LAYERS + 1]; /* dims[0] = input width, dims[j+1] = output width of layer j */
+    const float* W[GNF_MAX_LAYERS];   /* device, [dims[j], dims[j+1]] row-major */
+    const float* b[GNF_MAX_LAYERS];   /* device, [dims[j+1]] */
+    const float* packed;              /* device buffer written by gnf_pack_mlp (MFMA fragment order), or NULL */
+} GnfMlp;
+
+/* What a make_gnn_fn() product does around its MLP (gnn.py:238-257). */
+typedef struct GnfGnnSpec {
+    int32_t agg;        /* GnfAgg */
+    int32_t combine;    /* GnfCombine */
+    float epsilon;      /* AggThenMLPBlock.epsilon (gnn.py:120,123); ignored for concat */
+    int32_t activation; /* GnfAct */
+    float alpha;        /* leaky_relu slope (TF default 0.2) */
+} GnfGnnSpec;
+
+/* Parameter structure of GRevNet.__init__ (gnn.py:274-302).  s_nets / t_nets are HOST arrays of
+ * GnfMlp descriptors: 2*T entries indexed [half*T + i] (weight_sharing = 0, gnn.py:288-296) or 2
+ * entries indexed [half] (weight_sharing = 1, gnn.py:284-286).  half 0 nets read columns [0,D/2)
+ * and update [D/2,D); half 1 nets the reverse (gnn.py:320-338). */
+typedef struct GnfFlow {
+    int32_t num_timesteps; /* T */
+    int32_t weight_sharing;
+    const GnfMlp* s_nets; /* host */
+    const GnfMlp* t_nets; /* host */
+    GnfGnnSpec gnn;
+} GnfFlow;
+
+int gnf_abi_version(void);
+const char* gnf_last_error(void); /* thread-local, valid until the next failing call on this thread */
+
+/* Number of floats gnf_pack_mlp writes for this MLP (host computation, no device access). */
+int64_t gnf_packed_floats(const GnfMlp* mlp);
+
+/* Re-lay one MLP's weights into the zero-padded MFMA-fragment order the fused kernel streams
+ * (one-off, like any inference engine's weight pre-pack; replaces nothing in the reference -
+ * Sonnet keeps W as a [in,out] tf.Variable, gnn.py:167-174).  `packed` must hold
+ * gnf_packed_floats(mlp) floats. */
+int gnf_pack_mlp(const GnfMlp* mlp, float* packed, gnf_stream_t stream);
+
+/* Build the receiver-sorted CSR from a GraphsTuple edge list (senders/receivers with global node
+ * ids, graphs contiguous, n_node/n_edge per graph: the fields of gn.graphs.GraphsTuple built at
+ * train_grevnet_with_data.py:265-271 / graph_data.py:122).  Stable within each receiver.
+ * ws: gnf_csr_workspace_bytes(n_graphs, N) bytes. */
+size_t gnf_csr_workspace_bytes(int64_t n_graphs, int64_t n_nodes);
+int gnf_build_csr(const int32_t* senders, const int32_t* receivers, const int32_t* n_node,
+                  const int32_t* n_edge, int64_t n_graphs, int64_t n_nodes, int64_t n_edges,
+                  int32_t* rowptr, int32_t* col, void* ws, size_t ws_bytes, gnf_stream_t stream);
+
+/* Kernel A alone: out[r, 0:H) = reduce_{e: recv[e]=r} x[send[e], 0:H)   (sum, or sum/max(deg,1)).
+ * Replaces EdgeBlock gather + ReceivedEdgesToNodesAggregator (gnn.py:103-104,117-118,151-156). */
+int gnf_aggregate_f32(const GnfCsr* csr, const float* x, int64_t ldx, int32_t H, int32_t agg,
+                      float* out, int64_t ldo, gnf_stream_t stream);
+
+/* One GNN module call on its own, outside a coupling: out[N, dims[K]] = MLP(combine(x, agg(x))),
+ * i.e. NodeBlockGNN._build (gnn.py:155-156) -> AggThenMLPBlock / ConcatThenMLPBlock._build
+ * (gnn.py:122-126 / 107-111).  x is [N, H] (stride ldx), out is [N, mlp->dims[K]] (stride ldo).
+ * ws: gnf_gnn_workspace_bytes(N, H, mlp, combine). */
+size_t gnf_gnn_workspace_bytes(int64_t n_nodes, int32_t H, const GnfMlp* mlp, int32_t combine);
+int gnf_gnn_apply_f32(const GnfCsr* csr, const GnfMlp* mlp, const GnfGnnSpec* gnn, const float* x,
+                      int64_t ldx, int32_t H, float* out, int64_t ldo, void* ws, size_t ws_bytes,
+                      gnf_stream_t stream);
+
+/* Workspace (bytes) needed by gnf_coupling_half_f32 / gnf_grevnet_f32 for this problem. */
+size_t gnf_workspace_bytes(int64_t n_nodes, int32_t D, const GnfFlow* flow);
+
+/* One coupling half-step (one s-net + one t-net on the same conditioning half):
+ *   s = S(x_cond), t = T(x_cond);  x_upd <- x_upd*exp(s)+t  (FORWARD)  or  (x_upd - t)*exp(-s)  (INVERSE)
+ * x_cond / x_upd point at the first column of the two halves inside the [N, D] buffer (stride ld).
+ * If logdet_accum != NULL, sum(s) over all nodes and features is ADDED to *logdet_accum (device
+ * fp64; caller zeroes it).  Replaces gnn.py:320-323 (or 335-338 / 347-359 / 361-372). */
+int gnf_coupling_half_f32(const GnfCsr* csr, const GnfMlp* s_net, const GnfMlp* t_net,
+                          const GnfGnnSpec* gnn, const float* x_cond, float* x_upd, int64_t ld,
+                          int32_t H, int32_t direction, double* logdet_accum, void* ws,
+                          size_t ws_bytes, gnf_stream_t stream);
+
+/* The whole flow, in place on x[N, D]:
+ *   FORWARD  = GRevNet.f (gnn.py:304-341): x -> z; sums[0] = log_det_jacobian, sums[1] = sum(z^2)
+ *              (the data term of run_grevnet.py:292-294), both device fp64, written (not accumulated).
+ *   INVERSE  = GRevNet.g (gnn.py:343-373): z -> x; sums may be NULL (nothing written).
+ * use_batch_norm=False only. */
+int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld, int32_t D,
+                    int32_t direction, double* sums, void* ws, size_t ws_bytes, gnf_stream_t stream);
+
+/* Kernel D alone: *out = sum_{n,j} z[n,j]^2 in fp64 (device).  log_prob_zs =
+ * -0.5 * (*out) - 0.5 * D * ln(2*pi) * N   (tfd.MultivariateNormalDiag(0,1).log_prob summed,
+ * run_grevnet.py:292-294; train_grevnet_with_data.py:348-351). ws: gnf_workspace_bytes(...) or
+ * at least 8 * 1024 bytes. */
+int gnf_gauss_sumsq_f32(const float* z, int64_t n_nodes, int32_t D, int64_t ld, double* out,
+                        void* ws, size_t ws_bytes, gnf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNF_H */

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures tests/golden/*.npz from the oracle.
+
+The reference itself cannot be run (no TensorFlow 1.x / Sonnet / graph_nets / TFP in this image and
+`grevnet.py` is missing from its tree), and it ships no golden vectors, so these fixtures are
+outputs of oracle/gnf_oracle.py's float64 dense-adjacency restatement, written only after the
+float32 gather restatement agrees with it (asserted below).  "Parity unpinned" at the TF boundary.
+
+Each fixture holds: the batch (n_node, n_edge, senders, receivers with global ids), x, the flow
+hyper-parameters, every weight (w_{kind}_{half}_{i}_{layer}, b_...), and the expected z, logdet,
+log_prob_zs, log_prob_xs_per_node, plus x_roundtrip = g(z).
+
+Run from the repo root:  python tests/golden/make_golden.py
+Inputs: data/*.npz (edge lists converted from the reference's pickles by tools/convert_datasets.py).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import gnf_oracle as O  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def load(name):
+    d = np.load(os.path.join(ROOT, "data", name + ".npz"))
+    return d["n_node"], d["n_edge"], d["senders"], d["receivers"]
+
+
+CASES = [
+    # name, dataset, graph ids, D, latent, K, T, agg, combine, eps, activation, weight_sharing, final_scale
+    ("cfg1_grid_small_d2", "grid_small", [6], 2, 16, 3, 1, "mean", "agg", 1.0, "leaky_relu", False, 0.5),
+    ("cfg1_grid_small_d8", "grid_small", [6], 8, 32, 5, 1, "mean", "agg", 1.0, "leaky_relu", False, 0.5),
+    ("cfg2_small_community", "community_medium", None, 16, 32, 3, 2, "mean", "agg", 1.0, "leaky_relu", False, 0.5),
+    ("sum_concat_relu_shared", "grid_small", [0, 6, 7, 11], 6, 24, 4, 3, "sum", "concat", 0.0, "relu", True, 0.3),
+]
+
+
+def main():
+    for (name, ds, ids, d, latent, k, t, agg, combine, eps, act, ws, fscale) in CASES:
+        n_node, n_edge, sl, rl = load(ds)
+        rng = np.random.default_rng(12345)             # run_grevnet.py:108
+        if ids is None:                                # config 2 draw: with replacement from the 80% train split
+            ids = rng.choice(int(0.8 * len(n_node)), size=8, replace=True).tolist()
+        nn, ne, s, r = O.batch_graphs(n_node, n_edge, sl, rl, ids)
+        n = int(nn.sum())
+        x = rng.standard_normal((n, d)).astype(np.float32)
+        p = O.make_grevnet_params(2024, d // 2, latent, k, t, combine=combine, weight_sharing=ws,
+                                  final_scale=fscale)
+        o64 = O.Fp64Dense(s, r, n, agg=agg, combine=combine, epsilon=eps, activation=act)
+        res = o64.log_prob(x, p, t, ws)
+        o32 = O.Fp32Gather(s, r, n, agg=agg, combine=combine, epsilon=eps, activation=act)
+        r32 = o32.log_prob(o32.to_t(x), o32.prep_params(p), t, ws)
+        assert abs(res["log_prob_xs_per_node"] - r32["log_prob_xs_per_node"]) < 1e-5, name
+        assert np.abs(r32["z"].numpy() - res["z"]).max() < 5e-5, name
+        xr = o64.g(res["z"], p, t, ws)
+        assert np.abs(xr - x).max() < 1e-9
+        blob = dict(n_node=nn, n_edge=ne, senders=s, receivers=r, x=x, D=d, latent=latent, K=k, T=t,
+                    agg=agg, combine=combine, epsilon=eps, activation=act, weight_sharing=ws,
+                    z=res["z"], logdet=res["log_det_jacobian"], log_prob_zs=res["log_prob_zs"],
+                    log_prob_xs=res["log_prob_xs"], log_prob_xs_per_node=res["log_prob_xs_per_node"],
+                    x_roundtrip=xr)
+        for kind in ("s", "t"):
+            for half in range(2):
+                nets = [p[kind][half]] if ws else p[kind][half]
+                for i, mlp in enumerate(nets):
+                    for j, (w, b) in enumerate(mlp):
+                        blob[f"w_{kind}_{half}_{i}_{j}"] = w
+                        blob[f"b_{kind}_{half}_{i}_{j}"] = b
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **blob)
+        print(f"{name}: N={n} E={len(s)} per-node log-prob={res['log_prob_xs_per_node']:.6f} "
+              f"logdet={res['log_det_jacobian']:.4f} -> {os.path.getsize(path)} B")
+
+
+if __name__ == "__main__":
+    main()

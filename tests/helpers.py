@@ -1,0 +1,59 @@
+"""Shared test helpers: fixtures -> oracle params -> product objects."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN_CASES = ["cfg1_grid_small_d2", "cfg1_grid_small_d8", "cfg2_small_community", "sum_concat_relu_shared"]
+
+
+def load_golden(name):
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    g = {k: d[k] for k in d.files}
+    for k in ("D", "latent", "K", "T"):
+        g[k] = int(g[k])
+    for k in ("agg", "combine", "activation"):
+        g[k] = str(g[k])
+    g["epsilon"] = float(g["epsilon"])
+    g["weight_sharing"] = bool(g["weight_sharing"])
+    ws, t, k = g["weight_sharing"], g["T"], g["K"]
+    params = {}
+    for kind in ("s", "t"):
+        halves = []
+        for half in range(2):
+            nets = []
+            for i in range(1 if ws else t):
+                nets.append([(g[f"w_{kind}_{half}_{i}_{j}"], g[f"b_{kind}_{half}_{i}_{j}"]) for j in range(k)])
+            halves.append(nets[0] if ws else nets)
+        params[kind] = halves
+    g["params"] = params
+    return g
+
+
+def make_product_grevnet(hp, params):
+    """Build the product GRevNet through the reference-shaped factories (run_grevnet.py:154-180).
+    hp: dict with D, latent, K, T, agg, combine, epsilon, activation, weight_sharing."""
+    from functools import partial
+    from gnf_amd import gnn
+    act = gnn.leaky_relu if hp["activation"] == "leaky_relu" else gnn.relu
+    mk_mlp = partial(gnn.make_mlp_model, hp["latent"], hp["D"] / 2, hp["K"], act, 0.01, 0.1)
+    if hp["combine"] == "concat":
+        mk = partial(gnn.sum_concat_then_mlp_gnn if hp["agg"] == "sum" else gnn.avg_concat_then_mlp_gnn, mk_mlp)
+    else:
+        mk = partial(gnn.sum_then_mlp_gnn if hp["agg"] == "sum" else gnn.avg_then_mlp_gnn, mk_mlp, hp["epsilon"])
+    net = gnn.GRevNet(mk, hp["T"], hp["D"], use_batch_norm=False, weight_sharing=hp["weight_sharing"])
+    if params is not None:
+        net.set_params(params)
+    return net
+
+
+def graph_from_arrays(n_node, n_edge, senders, receivers, x, device="cpu"):
+    import torch
+    from gnf_amd.graphs import GraphsTuple
+    return GraphsTuple(nodes=torch.as_tensor(np.asarray(x, np.float32)).to(device),
+                       edges=torch.zeros(len(senders)).to(device),
+                       receivers=torch.as_tensor(np.asarray(receivers, np.int32)).to(device),
+                       senders=torch.as_tensor(np.asarray(senders, np.int32)).to(device),
+                       globals=torch.zeros(len(n_node)).to(device),
+                       n_node=torch.as_tensor(np.asarray(n_node, np.int32)).to(device),
+                       n_edge=torch.as_tensor(np.asarray(n_edge, np.int32)).to(device))

@@ -1,0 +1,152 @@
+"""Host-side logic of the drop-in surface (CPU): GraphsTuple batching, CSR construction, datasets,
+the reference-shaped class structure, parameter plumbing, sharding."""
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from gnf_amd import gnn
+from gnf_amd.datasets import (EdgeListDataset, GraphDataset, fully_connected_edges, senders_receivers,
+                              synthetic_ego, synthetic_protein, with_fully_connected_topology)
+from gnf_amd.graphs import GraphsTuple, build_csr_host, data_dicts_to_graphs_tuple
+from gnf_amd.sharding import shard_graph_ids
+from oracle import gnf_oracle as O
+
+
+def test_graphs_tuple_fields_and_replace():
+    assert GraphsTuple._fields == ("nodes", "edges", "receivers", "senders", "globals", "n_node", "n_edge")
+    g = data_dicts_to_graphs_tuple([
+        {"nodes": np.ones((2, 4)), "senders": [0, 1, 0], "receivers": [0, 1, 1]},
+        {"nodes": np.zeros((3, 4)), "senders": [0, 1, 2], "receivers": [2, 1, 0]}])
+    assert g.nodes.shape == (5, 4) and g.nodes.dtype == torch.float32
+    assert g.senders.tolist() == [0, 1, 0, 2, 3, 4] and g.receivers.tolist() == [0, 1, 1, 4, 3, 2]
+    assert g.senders.dtype == torch.int32
+    assert g.n_node.tolist() == [2, 3] and g.n_edge.tolist() == [3, 3]
+    h = g.replace(nodes=g.nodes * 2)
+    assert h.senders is g.senders and float(h.nodes.sum()) == 16.0 and float(g.nodes.sum()) == 8.0
+
+
+def test_batching_matches_oracle_batcher(community_medium):
+    n_node, n_edge, sl, rl = community_medium
+    ds = EdgeListDataset(n_node, n_edge, sl, rl)
+    ids = [5, 5, 100, 17]
+    g = data_dicts_to_graphs_tuple(ds.data_dicts(ids, lambda n: np.zeros((n, 2), np.float32)))
+    nn, ne, s, r = O.batch_graphs(n_node, n_edge, sl, rl, ids)
+    assert g.senders.numpy().tolist() == s.tolist() and g.receivers.numpy().tolist() == r.tolist()
+    assert g.n_node.numpy().tolist() == nn.tolist() and g.n_edge.numpy().tolist() == ne.tolist()
+
+
+def test_build_csr_host_is_stable_receiver_sort():
+    rng = np.random.default_rng(0)
+    n, e = 13, 90
+    s = rng.integers(0, n, e)
+    r = rng.integers(0, n - 2, e)          # nodes n-2, n-1 receive nothing (empty rows)
+    rowptr, col = build_csr_host(s, r, n)
+    assert rowptr[0] == 0 and rowptr[-1] == e and rowptr.dtype == np.int32
+    for v in range(n):
+        want = [int(s[i]) for i in range(e) if r[i] == v]      # original edge order
+        assert col[rowptr[v]:rowptr[v + 1]].tolist() == want
+    assert rowptr[n - 1] == rowptr[n] == rowptr[n - 2]
+
+
+def test_graph_dataset_semantics():
+    ds = GraphDataset("graph_rnn_community_medium", 6, seed=1)
+    assert len(ds.all) == 210 and len(ds.train_ids) == 168          # graph_data.py:77-78
+    g = ds.get_next_train_batch(16)
+    assert g.nodes.shape[1] == 6 and int(g.n_node.sum()) == g.nodes.shape[0]
+    assert int(g.n_edge.sum()) == g.senders.shape[0]
+    # one self loop per node, inserted first (graph_data.py:40-44)
+    s, r = g.senders.numpy(), g.receivers.numpy()
+    assert int((s == r).sum()) == g.nodes.shape[0]
+    # every edge stays inside its graph (block diagonal)
+    off = np.concatenate([[0], np.cumsum(g.n_node.numpy())])
+    gid_of = np.repeat(np.arange(16), g.n_node.numpy())
+    assert (gid_of[s] == gid_of[r]).all()
+    # symmetric (to_directed)
+    pairs = set(zip(s.tolist(), r.tolist()))
+    assert all((b, a) in pairs for a, b in pairs)
+
+
+def test_fully_connected_topology_order_and_count():
+    a, b = fully_connected_edges(3)
+    assert a.tolist() == [0, 0, 0, 1, 1, 1, 2, 2, 2] and b.tolist() == [0, 1, 2, 0, 1, 2, 0, 1, 2]  # utils.py:138-143
+    s, r, ne = senders_receivers([2, 3])
+    assert ne.tolist() == [4, 9] and s.max() == 4 and len(s) == 13
+    assert s[4:].min() == 2 and r[4:].min() == 2
+    ds = with_fully_connected_topology(EdgeListDataset([2, 3], [1, 1], [0, 0], [0, 0]))
+    assert ds.n_edge.tolist() == [4, 9]
+
+
+def test_synthetic_stand_ins_shape():
+    p = synthetic_protein(4, seed=3)
+    assert (p.n_node >= 100).all() and (p.n_node <= 500).all()
+    deg = p.n_edge.sum() / p.n_node.sum()
+    assert 3.5 < deg < 8
+    e = synthetic_ego(4, seed=3)
+    assert (e.n_node >= 50).all() and (e.n_node < 400).all()
+    for ds in (p, e):
+        n, s, r = ds.graph(0)
+        assert (s[:n] == np.arange(n)).all() and (r[:n] == np.arange(n)).all()   # self loops first
+        assert s.max() < n and r.max() < n
+
+
+def test_reference_shaped_structure():
+    mk_mlp = partial(gnn.make_mlp_model, 32, 8 / 2, 5, gnn.leaky_relu, 0.01, 0.1)   # run_grevnet.py:175-180
+    mk = partial(gnn.avg_then_mlp_gnn, mk_mlp, 1.0)
+    net = gnn.GRevNet(mk, 3, 8, use_batch_norm=False, weight_sharing=False)
+    assert len(net.s) == 2 and len(net.s[0]) == 3 and len(net.t[1]) == 3            # gnn.py:288-296
+    assert isinstance(net.s[0][0], gnn.NodeBlockGNN)
+    blk = net.s[0][0]._node_block
+    assert isinstance(blk, gnn.AggThenMLPBlock) and blk.epsilon == 1.0
+    assert blk._mlp.layer_sizes == [32, 32, 32, 32, 4] and blk._mlp.alpha == pytest.approx(0.2)
+    shared = gnn.GRevNet(mk, 3, 8, weight_sharing=True)
+    assert len(shared.s) == 2 and isinstance(shared.s[0], gnn.NodeBlockGNN)          # gnn.py:284-286
+    with pytest.raises(NotImplementedError):
+        gnn.GRevNet(mk, 3, 8, use_batch_norm=True)
+    c = gnn.sum_concat_then_mlp_gnn(mk_mlp)._node_block
+    assert isinstance(c, gnn.ConcatThenMLPBlock) and c.in_dim(4) == 8
+    assert gnn.EDGE_BLOCK_OPT == {"use_edges": False, "use_receiver_nodes": False, "use_sender_nodes": True,
+                                  "use_globals": False}
+    with pytest.raises(ValueError):
+        gnn.AggThenMLPBlock("max", mk_mlp, 1.0)
+
+
+def test_lazy_init_and_param_roundtrip():
+    gnn.set_random_seed(7)
+    m = gnn.make_mlp_model(16, 4, 3, gnn.relu, 0.01, 0.1)
+    assert m.params is None
+    m.ensure_built(6, "cpu")
+    assert [tuple(w.shape) for w, _ in m.params] == [(6, 16), (16, 16), (16, 4)]
+    w0 = m.params[0][0]
+    std = np.sqrt(2.0 / (6 + 16)) / 0.87962566103423978
+    assert float(w0.abs().max()) <= 2 * std + 1e-6                                   # truncated at 2 sigma
+    assert float(m.params[0][1].abs().max()) <= 0.2 + 1e-6
+    with pytest.raises(ValueError):
+        m.ensure_built(7, "cpu")
+    p = O.make_grevnet_params(1, 4, 16, 3, 2)
+    mk = partial(gnn.avg_then_mlp_gnn, partial(gnn.make_mlp_model, 16, 4, 3, gnn.leaky_relu), 1.0)
+    net = gnn.GRevNet(mk, 2, 8).set_params(p)
+    q = net.get_params()
+    for kind in ("s", "t"):
+        for half in range(2):
+            for i in range(2):
+                for (w, b), (w2, b2) in zip(p[kind][half][i], q[kind][half][i]):
+                    assert np.array_equal(w, w2) and np.array_equal(b, b2)
+    with pytest.raises(ValueError):
+        net.mlps("s")[0].set_params([(np.zeros((4, 16)), np.zeros(16))])            # wrong layer count
+
+
+def test_sharding_is_balanced_and_complete(community_medium):
+    n_node, n_edge, _, _ = community_medium
+    rng = np.random.default_rng(12345)
+    ids = rng.choice(168, size=512, replace=True)
+    nn, ne = n_node[ids], n_edge[ids]
+    shards = shard_graph_ids(nn, ne, 8)
+    allpos = np.sort(np.concatenate(shards))
+    assert allpos.tolist() == list(range(512))
+    loads = np.array([nn[s].sum() + 0.05 * ne[s].sum() for s in shards])
+    assert loads.max() / loads.mean() < 1.01
+    assert shard_graph_ids(nn, ne, 8)[3].tolist() == shards[3].tolist()             # deterministic
+    one = shard_graph_ids(nn[:3], ne[:3], 8)                                         # fewer graphs than ranks
+    assert sum(len(s) for s in one) == 3

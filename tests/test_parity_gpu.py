@@ -1,0 +1,359 @@
+"""Parity tests proper: the HIP path (through the C ABI) vs the CPU oracle on identical inputs, and vs
+the committed golden fixtures.  Run on a real MI355X:  python -m pytest tests -m gpu
+
+Tolerances (stated, fp32 path vs float64 oracle):
+  per-node log-prob  |delta| <= 1e-4        (BASELINE.json north_star)
+  z elementwise      atol 2e-4 + rtol 2e-4  (fp32 rounding through 2*T*K chained GEMMs + exp)
+  round trip         max|g(f(x)) - x| <= 2e-3 at fp32 for the deepest flows, 1e-4 for shallow ones
+  integer work (CSR) bit-exact
+"""
+import ctypes as C
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN_CASES, graph_from_arrays, load_golden, make_product_grevnet
+from oracle import gnf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu_and_native_lib():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from gnf_amd import _abi
+    _abi.lib()   # raises if libgnf_hip.so is missing: no silent fallback
+
+
+def _oracle(hp, s, r, n):
+    return O.Fp64Dense(s, r, n, agg=hp["agg"], combine=hp["combine"], epsilon=hp["epsilon"],
+                       activation=hp["activation"])
+
+
+def _batch(dataset, ids):
+    n_node, n_edge, sl, rl = dataset
+    return O.batch_graphs(n_node, n_edge, sl, rl, ids)
+
+
+def _run_forward(net, graph):
+    from gnf_amd.flow import log_prob_terms
+    out = log_prob_terms(net, graph)
+    torch.cuda.synchronize()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "layered"])
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_forward_matches_golden(name, fused):
+    g = load_golden(name)
+    net = make_product_grevnet(g, g["params"])
+    net.fused = fused
+    graph = graph_from_arrays(g["n_node"], g["n_edge"], g["senders"], g["receivers"], g["x"], DEV)
+    out = _run_forward(net, graph)
+    z = out["z_graph"].nodes.cpu().numpy()
+    np.testing.assert_allclose(z, g["z"], atol=2e-4, rtol=2e-4)
+    assert abs(float(out["log_det_jacobian"]) - float(g["logdet"])) <= 1e-4 * max(1.0, g["x"].shape[0])
+    assert abs(float(out["log_prob_xs_per_node"]) - float(g["log_prob_xs_per_node"])) <= 1e-4
+    # the input graph is untouched (TF ops are functional)
+    np.testing.assert_array_equal(graph.nodes.cpu().numpy(), g["x"])
+    # inverse: g(z) gives x back
+    x_back = net(out["z_graph"], inverse=False).nodes.cpu().numpy()
+    np.testing.assert_allclose(x_back, g["x_roundtrip"], atol=5e-4, rtol=5e-4)
+
+
+HP_DEFAULT = dict(D=64, latent=256, K=5, T=8, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu",
+                  weight_sharing=False)
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "layered"])
+def test_config2_shape_vs_oracle(community_medium, fused):
+    """community_medium batch (reduced to 16 graphs so the fp64 dense oracle takes seconds), full
+    BASELINE hyper-parameters: D=64, L=256, K=5, T=8, avg_then_mlp, leaky_relu."""
+    hp = dict(HP_DEFAULT)
+    rng = np.random.default_rng(12345)
+    ids = rng.choice(168, size=16, replace=True)
+    nn, ne, s, r = _batch(community_medium, ids)
+    n = int(nn.sum())
+    x = rng.standard_normal((n, hp["D"])).astype(np.float32)
+    p = O.make_grevnet_params(99, hp["D"] // 2, hp["latent"], hp["K"], hp["T"], final_scale=0.25)
+    ref = _oracle(hp, s, r, n).log_prob(x, p, hp["T"])
+    net = make_product_grevnet(hp, p)
+    net.fused = fused
+    out = _run_forward(net, graph_from_arrays(nn, ne, s, r, x, DEV))
+    assert abs(float(out["log_prob_xs_per_node"]) - ref["log_prob_xs_per_node"]) <= 1e-4
+    assert abs(float(out["log_prob_zs_per_node"]) - ref["log_prob_zs_per_node"]) <= 1e-4
+    assert abs(float(out["log_det_jacobian_per_node"]) - ref["log_det_jacobian_per_node"]) <= 1e-4
+    np.testing.assert_allclose(out["z_graph"].nodes.cpu().numpy(), ref["z"], atol=5e-4, rtol=5e-4)
+
+
+SHAPES = [
+    # D, latent, K, T, agg, combine, eps, act, ws   (odd reference-default widths: D=2 run_grevnet.py:39,
+    # D=100 run_gnn.py:111, D=200 train_grevnet_with_data.py:117; widths that are not multiples of 16)
+    (2, 16, 3, 2, "mean", "agg", 1.0, "leaky_relu", False),
+    (2, 256, 5, 3, "mean", "agg", 1.0, "leaky_relu", False),
+    (100, 48, 2, 2, "sum", "agg", 0.5, "relu", False),
+    (200, 40, 3, 1, "mean", "concat", 0.0, "relu", True),
+    (6, 20, 1, 2, "sum", "concat", 0.0, "leaky_relu", False),     # K = 1: a single Linear layer
+    (32, 128, 4, 4, "mean", "agg", 1.0, "leaky_relu", True),
+    (16, 8, 8, 1, "mean", "agg", 1.0, "leaky_relu", False),       # K = GNF_MAX_LAYERS
+]
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "layered"])
+@pytest.mark.parametrize("shape", SHAPES, ids=[f"D{s[0]}_L{s[1]}_K{s[2]}_T{s[3]}_{s[4]}_{s[5]}" for s in SHAPES])
+def test_shape_generic(grid_small, shape, fused):
+    d, latent, k, t, agg, combine, eps, act, ws = shape
+    hp = dict(D=d, latent=latent, K=k, T=t, agg=agg, combine=combine, epsilon=eps, activation=act,
+              weight_sharing=ws)
+    nn, ne, s, r = _batch(grid_small, list(range(12)))          # all 12 graphs, ragged sizes 4..20
+    n = int(nn.sum())
+    rng = np.random.default_rng(d * 1000 + latent)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    p = O.make_grevnet_params(d + k, d // 2, latent, k, t, combine=combine, weight_sharing=ws,
+                              final_scale=0.3 if agg == "mean" else 0.1)
+    o = _oracle(hp, s, r, n)
+    ref = o.log_prob(x, p, t, ws)
+    net = make_product_grevnet(hp, p)
+    net.fused = fused
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    out = _run_forward(net, graph)
+    assert abs(float(out["log_prob_xs_per_node"]) - ref["log_prob_xs_per_node"]) <= 1e-4
+    np.testing.assert_allclose(out["z_graph"].nodes.cpu().numpy(), ref["z"], atol=3e-4, rtol=3e-4)
+    # inverse on an independent latent sample vs the oracle's g
+    zs = rng.standard_normal((n, d)).astype(np.float32)
+    xg = net(graph.replace(nodes=torch.as_tensor(zs).to(DEV)), inverse=False).nodes.cpu().numpy()
+    np.testing.assert_allclose(xg, o.g(zs, p, t, ws), atol=3e-4, rtol=3e-4)
+
+
+def test_fully_connected_topology(community_medium):
+    """train_grevnet_with_data.py topology: every ordered pair incl. self (utils.py:164-183)."""
+    from gnf_amd.datasets import senders_receivers
+    n_node = community_medium[0][[3, 50, 77]]
+    s, r, ne = senders_receivers(n_node)
+    n = int(n_node.sum())
+    hp = dict(HP_DEFAULT, D=16, latent=64, K=3, T=2)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((n, 16)).astype(np.float32)
+    p = O.make_grevnet_params(5, 8, 64, 3, 2, final_scale=0.3)
+    ref = _oracle(hp, s, r, n).log_prob(x, p, 2)
+    out = _run_forward(make_product_grevnet(hp, p), graph_from_arrays(n_node, ne, s, r, x, DEV))
+    assert abs(float(out["log_prob_xs_per_node"]) - ref["log_prob_xs_per_node"]) <= 1e-4
+
+
+def test_isolated_nodes_and_missing_self_loops():
+    """Nodes without incoming edges: empty segment -> 0 for sum AND mean (unsorted_segment_mean
+    divides by max(count, 1))."""
+    s = np.array([0, 0, 2], np.int32)
+    r = np.array([1, 2, 1], np.int32)          # node 0 and node 3 receive nothing
+    n = 4
+    for agg in ("sum", "mean"):
+        hp = dict(HP_DEFAULT, D=4, latent=8, K=2, T=2, agg=agg)
+        x = np.random.default_rng(1).standard_normal((n, 4)).astype(np.float32)
+        p = O.make_grevnet_params(1, 2, 8, 2, 2, final_scale=0.5)
+        ref = _oracle(hp, s, r, n).log_prob(x, p, 2)
+        for fused in (True, False):
+            net = make_product_grevnet(hp, p)
+            net.fused = fused
+            out = _run_forward(net, graph_from_arrays([4], [3], s, r, x, DEV))
+            assert abs(float(out["log_prob_xs_per_node"]) - ref["log_prob_xs_per_node"]) <= 1e-4
+            np.testing.assert_allclose(out["z_graph"].nodes.cpu().numpy(), ref["z"], atol=1e-4, rtol=1e-4)
+
+
+def test_empty_batch():
+    hp = dict(HP_DEFAULT, D=4, latent=8, K=2, T=1)
+    net = make_product_grevnet(hp, O.make_grevnet_params(1, 2, 8, 2, 1))
+    g = graph_from_arrays(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32),
+                          np.zeros(0, np.int32), np.zeros((0, 4), np.float32), DEV)
+    zg, ld = net(g, inverse=True)
+    torch.cuda.synchronize()
+    assert zg.nodes.shape == (0, 4) and float(ld) == 0.0
+    assert float(net.last_sums[1]) == 0.0
+
+
+def test_additivity_over_shards_on_device(community_medium):
+    """The property multi-GPU sharding relies on: batch sums = sum of per-shard sums."""
+    from gnf_amd.flow import log_prob_terms
+    from gnf_amd.sharding import assemble_from_sums, shard_graph_ids
+    hp = dict(HP_DEFAULT, D=16, latent=32, K=3, T=2)
+    p = O.make_grevnet_params(3, 8, 32, 3, 2, final_scale=0.4)
+    rng = np.random.default_rng(2)
+    ids = rng.choice(168, size=12, replace=True)
+    n_node, n_edge, sl, rl = community_medium
+    nn, ne, s, r = O.batch_graphs(n_node, n_edge, sl, rl, ids)
+    n = int(nn.sum())
+    x = rng.standard_normal((n, 16)).astype(np.float32)
+    net = make_product_grevnet(hp, p)
+    full = log_prob_terms(net, graph_from_arrays(nn, ne, s, r, x, DEV))
+    noff = np.concatenate([[0], np.cumsum(nn)])
+    total = torch.zeros(3, dtype=torch.float64, device=DEV)
+    for shard in shard_graph_ids(nn, ne, 3):
+        rows = np.concatenate([np.arange(noff[i], noff[i + 1]) for i in shard])
+        n2, e2, s2, r2 = O.batch_graphs(n_node, n_edge, sl, rl, ids[shard])
+        total += log_prob_terms(net, graph_from_arrays(n2, e2, s2, r2, x[rows], DEV))["shard_sums"]
+    asm = assemble_from_sums(total)
+    assert abs(float(asm["log_prob_xs_per_node"]) - float(full["log_prob_xs_per_node"])) <= 1e-6
+    ref = _oracle(hp, s, r, n).log_prob(x, p, 2)
+    assert abs(float(asm["log_prob_xs_per_node"]) - ref["log_prob_xs_per_node"]) <= 1e-4
+
+
+def test_round_trip_at_full_size(community_medium):
+    """Size-independent property at BASELINE config 2's full size (batch 64, T=8, D=64, L=256, K=5):
+    g(f(x)) = x, f(g(z)) = z; and the fused and layered kernels agree with each other."""
+    hp = dict(HP_DEFAULT)
+    rng = np.random.default_rng(12345)
+    ids = rng.choice(168, size=64, replace=True)
+    nn, ne, s, r = _batch(community_medium, ids)
+    n = int(nn.sum())
+    x = rng.standard_normal((n, 64)).astype(np.float32)
+    p = O.make_grevnet_params(99, 32, 256, 5, 8, final_scale=0.25)
+    net = make_product_grevnet(hp, p)
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    zg, ld = net(graph, inverse=True)
+    back = net(zg, inverse=False).nodes
+    assert float((back - graph.nodes).abs().max()) <= 2e-3
+    z2, _ = net(net(graph, inverse=False), inverse=True)
+    assert float((z2.nodes - graph.nodes).abs().max()) <= 2e-3
+    lay = make_product_grevnet(hp, p)
+    lay.fused = False
+    zl, ldl = lay(graph, inverse=True)
+    torch.cuda.synchronize()
+    assert abs(float(ld) - float(ldl)) / n <= 2e-5
+    assert float((zl.nodes - zg.nodes).abs().max()) <= 1e-3
+    # reproducibility: bitwise identical on a re-run (fixed-order reductions, no atomics)
+    zg2, ld2 = net(graph, inverse=True)
+    assert torch.equal(zg2.nodes, zg.nodes) and float(ld2) == float(ld)
+
+
+# ------------------------------------------------------------------------------------------------
+# single entry points
+# ------------------------------------------------------------------------------------------------
+def test_device_csr_build_is_bit_exact(community_medium, grid_small):
+    from gnf_amd.graphs import build_csr_device, build_csr_host
+    from gnf_amd.datasets import senders_receivers
+    cases = []
+    rng = np.random.default_rng(0)
+    nn, ne, s, r = _batch(community_medium, rng.choice(210, size=40, replace=True))
+    cases.append((nn, ne, s, r))
+    cases.append(_batch(grid_small, list(range(12))))
+    n_node = np.array([100, 1, 37], np.int32)                 # FC incl. a 1-node graph; 10^4-edge graph
+    s2, r2, ne2 = senders_receivers(n_node)
+    cases.append((n_node, ne2, s2.astype(np.int32), r2.astype(np.int32)))
+    # shuffled edge order inside each graph (unsorted segment ids) + a graph with zero edges
+    nn3 = np.array([5, 3, 4], np.int32)
+    ne3 = np.array([7, 0, 5], np.int32)
+    s3 = np.array([4, 0, 2, 2, 1, 3, 0, 8, 11, 9, 10, 8], np.int32)
+    r3 = np.array([1, 1, 0, 4, 1, 3, 0, 10, 8, 8, 8, 11], np.int32)
+    cases.append((nn3, ne3, s3, r3))
+    for nn, ne, s, r in cases:
+        n = int(nn.sum())
+        g = graph_from_arrays(nn, ne, s, r, np.zeros((n, 2), np.float32), DEV)
+        csr = build_csr_device(g)
+        torch.cuda.synchronize()
+        rowptr, col = build_csr_host(s, r, n)
+        assert np.array_equal(csr.rowptr.cpu().numpy(), rowptr)
+        assert np.array_equal(csr.col.cpu().numpy()[:len(s)], col)
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean"])
+@pytest.mark.parametrize("h", [1, 32, 50, 300])
+def test_aggregate_kernel_alone(community_medium, agg, h):
+    from gnf_amd import _abi
+    from gnf_amd.graphs import csr_of
+    nn, ne, s, r = _batch(community_medium, [1, 2, 3, 200])
+    n = int(nn.sum())
+    x = np.random.default_rng(h).standard_normal((n, h)).astype(np.float32)
+    g = graph_from_arrays(nn, ne, s, r, x, DEV)
+    csr = csr_of(g)
+    out = torch.empty(n, h, device=DEV)
+    _abi.check(_abi.lib().gnf_aggregate_f32(C.byref(csr.desc), _abi.ptr(g.nodes), h, h,
+                                            _abi.GNF_AGG_MEAN if agg == "mean" else _abi.GNF_AGG_SUM,
+                                            _abi.ptr(out), h, _abi.stream_ptr()), "gnf_aggregate_f32")
+    o = O.Fp64Dense(s, r, n, agg=agg, epsilon=0.0)
+    want = o.adj @ x.astype(np.float64)
+    if agg == "mean":
+        want = want / o.deg
+    np.testing.assert_allclose(out.cpu().numpy(), want, atol=1e-5, rtol=1e-5)
+
+
+def test_gnn_module_call_alone(grid_small):
+    """A make_gnn_fn() product called like the reference calls it: module(GraphsTuple) -> GraphsTuple."""
+    from gnf_amd import gnn
+    nn, ne, s, r = _batch(grid_small, [6, 2])
+    n = int(nn.sum())
+    x = np.random.default_rng(3).standard_normal((n, 5)).astype(np.float32)
+    layers = O.make_mlp_params(np.random.default_rng(4), 10, 24, 7, 3)
+    mod = gnn.sum_concat_then_mlp_gnn(partial(gnn.make_mlp_model, 24, 7, 3, gnn.leaky_relu))
+    mod._node_block._mlp.set_params(layers)
+    out = mod(graph_from_arrays(nn, ne, s, r, x, DEV))
+    want = O.Fp64Dense(s, r, n, agg="sum", combine="concat").gnn(x.astype(np.float64), layers)
+    np.testing.assert_allclose(out.nodes.cpu().numpy(), want, atol=1e-4, rtol=1e-4)
+    assert out.senders is not None and out.nodes.shape == (n, 7)
+
+
+def test_coupling_half_entry_point_accumulates_logdet(grid_small):
+    from gnf_amd import _abi
+    from gnf_amd.graphs import csr_of
+    nn, ne, s, r = _batch(grid_small, [6])
+    n = int(nn.sum())
+    hp = dict(HP_DEFAULT, D=8, latent=16, K=2, T=1)
+    p = O.make_grevnet_params(8, 4, 16, 2, 1, final_scale=0.5)
+    x = np.random.default_rng(8).standard_normal((n, 8)).astype(np.float32)
+    net = make_product_grevnet(hp, p)
+    g = graph_from_arrays(nn, ne, s, r, x, DEV)
+    flow = net._flow(4, torch.device(DEV))
+    csr = csr_of(g)
+    lib = _abi.lib()
+    buf = g.nodes.clone()
+    acc = torch.full((1,), 10.0, dtype=torch.float64, device=DEV)     # pre-loaded: must be ADDED to
+    ws_bytes = lib.gnf_workspace_bytes(n, 8, C.byref(flow))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    spec = flow.gnn
+    _abi.check(lib.gnf_coupling_half_f32(C.byref(csr.desc), C.byref(flow.s_nets[0]), C.byref(flow.t_nets[0]),
+                                         C.byref(spec), C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr() + 16),
+                                         8, 4, 0, _abi.ptr(acc), _abi.ptr(ws), ws_bytes, _abi.stream_ptr()),
+               "gnf_coupling_half_f32")
+    o = _oracle(hp, s, r, n)
+    x0, x1 = x[:, :4].astype(np.float64), x[:, 4:].astype(np.float64)
+    sv = o.gnn(x0, p["s"][0][0])
+    tv = o.gnn(x0, p["t"][0][0])
+    got = buf.cpu().numpy()
+    np.testing.assert_allclose(got[:, 4:], x1 * np.exp(sv) + tv, atol=1e-5, rtol=1e-5)
+    np.testing.assert_array_equal(got[:, :4], x[:, :4])               # conditioning half untouched
+    assert abs(float(acc[0]) - (10.0 + sv.sum())) < 1e-4
+    # and the inverse direction restores the input
+    _abi.check(lib.gnf_coupling_half_f32(C.byref(csr.desc), C.byref(flow.s_nets[0]), C.byref(flow.t_nets[0]),
+                                         C.byref(spec), C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr() + 16),
+                                         8, 4, 1, None, _abi.ptr(ws), ws_bytes, _abi.stream_ptr()),
+               "gnf_coupling_half_f32")
+    np.testing.assert_allclose(buf.cpu().numpy(), x, atol=1e-5, rtol=1e-5)
+
+
+def test_gauss_sumsq_kernel_alone():
+    from gnf_amd.flow import gauss_sumsq
+    z = np.random.default_rng(6).standard_normal((1234, 10)).astype(np.float32)
+    got = float(gauss_sumsq(torch.as_tensor(z).to(DEV)))
+    assert abs(got - float((z.astype(np.float64) ** 2).sum())) < 1e-8 * got
+    zt = torch.as_tensor(z).to(DEV)[:, 2:8]                            # strided view (ld = 10, D = 6)
+    assert abs(float(gauss_sumsq(zt)) - float((z[:, 2:8].astype(np.float64) ** 2).sum())) < 1e-6
+
+
+def test_sampling_entry(grid_small):
+    from gnf_amd.flow import sample
+    nn, ne, s, r = _batch(grid_small, [6, 7])
+    n = int(nn.sum())
+    hp = dict(HP_DEFAULT, D=8, latent=16, K=3, T=2)
+    p = O.make_grevnet_params(2, 4, 16, 3, 2, final_scale=0.5)
+    net = make_product_grevnet(hp, p)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    out = sample(net, graph_from_arrays(nn, ne, s, r, np.zeros((n, 8), np.float32), DEV), generator=gen)
+    z = out["sample"].cpu().numpy()
+    want = _oracle(hp, s, r, n).g(z, p, 2)
+    np.testing.assert_allclose(out["grevnet_top_nodes"].cpu().numpy(), want, atol=2e-4, rtol=2e-4)
+    from scipy.stats import multivariate_normal
+    np.testing.assert_allclose(out["sample_log_prob"].cpu().numpy(),
+                               multivariate_normal(np.zeros(8), np.eye(8)).logpdf(z), atol=1e-5)
