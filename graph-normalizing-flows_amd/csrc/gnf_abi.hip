@@ -114,7 +114,7 @@ WorkspacePlan plan_workspace(int64_t n_nodes, int32_t H, const GnfMlp* net, int3
 }
 
 static int run_half(const HalfStep& hs, float* scratch, hipStream_t st) {
-    if (fused_supported(hs)) return launch_half_fused(hs, st);
+    if (fused_supported(hs)) return launch_half_fused(hs, scratch, st);
     return launch_half_layered(hs, scratch, st);
 }
 

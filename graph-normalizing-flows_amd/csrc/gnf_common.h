@@ -65,7 +65,9 @@ WorkspacePlan plan_workspace(int64_t n_nodes, int32_t H, const GnfMlp* net, int3
 
 // ---- launchers (each returns GNF_OK / GNF_E*) --------------------------------------------------
 bool fused_supported(const HalfStep& hs);
-int launch_half_fused(const HalfStep& hs, hipStream_t st);
+int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st);
+// coupling epilogue from global s / t [N, H] buffers (writes hs.partials, *hs.n_partials)
+int launch_coupling(const float* s, const float* t, const HalfStep& hs, hipStream_t st);
 int launch_half_layered(const HalfStep& hs, float* scratch, hipStream_t st);
 int launch_gnn_layered(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, const float* x,
                        int64_t ldx, int32_t H, const GnfGnnSpec& g, const GnfMlp* mlp, float* out,

@@ -1,25 +1,28 @@
 // Fused coupling half-step for gfx950 (MI355X): ONE launch does, for a tile of TM = 16*MT nodes,
 //   A  CSR segmented reduce of neighbour rows (coalesced row reads, sum | sum/max(deg,1))   gnn.py:103-104,117-118,151-156
 //      + combine  eps*x+agg | [x || agg]  straight into LDS                                 gnn.py:123 | 108-109
-//   B  the s-net and the t-net MLPs, all K layers, activations resident in LDS, on the      gnn.py:159-180
+//   B  the s-net and/or t-net MLP, all K layers, activations resident in LDS, on the        gnn.py:159-180
 //      exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32: bitwise an fmaf chain), weights
-//      streamed from L2 in pre-packed fragment order (one global_load_dwordx4 per 4 MFMAs)
+//      streamed from L2 in pre-packed fragment order (one buffer_load_dwordx4 per 4*MT MFMAs)
 //   C  x_upd <- x_upd*exp(s)+t  |  (x_upd-t)*exp(-s)  and a block-reduced fp64 sum(s)        gnn.py:322-323,337-338 | 359,372
 // so the [E,H] edge tensor, the aggregated tensor and every MLP activation of the reference's TF
 // graph never touch HBM.
 //
-// Work decomposition (MI355X-first, not a tiling borrowed from a 32-wide-warp design):
-//   * 512 threads = 8 wave64; waves 0-3 run the s-net, waves 4-7 the t-net, concurrently, two
-//     waves per SIMD so one wave's MFMA chain covers the other's loads.
-//   * inside a net, wave w owns output column tiles {w, w+4, w+8, ...} (16 columns each) and
-//     processes them four at a time: one ds_read_b128 of the A fragment (16 nodes x 16 k) feeds
-//     16 MFMAs per M-tile.  K order inside a group of 16 is permuted identically on both operands
-//     (k = 16*kg + 4*(lane>>4) + q) so that A is one 16-byte LDS read and B one 16-byte global read.
-//   * layer outputs go back to LDS in the accumulator layout (row = 4*(lane>>4)+r, col = lane&15)
-//     through a ping-pong pair of [TM][LS] buffers per net, LS = widest padded layer + 4 floats
-//     (keeps rows 16-byte aligned and spreads rows over LDS banks).
-//   * blockIdx -> tile mapping is XCD-aware (consecutive tiles = neighbouring nodes of the same
-//     graphs stay on one XCD's L2).
+// Two workgroup shapes (measured on MI355X, see DESIGN.md "per-CU weight streaming"):
+//   NETS = 2  one workgroup = a node tile x BOTH nets: waves 0-3 run the s-net, waves 4-7 the
+//             t-net, the coupling update C happens in the same launch.  Used when there are enough
+//             node tiles to fill the chip.
+//   NETS = 1  one workgroup = a node tile x ONE net (all 8 waves on it); s / t tiles go to a global
+//             scratch and the coupling update is the small k_coupling launch.  Half the LDS
+//             footprint: keeps layers up to 1024 wide on the fused path.  XCDs 0-3 take the s-net,
+//             XCDs 4-7 the t-net, so each XCD L2 holds one net's weights only.
+//
+// Inside a net, wave w owns output column tiles {w, w+WPN, w+2*WPN, ...} (16 columns each, WPN =
+// waves per net) and processes up to four at a time: one ds_read_b128 of the A fragment (16 nodes x
+// 16 k) per M-tile feeds 4*NV MFMAs.  K order inside a group of 16 is permuted identically on both
+// operands (k = 16*kg + 4*(lane>>4) + q) so that A is one 16-byte LDS read and B one 16-byte global
+// read.  Layer outputs go back to LDS in the accumulator layout through a ping-pong pair of
+// [TM][LS] buffers per net, LS = widest padded layer + 4 floats.  Biases are staged in LDS once.
 //
 // Zero padding: every layer width is padded to a multiple of 16 in the packed weights (pad rows,
 // pad columns and pad biases are 0), so padded activations are act(0) = 0 and never contribute.
@@ -35,8 +38,10 @@ static constexpr int kLdsLimit = 160 * 1024;
 static inline int pad16(int v) { return (v + 15) & ~15; }
 
 // ------------------------------------------------------------------------------------------------
-// packed weight layout of one MLP (floats):  for each layer j:  Wp[Op/16][Ip/16][64 lanes][4] | bias[Op]
-//   Wp[nt][kg][lane][q] = W[16*kg + 4*(lane>>4) + q][16*nt + (lane&15)]   (0 outside [I,O))
+// packed weight layout of one MLP (floats):  Wp_0 | Wp_1 | ... | Wp_{K-1} | bias_0 | ... | bias_{K-1}
+//   Wp_j[Op/16][Ip/16][64 lanes][4]:  Wp[nt][kg][lane][q] = W[16*kg + 4*(lane>>4) + q][16*nt + (lane&15)]
+//   bias_j[Op]; everything outside [I,O) is 0.  The bias block is contiguous so a workgroup stages it
+//   into LDS with one coalesced copy.
 // ------------------------------------------------------------------------------------------------
 int64_t packed_floats(const GnfMlp* m) {
     int64_t tot = 0;
@@ -49,7 +54,8 @@ int64_t packed_floats(const GnfMlp* m) {
 
 __global__ __launch_bounds__(256) void k_pack_layer(const float* __restrict__ W,
                                                     const float* __restrict__ b, int I, int O, int Ip,
-                                                    int Op, float* __restrict__ out) {
+                                                    int Op, float* __restrict__ wout,
+                                                    float* __restrict__ bout) {
     const int64_t nw = (int64_t)Ip * Op;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < nw) {
@@ -60,22 +66,29 @@ __global__ __launch_bounds__(256) void k_pack_layer(const float* __restrict__ W,
         const int nt = (int)(blk / kgs), kg = (int)(blk % kgs);
         const int k = 16 * kg + 4 * (lane >> 4) + q;
         const int c = 16 * nt + (lane & 15);
-        out[i] = (k < I && c < O) ? W[(int64_t)k * O + c] : 0.f;
+        wout[i] = (k < I && c < O) ? W[(int64_t)k * O + c] : 0.f;
     } else if (i < nw + Op) {
         const int c = (int)(i - nw);
-        out[i] = c < O ? b[c] : 0.f;
+        bout[c] = c < O ? b[c] : 0.f;
     }
 }
 
+static int64_t packed_weight_floats(const GnfMlp* m) {
+    int64_t tot = 0;
+    for (int j = 0; j < m->num_layers; ++j) tot += (int64_t)pad16(m->dims[j]) * pad16(m->dims[j + 1]);
+    return tot;
+}
+
 int launch_pack_mlp(const GnfMlp* m, float* packed, hipStream_t st) {
-    int64_t off = 0;
+    int64_t woff = 0, boff = packed_weight_floats(m);
     for (int j = 0; j < m->num_layers; ++j) {
         const int I = m->dims[j], O = m->dims[j + 1], Ip = pad16(I), Op = pad16(O);
         const int64_t tot = (int64_t)Ip * Op + Op;
         hipLaunchKernelGGL(k_pack_layer, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m->W[j],
-                           m->b[j], I, O, Ip, Op, packed + off);
+                           m->b[j], I, O, Ip, Op, packed + woff, packed + boff);
         GNF_LAUNCH_CHECK("k_pack_layer");
-        off += tot;
+        woff += (int64_t)Ip * Op;
+        boff += Op;
     }
     return GNF_OK;
 }
@@ -87,97 +100,252 @@ struct FusedArgs {
     const float* x_cond;
     float* x_upd;
     double* partials;
+    float* st_out[2];                    // NETS = 1: global [N, H] scratch for s (0) and t (1)
     const float* wp[2][GNF_MAX_LAYERS];  // [net][layer] packed weights
-    const float* bp[2][GNF_MAX_LAYERS];  // [net][layer] padded bias
+    const float* bias[2];                // [net] contiguous padded bias block (bias_tot floats)
     int32_t ipg[GNF_MAX_LAYERS];         // padded input width / 16 of layer j
     int32_t ont[GNF_MAX_LAYERS];         // padded output width / 16 of layer j
+    int32_t boff[GNF_MAX_LAYERS];        // offset of layer j's bias in the LDS bias block
     int64_t ld;
     int32_t n_nodes;
+    int32_t n_tiles;
     int32_t H;
-    int32_t in0;      // true layer-0 input width (H or 2H)
+    int32_t in0;       // true layer-0 input width (H or 2H)
     int32_t K;
-    int32_t LS;       // LDS row stride (floats)
+    int32_t LS;        // LDS row stride (floats)
+    int32_t bias_tot;  // floats of bias per net in LDS
     int32_t mean, concat, act, inverse;
     float eps, alpha;
 };
 
+#ifndef GNF_PF
+#define GNF_PF 1  // k-groups of weights in flight ahead of the one being multiplied
+#endif
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// B fragments come through a buffer descriptor: base = this (net, layer)'s packed weights (SGPRs),
+// soffset = wave-uniform byte offset of the 1 KiB fragment block, voffset = lane * 16.  No per-load
+// 64-bit VALU address arithmetic and a single constant address VGPR.
+#ifdef GNF_ABL_NOLOAD  // ablation: B operand from registers, no weight traffic
+#define GNF_LOAD_B(RSRC, VOFF, SOFF) (f32x4{1.f, 2.f, 3.f, 4.f} * (float)(SOFF))
+#else
+#define GNF_LOAD_B(RSRC, VOFF, SOFF) \
+    __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RSRC, VOFF, SOFF, 0))
+#endif
+
+// A wave's unit of work: NV (<= 4) column tiles {nt0, nt0+ts, ...} of one layer.  All wave-uniform.
+struct WChunk {
+    const float* wbase;  // packed weights of the layer
+    unsigned wbytes;
+    int ipg;  // k-groups (stages) of the layer
+    int nt0;  // first column tile
+    int nv;   // tiles in this chunk (1..4)
+};
+
+static constexpr int kPF = GNF_PF;
+
+// Issue the loads of the first kPF stages of chunk c into b_pre (4 tile slots; slots >= c.nv repeat the
+// last valid tile).  Called one round BEFORE the previous chunk ends - and before the prologue for
+// the first chunk - so that a layer never starts by waiting a full L2 round trip for its weights.
+__device__ __forceinline__ void prefetch_chunk(const WChunk& c, int ts, int voff, f32x4 (&b_pre)[kPF][4]) {
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.wbase), 0, (int)c.wbytes, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < kPF; ++u) {
+        const int kn = u < c.ipg ? u : c.ipg - 1;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int tb = b < c.nv ? b : c.nv - 1;
+            b_pre[u][b] = GNF_LOAD_B(rsrc, voff, ((c.nt0 + ts * tb) * c.ipg + kn) * 1024);
+        }
+    }
+}
+
 template <int MT, int NV>
-__device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int LS,
-                                          const f32x4* __restrict__ wp, const float* __restrict__ bp,
-                                          int ipg, int nt0, float* __restrict__ out_lds, bool last,
-                                          int act, float alpha, int lane) {
+__device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int LS, const WChunk& c,
+                                          const WChunk& nx, int ts, const float* __restrict__ bias_lds,
+                                          float* __restrict__ out_lds, float slope, int lane,
+                                          f32x4 (&b_pre)[kPF][4]) {
+    constexpr int PF = kPF;
+    constexpr int R = PF + 1;  // register ring: PF stages in flight + the one being consumed
     const int lrow = lane & 15, lgrp = lane >> 4;
+    const int ipg = c.ipg, nt0 = c.nt0;
     f32x4 acc[MT][NV];
 #pragma unroll
     for (int b = 0; b < NV; ++b) {
-        const float bias = bp[16 * (nt0 + 4 * b) + lrow];
+        const float bias = bias_lds[16 * (nt0 + ts * b) + lrow];
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m][b] = f32x4{bias, bias, bias, bias};
     }
-    const f32x4* wtile[NV];
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.wbase), 0, (int)c.wbytes, 0x00020000);
+    const int voff = lane * 16;
+    int wtile[NV];  // byte offset of stage 0 of each tile's fragment stream (1 KiB per stage)
 #pragma unroll
-    for (int b = 0; b < NV; ++b) wtile[b] = wp + ((int64_t)(nt0 + 4 * b) * ipg) * 64 + lane;
+    for (int b = 0; b < NV; ++b) wtile[b] = (nt0 + ts * b) * ipg * 1024;
     const float* arow[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) arow[m] = in_lds + (16 * m + lrow) * LS + 4 * lgrp;
 
-    f32x4 a_cur[MT], b_cur[NV];
+    f32x4 a_ring[R][MT], b_ring[R][NV];
+    // stage k always lives in ring slot k % R; the B side of the first PF stages was prefetched
 #pragma unroll
-    for (int m = 0; m < MT; ++m) a_cur[m] = *reinterpret_cast<const f32x4*>(arow[m]);
+    for (int u = 0; u < PF; ++u) {
+        const int kn = u < ipg ? u : ipg - 1;
 #pragma unroll
-    for (int b = 0; b < NV; ++b) b_cur[b] = wtile[b][0];
-
-    for (int kg = 0; kg < ipg; ++kg) {
-        f32x4 a_nxt[MT], b_nxt[NV];
-        const int kn = (kg + 1 < ipg) ? kg + 1 : kg;  // last iteration re-reads (harmless)
+        for (int m = 0; m < MT; ++m) a_ring[u][m] = *reinterpret_cast<const f32x4*>(arow[m] + 16 * kn);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a_nxt[m] = *reinterpret_cast<const f32x4*>(arow[m] + 16 * kn);
-#pragma unroll
-        for (int b = 0; b < NV; ++b) b_nxt[b] = wtile[b][(int64_t)kn * 64];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int b = 0; b < NV; ++b)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[m][q], b_cur[b][q],
-                                                                      acc[m][b], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
-#pragma unroll
-        for (int b = 0; b < NV; ++b) b_cur[b] = b_nxt[b];
+        for (int b = 0; b < NV; ++b) b_ring[u][b] = b_pre[u][b];
     }
-    // accumulator layout: col = lane&15, row = 4*(lane>>4) + r
+#ifndef GNF_ABL_NOMFMA
+#define GNF_MFMA_STAGE(U)                                                                          \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int b = 0; b < NV; ++b)   \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) acc[m][b] =                                 \
+            __builtin_amdgcn_mfma_f32_16x16x4f32(a_ring[U][m][q], b_ring[U][b][q], acc[m][b], 0, 0, 0);
+#else  // ablation: keep every load alive, issue no MFMA
+#define GNF_MFMA_STAGE(U)                                                                          \
+    _Pragma("unroll") for (int b = 0; b < NV; ++b) asm volatile("" ::"v"(b_ring[U][b]));           \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(a_ring[U][m]));
+#endif
+    // One round = R stages: for each, issue the loads of stage kg+PF, THEN the MFMAs of stage kg.  The
+    // sched_barriers pin that order (left alone, hipcc sinks every load of a round to its end and
+    // waits vmcnt(0) at the top of the next one), and there is NO branch inside a round (a branch
+    // makes hipcc drain vmcnt(0) as well).
+#define GNF_ROUND(KG0)                                                                             \
+    _Pragma("unroll") for (int u = 0; u < R; ++u) {                                                \
+        const int kg = (KG0) + u;                                                                  \
+        const int kn = (kg + PF < ipg) ? kg + PF : ipg - 1; /* tail re-reads the last stage */     \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) a_ring[(u + PF) % R][m] =                   \
+            *reinterpret_cast<const f32x4*>(arow[m] + 16 * kn);                                    \
+        _Pragma("unroll") for (int b = 0; b < NV; ++b) b_ring[(u + PF) % R][b] =                   \
+            GNF_LOAD_B(rsrc, voff, wtile[b] + kn * 1024);                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        GNF_MFMA_STAGE(u)                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    }
+    int kg0 = 0;
+    if (ipg >= R) {
+        for (; kg0 + 2 * R <= ipg; kg0 += R) {  // every full round but the last
+            GNF_ROUND(kg0)
+        }
+        // the next chunk's first stages go out one round early: they land while the last round's
+        // MFMAs, the output write-back and the layer barrier are in progress
+        prefetch_chunk(nx, ts, voff, b_pre);
+        __builtin_amdgcn_sched_barrier(0);
+        GNF_ROUND(kg0)
+        kg0 += R;
+    } else {
+        prefetch_chunk(nx, ts, voff, b_pre);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // tail: the last ipg % R stages are already in flight in slots 0 .. rem-1
+    const int rem = ipg - kg0;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        if (u < rem) {  // wave-uniform
+            GNF_MFMA_STAGE(u)
+        }
+    }
+#undef GNF_ROUND
+#undef GNF_MFMA_STAGE
+    // accumulator layout: col = lane&15, row = 4*(lane>>4) + r.  slope: 1 on the last (linear) layer,
+    // alpha (leaky) or 0 (relu) otherwise: max(v, slope*v) is branch-free for all three.
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int b = 0; b < NV; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = acc[m][b][r];
-                if (!last) v = (act == GNF_ACT_RELU) ? fmaxf(v, 0.f) : fmaxf(v, alpha * v);
-                out_lds[(16 * m + 4 * lgrp + r) * LS + 16 * (nt0 + 4 * b) + lrow] = v;
+                const float v = acc[m][b][r];
+                out_lds[(16 * m + 4 * lgrp + r) * LS + 16 * (nt0 + ts * b) + lrow] = fmaxf(v, slope * v);
             }
 }
 
-template <int MT>
+#ifdef GNF_TRACE  // developer build only: per-wave cycle stamps of workgroup 0
+__device__ unsigned long long g_trace[8][16];
+#define GNF_STAMP(slot)                                                                  \
+    do {                                                                                 \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)                                  \
+            g_trace[threadIdx.x >> 6][slot] = __builtin_amdgcn_s_memtime();              \
+    } while (0)
+#else
+#define GNF_STAMP(slot)
+#endif
+
+template <int MT, int NETS>
 __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TM = 16 * MT;
+    constexpr int WPN = 8 / NETS;  // waves per net
     const int LS = a.LS;
-    // [net][pingpong][TM][LS]
+    // [net][pingpong][TM][LS] | bias [NETS][bias_tot] | reduction scratch
     auto buf = [&](int net_, int pp_) -> float* { return smem + (2 * net_ + pp_) * TM * LS; };
-    double* red = reinterpret_cast<double*>(smem + 4 * TM * LS);  // 8 doubles
+    float* bias_lds = smem + 2 * NETS * TM * LS;
+    double* red = reinterpret_cast<double*>(bias_lds + NETS * a.bias_tot + ((NETS * a.bias_tot) & 1));
 
-    // XCD-aware, bijective blockIdx -> tile map (block b is dispatched to XCD b % 8)
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
-    const int tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    // blockIdx -> (tile, net).  Block b is dispatched to XCD b % 8.
+    //  NETS = 2: XCD-aware bijective remap, consecutive tiles (neighbouring nodes) share an XCD.
+    //  NETS = 1: XCDs 0-3 run the s-net, XCDs 4-7 the t-net (each XCD L2 caches one net's weights).
+    int tile, net0;
+    {
+        const int bid = blockIdx.x;
+        if (NETS == 2) {
+            const int nwg = gridDim.x, xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
+            tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+            net0 = 0;
+        } else {
+            const int xcd = bid & 7;
+            net0 = xcd >> 2;
+            tile = (bid >> 3) * 4 + (xcd & 3);
+            if (tile >= a.n_tiles) return;  // grid is padded to a multiple of 8
+        }
+    }
     const int row0 = tile * TM;
     const int tid = threadIdx.x;
     const int H = a.H;
 
-    // ---- A: aggregate + combine into both nets' layer-0 input --------------------------------
+    // wave-uniform ids go through readfirstlane so that hipcc keeps them (and everything derived:
+    // net, tile offsets, buffer descriptors, branches) in SGPRs instead of waterfalling on VGPRs
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int nl = wave / WPN, wl = wave % WPN;  // local net of this wave, wave index inside the net
+    const int net = net0 + nl;
+    const int voff = lane * 16;
+
+    // this wave's chunk sequence: for each layer j, column tiles wl, wl+WPN, ... four at a time
+    auto chunk_at = [&](int j, int nt0) -> WChunk {
+        WChunk c;
+        c.wbase = a.wp[net][j];
+        c.wbytes = (unsigned)a.ipg[j] * (unsigned)a.ont[j] * 1024u;
+        c.ipg = a.ipg[j];
+        c.nt0 = nt0;
+        const int nv = (a.ont[j] - nt0 + WPN - 1) / WPN;
+        c.nv = nv > 4 ? 4 : nv;
+        return c;
+    };
+    auto advance = [&](int& j, int& nt0) {  // -> next chunk of this wave, j == K when there is none
+        nt0 += 4 * WPN;
+        while (j < a.K && nt0 >= a.ont[j]) {
+            ++j;
+            nt0 = wl;
+        }
+    };
+    int cj = 0, cnt0 = wl;  // cursor on the next chunk to run
+    while (cj < a.K && cnt0 >= a.ont[cj]) ++cj;
+
+    GNF_STAMP(0);
+    // ---- weights of the first chunk start streaming before anything else -----------------------
+    f32x4 b_pre[kPF][4];
+    {
+        const WChunk first = chunk_at(cj < a.K ? cj : 0, cj < a.K ? cnt0 : 0);
+        prefetch_chunk(first, WPN, voff, b_pre);
+    }
+    // ---- biases of every layer -> LDS: one coalesced copy per net -----------------------------
+    for (int i = tid; i < NETS * a.bias_tot; i += kFusedThreads) {
+        const int n_ = i / a.bias_tot;
+        bias_lds[i] = a.bias[net0 + n_][i - n_ * a.bias_tot];
+    }
+    // ---- A: aggregate + combine into the layer-0 input of each net ----------------------------
     {
         const int in0p = a.ipg[0] * 16;
         for (int idx = tid; idx < TM * in0p; idx += kFusedThreads) {
@@ -190,8 +358,32 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
                     v = a.x_cond[(int64_t)r * a.ld + f];
                 } else {
                     const int beg = a.rowptr[r], end = a.rowptr[r + 1];
+                    const float* xf = a.x_cond + f;
                     float s = 0.f;
-                    for (int e = beg; e < end; ++e) s += a.x_cond[(int64_t)a.col[e] * a.ld + f];
+#ifndef GNF_ABL_NOAGG
+                    int e = beg;
+                    for (; e + 8 <= end; e += 8) {  // 8 independent gathers in flight, summed in edge order
+                        int ci[8];
+                        float vv[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) ci[q] = a.col[e + q];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) vv[q] = xf[(int64_t)ci[q] * a.ld];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) s += vv[q];
+                    }
+                    if (e < end) {  // up to 7 left: still issued together (indices clamped, adds predicated)
+                        int ci[7];
+                        float vv[7];
+#pragma unroll
+                        for (int q = 0; q < 7; ++q) ci[q] = a.col[e + q < end ? e + q : end - 1];
+#pragma unroll
+                        for (int q = 0; q < 7; ++q) vv[q] = xf[(int64_t)ci[q] * a.ld];
+#pragma unroll
+                        for (int q = 0; q < 7; ++q)
+                            if (e + q < end) s += vv[q];
+                    }
+#endif
                     if (a.mean) {
                         const int cnt = end - beg;
                         s = s / (float)(cnt > 1 ? cnt : 1);
@@ -200,61 +392,85 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
                 }
             }
             buf(0, 0)[rl * LS + c] = v;
-            buf(1, 0)[rl * LS + c] = v;
+            if (NETS == 2) buf(1, 0)[rl * LS + c] = v;
         }
     }
+    GNF_STAMP(1);
     __syncthreads();
+    GNF_STAMP(2);
 
-    // ---- B: K layers, s-net on waves 0-3, t-net on waves 4-7 ----------------------------------
-    const int wave = tid >> 6, lane = tid & 63;
-    const int net = wave >> 2, wl = wave & 3;
+    // ---- B: K layers ------------------------------------------------------------------------------
     int pp = 0;
+#ifdef GNF_ABL_NOLAYERS
+    for (int j = 0; j < 0; ++j) {
+#else
     for (int j = 0; j < a.K; ++j) {
-        const float* in_lds = buf(net, pp);
-        float* out_lds = buf(net, pp ^ 1);
-        const f32x4* wp = reinterpret_cast<const f32x4*>(a.wp[net][j]);
-        const float* bp = a.bp[net][j];
-        const int ipg = a.ipg[j], ont = a.ont[j];
-        const bool last = (j == a.K - 1);
-        for (int nt0 = wl; nt0 < ont; nt0 += 16) {
-            const int nv = (ont - nt0 + 3) >> 2;  // tiles nt0, nt0+4, ... still < ont
-            if (nv >= 4)
-                mlp_chunk<MT, 4>(in_lds, LS, wp, bp, ipg, nt0, out_lds, last, a.act, a.alpha, lane);
-            else if (nv == 3)
-                mlp_chunk<MT, 3>(in_lds, LS, wp, bp, ipg, nt0, out_lds, last, a.act, a.alpha, lane);
-            else if (nv == 2)
-                mlp_chunk<MT, 2>(in_lds, LS, wp, bp, ipg, nt0, out_lds, last, a.act, a.alpha, lane);
+#endif
+        const float* in_lds = buf(nl, pp);
+        float* out_lds = buf(nl, pp ^ 1);
+        const float* bl = bias_lds + nl * a.bias_tot + a.boff[j];
+        const float slope = (j == a.K - 1) ? 1.f : (a.act == GNF_ACT_RELU ? 0.f : a.alpha);
+        while (cj == j) {  // wave-uniform
+            const WChunk c = chunk_at(cj, cnt0);
+            advance(cj, cnt0);
+            const WChunk nx = cj < a.K ? chunk_at(cj, cnt0) : c;  // no next chunk: harmless re-load
+            if (c.nv >= 4)
+                mlp_chunk<MT, 4>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre);
+            else if (c.nv == 3)
+                mlp_chunk<MT, 3>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre);
+            else if (c.nv == 2)
+                mlp_chunk<MT, 2>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre);
             else
-                mlp_chunk<MT, 1>(in_lds, LS, wp, bp, ipg, nt0, out_lds, last, a.act, a.alpha, lane);
+                mlp_chunk<MT, 1>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre);
         }
         pp ^= 1;
+        GNF_STAMP(3 + 2 * j);
         __syncthreads();
+        GNF_STAMP(4 + 2 * j);
     }
 
-    // ---- C: coupling update + block-reduced sum(s) ---------------------------------------------
-    const float* s_lds = buf(0, pp);
-    const float* t_lds = buf(1, pp);
-    double local = 0.0;
-    for (int idx = tid; idx < TM * H; idx += kFusedThreads) {
-        const int rl = idx / H, f = idx - rl * H;
-        const int r = row0 + rl;
-        if (r < a.n_nodes) {
-            const float sv = s_lds[rl * LS + f], tv = t_lds[rl * LS + f];
-            float* px = a.x_upd + (int64_t)r * a.ld + f;
-            const float xv = *px;
-            *px = a.inverse ? (xv - tv) * expf(-sv) : xv * expf(sv) + tv;
-            local += (double)sv;
+    if (NETS == 1) {
+        // ---- hand the s (or t) tile to the coupling kernel through the global scratch ------------
+        const float* o_lds = buf(0, pp);
+        float* dst = a.st_out[net0];
+        for (int idx = tid; idx < TM * H; idx += kFusedThreads) {
+            const int rl = idx / H, f = idx - rl * H;
+            const int r = row0 + rl;
+            if (r < a.n_nodes) dst[(int64_t)r * H + f] = o_lds[rl * LS + f];
+        }
+    } else {
+        // ---- C: coupling update + block-reduced sum(s) -----------------------------------------
+        const float* s_lds = buf(0, pp);
+        const float* t_lds = buf(1, pp);
+        double local = 0.0;
+        for (int idx = tid; idx < TM * H; idx += kFusedThreads) {
+            const int rl = idx / H, f = idx - rl * H;
+            const int r = row0 + rl;
+            if (r < a.n_nodes) {
+                const float sv = s_lds[rl * LS + f], tv = t_lds[rl * LS + f];
+                float* px = a.x_upd + (int64_t)r * a.ld + f;
+                const float xv = *px;
+                *px = a.inverse ? (xv - tv) * expf(-sv) : xv * expf(sv) + tv;
+                local += (double)sv;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+        if (lane == 0) red[wave] = local;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int w = 0; w < kFusedThreads / 64; ++w) tot += red[w];
+            a.partials[tile] = tot;
         }
     }
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if (lane == 0) red[wave] = local;
-    __syncthreads();
-    if (tid == 0) {
-        double tot = 0.0;
-        for (int w = 0; w < kFusedThreads / 64; ++w) tot += red[w];
-        a.partials[tile] = tot;
-    }
+    GNF_STAMP(15);
 }
+
+#ifdef GNF_TRACE
+extern "C" int gnf_debug_read_trace(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 8 * 16);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 static int max_padded_width(const GnfMlp* m) {
@@ -263,9 +479,15 @@ static int max_padded_width(const GnfMlp* m) {
     return w;
 }
 
-static size_t fused_lds_bytes(const GnfMlp* m, int MT) {
+static int bias_total(const GnfMlp* m) {
+    int t = 0;
+    for (int j = 0; j < m->num_layers; ++j) t += pad16(m->dims[j + 1]);
+    return t;
+}
+
+static size_t fused_lds_bytes(const GnfMlp* m, int MT, int NETS) {
     const int LS = max_padded_width(m) + 4;
-    return (size_t)4 * 16 * MT * LS * sizeof(float) + 8 * sizeof(double);
+    return (size_t)(2 * NETS * 16 * MT * LS + NETS * bias_total(m) + 2) * sizeof(float) + 8 * sizeof(double);
 }
 
 bool fused_supported(const HalfStep& hs) {
@@ -274,30 +496,80 @@ bool fused_supported(const HalfStep& hs) {
     if (s->num_layers != t->num_layers) return false;
     for (int j = 0; j <= s->num_layers; ++j)
         if (s->dims[j] != t->dims[j]) return false;
-    return fused_lds_bytes(s, 1) <= (size_t)kLdsLimit;
+    return fused_lds_bytes(s, 1, 1) <= (size_t)kLdsLimit;
 }
 
-int launch_half_fused(const HalfStep& hs, hipStream_t st) {
+// (MT, NETS) choice, from measurements on MI355X at L=256, K=5 (profiles/):
+//   (1,2) 16 nodes x both nets : 37.5 us per launch, any tile count <= 256 (one tile per CU)
+//   (2,2) 32 nodes x both nets : 64 us per launch = 32 us per 16 nodes -> wins once there is more than
+//                                one 16-node tile per CU
+//   (*,1) one net per workgroup + k_coupling: never faster at these widths, but its LDS footprint is
+//         half, which keeps layers up to 1024 wide on the fused path.
+// GNF_FORCE_SHAPE=<MT><NETS> (e.g. 21) is a developer override for A/B runs.
+static void choose_shape(const HalfStep& hs, int* mt, int* nets) {
+    const GnfMlp* s = hs.s_net;
+    const int64_t tiles16 = (hs.n_nodes + 15) / 16;
+    auto fits = [&](int m, int n) { return fused_lds_bytes(s, m, n) <= (size_t)kLdsLimit; };
+    int m = 1, n = 1;
+    if (tiles16 > 256 && fits(2, 2)) {
+        m = 2, n = 2;
+    } else if (fits(1, 2)) {
+        m = 1, n = 2;
+    } else if (tiles16 > 256 && fits(2, 1)) {
+        m = 2, n = 1;
+    }
+    static const char* force = getenv("GNF_FORCE_SHAPE");
+    if (force && force[0] && force[1]) {
+        const int fm = force[0] - '0', fn = force[1] - '0';
+        if ((fm == 1 || fm == 2) && (fn == 1 || fn == 2) && fits(fm, fn)) m = fm, n = fn;
+    }
+    *mt = m;
+    *nets = n;
+}
+
+template <int MT, int NETS>
+static int launch_shape(const FusedArgs& a, unsigned grid, size_t lds, hipStream_t st) {
+    static bool attr_set = false;  // one process per GPU: a single device per process
+    if (!attr_set) {
+        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_fused<MT, NETS>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_half_fused<MT, NETS>), dim3(grid), dim3(kFusedThreads), lds, st, a);
+    GNF_LAUNCH_CHECK("k_half_fused");
+    return GNF_OK;
+}
+
+int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
     const GnfMlp *s = hs.s_net, *t = hs.t_net;
     *hs.n_partials = 0;
     if (hs.n_nodes == 0) return GNF_OK;
+    int MT, NETS;
+    choose_shape(hs, &MT, &NETS);
     FusedArgs a;
     a.rowptr = hs.rowptr;
     a.col = hs.col;
     a.x_cond = hs.x_cond;
     a.x_upd = hs.x_upd;
     a.partials = hs.partials;
+    // NETS = 1 scratch: s [N,H] | t [N,H] at the head of the float scratch
+    a.st_out[0] = scratch;
+    a.st_out[1] = scratch + hs.n_nodes * hs.H;
     int64_t off = 0;
+    int boff = 0;
     for (int j = 0; j < s->num_layers; ++j) {
         const int ip = pad16(s->dims[j]), op = pad16(s->dims[j + 1]);
         a.wp[0][j] = s->packed + off;
         a.wp[1][j] = t->packed + off;
-        a.bp[0][j] = s->packed + off + (int64_t)ip * op;
-        a.bp[1][j] = t->packed + off + (int64_t)ip * op;
         a.ipg[j] = ip / 16;
         a.ont[j] = op / 16;
-        off += (int64_t)ip * op + op;
+        a.boff[j] = boff;
+        boff += op;
+        off += (int64_t)ip * op;
     }
+    a.bias[0] = s->packed + off;  // contiguous bias block after the weights
+    a.bias[1] = t->packed + off;
+    a.bias_tot = boff;
     a.ld = hs.ld;
     a.n_nodes = (int32_t)hs.n_nodes;
     a.H = hs.H;
@@ -311,33 +583,20 @@ int launch_half_fused(const HalfStep& hs, hipStream_t st) {
     a.eps = hs.gnn.epsilon;
     a.alpha = hs.gnn.alpha;
 
-    // 16-node tiles keep every CU busy on small batches; 32-node tiles halve the weight traffic
-    // per node once there are enough tiles to fill 256 CUs twice over.
-    const int64_t tiles16 = (hs.n_nodes + 15) / 16;
-    const bool big = tiles16 > 1024 && fused_lds_bytes(s, 2) <= (size_t)kLdsLimit;
-    const int MT = big ? 2 : 1;
     const int64_t tiles = (hs.n_nodes + 16 * MT - 1) / (16 * MT);
-    const size_t lds = fused_lds_bytes(s, MT);
-    if (MT == 2) {
-        static bool attr2 = false;
-        if (!attr2) {
-            GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_fused<2>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
-            attr2 = true;
-        }
-        hipLaunchKernelGGL(k_half_fused<2>, dim3((unsigned)tiles), dim3(kFusedThreads), lds, st, a);
-    } else {
-        static bool attr1 = false;
-        if (!attr1) {
-            GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_fused<1>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
-            attr1 = true;
-        }
-        hipLaunchKernelGGL(k_half_fused<1>, dim3((unsigned)tiles), dim3(kFusedThreads), lds, st, a);
+    a.n_tiles = (int32_t)tiles;
+    const size_t lds = fused_lds_bytes(s, MT, NETS);
+    int rc;
+    if (NETS == 2) {
+        rc = MT == 2 ? launch_shape<2, 2>(a, (unsigned)tiles, lds, st) : launch_shape<1, 2>(a, (unsigned)tiles, lds, st);
+        if (rc) return rc;
+        *hs.n_partials = (int32_t)tiles;
+        return GNF_OK;
     }
-    GNF_LAUNCH_CHECK("k_half_fused");
-    *hs.n_partials = (int32_t)tiles;
-    return GNF_OK;
+    const unsigned grid = (unsigned)(8 * ((tiles + 3) / 4));  // 4 tile slots x 2 nets per group of 8 blocks
+    rc = MT == 2 ? launch_shape<2, 1>(a, grid, lds, st) : launch_shape<1, 1>(a, grid, lds, st);
+    if (rc) return rc;
+    return launch_coupling(a.st_out[0], a.st_out[1], hs, st);
 }
 
 }  // namespace gnf

@@ -287,6 +287,12 @@ int launch_half_layered(const HalfStep& hs, float* scratch, hipStream_t st) {
     if (rc) return rc;
     rc = run_mlp(hs.t_net, h0, in0, bufA, bufB, lmax, tbuf, H, n, hs.gnn, st);
     if (rc) return rc;
+    return launch_coupling(sbuf, tbuf, hs, st);
+}
+
+int launch_coupling(const float* sbuf, const float* tbuf, const HalfStep& hs, hipStream_t st) {
+    const int64_t n = hs.n_nodes;
+    const int H = hs.H;
     int64_t blocks = (n * H + 256 * 4 - 1) / (256 * 4);
     const int64_t cap = coupling_blocks_max(n);
     if (blocks > cap) blocks = cap;
