@@ -34,6 +34,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int kFusedThreads = 512;
 static constexpr int kLdsLimit = 160 * 1024;
+static constexpr int kRowptrPad = 40;   // LDS ints for rowptr[row0 .. row0+TM] (TM <= 32)
+static constexpr int kColCap = 2048;    // LDS ints for the tile's col segment (longer segments stay in global memory)
 
 static inline int pad16(int v) { return (v + 15) & ~15; }
 
@@ -119,7 +121,7 @@ struct FusedArgs {
 };
 
 #ifndef GNF_PF
-#define GNF_PF 1  // k-groups of weights in flight ahead of the one being multiplied
+#define GNF_PF 2  // k-groups of weights in flight ahead of the one being multiplied
 #endif
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -134,6 +136,25 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RSRC, VOFF, SOFF, 0))
 #endif
 
+#ifdef GNF_TRACE  // developer build only: per-wave cycle stamps of workgroup 0
+__device__ unsigned long long g_trace[8][16];
+__device__ unsigned long long g_stage[8][40];  // per-stage stamps of the traced layer
+__device__ int g_trace_layer = 1;
+#define GNF_STAMP(slot)                                                                  \
+    do {                                                                                 \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)                                  \
+            g_trace[threadIdx.x >> 6][slot] = __builtin_amdgcn_s_memtime();              \
+    } while (0)
+#define GNF_STAGE_STAMP(idx)                                                             \
+    do {                                                                                 \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && trace_on && (idx) < 40)        \
+            g_stage[threadIdx.x >> 6][idx] = __builtin_amdgcn_s_memtime();               \
+    } while (0)
+#else
+#define GNF_STAMP(slot)
+#define GNF_STAGE_STAMP(idx)
+#endif
+
 // A wave's unit of work: NV (<= 4) column tiles {nt0, nt0+ts, ...} of one layer.  All wave-uniform.
 struct WChunk {
     const float* wbase;  // packed weights of the layer
@@ -141,6 +162,9 @@ struct WChunk {
     int ipg;  // k-groups (stages) of the layer
     int nt0;  // first column tile
     int nv;   // tiles in this chunk (1..4)
+    int layer;
+    int boff;  // offset of the layer's bias inside the LDS bias block
+    int ont;   // column tiles of the layer
 };
 
 static constexpr int kPF = GNF_PF;
@@ -171,6 +195,10 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
     constexpr int R = PF + 1;  // register ring: PF stages in flight + the one being consumed
     const int lrow = lane & 15, lgrp = lane >> 4;
     const int ipg = c.ipg, nt0 = c.nt0;
+#ifdef GNF_TRACE
+    const bool trace_on = c.layer == g_trace_layer;
+#endif
+    GNF_STAGE_STAMP(0);
     f32x4 acc[MT][NV];
 #pragma unroll
     for (int b = 0; b < NV; ++b) {
@@ -208,10 +236,27 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
     _Pragma("unroll") for (int b = 0; b < NV; ++b) asm volatile("" ::"v"(b_ring[U][b]));           \
     _Pragma("unroll") for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(a_ring[U][m]));
 #endif
-    // One round = R stages: for each, issue the loads of stage kg+PF, THEN the MFMAs of stage kg.  The
-    // sched_barriers pin that order (left alone, hipcc sinks every load of a round to its end and
-    // waits vmcnt(0) at the top of the next one), and there is NO branch inside a round (a branch
-    // makes hipcc drain vmcnt(0) as well).
+    // One round = R stages; a stage = the 4*NV*MT MFMAs of k-group kg with the loads of k-group kg+PF
+    // (NV buffer loads, MT LDS reads) issued in their shadow: an MFMA occupies the matrix pipe for 32
+    // cycles but the wave's issue slot for ~4, so a load placed after an MFMA costs nothing, while
+    // loads bunched in front of the MFMAs leave the pipe idle whenever the partner wave on the SIMD
+    // has nothing to issue (the arbiter is oldest-first: the two waves run mostly one after the
+    // other, not interleaved).  sched_group_barrier spells the interleave, sched_barrier(0) closes
+    // the stage (left alone, hipcc sinks every load of a round to its end and waits vmcnt(0) at the
+    // top of the next one); there is NO branch inside a round (it would also force vmcnt(0)).
+#ifdef GNF_NO_INTERLEAVE
+#define GNF_INTERLEAVE()
+#else
+#define GNF_INTERLEAVE()                                                                           \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  /* 1 MFMA */                               \
+    __builtin_amdgcn_sched_group_barrier(0x100, MT, 0); /* the LDS reads of the next A fragments */ \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT - 1, 0);                                    \
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  /* 1 weight load */                        \
+    _Pragma("unroll") for (int b_ = 1; b_ < NV; ++b_) {                                            \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                         \
+    }
+#endif
 #define GNF_ROUND(KG0)                                                                             \
     _Pragma("unroll") for (int u = 0; u < R; ++u) {                                                \
         const int kg = (KG0) + u;                                                                  \
@@ -220,8 +265,9 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
             *reinterpret_cast<const f32x4*>(arow[m] + 16 * kn);                                    \
         _Pragma("unroll") for (int b = 0; b < NV; ++b) b_ring[(u + PF) % R][b] =                   \
             GNF_LOAD_B(rsrc, voff, wtile[b] + kn * 1024);                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
         GNF_MFMA_STAGE(u)                                                                          \
+        GNF_INTERLEAVE()                                                                           \
+        GNF_STAGE_STAMP(2 + kg);                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
     int kg0 = 0;
@@ -248,7 +294,9 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
         }
     }
 #undef GNF_ROUND
+#undef GNF_INTERLEAVE
 #undef GNF_MFMA_STAGE
+    GNF_STAGE_STAMP(38);
     // accumulator layout: col = lane&15, row = 4*(lane>>4) + r.  slope: 1 on the last (linear) layer,
     // alpha (leaky) or 0 (relu) otherwise: max(v, slope*v) is branch-free for all three.
 #pragma unroll
@@ -262,16 +310,6 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
             }
 }
 
-#ifdef GNF_TRACE  // developer build only: per-wave cycle stamps of workgroup 0
-__device__ unsigned long long g_trace[8][16];
-#define GNF_STAMP(slot)                                                                  \
-    do {                                                                                 \
-        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)                                  \
-            g_trace[threadIdx.x >> 6][slot] = __builtin_amdgcn_s_memtime();              \
-    } while (0)
-#else
-#define GNF_STAMP(slot)
-#endif
 
 template <int MT, int NETS>
 __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a) {
@@ -312,33 +350,90 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
     const int net = net0 + nl;
     const int voff = lane * 16;
 
-    // this wave's chunk sequence: for each layer j, column tiles wl, wl+WPN, ... four at a time
-    auto chunk_at = [&](int j, int nt0) -> WChunk {
-        WChunk c;
-        c.wbase = a.wp[net][j];
-        c.wbytes = (unsigned)a.ipg[j] * (unsigned)a.ont[j] * 1024u;
-        c.ipg = a.ipg[j];
+    // Per-layer descriptors live in a small LDS table: indexing the by-value kernel arguments with a
+    // run-time layer index costs a dependent scalar-memory round trip (~1.3k cycles measured) at the
+    // start of EVERY layer; an LDS read is ~10x cheaper.  Row j: {ipg, ont, boff, -, wp[net0] lo/hi,
+    // wp[net0+1] lo/hi}.  Only the very first chunk (prefetched before the table exists) reads the
+    // kernel arguments directly.
+    int* tab = reinterpret_cast<int*>(red + 8);
+    auto fill_chunk = [&](WChunk& c, int j, int ipg_, int ont_, int boff_, const float* wb, int nt0) {
+        c.wbase = wb;
+        c.wbytes = (unsigned)ipg_ * (unsigned)ont_ * 1024u;
+        c.ipg = ipg_;
+        c.ont = ont_;
+        c.boff = boff_;
         c.nt0 = nt0;
-        const int nv = (a.ont[j] - nt0 + WPN - 1) / WPN;
+        const int nv = (ont_ - nt0 + WPN - 1) / WPN;
         c.nv = nv > 4 ? 4 : nv;
+        c.layer = j;
+    };
+    auto chunk_from_args = [&](int j, int nt0) -> WChunk {
+        WChunk c;
+        fill_chunk(c, j, a.ipg[j], a.ont[j], a.boff[j], a.wp[net][j], nt0);
         return c;
     };
-    auto advance = [&](int& j, int& nt0) {  // -> next chunk of this wave, j == K when there is none
-        nt0 += 4 * WPN;
-        while (j < a.K && nt0 >= a.ont[j]) {
-            ++j;
-            nt0 = wl;
-        }
+    auto chunk_from_tab = [&](int j, int nt0) -> WChunk {
+        const int* row = tab + 8 * j;
+        const int ipg_ = __builtin_amdgcn_readfirstlane(row[0]);
+        const int ont_ = __builtin_amdgcn_readfirstlane(row[1]);
+        const int boff_ = __builtin_amdgcn_readfirstlane(row[2]);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane(row[4 + 2 * nl]);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane(row[5 + 2 * nl]);
+        WChunk c;
+        fill_chunk(c, j, ipg_, ont_, boff_,
+                   reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo), nt0);
+        return c;
     };
-    int cj = 0, cnt0 = wl;  // cursor on the next chunk to run
-    while (cj < a.K && cnt0 >= a.ont[cj]) ++cj;
+    // the chunk after `c` in this wave's sequence (layer == K: none); layers whose column tiles do
+    // not reach this wave (e.g. a 32-wide last layer has 2 tiles for 4 waves) are skipped
+    auto next_chunk = [&](const WChunk& c) -> WChunk {
+        int j = c.layer, nt0 = c.nt0 + 4 * WPN;
+        if (nt0 < c.ont) {
+            WChunk n = c;
+            n.nt0 = nt0;
+            const int nv = (c.ont - nt0 + WPN - 1) / WPN;
+            n.nv = nv > 4 ? 4 : nv;
+            return n;
+        }
+        for (++j; j < a.K; ++j) {
+            const int ont_ = __builtin_amdgcn_readfirstlane(tab[8 * j + 1]);
+#ifdef GNF_ARGS_CHUNKS
+            if (wl < ont_) return chunk_from_args(j, wl);
+#else
+            if (wl < ont_) return chunk_from_tab(j, wl);
+#endif
+        }
+        WChunk n = c;
+        n.layer = a.K;
+        return n;
+    };
+    WChunk cur;
+    {
+        int j0 = 0;
+        while (j0 < a.K && wl >= a.ont[j0]) ++j0;
+        cur = chunk_from_args(j0 < a.K ? j0 : 0, j0 < a.K ? wl : 0);
+        if (j0 >= a.K) cur.layer = a.K;  // (cannot happen: the last layer has >= 1 tile; wave 0 runs it)
+    }
 
     GNF_STAMP(0);
     // ---- weights of the first chunk start streaming before anything else -----------------------
     f32x4 b_pre[kPF][4];
-    {
-        const WChunk first = chunk_at(cj < a.K ? cj : 0, cj < a.K ? cnt0 : 0);
-        prefetch_chunk(first, WPN, voff, b_pre);
+    prefetch_chunk(cur, WPN, voff, b_pre);
+    // ---- layer table -> LDS (uniform loop: scalar loads of the kernel arguments) ----------------
+    for (int j = 0; j < a.K; ++j) {
+        if (tid == 0) {
+            const unsigned long long p0 = reinterpret_cast<unsigned long long>(a.wp[net0][j]);
+            const unsigned long long p1 = reinterpret_cast<unsigned long long>(a.wp[NETS == 2 ? 1 : net0][j]);
+            int* row = tab + 8 * j;
+            row[0] = a.ipg[j];
+            row[1] = a.ont[j];
+            row[2] = a.boff[j];
+            row[3] = 0;
+            row[4] = (int)(unsigned)p0;
+            row[5] = (int)(unsigned)(p0 >> 32);
+            row[6] = (int)(unsigned)p1;
+            row[7] = (int)(unsigned)(p1 >> 32);
+        }
     }
     // ---- biases of every layer -> LDS: one coalesced copy per net -----------------------------
     for (int i = tid; i < NETS * a.bias_tot; i += kFusedThreads) {
@@ -346,8 +441,57 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
         bias_lds[i] = a.bias[net0 + n_][i - n_ * a.bias_tot];
     }
     // ---- A: aggregate + combine into the layer-0 input of each net ----------------------------
+    // The tile's CSR slice is staged in LDS first (rowptr[row0..row0+TM], then the contiguous col
+    // segment, both coalesced), so that the neighbour-row gathers are independent loads issued 8 at a
+    // time instead of a rowptr -> col -> x chain of dependent global round trips per thread.
+    int* s_rowptr = tab + GNF_MAX_LAYERS * 8;
+    int* s_col = s_rowptr + kRowptrPad;
+    if (tid <= TM) {
+        const int r = row0 + tid;
+        s_rowptr[tid] = a.rowptr[r < a.n_nodes ? r : a.n_nodes];
+    }
+    __syncthreads();
+    const int seg_beg = s_rowptr[0];
+    const int seg_len = s_rowptr[TM] - seg_beg;
+#ifdef GNF_NO_STAGE_CSR
+    const bool staged = false;
+#else
+    const bool staged = seg_len <= kColCap;  // workgroup-uniform
+#endif
+    if (staged)
+        for (int i = tid; i < seg_len; i += kFusedThreads) s_col[i] = a.col[seg_beg + i];
+    __syncthreads();
     {
         const int in0p = a.ipg[0] * 16;
+        // sum of x_cond[nbr, f] over the incoming edges [beg, end) of one node, in edge order
+        auto gather = [&](int beg, int end, const float* xf, auto colat) -> float {
+            float s = 0.f;
+#ifndef GNF_ABL_NOAGG
+            int e = beg;
+            for (; e + 8 <= end; e += 8) {  // 8 independent row reads in flight
+                int ci[8];
+                float vv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ci[q] = colat(e + q);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vv[q] = xf[(int64_t)ci[q] * a.ld];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s += vv[q];
+            }
+            if (e < end) {  // up to 7 left: still issued together (indices clamped, adds predicated)
+                int ci[7];
+                float vv[7];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) ci[q] = colat(e + q < end ? e + q : end - 1);
+#pragma unroll
+                for (int q = 0; q < 7; ++q) vv[q] = xf[(int64_t)ci[q] * a.ld];
+#pragma unroll
+                for (int q = 0; q < 7; ++q)
+                    if (e + q < end) s += vv[q];
+            }
+#endif
+            return s;
+        };
         for (int idx = tid; idx < TM * in0p; idx += kFusedThreads) {
             const int rl = idx / in0p, c = idx - rl * in0p;
             const int r = row0 + rl;
@@ -357,33 +501,10 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
                 if (a.concat && c < H) {
                     v = a.x_cond[(int64_t)r * a.ld + f];
                 } else {
-                    const int beg = a.rowptr[r], end = a.rowptr[r + 1];
+                    const int beg = s_rowptr[rl], end = s_rowptr[rl + 1];
                     const float* xf = a.x_cond + f;
-                    float s = 0.f;
-#ifndef GNF_ABL_NOAGG
-                    int e = beg;
-                    for (; e + 8 <= end; e += 8) {  // 8 independent gathers in flight, summed in edge order
-                        int ci[8];
-                        float vv[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) ci[q] = a.col[e + q];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) vv[q] = xf[(int64_t)ci[q] * a.ld];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) s += vv[q];
-                    }
-                    if (e < end) {  // up to 7 left: still issued together (indices clamped, adds predicated)
-                        int ci[7];
-                        float vv[7];
-#pragma unroll
-                        for (int q = 0; q < 7; ++q) ci[q] = a.col[e + q < end ? e + q : end - 1];
-#pragma unroll
-                        for (int q = 0; q < 7; ++q) vv[q] = xf[(int64_t)ci[q] * a.ld];
-#pragma unroll
-                        for (int q = 0; q < 7; ++q)
-                            if (e + q < end) s += vv[q];
-                    }
-#endif
+                    float s = staged ? gather(beg, end, xf, [&](int e) { return s_col[e - seg_beg]; })
+                                     : gather(beg, end, xf, [&](int e) { return a.col[e]; });
                     if (a.mean) {
                         const int cnt = end - beg;
                         s = s / (float)(cnt > 1 ? cnt : 1);
@@ -408,12 +529,12 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
 #endif
         const float* in_lds = buf(nl, pp);
         float* out_lds = buf(nl, pp ^ 1);
-        const float* bl = bias_lds + nl * a.bias_tot + a.boff[j];
         const float slope = (j == a.K - 1) ? 1.f : (a.act == GNF_ACT_RELU ? 0.f : a.alpha);
-        while (cj == j) {  // wave-uniform
-            const WChunk c = chunk_at(cj, cnt0);
-            advance(cj, cnt0);
-            const WChunk nx = cj < a.K ? chunk_at(cj, cnt0) : c;  // no next chunk: harmless re-load
+        while (cur.layer == j) {  // wave-uniform
+            const WChunk c = cur;
+            const WChunk nxt = next_chunk(c);
+            const WChunk nx = nxt.layer < a.K ? nxt : c;  // no next chunk: harmless re-load
+            const float* bl = bias_lds + nl * a.bias_tot + c.boff;
             if (c.nv >= 4)
                 mlp_chunk<MT, 4>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre);
             else if (c.nv == 3)
@@ -422,6 +543,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
                 mlp_chunk<MT, 2>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre);
             else
                 mlp_chunk<MT, 1>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre);
+            cur = nxt;
         }
         pp ^= 1;
         GNF_STAMP(3 + 2 * j);
@@ -470,6 +592,9 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
 extern "C" int gnf_debug_read_trace(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 8 * 16);
 }
+extern "C" int gnf_debug_read_stages(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stage), sizeof(unsigned long long) * 8 * 40);
+}
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -487,7 +612,8 @@ static int bias_total(const GnfMlp* m) {
 
 static size_t fused_lds_bytes(const GnfMlp* m, int MT, int NETS) {
     const int LS = max_padded_width(m) + 4;
-    return (size_t)(2 * NETS * 16 * MT * LS + NETS * bias_total(m) + 2) * sizeof(float) + 8 * sizeof(double);
+    return (size_t)(2 * NETS * 16 * MT * LS + NETS * bias_total(m) + 2) * sizeof(float) + 8 * sizeof(double) +
+           (GNF_MAX_LAYERS * 8 + kRowptrPad + kColCap) * sizeof(int);
 }
 
 bool fused_supported(const HalfStep& hs) {
