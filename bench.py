@@ -32,6 +32,18 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HP = dict(D=64, latent=256, K=5, T=8, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu",
           weight_sharing=False)
 GRAPHS_PER_GPU = 64
+# --workload: the default is BASELINE.json configs[1]; the others are the remaining configs (parity /
+# shape coverage runs, not the headline bench line).  "dataset": a GraphDataset name or a generator.
+WORKLOADS = {
+    "config2": dict(desc="community_medium", dataset="graph_rnn_community_medium", graphs=64, hp={}, inverse=False, fc=False),
+    "config2_fc": dict(desc="community_medium, fully connected topology (utils.py:164-183)", dataset="graph_rnn_community_medium",
+                       graphs=64, hp={}, inverse=False, fc=True),
+    "config4": dict(desc="protein stand-in (synthetic k-NN, n~U{100..500}), inverse pass", dataset="synthetic_protein",
+                    graphs=256, hp={}, inverse=True, fc=False),
+    "config5": dict(desc="citeseer/ego stand-in (synthetic, n~U{50..399}), node-dim 256", dataset="synthetic_ego",
+                    graphs=128, hp=dict(D=256, T=16), inverse=False, fc=False),
+}
+WORKLOAD = WORKLOADS["config2"]
 WEIGHT_SEED = 99
 FINAL_SCALE = 0.25     # last Linear layer of every net scaled by this so |s| stays O(1) over 16 half-steps
 PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
@@ -77,14 +89,25 @@ def make_params(seed, hp, final_scale):
 def make_batch(n_gpus, rank, seed=12345):
     """Global batch = 64*n_gpus graphs drawn with replacement from the 80% train split
     (graph_data.py:77-78,112-122), sharded by greedy balance on nodes+edges; returns this rank's shard."""
-    from gnf_amd.datasets import GraphDataset
+    from gnf_amd import datasets as D
     from gnf_amd.sharding import shard_graph_ids
-    ds = GraphDataset("graph_rnn_community_medium", HP["D"], seed=seed)
-    ids = ds.sample_ids(GRAPHS_PER_GPU * n_gpus)
-    nn, ne = ds.all.n_node[ids], ds.all.n_edge[ids]
+    g_total = GRAPHS_PER_GPU * n_gpus
+    name = WORKLOAD["dataset"]
+    if name == "synthetic_protein":
+        pool = D.synthetic_protein(g_total, seed=seed)
+        ids = np.arange(g_total)
+    elif name == "synthetic_ego":
+        pool = D.synthetic_ego(g_total, seed=seed)
+        ids = np.arange(g_total)
+    else:
+        ds = D.GraphDataset(name, HP["D"], seed=seed)
+        pool, ids = ds.all, ds.sample_ids(g_total)
+    if WORKLOAD["fc"]:
+        pool = D.with_fully_connected_topology(pool)
+    nn, ne = pool.n_node[ids], pool.n_edge[ids]
     mine = ids[shard_graph_ids(nn, ne, n_gpus)[rank]]
     rng = np.random.default_rng(seed + 1000 + rank)
-    dicts = ds.all.data_dicts(mine, lambda n: rng.standard_normal((n, HP["D"])).astype(np.float32))
+    dicts = pool.data_dicts(mine, lambda n: rng.standard_normal((n, HP["D"])).astype(np.float32))
     return dicts, int(nn.sum()), int(ne.sum())
 
 
@@ -142,7 +165,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-each-step", action="store_true", help="latency mode: host waits for every step's scalar")
     ap.add_argument("--kernel-timing-steps", type=int, default=10)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="config2")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + GNF_BENCH_ONE_DEVICE=1 runs several ranks on ONE GPU to exercise the N>1 logic")
     args = ap.parse_args()
+    global WORKLOAD, GRAPHS_PER_GPU
+    WORKLOAD = WORKLOADS[args.workload]
+    GRAPHS_PER_GPU = WORKLOAD["graphs"]
+    HP.update(WORKLOAD["hp"])
+    inverse = WORKLOAD["inverse"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -152,13 +183,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if os.environ.get("GNF_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
     from helpers import make_product_grevnet
     from gnf_amd import _abi
@@ -185,6 +221,9 @@ def main():
     host = torch.zeros(args.steps + args.warmup + 1, 3, dtype=torch.float64).pin_memory()
 
     def step(i):
+        if inverse:   # config 4: sampling direction g (gnn.py:343-373); no scalar comes back
+            net(graph, inverse=False)
+            return
         _, s3 = forward_shard_sums(net, graph, sums3)
         if world > 1:
             s3[2] = float(n_local)           # all-reduce sums in place: restore this rank's count first
@@ -208,11 +247,12 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
     ms_per_step = 1e3 * elapsed / args.steps
-    last = log_prob_from_sums(host[args.warmup + args.steps - 1].tolist(), HP["D"])
+    last = ({"log_prob_xs_per_node": None} if inverse else
+            log_prob_from_sums(host[args.warmup + args.steps - 1].tolist(), HP["D"]))
     value = n_global * HP["T"] * args.steps / elapsed
 
     # ---- dominant-kernel timing with HIP events on the launch stream (one event pair per launch) ----
@@ -238,7 +278,7 @@ def main():
                 upd = buf.data_ptr() + (4 * h if half == 0 else 0)
                 _abi.check(lib.gnf_coupling_half_f32(C.byref(csr.desc), C.byref(flow.s_nets[q]),
                                                      C.byref(flow.t_nets[q]), C.byref(flow.gnn), C.c_void_p(cond),
-                                                     C.c_void_p(upd), buf.stride(0), h, 0, None, _abi.ptr(ws),
+                                                     C.c_void_p(upd), buf.stride(0), h, 1 if inverse else 0, None, _abi.ptr(ws),
                                                      ws_bytes, st), "gnf_coupling_half_f32")
         b.record()
         if it >= 2:
@@ -246,9 +286,20 @@ def main():
     torch.cuda.synchronize()
     kernel_us = 1e3 * float(np.mean([a.elapsed_time(b) for a, b in evs])) / (2 * HP["T"]) if evs else float("nan")
     flops, abytes = algorithmic_half_step(n_local, e_local, HP)
+    # HBM-side bytes per launch come from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
+    # correction + WRITE_SIZE; tools/profile_r1.sh + tools/summarize_profile.py): PMC counters cannot be
+    # collected from inside this process.  Only quoted for the workload they were measured on.
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if args.workload == "config2" and net.fused and "k_half_fused" in pm.get("kernel", ""):
+            traffic = round(pm["traffic_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        pass
     achieved_tflops = flops / (kernel_us * 1e-6) / 1e12
     roofline = {"bound": "mfma", "achieved": round(achieved_tflops, 3), "peak": PEAK_FP32_MATRIX_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": traffic,
+                "traffic_note": "HBM-side bytes per launch from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
                 "kernel": ("one coupling half-step = k_half_fused (+ k_coupling when one net per workgroup), HIP events "
                            "around the 2T back-to-back launches / 2T") if net.fused else
                           "layered half-step (aggregate + 2K x k_linear + k_coupling)",
@@ -257,12 +308,13 @@ def main():
                 "hbm_floor_us": round(abytes / (PEAK_HBM_GBS * 1e3), 3)}
 
     out = {
-        "metric": "node-updates/sec (fwd+logdet) on community_medium batch", "value": round(value, 1),
+        "metric": ("node-updates/sec (fwd+logdet) on community_medium batch" if args.workload == "config2" else
+                   f"node-updates/sec ({'inverse' if inverse else 'fwd+logdet'}) on {args.workload}"), "value": round(value, 1),
         "unit": "node-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"community_medium batch={GRAPHS_PER_GPU}/GPU ({GRAPHS_PER_GPU * world} graphs total), "
-                               f"{HP['T']}-step GRevNet fwd+logdet, D={HP['D']} L={HP['latent']} K={HP['K']} "
+        "config": {"workload": f"{args.workload}: {WORKLOAD['desc']} batch={GRAPHS_PER_GPU}/GPU ({GRAPHS_PER_GPU * world} graphs total), "
+                               f"{HP['T']}-step GRevNet {'inverse (sampling)' if inverse else 'fwd+logdet'}, D={HP['D']} L={HP['latent']} K={HP['K']} "
                                f"avg_then_mlp eps=1 leaky_relu(0.2), sparse topology+self loops",
                    "nodes_total": n_global, "edges_total": e_global, "nodes_rank0": n_local, "edges_rank0": e_local,
                    "weights": f"N(0,2/(fan_in+fan_out)), seed {WEIGHT_SEED}, last layer x{FINAL_SCALE}",
@@ -274,7 +326,13 @@ def main():
         "roofline": roofline,
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if inverse:   # round-trip check f(g(z)) = z on the device (size-independent property)
+        zg = net(graph, inverse=False)
+        back, _ = net(zg, inverse=True)
+        torch.cuda.synchronize()
+        out["round_trip_max_abs_err"] = float((back.nodes - graph.nodes).abs().max())
+        out["log_prob_xs_per_node"] = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not inverse:
         cb, ref = cpu_baseline(dicts, params)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_baseline"] = round(value / cb["value"], 2)

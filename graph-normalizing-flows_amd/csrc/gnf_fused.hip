@@ -41,7 +41,10 @@ static inline int pad16(int v) { return (v + 15) & ~15; }
 
 // ------------------------------------------------------------------------------------------------
 // packed weight layout of one MLP (floats):  Wp_0 | Wp_1 | ... | Wp_{K-1} | bias_0 | ... | bias_{K-1}
-//   Wp_j[Op/16][Ip/16][64 lanes][4]:  Wp[nt][kg][lane][q] = W[16*kg + 4*(lane>>4) + q][16*nt + (lane&15)]
+//   Wp_j[Ip/16][Op/16][64 lanes][4]:  Wp[kg][nt][lane][q] = W[16*kg + 4*(lane>>4) + q][16*nt + (lane&15)]
+//   (k-group major: at a given k-group the 8 waves of a workgroup - and every workgroup of the chip, which
+//   all walk the stream in step - read ONE contiguous Op/16 KiB region, so the requests spread over all
+//   L2 channels; tile-major order put them 16 KiB apart on a quarter of the channels)
 //   bias_j[Op]; everything outside [I,O) is 0.  The bias block is contiguous so a workgroup stages it
 //   into LDS with one coalesced copy.
 // ------------------------------------------------------------------------------------------------
@@ -63,9 +66,11 @@ __global__ __launch_bounds__(256) void k_pack_layer(const float* __restrict__ W,
     if (i < nw) {
         const int q = (int)(i & 3);
         const int lane = (int)((i >> 2) & 63);
-        const int64_t blk = i >> 8;  // nt * (Ip/16) + kg
+        const int64_t blk = i >> 8;  // kg * (Op/16) + nt
         const int kgs = Ip >> 4;
-        const int nt = (int)(blk / kgs), kg = (int)(blk % kgs);
+        const int nts = Op >> 4;
+        const int kg = (int)(blk / nts), nt = (int)(blk % nts);
+        (void)kgs;
         const int k = 16 * kg + 4 * (lane >> 4) + q;
         const int c = 16 * nt + (lane & 15);
         wout[i] = (k < I && c < O) ? W[(int64_t)k * O + c] : 0.f;
@@ -181,7 +186,7 @@ __device__ __forceinline__ void prefetch_chunk(const WChunk& c, int ts, int voff
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int tb = b < c.nv ? b : c.nv - 1;
-            b_pre[u][b] = GNF_LOAD_B(rsrc, voff, ((c.nt0 + ts * tb) * c.ipg + kn) * 1024);
+            b_pre[u][b] = GNF_LOAD_B(rsrc, voff, (kn * c.ont + c.nt0 + ts * tb) * 1024);
         }
     }
 }
@@ -209,9 +214,10 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.wbase), 0, (int)c.wbytes, 0x00020000);
     const int voff = lane * 16;
-    int wtile[NV];  // byte offset of stage 0 of each tile's fragment stream (1 KiB per stage)
+    int wtile[NV];  // byte offset of each tile's fragment block inside a k-group (1 KiB per tile)
 #pragma unroll
-    for (int b = 0; b < NV; ++b) wtile[b] = (nt0 + ts * b) * ipg * 1024;
+    for (int b = 0; b < NV; ++b) wtile[b] = (nt0 + ts * b) * 1024;
+    const int kstride = c.ont * 1024;  // bytes between consecutive k-groups
     const float* arow[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) arow[m] = in_lds + (16 * m + lrow) * LS + 4 * lgrp;
@@ -264,7 +270,7 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
         _Pragma("unroll") for (int m = 0; m < MT; ++m) a_ring[(u + PF) % R][m] =                   \
             *reinterpret_cast<const f32x4*>(arow[m] + 16 * kn);                                    \
         _Pragma("unroll") for (int b = 0; b < NV; ++b) b_ring[(u + PF) % R][b] =                   \
-            GNF_LOAD_B(rsrc, voff, wtile[b] + kn * 1024);                                          \
+            GNF_LOAD_B(rsrc, voff, wtile[b] + kn * kstride);                                       \
         GNF_MFMA_STAGE(u)                                                                          \
         GNF_INTERLEAVE()                                                                           \
         GNF_STAGE_STAMP(2 + kg);                                                                   \

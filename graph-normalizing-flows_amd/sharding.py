@@ -35,7 +35,13 @@ def all_reduce_shard_sums(shard_sums, group=None):
     `shard_sums` is a 3-element fp64 tensor (flow.log_prob_terms(...)["shard_sums"]) on this rank's
     device (cuda for RCCL, cpu for gloo).  Returns the reduced tensor (in place)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(shard_sums, op=dist.ReduceOp.SUM, group=group)
+        if shard_sums.is_cuda and dist.get_backend(group) == "gloo":
+            # debugging on a box without RCCL peers (several ranks on one GPU): stage through the host
+            host = shard_sums.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            shard_sums.copy_(host)
+        else:
+            dist.all_reduce(shard_sums, op=dist.ReduceOp.SUM, group=group)
     return shard_sums
 
 
