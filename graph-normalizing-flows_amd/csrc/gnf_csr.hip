@@ -2,18 +2,25 @@
 // (senders/receivers with global node ids + per-graph n_node/n_edge; the container the reference
 // builds at train_grevnet_with_data.py:265-271 and graph_data.py:122).
 //
-// Batched graphs are block-diagonal: every edge of graph g lies in one contiguous slice of the
-// edge list and touches only g's nodes.  One workgroup per graph therefore does a STABLE counting
-// sort locally: the edge slice is staged through LDS in tiles and each thread owns one receiver
-// node, walking the tile in edge order (an LDS broadcast read per edge).  Stable = neighbours of a
-// node appear in original edge order, which fixes the fp32 summation order of the aggregation.
-// Cost is O(n_g * e_g / 256) per graph - meant for GraphRNN-scale graphs (n_g up to a few 1000).
+// Batched graphs are block-diagonal: every edge of graph g lies in one contiguous slice of the edge
+// list and touches only g's nodes.  One workgroup per graph therefore sorts locally, in LDS:
+//   count : edge-parallel LDS-atomic histogram of the receivers            -> deg[node]
+//   scan  : one workgroup, chunked exclusive scan                          -> rowptr
+//   fill  : edge-parallel placement with an LDS-atomic cursor per receiver (order inside a row is
+//           arbitrary at this point), then one thread per node sorts its row by ORIGINAL EDGE INDEX
+//           (insertion sort; rows are short) and writes col[] = senders[edge].  Sorting by edge
+//           index makes the result identical to a stable sort by receiver, i.e. neighbours appear
+//           in original edge order, which fixes the fp32 summation order of the aggregation.
+// Graphs too large for the LDS budget (more than kCapE edges or kCapN nodes) take a slower
+// scan-based path (one thread per receiver walks the edge slice in order).
 #include "gnf_common.h"
 
 namespace gnf {
 
 static constexpr int kCsrBlock = 256;
 static constexpr int kEdgeTile = 2048;
+static constexpr int kCapE = 16384;  // edges per graph handled in LDS (64 KB of edge ids)
+static constexpr int kCapN = 2048;   // nodes per graph handled in LDS
 
 // out[0] = 0, out[i+1] = sum_{j<=i} in[j]; single workgroup, chunked.
 __device__ void block_exclusive_scan(const int32_t* __restrict__ in, int32_t* __restrict__ out,
@@ -49,45 +56,30 @@ __global__ __launch_bounds__(kCsrBlock) void k_graph_offsets(const int32_t* __re
     block_exclusive_scan(n_edge, edge_off, n_graphs, sh);
 }
 
-// pass 0: deg[node] -> rowptr_tmp[node];  pass 1: fill col using the scanned rowptr.
-template <int PASS>
-__global__ __launch_bounds__(kCsrBlock) void k_csr_graph(const int32_t* __restrict__ senders,
-                                                         const int32_t* __restrict__ receivers,
+// ---- count: deg[node] = number of incoming edges ------------------------------------------------
+__global__ __launch_bounds__(kCsrBlock) void k_csr_count(const int32_t* __restrict__ receivers,
                                                          const int32_t* __restrict__ node_off,
                                                          const int32_t* __restrict__ edge_off,
-                                                         int32_t* __restrict__ deg,
-                                                         const int32_t* __restrict__ rowptr,
-                                                         int32_t* __restrict__ col) {
-    __shared__ int32_t s_recv[kEdgeTile];
-    __shared__ int32_t s_send[kEdgeTile];
+                                                         int32_t* __restrict__ deg) {
+    __shared__ int32_t cnt[kCapN];
     const int g = blockIdx.x;
     const int n0 = node_off[g], n1 = node_off[g + 1];
     const int e0 = edge_off[g], e1 = edge_off[g + 1];
-    for (int nb = n0; nb < n1; nb += kCsrBlock) {  // node batches (one node per thread)
-        const int node = nb + threadIdx.x;
-        const bool live = node < n1;
-        int cursor = 0;
-        if (PASS == 1 && live) cursor = rowptr[node];
-        int count = 0;
-        for (int eb = e0; eb < e1; eb += kEdgeTile) {
-            const int m = (e1 - eb) < kEdgeTile ? (e1 - eb) : kEdgeTile;
-            __syncthreads();
-            for (int i = threadIdx.x; i < m; i += kCsrBlock) {
-                s_recv[i] = receivers[eb + i];
-                if (PASS == 1) s_send[i] = senders[eb + i];
-            }
-            __syncthreads();
-            if (live) {
-                for (int i = 0; i < m; ++i) {
-                    if (s_recv[i] == node) {
-                        if (PASS == 1) col[cursor + count] = s_send[i];
-                        ++count;
-                    }
-                }
-            }
-        }
-        if (PASS == 0 && live) deg[node] = count;
+    const int ng = n1 - n0;
+    if (ng <= kCapN) {
+        for (int i = threadIdx.x; i < ng; i += kCsrBlock) cnt[i] = 0;
+        __syncthreads();
+        for (int e = e0 + threadIdx.x; e < e1; e += kCsrBlock) atomicAdd(&cnt[receivers[e] - n0], 1);
+        __syncthreads();
+        for (int i = threadIdx.x; i < ng; i += kCsrBlock) deg[n0 + i] = cnt[i];
+    } else {  // very large graph: global atomics (deg zeroed by the caller-side memset kernel below)
+        for (int e = e0 + threadIdx.x; e < e1; e += kCsrBlock) atomicAdd(&deg[receivers[e]], 1);
     }
+}
+
+__global__ __launch_bounds__(kCsrBlock) void k_zero_i32(int32_t* __restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * kCsrBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kCsrBlock)
+        p[i] = 0;
 }
 
 __global__ __launch_bounds__(kCsrBlock) void k_rowptr_scan(const int32_t* __restrict__ deg,
@@ -95,6 +87,73 @@ __global__ __launch_bounds__(kCsrBlock) void k_rowptr_scan(const int32_t* __rest
     __shared__ int32_t sh[kCsrBlock + 1];
     block_exclusive_scan(deg, rowptr, n, sh);
 }
+
+// ---- fill ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kCsrBlock) void k_csr_fill(const int32_t* __restrict__ senders,
+                                                        const int32_t* __restrict__ receivers,
+                                                        const int32_t* __restrict__ node_off,
+                                                        const int32_t* __restrict__ edge_off,
+                                                        const int32_t* __restrict__ rowptr,
+                                                        int32_t* __restrict__ col) {
+    extern __shared__ __attribute__((aligned(16))) int32_t sm[];
+    const int g = blockIdx.x;
+    const int n0 = node_off[g], n1 = node_off[g + 1];
+    const int e0 = edge_off[g], e1 = edge_off[g + 1];
+    const int ng = n1 - n0, eg = e1 - e0;
+    if (eg == 0) return;
+    if (ng <= kCapN && eg <= kCapE) {
+        int32_t* rp = sm;                  // [ng + 1] row starts relative to the graph's first row
+        int32_t* cur = sm + kCapN + 1;     // [ng] placement cursors
+        int32_t* eid = cur + kCapN;        // [eg] edge ids (relative to e0), grouped by receiver
+        const int base = rowptr[n0];
+        for (int i = threadIdx.x; i <= ng; i += kCsrBlock) rp[i] = rowptr[n0 + i] - base;
+        for (int i = threadIdx.x; i < ng; i += kCsrBlock) cur[i] = 0;
+        __syncthreads();
+        for (int e = threadIdx.x; e < eg; e += kCsrBlock) {
+            const int r = receivers[e0 + e] - n0;
+            const int pos = atomicAdd(&cur[r], 1);
+            eid[rp[r] + pos] = e;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < ng; i += kCsrBlock) {
+            const int beg = rp[i], end = rp[i + 1];
+            for (int a = beg + 1; a < end; ++a) {  // insertion sort by edge id (rows are short)
+                const int key = eid[a];
+                int b = a - 1;
+                while (b >= beg && eid[b] > key) {
+                    eid[b + 1] = eid[b];
+                    --b;
+                }
+                eid[b + 1] = key;
+            }
+            for (int a = beg; a < end; ++a) col[base + a] = senders[e0 + eid[a]];
+        }
+    } else {
+        // slow path: one thread per receiver walks the graph's edge slice in order (tiles staged in LDS)
+        int32_t* s_recv = sm;
+        int32_t* s_send = sm + kEdgeTile;
+        for (int nb = n0; nb < n1; nb += kCsrBlock) {
+            const int node = nb + threadIdx.x;
+            const bool live = node < n1;
+            const int cursor = live ? rowptr[node] : 0;
+            int count = 0;
+            for (int eb = e0; eb < e1; eb += kEdgeTile) {
+                const int m = (e1 - eb) < kEdgeTile ? (e1 - eb) : kEdgeTile;
+                __syncthreads();
+                for (int i = threadIdx.x; i < m; i += kCsrBlock) {
+                    s_recv[i] = receivers[eb + i];
+                    s_send[i] = senders[eb + i];
+                }
+                __syncthreads();
+                if (live)
+                    for (int i = 0; i < m; ++i)
+                        if (s_recv[i] == node) col[cursor + count++] = s_send[i];
+            }
+        }
+    }
+}
+
+static constexpr size_t kFillLds = (size_t)(2 * kCapN + 1 + kCapE) * sizeof(int32_t);
 
 }  // namespace gnf
 
@@ -132,18 +191,29 @@ int gnf_build_csr(const int32_t* senders, const int32_t* receivers, const int32_
     hipLaunchKernelGGL(k_graph_offsets, dim3(1), dim3(kCsrBlock), 0, st, n_node, n_edge, n_graphs,
                        node_off, edge_off);
     GNF_LAUNCH_CHECK("k_graph_offsets");
+    if (n_nodes > 0) {
+        int64_t zb = (n_nodes + kCsrBlock - 1) / kCsrBlock;
+        if (zb > 1024) zb = 1024;
+        hipLaunchKernelGGL(k_zero_i32, dim3((unsigned)zb), dim3(kCsrBlock), 0, st, deg, n_nodes);
+        GNF_LAUNCH_CHECK("k_zero_i32");
+    }
     if (n_graphs > 0) {
-        hipLaunchKernelGGL(k_csr_graph<0>, dim3((unsigned)n_graphs), dim3(kCsrBlock), 0, st, senders,
-                           receivers, node_off, edge_off, deg, (const int32_t*)nullptr,
-                           (int32_t*)nullptr);
-        GNF_LAUNCH_CHECK("k_csr_graph<0>");
+        hipLaunchKernelGGL(k_csr_count, dim3((unsigned)n_graphs), dim3(kCsrBlock), 0, st, receivers,
+                           node_off, edge_off, deg);
+        GNF_LAUNCH_CHECK("k_csr_count");
     }
     hipLaunchKernelGGL(k_rowptr_scan, dim3(1), dim3(kCsrBlock), 0, st, deg, rowptr, n_nodes);
     GNF_LAUNCH_CHECK("k_rowptr_scan");
     if (n_graphs > 0 && n_edges > 0) {
-        hipLaunchKernelGGL(k_csr_graph<1>, dim3((unsigned)n_graphs), dim3(kCsrBlock), 0, st, senders,
-                           receivers, node_off, edge_off, (int32_t*)nullptr, rowptr, col);
-        GNF_LAUNCH_CHECK("k_csr_graph<1>");
+        static bool attr_set = false;
+        if (!attr_set) {
+            GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_csr_fill),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFillLds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_csr_fill, dim3((unsigned)n_graphs), dim3(kCsrBlock), kFillLds, st, senders,
+                           receivers, node_off, edge_off, rowptr, col);
+        GNF_LAUNCH_CHECK("k_csr_fill");
     }
     return GNF_OK;
 }

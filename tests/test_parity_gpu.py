@@ -249,6 +249,16 @@ def test_device_csr_build_is_bit_exact(community_medium, grid_small):
     s3 = np.array([4, 0, 2, 2, 1, 3, 0, 8, 11, 9, 10, 8], np.int32)
     r3 = np.array([1, 1, 0, 4, 1, 3, 0, 10, 8, 8, 8, 11], np.int32)
     cases.append((nn3, ne3, s3, r3))
+    # beyond the LDS budget of the fast path: one graph with > 16384 edges (FC, n = 130) and one with
+    # > 2048 nodes (a 2100-node ring, both directions + self loops, edge order shuffled)
+    s4, r4, ne4 = senders_receivers(np.array([130, 3], np.int32))
+    cases.append((np.array([130, 3], np.int32), ne4, s4.astype(np.int32), r4.astype(np.int32)))
+    m = 2100
+    ring_s = np.concatenate([np.arange(m), np.arange(m), (np.arange(m) + 1) % m])
+    ring_r = np.concatenate([np.arange(m), (np.arange(m) + 1) % m, np.arange(m)])
+    perm = np.random.default_rng(9).permutation(len(ring_s))
+    cases.append((np.array([m], np.int32), np.array([len(ring_s)], np.int32),
+                  ring_s[perm].astype(np.int32), ring_r[perm].astype(np.int32)))
     for nn, ne, s, r in cases:
         n = int(nn.sum())
         g = graph_from_arrays(nn, ne, s, r, np.zeros((n, 2), np.float32), DEV)
