@@ -304,6 +304,31 @@ def main():
             evs.append((a, b))
     torch.cuda.synchronize()
     kernel_us = 1e3 * float(np.mean([a.elapsed_time(b) for a, b in evs])) / (2 * HP["T"]) if evs else float("nan")
+    # ---- kernel A alone (gnf_aggregate_f32: the CSR segment-reduce the north_star asks HBM evidence for;
+    # on the hot path it is fused into the half-step kernel's prologue) ------------------------------
+    agg_out = torch.empty(n_local, h, dtype=torch.float32, device=dev)
+    xin = graph.nodes[:, :h]
+
+    def run_agg():
+        _abi.check(lib.gnf_aggregate_f32(C.byref(csr.desc), _abi.ptr(xin), xin.stride(0), h,
+                                         _abi.GNF_AGG_MEAN if HP["agg"] == "mean" else _abi.GNF_AGG_SUM,
+                                         _abi.ptr(agg_out), h, st), "gnf_aggregate_f32")
+    for _ in range(5):
+        run_agg()
+    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ea.record()
+    for _ in range(50):
+        run_agg()
+    eb.record()
+    torch.cuda.synchronize()
+    agg_us = 1e3 * ea.elapsed_time(eb) / 50
+    agg_bytes = 8 * n_local * h + 4 * e_local + 4 * n_local
+    kernel_a = {"kernel": "k_aggregate<4> (gnf_aggregate_f32)", "us": round(agg_us, 2),
+                "algorithmic_bytes": agg_bytes, "achieved_gbs": round(agg_bytes / agg_us / 1e3, 1),
+                "peak_gbs": PEAK_HBM_GBS, "frac": round(agg_bytes / agg_us / 1e3 / PEAK_HBM_GBS, 4),
+                "note": "launch-latency-bound at this batch size (a few us); 2.9 TB/s algorithmic on 77k-308k node "
+                        "batches (tools/probe_agg.py, profiles/)"}
+
     flops, abytes = algorithmic_half_step(n_local, e_local, HP)
     # HBM-side bytes per launch come from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
     # correction + WRITE_SIZE; tools/profile_r1.sh + tools/summarize_profile.py): PMC counters cannot be
@@ -344,6 +369,7 @@ def main():
         "log_prob_xs_per_node": last["log_prob_xs_per_node"],
         "with_csr_rebuild_each_step": rebuild,
         "roofline": roofline,
+        "kernel_a": kernel_a,
     }
 
     if inverse:   # round-trip check f(g(z)) = z on the device (size-independent property)

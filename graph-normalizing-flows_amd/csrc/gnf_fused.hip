@@ -352,7 +352,12 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
     // wave-uniform ids go through readfirstlane so that hipcc keeps them (and everything derived:
     // net, tile offsets, buffer descriptors, branches) in SGPRs instead of waterfalling on VGPRs
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int nl = wave / WPN, wl = wave % WPN;  // local net of this wave, wave index inside the net
+    const int nl = wave / WPN;  // local net of this wave
+    // column-tile owner index inside the net.  The second net's ownership is rotated by half a
+    // turn: waves w and w+4 share a SIMD, so on a layer with fewer tiles than waves (a 32-wide output
+    // layer has 2 tiles for 4 waves) the s-net keeps SIMDs 0-1 busy and the t-net SIMDs 2-3, instead
+    // of both nets queueing on SIMDs 0-1.
+    const int wl = (wave % WPN + nl * (WPN / 2)) % WPN;
     const int net = net0 + nl;
     const int voff = lane * 16;
 

@@ -14,39 +14,76 @@
 namespace gnf {
 
 // ------------------------------------------------------------------------------------------------
-// Kernel A: CSR segmented reduce of neighbour rows.  Lanes run along the feature axis so that each
-// neighbour row is one coalesced read; several rows per workgroup when H is small.
+// Kernel A: CSR segmented reduce of neighbour rows (gnn.py:103-104,117-118,151-156).
+// A group of G lanes (G = power of two <= 64) owns one receiver row; lanes run along the feature axis
+// VEC floats each, so every neighbour row is one coalesced read (16 B per lane when VEC = 4) and a
+// wave covers 64/G rows.  Four neighbour rows are in flight per lane; the adds stay in edge order.
 //   mode 0: out[r, f] = eps * x[r, f] + agg        (AggThenMLPBlock)
 //   mode 1: out[r, f] = x[r, f]; out[r, H+f] = agg (ConcatThenMLPBlock)
 //   mode 2: out[r, f] = agg                        (aggregator alone)
 // ------------------------------------------------------------------------------------------------
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<1> {
+    typedef float type;
+};
+template <>
+struct VecT<4> {
+    typedef float type __attribute__((ext_vector_type(4)));
+};
+
+template <int VEC>
 __global__ __launch_bounds__(256) void k_aggregate(const int32_t* __restrict__ rowptr,
                                                    const int32_t* __restrict__ col, int64_t n_nodes,
                                                    const float* __restrict__ x, int64_t ldx, int H,
                                                    int mean, int mode, float eps,
-                                                   float* __restrict__ out, int64_t ldo,
-                                                   int rows_per_block) {
-    const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
-    const int total = rows_per_block * H;
-    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-        const int rl = idx / H;
-        const int f = idx - rl * H;
-        const int64_t r = row0 + rl;
-        if (r >= n_nodes) continue;
-        const int beg = rowptr[r], end = rowptr[r + 1];
-        float acc = 0.f;
-        for (int e = beg; e < end; ++e) acc += x[(int64_t)col[e] * ldx + f];
-        if (mean) {
-            const int cnt = end - beg;
-            acc = acc / (float)(cnt > 1 ? cnt : 1);  // unsorted_segment_mean: sum / max(count, 1)
+                                                   float* __restrict__ out, int64_t ldo, int G) {
+    typedef typename VecT<VEC>::type V;
+    // XCD-aware bijective block remap (block b runs on XCD b % 8): consecutive row blocks - the nodes
+    // of one graph and their neighbours - share one XCD's L2 instead of being sprayed over all eight.
+    const int64_t nwg = gridDim.x, bid = blockIdx.x;
+    const int64_t xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
+    const int64_t blk = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int64_t gid = (blk * 256 + threadIdx.x) / G;  // row
+    const int gl = threadIdx.x & (G - 1);
+    if (gid >= n_nodes) return;
+    const int64_t r = gid;
+    const int beg = rowptr[r], end = rowptr[r + 1];
+    const float cnt = (float)((end - beg) > 1 ? (end - beg) : 1);  // unsorted_segment_mean: max(count, 1)
+    for (int f = gl * VEC; f < H; f += G * VEC) {
+        V acc = V(0.f);
+        int e = beg;
+        for (; e + 8 <= end; e += 8) {  // 8 neighbour rows in flight per lane
+            int ci[8];
+            V vv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ci[q] = col[e + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) vv[q] = *reinterpret_cast<const V*>(x + (int64_t)ci[q] * ldx + f);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += vv[q];
         }
+        if (e < end) {  // up to 7 left, still issued together (indices clamped, adds predicated)
+            int ci[7];
+            V vv[7];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) ci[q] = col[e + q < end ? e + q : end - 1];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) vv[q] = *reinterpret_cast<const V*>(x + (int64_t)ci[q] * ldx + f);
+#pragma unroll
+            for (int q = 0; q < 7; ++q)
+                if (e + q < end) acc += vv[q];
+        }
+        if (mean) acc = acc / cnt;
         if (mode == 0) {
-            out[r * ldo + f] = eps * x[r * ldx + f] + acc;
+            const V xs = *reinterpret_cast<const V*>(x + r * ldx + f);
+            *reinterpret_cast<V*>(out + r * ldo + f) = eps * xs + acc;
         } else if (mode == 1) {
-            out[r * ldo + f] = x[r * ldx + f];
-            out[r * ldo + H + f] = acc;
+            *reinterpret_cast<V*>(out + r * ldo + f) = *reinterpret_cast<const V*>(x + r * ldx + f);
+            *reinterpret_cast<V*>(out + r * ldo + H + f) = acc;
         } else {
-            out[r * ldo + f] = acc;
+            *reinterpret_cast<V*>(out + r * ldo + f) = acc;
         }
     }
 }
@@ -55,12 +92,18 @@ int launch_aggregate(const int32_t* rowptr, const int32_t* col, int64_t n_nodes,
                      int64_t ldx, int32_t H, int32_t mean, int32_t mode, float eps, float* out,
                      int64_t ldo, hipStream_t st) {
     if (n_nodes == 0) return GNF_OK;
-    int rows = 256 / H;
-    if (rows < 1) rows = 1;
-    if (rows > 64) rows = 64;
-    const int64_t blocks = (n_nodes + rows - 1) / rows;
-    hipLaunchKernelGGL(k_aggregate, dim3((unsigned)blocks), dim3(256), 0, st, rowptr, col, n_nodes, x,
-                       ldx, H, mean, mode, eps, out, ldo, rows);
+    const bool vec4 = (H % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
+    const int per_row = vec4 ? H / 4 : H;  // lanes a row can use
+    int G = 1;
+    while (G < per_row && G < 64) G <<= 1;
+    const int64_t blocks = (n_nodes * G + 255) / 256;
+    if (vec4)
+        hipLaunchKernelGGL(k_aggregate<4>, dim3((unsigned)blocks), dim3(256), 0, st, rowptr, col, n_nodes, x,
+                           ldx, H, mean, mode, eps, out, ldo, G);
+    else
+        hipLaunchKernelGGL(k_aggregate<1>, dim3((unsigned)blocks), dim3(256), 0, st, rowptr, col, n_nodes, x,
+                           ldx, H, mean, mode, eps, out, ldo, G);
     GNF_LAUNCH_CHECK("k_aggregate");
     return GNF_OK;
 }
