@@ -150,6 +150,11 @@ __device__ int g_trace_layer = 1;
         if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)                                  \
             g_trace[threadIdx.x >> 6][slot] = __builtin_amdgcn_s_memtime();              \
     } while (0)
+#define GNF_PSTAMP(idx)                                                                  \
+    do {                                                                                 \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)                                  \
+            g_stage[threadIdx.x >> 6][30 + (idx)] = __builtin_amdgcn_s_memtime();        \
+    } while (0)
 #define GNF_STAGE_STAMP(idx)                                                             \
     do {                                                                                 \
         if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && trace_on && (idx) < 40)        \
@@ -158,6 +163,7 @@ __device__ int g_trace_layer = 1;
 #else
 #define GNF_STAMP(slot)
 #define GNF_STAGE_STAMP(idx)
+#define GNF_PSTAMP(idx)
 #endif
 
 // A wave's unit of work: NV (<= 4) column tiles {nt0, nt0+ts, ...} of one layer.  All wave-uniform.
@@ -430,8 +436,29 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
     // ---- weights of the first chunk start streaming before anything else -----------------------
     f32x4 b_pre[kPF][4];
     prefetch_chunk(cur, WPN, voff, b_pre);
-    // ---- layer table -> LDS (uniform loop: scalar loads of the kernel arguments) ----------------
-    for (int j = 0; j < a.K; ++j) {
+    GNF_PSTAMP(0);
+    // ---- every independent global read of the prologue is ISSUED before any is consumed: rowptr of
+    // the tile, the biases (<= 8 floats per thread in registers), the layer table - one memory round
+    // trip instead of three back-to-back ones ----------------------------------------------------------
+    int* s_rowptr = tab + GNF_MAX_LAYERS * 8;
+    int* s_col = s_rowptr + kRowptrPad;
+    int rp_reg = 0;
+    if (tid <= TM) {
+        const int r = row0 + tid;
+        rp_reg = a.rowptr[r < a.n_nodes ? r : a.n_nodes];
+    }
+    constexpr int kBiasRegs = 8;
+    const int bias_all = NETS * a.bias_tot;
+    const float* bsrc0 = a.bias[net0];
+    const float* bsrc1 = a.bias[NETS == 2 ? 1 : net0];
+    float breg[kBiasRegs];
+#pragma unroll
+    for (int q = 0; q < kBiasRegs; ++q) {
+        const int i = tid + q * kFusedThreads;
+        const int ic = i < bias_all ? i : 0;  // clamped: the load is unconditional, the store is not
+        breg[q] = ic < a.bias_tot ? bsrc0[ic] : bsrc1[ic - a.bias_tot];
+    }
+    for (int j = 0; j < a.K; ++j) {  // layer table (uniform loop: scalar loads of the kernel arguments)
         if (tid == 0) {
             const unsigned long long p0 = reinterpret_cast<unsigned long long>(a.wp[net0][j]);
             const unsigned long long p1 = reinterpret_cast<unsigned long long>(a.wp[NETS == 2 ? 1 : net0][j]);
@@ -446,22 +473,22 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
             row[7] = (int)(unsigned)(p1 >> 32);
         }
     }
-    // ---- biases of every layer -> LDS: one coalesced copy per net -----------------------------
-    for (int i = tid; i < NETS * a.bias_tot; i += kFusedThreads) {
-        const int n_ = i / a.bias_tot;
-        bias_lds[i] = a.bias[net0 + n_][i - n_ * a.bias_tot];
+    GNF_PSTAMP(1);
+    if (tid <= TM) s_rowptr[tid] = rp_reg;
+#pragma unroll
+    for (int q = 0; q < kBiasRegs; ++q) {
+        const int i = tid + q * kFusedThreads;
+        if (i < bias_all) bias_lds[i] = breg[q];
     }
+    for (int i = tid + kBiasRegs * kFusedThreads; i < bias_all; i += kFusedThreads)  // very wide nets only
+        bias_lds[i] = i < a.bias_tot ? bsrc0[i] : bsrc1[i - a.bias_tot];
     // ---- A: aggregate + combine into the layer-0 input of each net ----------------------------
     // The tile's CSR slice is staged in LDS first (rowptr[row0..row0+TM], then the contiguous col
     // segment, both coalesced), so that the neighbour-row gathers are independent loads issued 8 at a
     // time instead of a rowptr -> col -> x chain of dependent global round trips per thread.
-    int* s_rowptr = tab + GNF_MAX_LAYERS * 8;
-    int* s_col = s_rowptr + kRowptrPad;
-    if (tid <= TM) {
-        const int r = row0 + tid;
-        s_rowptr[tid] = a.rowptr[r < a.n_nodes ? r : a.n_nodes];
-    }
+    GNF_PSTAMP(2);
     __syncthreads();
+    GNF_PSTAMP(3);
     const int seg_beg = s_rowptr[0];
     const int seg_len = s_rowptr[TM] - seg_beg;
 #ifdef GNF_NO_STAGE_CSR
@@ -472,6 +499,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
     if (staged)
         for (int i = tid; i < seg_len; i += kFusedThreads) s_col[i] = a.col[seg_beg + i];
     __syncthreads();
+    GNF_PSTAMP(4);
     {
         const int in0p = a.ipg[0] * 16;
         // sum of x_cond[nbr, f] over the incoming edges [beg, end) of one node, in edge order

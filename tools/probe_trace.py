@@ -57,3 +57,7 @@ if hasattr(raw, "gnf_debug_read_stages") and raw.gnf_debug_read_stages(st) == 0:
     print("layer-1 stage stamps relative to the layer's opening barrier (slot 0 = chunk entry, 2+kg = after stage kg, 38 = MFMAs done)")
     for sl in [0] + list(range(2, 18)) + [38]:
         print(f"{sl:3d} " + " ".join(f"{int(g[w, sl] - base[w]):8d}" for w in range(8)))
+
+    print("prologue stamps relative to kernel start (0 prefetch issued, 1 table filled, 2 bias copied, 3 rowptr staged+barrier, 4 col staged+barrier; then 'agg done' above)")
+    for sl in range(5):
+        print(f"P{sl}  " + " ".join(f"{int(g[w, 30 + sl] - t[w, 0]):8d}" for w in range(8)))
