@@ -1,0 +1,51 @@
+"""bench.py pieces that run without a GPU: the algorithmic work model, the weight
+generator, batch construction + sharding, and the workload table."""
+import numpy as np
+
+import bench
+
+
+def test_algorithmic_work_matches_survey_worked_example():
+    # config 2, D=64, L=256, K=5, agg-then: P_w = 212,992
+    hp = dict(bench.HP)
+    n, e = 2560, 29663
+    flops, nbytes = bench.algorithmic_half_step(n, e, hp)
+    p_w = 32 * 256 + 3 * 256 * 256 + 256 * 32
+    assert p_w == 212992
+    assert flops == n * 4 * p_w + e * 32 + 6 * n * 32
+    assert nbytes == 12 * n * 32 + 4 * e + 4 * n + 8 * (p_w + 4 * 256 + 32)
+    # per node-update (2 half-steps): F_nu ~ 1.705 MFLOP
+    assert abs(2 * flops / n - 1.705e6) / 1.705e6 < 0.01
+
+
+def test_make_params_layout_and_scale():
+    hp = dict(bench.HP, T=2)
+    p = bench.make_params(1, hp, 0.25)
+    assert len(p["s"]) == 2 and len(p["s"][0]) == 2 and len(p["t"][1]) == 2
+    mlp = p["s"][0][0]
+    assert [w.shape for w, _ in mlp] == [(32, 256), (256, 256), (256, 256), (256, 256), (256, 32)]
+    assert mlp[-1][0].std() < 0.5 * mlp[1][0].std()         # last layer scaled down
+    assert mlp[0][0].dtype == np.float32
+
+
+def test_make_batch_shards_cover_the_global_batch():
+    bench.WORKLOAD = bench.WORKLOADS["config2"]
+    bench.GRAPHS_PER_GPU = 8
+    try:
+        tot_n = 0
+        for rank in range(2):
+            dicts, n_global, e_global = bench.make_batch(2, rank)
+            tot_n += sum(d["n_node"] for d in dicts)
+            assert all(d["nodes"].shape == (d["n_node"], bench.HP["D"]) for d in dicts)
+        assert tot_n == n_global
+        d1, n1, e1 = bench.make_batch(1, 0)
+        assert len(d1) == 8 and sum(d["n_node"] for d in d1) == n1
+        assert sum(len(d["senders"]) for d in d1) == e1
+    finally:
+        bench.GRAPHS_PER_GPU = 64
+
+
+def test_workload_table():
+    assert set(bench.WORKLOADS) == {"config2", "config2_fc", "config4", "config5"}
+    assert bench.WORKLOADS["config5"]["hp"] == dict(D=256, T=16)
+    assert bench.WORKLOADS["config4"]["inverse"] is True
