@@ -104,8 +104,41 @@ class Fp64Dense:
                 h = self.act(h)
         return h
 
+    def attn_gnn(self, x, net):
+        """gnn.py:480-553 DMSelfAttentionMLP around gnn.py:385-477 DMSelfAttention, dense form.
+        NB the reference calls attn_module(project_v, project_q, project_k, graph) (gnn.py:528), i.e. the
+        module's "keys" are the Wq projection (taken at the SENDER) and its "queries" the Wk projection
+        (taken at the RECEIVER): logit[e,h] = <xWq[sender], xWk[receiver]>_h (gnn.py:446-457).
+        Softmax over the incoming edges of each receiver per head (graph_nets _unsorted_segment_softmax:
+        exp(x - segment_max) / segment_sum, upstream-unpinned); a node without incoming edges gets 0."""
+        a = net["attn"]
+        nh, kq, vd = int(a["num_heads"]), int(a["kq_dim"]), int(a["v_dim"])
+        n = x.shape[0]
+        q = (x @ np.asarray(a["wq"], np.float64)).reshape(n, nh, kq)
+        k = (x @ np.asarray(a["wk"], np.float64)).reshape(n, nh, kq)
+        v = x @ np.asarray(a["wv"], np.float64)                       # [N, v]; repeated over heads (gnn.py:524)
+        logits = np.einsum("shd,rhd->rsh", q, k)                        # [receiver, sender, head]
+        if a.get("kq_dim_division", False):
+            logits = logits / math.sqrt(kq)
+        mult = self.adj[:, :, None]                                     # edge multiplicity r <- s
+        masked = np.where(mult > 0, logits, -np.inf)
+        mx = masked.max(axis=1, keepdims=True)
+        mx = np.where(np.isfinite(mx), mx, 0.0)
+        ex = mult * np.exp(np.where(mult > 0, logits - mx, -np.inf))
+        den = ex.sum(axis=1, keepdims=True)
+        w = np.where(den > 0, ex / np.where(den > 0, den, 1.0), 0.0)   # [r, s, h]
+        agg = np.einsum("rsh,sj->rhj", w, v).reshape(n, nh * vd)       # [N, nh*v]
+        new = agg @ np.asarray(a["wo"], np.float64)                     # snt.Linear(C, use_bias=False) gnn.py:538-540
+        h0 = np.concatenate([x, new], axis=1) if a.get("concat", True) else new
+        out = self.mlp(h0, net["mlp"])
+        if a.get("residual", False):
+            out = out + x
+        return out
+
     def gnn(self, x, layers):
         """gnn.py:155-156 NodeBlockGNN -> gnn.py:122-126 AggThenMLPBlock / 107-111 ConcatThenMLPBlock."""
+        if isinstance(layers, dict):
+            return self.attn_gnn(x, layers)
         agg = self.adj @ x
         if self.agg == "mean":
             agg = agg / self.deg
@@ -177,6 +210,11 @@ class Fp32Gather:
     def prep_params(self, params):
         """numpy -> torch once, outside any timed region."""
         def conv(m):
+            if isinstance(m, dict) and "attn" in m:
+                a = dict(m["attn"])
+                for key in ("wq", "wk", "wv", "wo"):
+                    a[key] = self.to_t(a[key])
+                return {"attn": a, "mlp": conv(m["mlp"])}
             if isinstance(m, list) and m and isinstance(m[0], tuple):
                 return [(self.to_t(w), self.to_t(b)) for (w, b) in m]
             return [conv(q) for q in m]
@@ -196,8 +234,39 @@ class Fp32Gather:
                 h = self.act(h)
         return h
 
+    def attn_gnn(self, x, net):
+        """Edge-list form of gnn.py:385-553 in the reference's op order (gathers materialised per edge,
+        segment max / sum over receivers)."""
+        torch = self.torch
+        a = net["attn"]
+        nh, kq, vd = int(a["num_heads"]), int(a["kq_dim"]), int(a["v_dim"])
+        n, e = x.shape[0], self.senders.shape[0]
+        q = (x @ a["wq"]).reshape(n, nh, kq)
+        k = (x @ a["wk"]).reshape(n, nh, kq)
+        v = (x @ a["wv"]).unsqueeze(1).expand(n, nh, vd)               # keras.backend.repeat
+        sender_keys = q.index_select(0, self.senders)                   # "keys"    = Wq projection at the sender
+        receiver_queries = k.index_select(0, self.receivers)            # "queries" = Wk projection at the receiver
+        logits = (sender_keys * receiver_queries).sum(dim=-1)           # [E, nh]
+        if a.get("kq_dim_division", False):
+            logits = logits / math.sqrt(kq)
+        idx = self.receivers.unsqueeze(1).expand(e, nh)
+        seg_max = torch.full((n, nh), -float("inf"), dtype=self.dtype).scatter_reduce(0, idx, logits, "amax")
+        ex = torch.exp(logits - seg_max.index_select(0, self.receivers))
+        seg_sum = torch.zeros(n, nh, dtype=self.dtype).index_add_(0, self.receivers, ex)
+        w = ex / seg_sum.index_select(0, self.receivers)
+        attended = v.index_select(0, self.senders) * w.unsqueeze(-1)    # [E, nh, v]
+        agg = torch.zeros(n, nh, vd, dtype=self.dtype).index_add_(0, self.receivers, attended)
+        new = agg.reshape(n, nh * vd) @ a["wo"]
+        h0 = torch.cat([x, new], dim=1) if a.get("concat", True) else new
+        out = self.mlp(h0, net["mlp"])
+        if a.get("residual", False):
+            out = out + x
+        return out
+
     def gnn(self, x, layers):
         torch = self.torch
+        if isinstance(layers, dict):
+            return self.attn_gnn(x, layers)
         edges = x.index_select(0, self.senders)                       # GatherV2 (gnn.py:151-156), materialised [E,H]
         agg = torch.zeros_like(x).index_add_(0, self.receivers, edges)  # UnsortedSegmentSum
         if self.agg == "mean":
@@ -273,6 +342,36 @@ def make_grevnet_params(seed, hdim, latent, num_layers, num_timesteps, combine="
 
     def one():
         return make_mlp_params(rng, in_dim, latent, hdim, num_layers, bias_std, final_scale, dtype)
+
+    if weight_sharing:
+        return {"s": [one(), one()], "t": [one(), one()]}
+    return {"s": [[one() for _ in range(num_timesteps)] for _ in range(2)],
+            "t": [[one() for _ in range(num_timesteps)] for _ in range(2)]}
+
+
+def make_attn_net_params(rng, hdim, latent, num_layers, num_heads=8, kq_dim=10, v_dim=10, out_dim=80,
+                         concat=True, kq_dim_division=False, residual=False, bias_std=0.1,
+                         final_scale=1.0, dtype=np.float32):
+    """One DMSelfAttentionMLP net (gnn.py:480-553): Wq, Wk [H, nh*kq], Wv [H, v] xavier-uniform
+    (gnn.py:504-506), Wo [nh*v, C] (snt.Linear default init ~ 1/sqrt(fan_in)), then the MLP on
+    [x || new] (H + C inputs) or new (C inputs)."""
+    def xavier(fi, fo):
+        a = math.sqrt(6.0 / (fi + fo))
+        return rng.uniform(-a, a, size=(fi, fo)).astype(dtype)
+    attn = {"num_heads": num_heads, "kq_dim": kq_dim, "v_dim": v_dim, "concat": concat,
+            "kq_dim_division": kq_dim_division, "residual": residual,
+            "wq": xavier(hdim, num_heads * kq_dim), "wk": xavier(hdim, num_heads * kq_dim),
+            "wv": xavier(hdim, v_dim),
+            "wo": (rng.standard_normal((num_heads * v_dim, out_dim)) / math.sqrt(num_heads * v_dim)).astype(dtype)}
+    in_dim = hdim + out_dim if concat else out_dim
+    return {"attn": attn, "mlp": make_mlp_params(rng, in_dim, latent, hdim, num_layers, bias_std, final_scale, dtype)}
+
+
+def make_attn_grevnet_params(seed, hdim, latent, num_layers, num_timesteps, weight_sharing=False, **kw):
+    rng = np.random.default_rng(seed)
+
+    def one():
+        return make_attn_net_params(rng, hdim, latent, num_layers, **kw)
 
     if weight_sharing:
         return {"s": [one(), one()], "t": [one(), one()]}

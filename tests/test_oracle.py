@@ -170,3 +170,69 @@ def test_activation_semantics():
     np.testing.assert_allclose(o.act(np.array([-2.0, 0.0, 3.0])), [-0.4, 0.0, 3.0])
     o.activation = "relu"
     np.testing.assert_allclose(o.act(np.array([-2.0, 0.0, 3.0])), [0.0, 0.0, 3.0])
+
+
+# ------------------------------------------------------------------------------------------------
+# edge-list attention GNN (DMSelfAttentionMLP, gnn.py:385-553)
+# ------------------------------------------------------------------------------------------------
+def test_attention_dual_restatement_agreement(grid_small):
+    n_node, n_edge, sl, rl = grid_small
+    nn, ne, s, r = O.batch_graphs(n_node, n_edge, sl, rl, [6, 0, 3])
+    n = int(nn.sum())
+    rng = np.random.default_rng(7)
+    for concat, div, res in [(True, False, False), (False, True, True)]:
+        d, t = 8, (1 if res else 2)      # residual feeds x straight into s: keep that flow shallow
+        p = O.make_attn_grevnet_params(3, d // 2, 24, 3, t, num_heads=4, kq_dim=5, v_dim=6, out_dim=12,
+                                       concat=concat, kq_dim_division=div, residual=res, final_scale=0.5)
+        x = (rng.standard_normal((n, d)) * (0.3 if res else 1.0)).astype(np.float32)
+        a = O.Fp64Dense(s, r, n, activation="relu")
+        b = O.Fp32Gather(s, r, n, activation="relu")
+        ra = a.log_prob(x, p, t)
+        rb = b.log_prob(b.to_t(x), b.prep_params(p), t)
+        assert abs(ra["log_prob_xs_per_node"] - rb["log_prob_xs_per_node"]) < 1e-5
+        np.testing.assert_allclose(rb["z"].numpy(), ra["z"], atol=3e-5, rtol=3e-5)
+        np.testing.assert_allclose(a.g(ra["z"], p, t), x, atol=1e-9)
+
+
+def test_attention_reduces_to_mean_aggregation_when_logits_are_constant():
+    """Wq = 0 -> every logit is 0 -> softmax weights = 1/in-degree -> the attended value is the MEAN of
+    the senders' values: with Wv = I, one head and Wo = I the block equals avg_concat_then_mlp."""
+    s, r, n = tiny_graph()
+    h = 3
+    x = np.random.default_rng(0).standard_normal((n, h))
+    mlp = O.make_mlp_params(np.random.default_rng(1), 2 * h, 8, h, 2, dtype=np.float64)
+    net = {"attn": {"num_heads": 1, "kq_dim": 2, "v_dim": h, "concat": True, "kq_dim_division": False,
+                    "residual": False, "wq": np.zeros((h, 2)), "wk": np.ones((h, 2)), "wv": np.eye(h),
+                    "wo": np.eye(h)}, "mlp": mlp}
+    got = O.Fp64Dense(s, r, n, activation="relu").gnn(x, net)
+    want = O.Fp64Dense(s, r, n, agg="mean", combine="concat", activation="relu").gnn(x, mlp)
+    np.testing.assert_allclose(got, want, atol=1e-12)
+
+
+def test_attention_hand_computed_two_edges():
+    """node 1 receives from node 0 and itself; one head, kq = 1: weights = softmax([q0*k1, q1*k1])."""
+    s_idx = np.array([0, 1, 0], np.int32)
+    r_idx = np.array([0, 1, 1], np.int32)
+    x = np.array([[2.0], [-1.0]])
+    net = {"attn": {"num_heads": 1, "kq_dim": 1, "v_dim": 1, "concat": False, "kq_dim_division": False,
+                    "residual": False, "wq": np.array([[0.5]]), "wk": np.array([[2.0]]),
+                    "wv": np.array([[3.0]]), "wo": np.array([[1.0]])},
+           "mlp": [(np.array([[1.0]]), np.array([0.0]))]}
+    out = O.Fp64Dense(s_idx, r_idx, 2, activation="relu").gnn(x, net)
+    q, k, v = 0.5 * x[:, 0], 2.0 * x[:, 0], 3.0 * x[:, 0]
+    l0, l1 = q[0] * k[1], q[1] * k[1]                  # sender 0 -> 1, sender 1 -> 1
+    w0, w1 = np.exp(l0) / (np.exp(l0) + np.exp(l1)), np.exp(l1) / (np.exp(l0) + np.exp(l1))
+    np.testing.assert_allclose(out[:, 0], [v[0], w0 * v[0] + w1 * v[1]], rtol=1e-13)
+
+
+def test_attention_logdet_equals_jacobian_logdet():
+    s, r, n = tiny_graph()
+    d, t = 4, 2
+    p = O.make_attn_grevnet_params(5, d // 2, 8, 2, t, num_heads=2, kq_dim=3, v_dim=2, out_dim=4,
+                                   final_scale=0.6, dtype=np.float64)
+    o = O.Fp32Gather(s, r, n, activation="relu", dtype=torch.float64)
+    pt = o.prep_params(p)
+    x = torch.as_tensor(np.random.default_rng(2).standard_normal((n, d)))
+    z, ld = o.f(x, pt, t)
+    jac = torch.autograd.functional.jacobian(lambda v: o.f(v.reshape(n, d), pt, t)[0].reshape(-1), x.reshape(-1))
+    assert abs(float(torch.linalg.slogdet(jac)[1]) - float(ld)) < 1e-9
