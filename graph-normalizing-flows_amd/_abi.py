@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 GNF_MAX_LAYERS = 8
-GNF_ABI_VERSION = 1
+GNF_ABI_VERSION = 2
 
 GNF_AGG_SUM, GNF_AGG_MEAN = 0, 1
 GNF_COMBINE_EPS, GNF_COMBINE_CONCAT = 0, 1
@@ -29,10 +29,17 @@ class GnfCsr(C.Structure):
                 ("n_edges", C.c_int64)]
 
 
+class GnfAttn(C.Structure):
+    _fields_ = [("num_heads", C.c_int32), ("kq_dim", C.c_int32), ("v_dim", C.c_int32), ("out_dim", C.c_int32),
+                ("concat", C.c_int32), ("kq_dim_division", C.c_int32), ("residual", C.c_int32),
+                ("reserved", C.c_int32), ("Wq", C.c_void_p), ("Wk", C.c_void_p), ("Wv", C.c_void_p),
+                ("Wo", C.c_void_p)]
+
+
 class GnfMlp(C.Structure):
     _fields_ = [("num_layers", C.c_int32), ("dims", C.c_int32 * (GNF_MAX_LAYERS + 1)),
                 ("W", C.c_void_p * GNF_MAX_LAYERS), ("b", C.c_void_p * GNF_MAX_LAYERS),
-                ("packed", C.c_void_p)]
+                ("packed", C.c_void_p), ("attn", C.POINTER(GnfAttn))]
 
 
 class GnfGnnSpec(C.Structure):

@@ -84,7 +84,22 @@ static int validate_pair(const GnfMlp* s, const GnfMlp* t, const GnfGnnSpec* g, 
     if (rc) return rc;
     rc = validate_mlp(t, "t_net");
     if (rc) return rc;
-    const int in0 = (g->combine == GNF_COMBINE_CONCAT) ? 2 * H : H;
+    if ((s->attn != nullptr) != (t->attn != nullptr)) {
+        set_error("s_net and t_net must both have (or both lack) an attention front-end");
+        return GNF_ESHAPE;
+    }
+    if (s->attn) {
+        rc = validate_attn(s->attn, s, H, "s_net");
+        if (rc) return rc;
+        rc = validate_attn(t->attn, t, H, "t_net");
+        if (rc) return rc;
+    }
+    if (s->num_layers != t->num_layers || memcmp(s->dims, t->dims, sizeof(int32_t) * (s->num_layers + 1))) {
+        // one make_gnn_fn builds both nets of a coupling (gnn.py:288-296): identical layer widths
+        set_error("s_net and t_net must have identical layer widths");
+        return GNF_ESHAPE;
+    }
+    const int in0 = s->attn ? s->dims[0] : ((g->combine == GNF_COMBINE_CONCAT) ? 2 * H : H);
     const GnfMlp* nets[2] = {s, t};
     for (int q = 0; q < 2; ++q) {
         const GnfMlp* m = nets[q];
@@ -107,8 +122,9 @@ WorkspacePlan plan_workspace(int64_t n_nodes, int32_t H, const GnfMlp* net, int3
     int lmax = 1;
     if (net)
         for (int j = 1; j < net->num_layers; ++j) lmax = lmax > net->dims[j] ? lmax : net->dims[j];
-    const int in0 = (combine == GNF_COMBINE_CONCAT) ? 2 * H : H;
-    p.scratch_floats = (size_t)n_nodes * (size_t)(in0 + 2 * lmax + 2 * H);
+    const int in0 = net ? net->dims[0] : ((combine == GNF_COMBINE_CONCAT) ? 2 * H : H);
+    p.base_floats = (size_t)n_nodes * (size_t)(in0 + 2 * lmax + 2 * H);
+    p.scratch_floats = p.base_floats + attn_scratch_floats(net ? net->attn : nullptr, n_nodes, in0);
     p.total_bytes = p.partial_bytes + p.scratch_floats * sizeof(float);
     return p;
 }
@@ -184,7 +200,15 @@ int gnf_gnn_apply_f32(const GnfCsr* csr, const GnfMlp* mlp, const GnfGnnSpec* gn
     if (rc) return rc;
     rc = validate_mlp(mlp, "gnf_gnn_apply_f32");
     if (rc) return rc;
-    const int in0 = (gnn->combine == GNF_COMBINE_CONCAT) ? 2 * H : H;
+    if (H < 1) {
+        set_error("gnf_gnn_apply_f32: H=%d", H);
+        return GNF_ESHAPE;
+    }
+    if (mlp->attn) {
+        rc = validate_attn(mlp->attn, mlp, H, "gnf_gnn_apply_f32");
+        if (rc) return rc;
+    }
+    const int in0 = mlp->attn ? mlp->dims[0] : ((gnn->combine == GNF_COMBINE_CONCAT) ? 2 * H : H);
     const int od = mlp->dims[mlp->num_layers];
     if (H < 1 || ldx < H || ldo < od || mlp->dims[0] != in0) {
         set_error("gnf_gnn_apply_f32: H=%d ldx=%lld ldo=%lld, MLP maps %d -> %d, needs input %d", H,

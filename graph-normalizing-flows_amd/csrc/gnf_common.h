@@ -57,7 +57,8 @@ struct WorkspacePlan {
     int64_t partial_stride;  // doubles per half-step
     int64_t n_halfsteps;
     size_t partial_bytes;    // (n_halfsteps * stride + kMaxGaussBlocks) * 8, 256-aligned
-    size_t scratch_floats;   // layered path activations
+    size_t scratch_floats;   // layered path activations (+ attention front-end region at its end)
+    size_t base_floats;      // offset of the attention region inside the scratch
     size_t total_bytes;
 };
 WorkspacePlan plan_workspace(int64_t n_nodes, int32_t H, const GnfMlp* net, int32_t combine,
@@ -67,8 +68,9 @@ WorkspacePlan plan_workspace(int64_t n_nodes, int32_t H, const GnfMlp* net, int3
 bool fused_supported(const HalfStep& hs);
 int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st);
 // coupling epilogue from global s / t [N, H] buffers (writes hs.partials, *hs.n_partials)
-int launch_coupling(const float* s, const float* t, const HalfStep& hs, hipStream_t st);
+int launch_coupling(const float* s, const float* t, const HalfStep& hs, const float* xres, hipStream_t st);
 int launch_half_layered(const HalfStep& hs, float* scratch, hipStream_t st);
+int launch_attn_pair(const HalfStep& hs, float* scratch, float** h0_pair, hipStream_t st);
 int launch_gnn_layered(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, const float* x,
                        int64_t ldx, int32_t H, const GnfGnnSpec& g, const GnfMlp* mlp, float* out,
                        int64_t ldo, float* scratch, hipStream_t st);
@@ -84,5 +86,13 @@ int launch_pack_mlp(const GnfMlp* mlp, float* packed, hipStream_t st);
 int64_t packed_floats(const GnfMlp* mlp);
 
 int validate_mlp(const GnfMlp* m, const char* what);
+// attention front-end (gnf_attn.hip)
+int validate_attn(const GnfAttn* at, const GnfMlp* mlp, int32_t H, const char* what);
+size_t attn_scratch_floats(const GnfAttn* at, int64_t n_nodes, int32_t in0);
+int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, const float* x, int64_t ldx,
+                      int32_t H, const GnfAttn* const* at, int nets, int32_t in0, float* scratch,
+                      float* const* h0_out, hipStream_t st);
+// dst[r, 0:W) += src[r, 0:W)
+int launch_add_rows(float* dst, int64_t ldd, const float* src, int64_t lds_, int64_t n, int32_t W, hipStream_t st);
 
 }  // namespace gnf

@@ -108,6 +108,7 @@ struct FusedArgs {
     float* x_upd;
     double* partials;
     float* st_out[2];                    // NETS = 1: global [N, H] scratch for s (0) and t (1)
+    const float* h0[2];                  // precomputed layer-0 input per net ([N, in0], attention GNNs) or NULL
     const float* wp[2][GNF_MAX_LAYERS];  // [net][layer] packed weights
     const float* bias[2];                // [net] contiguous padded bias block (bias_tot floats)
     int32_t ipg[GNF_MAX_LAYERS];         // padded input width / 16 of layer j
@@ -122,6 +123,7 @@ struct FusedArgs {
     int32_t LS;        // LDS row stride (floats)
     int32_t bias_tot;  // floats of bias per net in LDS
     int32_t mean, concat, act, inverse;
+    int32_t residual;  // attention block with residual: s, t += x_cond (gnn.py:547-548)
     float eps, alpha;
 };
 
@@ -489,6 +491,17 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
     GNF_PSTAMP(2);
     __syncthreads();
     GNF_PSTAMP(3);
+    if (a.h0[0] != nullptr) {
+        // attention GNNs: the layer-0 input of each net was produced by the attention front-end
+        const int in0p = a.ipg[0] * 16;
+        for (int idx = tid; idx < TM * in0p; idx += kFusedThreads) {
+            const int rl = idx / in0p, c = idx - rl * in0p;
+            const int r = row0 + rl;
+            const bool live = r < a.n_nodes && c < a.in0;
+            buf(0, 0)[rl * LS + c] = live ? a.h0[net0][(int64_t)r * a.in0 + c] : 0.f;
+            if (NETS == 2) buf(1, 0)[rl * LS + c] = live ? a.h0[1][(int64_t)r * a.in0 + c] : 0.f;
+        }
+    } else {
     const int seg_beg = s_rowptr[0];
     const int seg_len = s_rowptr[TM] - seg_beg;
 #ifdef GNF_NO_STAGE_CSR
@@ -555,6 +568,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
             if (NETS == 2) buf(1, 0)[rl * LS + c] = v;
         }
     }
+    }  // message-passing prologue
     GNF_STAMP(1);
     __syncthreads();
     GNF_STAMP(2);
@@ -597,7 +611,8 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
         for (int idx = tid; idx < TM * H; idx += kFusedThreads) {
             const int rl = idx / H, f = idx - rl * H;
             const int r = row0 + rl;
-            if (r < a.n_nodes) dst[(int64_t)r * H + f] = o_lds[rl * LS + f];
+            if (r < a.n_nodes)
+                dst[(int64_t)r * H + f] = o_lds[rl * LS + f] + (a.residual ? a.x_cond[(int64_t)r * a.ld + f] : 0.f);
         }
     } else {
         // ---- C: coupling update + block-reduced sum(s) -----------------------------------------
@@ -608,7 +623,12 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
             const int rl = idx / H, f = idx - rl * H;
             const int r = row0 + rl;
             if (r < a.n_nodes) {
-                const float sv = s_lds[rl * LS + f], tv = t_lds[rl * LS + f];
+                float sv = s_lds[rl * LS + f], tv = t_lds[rl * LS + f];
+                if (a.residual) {
+                    const float xr = a.x_cond[(int64_t)r * a.ld + f];
+                    sv += xr;
+                    tv += xr;
+                }
                 float* px = a.x_upd + (int64_t)r * a.ld + f;
                 const float xv = *px;
                 *px = a.inverse ? (xv - tv) * expf(-sv) : xv * expf(sv) + tv;
@@ -720,6 +740,16 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
     // NETS = 1 scratch: s [N,H] | t [N,H] at the head of the float scratch
     a.st_out[0] = scratch;
     a.st_out[1] = scratch + hs.n_nodes * hs.H;
+    a.h0[0] = a.h0[1] = nullptr;
+    a.residual = 0;
+    if (s->attn) {
+        float* h0_pair[2];
+        const int rc0 = launch_attn_pair(hs, scratch, h0_pair, st);
+        if (rc0) return rc0;
+        a.h0[0] = h0_pair[0];
+        a.h0[1] = h0_pair[1];
+        a.residual = s->attn->residual ? 1 : 0;
+    }
     int64_t off = 0;
     int boff = 0;
     for (int j = 0; j < s->num_layers; ++j) {
@@ -761,7 +791,7 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
     const unsigned grid = (unsigned)(8 * ((tiles + 3) / 4));  // 4 tile slots x 2 nets per group of 8 blocks
     rc = MT == 2 ? launch_shape<2, 1>(a, grid, lds, st) : launch_shape<1, 1>(a, grid, lds, st);
     if (rc) return rc;
-    return launch_coupling(a.st_out[0], a.st_out[1], hs, st);
+    return launch_coupling(a.st_out[0], a.st_out[1], hs, nullptr, st);  // residual already added above
 }
 
 }  // namespace gnf

@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void k_coupling(const float* __restrict__ s,
                                                   const float* __restrict__ t, int64_t lds_,
                                                   float* __restrict__ x_upd, int64_t ld,
                                                   int64_t n_nodes, int H, int inverse,
-                                                  double* __restrict__ partials) {
+                                                  double* __restrict__ partials,
+                                                  const float* __restrict__ xres) {
     __shared__ double sh[4];
     const int64_t total = n_nodes * H;
     const int64_t per_block = ((total + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
@@ -200,7 +201,12 @@ __global__ __launch_bounds__(256) void k_coupling(const float* __restrict__ s,
     for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
         const int64_t r = i / H;
         const int f = (int)(i - r * H);
-        const float sv = s[r * lds_ + f], tv = t[r * lds_ + f];
+        float sv = s[r * lds_ + f], tv = t[r * lds_ + f];
+        if (xres) {  // attention block with residual (gnn.py:547-548): both nets' outputs += x_cond
+            const float xr = xres[r * ld + f];
+            sv += xr;
+            tv += xr;
+        }
         const float xv = x_upd[r * ld + f];
         x_upd[r * ld + f] = inverse ? (xv - tv) * expf(-sv) : xv * expf(sv) + tv;
         local += (double)sv;
@@ -293,47 +299,111 @@ static int run_mlp(const GnfMlp* m, const float* h0, int64_t ld0, float* bufA, f
     return GNF_OK;
 }
 
-// One GNN module call: scratch = h0 [N, in0] | bufA [N, Lmax] | bufB [N, Lmax]
+__global__ __launch_bounds__(256) void k_add_rows(float* __restrict__ dst, int64_t ldd,
+                                                  const float* __restrict__ src, int64_t lds_, int64_t n, int W) {
+    const int64_t total = n * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / W;
+        const int f = (int)(i - r * W);
+        dst[r * ldd + f] += src[r * lds_ + f];
+    }
+}
+
+int launch_add_rows(float* dst, int64_t ldd, const float* src, int64_t lds_, int64_t n, int32_t W, hipStream_t st) {
+    if (n == 0) return GNF_OK;
+    int64_t blocks = (n * W + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_add_rows, dim3((unsigned)blocks), dim3(256), 0, st, dst, ldd, src, lds_, n, W);
+    GNF_LAUNCH_CHECK("k_add_rows");
+    return GNF_OK;
+}
+
+static int lmax_of(const GnfMlp* m) {
+    int lmax = 1;
+    for (int j = 1; j < m->num_layers; ++j) lmax = lmax > m->dims[j] ? lmax : m->dims[j];
+    return lmax;
+}
+
+// One GNN module call: scratch = h0 [N, in0] | bufA [N, Lmax] | bufB [N, Lmax] | (s, t unused) | attention region
 int launch_gnn_layered(const int32_t* rowptr, const int32_t* col, int64_t n, const float* x,
                        int64_t ldx, int32_t H, const GnfGnnSpec& g, const GnfMlp* mlp, float* out,
                        int64_t ldo, float* scratch, hipStream_t st) {
     const int in0 = mlp->dims[0];
-    int lmax = 1;
-    for (int j = 1; j < mlp->num_layers; ++j) lmax = lmax > mlp->dims[j] ? lmax : mlp->dims[j];
+    const int lmax = lmax_of(mlp);
     float* h0 = scratch;
     float* bufA = h0 + n * in0;
     float* bufB = bufA + n * lmax;
-    int rc = launch_aggregate(rowptr, col, n, x, ldx, H, g.agg == GNF_AGG_MEAN,
+    int rc;
+    if (mlp->attn) {
+        float* attn_scratch = scratch + (size_t)n * (size_t)(in0 + 2 * lmax + 2 * H);
+        const GnfAttn* at[1] = {mlp->attn};
+        float* h0s[1] = {h0};
+        rc = launch_attn_front(rowptr, col, n, x, ldx, H, at, 1, in0, attn_scratch, h0s, st);
+    } else {
+        rc = launch_aggregate(rowptr, col, n, x, ldx, H, g.agg == GNF_AGG_MEAN,
                               g.combine == GNF_COMBINE_CONCAT ? 1 : 0, g.epsilon, h0, in0, st);
+    }
     if (rc) return rc;
-    return run_mlp(mlp, h0, in0, bufA, bufB, lmax, out, ldo, n, g, st);
+    rc = run_mlp(mlp, h0, in0, bufA, bufB, lmax, out, ldo, n, g, st);
+    if (rc) return rc;
+    if (mlp->attn && mlp->attn->residual) return launch_add_rows(out, ldo, x, ldx, n, H, st);
+    return GNF_OK;
 }
 
+// scratch layout (floats): h0 [N,in0] | bufA | bufB | s [N,H] | t [N,H] | attention region: qkv x2, h0_s, h0_t
 int launch_half_layered(const HalfStep& hs, float* scratch, hipStream_t st) {
     const int64_t n = hs.n_nodes;
     *hs.n_partials = 0;
     if (n == 0) return GNF_OK;
     const int H = hs.H;
     const int in0 = hs.s_net->dims[0];
-    int lmax = 1;
-    for (int j = 1; j < hs.s_net->num_layers; ++j) lmax = lmax > hs.s_net->dims[j] ? lmax : hs.s_net->dims[j];
-    for (int j = 1; j < hs.t_net->num_layers; ++j) lmax = lmax > hs.t_net->dims[j] ? lmax : hs.t_net->dims[j];
+    int lmax = lmax_of(hs.s_net);
+    const int lt = lmax_of(hs.t_net);
+    lmax = lmax > lt ? lmax : lt;
     float* h0 = scratch;
     float* bufA = h0 + n * in0;
     float* bufB = bufA + n * lmax;
     float* sbuf = bufB + n * lmax;
     float* tbuf = sbuf + n * H;
-    int rc = launch_aggregate(hs.rowptr, hs.col, n, hs.x_cond, hs.ld, H, hs.gnn.agg == GNF_AGG_MEAN,
+    const float* h0s = h0;
+    const float* h0t = h0;
+    int rc;
+    if (hs.s_net->attn) {
+        float* h0_pair[2];
+        rc = launch_attn_pair(hs, scratch, h0_pair, st);
+        h0s = h0_pair[0];
+        h0t = h0_pair[1];
+    } else {
+        rc = launch_aggregate(hs.rowptr, hs.col, n, hs.x_cond, hs.ld, H, hs.gnn.agg == GNF_AGG_MEAN,
                               hs.gnn.combine == GNF_COMBINE_CONCAT ? 1 : 0, hs.gnn.epsilon, h0, in0, st);
+    }
     if (rc) return rc;
-    rc = run_mlp(hs.s_net, h0, in0, bufA, bufB, lmax, sbuf, H, n, hs.gnn, st);
+    rc = run_mlp(hs.s_net, h0s, in0, bufA, bufB, lmax, sbuf, H, n, hs.gnn, st);
     if (rc) return rc;
-    rc = run_mlp(hs.t_net, h0, in0, bufA, bufB, lmax, tbuf, H, n, hs.gnn, st);
+    rc = run_mlp(hs.t_net, h0t, in0, bufA, bufB, lmax, tbuf, H, n, hs.gnn, st);
     if (rc) return rc;
-    return launch_coupling(sbuf, tbuf, hs, st);
+    const bool res = hs.s_net->attn && hs.s_net->attn->residual;
+    return launch_coupling(sbuf, tbuf, hs, res ? hs.x_cond : nullptr, st);
 }
 
-int launch_coupling(const float* sbuf, const float* tbuf, const HalfStep& hs, hipStream_t st) {
+// Attention front-end of BOTH nets of a half-step into the scratch's attention region; returns the two
+// h0 pointers ([N, in0] each).
+int launch_attn_pair(const HalfStep& hs, float* scratch, float** h0_pair, hipStream_t st) {
+    const int64_t n = hs.n_nodes;
+    const int in0 = hs.s_net->dims[0];
+    int lmax = lmax_of(hs.s_net);
+    const int lt = lmax_of(hs.t_net);
+    lmax = lmax > lt ? lmax : lt;
+    float* region = scratch + (size_t)n * (size_t)(in0 + 2 * lmax + 2 * hs.H);
+    const GnfAttn* a0 = hs.s_net->attn;
+    const size_t P = 2 * (size_t)a0->num_heads * a0->kq_dim + a0->v_dim;
+    h0_pair[0] = region + 2 * (size_t)n * P;
+    h0_pair[1] = h0_pair[0] + (size_t)n * in0;
+    const GnfAttn* at[2] = {hs.s_net->attn, hs.t_net->attn};
+    return launch_attn_front(hs.rowptr, hs.col, n, hs.x_cond, hs.ld, hs.H, at, 2, in0, region, h0_pair, st);
+}
+
+int launch_coupling(const float* sbuf, const float* tbuf, const HalfStep& hs, const float* xres, hipStream_t st) {
     const int64_t n = hs.n_nodes;
     const int H = hs.H;
     int64_t blocks = (n * H + 256 * 4 - 1) / (256 * 4);
@@ -341,7 +411,7 @@ int launch_coupling(const float* sbuf, const float* tbuf, const HalfStep& hs, hi
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_coupling, dim3((unsigned)blocks), dim3(256), 0, st, sbuf, tbuf, (int64_t)H,
-                       hs.x_upd, hs.ld, n, H, hs.direction == GNF_INVERSE ? 1 : 0, hs.partials);
+                       hs.x_upd, hs.ld, n, H, hs.direction == GNF_INVERSE ? 1 : 0, hs.partials, xres);
     GNF_LAUNCH_CHECK("k_coupling");
     *hs.n_partials = (int32_t)blocks;
     return GNF_OK;

@@ -189,6 +189,18 @@ class _NodeBlock:
     def in_dim(self, h):
         return 2 * h if self.combine == _abi.GNF_COMBINE_CONCAT else h
 
+    def signature(self):
+        """What must be identical across the s/t GNNs of one GRevNet (they come from one make_gnn_fn)."""
+        return (type(self).__name__, self.combine, self._agg, float(getattr(self, "epsilon", 0.0)),
+                self._mlp.act_code, self._mlp.alpha)
+
+    def attn_version(self):
+        return 0
+
+    def attn_desc(self, h, device):
+        """ctypes GnfAttn of the attention front-end, or None for the message-passing blocks."""
+        return None
+
     def _build(self, graph):
         """One GNN evaluation outside a coupling: gnf_gnn_apply_f32."""
         lib = _abi.lib()
@@ -200,6 +212,9 @@ class _NodeBlock:
         mlp = self._mlp.ensure_built(self.in_dim(h), x.device)
         desc = _abi.GnfMlp()
         mlp.fill_desc(desc, 0)
+        attn = self.attn_desc(h, x.device)          # kept alive until the call returns
+        if attn is not None:
+            desc.attn = C.pointer(attn)
         spec = self.spec()
         csr = csr_of(graph)
         out = torch.empty(n, mlp.layer_sizes[-1], dtype=torch.float32, device=x.device)
@@ -235,6 +250,103 @@ class AggThenMLPBlock(_NodeBlock):
         self.name = name
 
 
+class DMSelfAttentionMLP(_NodeBlock):
+    """gnn.py:480-553 (with DMSelfAttention, gnn.py:385-477, fused in): edge-list multi-head
+    self-attention over the incoming edges of every node, heads concatenated and projected to
+    `concat_heads_output_dim`, optionally concatenated with the node's own features, then the MLP.
+    It is a GNN module by itself (the reference does not wrap it in NodeBlockGNN, gnn.py:556-573).
+    `layer_norm=True` is not supported.  Weights (all [in, out], no bias, gnn.py:509-540):
+    wq, wk [H, heads*kq], wv [H, v], wo [heads*v, C]; created at first connection like Sonnet does
+    (xavier-uniform for q/k/v, gnn.py:504-506; Sonnet's default 1/sqrt(fan_in) truncated normal for wo)."""
+    combine = _abi.GNF_COMBINE_EPS   # unused by attention nets
+    _agg = _abi.GNF_AGG_SUM          # unused by attention nets
+
+    def __init__(self, kq_dim, v_dim, make_mlp_fn, num_heads=8, concat_heads_output_dim=20, concat=True,
+                 residual=False, layer_norm=False, kq_dim_division=False, name="dm_self_attention"):
+        if layer_norm:
+            raise NotImplementedError("DMSelfAttentionMLP(layer_norm=True) (snt.LayerNorm, gnn.py:550-552) is not supported")
+        self.kq_dim = int(kq_dim)
+        self.v_dim = int(v_dim)
+        self.mlp = make_mlp_fn()
+        self._mlp = self.mlp
+        self.num_heads = int(num_heads)
+        self.concat_heads_output_dim = int(concat_heads_output_dim)
+        self.concat = bool(concat)
+        self.residual = bool(residual)
+        self.layer_norm = False
+        self.kq_dim_division = bool(kq_dim_division)
+        self.name = name
+        self.attn_params = None     # {"wq", "wk", "wv", "wo"} fp32 tensors
+        self._attn_version = 0
+
+    def in_dim(self, h):
+        return (h if self.concat else 0) + self.concat_heads_output_dim
+
+    def signature(self):
+        return (type(self).__name__, self.num_heads, self.kq_dim, self.v_dim, self.concat_heads_output_dim,
+                self.concat, self.residual, self.kq_dim_division, self._mlp.act_code, self._mlp.alpha)
+
+    def attn_version(self):
+        return self._attn_version
+
+    def _shapes(self, h):
+        nq = self.num_heads * self.kq_dim
+        return {"wq": (h, nq), "wk": (h, nq), "wv": (h, self.v_dim),
+                "wo": (self.num_heads * self.v_dim, self.concat_heads_output_dim)}
+
+    def ensure_attn_built(self, h, device):
+        if self.attn_params is None:
+            p = {}
+            for key, (fi, fo) in self._shapes(h).items():
+                w = torch.empty(fi, fo)
+                if key == "wo":
+                    std = 1.0 / math.sqrt(fi)
+                    torch.nn.init.trunc_normal_(w, 0.0, std, -2 * std, 2 * std, generator=_GEN)
+                else:
+                    a = math.sqrt(6.0 / (fi + fo))
+                    w.uniform_(-a, a, generator=_GEN)
+                p[key] = w
+            self.attn_params = p
+            self._attn_version += 1
+        for key, shp in self._shapes(h).items():
+            if tuple(self.attn_params[key].shape) != shp:
+                raise ValueError(f"{self.name}: {key} has shape {tuple(self.attn_params[key].shape)}, expected {shp}")
+        if self.attn_params["wq"].device != torch.device(device):
+            self.attn_params = {k: v.to(device) for k, v in self.attn_params.items()}
+            self._attn_version += 1
+        return self
+
+    def set_attn_params(self, attn):
+        """attn: dict with wq, wk, wv, wo (numpy or torch, [in, out]); other keys are ignored."""
+        p = {}
+        for key in ("wq", "wk", "wv", "wo"):
+            w = attn[key]
+            w = torch.as_tensor(np.asarray(w) if not isinstance(w, torch.Tensor) else w).to(torch.float32).contiguous()
+            if w.ndim != 2:
+                raise ValueError(f"{self.name}: {key} must be 2-D [in, out]")
+            p[key] = w
+        self.attn_params = p
+        self._attn_version += 1
+        return self
+
+    def get_attn_params(self):
+        return None if self.attn_params is None else {k: v.detach().cpu().numpy().copy() for k, v in self.attn_params.items()}
+
+    def attn_desc(self, h, device):
+        self.ensure_attn_built(h, device)
+        p = self.attn_params
+        return _abi.GnfAttn(self.num_heads, self.kq_dim, self.v_dim, self.concat_heads_output_dim,
+                            int(self.concat), int(self.kq_dim_division), int(self.residual), 0,
+                            p["wq"].data_ptr(), p["wk"].data_ptr(), p["wv"].data_ptr(), p["wo"].data_ptr())
+
+
+def dm_self_attn_gnn(kq_dim, v_dim, make_mlp_fn, num_heads, concat_heads_output_dim, concat=True,
+                     residual=False, layer_norm=False, kq_dim_division=False):      # gnn.py:556-573
+    return DMSelfAttentionMLP(kq_dim=kq_dim, v_dim=v_dim, make_mlp_fn=make_mlp_fn, num_heads=num_heads,
+                              concat_heads_output_dim=concat_heads_output_dim, concat=concat,
+                              residual=residual, layer_norm=layer_norm, kq_dim_division=kq_dim_division)
+
+
 class IdentityModule:
     """gnn.py:130-132: the edge model (edges[e] = nodes[senders[e]]); fused away in the kernels."""
 
@@ -255,9 +367,9 @@ class NodeBlockGNN:
     to edges, which the CSR gather inside the kernels does without materialising [E, H]."""
 
     def __init__(self, node_block, edge_block_opt=EDGE_BLOCK_OPT, name="NodeBlockGNN"):
-        if not isinstance(node_block, _NodeBlock):
+        if not isinstance(node_block, (AggThenMLPBlock, ConcatThenMLPBlock)):
             raise TypeError("NodeBlockGNN supports AggThenMLPBlock / ConcatThenMLPBlock node blocks "
-                            "(GRU / attention blocks are outside the hot path, SURVEY.md 8f)")
+                            "(GRU and dense attention blocks are outside the hot path, SURVEY.md 8f)")
         if dict(edge_block_opt) != EDGE_BLOCK_OPT:
             raise ValueError("only the reference's EDGE_BLOCK_OPT (sender nodes only) is supported")
         self._node_block = node_block
@@ -318,27 +430,40 @@ class GRevNet:
         nets = self.s if kind == "s" else self.t
         return [nets[0], nets[1]] if self.weight_sharing else list(nets[0]) + list(nets[1])
 
+    @staticmethod
+    def _block_of(g):
+        return g._node_block if isinstance(g, NodeBlockGNN) else g
+
+    def blocks(self, kind):
+        """Flat list of node blocks in ABI order: index half*T + i (or half with weight sharing)."""
+        return [self._block_of(g) for g in self._gnns(kind)]
+
     def _blocks(self):
-        return [g._node_block for g in self._gnns("s") + self._gnns("t")]
+        return self.blocks("s") + self.blocks("t")
 
     def mlps(self, kind):
         """Flat list of MLPs in ABI order: index half*T + i (or half with weight sharing)."""
-        return [g._node_block._mlp for g in self._gnns(kind)]
+        return [b._mlp for b in self.blocks(kind)]
 
     def set_params(self, params):
         """params in the oracle / fixture layout: {"s": [[mlp]*T, [mlp]*T], "t": ...} or, with weight
         sharing, {"s": [mlp, mlp], "t": [mlp, mlp]}; mlp = [(W[in,out], b[out]), ...]."""
         for kind in ("s", "t"):
             flat = list(params[kind]) if self.weight_sharing else list(params[kind][0]) + list(params[kind][1])
-            for mlp, layers in zip(self.mlps(kind), flat):
-                mlp.set_params(layers)
+            for blk, net in zip(self.blocks(kind), flat):
+                if isinstance(net, dict):       # attention net: {"attn": {wq, wk, wv, wo, ...}, "mlp": [...]}
+                    blk.set_attn_params(net["attn"])
+                    blk._mlp.set_params(net["mlp"])
+                else:
+                    blk._mlp.set_params(net)
         self._cache = None
         return self
 
     def get_params(self):
         out = {}
         for kind in ("s", "t"):
-            flat = [m.get_params() for m in self.mlps(kind)]
+            flat = [({"attn": b.get_attn_params(), "mlp": b._mlp.get_params()} if isinstance(b, DMSelfAttentionMLP)
+                     else b._mlp.get_params()) for b in self.blocks(kind)]
             t = self.num_timesteps
             out[kind] = flat if self.weight_sharing else [flat[:t], flat[t:]]
         return out
@@ -352,16 +477,21 @@ class GRevNet:
         blocks = self._blocks()
         b0 = blocks[0]
         for b in blocks:
-            if (b.combine, b._agg, float(getattr(b, "epsilon", 0.0)), b._mlp.act_code, b._mlp.alpha) != \
-               (b0.combine, b0._agg, float(getattr(b0, "epsilon", 0.0)), b0._mlp.act_code, b0._mlp.alpha):
+            if b.signature() != b0.signature():
                 raise ValueError("all s/t GNNs of a GRevNet must come from the same make_gnn_fn")
         s_mlps = [m.ensure_built(b0.in_dim(hdim), device) for m in self.mlps("s")]
         t_mlps = [m.ensure_built(b0.in_dim(hdim), device) for m in self.mlps("t")]
-        key = (str(device), hdim, bool(self.fused), tuple(m.version for m in s_mlps + t_mlps))
+        attn_descs = [b.attn_desc(hdim, device) for b in blocks]          # None for message-passing blocks
+        key = (str(device), hdim, bool(self.fused), tuple(m.version for m in s_mlps + t_mlps),
+               tuple(b.attn_version() for b in blocks))
         if self._cache is not None and self._cache[0] == key:
             return self._cache[1]
         n = len(s_mlps)
         s_arr, t_arr = (_abi.GnfMlp * n)(), (_abi.GnfMlp * n)()
+        attn_arr = (_abi.GnfAttn * (2 * n))()
+        for q, ad in enumerate(attn_descs):
+            if ad is not None:
+                attn_arr[q] = ad
         sizes = [m.packed_floats() for m in s_mlps + t_mlps]
         packed = torch.empty(max(sum(sizes), 1), dtype=torch.float32, device=device)
         off = 0
@@ -370,6 +500,9 @@ class GRevNet:
             for arr, mlps in ((s_arr, s_mlps), (t_arr, t_mlps)):
                 for q, m in enumerate(mlps):
                     m.fill_desc(arr[q], packed.data_ptr() + 4 * off if self.fused else 0)
+                    aq = q + (0 if arr is s_arr else n)
+                    if attn_descs[aq] is not None:
+                        arr[q].attn = C.cast(C.byref(attn_arr, aq * C.sizeof(_abi.GnfAttn)), C.POINTER(_abi.GnfAttn))
                     if lib.gnf_packed_floats(C.byref(arr[q])) != m.packed_floats():
                         raise _abi.GnfError("packed size mismatch between binding and library")
                     if self.fused:
@@ -379,7 +512,7 @@ class GRevNet:
         flow = _abi.GnfFlow(self.num_timesteps, int(self.weight_sharing),
                             C.cast(s_arr, C.POINTER(_abi.GnfMlp)), C.cast(t_arr, C.POINTER(_abi.GnfMlp)),
                             b0.spec())
-        self._cache = (key, flow, (s_arr, t_arr, packed, s_mlps, t_mlps))
+        self._cache = (key, flow, (s_arr, t_arr, attn_arr, packed, s_mlps, t_mlps, blocks))
         return flow
 
     def _run(self, graph, direction, sums_out=None):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GNF_ABI_VERSION 1
+#define GNF_ABI_VERSION 2
 #define GNF_MAX_LAYERS 8 /* Linear layers per MLP (gnn.py:165-166 builds num_layers of them) */
 
 typedef void* gnf_stream_t; /* hipStream_t */
@@ -59,6 +59,30 @@ typedef struct GnfCsr {
     int64_t n_edges;       /* E = sum(n_edge), self loops included */
 } GnfCsr;
 
+/* Optional attention front-end of a net: DMSelfAttentionMLP (gnn.py:480-553) around DMSelfAttention
+ * (gnn.py:385-477), the reference drivers' default make_gnn_fn (run_grevnet.py:56,199-211).  With it,
+ * the MLP input is [x || new] (concat) or new, new = reshape(attended, heads*v) @ Wo:
+ *   q = x Wq, k = x Wk [N, heads, kq]; v = x Wv [N, v] repeated over heads;
+ *   logit[e,h] = <q[sender e, h], k[receiver e, h]> (/ sqrt(kq) if kq_dim_division);
+ *   softmax over each receiver's incoming edges; attended[r,h] = sum_e w[e,h] v[sender e].
+ * All weights device, row-major [in, out] like snt.Linear(use_bias=False) (gnn.py:509-540).
+ * GnfGnnSpec.agg / combine / epsilon are ignored for such a net; activation / alpha still apply to
+ * the MLP.  residual: MLP output += x (gnn.py:547-548).  layer_norm is not supported. */
+typedef struct GnfAttn {
+    int32_t num_heads;       /* 1..64 */
+    int32_t kq_dim;          /* 1..32 */
+    int32_t v_dim;           /* 1..32 */
+    int32_t out_dim;         /* concat_heads_output_dim */
+    int32_t concat;          /* attn_concat */
+    int32_t kq_dim_division; /* divide logits by sqrt(kq_dim) */
+    int32_t residual;
+    int32_t reserved;
+    const float* Wq; /* [H, num_heads*kq_dim] */
+    const float* Wk; /* [H, num_heads*kq_dim] */
+    const float* Wv; /* [H, v_dim] */
+    const float* Wo; /* [num_heads*v_dim, out_dim] */
+} GnfAttn;
+
 /* One snt.nets.MLP (gnn.py:159-180): num_layers Linear layers, y = x @ W + b, W row-major [in,out];
  * activation between layers, none after the last (activate_final=False, gnn.py:179). */
 typedef struct GnfMlp {
@@ -67,6 +91,8 @@ typedef struct GnfMlp {
     const float* W[GNF_MAX_LAYERS];   /* device, [dims[j], dims[j+1]] row-major */
     const float* b[GNF_MAX_LAYERS];   /* device, [dims[j+1]] */
     const float* packed;              /* device buffer written by gnf_pack_mlp (MFMA fragment order), or NULL */
+    const GnfAttn* attn;              /* HOST pointer: attention front-end of this net, or NULL for the
+                                         message-passing blocks described by GnfGnnSpec */
 } GnfMlp;
 
 /* What a make_gnn_fn() product does around its MLP (gnn.py:238-257). */

@@ -30,6 +30,14 @@ def load(name):
     return d["n_node"], d["n_edge"], d["senders"], d["receivers"]
 
 
+# attention cases: (name, dataset, ids, D, latent, K, T, attention kwargs, weight_sharing, final_scale)
+ATTN_CASES = [
+    ("attn_cfg1_grid_small", "grid_small", [6, 2], 8, 32, 3, 2,
+     dict(num_heads=8, kq_dim=10, v_dim=10, out_dim=80, concat=True, kq_dim_division=False, residual=False), False, 0.5),
+    ("attn_small_community_noconcat_div", "community_medium", None, 12, 24, 2, 2,
+     dict(num_heads=3, kq_dim=7, v_dim=5, out_dim=20, concat=False, kq_dim_division=True, residual=False), True, 0.4),
+]
+
 CASES = [
     # name, dataset, graph ids, D, latent, K, T, agg, combine, eps, activation, weight_sharing, final_scale
     ("cfg1_grid_small_d2", "grid_small", [6], 2, 16, 3, 1, "mean", "agg", 1.0, "leaky_relu", False, 0.5),
@@ -76,5 +84,44 @@ def main():
               f"logdet={res['log_det_jacobian']:.4f} -> {os.path.getsize(path)} B")
 
 
+def main_attn():
+    for (name, ds, ids, d, latent, k, t, akw, ws, fscale) in ATTN_CASES:
+        n_node, n_edge, sl, rl = load(ds)
+        rng = np.random.default_rng(12345)
+        if ids is None:
+            ids = rng.choice(int(0.8 * len(n_node)), size=6, replace=True).tolist()
+        nn, ne, s, r = O.batch_graphs(n_node, n_edge, sl, rl, ids)
+        n = int(nn.sum())
+        x = rng.standard_normal((n, d)).astype(np.float32)
+        p = O.make_attn_grevnet_params(2025, d // 2, latent, k, t, weight_sharing=ws, final_scale=fscale, **akw)
+        o64 = O.Fp64Dense(s, r, n, activation="relu")          # attention GNNs use tf.nn.relu (run_grevnet.py:205)
+        res = o64.log_prob(x, p, t, ws)
+        o32 = O.Fp32Gather(s, r, n, activation="relu")
+        r32 = o32.log_prob(o32.to_t(x), o32.prep_params(p), t, ws)
+        assert abs(res["log_prob_xs_per_node"] - r32["log_prob_xs_per_node"]) < 1e-5, name
+        assert np.abs(r32["z"].numpy() - res["z"]).max() < 5e-5, name
+        xr = o64.g(res["z"], p, t, ws)
+        assert np.abs(xr - x).max() < 1e-9
+        blob = dict(n_node=nn, n_edge=ne, senders=s, receivers=r, x=x, D=d, latent=latent, K=k, T=t,
+                    agg="mean", combine="agg", epsilon=0.0, activation="relu", weight_sharing=ws, gnn="dm_self_attn",
+                    z=res["z"], logdet=res["log_det_jacobian"], log_prob_zs=res["log_prob_zs"],
+                    log_prob_xs=res["log_prob_xs"], log_prob_xs_per_node=res["log_prob_xs_per_node"],
+                    x_roundtrip=xr, **{"attn_" + kk: vv for kk, vv in akw.items()})
+        for kind in ("s", "t"):
+            for half in range(2):
+                nets = [p[kind][half]] if ws else p[kind][half]
+                for i, net in enumerate(nets):
+                    for key in ("wq", "wk", "wv", "wo"):
+                        blob[f"a_{kind}_{half}_{i}_{key}"] = net["attn"][key]
+                    for j, (w, b) in enumerate(net["mlp"]):
+                        blob[f"w_{kind}_{half}_{i}_{j}"] = w
+                        blob[f"b_{kind}_{half}_{i}_{j}"] = b
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **blob)
+        print(f"{name}: N={n} E={len(s)} per-node log-prob={res['log_prob_xs_per_node']:.6f} "
+              f"logdet={res['log_det_jacobian']:.4f} -> {os.path.getsize(path)} B")
+
+
 if __name__ == "__main__":
     main()
+    main_attn()

@@ -4,7 +4,9 @@ import numpy as np
 import pytest
 
 from oracle import gnf_oracle as O
-from helpers import GOLDEN_CASES, load_golden
+from helpers import ATTN_GOLDEN_CASES, GOLDEN_CASES, load_golden
+
+GOLDEN_CASES = GOLDEN_CASES + ATTN_GOLDEN_CASES   # attention fixtures run through the same checks
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN_CASES, graph_from_arrays, load_golden, make_product_grevnet
+from helpers import ATTN_GOLDEN_CASES, GOLDEN_CASES, graph_from_arrays, load_golden, make_product_grevnet
 from oracle import gnf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -48,7 +48,7 @@ def _run_forward(net, graph):
 
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "layered"])
-@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("name", GOLDEN_CASES + ATTN_GOLDEN_CASES)
 def test_forward_matches_golden(name, fused):
     g = load_golden(name)
     net = make_product_grevnet(g, g["params"])
@@ -367,3 +367,59 @@ def test_sampling_entry(grid_small):
     from scipy.stats import multivariate_normal
     np.testing.assert_allclose(out["sample_log_prob"].cpu().numpy(),
                                multivariate_normal(np.zeros(8), np.eye(8)).logpdf(z), atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# edge-list attention GNN (DMSelfAttentionMLP, gnn.py:385-553): the reference drivers' default make_gnn_fn
+# ------------------------------------------------------------------------------------------------
+ATTN_SHAPES = [
+    # D, latent, K, T, heads, kq, v, C, concat, kq_div, residual, ws
+    (64, 256, 5, 2, 8, 10, 10, 80, True, False, False, False),     # reference defaults (run_grevnet.py:59-80) at D=64
+    (2, 32, 3, 2, 8, 10, 10, 80, True, False, False, False),       # node_embedding_dim default 2 -> H = 1
+    (20, 48, 2, 1, 3, 7, 5, 20, False, True, True, True),          # no concat, scaled logits, residual, shared
+    (12, 16, 1, 2, 1, 32, 32, 9, True, True, False, False),        # single head at the kq / v limits, K = 1
+]
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "layered"])
+@pytest.mark.parametrize("shape", ATTN_SHAPES, ids=[f"D{s[0]}_L{s[1]}_h{s[4]}_kq{s[5]}_v{s[6]}_C{s[7]}" for s in ATTN_SHAPES])
+def test_attention_gnn_vs_oracle(grid_small, community_medium, shape, fused):
+    d, latent, k, t, nh, kq, vd, c, concat, div, res, ws = shape
+    akw = dict(num_heads=nh, kq_dim=kq, v_dim=vd, out_dim=c, concat=concat, kq_dim_division=div, residual=res)
+    hp = dict(D=d, latent=latent, K=k, T=t, agg="mean", combine="agg", epsilon=0.0, activation="relu",
+              weight_sharing=ws, attn=akw)
+    nn, ne, s, r = _batch(grid_small, list(range(12))) if d != 64 else _batch(community_medium, [3, 77, 150, 9])
+    n = int(nn.sum())
+    rng = np.random.default_rng(d * 100 + nh)
+    x = (rng.standard_normal((n, d)) * (0.3 if res else 1.0)).astype(np.float32)
+    p = O.make_attn_grevnet_params(d + nh, d // 2, latent, k, t, weight_sharing=ws, final_scale=0.3, **akw)
+    o = O.Fp64Dense(s, r, n, activation="relu")
+    ref = o.log_prob(x, p, t, ws)
+    net = make_product_grevnet(hp, p)
+    net.fused = fused
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    out = _run_forward(net, graph)
+    assert abs(float(out["log_prob_xs_per_node"]) - ref["log_prob_xs_per_node"]) <= 1e-4
+    np.testing.assert_allclose(out["z_graph"].nodes.cpu().numpy(), ref["z"], atol=3e-4, rtol=3e-4)
+    zs = (rng.standard_normal((n, d)) * (0.3 if res else 1.0)).astype(np.float32)
+    xg = net(graph.replace(nodes=torch.as_tensor(zs).to(DEV)), inverse=False).nodes.cpu().numpy()
+    np.testing.assert_allclose(xg, o.g(zs, p, t, ws), atol=3e-4, rtol=3e-4)
+
+
+def test_attention_module_call_alone_and_isolated_nodes():
+    """module(GraphsTuple) -> GraphsTuple for a dm_self_attn_gnn product; a node without incoming edges
+    gets attended value 0 (gnn.py:403)."""
+    from gnf_amd import gnn
+    s = np.array([0, 0, 2, 1], np.int32)
+    r = np.array([1, 2, 1, 1], np.int32)          # nodes 0 and 3 receive nothing; node 1 has 3 incoming
+    n, h = 4, 6
+    x = np.random.default_rng(0).standard_normal((n, h)).astype(np.float32)
+    net = O.make_attn_net_params(np.random.default_rng(1), h, 16, 2, num_heads=4, kq_dim=3, v_dim=2, out_dim=5)
+    net["mlp"] = O.make_mlp_params(np.random.default_rng(2), h + 5, 16, 7, 2)     # free output width
+    mod = gnn.dm_self_attn_gnn(kq_dim=3, v_dim=2, make_mlp_fn=partial(gnn.make_mlp_model, 16, 7, 2, gnn.relu),
+                               num_heads=4, concat_heads_output_dim=5)
+    mod.set_attn_params(net["attn"])
+    mod._mlp.set_params(net["mlp"])
+    out = mod(graph_from_arrays([4], [4], s, r, x, DEV))
+    want = O.Fp64Dense(s, r, n, activation="relu").gnn(x.astype(np.float64), net)
+    np.testing.assert_allclose(out.nodes.cpu().numpy(), want, atol=1e-4, rtol=1e-4)
