@@ -42,6 +42,12 @@ WORKLOADS = {
                     graphs=256, hp={}, inverse=True, fc=False),
     "config5": dict(desc="citeseer/ego stand-in (synthetic, n~U{50..399}), node-dim 256", dataset="synthetic_ego",
                     graphs=128, hp=dict(D=256, T=16), inverse=False, fc=False),
+    # the reference drivers' DEFAULT make_gnn_fn (run_grevnet.py:56,199-211): edge-list self-attention GNN
+    "config2_attn": dict(desc="community_medium, dm_self_attn GNN (8 heads, kq=v=10, C=80, relu: run_grevnet.py:74-80)",
+                         dataset="graph_rnn_community_medium", graphs=64,
+                         hp=dict(activation="relu", attn=dict(num_heads=8, kq_dim=10, v_dim=10, out_dim=80, concat=True,
+                                                              kq_dim_division=False, residual=False)),
+                         inverse=False, fc=False),
 }
 WORKLOAD = WORKLOADS["config2"]
 WEIGHT_SEED = 99
@@ -54,13 +60,21 @@ def algorithmic_half_step(n, e, hp):
     """flops and minimum HBM bytes of ONE fused coupling half-step launch."""
     h, l, k = hp["D"] // 2, hp["latent"], hp["K"]
     in0 = 2 * h if hp["combine"] == "concat" else h
+    att = hp.get("attn")
+    extra_f = extra_b = 0
+    if att:   # per net: q/k/v projection, logits (two passes), weighted values, output projection
+        nh, kq, vd, c = att["num_heads"], att["kq_dim"], att["v_dim"], att["out_dim"]
+        in0 = (h if att["concat"] else 0) + c
+        pw_att = h * (2 * nh * kq + vd) + nh * vd * c
+        extra_f = 2 * (2 * n * pw_att + e * nh * (4 * kq + 2 * vd + 4))
+        extra_b = 8 * pw_att
     if k == 1:
         p_w, p_b = in0 * h, h
     else:
         p_w = in0 * l + (k - 2) * l * l + l * h
         p_b = (k - 1) * l + h
-    flops = n * 4 * p_w + e * h + 6 * n * h
-    bytes_ = 12 * n * h + 4 * e + 4 * n + 8 * (p_w + p_b)
+    flops = n * 4 * p_w + (0 if att else e * h) + 6 * n * h + extra_f
+    bytes_ = 12 * n * h + 4 * e + 4 * n + 8 * (p_w + p_b) + extra_b
     return flops, bytes_
 
 
@@ -70,6 +84,18 @@ def make_params(seed, hp, final_scale):
     rng = np.random.default_rng(seed)
     h, l, k, t = hp["D"] // 2, hp["latent"], hp["K"], hp["T"]
     in0 = 2 * h if hp["combine"] == "concat" else h
+    att = hp.get("attn")
+    if att:
+        in0 = (h if att["concat"] else 0) + att["out_dim"]
+
+    def attn_weights():   # xavier-uniform q/k/v (gnn.py:504-506), 1/sqrt(fan_in) output projection
+        nq = att["num_heads"] * att["kq_dim"]
+        def xav(fi, fo):
+            a = np.sqrt(6.0 / (fi + fo))
+            return rng.uniform(-a, a, size=(fi, fo)).astype(np.float32)
+        nv = att["num_heads"] * att["v_dim"]
+        return dict(att, wq=xav(h, nq), wk=xav(h, nq), wv=xav(h, att["v_dim"]),
+                    wo=(rng.standard_normal((nv, att["out_dim"])) / np.sqrt(nv)).astype(np.float32))
 
     def mlp():
         layers, fan_in = [], in0
@@ -83,7 +109,10 @@ def make_params(seed, hp, final_scale):
             fan_in = fan_out
         return layers
 
-    return {"s": [[mlp() for _ in range(t)] for _ in range(2)], "t": [[mlp() for _ in range(t)] for _ in range(2)]}
+    def net():
+        return {"attn": attn_weights(), "mlp": mlp()} if att else mlp()
+
+    return {"s": [[net() for _ in range(t)] for _ in range(2)], "t": [[net() for _ in range(t)] for _ in range(2)]}
 
 
 def make_batch(n_gpus, rank, seed=12345):
@@ -359,7 +388,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {WORKLOAD['desc']} batch={GRAPHS_PER_GPU}/GPU ({GRAPHS_PER_GPU * world} graphs total), "
                                f"{HP['T']}-step GRevNet {'inverse (sampling)' if inverse else 'fwd+logdet'}, D={HP['D']} L={HP['latent']} K={HP['K']} "
-                               f"avg_then_mlp eps=1 leaky_relu(0.2), sparse topology+self loops",
+                               + ("dm_self_attn GNN relu" if HP.get("attn") else "avg_then_mlp eps=1 leaky_relu(0.2)")
+                               + (", fully connected topology" if WORKLOAD["fc"] else ", sparse topology+self loops"),
                    "nodes_total": n_global, "edges_total": e_global, "nodes_rank0": n_local, "edges_rank0": e_local,
                    "weights": f"N(0,2/(fan_in+fan_out)), seed {WEIGHT_SEED}, last layer x{FINAL_SCALE}",
                    "parallelism": f"graph-shard dp{world}, 1 all-reduce of 3xfp64 per step" if world > 1 else "single GPU",

@@ -16,9 +16,8 @@
 
 namespace gnf {
 
-static constexpr int kAttnMaxKq = 32;
-static constexpr int kAttnMaxV = 32;
-static constexpr int kProjRows = 16;
+static constexpr int kAttnMaxKq = 256;  // bounds keep the LDS tile small; the kernels loop at run time
+static constexpr int kAttnMaxV = 256;
 
 struct AttnArgs {
     const float* Wq[2];
@@ -35,107 +34,288 @@ struct AttnArgs {
     float scale;  // 1 or 1/sqrt(kq)
 };
 
-// qkv[r, :] = x[r, :] @ [Wq | Wk | Wv]
+// RULE for these small kernels (measured: kernel time ~ number of SEQUENTIAL global-memory round trips,
+// ~1-2 us each at this occupancy): every staging phase first issues ALL of its loads into registers
+// and only then stores to LDS.  A "load; store; next iteration" loop costs one round trip per
+// iteration.
+#define GNF_STAGE_COPY(DST, SRC, COUNT, TID, NTHR)                                              \
+    do {                                                                                         \
+        for (int base_ = 0; base_ < (COUNT); base_ += (NTHR)*16) {                               \
+            float reg_[16];                                                                      \
+            _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                  \
+                const int i_ = base_ + (TID) + q_ * (NTHR);                                      \
+                reg_[q_] = (SRC)[i_ < (COUNT) ? i_ : 0];                                         \
+            }                                                                                    \
+            _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                  \
+                const int i_ = base_ + (TID) + q_ * (NTHR);                                      \
+                if (i_ < (COUNT)) (DST)[i_] = reg_[q_];                                          \
+            }                                                                                    \
+        }                                                                                        \
+    } while (0)
+
+// qkv[r, :] = x[r, :] @ [Wq | Wk | Wv].  Block = (64 column lanes) x (4 row quads) = 16 rows; Wq, Wk, Wv
+// are staged in LDS as three plain copies (no index arithmetic), the 16 x rows likewise; a thread owns
+// columns tx, tx+64, ... for its 4 rows (x values are LDS broadcasts).
+static constexpr int kProjRows = 16;
+
 __global__ __launch_bounds__(256) void k_attn_proj(const AttnArgs a) {
-    extern __shared__ float xs[];  // [kProjRows][H]
+    extern __shared__ float sm[];  // Wq [H][nq] | Wk [H][nq] | Wv [H][v] | x rows [kProjRows][H]
     const int net = blockIdx.y;
     const int row0 = blockIdx.x * kProjRows;
-    const int H = a.H, nq = a.nh * a.kq, P = 2 * nq + a.v;
-    for (int i = threadIdx.x; i < kProjRows * H; i += 256) {
-        const int rl = i / H, f = i - rl * H;
-        const int r = row0 + rl;
-        xs[i] = r < a.n_nodes ? a.x[(int64_t)r * a.ldx + f] : 0.f;
+    const int H = a.H, nq = a.nh * a.kq, vd = a.v, P = 2 * nq + vd;
+    float* wq = sm;
+    float* wk = wq + H * nq;
+    float* wv = wk + H * nq;
+    float* xs = wv + H * vd;
+    const int tid = threadIdx.x;
+    const int tx = tid & 63, ty = tid >> 6;
+    // one round trip: weights and the x rows (the rows are contiguous when ldx == H; else row by row)
+    {
+        const float* Wq = a.Wq[net];
+        const float* Wk = a.Wk[net];
+        const float* Wv = a.Wv[net];
+        float xr[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // up to 4*64 = 256 features per row quad lane set
+            const int rl = ty * 4 + q;
+            const int r = row0 + rl < a.n_nodes ? row0 + rl : a.n_nodes - 1;
+            xr[q] = tx < H ? a.x[(int64_t)r * a.ldx + tx] : 0.f;
+        }
+        GNF_STAGE_COPY(wq, Wq, H * nq, tid, 256);
+        GNF_STAGE_COPY(wk, Wk, H * nq, tid, 256);
+        GNF_STAGE_COPY(wv, Wv, H * vd, tid, 256);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (tx < H) xs[(ty * 4 + q) * H + tx] = xr[q];
+        for (int f = tx + 64; f < H; f += 64)  // H > 64: remaining features (rare)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rl = ty * 4 + q;
+                const int r = row0 + rl < a.n_nodes ? row0 + rl : a.n_nodes - 1;
+                xs[rl * H + f] = a.x[(int64_t)r * a.ldx + f];
+            }
     }
     __syncthreads();
-    const float* Wq = a.Wq[net];
-    const float* Wk = a.Wk[net];
-    const float* Wv = a.Wv[net];
     float* out = a.qkv[net];
-    for (int i = threadIdx.x; i < kProjRows * P; i += 256) {
-        const int rl = i / P, c = i - rl * P;
-        const int r = row0 + rl;
-        if (r >= a.n_nodes) continue;
-        const float* W;
-        int ldw, cc;
+    const int rb = ty * 4;
+    for (int c = tx; c < P; c += 64) {
+        const float* w;
+        int ldw;
         if (c < nq) {
-            W = Wq, ldw = nq, cc = c;
+            w = wq + c, ldw = nq;
         } else if (c < 2 * nq) {
-            W = Wk, ldw = nq, cc = c - nq;
+            w = wk + (c - nq), ldw = nq;
         } else {
-            W = Wv, ldw = a.v, cc = c - 2 * nq;
+            w = wv + (c - 2 * nq), ldw = vd;
         }
-        float acc = 0.f;
-        for (int k = 0; k < H; ++k) acc = fmaf(xs[rl * H + k], W[(int64_t)k * ldw + cc], acc);
-        out[(int64_t)r * P + c] = acc;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int k = 0; k < H; ++k) {
+            const float wv_ = w[k * ldw];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = fmaf(xs[(rb + q) * H + k], wv_, acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = row0 + rb + q;
+            if (r < a.n_nodes) out[(int64_t)r * P + c] = acc[q];
+        }
     }
 }
 
-// one thread per (receiver row, head); RB rows per workgroup; then the output projection
-__global__ __launch_bounds__(256) void k_attn_agg(const AttnArgs a, int RB) {
-    extern __shared__ float agg_lds[];  // [RB][nh*v]
+// Attention + output projection (+ concat) for RB consecutive receiver rows per workgroup.
+//   round trip 1: rowptr slice, the receivers' k rows ("queries"), their x rows, Wo  -> LDS
+//   round trip 2: the col segment of the tile
+//   round trip 3: q ("keys") and v rows of every sender on the tile's edges, one sender row per wave
+//                 iteration, coalesced along the feature axis, all issued before the first LDS store
+//   then, from LDS only: a group of kEL consecutive lanes owns one (row, head) and takes the row's edges
+//   kEL at a time (logit = <q[sender], k[receiver]>), max and sum combined with xor-shuffles; one lane
+//   per (row, head, value component) forms attended = sum_e w[e,h] v[e,j]; output projection with Wo.
+// All loops have run-time bounds.  Rows are processed in edge tiles of kEdgeCap (max pass over all
+// tiles first when there is more than one), so any degree is supported.
+static constexpr int kEL = 4;
+static constexpr int kEdgeCap = 256;
+
+__global__ __launch_bounds__(512) void k_attn_agg(const AttnArgs a, int RB) {
+    extern __shared__ float lds[];
     const int net = blockIdx.y;
     const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
+    const int QV = nq + vd;  // floats staged per edge: q (all heads) then v
+    float* agg_lds = lds;                          // [RB][NV]   attended values (accumulated over tiles)
+    float* e_lds = agg_lds + RB * NV;              // [kEdgeCap][QV]
+    float* k_lds = e_lds + kEdgeCap * QV;          // [RB][nq]   receivers' "queries"
+    float* w_lds = k_lds + RB * nq;                // [kEdgeCap][nh] logits, then exp weights
+    float* mx_lds = w_lds + kEdgeCap * nh;         // [RB][nh] running max
+    float* den_lds = mx_lds + RB * nh;             // [RB][nh]
+    float* wo_lds = den_lds + RB * nh;             // [NV][C]
+    float* x_lds = wo_lds + NV * a.C;              // [RB][H]
+    int* rp_lds = reinterpret_cast<int*>(x_lds + RB * a.H);  // [RB + 1]
+    int* col_lds = rp_lds + RB + 1;                // [kEdgeCap]
     const int row0 = blockIdx.x * RB;
     const float* qkv = a.qkv[net];
-    const int tid = threadIdx.x;
-    if (tid < RB * nh) {
-        const int rl = tid / nh, h = tid - rl * nh;
-        const int r = row0 + rl;
-        float acc[kAttnMaxV];
-#pragma unroll
-        for (int j = 0; j < kAttnMaxV; ++j) acc[j] = 0.f;
-        float den = 0.f;
-        if (r < a.n_nodes) {
-            float kr[kAttnMaxKq];  // the receiver's "query" (Wk projection), this head
-#pragma unroll
-            for (int d = 0; d < kAttnMaxKq; ++d) kr[d] = d < kq ? qkv[(int64_t)r * P + nq + h * kq + d] : 0.f;
-            const int beg = a.rowptr[r], end = a.rowptr[r + 1];
-            float mx = -INFINITY;
-            for (int e = beg; e < end; ++e) {
-                const float* qs = qkv + (int64_t)a.col[e] * P + h * kq;
-                float l = 0.f;
-#pragma unroll
-                for (int d = 0; d < kAttnMaxKq; ++d)
-                    if (d < kq) l = fmaf(qs[d], kr[d], l);
-                mx = fmaxf(mx, l * a.scale);
-            }
-            for (int e = beg; e < end; ++e) {
-                const int sidx = a.col[e];
-                const float* qs = qkv + (int64_t)sidx * P + h * kq;
-                float l = 0.f;
-#pragma unroll
-                for (int d = 0; d < kAttnMaxKq; ++d)
-                    if (d < kq) l = fmaf(qs[d], kr[d], l);
-                const float w = expf(l * a.scale - mx);
-                den += w;
-                const float* vs = qkv + (int64_t)sidx * P + 2 * nq;
-#pragma unroll
-                for (int j = 0; j < kAttnMaxV; ++j)
-                    if (j < vd) acc[j] = fmaf(w, vs[j], acc[j]);
-            }
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+    // ---- round trip 1 ----------------------------------------------------------------------------
+    {
+        int rp = 0;
+        if (tid <= RB) {
+            const int r = row0 + tid;
+            rp = a.rowptr[r < a.n_nodes ? r : a.n_nodes];
         }
-        const float inv = den > 0.f ? 1.f / den : 0.f;  // no incoming edge -> 0 (gnn.py:403)
+        // k rows and x rows of the RB receivers: (row, feature) flattened, rows clamped
+        float kreg[4], xreg[4];
 #pragma unroll
-        for (int j = 0; j < kAttnMaxV; ++j)
-            if (j < vd) agg_lds[rl * NV + h * vd + j] = acc[j] * inv;
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * nthr;
+            const int rl = i / nq < RB ? i / nq : RB - 1, c = i - (i / nq) * nq;
+            const int r = row0 + rl < a.n_nodes ? row0 + rl : a.n_nodes - 1;
+            kreg[q] = qkv[(int64_t)r * P + nq + c];
+            const int rl2 = i / a.H < RB ? i / a.H : RB - 1, f = i - (i / a.H) * a.H;
+            const int r2 = row0 + rl2 < a.n_nodes ? row0 + rl2 : a.n_nodes - 1;
+            xreg[q] = a.x[(int64_t)r2 * a.ldx + f];
+        }
+        GNF_STAGE_COPY(wo_lds, a.Wo[net], NV * a.C, tid, nthr);
+        if (tid <= RB) rp_lds[tid] = rp;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + q * nthr;
+            if (i < RB * nq) k_lds[i] = kreg[q];
+            if (i < RB * a.H) x_lds[i] = xreg[q];
+        }
+        for (int i = tid + 4 * nthr; i < RB * nq; i += nthr) {  // very wide heads only
+            const int rl = i / nq, c = i - rl * nq;
+            const int r = row0 + rl < a.n_nodes ? row0 + rl : a.n_nodes - 1;
+            k_lds[i] = qkv[(int64_t)r * P + nq + c];
+        }
+        for (int i = tid + 4 * nthr; i < RB * a.H; i += nthr) {
+            const int rl = i / a.H, f = i - rl * a.H;
+            const int r = row0 + rl < a.n_nodes ? row0 + rl : a.n_nodes - 1;
+            x_lds[i] = a.x[(int64_t)r * a.ldx + f];
+        }
+        for (int i = tid; i < RB * NV; i += nthr) agg_lds[i] = 0.f;
+        for (int i = tid; i < RB * nh; i += nthr) {
+            mx_lds[i] = -INFINITY;
+            den_lds[i] = 0.f;
+        }
     }
     __syncthreads();
-    const float* Wo = a.Wo[net];
+    const int seg_beg = rp_lds[0], seg_end = rp_lds[RB];
+    const int el = tid & (kEL - 1);
+    const int grp = tid / kEL;  // (row, head) pair index inside the workgroup
+    const bool has_grp = grp < RB * nh;
+    const int g_rl = has_grp ? grp / nh : 0, g_h = has_grp ? grp - g_rl * nh : 0;
+    const int ntiles = (seg_end - seg_beg + kEdgeCap - 1) / kEdgeCap;
+
+    for (int pass = (ntiles > 1 ? 0 : 1); pass < 2; ++pass) {  // pass 0: max over all tiles (multi-tile only)
+        for (int t0 = seg_beg; t0 < seg_end; t0 += kEdgeCap) {
+            const int t1 = t0 + kEdgeCap < seg_end ? t0 + kEdgeCap : seg_end;
+            const int ne = t1 - t0;
+            __syncthreads();
+            // ---- round trip 2: col ------------------------------------------------------------------
+            if (tid < ne) col_lds[tid] = a.col[t0 + tid];  // kEdgeCap <= blockDim is guaranteed by the launcher
+            __syncthreads();
+            // ---- round trip 3: sender rows (q, and v when needed); wave w takes edges w, w+nwave, ... -----
+            {
+                constexpr int kMaxIt = 16;  // kEdgeCap / min(nwave) = 128 / 8... covered by the outer loop
+                const bool need_v = (pass == 1 || ntiles == 1);
+                for (int eb = 0; eb < ne; eb += nwave * kMaxIt) {
+                    float rq[kMaxIt][2], rv[kMaxIt];
+#pragma unroll
+                    for (int it = 0; it < kMaxIt; ++it) {
+                        const int e = eb + wave + it * nwave;
+                        const float* src = qkv + (int64_t)col_lds[e < ne ? e : 0] * P;
+                        rq[it][0] = src[lane < nq ? lane : 0];
+                        rq[it][1] = src[lane + 64 < nq ? lane + 64 : 0];
+                        rv[it] = src[2 * nq + (lane < vd ? lane : 0)];
+                    }
+#pragma unroll
+                    for (int it = 0; it < kMaxIt; ++it) {
+                        const int e = eb + wave + it * nwave;
+                        if (e < ne) {
+                            if (lane < nq) e_lds[e * QV + lane] = rq[it][0];
+                            if (lane + 64 < nq) e_lds[e * QV + lane + 64] = rq[it][1];
+                            if (need_v && lane < vd) e_lds[e * QV + nq + lane] = rv[it];
+                        }
+                    }
+                    // heads*kq > 128 or v > 64: the rest, plainly
+                    for (int it = 0; it < kMaxIt; ++it) {
+                        const int e = eb + wave + it * nwave;
+                        if (e >= ne) break;
+                        const float* src = qkv + (int64_t)col_lds[e] * P;
+                        for (int c = lane + 128; c < nq; c += 64) e_lds[e * QV + c] = src[c];
+                        if (need_v)
+                            for (int c = lane + 64; c < vd; c += 64) e_lds[e * QV + nq + c] = src[2 * nq + c];
+                    }
+                }
+            }
+            __syncthreads();
+            if (has_grp) {
+                const int beg = rp_lds[g_rl] > t0 ? rp_lds[g_rl] : t0;
+                const int end = rp_lds[g_rl + 1] < t1 ? rp_lds[g_rl + 1] : t1;
+                const float* kr = k_lds + g_rl * nq + g_h * kq;
+                float mx = -INFINITY;
+                for (int e = beg + el; e < end; e += kEL) {
+                    const float* qs = e_lds + (e - t0) * QV + g_h * kq;
+                    float l = 0.f;
+                    for (int d = 0; d < kq; ++d) l = fmaf(qs[d], kr[d], l);
+                    l *= a.scale;
+                    w_lds[(e - t0) * nh + g_h] = l;
+                    mx = fmaxf(mx, l);
+                }
+#pragma unroll
+                for (int o = 1; o < kEL; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                if (ntiles > 1 && pass == 0) {
+                    if (el == 0) mx_lds[grp] = fmaxf(mx_lds[grp], mx);
+                } else {
+                    if (ntiles > 1) mx = mx_lds[grp];  // global max of the row from pass 0
+                    float den = 0.f;
+                    for (int e = beg + el; e < end; e += kEL) {
+                        const float w = expf(w_lds[(e - t0) * nh + g_h] - mx);
+                        w_lds[(e - t0) * nh + g_h] = w;
+                        den += w;
+                    }
+#pragma unroll
+                    for (int o = 1; o < kEL; o <<= 1) den += __shfl_xor(den, o, 64);
+                    if (el == 0) den_lds[grp] += den;
+                }
+            }
+            if (pass == 1 || ntiles == 1) {
+                __syncthreads();
+                // attended[rl, h, j] += sum over the tile's edges of this row of w[e, h] * v[e, j]
+                for (int i = tid; i < RB * NV; i += nthr) {
+                    const int rl = i / NV, hj = i - rl * NV, h = hj / vd, j = hj - h * vd;
+                    const int beg = rp_lds[rl] > t0 ? rp_lds[rl] : t0;
+                    const int end = rp_lds[rl + 1] < t1 ? rp_lds[rl + 1] : t1;
+                    float acc = 0.f;
+                    for (int e = beg; e < end; ++e) acc = fmaf(w_lds[(e - t0) * nh + h], e_lds[(e - t0) * QV + nq + j], acc);
+                    agg_lds[i] += acc;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < RB * NV; i += nthr) {
+        const int rl = i / NV, h = (i - rl * NV) / vd;
+        const float den = den_lds[rl * nh + h];
+        agg_lds[i] = den > 0.f ? agg_lds[i] / den : 0.f;  // no incoming edge -> 0 (gnn.py:403)
+    }
+    __syncthreads();
     float* h0 = a.h0[net];
     const int off = a.concat ? a.H : 0;
-    for (int i = tid; i < RB * a.C; i += blockDim.x) {
+    for (int i = tid; i < RB * a.C; i += nthr) {
         const int rl = i / a.C, c = i - rl * a.C;
         const int r = row0 + rl;
         if (r >= a.n_nodes) continue;
         float acc = 0.f;
-        for (int k = 0; k < NV; ++k) acc = fmaf(agg_lds[rl * NV + k], Wo[(int64_t)k * a.C + c], acc);
+#pragma unroll 8
+        for (int k = 0; k < NV; ++k) acc = fmaf(agg_lds[rl * NV + k], wo_lds[k * a.C + c], acc);
         h0[(int64_t)r * a.in0 + off + c] = acc;
     }
     if (a.concat)
-        for (int i = tid; i < RB * a.H; i += blockDim.x) {
+        for (int i = tid; i < RB * a.H; i += nthr) {
             const int rl = i / a.H, f = i - rl * a.H;
             const int r = row0 + rl;
-            if (r < a.n_nodes) h0[(int64_t)r * a.in0 + f] = a.x[(int64_t)r * a.ldx + f];
+            if (r < a.n_nodes) h0[(int64_t)r * a.in0 + f] = x_lds[i];
         }
 }
 
@@ -206,18 +386,39 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
     a.concat = a0->concat ? 1 : 0;
     a.in0 = in0;
     a.scale = a0->kq_dim_division ? 1.f / sqrtf((float)a0->kq_dim) : 1.f;
-    hipLaunchKernelGGL(k_attn_proj, dim3((unsigned)((n + kProjRows - 1) / kProjRows), nets), dim3(256),
-                       kProjRows * H * sizeof(float), st, a);
+    const size_t proj_lds = ((size_t)H * P + (size_t)kProjRows * H) * sizeof(float);
+    if (proj_lds > 160 * 1024) {
+        set_error("attention projection needs %zu bytes of LDS (H=%d x %zu projected columns): unsupported", proj_lds, H, P);
+        return GNF_EUNSUPPORTED;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_proj),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_attn_proj, dim3((unsigned)((n + kProjRows - 1) / kProjRows), nets), dim3(256), proj_lds, st, a);
     GNF_LAUNCH_CHECK("k_attn_proj");
-    int RB = 256 / a.nh;
+    int RB = 512 / (a.nh * kEL);  // (row, head) groups of kEL lanes
     if (RB < 1) RB = 1;
-    if (RB > 32) RB = 32;
-    while ((size_t)RB * a.nh * a.v * sizeof(float) > 60 * 1024 && RB > 1) RB >>= 1;
-    int threads = RB * a.nh;
+    int threads = RB * a.nh * kEL;  // nh <= 64 -> at most 512 when RB == 1
     threads = (threads + 63) / 64 * 64;
-    if (threads < 64) threads = 64;
-    hipLaunchKernelGGL(k_attn_agg, dim3((unsigned)((n + RB - 1) / RB), nets), dim3(threads),
-                       (size_t)RB * a.nh * a.v * sizeof(float), st, a, RB);
+    if (threads < kEdgeCap) threads = kEdgeCap;  // the col tile is staged one edge per thread
+    const size_t agg_lds = ((size_t)RB * a.nh * a.v + (size_t)kEdgeCap * (a.nh * a.kq + a.v) + (size_t)RB * a.nh * a.kq +
+                            (size_t)kEdgeCap * a.nh + 2 * (size_t)RB * a.nh + (size_t)a.nh * a.v * a.C + (size_t)RB * H) *
+                               sizeof(float) +
+                           (size_t)(RB + 1 + kEdgeCap) * sizeof(int);
+    if (agg_lds > 160 * 1024) {
+        set_error("attention tile needs %zu bytes of LDS: unsupported head configuration", agg_lds);
+        return GNF_EUNSUPPORTED;
+    }
+    static bool attr_set2 = false;
+    if (!attr_set2) {
+        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_agg),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set2 = true;
+    }
+    hipLaunchKernelGGL(k_attn_agg, dim3((unsigned)((n + RB - 1) / RB), nets), dim3(threads), agg_lds, st, a, RB);
     GNF_LAUNCH_CHECK("k_attn_agg");
     return GNF_OK;
 }
