@@ -58,11 +58,12 @@ struct AttnArgs {
 // columns tx, tx+64, ... for its 4 rows (x values are LDS broadcasts).
 static constexpr int kProjRows = 16;
 
+template <int NH, int KQ, int VD>  // 0 = run-time value; the reference defaults (8, 10, 10) get a folded instance
 __global__ __launch_bounds__(256) void k_attn_proj(const AttnArgs a) {
     extern __shared__ float sm[];  // Wq [H][nq] | Wk [H][nq] | Wv [H][v] | x rows [kProjRows][H]
     const int net = blockIdx.y;
     const int row0 = blockIdx.x * kProjRows;
-    const int H = a.H, nq = a.nh * a.kq, vd = a.v, P = 2 * nq + vd;
+    const int H = a.H, nq = (NH ? NH : a.nh) * (KQ ? KQ : a.kq), vd = VD ? VD : a.v, P = 2 * nq + vd;
     float* wq = sm;
     float* wk = wq + H * nq;
     float* wv = wk + H * nq;
@@ -136,10 +137,12 @@ __global__ __launch_bounds__(256) void k_attn_proj(const AttnArgs a) {
 static constexpr int kEL = 4;
 static constexpr int kEdgeCap = 256;
 
+template <int NH, int KQ, int VD, int OC>  // 0 = run-time value
 __global__ __launch_bounds__(512) void k_attn_agg(const AttnArgs a, int RB) {
     extern __shared__ float lds[];
     const int net = blockIdx.y;
-    const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
+    const int nh = NH ? NH : a.nh, kq = KQ ? KQ : a.kq, vd = VD ? VD : a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
+    const int OCr = OC ? OC : a.C;
     const int QV = nq + vd;  // floats staged per edge: q (all heads) then v
     float* agg_lds = lds;                          // [RB][NV]   attended values (accumulated over tiles)
     float* e_lds = agg_lds + RB * NV;              // [kEdgeCap][QV]
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(512) void k_attn_agg(const AttnArgs a, int RB) {
     float* mx_lds = w_lds + kEdgeCap * nh;         // [RB][nh] running max
     float* den_lds = mx_lds + RB * nh;             // [RB][nh]
     float* wo_lds = den_lds + RB * nh;             // [NV][C]
-    float* x_lds = wo_lds + NV * a.C;              // [RB][H]
+    float* x_lds = wo_lds + NV * OCr;              // [RB][H]
     int* rp_lds = reinterpret_cast<int*>(x_lds + RB * a.H);  // [RB + 1]
     int* col_lds = rp_lds + RB + 1;                // [kEdgeCap]
     const int row0 = blockIdx.x * RB;
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(512) void k_attn_agg(const AttnArgs a, int RB) {
             const int r2 = row0 + rl2 < a.n_nodes ? row0 + rl2 : a.n_nodes - 1;
             xreg[q] = a.x[(int64_t)r2 * a.ldx + f];
         }
-        GNF_STAGE_COPY(wo_lds, a.Wo[net], NV * a.C, tid, nthr);
+        GNF_STAGE_COPY(wo_lds, a.Wo[net], NV * OCr, tid, nthr);
         if (tid <= RB) rp_lds[tid] = rp;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -302,13 +305,13 @@ __global__ __launch_bounds__(512) void k_attn_agg(const AttnArgs a, int RB) {
     __syncthreads();
     float* h0 = a.h0[net];
     const int off = a.concat ? a.H : 0;
-    for (int i = tid; i < RB * a.C; i += nthr) {
-        const int rl = i / a.C, c = i - rl * a.C;
+    for (int i = tid; i < RB * OCr; i += nthr) {
+        const int rl = i / OCr, c = i - rl * OCr;
         const int r = row0 + rl;
         if (r >= a.n_nodes) continue;
         float acc = 0.f;
 #pragma unroll 8
-        for (int k = 0; k < NV; ++k) acc = fmaf(agg_lds[rl * NV + k], wo_lds[k * a.C + c], acc);
+        for (int k = 0; k < NV; ++k) acc = fmaf(agg_lds[rl * NV + k], wo_lds[k * OCr + c], acc);
         h0[(int64_t)r * a.in0 + off + c] = acc;
     }
     if (a.concat)
@@ -393,11 +396,18 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
     }
     static bool attr_set = false;
     if (!attr_set) {
-        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_proj),
+        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_proj<0, 0, 0>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_proj<8, 10, 10>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_attn_proj, dim3((unsigned)((n + kProjRows - 1) / kProjRows), nets), dim3(256), proj_lds, st, a);
+    const bool ref_default = a.nh == 8 && a.kq == 10 && a.v == 10;  // run_grevnet.py:74-76
+    const dim3 pgrid((unsigned)((n + kProjRows - 1) / kProjRows), nets);
+    if (ref_default)
+        hipLaunchKernelGGL((k_attn_proj<8, 10, 10>), pgrid, dim3(256), proj_lds, st, a);
+    else
+        hipLaunchKernelGGL((k_attn_proj<0, 0, 0>), pgrid, dim3(256), proj_lds, st, a);
     GNF_LAUNCH_CHECK("k_attn_proj");
     int RB = 512 / (a.nh * kEL);  // (row, head) groups of kEL lanes
     if (RB < 1) RB = 1;
@@ -414,11 +424,17 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
     }
     static bool attr_set2 = false;
     if (!attr_set2) {
-        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_agg),
+        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_agg<0, 0, 0, 0>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_agg<8, 10, 10, 80>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set2 = true;
     }
-    hipLaunchKernelGGL(k_attn_agg, dim3((unsigned)((n + RB - 1) / RB), nets), dim3(threads), agg_lds, st, a, RB);
+    const dim3 agrid((unsigned)((n + RB - 1) / RB), nets);
+    if (ref_default && a.C == 80)  // + attn_concat_heads_output_dim = 80 (run_grevnet.py:77)
+        hipLaunchKernelGGL((k_attn_agg<8, 10, 10, 80>), agrid, dim3(threads), agg_lds, st, a, RB);
+    else
+        hipLaunchKernelGGL((k_attn_agg<0, 0, 0, 0>), agrid, dim3(threads), agg_lds, st, a, RB);
     GNF_LAUNCH_CHECK("k_attn_agg");
     return GNF_OK;
 }
