@@ -96,3 +96,45 @@ def sample(grevnet, graph, generator=None):
     sample_log_prob = -0.5 * (z.double() ** 2).sum(dim=1) - 0.5 * d * LN_2PI
     top = grevnet(graph.replace(nodes=z), inverse=False)
     return {"sample": z, "sample_log_prob": sample_log_prob, "grevnet_top": top, "grevnet_top_nodes": top.nodes}
+
+
+def scaled_hacky_sigmoid_l2(*_a, **_k):
+    """Token for the distance function of loss.py:45-53 (the only one pred_adj is used with on this
+    path); the arithmetic runs inside gnf_pred_adj_f32."""
+    raise NotImplementedError("token only: pass it as distance_fn to pred_adj")
+
+
+def pred_adj(gnn_output, distance_fn=scaled_hacky_sigmoid_l2, max_nodes_per_graph=None):
+    """loss.py:154-159 for the sampling path (train_grevnet_with_data.py:415-416): edge probabilities
+    sigmoid(10 * (1 - ||z_i - z_j||^2 / sqrt(D))) between the nodes of each graph, zero diagonal.  The
+    reference returns a dense block-diagonal-masked [N, N] matrix; this returns the list of per-graph
+    [n_g, n_g] blocks (views of one device buffer), which is what its consumer slices out
+    (train_grevnet_with_data.py:538-540).  `adjacency = block > 0.5` gives the sampled graphs."""
+    if distance_fn is not scaled_hacky_sigmoid_l2:
+        raise NotImplementedError("pred_adj supports distance_fn=scaled_hacky_sigmoid_l2 (loss.py:45-53)")
+    lib = _abi.lib()
+    z = gnn_output.nodes
+    if z.device.type != "cuda":
+        raise _abi.GnfError("pred_adj runs on a HIP device only (no CPU path)")
+    z = z.to(torch.float32)
+    if z.stride(1) != 1:
+        z = z.contiguous()
+    n_node_host = gnn_output.n_node.cpu().tolist()          # sizes the output (the reference syncs here too)
+    b = len(n_node_host)
+    total = sum(n * n for n in n_node_host)
+    cap = int(max_nodes_per_graph) if max_nodes_per_graph is not None else (max(n_node_host) if b else 0)
+    dev = z.device
+    out = torch.empty(max(total, 1), dtype=torch.float32, device=dev)
+    off = torch.empty(b + 1, dtype=torch.int64, device=dev)
+    ws_bytes = lib.gnf_pred_adj_workspace_bytes(b)
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=dev)
+    nn = gnn_output.n_node.to(torch.int32).contiguous()
+    with torch.cuda.device(dev):
+        _abi.check(lib.gnf_pred_adj_f32(_abi.ptr(z), z.stride(0), z.shape[1], _abi.ptr(nn), b, cap, _abi.ptr(out),
+                                        _abi.ptr(off), _abi.ptr(ws), ws_bytes, _abi.stream_ptr(dev)),
+                   "gnf_pred_adj_f32")
+    blocks, o = [], 0
+    for n in n_node_host:
+        blocks.append(out[o:o + n * n].view(n, n))
+        o += n * n
+    return blocks

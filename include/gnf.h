@@ -179,6 +179,20 @@ int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld
 int gnf_gauss_sumsq_f32(const float* z, int64_t n_nodes, int32_t D, int64_t ld, double* out,
                         void* ws, size_t ws_bytes, gnf_stream_t stream);
 
+/* Decoder that follows the sampling pass: pred_adj(graph, scaled_hacky_sigmoid_l2)
+ * (loss.py:45-53 distance, 131-151 block-diagonal mask, 154-159 pred_adj with remove_diag; called at
+ * train_grevnet_with_data.py:415-416 and thresholded at 0.5 at :532-533):
+ *   P[i,j] = sigmoid(10 * (1 - ||z_i - z_j||^2 / sqrt(D)))  for i != j in the same graph, 0 on the diagonal.
+ * The reference builds a dense masked [N,N] matrix; only the per-graph [n_g, n_g] blocks are produced
+ * here: out_blocks holds them concatenated (sum n_g^2 floats), block g starts at block_off[g]
+ * (block_off: device int64[n_graphs + 1], written by this call).  max_nodes_per_graph: any upper
+ * bound on n_node (sizes the launch; nothing is read from the host).
+ * ws: gnf_pred_adj_workspace_bytes(n_graphs). */
+size_t gnf_pred_adj_workspace_bytes(int64_t n_graphs);
+int gnf_pred_adj_f32(const float* z, int64_t ld, int32_t D, const int32_t* n_node, int64_t n_graphs,
+                     int32_t max_nodes_per_graph, float* out_blocks, int64_t* block_off, void* ws,
+                     size_t ws_bytes, gnf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

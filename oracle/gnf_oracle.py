@@ -379,6 +379,27 @@ def make_attn_grevnet_params(seed, hdim, latent, num_layers, num_timesteps, weig
             "t": [[one() for _ in range(num_timesteps)] for _ in range(2)]}
 
 
+def pred_adj_blocks(z, n_node):
+    """loss.py:154-159 pred_adj with distance_fn = scaled_hacky_sigmoid_l2 (loss.py:45-53), restated in the
+    reference's own formula and float64:  D = r - 2 z z^T + r^T, D /= sqrt(dim), sigmoid(10 (1 - D)); the
+    block-diagonal loss_mask (loss.py:131-151) and remove_diag keep, per graph, the [n_g, n_g] block with
+    a zero diagonal - returned as a list of blocks (the rest of the dense matrix is zero by the mask)."""
+    z = np.asarray(z, np.float64)
+    dim = z.shape[1]
+    out, off = [], 0
+    for n in n_node:
+        n = int(n)
+        zz = z[off:off + n]
+        r = np.sum(zz * zz, axis=1).reshape(-1, 1)
+        d = r - 2.0 * zz @ zz.T + r.T
+        d = d / math.sqrt(dim)
+        p = 1.0 / (1.0 + np.exp(-10.0 * (1.0 - d)))
+        np.fill_diagonal(p, 0.0)
+        out.append(p)
+        off += n
+    return out
+
+
 def batch_graphs(n_node, n_edge, senders_local, receivers_local, graph_ids):
     """Concatenate the chosen graphs with node-id offsets (what gn.utils_np.*_to_graphs_tuple does;
     graph_data.py:122, grevnet_synthetic_data.py:45-47).  Returns (n_node[B], n_edge[B], senders, receivers)."""

@@ -236,3 +236,29 @@ def test_attention_logdet_equals_jacobian_logdet():
     z, ld = o.f(x, pt, t)
     jac = torch.autograd.functional.jacobian(lambda v: o.f(v.reshape(n, d), pt, t)[0].reshape(-1), x.reshape(-1))
     assert abs(float(torch.linalg.slogdet(jac)[1]) - float(ld)) < 1e-9
+
+
+def test_pred_adj_blocks_against_dense_masked_formula():
+    """Restatement check: the per-graph blocks equal the reference's dense construction
+    (distance on ALL nodes, times the block-diagonal mask, diagonal removed)."""
+    rng = np.random.default_rng(0)
+    n_node = [3, 1, 4]
+    z = rng.standard_normal((8, 6)) * 0.5
+    blocks = O.pred_adj_blocks(z, n_node)
+    r = (z * z).sum(1, keepdims=True)
+    dense = 1.0 / (1.0 + np.exp(-10.0 * (1.0 - (r - 2 * z @ z.T + r.T) / np.sqrt(6))))
+    mask = np.zeros((8, 8))
+    off = 0
+    for n in n_node:
+        mask[off:off + n, off:off + n] = 1.0
+        off += n
+    dense = dense * mask * (1.0 - np.eye(8))
+    off = 0
+    for b, n in zip(blocks, n_node):
+        np.testing.assert_allclose(b, dense[off:off + n, off:off + n], atol=1e-12)
+        off += n
+    assert blocks[1].shape == (1, 1) and blocks[1][0, 0] == 0.0
+    # symmetric, in (0, 1), identical points -> sigmoid(10) off the diagonal
+    assert np.allclose(blocks[2], blocks[2].T)
+    same = O.pred_adj_blocks(np.ones((2, 4)), [2])[0]
+    assert abs(same[0, 1] - 1.0 / (1.0 + np.exp(-10.0))) < 1e-15

@@ -423,3 +423,26 @@ def test_attention_module_call_alone_and_isolated_nodes():
     out = mod(graph_from_arrays([4], [4], s, r, x, DEV))
     want = O.Fp64Dense(s, r, n, activation="relu").gnn(x.astype(np.float64), net)
     np.testing.assert_allclose(out.nodes.cpu().numpy(), want, atol=1e-4, rtol=1e-4)
+
+
+def test_pred_adj_decoder_after_sampling(community_medium):
+    """pred_adj(grevnet(sample, inverse=False), scaled_hacky_sigmoid_l2) -> per-graph edge
+    probabilities (loss.py:45-53,131-159; train_grevnet_with_data.py:397-416), incl. a 1-node graph and a
+    launch bound (max_nodes_per_graph) larger than any graph."""
+    from gnf_amd.flow import pred_adj, scaled_hacky_sigmoid_l2
+    rng = np.random.default_rng(4)
+    n_node = np.array([17, 1, 40, 33], np.int32)
+    n = int(n_node.sum())
+    for d in (2, 64, 200):
+        z = (rng.standard_normal((n, d)) * 0.7).astype(np.float32)
+        g = graph_from_arrays(n_node, np.zeros(4, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32), z, DEV)
+        for cap in (None, 64):
+            blocks = pred_adj(g, distance_fn=scaled_hacky_sigmoid_l2, max_nodes_per_graph=cap)
+            want = O.pred_adj_blocks(z, n_node)
+            assert [tuple(b.shape) for b in blocks] == [(17, 17), (1, 1), (40, 40), (33, 33)]
+            for b, w in zip(blocks, want):
+                np.testing.assert_allclose(b.cpu().numpy(), w, atol=2e-5, rtol=1e-4)
+                assert float(torch.diagonal(b).abs().max()) == 0.0
+    # thresholded adjacency is symmetric (what train_grevnet_with_data.py:532-540 turns into graphs)
+    adj = (blocks[2] > 0.5)
+    assert bool((adj == adj.T).all())
