@@ -123,7 +123,7 @@ WorkspacePlan plan_workspace(int64_t n_nodes, int32_t H, const GnfMlp* net, int3
     if (net)
         for (int j = 1; j < net->num_layers; ++j) lmax = lmax > net->dims[j] ? lmax : net->dims[j];
     const int in0 = net ? net->dims[0] : ((combine == GNF_COMBINE_CONCAT) ? 2 * H : H);
-    p.base_floats = (size_t)n_nodes * (size_t)(in0 + 2 * lmax + 2 * H);
+    p.base_floats = (size_t)n_nodes * (size_t)(in0 + kLayeredActBufs * lmax + 2 * H);
     p.scratch_floats = p.base_floats + attn_scratch_floats(net ? net->attn : nullptr, n_nodes, in0);
     p.total_bytes = p.partial_bytes + p.scratch_floats * sizeof(float);
     return p;

@@ -53,6 +53,9 @@ static constexpr int kMaxGaussBlocks = 1024;
 
 inline int64_t coupling_blocks_max(int64_t n_nodes) { return (n_nodes + 15) / 16 + 1; }
 
+// layered path: ping-pong activation buffers per net x two nets side by side (grouped GEMM launches)
+static constexpr int kLayeredActBufs = 4;
+
 struct WorkspacePlan {
     int64_t partial_stride;  // doubles per half-step
     int64_t n_halfsteps;

@@ -169,6 +169,148 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same linear layer on the fp32 matrix cores, for layers too wide for the LDS-resident fused
+// kernel (e.g. the 2048-wide MLPs of train_grevnet_with_data.py:111-112).  128x64 output tile, BK = 32,
+// 8 waves: wave w owns node tile (w & 3) * 32 .. +32 (two 16-row M-tiles) x column half (w >> 2) * 32
+// (two 16-column N-tiles).  X and W tiles are staged in LDS (X row-major, W row-major); A fragments
+// are ds_read_b128 with the same k permutation as the fused kernel (k = 16*kg + 4*(lane>>4) + q),
+// B fragments four ds_read_b32 rows.  Exact fp32 (v_mfma_f32_16x16x4_f32 = fmaf chain).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+static constexpr int GM = 128, GN = 64, GK = 32;
+
+// One GEMM of a grouped launch (blockIdx.z picks the job: the s- and the t-net of a half-step have the
+// same layer shapes, gnf_abi.hip validate_pair, so their layers run side by side in one grid).
+struct LinJob {
+    const float* X;
+    const float* W;
+    const float* b;
+    float* Y;
+};
+
+// VEC: X rows, W rows and both base pointers are 16-byte aligned and I, O are multiples of 4, so tiles
+// are fetched with dwordx4 loads; otherwise dword loads with per-element bounds.
+template <bool VEC>
+__global__ __launch_bounds__(512) void k_linear_mfma(LinJob j0, LinJob j1, int64_t ldx, int64_t ldy,
+                                                     int64_t n_rows, int I, int O, int act, float alpha,
+                                                     int apply_act) {
+    __shared__ __attribute__((aligned(16))) float Xs[GM][GK + 4];  // +4: rows stay 16-B aligned, banks spread
+    __shared__ __attribute__((aligned(16))) float Ws[GK][GN + 4];
+    const LinJob job = blockIdx.z ? j1 : j0;
+    const float* __restrict__ X = job.X;
+    const float* __restrict__ W = job.W;
+    const int64_t row0 = (int64_t)blockIdx.y * GM;
+    const int col0 = blockIdx.x * GN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    const int wm = (wave & 3) * 32, wn = (wave >> 2) * 32;
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int gc = col0 + wn + 16 * b + lrow;
+            const float bv = gc < O ? job.b[gc] : 0.f;
+            acc[m][b] = f32x4_t{bv, bv, bv, bv};
+        }
+    // register stage of the NEXT k-tile: fetched while the matrix cores work on the current one
+    f32x4_t xv[2], wv;
+    float xr[8], wr[4];
+    auto fetch = [&](int k0) {
+        if (VEC) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int i = tid + q * 512, r = i >> 3, k = (i & 7) * 4;
+                const int64_t gr = row0 + r;
+                xv[q] = (gr < n_rows && k0 + k < I)
+                            ? *reinterpret_cast<const f32x4_t*>(X + gr * ldx + k0 + k)
+                            : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+            const int k = tid >> 4, c = (tid & 15) * 4;
+            wv = (k0 + k < I && col0 + c < O)
+                     ? *reinterpret_cast<const f32x4_t*>(W + (int64_t)(k0 + k) * O + col0 + c)
+                     : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = tid + q * 512, r = i >> 5, k = i & 31;
+                const int64_t gr = row0 + r;
+                xr[q] = (gr < n_rows && k0 + k < I) ? X[gr * ldx + k0 + k] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = tid + q * 512, k = i >> 6, c = i & 63;
+                wr[q] = (k0 + k < I && col0 + c < O) ? W[(int64_t)(k0 + k) * O + col0 + c] : 0.f;
+            }
+        }
+    };
+    auto stash = [&]() {
+        if (VEC) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int i = tid + q * 512;
+                *reinterpret_cast<f32x4_t*>(&Xs[i >> 3][(i & 7) * 4]) = xv[q];
+            }
+            *reinterpret_cast<f32x4_t*>(&Ws[tid >> 4][(tid & 15) * 4]) = wv;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = tid + q * 512;
+                Xs[i >> 5][i & 31] = xr[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = tid + q * 512;
+                Ws[i >> 6][i & 63] = wr[q];
+            }
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < I; k0 += GK) {
+        __syncthreads();  // previous tile fully consumed
+        stash();
+        __syncthreads();
+        if (k0 + GK < I) fetch(k0 + GK);
+#pragma unroll
+        for (int kg = 0; kg < GK / 16; ++kg) {
+            f32x4_t a[2];
+            float bq[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                a[m] = *reinterpret_cast<const f32x4_t*>(&Xs[wm + 16 * m + lrow][16 * kg + 4 * lgrp]);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bq[b][q] = Ws[16 * kg + 4 * lgrp + q][wn + 16 * b + lrow];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][q], bq[b][q], acc[m][b], 0, 0, 0);
+        }
+    }
+    // accumulator layout: col = lane & 15, row = 4 * (lane >> 4) + r
+    float* __restrict__ Y = job.Y;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int gc = col0 + wn + 16 * b + lrow;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gr = row0 + wm + 16 * m + 4 * lgrp + r;
+                if (gr < n_rows && gc < O) {
+                    float v = acc[m][b][r];
+                    if (apply_act) v = (act == GNF_ACT_RELU) ? fmaxf(v, 0.f) : fmaxf(v, alpha * v);
+                    Y[gr * ldy + gc] = v;
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Coupling epilogue: x_upd <- x_upd*exp(s)+t  or  (x_upd-t)*exp(-s); one fp64 partial of sum(s)
 // per workgroup (fixed in-block order -> bitwise reproducible).
 // ------------------------------------------------------------------------------------------------
@@ -277,23 +419,51 @@ int launch_finalize(const double* a, int64_t na, const double* b, int64_t nb, do
 
 // ------------------------------------------------------------------------------------------------
 // One half-step through the scratch buffer.
-// scratch layout (floats): h0 [N, in0] | bufA [N, Lmax] | bufB [N, Lmax] | s [N, H] | t [N, H]
+// scratch layout (floats): h0 [N, in0] | s-net bufA, bufB [N, Lmax] | t-net bufA, bufB | s [N, H] | t [N, H]
 // ------------------------------------------------------------------------------------------------
-static int run_mlp(const GnfMlp* m, const float* h0, int64_t ld0, float* bufA, float* bufB,
-                   int64_t ldbuf, float* outp, int64_t ldout, int64_t n, const GnfGnnSpec& g,
-                   hipStream_t st) {
-    const float* in = h0;
+// nets[0..nj): MLPs with identical layer shapes (nj = 2: the s- and t-net of a half-step), each with its
+// own input h0[q], ping-pong buffers bufA[q] / bufB[q] (row stride ldbuf) and output outp[q].
+static int run_mlps(const GnfMlp* const* nets, int nj, const float* const* h0, int64_t ld0, float* const* bufA,
+                    float* const* bufB, int64_t ldbuf, float* const* outp, int64_t ldout, int64_t n,
+                    const GnfGnnSpec& g, hipStream_t st) {
+    const GnfMlp* m = nets[0];
+    const float* in[2] = {h0[0], h0[nj - 1]};
     int64_t ldin = ld0;
     for (int j = 0; j < m->num_layers; ++j) {
         const bool last = (j == m->num_layers - 1);
-        float* dst = last ? outp : ((j & 1) ? bufB : bufA);
+        float* dst[2];
+        for (int q = 0; q < 2; ++q) {
+            const int qq = q < nj ? q : nj - 1;
+            dst[q] = last ? outp[qq] : ((j & 1) ? bufB[qq] : bufA[qq]);
+        }
         const int64_t lddst = last ? ldout : ldbuf;
         const int I = m->dims[j], O = m->dims[j + 1];
-        dim3 grid((O + LT - 1) / LT, (unsigned)((n + LT - 1) / LT));
-        hipLaunchKernelGGL(k_linear, grid, dim3(256), 0, st, in, ldin, m->W[j], m->b[j], dst, lddst, n,
-                           I, O, g.activation, g.alpha, last ? 0 : 1);
-        GNF_LAUNCH_CHECK("k_linear");
-        in = dst;
+        if (I >= 32 && O >= 32) {  // matrix cores once the layer is GEMM-shaped
+            LinJob jobs[2];
+            bool vec = (I % 4 == 0) && (O % 4 == 0) && (ldin % 4 == 0);
+            for (int q = 0; q < 2; ++q) {
+                const GnfMlp* mq = nets[q < nj ? q : nj - 1];
+                jobs[q] = LinJob{in[q], mq->W[j], mq->b[j], dst[q]};
+                vec = vec && ((uintptr_t)in[q] % 16 == 0) && ((uintptr_t)mq->W[j] % 16 == 0);
+            }
+            dim3 grid((O + GN - 1) / GN, (unsigned)((n + GM - 1) / GM), nj);
+            if (vec)
+                hipLaunchKernelGGL(k_linear_mfma<true>, grid, dim3(512), 0, st, jobs[0], jobs[1], ldin, lddst, n, I,
+                                   O, g.activation, g.alpha, last ? 0 : 1);
+            else
+                hipLaunchKernelGGL(k_linear_mfma<false>, grid, dim3(512), 0, st, jobs[0], jobs[1], ldin, lddst, n,
+                                   I, O, g.activation, g.alpha, last ? 0 : 1);
+            GNF_LAUNCH_CHECK("k_linear_mfma");
+        } else {
+            dim3 grid((O + LT - 1) / LT, (unsigned)((n + LT - 1) / LT));
+            for (int q = 0; q < nj; ++q) {
+                hipLaunchKernelGGL(k_linear, grid, dim3(256), 0, st, in[q], ldin, nets[q]->W[j], nets[q]->b[j],
+                                   dst[q], lddst, n, I, O, g.activation, g.alpha, last ? 0 : 1);
+                GNF_LAUNCH_CHECK("k_linear");
+            }
+        }
+        in[0] = dst[0];
+        in[1] = dst[1];
         ldin = lddst;
     }
     return GNF_OK;
@@ -335,7 +505,7 @@ int launch_gnn_layered(const int32_t* rowptr, const int32_t* col, int64_t n, con
     float* bufB = bufA + n * lmax;
     int rc;
     if (mlp->attn) {
-        float* attn_scratch = scratch + (size_t)n * (size_t)(in0 + 2 * lmax + 2 * H);
+        float* attn_scratch = scratch + (size_t)n * (size_t)(in0 + kLayeredActBufs * lmax + 2 * H);
         const GnfAttn* at[1] = {mlp->attn};
         float* h0s[1] = {h0};
         rc = launch_attn_front(rowptr, col, n, x, ldx, H, at, 1, in0, attn_scratch, h0s, st);
@@ -344,13 +514,16 @@ int launch_gnn_layered(const int32_t* rowptr, const int32_t* col, int64_t n, con
                               g.combine == GNF_COMBINE_CONCAT ? 1 : 0, g.epsilon, h0, in0, st);
     }
     if (rc) return rc;
-    rc = run_mlp(mlp, h0, in0, bufA, bufB, lmax, out, ldo, n, g, st);
+    {
+        const float* h0c = h0;
+        rc = run_mlps(&mlp, 1, &h0c, in0, &bufA, &bufB, lmax, &out, ldo, n, g, st);
+    }
     if (rc) return rc;
     if (mlp->attn && mlp->attn->residual) return launch_add_rows(out, ldo, x, ldx, n, H, st);
     return GNF_OK;
 }
 
-// scratch layout (floats): h0 [N,in0] | bufA | bufB | s [N,H] | t [N,H] | attention region: qkv x2, h0_s, h0_t
+// scratch layout (floats): h0 [N,in0] | bufA,bufB (s) | bufA,bufB (t) | s [N,H] | t [N,H] | attention region: qkv x2, h0_s, h0_t
 int launch_half_layered(const HalfStep& hs, float* scratch, hipStream_t st) {
     const int64_t n = hs.n_nodes;
     *hs.n_partials = 0;
@@ -361,9 +534,9 @@ int launch_half_layered(const HalfStep& hs, float* scratch, hipStream_t st) {
     const int lt = lmax_of(hs.t_net);
     lmax = lmax > lt ? lmax : lt;
     float* h0 = scratch;
-    float* bufA = h0 + n * in0;
-    float* bufB = bufA + n * lmax;
-    float* sbuf = bufB + n * lmax;
+    float* bufA[2] = {h0 + n * in0, h0 + n * in0 + 2 * n * lmax};   // per net: A | B
+    float* bufB[2] = {bufA[0] + n * lmax, bufA[1] + n * lmax};
+    float* sbuf = bufA[0] + n * lmax * kLayeredActBufs;
     float* tbuf = sbuf + n * H;
     const float* h0s = h0;
     const float* h0t = h0;
@@ -378,9 +551,12 @@ int launch_half_layered(const HalfStep& hs, float* scratch, hipStream_t st) {
                               hs.gnn.combine == GNF_COMBINE_CONCAT ? 1 : 0, hs.gnn.epsilon, h0, in0, st);
     }
     if (rc) return rc;
-    rc = run_mlp(hs.s_net, h0s, in0, bufA, bufB, lmax, sbuf, H, n, hs.gnn, st);
-    if (rc) return rc;
-    rc = run_mlp(hs.t_net, h0t, in0, bufA, bufB, lmax, tbuf, H, n, hs.gnn, st);
+    {
+        const GnfMlp* nets[2] = {hs.s_net, hs.t_net};
+        const float* h0p[2] = {h0s, h0t};
+        float* outs[2] = {sbuf, tbuf};
+        rc = run_mlps(nets, 2, h0p, in0, bufA, bufB, lmax, outs, H, n, hs.gnn, st);
+    }
     if (rc) return rc;
     const bool res = hs.s_net->attn && hs.s_net->attn->residual;
     return launch_coupling(sbuf, tbuf, hs, res ? hs.x_cond : nullptr, st);
@@ -394,7 +570,7 @@ int launch_attn_pair(const HalfStep& hs, float* scratch, float** h0_pair, hipStr
     int lmax = lmax_of(hs.s_net);
     const int lt = lmax_of(hs.t_net);
     lmax = lmax > lt ? lmax : lt;
-    float* region = scratch + (size_t)n * (size_t)(in0 + 2 * lmax + 2 * hs.H);
+    float* region = scratch + (size_t)n * (size_t)(in0 + kLayeredActBufs * lmax + 2 * hs.H);
     const GnfAttn* a0 = hs.s_net->attn;
     const size_t P = 2 * (size_t)a0->num_heads * a0->kq_dim + a0->v_dim;
     h0_pair[0] = region + 2 * (size_t)n * P;

@@ -101,6 +101,10 @@ SHAPES = [
     (6, 20, 1, 2, "sum", "concat", 0.0, "leaky_relu", False),     # K = 1: a single Linear layer
     (32, 128, 4, 4, "mean", "agg", 1.0, "leaky_relu", True),
     (16, 8, 8, 1, "mean", "agg", 1.0, "leaky_relu", False),       # K = GNF_MAX_LAYERS
+    # train_grevnet_with_data.py:111-117 defaults (latent 2048, 3 layers, D = 200): too wide for the
+    # LDS-resident kernel, both settings run the layered path's matrix-core GEMM
+    (200, 2048, 3, 2, "mean", "agg", 1.0, "leaky_relu", False),
+    (70, 1100, 2, 1, "sum", "concat", 0.0, "relu", False),        # ragged in every GEMM dimension
 ]
 
 
