@@ -53,6 +53,9 @@ WORKLOADS = {
     "wide_fc": dict(desc="community_medium, fully connected, latent 2048 x 3 layers, D = 200, T = 10 (layered GEMM path)",
                     dataset="graph_rnn_community_medium", graphs=64, hp=dict(D=200, latent=2048, K=3, T=10),
                     inverse=False, fc=True),
+    # one training iteration of run_grevnet.py:440-447 per step: forward + reversible backward + Adam + re-pack
+    "config2_train": dict(desc="community_medium, TRAINING step (fwd + reversible backward + Adam)",
+                          dataset="graph_rnn_community_medium", graphs=64, hp={}, inverse=False, fc=False, train=True),
 }
 WORKLOAD = WORKLOADS["config2"]
 WEIGHT_SEED = 99
@@ -257,7 +260,15 @@ def main():
     sums3[2] = float(n_local)
     host = torch.zeros(args.steps + args.warmup + 1, 3, dtype=torch.float64).pin_memory()
 
+    trainer = None
+    if WORKLOAD.get("train"):
+        from gnf_amd.train import GRevNetTrainer
+        trainer = GRevNetTrainer(net, lr=1e-5, use_lr_decay=False)
+
     def step(i):
+        if trainer is not None:   # gradient all-reduce (one flat RCCL all-reduce) when sharded
+            trainer.step(graph, all_reduce=world > 1)
+            return
         if inverse:   # config 4: sampling direction g (gnn.py:343-373); no scalar comes back
             net(graph, inverse=False)
             return
@@ -288,6 +299,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
     ms_per_step = 1e3 * elapsed / args.steps
+    if trainer is not None:
+        host[args.warmup + args.steps - 1, :2] = net.last_sums[:2].cpu()
+        host[args.warmup + args.steps - 1, 2] = float(n_local)
     last = ({"log_prob_xs_per_node": None} if inverse else
             log_prob_from_sums(host[args.warmup + args.steps - 1].tolist(), HP["D"]))
     value = n_global * HP["T"] * args.steps / elapsed
@@ -295,7 +309,7 @@ def main():
     # ---- secondary figure: the same step when the batch's topology is new every step (training loop
     # of run_grevnet.py:440-447 draws a fresh batch per step): CSR rebuilt on device inside the step
     rebuild = None
-    if not inverse and world == 1:
+    if not inverse and world == 1 and trainer is None:
         from gnf_amd.graphs import clear_csr_cache
         nreb = max(10, min(50, args.steps))
         torch.cuda.synchronize()
@@ -413,7 +427,7 @@ def main():
         torch.cuda.synchronize()
         out["round_trip_max_abs_err"] = float((back.nodes - graph.nodes).abs().max())
         out["log_prob_xs_per_node"] = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not inverse:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not inverse and trainer is None:
         cb, ref = cpu_baseline(dicts, params)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_baseline"] = round(value / cb["value"], 2)

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 GNF_MAX_LAYERS = 8
-GNF_ABI_VERSION = 2
+GNF_ABI_VERSION = 3
 
 GNF_AGG_SUM, GNF_AGG_MEAN = 0, 1
 GNF_COMBINE_EPS, GNF_COMBINE_CONCAT = 0, 1
@@ -76,6 +76,15 @@ _SIGNATURES = {
     "gnf_pred_adj_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gnf_pred_adj_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gnf_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.POINTER(GnfFlow)]),
+    "gnf_grevnet_backward_f32": (C.c_int, [C.POINTER(GnfCsr), C.POINTER(GnfCsr), C.POINTER(GnfFlow),
+                                           C.POINTER(GnfFlow), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                           C.c_size_t, C.c_void_p]),
+    "gnf_pack_flow": (C.c_int, [C.POINTER(GnfFlow), C.c_void_p]),
+    "gnf_adam_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                               C.c_float, C.c_float, C.c_void_p]),
+    "gnf_clip_by_value_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p]),
+    "gnf_clip_by_norm_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p]),
     "gnf_gauss_sumsq_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p,
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
 }

@@ -138,6 +138,43 @@ static const GnfMlp* pick(const GnfFlow* f, const GnfMlp* nets, int half, int i)
     return f->weight_sharing ? &nets[half] : &nets[half * f->num_timesteps + i];
 }
 
+// Argument checks shared by the whole-flow entry points (forward / inverse / backward).
+int validate_flow_call(const GnfCsr* csr, const GnfFlow* flow, int64_t ld, int32_t D, const char* what) {
+    int rc = validate_csr(csr);
+    if (rc) return rc;
+    if (!flow || !flow->s_nets || !flow->t_nets) {
+        set_error("%s: null flow / nets", what);
+        return GNF_EINVAL;
+    }
+    rc = validate_spec(&flow->gnn);
+    if (rc) return rc;
+    if (flow->num_timesteps < 0) {
+        set_error("%s: num_timesteps=%d", what, flow->num_timesteps);
+        return GNF_ESHAPE;
+    }
+    if (D < 2 || (D & 1) || ld < D) {
+        // tf.split(x, 2, axis=1) (gnn.py:306) requires an even feature width
+        set_error("%s: D=%d must be even and >= 2, ld=%lld >= D", what, D, (long long)ld);
+        return GNF_ESHAPE;
+    }
+    const int H = D / 2;
+    const int T = flow->num_timesteps;
+    const int n_nets = flow->weight_sharing ? 2 : 2 * T;
+    for (int q = 0; q < n_nets; ++q) {
+        rc = validate_pair(&flow->s_nets[q], &flow->t_nets[q], &flow->gnn, H);
+        if (rc) return rc;
+        // one make_gnn_fn builds every net (gnn.py:266-267): identical layer widths
+        if (memcmp(flow->s_nets[q].dims, flow->s_nets[0].dims, sizeof(int32_t) * (GNF_MAX_LAYERS + 1)) ||
+            flow->s_nets[q].num_layers != flow->s_nets[0].num_layers ||
+            memcmp(flow->t_nets[q].dims, flow->s_nets[0].dims, sizeof(int32_t) * (GNF_MAX_LAYERS + 1)) ||
+            flow->t_nets[q].num_layers != flow->s_nets[0].num_layers) {
+            set_error("%s: net %d has different layer widths than net 0", what, q);
+            return GNF_ESHAPE;
+        }
+    }
+    return GNF_OK;
+}
+
 }  // namespace gnf
 
 using namespace gnf;
@@ -277,23 +314,8 @@ int gnf_coupling_half_f32(const GnfCsr* csr, const GnfMlp* s_net, const GnfMlp* 
 
 int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld, int32_t D,
                     int32_t direction, double* sums, void* ws, size_t ws_bytes, gnf_stream_t stream) {
-    int rc = validate_csr(csr);
+    int rc = validate_flow_call(csr, flow, ld, D, "gnf_grevnet_f32");
     if (rc) return rc;
-    if (!flow || !flow->s_nets || !flow->t_nets) {
-        set_error("gnf_grevnet_f32: null flow / nets");
-        return GNF_EINVAL;
-    }
-    rc = validate_spec(&flow->gnn);
-    if (rc) return rc;
-    if (flow->num_timesteps < 0) {
-        set_error("gnf_grevnet_f32: num_timesteps=%d", flow->num_timesteps);
-        return GNF_ESHAPE;
-    }
-    if (D < 2 || (D & 1) || ld < D) {
-        // tf.split(x, 2, axis=1) (gnn.py:306) requires an even feature width
-        set_error("gnf_grevnet_f32: D=%d must be even and >= 2, ld=%lld >= D", D, (long long)ld);
-        return GNF_ESHAPE;
-    }
     if (direction != GNF_FORWARD && direction != GNF_INVERSE) {
         set_error("gnf_grevnet_f32: direction=%d", direction);
         return GNF_EINVAL;
@@ -301,18 +323,6 @@ int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld
     const int H = D / 2;
     const int T = flow->num_timesteps;
     const int n_nets = flow->weight_sharing ? 2 : 2 * T;
-    for (int q = 0; q < n_nets; ++q) {
-        rc = validate_pair(&flow->s_nets[q], &flow->t_nets[q], &flow->gnn, H);
-        if (rc) return rc;
-        // one make_gnn_fn builds every net (gnn.py:266-267): identical layer widths
-        if (memcmp(flow->s_nets[q].dims, flow->s_nets[0].dims, sizeof(int32_t) * (GNF_MAX_LAYERS + 1)) ||
-            flow->s_nets[q].num_layers != flow->s_nets[0].num_layers ||
-            memcmp(flow->t_nets[q].dims, flow->s_nets[0].dims, sizeof(int32_t) * (GNF_MAX_LAYERS + 1)) ||
-            flow->t_nets[q].num_layers != flow->s_nets[0].num_layers) {
-            set_error("gnf_grevnet_f32: net %d has different layer widths than net 0", q);
-            return GNF_ESHAPE;
-        }
-    }
     if (direction == GNF_FORWARD && !sums) {
         set_error("gnf_grevnet_f32: FORWARD needs a device sums[2] buffer");
         return GNF_EINVAL;

@@ -89,6 +89,7 @@ int launch_pack_mlp(const GnfMlp* mlp, float* packed, hipStream_t st);
 int64_t packed_floats(const GnfMlp* mlp);
 
 int validate_mlp(const GnfMlp* m, const char* what);
+int validate_flow_call(const GnfCsr* csr, const GnfFlow* flow, int64_t ld, int32_t D, const char* what);
 // attention front-end (gnf_attn.hip)
 int validate_attn(const GnfAttn* at, const GnfMlp* mlp, int32_t H, const char* what);
 size_t attn_scratch_floats(const GnfAttn* at, int64_t n_nodes, int32_t in0);

@@ -1,0 +1,721 @@
+// Training step of the GRevNet hot path on gfx950: gradient of
+//     total_loss = -(sum_n log N(z_n; 0, I) + log_det_jacobian)            run_grevnet.py:291-295
+// with respect to every MLP weight and bias, by REVERSIBLE back-propagation: the backward pass walks
+// the coupling half-steps of f (gnn.py:304-341) in reverse, rebuilds each half-step's input from its
+// output with the inverse update (gnn.py:359,372) and recomputes the two GNNs, so no activation of
+// the forward pass is kept - what the drivers' `use_efficient_backprop` flag asks of the missing
+// GNFBlock (run_grevnet.py:46,282-288).  The reference gets the same numbers from tf.gradients
+// through optimizer.compute_gradients(total_loss) (run_grevnet.py:361-362).
+//
+// One half-step, given its output y (state) and g = dL/dy:
+//   recompute  h0 = combine(x_a, agg(x_a)); s, t = MLP_s(h0), MLP_t(h0)  (all layer outputs kept in the workspace)
+//   coupling   x_b = (y_b - t) exp(-s);  g_t = g_b;  g_s = g_b (y_b - t) - 1;  g_b <- g_b exp(s)
+//   per layer  dW_j = h_j^T dP_j (split over node chunks, fixed-order reduce), db_j = colsum(dP_j),
+//              dP_{j-1} = (dP_j W_j^T) * act'(h_j)
+//   message    g_a += eps dh0 + A^T (dh0 / max(deg, 1))      (transposed CSR; concat: the two column blocks)
+// All three GEMM shapes run on the exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32) through ONE kernel
+// whose operands are staged in LDS in their natural global layout, so no transposed copy of anything
+// is ever made.  Also here: the multi-tensor weight re-pack after an optimiser step, Adam
+// (tf.train.AdamOptimizer, run_grevnet.py:352-356) and the two gradient clippers (run_grevnet.py:363-373).
+#include "gnf_common.h"
+
+#include <string.h>
+
+namespace gnf {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+static constexpr int TGM = 128, TGN = 64, TGK = 32;
+static constexpr int kGemmThreads = 512;
+
+// operand storage: KC = rows indexed by the GEMM's m (or n), k contiguous;  MC = rows indexed by k
+enum { OPND_KC = 0, OPND_MC = 1 };
+enum { EPI_BIAS_ACT = 0, EPI_MASK = 1, EPI_SLAB = 2 };
+
+struct GemmJob {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* aux;  // EPI_BIAS_ACT: bias [N];  EPI_MASK: activation matrix [M, N] or NULL
+    float* aux_out;    // EPI_SLAB: column sums of B per k-chunk [chunks, N] or NULL
+};
+
+struct GemmShape {
+    int64_t lda, ldb, ldc, ldaux;
+    int64_t M, K;    // rows of C, reduction length
+    int32_t N;       // columns of C
+    int32_t chunks;  // split of K (EPI_SLAB only; 1 otherwise)
+    int64_t kchunk;  // multiple of TGK
+    int32_t act;
+    float alpha;
+    int32_t apply_act;
+};
+
+// One R x C tile (C contiguous) of a row-major matrix -> registers (U float4 per thread), zero filled
+// outside [rlim, clim).
+template <int R, int C, int U>
+__device__ __forceinline__ void tile_fetch(const float* __restrict__ base, int64_t ld, int64_t rlim, int64_t clim,
+                                           bool vec, int tid, f32x4_t (&v)[U]) {
+    constexpr int C4 = C / 4;
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+        const int u = tid + q * kGemmThreads;
+        const int r = u / C4, c = (u % C4) * 4;
+        f32x4_t w = {0.f, 0.f, 0.f, 0.f};
+        if (r < rlim && c < clim) {
+            const float* p = base + (int64_t)r * ld + c;
+            if (vec && c + 3 < clim) {
+                w = *reinterpret_cast<const f32x4_t*>(p);
+            } else {
+                w[0] = p[0];
+                if (c + 1 < clim) w[1] = p[1];
+                if (c + 2 < clim) w[2] = p[2];
+                if (c + 3 < clim) w[3] = p[3];
+            }
+        }
+        v[q] = w;
+    }
+}
+
+template <int R, int C, int U>
+__device__ __forceinline__ void tile_stash(float* __restrict__ lds, int tid, const f32x4_t (&v)[U]) {
+    constexpr int C4 = C / 4;
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+        const int u = tid + q * kGemmThreads;
+        const int r = u / C4, c = (u % C4) * 4;
+        *reinterpret_cast<f32x4_t*>(lds + r * (C + 4) + c) = v[q];
+    }
+}
+
+// C[M, N] = A . B.  128 x 64 output tile per workgroup, BK = 32, 8 waves (wave w: rows (w & 3) * 32,
+// columns (w >> 2) * 32, 2 x 2 MFMA tiles); the next k-tile is fetched into registers while the matrix
+// cores work on the current one.  blockIdx.z = job * chunks + chunk.
+template <int AK, int BK, int EPI>
+__global__ __launch_bounds__(kGemmThreads) void k_gemm(GemmJob j0, GemmJob j1, GemmShape sh) {
+    constexpr int AR = AK == OPND_KC ? TGM : TGK, AC = AK == OPND_KC ? TGK : TGM;  // LDS tile rows x cols
+    constexpr int BR = BK == OPND_KC ? TGN : TGK, BC = BK == OPND_KC ? TGK : TGN;
+    __shared__ __attribute__((aligned(16))) float As[AR * (AC + 4)];
+    __shared__ __attribute__((aligned(16))) float Bs[BR * (BC + 4)];
+    const int jz = blockIdx.z / sh.chunks, chunk = blockIdx.z - jz * sh.chunks;
+    const GemmJob job = jz ? j1 : j0;
+    const int64_t m0 = (int64_t)blockIdx.y * TGM;
+    const int n0 = blockIdx.x * TGN;
+    const int64_t kbeg = (int64_t)chunk * sh.kchunk;
+    const int64_t kend = (EPI == EPI_SLAB) ? (kbeg + sh.kchunk < sh.K ? kbeg + sh.kchunk : sh.K) : sh.K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    const int wm = (wave & 3) * 32, wn = (wave >> 2) * 32;
+    const bool avec = (sh.lda % 4 == 0) && (reinterpret_cast<uintptr_t>(job.A) % 16 == 0);
+    const bool bvec = (sh.ldb % 4 == 0) && (reinterpret_cast<uintptr_t>(job.B) % 16 == 0);
+
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float bv = 0.f;
+            if (EPI == EPI_BIAS_ACT) {
+                const int gc = n0 + wn + 16 * b + lrow;
+                bv = gc < sh.N ? job.aux[gc] : 0.f;
+            }
+            acc[m][b] = f32x4_t{bv, bv, bv, bv};
+        }
+    float colsum = 0.f;  // EPI_SLAB: sum over this chunk's k of B[k][n0 + tid]
+
+    f32x4_t av[2], bvr[1];
+    auto fetch = [&](int64_t k0) {
+        if (AK == OPND_KC)
+            tile_fetch<AR, AC, 2>(job.A + m0 * sh.lda + k0, sh.lda, sh.M - m0, kend - k0, avec, tid, av);
+        else
+            tile_fetch<AR, AC, 2>(job.A + k0 * sh.lda + m0, sh.lda, kend - k0, sh.M - m0, avec, tid, av);
+        if (BK == OPND_KC)
+            tile_fetch<BR, BC, 1>(job.B + (int64_t)n0 * sh.ldb + k0, sh.ldb, sh.N - n0, kend - k0, bvec, tid, bvr);
+        else
+            tile_fetch<BR, BC, 1>(job.B + k0 * sh.ldb + n0, sh.ldb, kend - k0, sh.N - n0, bvec, tid, bvr);
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int64_t k0 = kbeg; k0 < kend; k0 += TGK) {
+        __syncthreads();  // previous tile fully consumed
+        tile_stash<AR, AC, 2>(As, tid, av);
+        tile_stash<BR, BC, 1>(Bs, tid, bvr);
+        __syncthreads();
+        if (k0 + TGK < kend) fetch(k0 + TGK);
+        if (EPI == EPI_SLAB && BK == OPND_MC) {
+            if (blockIdx.y == 0 && tid < TGN) {
+#pragma unroll 8
+                for (int k = 0; k < TGK; ++k) colsum += Bs[k * (BC + 4) + tid];
+            }
+        }
+#pragma unroll
+        for (int kg = 0; kg < TGK / 16; ++kg) {
+            float a[2][4], b[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                if (AK == OPND_KC) {
+                    const f32x4_t t = *reinterpret_cast<const f32x4_t*>(As + (wm + 16 * m + lrow) * (AC + 4) + 16 * kg + 4 * lgrp);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[m][q] = t[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[m][q] = As[(16 * kg + 4 * lgrp + q) * (AC + 4) + wm + 16 * m + lrow];
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                if (BK == OPND_KC) {
+                    const f32x4_t t = *reinterpret_cast<const f32x4_t*>(Bs + (wn + 16 * n + lrow) * (BC + 4) + 16 * kg + 4 * lgrp);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b[n][q] = t[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b[n][q] = Bs[(16 * kg + 4 * lgrp + q) * (BC + 4) + wn + 16 * n + lrow];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][q], b[n][q], acc[m][n], 0, 0, 0);
+        }
+    }
+    // accumulator layout: col = lane & 15, row = 4 * (lane >> 4) + r
+    float* __restrict__ Cp = job.C;
+    if (EPI == EPI_SLAB) Cp += (int64_t)chunk * sh.M * sh.N;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int gc = n0 + wn + 16 * b + lrow;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gr = m0 + wm + 16 * m + 4 * lgrp + r;
+                if (gr < sh.M && gc < sh.N) {
+                    float v = acc[m][b][r];
+                    if (EPI == EPI_BIAS_ACT) {
+                        if (sh.apply_act) v = (sh.act == GNF_ACT_RELU) ? fmaxf(v, 0.f) : fmaxf(v, sh.alpha * v);
+                    } else if (EPI == EPI_MASK) {
+                        if (job.aux) {  // act'(pre) read off the stored activation: h > 0 <=> pre > 0
+                            const float h = job.aux[gr * sh.ldaux + gc];
+                            const float slope = (sh.act == GNF_ACT_RELU) ? 0.f : sh.alpha;
+                            v = h > 0.f ? v : v * slope;
+                        }
+                    }
+                    Cp[gr * sh.ldc + gc] = v;
+                }
+            }
+        }
+    if (EPI == EPI_SLAB && job.aux_out && blockIdx.y == 0 && tid < TGN && n0 + tid < sh.N)
+        job.aux_out[(int64_t)chunk * sh.N + n0 + tid] = colsum;
+}
+
+template <int AK, int BK, int EPI>
+static int launch_gemm(const GemmJob* jobs, int nj, const GemmShape& sh, hipStream_t st) {
+    if (sh.M == 0 || sh.N == 0) return GNF_OK;
+    dim3 grid((unsigned)((sh.N + TGN - 1) / TGN), (unsigned)((sh.M + TGM - 1) / TGM), (unsigned)(nj * sh.chunks));
+    hipLaunchKernelGGL((k_gemm<AK, BK, EPI>), grid, dim3(kGemmThreads), 0, st, jobs[0], jobs[nj - 1], sh);
+    GNF_LAUNCH_CHECK("k_gemm");
+    return GNF_OK;
+}
+
+// G[e] (+)= sum over chunks of slab[chunk][e]   (fixed order).  blockIdx.y = job.
+struct ReduceJob {
+    const float* wslab;
+    const float* bslab;
+    float* gw;
+    float* gb;
+};
+__global__ __launch_bounds__(256) void k_reduce_slabs(ReduceJob j0, ReduceJob j1, int64_t nw, int nb, int chunks,
+                                                      int accumulate) {
+    const ReduceJob job = blockIdx.y ? j1 : j0;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < nw) {
+        float s = 0.f;
+        for (int c = 0; c < chunks; ++c) s += job.wslab[(int64_t)c * nw + e];
+        job.gw[e] = accumulate ? job.gw[e] + s : s;
+    } else if (e < nw + nb) {
+        const int i = (int)(e - nw);
+        float s = 0.f;
+        for (int c = 0; c < chunks; ++c) s += job.bslab[(int64_t)c * nb + i];
+        job.gb[i] = accumulate ? job.gb[i] + s : s;
+    }
+}
+
+// g[N, D] <- z[N, D]: dL/dz of L = 1/2 sum z^2 + const - logdet
+__global__ __launch_bounds__(256) void k_copy_rows(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst,
+                                                   int64_t ldd, int64_t n, int W) {
+    const int64_t total = n * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / W;
+        const int f = (int)(i - r * W);
+        dst[r * ldd + f] = src[r * lds_ + f];
+    }
+}
+
+// coupling backward (see the file header): y, g in place; gs, gt dense [N, H]
+__global__ __launch_bounds__(256) void k_coupling_bwd(const float* __restrict__ s, const float* __restrict__ t,
+                                                      float* __restrict__ y, int64_t ldy, float* __restrict__ g,
+                                                      int64_t ldg, float* __restrict__ gs, float* __restrict__ gt,
+                                                      int64_t n, int H) {
+    const int64_t total = n * H;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / H;
+        const int f = (int)(i - r * H);
+        const float sv = s[i], tv = t[i];
+        const float yv = y[r * ldy + f], gv = g[r * ldg + f];
+        const float d = yv - tv;
+        y[r * ldy + f] = d * expf(-sv);   // the half-step's input, gnn.py:359,372
+        g[r * ldg + f] = gv * expf(sv);
+        gs[i] = gv * d - 1.f;             // through x_b exp(s), and -1 from -logdet
+        gt[i] = gv;
+    }
+}
+
+// message-passing backward: g_cond[u, f] += base + sum over edges u -> v of dh[v, aggcol + f] * w(v)
+//   dh = dh_s + dh_t ([N, in0] each);  agg-combine: base = eps * dh[u, f], aggcol = 0;
+//   concat: base = dh[u, f], aggcol = H;  w(v) = 1 / max(indeg(v), 1) for the mean aggregator.
+// rowptr_t / col_t: CSR by SENDER (row u lists the receivers v of u's out-edges, in edge order).
+__global__ __launch_bounds__(256) void k_aggregate_bwd(const int32_t* __restrict__ rowptr_t,
+                                                       const int32_t* __restrict__ col_t,
+                                                       const int32_t* __restrict__ rowptr, int64_t n,
+                                                       const float* __restrict__ dhs, const float* __restrict__ dht,
+                                                       int in0, int H, int mean, int concat, float eps,
+                                                       float* __restrict__ g, int64_t ldg, int G) {
+    const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    const int gl = threadIdx.x & (G - 1);
+    if (u >= n) return;
+    const int beg = rowptr_t[u], end = rowptr_t[u + 1];
+    const int aggcol = concat ? H : 0;
+    for (int f = gl; f < H; f += G) {
+        float acc = 0.f;
+        for (int e = beg; e < end; ++e) {
+            const int v = col_t[e];
+            float w = 1.f;
+            if (mean) {
+                const int dg = rowptr[v + 1] - rowptr[v];
+                w = 1.f / (float)(dg > 1 ? dg : 1);
+            }
+            const int64_t o = (int64_t)v * in0 + aggcol + f;
+            acc += (dhs[o] + dht[o]) * w;
+        }
+        const int64_t o = u * in0 + f;
+        const float own = dhs[o] + dht[o];
+        g[u * ldg + f] += (concat ? own : eps * own) + acc;
+    }
+}
+
+// ---- workspace ---------------------------------------------------------------------------------
+struct BwdPlan {
+    int K, in0, lmax, H, chunks;
+    int64_t n, kchunk;
+    size_t g, h0, acts, st, gst, dbuf, dh0, wslab, bslab, total;  // float offsets
+};
+
+static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net) {
+    BwdPlan p;
+    memset(&p, 0, sizeof(p));
+    p.n = n;
+    p.H = D / 2;
+    p.K = net->num_layers;
+    p.in0 = net->dims[0];
+    int lmax = 1, wmax = 1;
+    for (int j = 0; j < p.K; ++j) {
+        if (j >= 1) lmax = lmax > net->dims[j] ? lmax : net->dims[j];
+        const int w = net->dims[j] * net->dims[j + 1];
+        wmax = wmax > w ? wmax : w;
+    }
+    int omax = 1;
+    for (int j = 1; j <= p.K; ++j) omax = omax > net->dims[j] ? omax : net->dims[j];
+    p.lmax = lmax;
+    // split of the node axis for dW: enough workgroups to fill the chip, chunks of >= 128 nodes
+    int64_t chunks = (n + 127) / 128;
+    if (chunks > 64) chunks = 64;
+    if (chunks < 1) chunks = 1;
+    int64_t kchunk = (n + chunks - 1) / chunks;
+    kchunk = (kchunk + TGK - 1) / TGK * TGK;
+    if (kchunk < TGK) kchunk = TGK;
+    chunks = n > 0 ? (n + kchunk - 1) / kchunk : 1;
+    p.chunks = (int)chunks;
+    p.kchunk = kchunk;
+    auto al = [](size_t v) { return (v + 63) / 64 * 64; };  // keep every region 256-byte aligned
+    size_t off = 0;
+    p.g = off, off += al((size_t)n * D);
+    p.h0 = off, off += al((size_t)n * p.in0);
+    p.acts = off, off += 2 * (size_t)(p.K > 1 ? p.K - 1 : 0) * al((size_t)n * lmax);
+    p.st = off, off += 2 * al((size_t)n * p.H);
+    p.gst = off, off += 2 * al((size_t)n * p.H);
+    p.dbuf = off, off += 4 * al((size_t)n * lmax);
+    p.dh0 = off, off += 2 * al((size_t)n * p.in0);
+    p.wslab = off, off += 2 * al((size_t)chunks * wmax);
+    p.bslab = off, off += 2 * al((size_t)chunks * omax);
+    p.total = off;
+    return p;
+}
+
+static inline size_t al64(size_t v) { return (v + 63) / 64 * 64; }
+
+static const GnfMlp* pick_net(const GnfFlow* f, const GnfMlp* nets, int half, int i) {
+    return f->weight_sharing ? &nets[half] : &nets[half * f->num_timesteps + i];
+}
+
+static int backward_half(const BwdPlan& p, const GnfCsr* csr, const GnfCsr* csr_t, const GnfGnnSpec& gnn,
+                         const GnfMlp* const* nets, const GnfMlp* const* grads, bool accumulate, float* x_cond,
+                         float* y_upd, int64_t ld, float* g_cond, float* g_upd, int64_t ldg, float* ws,
+                         hipStream_t st) {
+    const int64_t n = p.n;
+    const int K = p.K, H = p.H, in0 = p.in0;
+    const int64_t lmax = p.lmax;
+    float* h0 = ws + p.h0;
+    const size_t act_sz = al64((size_t)n * lmax);
+    auto act = [&](int net, int j) -> float* {  // output of layer j-1 = input of layer j (j >= 1)
+        return ws + p.acts + ((size_t)net * (K - 1) + (j - 1)) * act_sz;
+    };
+    float* stb[2] = {ws + p.st, ws + p.st + al64((size_t)n * H)};
+    float* gst[2] = {ws + p.gst, ws + p.gst + al64((size_t)n * H)};
+    float* dbuf[2][2] = {{ws + p.dbuf, ws + p.dbuf + act_sz}, {ws + p.dbuf + 2 * act_sz, ws + p.dbuf + 3 * act_sz}};
+    float* dh0[2] = {ws + p.dh0, ws + p.dh0 + al64((size_t)n * in0)};
+    int rc = launch_aggregate(csr->rowptr, csr->col, n, x_cond, ld, H, gnn.agg == GNF_AGG_MEAN,
+                              gnn.combine == GNF_COMBINE_CONCAT ? 1 : 0, gnn.epsilon, h0, in0, st);
+    if (rc) return rc;
+    // ---- recompute the two MLPs, keeping every layer output ------------------------------------
+    for (int j = 0; j < K; ++j) {
+        const int I = nets[0]->dims[j], O = nets[0]->dims[j + 1];
+        const bool last = j == K - 1;
+        GemmJob jobs[2];
+        for (int q = 0; q < 2; ++q)
+            jobs[q] = GemmJob{j == 0 ? h0 : act(q, j), nets[q]->W[j], last ? stb[q] : act(q, j + 1), nets[q]->b[j], nullptr};
+        GemmShape sh;
+        memset(&sh, 0, sizeof(sh));
+        sh.lda = j == 0 ? in0 : lmax;
+        sh.ldb = O;
+        sh.ldc = last ? H : lmax;
+        sh.M = n, sh.K = I, sh.N = O, sh.chunks = 1, sh.kchunk = TGK;
+        sh.act = gnn.activation, sh.alpha = gnn.alpha, sh.apply_act = last ? 0 : 1;
+        rc = launch_gemm<OPND_KC, OPND_MC, EPI_BIAS_ACT>(jobs, 2, sh, st);
+        if (rc) return rc;
+    }
+    // ---- coupling ------------------------------------------------------------------------------
+    {
+        int64_t blocks = (n * H + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_coupling_bwd, dim3((unsigned)blocks), dim3(256), 0, st, stb[0], stb[1], y_upd, ld,
+                           g_upd, ldg, gst[0], gst[1], n, H);
+        GNF_LAUNCH_CHECK("k_coupling_bwd");
+    }
+    // ---- layers, last to first -----------------------------------------------------------------
+    for (int j = K - 1; j >= 0; --j) {
+        const int I = nets[0]->dims[j], O = nets[0]->dims[j + 1];
+        const float* dP[2];
+        int64_t lddp;
+        for (int q = 0; q < 2; ++q) dP[q] = (j == K - 1) ? gst[q] : dbuf[q][j & 1];
+        lddp = (j == K - 1) ? H : lmax;
+        // dW_j, db_j: [I, nodes] x [nodes, O] split over node chunks
+        {
+            GemmJob jobs[2];
+            float* wsl[2] = {ws + p.wslab, ws + p.wslab + (p.bslab - p.wslab) / 2};
+            float* bsl[2] = {ws + p.bslab, ws + p.bslab + (p.total - p.bslab) / 2};
+            for (int q = 0; q < 2; ++q) jobs[q] = GemmJob{j == 0 ? h0 : act(q, j), dP[q], wsl[q], nullptr, bsl[q]};
+            GemmShape sh;
+            memset(&sh, 0, sizeof(sh));
+            sh.lda = j == 0 ? in0 : lmax;
+            sh.ldb = lddp;
+            sh.ldc = O;
+            sh.M = I, sh.K = n, sh.N = O, sh.chunks = p.chunks, sh.kchunk = p.kchunk;
+            rc = launch_gemm<OPND_MC, OPND_MC, EPI_SLAB>(jobs, 2, sh, st);
+            if (rc) return rc;
+            const int64_t nw = (int64_t)I * O;
+            ReduceJob rj[2];
+            for (int q = 0; q < 2; ++q) rj[q] = ReduceJob{wsl[q], bsl[q], const_cast<float*>(grads[q]->W[j]), const_cast<float*>(grads[q]->b[j])};
+            hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((nw + O + 255) / 256), 2), dim3(256), 0, st, rj[0],
+                               rj[1], nw, O, p.chunks, accumulate ? 1 : 0);
+            GNF_LAUNCH_CHECK("k_reduce_slabs");
+        }
+        // dP_{j-1} = (dP_j W_j^T) * act'(h_j)      [nodes, O] x [O, I]
+        {
+            GemmJob jobs[2];
+            for (int q = 0; q < 2; ++q)
+                jobs[q] = GemmJob{dP[q], nets[q]->W[j], j == 0 ? dh0[q] : dbuf[q][(j - 1) & 1],
+                                  j == 0 ? nullptr : act(q, j), nullptr};
+            GemmShape sh;
+            memset(&sh, 0, sizeof(sh));
+            sh.lda = lddp;
+            sh.ldb = O;
+            sh.ldc = j == 0 ? in0 : lmax;
+            sh.ldaux = lmax;
+            sh.M = n, sh.K = O, sh.N = I, sh.chunks = 1, sh.kchunk = TGK;
+            sh.act = gnn.activation, sh.alpha = gnn.alpha;
+            rc = launch_gemm<OPND_KC, OPND_KC, EPI_MASK>(jobs, 2, sh, st);
+            if (rc) return rc;
+        }
+    }
+    // ---- message passing -----------------------------------------------------------------------
+    {
+        int G = 1;
+        while (G < H && G < 64) G <<= 1;
+        const int64_t blocks = (n * G + 255) / 256;
+        hipLaunchKernelGGL(k_aggregate_bwd, dim3((unsigned)blocks), dim3(256), 0, st, csr_t->rowptr, csr_t->col,
+                           csr->rowptr, n, dh0[0], dh0[1], in0, H, gnn.agg == GNF_AGG_MEAN ? 1 : 0,
+                           gnn.combine == GNF_COMBINE_CONCAT ? 1 : 0, gnn.epsilon, g_cond, ldg, G);
+        GNF_LAUNCH_CHECK("k_aggregate_bwd");
+    }
+    return GNF_OK;
+}
+
+// ---- multi-tensor re-pack (after an optimiser step every net's MFMA fragment copy is stale) ----------
+struct PackDesc {
+    const float* W;
+    const float* b;
+    float* wout;
+    float* bout;
+    int32_t I, O, Ip, Op;
+};
+static constexpr int kPackBatch = 64;
+struct PackBatch {
+    PackDesc d[kPackBatch];
+};
+
+__global__ __launch_bounds__(256) void k_pack_multi(const PackBatch pb) {
+    const PackDesc& d = pb.d[blockIdx.y];
+    const int64_t nw = (int64_t)d.Ip * d.Op;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nw) {  // same fragment order as k_pack_layer (gnf_fused.hip)
+        const int q = (int)(i & 3);
+        const int lane = (int)((i >> 2) & 63);
+        const int64_t blk = i >> 8;
+        const int nts = d.Op >> 4;
+        const int kg = (int)(blk / nts), nt = (int)(blk % nts);
+        const int k = 16 * kg + 4 * (lane >> 4) + q;
+        const int c = 16 * nt + (lane & 15);
+        d.wout[i] = (k < d.I && c < d.O) ? d.W[(int64_t)k * d.O + c] : 0.f;
+    } else if (i < nw + d.Op) {
+        const int c = (int)(i - nw);
+        d.bout[c] = c < d.O ? d.b[c] : 0.f;
+    }
+}
+
+static inline int pad16i(int v) { return (v + 15) & ~15; }
+
+static int pack_flow(const GnfFlow* flow, hipStream_t st) {
+    const int n_nets = flow->weight_sharing ? 2 : 2 * flow->num_timesteps;
+    PackBatch pb;
+    int cnt = 0;
+    int64_t maxtot = 0;
+    auto flush = [&]() -> int {
+        if (!cnt) return GNF_OK;
+        hipLaunchKernelGGL(k_pack_multi, dim3((unsigned)((maxtot + 255) / 256), cnt), dim3(256), 0, st, pb);
+        GNF_LAUNCH_CHECK("k_pack_multi");
+        cnt = 0;
+        maxtot = 0;
+        return GNF_OK;
+    };
+    for (int kind = 0; kind < 2; ++kind)
+        for (int q = 0; q < n_nets; ++q) {
+            const GnfMlp* m = kind ? &flow->t_nets[q] : &flow->s_nets[q];
+            if (!m->packed) continue;
+            int64_t woff = 0, boff = 0;
+            for (int j = 0; j < m->num_layers; ++j) boff += (int64_t)pad16i(m->dims[j]) * pad16i(m->dims[j + 1]);
+            for (int j = 0; j < m->num_layers; ++j) {
+                const int I = m->dims[j], O = m->dims[j + 1], Ip = pad16i(I), Op = pad16i(O);
+                float* pk = const_cast<float*>(m->packed);
+                pb.d[cnt++] = PackDesc{m->W[j], m->b[j], pk + woff, pk + boff, I, O, Ip, Op};
+                const int64_t tot = (int64_t)Ip * Op + Op;
+                maxtot = maxtot > tot ? maxtot : tot;
+                woff += (int64_t)Ip * Op;
+                boff += Op;
+                if (cnt == kPackBatch) {
+                    const int rc = flush();
+                    if (rc) return rc;
+                }
+            }
+        }
+    return flush();
+}
+
+// ---- optimiser ---------------------------------------------------------------------------------
+// tf.train.AdamOptimizer (run_grevnet.py:352-356): lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) is computed by the
+// caller (fp64 on the host, like TF's python side);  m <- b1 m + (1-b1) g;  v <- b2 v + (1-b2) g^2;
+// w <- w - lr_t m / (sqrt(v) + eps)
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, int64_t n, float lr_t, float b1, float b2,
+                                              float eps) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gv = g[i];
+        const float mv = b1 * m[i] + (1.f - b1) * gv;
+        const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+        m[i] = mv;
+        v[i] = vv;
+        w[i] = w[i] - lr_t * mv / (sqrtf(vv) + eps);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_clip_value(float* __restrict__ g, int64_t n, float lo, float hi) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        g[i] = fminf(fmaxf(g[i], lo), hi);
+}
+
+// tf.clip_by_norm per gradient tensor (run_grevnet.py:369-372): t * clip / max(||t||_2, clip).
+// One workgroup per tensor; offsets[i] .. offsets[i+1] delimit tensor i inside the flat gradient.
+__global__ __launch_bounds__(256) void k_clip_norm(float* __restrict__ g, const int64_t* __restrict__ offsets,
+                                                   float clip) {
+    __shared__ double red[256];
+    const int64_t beg = offsets[blockIdx.x], end = offsets[blockIdx.x + 1];
+    double s = 0.0;
+    for (int64_t i = beg + threadIdx.x; i < end; i += 256) s += (double)g[i] * (double)g[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float nrm = (float)sqrt(red[0]);
+    const float scale = clip / fmaxf(nrm, clip);
+    for (int64_t i = beg + threadIdx.x; i < end; i += 256) g[i] *= scale;
+}
+
+}  // namespace gnf
+
+using namespace gnf;
+
+extern "C" {
+
+size_t gnf_backward_workspace_bytes(int64_t n_nodes, int32_t D, const GnfFlow* flow) {
+    if (n_nodes < 0 || D < 2 || (D & 1) || !flow || !flow->s_nets) return 0;
+    return plan_backward(n_nodes, D, &flow->s_nets[0]).total * sizeof(float);
+}
+
+int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFlow* flow, const GnfFlow* grad,
+                             float* z, int64_t ld, int32_t D, void* ws, size_t ws_bytes, gnf_stream_t stream) {
+    int rc = validate_flow_call(csr, flow, ld, D, "gnf_grevnet_backward_f32");
+    if (rc) return rc;
+    if (!csr_t || csr_t->n_nodes != csr->n_nodes || csr_t->n_edges != csr->n_edges ||
+        (csr->n_nodes > 0 && (!csr_t->rowptr || (csr->n_edges > 0 && !csr_t->col)))) {
+        set_error("gnf_grevnet_backward_f32: csr_t must be the by-sender CSR of the same batch");
+        return GNF_EINVAL;
+    }
+    if (!grad || !grad->s_nets || !grad->t_nets || grad->num_timesteps != flow->num_timesteps ||
+        grad->weight_sharing != flow->weight_sharing) {
+        set_error("gnf_grevnet_backward_f32: grad must mirror flow (same T, weight_sharing)");
+        return GNF_EINVAL;
+    }
+    const int T = flow->num_timesteps;
+    const int n_nets = flow->weight_sharing ? 2 : 2 * T;
+    for (int q = 0; q < n_nets; ++q) {
+        const GnfMlp* pairs[2][2] = {{&flow->s_nets[q], &grad->s_nets[q]}, {&flow->t_nets[q], &grad->t_nets[q]}};
+        for (auto& pr : pairs) {
+            if (pr[0]->attn) {
+                set_error("gnf_grevnet_backward_f32: attention GNNs have no backward pass yet");
+                return GNF_EUNSUPPORTED;
+            }
+            if (pr[1]->num_layers != pr[0]->num_layers ||
+                memcmp(pr[1]->dims, pr[0]->dims, sizeof(int32_t) * (pr[0]->num_layers + 1))) {
+                set_error("gnf_grevnet_backward_f32: grad net %d has other layer widths than the flow's", q);
+                return GNF_ESHAPE;
+            }
+            for (int j = 0; j < pr[0]->num_layers; ++j)
+                if (!pr[1]->W[j] || !pr[1]->b[j]) {
+                    set_error("gnf_grevnet_backward_f32: grad net %d layer %d has null buffers", q, j);
+                    return GNF_EINVAL;
+                }
+        }
+    }
+    const int64_t n = csr->n_nodes;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_nets == 0) return GNF_OK;
+    const BwdPlan p = plan_backward(n, D, &flow->s_nets[0]);
+    if (n > 0 && (!z || !ws || ws_bytes < p.total * sizeof(float))) {
+        set_error("gnf_grevnet_backward_f32: workspace %zu < %zu bytes (or null z/ws)", ws_bytes,
+                  p.total * sizeof(float));
+        return GNF_EWORKSPACE;
+    }
+    const int H = D / 2;
+    if (n == 0) {  // an empty batch has zero gradient
+        for (int q = 0; q < n_nets; ++q)
+            for (int kind = 0; kind < 2; ++kind) {
+                const GnfMlp* gm = kind ? &grad->t_nets[q] : &grad->s_nets[q];
+                for (int j = 0; j < gm->num_layers; ++j) {
+                    GNF_HIP_TRY(hipMemsetAsync(const_cast<float*>(gm->W[j]), 0, sizeof(float) * gm->dims[j] * gm->dims[j + 1], st));
+                    GNF_HIP_TRY(hipMemsetAsync(const_cast<float*>(gm->b[j]), 0, sizeof(float) * gm->dims[j + 1], st));
+                }
+            }
+        return GNF_OK;
+    }
+    float* wsf = (float*)ws;
+    float* g = wsf + p.g;
+    {
+        int64_t blocks = (n * D + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)blocks), dim3(256), 0, st, z, ld, g, (int64_t)D, n, D);
+        GNF_LAUNCH_CHECK("k_copy_rows");
+    }
+    bool used[2] = {false, false};  // weight sharing: the T uses of a net accumulate
+    for (int i = T - 1; i >= 0; --i)
+        for (int half = 1; half >= 0; --half) {
+            const GnfMlp* nets[2] = {pick_net(flow, flow->s_nets, half, i), pick_net(flow, flow->t_nets, half, i)};
+            const GnfMlp* grads[2] = {pick_net(grad, grad->s_nets, half, i), pick_net(grad, grad->t_nets, half, i)};
+            const bool acc = flow->weight_sharing && used[half];
+            used[half] = true;
+            const int co = half == 0 ? 0 : H, uo = half == 0 ? H : 0;
+            rc = backward_half(p, csr, csr_t, flow->gnn, nets, grads, acc, z + co, z + uo, ld, g + co, g + uo, D,
+                               wsf, st);
+            if (rc) return rc;
+        }
+    return GNF_OK;
+}
+
+int gnf_pack_flow(const GnfFlow* flow, gnf_stream_t stream) {
+    if (!flow || !flow->s_nets || !flow->t_nets || flow->num_timesteps < 0) {
+        set_error("gnf_pack_flow: null flow / nets");
+        return GNF_EINVAL;
+    }
+    const int n_nets = flow->weight_sharing ? 2 : 2 * flow->num_timesteps;
+    for (int q = 0; q < n_nets; ++q) {
+        int rc = validate_mlp(&flow->s_nets[q], "gnf_pack_flow s_net");
+        if (rc) return rc;
+        rc = validate_mlp(&flow->t_nets[q], "gnf_pack_flow t_net");
+        if (rc) return rc;
+    }
+    return pack_flow(flow, (hipStream_t)stream);
+}
+
+int gnf_adam_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                 float epsilon, gnf_stream_t stream) {
+    if (n < 0 || (n > 0 && (!w || !g || !m || !v))) {
+        set_error("gnf_adam_f32: null buffer or n=%lld", (long long)n);
+        return GNF_EINVAL;
+    }
+    if (n == 0) return GNF_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n, lr_t, beta1,
+                       beta2, epsilon);
+    GNF_LAUNCH_CHECK("k_adam");
+    return GNF_OK;
+}
+
+int gnf_clip_by_value_f32(float* g, int64_t n, float lo, float hi, gnf_stream_t stream) {
+    if (n < 0 || (n > 0 && !g) || !(lo <= hi)) {
+        set_error("gnf_clip_by_value_f32: bad arguments");
+        return GNF_EINVAL;
+    }
+    if (n == 0) return GNF_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_clip_value, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, lo, hi);
+    GNF_LAUNCH_CHECK("k_clip_value");
+    return GNF_OK;
+}
+
+int gnf_clip_by_norm_f32(float* g, const int64_t* offsets, int32_t n_tensors, float clip_norm, gnf_stream_t stream) {
+    if (n_tensors < 0 || (n_tensors > 0 && (!g || !offsets)) || !(clip_norm > 0.f)) {
+        set_error("gnf_clip_by_norm_f32: bad arguments");
+        return GNF_EINVAL;
+    }
+    if (n_tensors == 0) return GNF_OK;
+    hipLaunchKernelGGL(k_clip_norm, dim3((unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, g, offsets, clip_norm);
+    GNF_LAUNCH_CHECK("k_clip_norm");
+    return GNF_OK;
+}
+
+}  // extern "C"

@@ -102,8 +102,10 @@ def build_csr_host(senders, receivers, n_nodes):
     return rowptr, col
 
 
-def build_csr_device(graph):
-    """gnf_build_csr on the GraphsTuple's own device tensors (no host round trip)."""
+def build_csr_device(graph, by_sender=False):
+    """gnf_build_csr on the GraphsTuple's own device tensors (no host round trip).
+    by_sender=True groups the same edges by SENDER (row u lists the receivers of u's out-edges): the
+    transposed topology the backward pass of the aggregation needs (gnf_grevnet_backward_f32)."""
     lib = _abi.lib()
     dev = graph.senders.device
     if dev.type != "cuda":
@@ -113,6 +115,8 @@ def build_csr_device(graph):
     b = int(graph.n_node.shape[0])
     snd = graph.senders.to(torch.int32).contiguous()
     rcv = graph.receivers.to(torch.int32).contiguous()
+    if by_sender:
+        snd, rcv = rcv, snd
     nn = graph.n_node.to(torch.int32).contiguous()
     ne = graph.n_edge.to(torch.int32).contiguous()
     rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
@@ -130,15 +134,15 @@ _CSR_CACHE = collections.OrderedDict()
 _CSR_CACHE_MAX = 16
 
 
-def csr_of(graph):
+def csr_of(graph, by_sender=False):
     """CSR of a GraphsTuple, cached on the identity of its senders/receivers tensors."""
     key = (graph.senders.data_ptr(), graph.receivers.data_ptr(), int(graph.senders.shape[0]),
-           int(graph.nodes.shape[0]), str(graph.senders.device))
+           int(graph.nodes.shape[0]), str(graph.senders.device), bool(by_sender))
     hit = _CSR_CACHE.get(key)
     if hit is not None:
         _CSR_CACHE.move_to_end(key)
         return hit[0]
-    csr = build_csr_device(graph)
+    csr = build_csr_device(graph, by_sender)
     # keep the index tensors alive so the data_ptr key cannot be recycled while cached
     _CSR_CACHE[key] = (csr, graph.senders, graph.receivers)
     while len(_CSR_CACHE) > _CSR_CACHE_MAX:

@@ -1,0 +1,225 @@
+"""Training step of the GRevNet drivers (/root/reference/run_grevnet.py:340-377, 440-447; same at
+train_grevnet_with_data.py:356-395) on the MI355X kernels:
+
+    grads_and_vars = optimizer.compute_gradients(total_loss)      -> gnf_grevnet_backward_f32 (reversible backprop)
+    tf.clip_by_value / tf.clip_by_norm on every gradient           -> gnf_clip_by_value_f32 / gnf_clip_by_norm_f32
+    tf.train.AdamOptimizer(lr, beta1, beta2, epsilon).apply_gradients -> gnf_adam_f32 + gnf_pack_flow
+
+Every trainable variable of the flow lives in ONE flat fp32 device vector (`theta`; the MLPs' W / b are
+views into it, in snt.Linear's own [in, out] layout), the gradient, and Adam's two moment vectors have
+the same layout: the optimiser is one elementwise launch over the whole model, and the data-parallel
+gradient exchange is one flat all-reduce (RCCL over xGMI), not one collective per variable.
+
+Learning-rate schedules of the drivers: `exponential_decay` (run_grevnet.py:341-347) and
+`get_learning_rate` (utils.py:93-105) are restated as host functions.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _abi
+from .flow import LN_2PI
+from .graphs import csr_of
+
+
+def exponential_decay(learning_rate, global_step, decay_steps, decay_rate, staircase=False):
+    """tf.train.exponential_decay as the drivers call it (run_grevnet.py:341-347)."""
+    p = global_step / float(decay_steps)
+    if staircase:
+        p = math.floor(p)
+    return learning_rate * decay_rate ** p
+
+
+def get_learning_rate(timestep, max_lr, ramp_up=1000, hold_steady=2000, const_multiple=3):
+    """utils.py:93-105: linear ramp-up, hold, then 1/sqrt decay."""
+    if timestep < ramp_up:
+        return timestep * max_lr / ramp_up
+    if timestep <= hold_steady:
+        return max_lr
+    sqrt_diff = math.sqrt(timestep - hold_steady)
+    return min(1 / sqrt_diff, const_multiple / sqrt_diff) * max_lr
+
+
+class GRevNetTrainer:
+    """total_loss, its gradient and the Adam update for one GRevNet (message-passing GNNs; the attention
+    GNN family has no backward pass yet and raises GnfError / GNF_EUNSUPPORTED).
+
+    Hyper-parameters default to the drivers' flags (run_grevnet.py:114-131): lr 1e-4, beta1 0.9,
+    beta2 0.9, epsilon 1e-8, exponential lr decay (1000 steps, 0.96), no clipping."""
+
+    def __init__(self, grevnet, lr=1e-4, adam_beta1=0.9, adam_beta2=0.9, adam_epsilon=1e-8, use_lr_decay=True,
+                 lr_decay_steps=1000, lr_decay_rate=0.96, clip_gradient_by_value=False,
+                 clip_gradient_value_lower=-1.0, clip_gradient_value_upper=5.0, clip_gradient_by_norm=False,
+                 clip_gradient_norm=10.0):
+        self.net = grevnet
+        self.lr, self.beta1, self.beta2, self.epsilon = float(lr), float(adam_beta1), float(adam_beta2), float(adam_epsilon)
+        self.use_lr_decay, self.lr_decay_steps, self.lr_decay_rate = bool(use_lr_decay), int(lr_decay_steps), float(lr_decay_rate)
+        self.clip_by_value = bool(clip_gradient_by_value)
+        self.clip_lo, self.clip_hi = float(clip_gradient_value_lower), float(clip_gradient_value_upper)
+        self.clip_by_norm, self.clip_norm = bool(clip_gradient_by_norm), float(clip_gradient_norm)
+        self.global_step = 0
+        self.theta = self.grad = self.m = self.v = None
+        self._grad_flow = None
+        self._keep = None
+        self._offsets = None
+        self._ws = None
+
+    # ---- parameter arena ---------------------------------------------------------------------
+    def _ensure_arena(self, hdim, device):
+        net = self.net
+        net._flow(hdim, device)                      # builds lazily-initialised MLPs (Sonnet-style first connect)
+        if self.theta is not None and self.theta.device == torch.device(device):
+            return
+        mlps = net.mlps("s") + net.mlps("t")
+        sizes = []
+        for m in mlps:
+            for (w, b) in m.params:
+                sizes += [w.numel(), b.numel()]
+        total = sum(sizes)
+        theta = torch.empty(total, dtype=torch.float32, device=device)
+        off, bounds = 0, [0]
+        for m in mlps:
+            views = []
+            for (w, b) in m.params:
+                wv = theta[off:off + w.numel()].view_as(w)
+                wv.copy_(w)
+                off += w.numel()
+                bounds.append(off)
+                bv = theta[off:off + b.numel()].view_as(b)
+                bv.copy_(b)
+                off += b.numel()
+                bounds.append(off)
+                views.append((wv, bv))
+            m.params = views                          # the MLP now reads / is updated through the arena
+            m.version += 1
+        net._cache = None
+        self.theta = theta
+        self.grad = torch.zeros_like(theta)
+        self.m = torch.zeros_like(theta)
+        self.v = torch.zeros_like(theta)
+        self._offsets = torch.tensor(bounds, dtype=torch.int64, device=device)
+        # gradient flow descriptor: same shapes, W / b pointing into self.grad
+        n = len(net.mlps("s"))
+        gs, gt = (_abi.GnfMlp * n)(), (_abi.GnfMlp * n)()
+        off = 0
+        for arr, ms in ((gs, net.mlps("s")), (gt, net.mlps("t"))):
+            for q, m in enumerate(ms):
+                arr[q].num_layers = len(m.layer_sizes)
+                for j, d in enumerate(m.dims()):
+                    arr[q].dims[j] = d
+                for j, (w, b) in enumerate(m.params):
+                    arr[q].W[j] = self.grad.data_ptr() + 4 * off
+                    off += w.numel()
+                    arr[q].b[j] = self.grad.data_ptr() + 4 * off
+                    off += b.numel()
+        spec = net.blocks("s")[0].spec()
+        self._grad_flow = _abi.GnfFlow(net.num_timesteps, int(net.weight_sharing),
+                                       C.cast(gs, C.POINTER(_abi.GnfMlp)), C.cast(gt, C.POINTER(_abi.GnfMlp)), spec)
+        self._keep = (gs, gt)
+
+    def named_gradients(self):
+        """Gradients in the oracle / fixture container layout ({"s": [[mlp]*T, [mlp]*T], "t": ...}; mlp =
+        [(dW, db), ...]) as numpy arrays (host copy; for tests and summaries)."""
+        net, out, off = self.net, {}, 0
+        g = self.grad.detach().cpu().numpy()
+        for kind in ("s", "t"):
+            flat = []
+            for m in net.mlps(kind):
+                layers = []
+                for (w, b) in m.params:
+                    dw = g[off:off + w.numel()].reshape(tuple(w.shape)).copy()
+                    off += w.numel()
+                    db = g[off:off + b.numel()].copy()
+                    off += b.numel()
+                    layers.append((dw, db))
+                flat.append(layers)
+            t = net.num_timesteps
+            out[kind] = flat if net.weight_sharing else [flat[:t], flat[t:]]
+        return out
+
+    # ---- compute_gradients ---------------------------------------------------------------------
+    def loss_and_grads(self, graph):
+        """run_grevnet.py:291-302 + optimizer.compute_gradients(total_loss) (:361-362).  Leaves the gradient in
+        self.grad (flat, arena layout) and returns the scalar terms (0-d fp64 device tensors)."""
+        lib = _abi.lib()
+        net = self.net
+        x = graph.nodes
+        if x.device.type != "cuda":
+            raise _abi.GnfError("training runs on a HIP device only (no CPU path)")
+        n, d = x.shape
+        dev = x.device
+        self._ensure_arena(d // 2, dev)
+        z_graph, _ = net(graph, inverse=True)                     # f: fused forward kernels
+        sums = net.last_sums
+        logdet = sums[0]
+        log_prob_zs = -0.5 * sums[1] - 0.5 * d * LN_2PI * n
+        log_prob_xs = log_prob_zs + logdet
+        flow = net._flow(d // 2, dev)
+        csr, csr_t = csr_of(graph), csr_of(graph, by_sender=True)
+        ws_bytes = lib.gnf_backward_workspace_bytes(n, d, C.byref(flow))
+        if self._ws is None or self._ws.numel() < ws_bytes or self._ws.device != dev:
+            self._ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
+        state = z_graph.nodes.clone()                             # z in, x (reconstructed) out
+        with torch.cuda.device(dev):
+            _abi.check(lib.gnf_grevnet_backward_f32(C.byref(csr.desc), C.byref(csr_t.desc), C.byref(flow),
+                                                    C.byref(self._grad_flow), _abi.ptr(state), state.stride(0), d,
+                                                    _abi.ptr(self._ws), ws_bytes, _abi.stream_ptr(dev)),
+                       "gnf_grevnet_backward_f32")
+        num_nodes = float(n)
+        return {"z_graph": z_graph, "reconstruction": state, "log_det_jacobian": logdet, "log_prob_zs": log_prob_zs,
+                "log_prob_xs": log_prob_xs, "total_loss": -log_prob_xs, "num_nodes": num_nodes,
+                "loss_per_node": -log_prob_xs / num_nodes, "log_prob_xs_per_node": log_prob_xs / num_nodes,
+                "log_prob_zs_per_node": log_prob_zs / num_nodes, "log_det_jacobian_per_node": logdet / num_nodes}
+
+    # ---- apply_gradients -----------------------------------------------------------------------
+    def current_learning_rate(self):
+        if self.use_lr_decay:
+            return exponential_decay(self.lr, self.global_step, self.lr_decay_steps, self.lr_decay_rate)
+        return self.lr
+
+    def apply_gradients(self, learning_rate=None):
+        """Clipping (run_grevnet.py:363-373) then tf.train.AdamOptimizer.apply_gradients (:375) and the re-pack
+        of the matrix-core weight copies."""
+        lib = _abi.lib()
+        dev = self.theta.device
+        lr = self.current_learning_rate() if learning_rate is None else float(learning_rate)
+        t = self.global_step + 1
+        lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+        n = self.theta.numel()
+        with torch.cuda.device(dev):
+            st = _abi.stream_ptr(dev)
+            if self.clip_by_value:
+                _abi.check(lib.gnf_clip_by_value_f32(_abi.ptr(self.grad), n, self.clip_lo, self.clip_hi, st),
+                           "gnf_clip_by_value_f32")
+            if self.clip_by_norm:
+                _abi.check(lib.gnf_clip_by_norm_f32(_abi.ptr(self.grad), _abi.ptr(self._offsets),
+                                                    self._offsets.numel() - 1, self.clip_norm, st),
+                           "gnf_clip_by_norm_f32")
+            _abi.check(lib.gnf_adam_f32(_abi.ptr(self.theta), _abi.ptr(self.grad), _abi.ptr(self.m), _abi.ptr(self.v),
+                                        n, lr_t, self.beta1, self.beta2, self.epsilon, st), "gnf_adam_f32")
+            h = self.net.mlps("s")[0].layer_sizes[-1]
+            flow = self.net._flow(h, dev)
+            if self.net.fused:
+                _abi.check(lib.gnf_pack_flow(C.byref(flow), st), "gnf_pack_flow")
+        self.global_step = t
+
+    def all_reduce_gradients(self, group=None):
+        """Data parallelism: total_loss is a SUM over nodes (run_grevnet.py:295), so the gradient of the global
+        batch is the sum of the shard gradients: one flat all-reduce of the whole gradient vector."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            if self.grad.is_cuda and dist.get_backend(group) == "gloo":
+                host = self.grad.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                self.grad.copy_(host)
+            else:
+                dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+
+    def step(self, graph, learning_rate=None, all_reduce=False):
+        """One iteration of the training loop (run_grevnet.py:440-447): returns the scalars of values_map."""
+        out = self.loss_and_grads(graph)
+        if all_reduce:
+            self.all_reduce_gradients()
+        self.apply_gradients(learning_rate)
+        return out

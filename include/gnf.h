@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GNF_ABI_VERSION 2
+#define GNF_ABI_VERSION 3
 #define GNF_MAX_LAYERS 8 /* Linear layers per MLP (gnn.py:165-166 builds num_layers of them) */
 
 typedef void* gnf_stream_t; /* hipStream_t */
@@ -192,6 +192,39 @@ size_t gnf_pred_adj_workspace_bytes(int64_t n_graphs);
 int gnf_pred_adj_f32(const float* z, int64_t ld, int32_t D, const int32_t* n_node, int64_t n_graphs,
                      int32_t max_nodes_per_graph, float* out_blocks, int64_t* block_off, void* ws,
                      size_t ws_bytes, gnf_stream_t stream);
+
+/* ---- training step ---------------------------------------------------------------
+ * Replaces optimizer.compute_gradients(total_loss) (run_grevnet.py:361-362) for
+ *   total_loss = -(sum_n log N(z_n; 0, I) + log_det_jacobian)           (run_grevnet.py:291-295)
+ * by reversible back-propagation through GRevNet.f (gnn.py:304-341): the half-steps are walked in
+ * reverse, each one's input is rebuilt from its output with the inverse update (gnn.py:359,372) and
+ * its two GNNs are recomputed - no forward activation is kept (the drivers' use_efficient_backprop,
+ * run_grevnet.py:46,282-288).
+ *   csr    the batch's CSR by receiver (gnf_build_csr)
+ *   csr_t  the same edges grouped by SENDER: gnf_build_csr(receivers, senders, ...) (arguments swapped)
+ *   flow   the nets, exactly as passed to gnf_grevnet_f32 (raw W/b are read; `packed` is ignored)
+ *   grad   a GnfFlow of the same shape whose W[j]/b[j] point at the GRADIENT buffers ([in,out] / [out],
+ *          overwritten; with weight_sharing the T uses of a net are summed); packed/attn ignored
+ *   z      in: f(x) as left by gnf_grevnet_f32(GNF_FORWARD); out: x again (the reconstruction)
+ * Attention GNNs: GNF_EUNSUPPORTED.  ws: gnf_backward_workspace_bytes(n_nodes, D, flow). */
+size_t gnf_backward_workspace_bytes(int64_t n_nodes, int32_t D, const GnfFlow* flow);
+int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFlow* flow, const GnfFlow* grad,
+                             float* z, int64_t ld, int32_t D, void* ws, size_t ws_bytes, gnf_stream_t stream);
+
+/* Re-pack EVERY net of a flow (W/b -> `packed`, nets with packed == NULL skipped) in a handful of
+ * launches; call after an optimiser step.  Nothing in the reference (weight pre-pack). */
+int gnf_pack_flow(const GnfFlow* flow, gnf_stream_t stream);
+
+/* tf.train.AdamOptimizer.apply_gradients on one flat fp32 parameter vector (run_grevnet.py:352-356, 375):
+ *   m <- b1 m + (1-b1) g;  v <- b2 v + (1-b2) g^2;  w <- w - lr_t m / (sqrt(v) + epsilon)
+ * lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) is computed by the caller (TF does it on the host side too). */
+int gnf_adam_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                 float epsilon, gnf_stream_t stream);
+/* tf.clip_by_value on a flat gradient (run_grevnet.py:363-367). */
+int gnf_clip_by_value_f32(float* g, int64_t n, float lo, float hi, gnf_stream_t stream);
+/* tf.clip_by_norm per gradient tensor (run_grevnet.py:369-372): tensor i = g[offsets[i] .. offsets[i+1])
+ * (offsets: device int64[n_tensors + 1]) is scaled by clip_norm / max(||t||_2, clip_norm). */
+int gnf_clip_by_norm_f32(float* g, const int64_t* offsets, int32_t n_tensors, float clip_norm, gnf_stream_t stream);
 
 #ifdef __cplusplus
 }

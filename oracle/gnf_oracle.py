@@ -315,6 +315,73 @@ class Fp32Gather:
 
 
 # ----------------------------------------------------------------------------------------------
+# training step: total_loss, its gradient, Adam  (run_grevnet.py:291-295, 340-377)
+# ----------------------------------------------------------------------------------------------
+def loss_and_grads(senders, receivers, n_total, x, params, num_timesteps, weight_sharing=False, **gnn_kw):
+    """total_loss = -(sum_n MVN(0, I).log_prob(z_n) + log_det_jacobian) (run_grevnet.py:291-295) and
+    d total_loss / d(every W, b), i.e. what optimizer.compute_gradients(total_loss) (run_grevnet.py:361-362)
+    returns.  The reference differentiates its TF graph with tf.gradients; here torch autograd
+    differentiates the float64 edition of the `Fp32Gather` restatement above (same op graph), which
+    tests/test_oracle.py pins against central finite differences of `Fp64Dense`.
+    Returns {"total_loss", "log_det_jacobian", "log_prob_zs", "z", "grads"}; grads has the layout of params."""
+    import torch
+    o = Fp32Gather(senders, receivers, n_total, dtype=torch.float64, **gnn_kw)
+    pt = o.prep_params(params)
+    leaves = []
+
+    def mark(m):
+        if isinstance(m, list) and m and isinstance(m[0], tuple):
+            out = []
+            for (w, b) in m:
+                w = w.clone().requires_grad_(True)
+                b = b.clone().requires_grad_(True)
+                leaves.extend([w, b])
+                out.append((w, b))
+            return out
+        return [mark(q) for q in m]
+
+    pt = {k: mark(v) for k, v in pt.items()}
+    z, logdet = o.f(o.to_t(x), pt, num_timesteps, weight_sharing)
+    d = z.shape[1]
+    log_prob_zs = (-0.5 * (z * z).sum(dim=1) - 0.5 * d * LN_2PI).sum()
+    total_loss = -(log_prob_zs + logdet)
+    total_loss.backward()
+
+    def grads_of(m):
+        if isinstance(m, list) and m and isinstance(m[0], tuple):
+            return [(w.grad.numpy().copy(), b.grad.numpy().copy()) for (w, b) in m]
+        return [grads_of(q) for q in m]
+
+    return {"total_loss": float(total_loss.detach()), "log_det_jacobian": float(logdet.detach()),
+            "log_prob_zs": float(log_prob_zs.detach()),
+            "z": z.detach().numpy(), "grads": {k: grads_of(v) for k, v in pt.items()}}
+
+
+def adam_step(w, g, m, v, t, lr, beta1=0.9, beta2=0.9, epsilon=1e-8):
+    """tf.train.AdamOptimizer (TensorFlow 1.x, third party; training_ops ApplyAdam) as configured at
+    run_grevnet.py:352-356, step t = 1, 2, ...:
+        lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
+        m <- beta1 m + (1 - beta1) g ;  v <- beta2 v + (1 - beta2) g^2 ;  w <- w - lr_t m / (sqrt(v) + epsilon)
+    float64 numpy; returns (w, m, v)."""
+    w, g, m, v = (np.asarray(a, np.float64) for a in (w, g, m, v))
+    lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    m = beta1 * m + (1.0 - beta1) * g
+    v = beta2 * v + (1.0 - beta2) * g * g
+    return w - lr_t * m / (np.sqrt(v) + epsilon), m, v
+
+
+def clip_by_value(g, lo, hi):
+    """tf.clip_by_value (run_grevnet.py:363-367)."""
+    return np.clip(np.asarray(g, np.float64), lo, hi)
+
+
+def clip_by_norm(g, clip_norm):
+    """tf.clip_by_norm on one tensor (run_grevnet.py:369-372): g * clip_norm / max(||g||_2, clip_norm)."""
+    g = np.asarray(g, np.float64)
+    return g * clip_norm / max(float(np.sqrt((g * g).sum())), clip_norm)
+
+
+# ----------------------------------------------------------------------------------------------
 # deterministic test-parameter generator (NOT the reference's initializer; just reproducible weights)
 # ----------------------------------------------------------------------------------------------
 def make_mlp_params(rng, in_dim, latent, out_dim, num_layers, bias_std=0.1, final_scale=1.0,

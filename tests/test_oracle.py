@@ -262,3 +262,80 @@ def test_pred_adj_blocks_against_dense_masked_formula():
     assert np.allclose(blocks[2], blocks[2].T)
     same = O.pred_adj_blocks(np.ones((2, 4)), [2])[0]
     assert abs(same[0, 1] - 1.0 / (1.0 + np.exp(-10.0))) < 1e-15
+
+
+# ---- training-step oracle (run_grevnet.py:291-295, 340-377) -----------------------------------------
+def _params_f64(p):
+    if isinstance(p, tuple):
+        return tuple(np.asarray(a, np.float64) for a in p)
+    if isinstance(p, dict):
+        return {k: _params_f64(v) for k, v in p.items()}
+    return [_params_f64(q) for q in p]
+
+
+@pytest.mark.parametrize("agg,combine,activation", [("mean", "agg", "leaky_relu"), ("sum", "concat", "relu")])
+def test_gradient_oracle_matches_finite_differences(agg, combine, activation):
+    """autograd of the torch restatement vs central differences of the independent numpy fp64-dense form."""
+    import copy
+    s, r, n = tiny_graph()
+    t = 2
+    p = _params_f64(O.make_grevnet_params(3, 2, 6, 3, t, combine=combine, final_scale=0.5))
+    x = np.random.default_rng(0).standard_normal((n, 4))
+    kw = dict(agg=agg, combine=combine, epsilon=0.7, activation=activation)
+    res = O.loss_and_grads(s, r, n, x, p, t, **kw)
+    dense = O.Fp64Dense(s, r, n, **kw)
+
+    def loss(pp):
+        return -dense.log_prob(x, pp, t)["log_prob_xs"]
+
+    assert abs(res["total_loss"] - loss(p)) < 1e-9
+    eps = 1e-6
+    for (kind, half, i, j, which) in [("s", 1, 0, 1, 0), ("t", 0, 1, 0, 0), ("s", 0, 0, 2, 1), ("t", 1, 1, 2, 0)]:
+        w = p[kind][half][i][j][which]
+        ga = res["grads"][kind][half][i][j][which]
+        it = np.nditer(w, flags=["multi_index"])
+        for _ in it:
+            idx = it.multi_index
+            pp = copy.deepcopy(p)
+            pp[kind][half][i][j][which][idx] += eps
+            lp = loss(pp)
+            pp[kind][half][i][j][which][idx] -= 2 * eps
+            lm = loss(pp)
+            assert abs((lp - lm) / (2 * eps) - ga[idx]) < 1e-5 * max(1.0, abs(ga[idx]))
+
+
+def test_gradient_oracle_weight_sharing_sums_uses():
+    """With weight sharing a net is used at every timestep; its gradient is the sum over the uses: equal to
+    the sum of the per-timestep gradients of the un-shared flow built from the same weights."""
+    s, r, n = tiny_graph()
+    t = 3
+    shared = O.make_grevnet_params(5, 2, 5, 2, t, weight_sharing=True, final_scale=0.5)
+    unshared = {k: [[shared[k][0]] * t, [shared[k][1]] * t] for k in ("s", "t")}
+    x = np.random.default_rng(1).standard_normal((n, 4))
+    a = O.loss_and_grads(s, r, n, x, shared, t, weight_sharing=True)
+    b = O.loss_and_grads(s, r, n, x, unshared, t, weight_sharing=False)
+    assert abs(a["total_loss"] - b["total_loss"]) < 1e-10
+    for kind in ("s", "t"):
+        for half in range(2):
+            for j in range(2):
+                for which in range(2):
+                    tot = sum(b["grads"][kind][half][i][j][which] for i in range(t))
+                    np.testing.assert_allclose(a["grads"][kind][half][j][which], tot, atol=1e-10)
+
+
+def test_adam_first_step_closed_form():
+    """t = 1 from zero moments: w1 = w0 - lr * g / (|g| + eps / sqrt(1 - beta2))."""
+    rng = np.random.default_rng(2)
+    w, g = rng.standard_normal(50), rng.standard_normal(50)
+    lr, b1, b2, eps = 1e-3, 0.9, 0.9, 1e-8
+    w1, m1, v1 = O.adam_step(w, g, np.zeros(50), np.zeros(50), 1, lr, b1, b2, eps)
+    np.testing.assert_allclose(w1, w - lr * g / (np.abs(g) + eps / math.sqrt(1 - b2)), rtol=1e-12)
+    np.testing.assert_allclose(m1, (1 - b1) * g)
+    np.testing.assert_allclose(v1, (1 - b2) * g * g)
+
+
+def test_clippers():
+    g = np.array([-3.0, 0.5, 7.0])
+    np.testing.assert_allclose(O.clip_by_value(g, -1.0, 5.0), [-1.0, 0.5, 5.0])
+    np.testing.assert_allclose(O.clip_by_norm(g, 100.0), g)                       # below the norm: untouched
+    np.testing.assert_allclose(np.linalg.norm(O.clip_by_norm(g, 2.0)), 2.0)

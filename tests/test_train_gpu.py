@@ -1,0 +1,210 @@
+"""Training step on the GPU: gnf_grevnet_backward_f32 / gnf_adam_f32 / clippers /
+gnf_pack_flow through the product's GRevNetTrainer vs the CPU oracle (torch-autograd float64 restatement,
+pinned by finite differences in test_oracle.py).
+
+Tolerances: a gradient tensor is compared with atol = 3e-4 * max|g| of that tensor (+1e-5) - fp32 GEMMs
+reducing over thousands of nodes against a float64 reference; Adam / clipping are elementwise fp32:
+rtol 2e-6.  The deep (T = 8, K = 5) case states a second bound: relu / leaky_relu are not differentiable
+at 0, so a pre-activation within fp32 rounding of 0 can take the other branch of act' than the float64
+oracle does and shifts every earlier layer's gradient of that one net by O(1e-3) of its scale (measured:
+2 nets of 32 at 4e-3 .. 7e-3; a float32 autograd run of the oracle itself shows the same 7e-3 worst case);
+there, 90 % of the tensors must meet 1e-3 and all of them 2e-2."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import graph_from_arrays, make_product_grevnet
+from oracle import gnf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu_and_native_lib():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from gnf_amd import _abi
+    _abi.lib()
+
+
+def _batch(dataset, ids):
+    n_node, n_edge, sl, rl = dataset
+    return O.batch_graphs(n_node, n_edge, sl, rl, ids)
+
+
+def _flat(grads, ws):
+    for kind in ("s", "t"):
+        nets = grads[kind] if ws else grads[kind][0] + grads[kind][1]
+        for q, net in enumerate(nets):
+            for j, (w, b) in enumerate(net):
+                yield f"{kind}[{q}].W{j}", w
+                yield f"{kind}[{q}].b{j}", b
+
+
+def _check_grads(got, ref, ws, scale=3e-4):
+    for (name, a), (_, b) in zip(_flat(got, ws), _flat(ref, ws)):
+        tol = scale * float(np.abs(b).max()) + 1e-5
+        err = float(np.abs(a - b).max())
+        assert err <= tol, f"{name}: max err {err:.3e} > {tol:.3e} (max|g| {np.abs(b).max():.3e})"
+
+
+CASES = [
+    # D, latent, K, T, agg, combine, eps, act, ws
+    (8, 32, 3, 2, "mean", "agg", 1.0, "leaky_relu", False),
+    (6, 20, 2, 2, "sum", "concat", 0.0, "relu", False),
+    (12, 48, 4, 3, "mean", "concat", 0.0, "leaky_relu", True),      # weight sharing: uses summed
+    (10, 24, 1, 2, "sum", "agg", 0.5, "leaky_relu", False),         # K = 1: a single Linear layer
+    (64, 256, 5, 2, "mean", "agg", 1.0, "leaky_relu", False),       # BASELINE widths
+    (100, 70, 3, 1, "mean", "agg", 1.0, "relu", False),             # ragged in every GEMM dimension
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"D{c[0]}_L{c[1]}_K{c[2]}_T{c[3]}_{c[4]}_{c[5]}{'_ws' if c[8] else ''}" for c in CASES])
+def test_gradients_vs_oracle(grid_small, case):
+    from gnf_amd.train import GRevNetTrainer
+    d, latent, k, t, agg, combine, eps, act, ws = case
+    hp = dict(D=d, latent=latent, K=k, T=t, agg=agg, combine=combine, epsilon=eps, activation=act, weight_sharing=ws)
+    nn, ne, s, r = _batch(grid_small, list(range(12)))
+    n = int(nn.sum())
+    rng = np.random.default_rng(d * 7 + k)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    p = O.make_grevnet_params(d + k, d // 2, latent, k, t, combine=combine, weight_sharing=ws,
+                              final_scale=0.3 if agg == "mean" else 0.1)
+    ref = O.loss_and_grads(s, r, n, x, p, t, ws, agg=agg, combine=combine, epsilon=eps, activation=act)
+    net = make_product_grevnet(hp, p)
+    tr = GRevNetTrainer(net)
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    out = tr.loss_and_grads(graph)
+    torch.cuda.synchronize()
+    assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
+    # reversible backprop rebuilds the input on its way back
+    np.testing.assert_allclose(out["reconstruction"].cpu().numpy(), x, atol=2e-4, rtol=2e-4)
+    _check_grads(tr.named_gradients(), ref["grads"], ws)
+    # calling it again overwrites (does not accumulate into) the gradient
+    tr.loss_and_grads(graph)
+    torch.cuda.synchronize()
+    _check_grads(tr.named_gradients(), ref["grads"], ws)
+
+
+def test_gradients_config2_batch(community_medium):
+    """community_medium batch of 32 graphs, BASELINE hyper-parameters (D=64, L=256, K=5, T=8)."""
+    from gnf_amd.train import GRevNetTrainer
+    hp = dict(D=64, latent=256, K=5, T=8, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu",
+              weight_sharing=False)
+    rng = np.random.default_rng(77)
+    nn, ne, s, r = _batch(community_medium, rng.choice(168, size=32, replace=True))
+    n = int(nn.sum())
+    x = rng.standard_normal((n, 64)).astype(np.float32)
+    p = O.make_grevnet_params(99, 32, 256, 5, 8, final_scale=0.25)
+    ref = O.loss_and_grads(s, r, n, x, p, 8, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu")
+    tr = GRevNetTrainer(make_product_grevnet(hp, p))
+    out = tr.loss_and_grads(graph_from_arrays(nn, ne, s, r, x, DEV))
+    torch.cuda.synchronize()
+    assert abs(float(out["loss_per_node"]) - ref["total_loss"] / n) <= 1e-4
+    np.testing.assert_allclose(out["reconstruction"].cpu().numpy(), x, atol=2e-3, rtol=2e-3)
+    rel = [float(np.abs(a - b).max() / np.abs(b).max())
+           for (_, a), (_, b) in zip(_flat(tr.named_gradients(), False), _flat(ref["grads"], False))]
+    assert max(rel) <= 2e-2, max(rel)
+    assert np.mean(np.array(rel) <= 1e-3) >= 0.9, sorted(rel)[-40:]
+
+
+def test_isolated_nodes_and_directed_edges():
+    """A directed, asymmetric edge list with isolated nodes: the backward aggregation runs over the by-sender
+    CSR, which is NOT the receiver CSR here."""
+    from gnf_amd.train import GRevNetTrainer
+    s = np.array([0, 0, 2, 4, 4, 4], np.int32)
+    r = np.array([1, 2, 1, 0, 1, 4], np.int32)      # node 3 isolated; node 4 has a self loop
+    n = 5
+    for agg in ("sum", "mean"):
+        hp = dict(D=4, latent=8, K=2, T=2, agg=agg, combine="agg", epsilon=1.0, activation="leaky_relu",
+                  weight_sharing=False)
+        x = np.random.default_rng(1).standard_normal((n, 4)).astype(np.float32)
+        p = O.make_grevnet_params(1, 2, 8, 2, 2, final_scale=0.5)
+        ref = O.loss_and_grads(s, r, n, x, p, 2, agg=agg, combine="agg", epsilon=1.0, activation="leaky_relu")
+        tr = GRevNetTrainer(make_product_grevnet(hp, p))
+        tr.loss_and_grads(graph_from_arrays([5], [6], s, r, x, DEV))
+        torch.cuda.synchronize()
+        _check_grads(tr.named_gradients(), ref["grads"], False)
+
+
+def test_adam_and_clipping_vs_oracle():
+    import ctypes as C
+    from gnf_amd import _abi
+    lib = _abi.lib()
+    rng = np.random.default_rng(3)
+    n = 100003
+    w0, g0 = rng.standard_normal(n).astype(np.float32), (rng.standard_normal(n) * 3).astype(np.float32)
+    w, g = torch.tensor(w0, device=DEV), torch.tensor(g0, device=DEV)
+    m, v = torch.zeros_like(w), torch.zeros_like(w)
+    wr, mr, vr = w0.astype(np.float64), np.zeros(n), np.zeros(n)
+    import math
+    st = _abi.stream_ptr(torch.device(DEV))
+    for t in (1, 2, 3):
+        lr_t = 1e-2 * math.sqrt(1 - 0.9 ** t) / (1 - 0.9 ** t)
+        _abi.check(lib.gnf_adam_f32(_abi.ptr(w), _abi.ptr(g), _abi.ptr(m), _abi.ptr(v), n, lr_t, 0.9, 0.9, 1e-8, st), "adam")
+        wr, mr, vr = O.adam_step(wr, g0, mr, vr, t, 1e-2, 0.9, 0.9, 1e-8)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(w.cpu().numpy(), wr, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(m.cpu().numpy(), mr, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(v.cpu().numpy(), vr, rtol=2e-6, atol=1e-7)
+    # clip by value
+    gc = g.clone()
+    _abi.check(lib.gnf_clip_by_value_f32(_abi.ptr(gc), n, -1.0, 5.0, st), "clip value")
+    np.testing.assert_array_equal(gc.cpu().numpy(), np.clip(g0, -1.0, 5.0))
+    # clip by norm per tensor (three tensors of very different sizes, one of them empty)
+    bounds = np.array([0, 10, 10, 70000, n], np.int64)
+    off = torch.tensor(bounds, device=DEV)
+    gn = g.clone()
+    _abi.check(lib.gnf_clip_by_norm_f32(_abi.ptr(gn), _abi.ptr(off), len(bounds) - 1, 10.0, st), "clip norm")
+    got = gn.cpu().numpy()
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        if b > a:
+            np.testing.assert_allclose(got[a:b], O.clip_by_norm(g0[a:b], 10.0), rtol=3e-6, atol=1e-7)
+
+
+def test_training_loop_reduces_loss_and_keeps_packed_weights_fresh(grid_small):
+    """A few iterations of run_grevnet.py:440-447: the loss goes down, and after every step the fused kernels
+    (which read the re-packed matrix-core copy) agree with the layered kernels (which read W / b)."""
+    from gnf_amd.flow import log_prob_terms
+    from gnf_amd.train import GRevNetTrainer
+    hp = dict(D=8, latent=32, K=3, T=2, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu",
+              weight_sharing=False)
+    nn, ne, s, r = _batch(grid_small, list(range(12)))
+    n = int(nn.sum())
+    x = (np.random.default_rng(0).standard_normal((n, 8)) * 2 + 1).astype(np.float32)
+    p = O.make_grevnet_params(4, 4, 32, 3, 2, final_scale=0.3)
+    net = make_product_grevnet(hp, p)
+    tr = GRevNetTrainer(net, lr=3e-3, use_lr_decay=False, clip_gradient_by_norm=True, clip_gradient_norm=50.0)
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    losses = []
+    for _ in range(30):
+        losses.append(float(tr.step(graph)["loss_per_node"]))
+    assert losses[-1] < losses[0] - 0.05, losses
+    fused = float(log_prob_terms(net, graph)["log_prob_xs_per_node"])
+    net.fused = False
+    layered = float(log_prob_terms(net, graph)["log_prob_xs_per_node"])
+    assert abs(fused - layered) <= 1e-5
+    # one oracle step from the same start reproduces the first update
+    ref = O.loss_and_grads(s, r, n, x, p, 2, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu")
+    net2 = make_product_grevnet(hp, p)
+    tr2 = GRevNetTrainer(net2, lr=3e-3, use_lr_decay=False)
+    tr2.step(graph)
+    torch.cuda.synchronize()
+    w_new = net2.get_params()["s"][0][0][0][0]
+    g = ref["grads"]["s"][0][0][0][0]
+    w_ref, _, _ = O.adam_step(p["s"][0][0][0][0], g, 0 * g, 0 * g, 1, 3e-3, 0.9, 0.9, 1e-8)
+    big = np.abs(g) > 1e-3 * np.abs(g).max()      # where |g| ~ 0 the first Adam step is sign-sensitive
+    np.testing.assert_allclose(w_new[big], w_ref[big], atol=2e-5)
+
+
+def test_attention_backward_is_refused(grid_small):
+    from gnf_amd import _abi
+    from gnf_amd.train import GRevNetTrainer
+    from helpers import load_golden
+    g = load_golden("attn_cfg1_grid_small")
+    hp = dict(D=g["D"], latent=g["latent"], K=g["K"], T=g["T"], agg=g["agg"], combine=g["combine"],
+              epsilon=g["epsilon"], activation=g["activation"], weight_sharing=g["weight_sharing"], attn=g["attn"])
+    net = make_product_grevnet(hp, g["params"])
+    graph = graph_from_arrays(g["n_node"], g["n_edge"], g["senders"], g["receivers"], g["x"], DEV)
+    with pytest.raises(_abi.GnfError):
+        GRevNetTrainer(net).loss_and_grads(graph)
