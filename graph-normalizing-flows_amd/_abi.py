@@ -79,7 +79,7 @@ _SIGNATURES = {
     "gnf_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.POINTER(GnfFlow)]),
     "gnf_grevnet_backward_f32": (C.c_int, [C.POINTER(GnfCsr), C.POINTER(GnfCsr), C.POINTER(GnfFlow),
                                            C.POINTER(GnfFlow), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
-                                           C.c_size_t, C.c_void_p]),
+                                           C.c_size_t, C.c_void_p, C.c_void_p]),
     "gnf_pack_flow": (C.c_int, [C.POINTER(GnfFlow), C.c_void_p]),
     "gnf_adam_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_void_p]),

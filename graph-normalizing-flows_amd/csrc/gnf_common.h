@@ -88,6 +88,13 @@ int launch_finalize(const double* a, int64_t na, const double* b, int64_t nb, do
 int launch_pack_mlp(const GnfMlp* mlp, float* packed, hipStream_t st);
 int64_t packed_floats(const GnfMlp* mlp);
 
+// fused backward half-step (gnf_fused_bwd.hip)
+bool fused_bwd_supported(const GnfMlp* s, const GnfMlp* t);
+int launch_half_bwd_fused(const int32_t* rowptr, const int32_t* col, int64_t n, const GnfGnnSpec& gnn,
+                          const GnfMlp* s, const GnfMlp* t, const float* x_cond, float* y_upd, int64_t ld,
+                          float* g_upd, int64_t ldg, int32_t H, float* h0_out, float* const* hin, int64_t ldh,
+                          float* const* dP, int64_t lddp, float* const* gst, float* const* dh0, hipStream_t st);
+
 int validate_mlp(const GnfMlp* m, const char* what);
 int validate_flow_call(const GnfCsr* csr, const GnfFlow* flow, int64_t ld, int32_t D, const char* what);
 // attention front-end (gnf_attn.hip)

@@ -1,0 +1,417 @@
+// Fused backward of one coupling half-step for gfx950 (MI355X), the training-side twin of gnf_fused.hip.
+// ONE launch does, for a tile of 16 nodes and BOTH nets (waves 0-3 the s-net, waves 4-7 the t-net):
+//   A   the same CSR aggregate + combine prologue as the forward kernel (h0 also goes to global memory)
+//   B   recompute of the K layers on the exact-fp32 matrix cores; every hidden activation h_j is kept as a
+//       byte sign mask in LDS (act' for the way back) and written to global memory (the dW GEMM's operand)
+//   C'  the coupling update undone and differentiated in LDS / registers:
+//         x_b = (y_b - t) exp(-s);  g_s = g_b (y_b - t) - 1;  g_t = g_b;  g_b <- g_b exp(s)
+//   B'  the K layers backwards: dP_{j-1} = (dP_j W_j^T) * act'(h_j), streaming the TRANSPOSED packed
+//       fragments (WpT_j, written next to Wp_j by the pack kernels); every dP_j also goes to global memory
+// so a training half-step is this launch + one grouped dW GEMM + one reduce + the message-passing
+// backward (gnf_train.hip), instead of 2K + 2K GEMM launches through global memory.
+// The 2K "layers" (K forward rows then K backward rows) share the forward kernel's chunk loop
+// (gnf_fused_dev.h): a backward row is a layer whose packed weights are WpT_j, whose bias is zero and
+// whose activation is the mask multiply.
+#include "gnf_fused_dev.h"
+
+#include <string.h>
+
+namespace gnf {
+
+static constexpr int kBwdThreads = 512;
+static constexpr int kBwdLdsLimit = 160 * 1024;
+static constexpr int kBwdRowptrPad = 40;
+static constexpr int kBwdColCap = 2048;
+static constexpr int kRows = 2 * GNF_MAX_LAYERS;
+
+// table row: 0 ipg, 1 ont, 2 boff, 3 true output width, 4 mode (0 recompute, 1 backward), 5 mask slot (-1: none),
+//            6 dump row stride, 7 -, 8-9 packed weights net 0, 10-11 net 1, 12-13 dump pointer net 0, 14-15 net 1
+struct BwdArgs {
+    const int32_t* rowptr;
+    const int32_t* col;
+    const float* x_cond;
+    float* y_upd;
+    float* g_upd;
+    float* h0_out;
+    float* gst[2];
+    const float* bias[2];
+    int32_t tab[kRows][16];
+    int64_t ld, ldg;
+    int32_t n_nodes, n_tiles, H, in0, K, LS, bias_tot, bias_tot2, mld;
+    int32_t mean, concat, act;
+    float eps, alpha;
+};
+
+__global__ __launch_bounds__(kBwdThreads) void k_half_bwd_fused(const BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int MT = 1, TM = 16, WPN = 4;
+    const int LS = a.LS;
+    auto buf = [&](int net_, int pp_) -> float* { return smem + (2 * net_ + pp_) * TM * LS; };
+    float* bias_lds = smem + 4 * TM * LS;
+    int* tab = reinterpret_cast<int*>(bias_lds + 2 * a.bias_tot2);
+    int* s_rowptr = tab + kRows * 16;
+    int* s_col = s_rowptr + kBwdRowptrPad;
+    unsigned char* masks = reinterpret_cast<unsigned char*>(s_col + kBwdColCap);
+
+    int tile;
+    {
+        const int bid = blockIdx.x, nwg = gridDim.x, xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
+        tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    }
+    const int row0 = tile * TM;
+    const int tid = threadIdx.x;
+    const int H = a.H;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int nl = wave / WPN;
+    const int wl = (wave % WPN + nl * (WPN / 2)) % WPN;  // t-net ownership rotated by half a turn (see gnf_fused.hip)
+    const int voff = lane * 16;
+    const int R = 2 * a.K;  // rows of the layer table
+
+    auto fill_chunk = [&](WChunk& c, int r, int ipg_, int ont_, int boff_, const float* wb, int nt0) {
+        c.wbase = wb;
+        c.wbytes = (unsigned)ipg_ * (unsigned)ont_ * 1024u;
+        c.ipg = ipg_;
+        c.ont = ont_;
+        c.boff = boff_;
+        c.nt0 = nt0;
+        const int nv = (ont_ - nt0 + WPN - 1) / WPN;
+        c.nv = nv > 4 ? 4 : nv;
+        c.layer = r;
+    };
+    auto ptr_of = [&](const int* row, int slot) -> unsigned long long {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane(row[slot]);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane(row[slot + 1]);
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    auto chunk_from_tab = [&](int r, int nt0) -> WChunk {
+        const int* row = tab + 16 * r;
+        WChunk c;
+        fill_chunk(c, r, __builtin_amdgcn_readfirstlane(row[0]), __builtin_amdgcn_readfirstlane(row[1]),
+                   __builtin_amdgcn_readfirstlane(row[2]), reinterpret_cast<const float*>(ptr_of(row, 8 + 2 * nl)), nt0);
+        return c;
+    };
+    auto next_chunk = [&](const WChunk& c) -> WChunk {
+        int r = c.layer, nt0 = c.nt0 + 4 * WPN;
+        if (nt0 < c.ont) {
+            WChunk n = c;
+            n.nt0 = nt0;
+            const int nv = (c.ont - nt0 + WPN - 1) / WPN;
+            n.nv = nv > 4 ? 4 : nv;
+            return n;
+        }
+        for (++r; r < R; ++r) {
+            const int ont_ = __builtin_amdgcn_readfirstlane(tab[16 * r + 1]);
+            if (wl < ont_) return chunk_from_tab(r, wl);
+        }
+        WChunk n = c;
+        n.layer = R;
+        return n;
+    };
+    WChunk cur;
+    {   // first chunk straight from the kernel arguments (the LDS table does not exist yet)
+        int r0 = 0;
+        while (r0 < R && wl >= a.tab[r0][1]) ++r0;
+        const int rr = r0 < R ? r0 : 0;
+        const unsigned long long wp = ((unsigned long long)(unsigned)a.tab[rr][9 + 2 * nl] << 32) |
+                                      (unsigned)a.tab[rr][8 + 2 * nl];
+        fill_chunk(cur, rr, a.tab[rr][0], a.tab[rr][1], a.tab[rr][2], reinterpret_cast<const float*>(wp),
+                   r0 < R ? wl : 0);
+        if (r0 >= R) cur.layer = R;
+    }
+    f32x4 b_pre[kPF][4];
+    prefetch_chunk(cur, WPN, voff, b_pre);
+
+    // ---- prologue loads, all issued before any is consumed ----------------------------------------
+    int rp_reg = 0;
+    if (tid <= TM) {
+        const int r = row0 + tid;
+        rp_reg = a.rowptr[r < a.n_nodes ? r : a.n_nodes];
+    }
+    constexpr int kBiasRegs = 8;
+    const int bias_all = 2 * a.bias_tot2;
+    float breg[kBiasRegs];
+#pragma unroll
+    for (int q = 0; q < kBiasRegs; ++q) {
+        const int i = tid + q * kBwdThreads;
+        const int net_ = i >= a.bias_tot2 ? 1 : 0;
+        const int k = i - net_ * a.bias_tot2;
+        const bool live = i < bias_all && k < a.bias_tot;
+        const float* src = net_ ? a.bias[1] : a.bias[0];
+        breg[q] = live ? src[k] : 0.f;  // the tail of each net's block is the zero bias of the backward rows
+    }
+    if (tid < R * 16) tab[tid] = a.tab[tid >> 4][tid & 15];
+    if (tid <= TM) s_rowptr[tid] = rp_reg;
+#pragma unroll
+    for (int q = 0; q < kBiasRegs; ++q) {
+        const int i = tid + q * kBwdThreads;
+        if (i < bias_all) bias_lds[i] = breg[q];
+    }
+    for (int i = tid + kBiasRegs * kBwdThreads; i < bias_all; i += kBwdThreads) {
+        const int net_ = i >= a.bias_tot2 ? 1 : 0;
+        const int k = i - net_ * a.bias_tot2;
+        bias_lds[i] = k < a.bias_tot ? (net_ ? a.bias[1] : a.bias[0])[k] : 0.f;
+    }
+    __syncthreads();
+    // ---- A: aggregate + combine (same arithmetic and order as the forward kernel) ----------------
+    {
+        const int seg_beg = s_rowptr[0];
+        const int seg_len = s_rowptr[TM] - seg_beg;
+        const bool staged = seg_len <= kBwdColCap;
+        if (staged)
+            for (int i = tid; i < seg_len; i += kBwdThreads) s_col[i] = a.col[seg_beg + i];
+        __syncthreads();
+        const int in0p = a.tab[0][0] * 16;
+        auto gather = [&](int beg, int end, const float* xf, auto colat) -> float {
+            float s = 0.f;
+            int e = beg;
+            for (; e + 8 <= end; e += 8) {
+                int ci[8];
+                float vv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ci[q] = colat(e + q);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vv[q] = xf[(int64_t)ci[q] * a.ld];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s += vv[q];
+            }
+            if (e < end) {
+                int ci[7];
+                float vv[7];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) ci[q] = colat(e + q < end ? e + q : end - 1);
+#pragma unroll
+                for (int q = 0; q < 7; ++q) vv[q] = xf[(int64_t)ci[q] * a.ld];
+#pragma unroll
+                for (int q = 0; q < 7; ++q)
+                    if (e + q < end) s += vv[q];
+            }
+            return s;
+        };
+        for (int idx = tid; idx < TM * in0p; idx += kBwdThreads) {
+            const int rl = idx / in0p, c = idx - rl * in0p;
+            const int r = row0 + rl;
+            float v = 0.f;
+            if (r < a.n_nodes && c < a.in0) {
+                const int f = c < H ? c : c - H;
+                if (a.concat && c < H) {
+                    v = a.x_cond[(int64_t)r * a.ld + f];
+                } else {
+                    const int beg = s_rowptr[rl], end = s_rowptr[rl + 1];
+                    const float* xf = a.x_cond + f;
+                    float s = staged ? gather(beg, end, xf, [&](int e) { return s_col[e - seg_beg]; })
+                                     : gather(beg, end, xf, [&](int e) { return a.col[e]; });
+                    if (a.mean) {
+                        const int cnt = end - beg;
+                        s = s / (float)(cnt > 1 ? cnt : 1);
+                    }
+                    v = a.concat ? s : a.eps * a.x_cond[(int64_t)r * a.ld + f] + s;
+                }
+                a.h0_out[(int64_t)r * a.in0 + c] = v;
+            }
+            buf(0, 0)[rl * LS + c] = v;
+            buf(1, 0)[rl * LS + c] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- one table row = one layer of one direction --------------------------------------------
+    int pp = 0;
+    auto run_row = [&](int r) {
+        const int* row = tab + 16 * r;
+        const int mode = __builtin_amdgcn_readfirstlane(row[4]);
+        const int slot = __builtin_amdgcn_readfirstlane(row[5]);
+        const bool last_fwd = (r == a.K - 1);
+        const float* in_lds = buf(nl, pp);
+        float* out_lds = buf(nl, pp ^ 1);
+        const float act_slope = a.act == GNF_ACT_RELU ? 0.f : a.alpha;
+        const float slope = (mode == 1 || last_fwd) ? 1.f : act_slope;
+        EpiArgs ea;
+        ea.mode = mode;
+        ea.dump = reinterpret_cast<float*>(ptr_of(row, 12 + 2 * nl));
+        ea.dld = __builtin_amdgcn_readfirstlane(row[6]);
+        ea.width = __builtin_amdgcn_readfirstlane(row[3]);
+        ea.row0 = row0;
+        ea.n_nodes = a.n_nodes;
+        ea.mask = slot >= 0 ? masks + ((size_t)(nl * (a.K - 1) + slot)) * TM * a.mld : nullptr;
+        ea.mld = a.mld;
+        ea.act_slope = act_slope;
+        while (cur.layer == r) {  // wave-uniform
+            const WChunk c = cur;
+            const WChunk nxt = next_chunk(c);
+            const WChunk nx = nxt.layer < R ? nxt : c;
+            const float* bl = bias_lds + nl * a.bias_tot2 + c.boff;
+            if (c.nv >= 4)
+                mlp_chunk<MT, 4, EPI_EX>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea);
+            else if (c.nv == 3)
+                mlp_chunk<MT, 3, EPI_EX>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea);
+            else if (c.nv == 2)
+                mlp_chunk<MT, 2, EPI_EX>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea);
+            else
+                mlp_chunk<MT, 1, EPI_EX>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea);
+            cur = nxt;
+        }
+        pp ^= 1;
+        __syncthreads();
+    };
+
+    // ---- B: recompute -------------------------------------------------------------------------
+    for (int r = 0; r < a.K; ++r) run_row(r);
+
+    // ---- C': coupling, undone and differentiated --------------------------------------------------
+    {
+        const float* s_lds = buf(0, pp);
+        const float* t_lds = buf(1, pp);
+        float* gs_lds = buf(0, pp ^ 1);
+        float* gt_lds = buf(1, pp ^ 1);
+        const int hp = a.tab[a.K][0] * 16;  // padded input width of the first backward row
+        for (int idx = tid; idx < TM * hp; idx += kBwdThreads) {
+            const int rl = idx / hp, f = idx - rl * hp;
+            const int r = row0 + rl;
+            float gs = 0.f, gt = 0.f;
+            if (r < a.n_nodes && f < H) {
+                const float sv = s_lds[rl * LS + f], tv = t_lds[rl * LS + f];
+                float* py = a.y_upd + (int64_t)r * a.ld + f;
+                float* pg = a.g_upd + (int64_t)r * a.ldg + f;
+                const float yv = *py, gv = *pg;
+                const float d = yv - tv;
+                *py = d * expf(-sv);
+                *pg = gv * expf(sv);
+                gs = gv * d - 1.f;
+                gt = gv;
+                a.gst[0][(int64_t)r * H + f] = gs;
+                a.gst[1][(int64_t)r * H + f] = gt;
+            }
+            gs_lds[rl * LS + f] = gs;
+            gt_lds[rl * LS + f] = gt;
+        }
+        pp ^= 1;
+        __syncthreads();
+    }
+
+    // ---- B': the layers backwards -----------------------------------------------------------------
+    for (int r = a.K; r < R; ++r) run_row(r);
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline int pad16b(int v) { return (v + 15) & ~15; }
+
+static int max_padded_width_b(const GnfMlp* m) {
+    int w = 16;
+    for (int j = 0; j <= m->num_layers; ++j) w = w > pad16b(m->dims[j]) ? w : pad16b(m->dims[j]);
+    return w;
+}
+
+static size_t bwd_lds_bytes(const GnfMlp* m) {
+    const int K = m->num_layers;
+    const int LS = max_padded_width_b(m) + 4;
+    int bias_tot = 0, mld = 16;
+    for (int j = 0; j < K; ++j) bias_tot += pad16b(m->dims[j + 1]);
+    for (int j = 1; j < K; ++j) mld = mld > pad16b(m->dims[j]) ? mld : pad16b(m->dims[j]);
+    const int bias_tot2 = bias_tot + max_padded_width_b(m);
+    return (size_t)(4 * 16 * LS + 2 * bias_tot2) * sizeof(float) +
+           (size_t)(kRows * 16 + kBwdRowptrPad + kBwdColCap) * sizeof(int) + (size_t)2 * (K > 1 ? K - 1 : 0) * 16 * mld;
+}
+
+bool fused_bwd_supported(const GnfMlp* s, const GnfMlp* t) {
+    if (!s->packed || !t->packed || s->attn || t->attn) return false;
+    if (s->num_layers != t->num_layers) return false;
+    for (int j = 0; j <= s->num_layers; ++j)
+        if (s->dims[j] != t->dims[j]) return false;
+    return bwd_lds_bytes(s) <= (size_t)kBwdLdsLimit;
+}
+
+// hin / dP: [net * K + j] global buffers the dW GEMM will read: hin[.][j] = input of layer j (j >= 1; h0 is
+// shared), dP[.][j] = dL/d(pre-activation of layer j) for j <= K-2; dh0: [net] = dL/dh0.
+int launch_half_bwd_fused(const int32_t* rowptr, const int32_t* col, int64_t n, const GnfGnnSpec& gnn,
+                          const GnfMlp* s, const GnfMlp* t, const float* x_cond, float* y_upd, int64_t ld,
+                          float* g_upd, int64_t ldg, int32_t H, float* h0_out, float* const* hin, int64_t ldh,
+                          float* const* dP, int64_t lddp, float* const* gst, float* const* dh0, hipStream_t st) {
+    if (n == 0) return GNF_OK;
+    const int K = s->num_layers;
+    BwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rowptr = rowptr;
+    a.col = col;
+    a.x_cond = x_cond;
+    a.y_upd = y_upd;
+    a.g_upd = g_upd;
+    a.h0_out = h0_out;
+    a.gst[0] = gst[0];
+    a.gst[1] = gst[1];
+    a.ld = ld;
+    a.ldg = ldg;
+    int bias_tot = 0, mld = 16;
+    int64_t wtot = 0;
+    for (int j = 0; j < K; ++j) {
+        bias_tot += pad16b(s->dims[j + 1]);
+        wtot += (int64_t)pad16b(s->dims[j]) * pad16b(s->dims[j + 1]);
+    }
+    for (int j = 1; j < K; ++j) mld = mld > pad16b(s->dims[j]) ? mld : pad16b(s->dims[j]);
+    a.bias[0] = s->packed + wtot;
+    a.bias[1] = t->packed + wtot;
+    a.bias_tot = bias_tot;
+    a.bias_tot2 = bias_tot + max_padded_width_b(s);
+    a.mld = mld;
+    const GnfMlp* nets[2] = {s, t};
+    auto put_ptr = [&](int r, int slot, const void* p) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+        a.tab[r][slot] = (int)(unsigned)v;
+        a.tab[r][slot + 1] = (int)(unsigned)(v >> 32);
+    };
+    int64_t off = 0;
+    int boff = 0;
+    for (int j = 0; j < K; ++j) {  // forward rows
+        const int ip = pad16b(s->dims[j]), op = pad16b(s->dims[j + 1]);
+        int* row = a.tab[j];
+        row[0] = ip / 16;
+        row[1] = op / 16;
+        row[2] = boff;
+        row[3] = s->dims[j + 1];
+        row[4] = 0;
+        row[5] = j < K - 1 ? j : -1;  // mask slot j = sign of h_{j+1}
+        row[6] = (int)ldh;
+        for (int q = 0; q < 2; ++q) {
+            put_ptr(j, 8 + 2 * q, nets[q]->packed + off);
+            put_ptr(j, 12 + 2 * q, j < K - 1 ? hin[q * K + j + 1] : nullptr);
+        }
+        // backward row of the same layer: r = K + (K-1-j)
+        const int r = K + (K - 1 - j);
+        int* brow = a.tab[r];
+        brow[0] = op / 16;
+        brow[1] = ip / 16;
+        brow[2] = bias_tot;  // zero bias
+        brow[3] = s->dims[j];
+        brow[4] = 1;
+        brow[5] = j >= 1 ? j - 1 : -1;  // act' of h_j
+        brow[6] = j >= 1 ? (int)lddp : s->dims[0];
+        for (int q = 0; q < 2; ++q) {
+            put_ptr(r, 8 + 2 * q, nets[q]->packed + wtot + bias_tot + off);
+            put_ptr(r, 12 + 2 * q, j >= 1 ? dP[q * K + j - 1] : dh0[q]);
+        }
+        boff += op;
+        off += (int64_t)ip * op;
+    }
+    a.n_nodes = (int32_t)n;
+    a.H = H;
+    a.in0 = s->dims[0];
+    a.K = K;
+    a.LS = max_padded_width_b(s) + 4;
+    a.mean = gnn.agg == GNF_AGG_MEAN;
+    a.concat = gnn.combine == GNF_COMBINE_CONCAT;
+    a.act = gnn.activation;
+    a.eps = gnn.epsilon;
+    a.alpha = gnn.alpha;
+    const int64_t tiles = (n + 15) / 16;
+    a.n_tiles = (int32_t)tiles;
+    static bool attr_set = false;
+    if (!attr_set) {
+        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_bwd_fused),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLdsLimit));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_half_bwd_fused, dim3((unsigned)tiles), dim3(kBwdThreads), bwd_lds_bytes(s), st, a);
+    GNF_LAUNCH_CHECK("k_half_bwd_fused");
+    return GNF_OK;
+}
+
+}  // namespace gnf

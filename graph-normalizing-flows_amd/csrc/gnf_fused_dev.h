@@ -1,0 +1,223 @@
+// Device code shared by the fused forward (gnf_fused.hip) and fused backward (gnf_fused_bwd.hip) half-step
+// kernels: the per-wave MLP chunk loop on the exact-fp32 matrix cores with weights streamed from L2 in
+// packed fragment order.  See gnf_fused.hip for the design notes.
+#pragma once
+#include "gnf_common.h"
+
+namespace gnf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef GNF_STAMP  // the trace hooks exist in developer builds of gnf_fused.hip only
+#define GNF_STAMP(slot)
+#define GNF_STAGE_STAMP(idx)
+#define GNF_PSTAMP(idx)
+#endif
+
+#ifndef GNF_PF
+#define GNF_PF 2  // k-groups of weights in flight ahead of the one being multiplied
+#endif
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// B fragments come through a buffer descriptor: base = this (net, layer)'s packed weights (SGPRs),
+// soffset = wave-uniform byte offset of the 1 KiB fragment block, voffset = lane * 16.  No per-load
+// 64-bit VALU address arithmetic and a single constant address VGPR.
+#ifdef GNF_ABL_NOLOAD  // ablation: B operand from registers, no weight traffic
+#define GNF_LOAD_B(RSRC, VOFF, SOFF) (f32x4{1.f, 2.f, 3.f, 4.f} * (float)(SOFF))
+#else
+#define GNF_LOAD_B(RSRC, VOFF, SOFF) \
+    __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RSRC, VOFF, SOFF, 0))
+#endif
+
+// A wave's unit of work: NV (<= 4) column tiles {nt0, nt0+ts, ...} of one layer.  All wave-uniform.
+struct WChunk {
+    const float* wbase;  // packed weights of the layer
+    unsigned wbytes;
+    int ipg;  // k-groups (stages) of the layer
+    int nt0;  // first column tile
+    int nv;   // tiles in this chunk (1..4)
+    int layer;
+    int boff;  // offset of the layer's bias inside the LDS bias block
+    int ont;   // column tiles of the layer
+};
+
+static constexpr int kPF = GNF_PF;
+
+// Issue the loads of the first kPF stages of chunk c into b_pre (4 tile slots; slots >= c.nv repeat the
+// last valid tile).  Called one round BEFORE the previous chunk ends - and before the prologue for
+// the first chunk - so that a layer never starts by waiting a full L2 round trip for its weights.
+__device__ __forceinline__ void prefetch_chunk(const WChunk& c, int ts, int voff, f32x4 (&b_pre)[kPF][4]) {
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.wbase), 0, (int)c.wbytes, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < kPF; ++u) {
+        const int kn = u < c.ipg ? u : c.ipg - 1;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int tb = b < c.nv ? b : c.nv - 1;
+            b_pre[u][b] = GNF_LOAD_B(rsrc, voff, (kn * c.ont + c.nt0 + ts * tb) * 1024);
+        }
+    }
+}
+
+// What happens to a chunk's outputs besides the write into the LDS activation buffer:
+//   EPI_PLAIN  nothing (forward kernel)
+//   EPI_EX     backward kernel (ea.mode is wave-uniform):
+//     mode 0   forward (recompute) layer: activation as usual, its sign (= act' of this layer) goes into an
+//              LDS byte mask, the value also to global memory (input of the dW GEMM)
+//     mode 1   backward layer: multiply by act' read from the byte mask, store to LDS and global memory
+enum { EPI_PLAIN = 0, EPI_EX = 1 };
+struct EpiArgs {
+    int mode;
+    float* dump;               // global [n_nodes, dld] or NULL
+    int64_t dld;
+    int width;                 // true (unpadded) output width of the layer
+    int row0, n_nodes;
+    unsigned char* mask;       // LDS [TM][mld] bytes: written in mode 0, read in mode 1 (NULL: no mask)
+    int mld;
+    float act_slope;           // act' on the negative side (alpha, or 0 for relu)
+};
+
+template <int MT, int NV, int EPI = EPI_PLAIN>
+__device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int LS, const WChunk& c,
+                                          const WChunk& nx, int ts, const float* __restrict__ bias_lds,
+                                          float* __restrict__ out_lds, float slope, int lane,
+                                          f32x4 (&b_pre)[kPF][4], const EpiArgs& ea = EpiArgs{}) {
+    constexpr int PF = kPF;
+    constexpr int R = PF + 1;  // register ring: PF stages in flight + the one being consumed
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    const int ipg = c.ipg, nt0 = c.nt0;
+#ifdef GNF_TRACE
+    const bool trace_on = c.layer == g_trace_layer;
+#endif
+    GNF_STAGE_STAMP(0);
+    f32x4 acc[MT][NV];
+#pragma unroll
+    for (int b = 0; b < NV; ++b) {
+        const float bias = bias_lds[16 * (nt0 + ts * b) + lrow];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][b] = f32x4{bias, bias, bias, bias};
+    }
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.wbase), 0, (int)c.wbytes, 0x00020000);
+    const int voff = lane * 16;
+    int wtile[NV];  // byte offset of each tile's fragment block inside a k-group (1 KiB per tile)
+#pragma unroll
+    for (int b = 0; b < NV; ++b) wtile[b] = (nt0 + ts * b) * 1024;
+    const int kstride = c.ont * 1024;  // bytes between consecutive k-groups
+    const float* arow[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) arow[m] = in_lds + (16 * m + lrow) * LS + 4 * lgrp;
+
+    f32x4 a_ring[R][MT], b_ring[R][NV];
+    // stage k always lives in ring slot k % R; the B side of the first PF stages was prefetched
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int kn = u < ipg ? u : ipg - 1;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a_ring[u][m] = *reinterpret_cast<const f32x4*>(arow[m] + 16 * kn);
+#pragma unroll
+        for (int b = 0; b < NV; ++b) b_ring[u][b] = b_pre[u][b];
+    }
+#ifndef GNF_ABL_NOMFMA
+#define GNF_MFMA_STAGE(U)                                                                          \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int b = 0; b < NV; ++b)   \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) acc[m][b] =                                 \
+            __builtin_amdgcn_mfma_f32_16x16x4f32(a_ring[U][m][q], b_ring[U][b][q], acc[m][b], 0, 0, 0);
+#else  // ablation: keep every load alive, issue no MFMA
+#define GNF_MFMA_STAGE(U)                                                                          \
+    _Pragma("unroll") for (int b = 0; b < NV; ++b) asm volatile("" ::"v"(b_ring[U][b]));           \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(a_ring[U][m]));
+#endif
+    // One round = R stages; a stage = the 4*NV*MT MFMAs of k-group kg with the loads of k-group kg+PF
+    // (NV buffer loads, MT LDS reads) issued in their shadow: an MFMA occupies the matrix pipe for 32
+    // cycles but the wave's issue slot for ~4, so a load placed after an MFMA costs nothing, while
+    // loads bunched in front of the MFMAs leave the pipe idle whenever the partner wave on the SIMD
+    // has nothing to issue (the arbiter is oldest-first: the two waves run mostly one after the
+    // other, not interleaved).  sched_group_barrier spells the interleave, sched_barrier(0) closes
+    // the stage (left alone, hipcc sinks every load of a round to its end and waits vmcnt(0) at the
+    // top of the next one); there is NO branch inside a round (it would also force vmcnt(0)).
+#ifdef GNF_NO_INTERLEAVE
+#define GNF_INTERLEAVE()
+#else
+#define GNF_INTERLEAVE()                                                                           \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  /* 1 MFMA */                               \
+    __builtin_amdgcn_sched_group_barrier(0x100, MT, 0); /* the LDS reads of the next A fragments */ \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT - 1, 0);                                    \
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  /* 1 weight load */                        \
+    _Pragma("unroll") for (int b_ = 1; b_ < NV; ++b_) {                                            \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                         \
+    }
+#endif
+#define GNF_ROUND(KG0)                                                                             \
+    _Pragma("unroll") for (int u = 0; u < R; ++u) {                                                \
+        const int kg = (KG0) + u;                                                                  \
+        const int kn = (kg + PF < ipg) ? kg + PF : ipg - 1; /* tail re-reads the last stage */     \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) a_ring[(u + PF) % R][m] =                   \
+            *reinterpret_cast<const f32x4*>(arow[m] + 16 * kn);                                    \
+        _Pragma("unroll") for (int b = 0; b < NV; ++b) b_ring[(u + PF) % R][b] =                   \
+            GNF_LOAD_B(rsrc, voff, wtile[b] + kn * kstride);                                       \
+        GNF_MFMA_STAGE(u)                                                                          \
+        GNF_INTERLEAVE()                                                                           \
+        GNF_STAGE_STAMP(2 + kg);                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    }
+    int kg0 = 0;
+    if (ipg >= R) {
+        for (; kg0 + 2 * R <= ipg; kg0 += R) {  // every full round but the last
+            GNF_ROUND(kg0)
+        }
+        // the next chunk's first stages go out one round early: they land while the last round's
+        // MFMAs, the output write-back and the layer barrier are in progress
+        prefetch_chunk(nx, ts, voff, b_pre);
+        __builtin_amdgcn_sched_barrier(0);
+        GNF_ROUND(kg0)
+        kg0 += R;
+    } else {
+        prefetch_chunk(nx, ts, voff, b_pre);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // tail: the last ipg % R stages are already in flight in slots 0 .. rem-1
+    const int rem = ipg - kg0;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        if (u < rem) {  // wave-uniform
+            GNF_MFMA_STAGE(u)
+        }
+    }
+#undef GNF_ROUND
+#undef GNF_INTERLEAVE
+#undef GNF_MFMA_STAGE
+    GNF_STAGE_STAMP(38);
+    // accumulator layout: col = lane&15, row = 4*(lane>>4) + r.  slope: 1 on the last (linear) layer,
+    // alpha (leaky) or 0 (relu) otherwise: max(v, slope*v) is branch-free for all three.
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int b = 0; b < NV; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[m][b][r];
+                const int rl = 16 * m + 4 * lgrp + r, col = 16 * (nt0 + ts * b) + lrow;
+                if (EPI == EPI_PLAIN) {
+                    out_lds[rl * LS + col] = fmaxf(v, slope * v);
+                } else {
+                    float o;
+                    if (ea.mode == 0) {
+                        o = fmaxf(v, slope * v);
+                        if (ea.mask) ea.mask[rl * ea.mld + col] = o > 0.f ? 1 : 0;
+                    } else {
+                        o = (ea.mask == nullptr || ea.mask[rl * ea.mld + col]) ? v : v * ea.act_slope;
+                    }
+                    out_lds[rl * LS + col] = o;
+                    if (ea.dump && ea.row0 + rl < ea.n_nodes && col < ea.width)
+                        ea.dump[(int64_t)(ea.row0 + rl) * ea.dld + col] = o;
+                }
+            }
+}
+
+
+
+}  // namespace gnf

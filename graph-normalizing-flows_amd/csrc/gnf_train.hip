@@ -19,6 +19,7 @@
 // (tf.train.AdamOptimizer, run_grevnet.py:352-356) and the two gradient clippers (run_grevnet.py:363-373).
 #include "gnf_common.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace gnf {
@@ -92,15 +93,14 @@ __device__ __forceinline__ void tile_stash(float* __restrict__ lds, int tid, con
 // columns (w >> 2) * 32, 2 x 2 MFMA tiles); the next k-tile is fetched into registers while the matrix
 // cores work on the current one.  blockIdx.z = job * chunks + chunk.
 template <int AK, int BK, int EPI>
-__global__ __launch_bounds__(kGemmThreads) void k_gemm(GemmJob j0, GemmJob j1, GemmShape sh) {
+__device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& sh, const int bx, const int by,
+                                          const int chunk) {
     constexpr int AR = AK == OPND_KC ? TGM : TGK, AC = AK == OPND_KC ? TGK : TGM;  // LDS tile rows x cols
     constexpr int BR = BK == OPND_KC ? TGN : TGK, BC = BK == OPND_KC ? TGK : TGN;
     __shared__ __attribute__((aligned(16))) float As[AR * (AC + 4)];
     __shared__ __attribute__((aligned(16))) float Bs[BR * (BC + 4)];
-    const int jz = blockIdx.z / sh.chunks, chunk = blockIdx.z - jz * sh.chunks;
-    const GemmJob job = jz ? j1 : j0;
-    const int64_t m0 = (int64_t)blockIdx.y * TGM;
-    const int n0 = blockIdx.x * TGN;
+    const int64_t m0 = (int64_t)by * TGM;
+    const int n0 = bx * TGN;
     const int64_t kbeg = (int64_t)chunk * sh.kchunk;
     const int64_t kend = (EPI == EPI_SLAB) ? (kbeg + sh.kchunk < sh.K ? kbeg + sh.kchunk : sh.K) : sh.K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kGemmThreads) void k_gemm(GemmJob j0, GemmJob j1, G
         __syncthreads();
         if (k0 + TGK < kend) fetch(k0 + TGK);
         if (EPI == EPI_SLAB && BK == OPND_MC) {
-            if (blockIdx.y == 0 && tid < TGN) {
+            if (by == 0 && tid < TGN) {
 #pragma unroll 8
                 for (int k = 0; k < TGK; ++k) colsum += Bs[k * (BC + 4) + tid];
             }
@@ -207,8 +207,37 @@ __global__ __launch_bounds__(kGemmThreads) void k_gemm(GemmJob j0, GemmJob j1, G
                 }
             }
         }
-    if (EPI == EPI_SLAB && job.aux_out && blockIdx.y == 0 && tid < TGN && n0 + tid < sh.N)
+    if (EPI == EPI_SLAB && job.aux_out && by == 0 && tid < TGN && n0 + tid < sh.N)
         job.aux_out[(int64_t)chunk * sh.N + n0 + tid] = colsum;
+}
+
+template <int AK, int BK, int EPI>
+__global__ __launch_bounds__(kGemmThreads) void k_gemm(GemmJob j0, GemmJob j1, GemmShape sh) {
+    const int jz = blockIdx.z / sh.chunks, chunk = blockIdx.z - jz * sh.chunks;
+    const GemmJob job = jz ? j1 : j0;
+    gemm_tile<AK, BK, EPI>(job, sh, blockIdx.x, blockIdx.y, chunk);
+}
+
+// Grouped split-K launch: up to kMaxGroup GEMMs of different M x N (the dW of every layer of both nets of
+// a half-step) over the same K = node axis, in one grid.  blockIdx.z = job * chunks + chunk.
+static constexpr int kMaxGroup = 2 * GNF_MAX_LAYERS;
+struct GroupedGemm {
+    GemmJob job[kMaxGroup];
+    int64_t lda[kMaxGroup], ldb[kMaxGroup];
+    int32_t M[kMaxGroup], N[kMaxGroup];
+    int64_t K, kchunk;
+    int32_t chunks;
+};
+__global__ __launch_bounds__(kGemmThreads) void k_gemm_dw_grouped(const GroupedGemm g) {
+    const int jz = blockIdx.z / g.chunks, chunk = blockIdx.z - jz * g.chunks;
+    const int M = g.M[jz], N = g.N[jz];
+    if ((int)blockIdx.x * TGN >= N || (int)blockIdx.y * TGM >= M) return;  // grid covers the largest job
+    GemmShape sh;
+    sh.lda = g.lda[jz], sh.ldb = g.ldb[jz], sh.ldc = N, sh.ldaux = 0;
+    sh.M = M, sh.K = g.K, sh.N = N, sh.chunks = g.chunks, sh.kchunk = g.kchunk;
+    sh.act = 0, sh.alpha = 0.f, sh.apply_act = 0;
+    const GemmJob job = g.job[jz];
+    gemm_tile<OPND_MC, OPND_MC, EPI_SLAB>(job, sh, blockIdx.x, blockIdx.y, chunk);
 }
 
 template <int AK, int BK, int EPI>
@@ -240,6 +269,30 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(ReduceJob j0, ReduceJob j1
         float s = 0.f;
         for (int c = 0; c < chunks; ++c) s += job.bslab[(int64_t)c * nb + i];
         job.gb[i] = accumulate ? job.gb[i] + s : s;
+    }
+}
+
+struct GroupedReduce {
+    ReduceJob job[kMaxGroup];
+    int64_t nw[kMaxGroup];
+    int32_t nb[kMaxGroup];
+    int32_t chunks, accumulate;
+};
+__global__ __launch_bounds__(256) void k_reduce_grouped(const GroupedReduce g) {
+    const int j = blockIdx.y;
+    const ReduceJob job = g.job[j];
+    const int64_t nw = g.nw[j];
+    const int nb = g.nb[j];
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < nw) {
+        float s = 0.f;
+        for (int c = 0; c < g.chunks; ++c) s += job.wslab[(int64_t)c * nw + e];
+        job.gw[e] = g.accumulate ? job.gw[e] + s : s;
+    } else if (e < nw + nb) {
+        const int i = (int)(e - nw);
+        float s = 0.f;
+        for (int c = 0; c < g.chunks; ++c) s += job.bslab[(int64_t)c * nb + i];
+        job.gb[i] = g.accumulate ? job.gb[i] + s : s;
     }
 }
 
@@ -275,34 +328,61 @@ __global__ __launch_bounds__(256) void k_coupling_bwd(const float* __restrict__ 
 
 // message-passing backward: g_cond[u, f] += base + sum over edges u -> v of dh[v, aggcol + f] * w(v)
 //   dh = dh_s + dh_t ([N, in0] each);  agg-combine: base = eps * dh[u, f], aggcol = 0;
-//   concat: base = dh[u, f], aggcol = H;  w(v) = 1 / max(indeg(v), 1) for the mean aggregator.
+//   concat: base = dh[u, f], aggcol = H;  w(v) = 1 / max(indeg(v), 1) for the mean aggregator (invdeg, or NULL).
 // rowptr_t / col_t: CSR by SENDER (row u lists the receivers v of u's out-edges, in edge order).
+// Same shape as kernel A (gnf_layered.hip): a group of G lanes owns a row, VEC floats per lane, four
+// neighbour rows in flight; the adds stay in edge order.
+__global__ __launch_bounds__(256) void k_invdeg(const int32_t* __restrict__ rowptr, int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const int dg = rowptr[i + 1] - rowptr[i];
+        out[i] = 1.f / (float)(dg > 1 ? dg : 1);
+    }
+}
+
+template <int VEC>
 __global__ __launch_bounds__(256) void k_aggregate_bwd(const int32_t* __restrict__ rowptr_t,
                                                        const int32_t* __restrict__ col_t,
-                                                       const int32_t* __restrict__ rowptr, int64_t n,
+                                                       const float* __restrict__ invdeg, int64_t n,
                                                        const float* __restrict__ dhs, const float* __restrict__ dht,
-                                                       int in0, int H, int mean, int concat, float eps,
+                                                       int in0, int H, int concat, float eps,
                                                        float* __restrict__ g, int64_t ldg, int G) {
-    const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    typedef float V __attribute__((ext_vector_type(VEC)));
+    const int64_t nwg = gridDim.x, bid = blockIdx.x;
+    const int64_t xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;  // XCD-aware remap as in kernel A
+    const int64_t blk = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int64_t u = (blk * 256 + threadIdx.x) / G;
     const int gl = threadIdx.x & (G - 1);
     if (u >= n) return;
     const int beg = rowptr_t[u], end = rowptr_t[u + 1];
     const int aggcol = concat ? H : 0;
-    for (int f = gl; f < H; f += G) {
-        float acc = 0.f;
-        for (int e = beg; e < end; ++e) {
-            const int v = col_t[e];
-            float w = 1.f;
-            if (mean) {
-                const int dg = rowptr[v + 1] - rowptr[v];
-                w = 1.f / (float)(dg > 1 ? dg : 1);
+    auto ld2 = [&](int64_t o) -> V {
+        return *reinterpret_cast<const V*>(dhs + o) + *reinterpret_cast<const V*>(dht + o);
+    };
+    for (int f = gl * VEC; f < H; f += G * VEC) {
+        V acc = V(0.f);
+        int e = beg;
+        for (; e + 4 <= end; e += 4) {
+            int vi[4];
+            float w[4];
+            V vv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vi[q] = col_t[e + q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                w[q] = invdeg ? invdeg[vi[q]] : 1.f;
+                vv[q] = ld2((int64_t)vi[q] * in0 + aggcol + f);
             }
-            const int64_t o = (int64_t)v * in0 + aggcol + f;
-            acc += (dhs[o] + dht[o]) * w;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc += vv[q] * w[q];
         }
-        const int64_t o = u * in0 + f;
-        const float own = dhs[o] + dht[o];
-        g[u * ldg + f] += (concat ? own : eps * own) + acc;
+        for (; e < end; ++e) {
+            const int v = col_t[e];
+            acc += ld2((int64_t)v * in0 + aggcol + f) * (invdeg ? invdeg[v] : 1.f);
+        }
+        const V own = ld2(u * in0 + f);
+        V* pg = reinterpret_cast<V*>(g + u * ldg + f);
+        *pg = *pg + (concat ? own : own * eps) + acc;
     }
 }
 
@@ -310,8 +390,13 @@ __global__ __launch_bounds__(256) void k_aggregate_bwd(const int32_t* __restrict
 struct BwdPlan {
     int K, in0, lmax, H, chunks;
     int64_t n, kchunk;
-    size_t g, h0, acts, st, gst, dbuf, dh0, wslab, bslab, total;  // float offsets
+    int64_t wsum, osum;  // sum_j I_j * O_j, sum_j O_j of one net
+    size_t g, invdeg, h0, acts, st, gst, dpb, dh0, wslab, bslab, total;  // float offsets
+    size_t set_stride;  // the dW operands (h0, acts, gst, dpb) exist twice: half-step k's dW GEMM may run on the
+                        // auxiliary stream while half-step k-1's fused kernel already refills the other set
 };
+
+static inline size_t al64(size_t v) { return (v + 63) / 64 * 64; }  // keep every region 256-byte aligned
 
 static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net) {
     BwdPlan p;
@@ -320,18 +405,17 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net) {
     p.H = D / 2;
     p.K = net->num_layers;
     p.in0 = net->dims[0];
-    int lmax = 1, wmax = 1;
+    int lmax = 1;
     for (int j = 0; j < p.K; ++j) {
         if (j >= 1) lmax = lmax > net->dims[j] ? lmax : net->dims[j];
-        const int w = net->dims[j] * net->dims[j + 1];
-        wmax = wmax > w ? wmax : w;
+        p.wsum += (int64_t)net->dims[j] * net->dims[j + 1];
+        p.osum += net->dims[j + 1];
     }
-    int omax = 1;
-    for (int j = 1; j <= p.K; ++j) omax = omax > net->dims[j] ? omax : net->dims[j];
     p.lmax = lmax;
-    // split of the node axis for dW: enough workgroups to fill the chip, chunks of >= 128 nodes
-    int64_t chunks = (n + 127) / 128;
-    if (chunks > 64) chunks = 64;
+    // split of the node axis for dW: every layer of both nets goes out in ONE grouped launch, so a few
+    // chunks already fill the chip; fewer chunks = fewer slabs to write and reduce
+    int64_t chunks = (n + 255) / 256;
+    if (chunks > 32) chunks = 32;
     if (chunks < 1) chunks = 1;
     int64_t kchunk = (n + chunks - 1) / chunks;
     kchunk = (kchunk + TGK - 1) / TGK * TGK;
@@ -339,27 +423,103 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net) {
     chunks = n > 0 ? (n + kchunk - 1) / kchunk : 1;
     p.chunks = (int)chunks;
     p.kchunk = kchunk;
-    auto al = [](size_t v) { return (v + 63) / 64 * 64; };  // keep every region 256-byte aligned
+    const size_t nk1 = (size_t)(p.K > 1 ? p.K - 1 : 0);
     size_t off = 0;
-    p.g = off, off += al((size_t)n * D);
-    p.h0 = off, off += al((size_t)n * p.in0);
-    p.acts = off, off += 2 * (size_t)(p.K > 1 ? p.K - 1 : 0) * al((size_t)n * lmax);
-    p.st = off, off += 2 * al((size_t)n * p.H);
-    p.gst = off, off += 2 * al((size_t)n * p.H);
-    p.dbuf = off, off += 4 * al((size_t)n * lmax);
-    p.dh0 = off, off += 2 * al((size_t)n * p.in0);
-    p.wslab = off, off += 2 * al((size_t)chunks * wmax);
-    p.bslab = off, off += 2 * al((size_t)chunks * omax);
+    p.g = off, off += al64((size_t)n * D);
+    p.invdeg = off, off += al64((size_t)n);
+    p.st = off, off += 2 * al64((size_t)n * p.H);
+    p.dh0 = off, off += 2 * al64((size_t)n * p.in0);
+    p.wslab = off, off += 2 * al64((size_t)chunks * p.wsum);
+    p.bslab = off, off += 2 * al64((size_t)chunks * p.osum);
+    const size_t set0 = off;
+    p.h0 = off, off += al64((size_t)n * p.in0);
+    p.acts = off, off += 2 * nk1 * al64((size_t)n * lmax);   // [net][j = 1..K-1]: input of layer j
+    p.gst = off, off += 2 * al64((size_t)n * p.H);           // dP of the last layer (g_s, g_t)
+    p.dpb = off, off += 2 * nk1 * al64((size_t)n * lmax);    // [net][j = 0..K-2]: dP_j = dL/d(pre-activation of layer j)
+    p.set_stride = off - set0;
+    off += p.set_stride;                                      // second set
     p.total = off;
     return p;
 }
-
-static inline size_t al64(size_t v) { return (v + 63) / 64 * 64; }
 
 static const GnfMlp* pick_net(const GnfFlow* f, const GnfMlp* nets, int half, int i) {
     return f->weight_sharing ? &nets[half] : &nets[half * f->num_timesteps + i];
 }
 
+// dW_j = h_j^T dP_j and db_j = colsum(dP_j) for every layer of both nets: one grouped split-K GEMM launch
+// into per-chunk slabs + one fixed-order reduce launch into the gradient buffers.
+static int launch_weight_grads(const BwdPlan& p, const GnfMlp* const* nets, const GnfMlp* const* grads,
+                               bool accumulate, const float* const* hin /*[net*K + j]*/,
+                               const int64_t* ldh, const float* const* dP /*[net*K + j]*/, const int64_t* lddp,
+                               float* ws, hipStream_t st) {
+    const int K = p.K;
+    GroupedGemm gg;
+    GroupedReduce gr;
+    memset(&gg, 0, sizeof(gg));
+    memset(&gr, 0, sizeof(gr));
+    int maxM = 1, maxN = 1;
+    int64_t maxred = 1;
+    for (int q = 0; q < 2; ++q) {
+        float* wsl = ws + p.wslab + q * al64((size_t)p.chunks * p.wsum);
+        float* bsl = ws + p.bslab + q * al64((size_t)p.chunks * p.osum);
+        int64_t woff = 0, boff = 0;
+        for (int j = 0; j < K; ++j) {
+            const int I = nets[q]->dims[j], O = nets[q]->dims[j + 1];
+            const int e = q * K + j;
+            gg.job[e] = GemmJob{hin[e], dP[e], wsl + p.chunks * woff, nullptr, bsl + p.chunks * boff};
+            gg.lda[e] = ldh[e];
+            gg.ldb[e] = lddp[e];
+            gg.M[e] = I;
+            gg.N[e] = O;
+            gr.job[e] = ReduceJob{wsl + p.chunks * woff, bsl + p.chunks * boff, const_cast<float*>(grads[q]->W[j]),
+                                  const_cast<float*>(grads[q]->b[j])};
+            gr.nw[e] = (int64_t)I * O;
+            gr.nb[e] = O;
+            maxM = maxM > I ? maxM : I;
+            maxN = maxN > O ? maxN : O;
+            maxred = maxred > (int64_t)I * O + O ? maxred : (int64_t)I * O + O;
+            woff += (int64_t)I * O;
+            boff += O;
+        }
+    }
+    gg.K = p.n;
+    gg.kchunk = p.kchunk;
+    gg.chunks = p.chunks;
+    gr.chunks = p.chunks;
+    gr.accumulate = accumulate ? 1 : 0;
+    dim3 grid((unsigned)((maxN + TGN - 1) / TGN), (unsigned)((maxM + TGM - 1) / TGM), (unsigned)(2 * K * p.chunks));
+    hipLaunchKernelGGL(k_gemm_dw_grouped, grid, dim3(kGemmThreads), 0, st, gg);
+    GNF_LAUNCH_CHECK("k_gemm_dw_grouped");
+    hipLaunchKernelGGL(k_reduce_grouped, dim3((unsigned)((maxred + 255) / 256), (unsigned)(2 * K)), dim3(256), 0, st, gr);
+    GNF_LAUNCH_CHECK("k_reduce_grouped");
+    return GNF_OK;
+}
+
+static int launch_aggregate_bwd(const BwdPlan& p, const GnfCsr* csr, const GnfCsr* csr_t, const GnfGnnSpec& gnn,
+                                const float* invdeg, const float* dh0s, const float* dh0t, float* g_cond, int64_t ldg,
+                                hipStream_t st) {
+    (void)csr;
+    const int H = p.H;
+    const bool vec4 = (H % 4 == 0) && (p.in0 % 4 == 0) && (ldg % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(dh0s) | reinterpret_cast<uintptr_t>(dh0t) |
+                        reinterpret_cast<uintptr_t>(g_cond)) % 16 == 0);
+    const int per_row = vec4 ? H / 4 : H;
+    int G = 1;
+    while (G < per_row && G < 64) G <<= 1;
+    const int64_t blocks = (p.n * G + 255) / 256;
+    const float* w = gnn.agg == GNF_AGG_MEAN ? invdeg : nullptr;
+    const int concat = gnn.combine == GNF_COMBINE_CONCAT ? 1 : 0;
+    if (vec4)
+        hipLaunchKernelGGL(k_aggregate_bwd<4>, dim3((unsigned)blocks), dim3(256), 0, st, csr_t->rowptr, csr_t->col, w,
+                           p.n, dh0s, dh0t, p.in0, H, concat, gnn.epsilon, g_cond, ldg, G);
+    else
+        hipLaunchKernelGGL(k_aggregate_bwd<1>, dim3((unsigned)blocks), dim3(256), 0, st, csr_t->rowptr, csr_t->col, w,
+                           p.n, dh0s, dh0t, p.in0, H, concat, gnn.epsilon, g_cond, ldg, G);
+    GNF_LAUNCH_CHECK("k_aggregate_bwd");
+    return GNF_OK;
+}
+
+// Generic (any layer width) backward of one half-step out of GEMM building blocks.
 static int backward_half(const BwdPlan& p, const GnfCsr* csr, const GnfCsr* csr_t, const GnfGnnSpec& gnn,
                          const GnfMlp* const* nets, const GnfMlp* const* grads, bool accumulate, float* x_cond,
                          float* y_upd, int64_t ld, float* g_cond, float* g_upd, int64_t ldg, float* ws,
@@ -372,9 +532,11 @@ static int backward_half(const BwdPlan& p, const GnfCsr* csr, const GnfCsr* csr_
     auto act = [&](int net, int j) -> float* {  // output of layer j-1 = input of layer j (j >= 1)
         return ws + p.acts + ((size_t)net * (K - 1) + (j - 1)) * act_sz;
     };
+    auto dpb = [&](int net, int j) -> float* {  // dP_j, j <= K-2
+        return ws + p.dpb + ((size_t)net * (K - 1) + j) * act_sz;
+    };
     float* stb[2] = {ws + p.st, ws + p.st + al64((size_t)n * H)};
     float* gst[2] = {ws + p.gst, ws + p.gst + al64((size_t)n * H)};
-    float* dbuf[2][2] = {{ws + p.dbuf, ws + p.dbuf + act_sz}, {ws + p.dbuf + 2 * act_sz, ws + p.dbuf + 3 * act_sz}};
     float* dh0[2] = {ws + p.dh0, ws + p.dh0 + al64((size_t)n * in0)};
     int rc = launch_aggregate(csr->rowptr, csr->col, n, x_cond, ld, H, gnn.agg == GNF_AGG_MEAN,
                               gnn.combine == GNF_COMBINE_CONCAT ? 1 : 0, gnn.epsilon, h0, in0, st);
@@ -404,63 +566,76 @@ static int backward_half(const BwdPlan& p, const GnfCsr* csr, const GnfCsr* csr_
                            g_upd, ldg, gst[0], gst[1], n, H);
         GNF_LAUNCH_CHECK("k_coupling_bwd");
     }
-    // ---- layers, last to first -----------------------------------------------------------------
+    // ---- dP chain, last layer to first:  dP_{j-1} = (dP_j W_j^T) * act'(h_j)   [nodes, O] x [O, I] -----
+    const float* hin[kMaxGroup];
+    const float* dPs[kMaxGroup];
+    int64_t ldh[kMaxGroup], lddp[kMaxGroup];
+    for (int q = 0; q < 2; ++q)
+        for (int j = 0; j < K; ++j) {
+            hin[q * K + j] = j == 0 ? h0 : act(q, j);
+            ldh[q * K + j] = j == 0 ? in0 : lmax;
+            dPs[q * K + j] = j == K - 1 ? gst[q] : dpb(q, j);
+            lddp[q * K + j] = j == K - 1 ? H : lmax;
+        }
     for (int j = K - 1; j >= 0; --j) {
         const int I = nets[0]->dims[j], O = nets[0]->dims[j + 1];
-        const float* dP[2];
-        int64_t lddp;
-        for (int q = 0; q < 2; ++q) dP[q] = (j == K - 1) ? gst[q] : dbuf[q][j & 1];
-        lddp = (j == K - 1) ? H : lmax;
-        // dW_j, db_j: [I, nodes] x [nodes, O] split over node chunks
-        {
-            GemmJob jobs[2];
-            float* wsl[2] = {ws + p.wslab, ws + p.wslab + (p.bslab - p.wslab) / 2};
-            float* bsl[2] = {ws + p.bslab, ws + p.bslab + (p.total - p.bslab) / 2};
-            for (int q = 0; q < 2; ++q) jobs[q] = GemmJob{j == 0 ? h0 : act(q, j), dP[q], wsl[q], nullptr, bsl[q]};
-            GemmShape sh;
-            memset(&sh, 0, sizeof(sh));
-            sh.lda = j == 0 ? in0 : lmax;
-            sh.ldb = lddp;
-            sh.ldc = O;
-            sh.M = I, sh.K = n, sh.N = O, sh.chunks = p.chunks, sh.kchunk = p.kchunk;
-            rc = launch_gemm<OPND_MC, OPND_MC, EPI_SLAB>(jobs, 2, sh, st);
-            if (rc) return rc;
-            const int64_t nw = (int64_t)I * O;
-            ReduceJob rj[2];
-            for (int q = 0; q < 2; ++q) rj[q] = ReduceJob{wsl[q], bsl[q], const_cast<float*>(grads[q]->W[j]), const_cast<float*>(grads[q]->b[j])};
-            hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((nw + O + 255) / 256), 2), dim3(256), 0, st, rj[0],
-                               rj[1], nw, O, p.chunks, accumulate ? 1 : 0);
-            GNF_LAUNCH_CHECK("k_reduce_slabs");
-        }
-        // dP_{j-1} = (dP_j W_j^T) * act'(h_j)      [nodes, O] x [O, I]
-        {
-            GemmJob jobs[2];
-            for (int q = 0; q < 2; ++q)
-                jobs[q] = GemmJob{dP[q], nets[q]->W[j], j == 0 ? dh0[q] : dbuf[q][(j - 1) & 1],
-                                  j == 0 ? nullptr : act(q, j), nullptr};
-            GemmShape sh;
-            memset(&sh, 0, sizeof(sh));
-            sh.lda = lddp;
-            sh.ldb = O;
-            sh.ldc = j == 0 ? in0 : lmax;
-            sh.ldaux = lmax;
-            sh.M = n, sh.K = O, sh.N = I, sh.chunks = 1, sh.kchunk = TGK;
-            sh.act = gnn.activation, sh.alpha = gnn.alpha;
-            rc = launch_gemm<OPND_KC, OPND_KC, EPI_MASK>(jobs, 2, sh, st);
-            if (rc) return rc;
-        }
+        GemmJob jobs[2];
+        for (int q = 0; q < 2; ++q)
+            jobs[q] = GemmJob{dPs[q * K + j], nets[q]->W[j], j == 0 ? dh0[q] : dpb(q, j - 1),
+                              j == 0 ? nullptr : act(q, j), nullptr};
+        GemmShape sh;
+        memset(&sh, 0, sizeof(sh));
+        sh.lda = lddp[j];
+        sh.ldb = O;
+        sh.ldc = j == 0 ? in0 : lmax;
+        sh.ldaux = lmax;
+        sh.M = n, sh.K = O, sh.N = I, sh.chunks = 1, sh.kchunk = TGK;
+        sh.act = gnn.activation, sh.alpha = gnn.alpha;
+        rc = launch_gemm<OPND_KC, OPND_KC, EPI_MASK>(jobs, 2, sh, st);
+        if (rc) return rc;
     }
-    // ---- message passing -----------------------------------------------------------------------
-    {
-        int G = 1;
-        while (G < H && G < 64) G <<= 1;
-        const int64_t blocks = (n * G + 255) / 256;
-        hipLaunchKernelGGL(k_aggregate_bwd, dim3((unsigned)blocks), dim3(256), 0, st, csr_t->rowptr, csr_t->col,
-                           csr->rowptr, n, dh0[0], dh0[1], in0, H, gnn.agg == GNF_AGG_MEAN ? 1 : 0,
-                           gnn.combine == GNF_COMBINE_CONCAT ? 1 : 0, gnn.epsilon, g_cond, ldg, G);
-        GNF_LAUNCH_CHECK("k_aggregate_bwd");
-    }
-    return GNF_OK;
+    rc = launch_weight_grads(p, nets, grads, accumulate, hin, ldh, dPs, lddp, ws, st);
+    if (rc) return rc;
+    return launch_aggregate_bwd(p, csr, csr_t, gnn, ws + p.invdeg, dh0[0], dh0[1], g_cond, ldg, st);
+}
+
+// The same half-step with the LDS-resident fused kernel (gnf_fused_bwd.hip) in place of the 2K + 2K GEMM launches.
+// `set` picks one of the two dW operand sets.  The weight gradients (grouped GEMM + reduce) are off the
+// critical path of the backward walk - the next half-step only needs g - so with an auxiliary stream they
+// overlap the next half-step's fused kernel, which leaves a third of the CUs idle on a 64-graph batch.
+struct BwdOperands {
+    float* hin[kMaxGroup];
+    float* dPs[kMaxGroup];
+    const float* hin_c[kMaxGroup];
+    const float* dPs_c[kMaxGroup];
+    int64_t ldh[kMaxGroup], lddp[kMaxGroup];
+    float* gst[2];
+    float* dh0[2];
+    float* h0;
+};
+
+static BwdOperands bwd_operands(const BwdPlan& p, float* ws, int set) {
+    BwdOperands o;
+    const int64_t n = p.n;
+    const int K = p.K;
+    float* wss = ws + (size_t)set * p.set_stride;
+    const size_t act_sz = al64((size_t)n * p.lmax);
+    o.h0 = wss + p.h0;
+    o.gst[0] = wss + p.gst;
+    o.gst[1] = wss + p.gst + al64((size_t)n * p.H);
+    o.dh0[0] = ws + p.dh0;
+    o.dh0[1] = ws + p.dh0 + al64((size_t)n * p.in0);
+    for (int q = 0; q < 2; ++q)
+        for (int j = 0; j < K; ++j) {
+            const int e = q * K + j;
+            o.hin[e] = j == 0 ? o.h0 : wss + p.acts + ((size_t)q * (K - 1) + (j - 1)) * act_sz;
+            o.ldh[e] = j == 0 ? p.in0 : p.lmax;
+            o.dPs[e] = j == K - 1 ? o.gst[q] : wss + p.dpb + ((size_t)q * (K - 1) + j) * act_sz;
+            o.lddp[e] = j == K - 1 ? p.H : p.lmax;
+            o.hin_c[e] = o.hin[e];
+            o.dPs_c[e] = o.dPs[e];
+        }
+    return o;
 }
 
 // ---- multi-tensor re-pack (after an optimiser step every net's MFMA fragment copy is stale) ----------
@@ -469,9 +644,10 @@ struct PackDesc {
     const float* b;
     float* wout;
     float* bout;
+    float* wtout;
     int32_t I, O, Ip, Op;
 };
-static constexpr int kPackBatch = 64;
+static constexpr int kPackBatch = 56;
 struct PackBatch {
     PackDesc d[kPackBatch];
 };
@@ -489,6 +665,11 @@ __global__ __launch_bounds__(256) void k_pack_multi(const PackBatch pb) {
         const int k = 16 * kg + 4 * (lane >> 4) + q;
         const int c = 16 * nt + (lane & 15);
         d.wout[i] = (k < d.I && c < d.O) ? d.W[(int64_t)k * d.O + c] : 0.f;
+        const int nts_t = d.Ip >> 4;
+        const int kg_t = (int)(blk / nts_t), nt_t = (int)(blk % nts_t);
+        const int ko = 16 * kg_t + 4 * (lane >> 4) + q;
+        const int ci = 16 * nt_t + (lane & 15);
+        d.wtout[i] = (ci < d.I && ko < d.O) ? d.W[(int64_t)ci * d.O + ko] : 0.f;
     } else if (i < nw + d.Op) {
         const int c = (int)(i - nw);
         d.bout[c] = c < d.O ? d.b[c] : 0.f;
@@ -516,10 +697,12 @@ static int pack_flow(const GnfFlow* flow, hipStream_t st) {
             if (!m->packed) continue;
             int64_t woff = 0, boff = 0;
             for (int j = 0; j < m->num_layers; ++j) boff += (int64_t)pad16i(m->dims[j]) * pad16i(m->dims[j + 1]);
+            int64_t toff = boff;
+            for (int j = 0; j < m->num_layers; ++j) toff += pad16i(m->dims[j + 1]);
             for (int j = 0; j < m->num_layers; ++j) {
                 const int I = m->dims[j], O = m->dims[j + 1], Ip = pad16i(I), Op = pad16i(O);
                 float* pk = const_cast<float*>(m->packed);
-                pb.d[cnt++] = PackDesc{m->W[j], m->b[j], pk + woff, pk + boff, I, O, Ip, Op};
+                pb.d[cnt++] = PackDesc{m->W[j], m->b[j], pk + woff, pk + boff, pk + toff + woff, I, O, Ip, Op};
                 const int64_t tot = (int64_t)Ip * Op + Op;
                 maxtot = maxtot > tot ? maxtot : tot;
                 woff += (int64_t)Ip * Op;
@@ -586,7 +769,8 @@ size_t gnf_backward_workspace_bytes(int64_t n_nodes, int32_t D, const GnfFlow* f
 }
 
 int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFlow* flow, const GnfFlow* grad,
-                             float* z, int64_t ld, int32_t D, void* ws, size_t ws_bytes, gnf_stream_t stream) {
+                             float* z, int64_t ld, int32_t D, void* ws, size_t ws_bytes, gnf_stream_t stream,
+                             gnf_stream_t aux_stream) {
     int rc = validate_flow_call(csr, flow, ld, D, "gnf_grevnet_backward_f32");
     if (rc) return rc;
     if (!csr_t || csr_t->n_nodes != csr->n_nodes || csr_t->n_edges != csr->n_edges ||
@@ -648,7 +832,24 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)blocks), dim3(256), 0, st, z, ld, g, (int64_t)D, n, D);
         GNF_LAUNCH_CHECK("k_copy_rows");
+        if (flow->gnn.agg == GNF_AGG_MEAN) {
+            hipLaunchKernelGGL(k_invdeg, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, csr->rowptr, n,
+                               wsf + p.invdeg);
+            GNF_LAUNCH_CHECK("k_invdeg");
+        }
     }
+    // fork / join events of the weight-gradient stream: three flag-only events per process, made on first use
+    // (the one piece of state this library keeps; they hold no memory)
+    hipStream_t aux = (hipStream_t)aux_stream;
+    if (aux == st) aux = nullptr;
+    static hipEvent_t g_ev[2] = {nullptr, nullptr}, ev_ready = nullptr;
+    if (aux && !ev_ready) {
+        GNF_HIP_TRY(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
+        GNF_HIP_TRY(hipEventCreateWithFlags(&g_ev[0], hipEventDisableTiming));
+        GNF_HIP_TRY(hipEventCreateWithFlags(&g_ev[1], hipEventDisableTiming));
+    }
+    hipEvent_t ev_done[2] = {nullptr, nullptr};
+    int step = 0;
     bool used[2] = {false, false};  // weight sharing: the T uses of a net accumulate
     for (int i = T - 1; i >= 0; --i)
         for (int half = 1; half >= 0; --half) {
@@ -657,10 +858,40 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             const bool acc = flow->weight_sharing && used[half];
             used[half] = true;
             const int co = half == 0 ? 0 : H, uo = half == 0 ? H : 0;
-            rc = backward_half(p, csr, csr_t, flow->gnn, nets, grads, acc, z + co, z + uo, ld, g + co, g + uo, D,
-                               wsf, st);
+            static const bool no_fused = getenv("GNF_BWD_GENERIC") != nullptr;  // developer A/B switch
+            if (!no_fused && fused_bwd_supported(nets[0], nets[1])) {
+                const int set = step & 1;
+                const BwdOperands o = bwd_operands(p, wsf, set);
+                // this set's previous reader (the dW GEMM of two half-steps ago) must be done
+                if (aux && ev_done[set]) GNF_HIP_TRY(hipStreamWaitEvent(st, ev_done[set], 0));
+                rc = launch_half_bwd_fused(csr->rowptr, csr->col, n, flow->gnn, nets[0], nets[1], z + co, z + uo, ld,
+                                           g + uo, D, H, o.h0, o.hin, p.lmax, o.dPs, p.lmax, o.gst, o.dh0, st);
+                if (rc) return rc;
+                // the message-passing backward is on the critical path (the next half-step's coupling reads g):
+                // it goes first; the weight gradients fork off behind it
+                rc = launch_aggregate_bwd(p, csr, csr_t, flow->gnn, wsf + p.invdeg, o.dh0[0], o.dh0[1], g + co, D, st);
+                if (rc) return rc;
+                hipStream_t wst = st;
+                if (aux) {
+                    GNF_HIP_TRY(hipEventRecord(ev_ready, st));
+                    GNF_HIP_TRY(hipStreamWaitEvent(aux, ev_ready, 0));
+                    wst = aux;
+                }
+                rc = launch_weight_grads(p, nets, grads, acc, o.hin_c, o.ldh, o.dPs_c, o.lddp, wsf, wst);
+                if (rc) return rc;
+                if (aux) {
+                    GNF_HIP_TRY(hipEventRecord(g_ev[set], aux));
+                    ev_done[set] = g_ev[set];
+                }
+            } else {
+                rc = backward_half(p, csr, csr_t, flow->gnn, nets, grads, acc, z + co, z + uo, ld, g + co, g + uo, D,
+                                   wsf, st);
+            }
+            ++step;
             if (rc) return rc;
         }
+    for (int q = 0; q < 2; ++q)  // join: the gradients are complete on `stream`
+        if (aux && ev_done[q]) GNF_HIP_TRY(hipStreamWaitEvent(st, ev_done[q], 0));
     return GNF_OK;
 }
 

@@ -168,3 +168,121 @@ def synthetic_ego(num_graphs, seed=12345):
         r = np.concatenate([idx, und[:, 1], und[:, 0]])
         nn.append(n); ne.append(len(s)); S.append(s); R.append(r)
     return EdgeListDataset(nn, ne, np.concatenate(S), np.concatenate(R))
+
+
+# ----------------------------------------------------------------------------------------------
+# On-disk embedding chunks of the data-backed trainer
+#   writer: generate_grevnet_training_data.py:89-97,116-120   reader: train_grevnet_with_data.py:145-234
+# A chunk is pickle.dump((node_embeddings[sum(n_node), D] float, n_node[B] int32)); a directory of chunks
+# is consumed in os.listdir order.
+# ----------------------------------------------------------------------------------------------
+def write_embedding_chunk(path, node_embeddings, n_node):
+    """generate_grevnet_training_data.py:91-92."""
+    import pickle
+    node_embeddings = np.asarray(node_embeddings)
+    n_node = np.asarray(n_node, np.int32)
+    if node_embeddings.ndim != 2 or int(n_node.sum()) != node_embeddings.shape[0]:
+        raise ValueError("node_embeddings must be [sum(n_node), D]")
+    with open(path, "wb") as f:
+        pickle.dump((node_embeddings, n_node), f)
+
+
+def _read_embedding_chunk(path):
+    import pickle
+    with open(path, "rb") as f:
+        d = pickle.load(f)
+    return d[0], d[1], np.cumsum(d[1])
+
+
+class GrevnetDatasetFixed:
+    """train_grevnet_with_data.py:145-180: fixed number of graphs per batch; when the current chunk cannot
+    supply a whole batch its tail is dropped and the next file is opened (as the reference does).
+    `train_epochs` is FLAGS.train_epochs (the file list is repeated that many times)."""
+
+    def __init__(self, train_data_dir, train_batch_size, train_epochs=1):
+        import os
+        self.files = os.listdir(train_data_dir) * int(train_epochs)
+        self.file_ind = 0
+        self.prev_graph_ind = 0
+        self.prev_node_embedding_ind = 0
+        self.train_batch_size = int(train_batch_size)
+        self.train_data_dir = train_data_dir
+        self._os = os
+        self.node_embeddings, self.n_node, self.n_node_cs = _read_embedding_chunk(
+            os.path.join(train_data_dir, self.files[self.file_ind]))
+
+    def train_batch(self):
+        new_ind = self.prev_graph_ind + self.train_batch_size
+        if new_ind > len(self.n_node):
+            self.file_ind += 1
+            if self.file_ind >= len(self.files):
+                raise IndexError("GrevnetDatasetFixed: out of training files (the reference raises IndexError too)")
+            self.node_embeddings, self.n_node, self.n_node_cs = _read_embedding_chunk(
+                self._os.path.join(self.train_data_dir, self.files[self.file_ind]))
+            self.prev_graph_ind = 0
+            self.prev_node_embedding_ind = 0
+            new_ind = self.train_batch_size
+        node_embeddings = self.node_embeddings[self.prev_node_embedding_ind:self.n_node_cs[new_ind - 1]]
+        n_node = self.n_node[self.prev_graph_ind:new_ind]
+        self.prev_graph_ind = new_ind
+        self.prev_node_embedding_ind = self.n_node_cs[new_ind - 1]
+        return node_embeddings, n_node
+
+
+class GrevnetDatasetVariable:
+    """train_grevnet_with_data.py:183-234: as many consecutive graphs as fit UNDER max_nodes per batch; the
+    batch that reaches the end of a chunk is returned short and the next file is opened."""
+
+    def __init__(self, train_data_dir, max_nodes):
+        import os
+        self.files = os.listdir(train_data_dir)
+        self.file_ind = 0
+        self.graph_ind = 0
+        self.prev_graph_ind = 0
+        self.prev_node_embedding_ind = 0
+        self.max_nodes = int(max_nodes)
+        self.train_data_dir = train_data_dir
+        self._os = os
+        self.node_embeddings, self.n_node, self.n_node_cs = _read_embedding_chunk(
+            os.path.join(train_data_dir, self.files[self.file_ind]))
+
+    def train_batch(self):
+        total_nodes = 0
+        while True:
+            if self.graph_ind >= len(self.n_node):
+                node_embeddings = self.node_embeddings[self.prev_node_embedding_ind:self.n_node_cs[self.graph_ind - 1]]
+                n_node = self.n_node[self.prev_graph_ind:self.graph_ind]
+                self.file_ind += 1
+                self.prev_graph_ind = 0
+                self.graph_ind = 0
+                self.prev_node_embedding_ind = 0
+                if self.file_ind >= len(self.files):
+                    raise IndexError("GrevnetDatasetVariable: out of training files (the reference raises IndexError too)")
+                self.node_embeddings, self.n_node, self.n_node_cs = _read_embedding_chunk(
+                    self._os.path.join(self.train_data_dir, self.files[self.file_ind]))
+                return node_embeddings, n_node
+            if total_nodes + self.n_node[self.graph_ind] < self.max_nodes:
+                total_nodes += self.n_node[self.graph_ind]
+                self.graph_ind += 1
+            else:
+                break
+        node_embeddings = self.node_embeddings[self.prev_node_embedding_ind:self.n_node_cs[self.graph_ind - 1]]
+        n_node = self.n_node[self.prev_graph_ind:self.graph_ind]
+        self.prev_graph_ind = self.graph_ind
+        self.prev_node_embedding_ind = self.n_node_cs[self.graph_ind - 1]
+        return node_embeddings, n_node
+
+
+def transform_example(node_embeddings, n_node, device=None):
+    """train_grevnet_with_data.py:237-271: a (node_embeddings, n_node) batch -> GraphsTuple with the complete
+    topology incl. self loops (utils.py:164-183), n_edge = n_node**2, zero edges / globals."""
+    import torch
+    from .graphs import GraphsTuple
+    n_node = np.asarray(n_node, np.int32)
+    s, r, n_edge = senders_receivers(n_node)
+    g = GraphsTuple(nodes=torch.as_tensor(np.asarray(node_embeddings, np.float32)),
+                    edges=torch.zeros(len(s), dtype=torch.float32),
+                    receivers=torch.as_tensor(r.astype(np.int32)), senders=torch.as_tensor(s.astype(np.int32)),
+                    globals=torch.zeros(len(n_node), dtype=torch.float32),
+                    n_node=torch.as_tensor(n_node), n_edge=torch.as_tensor(n_edge.astype(np.int32)))
+    return g.to(device) if device is not None else g

@@ -147,7 +147,7 @@ class MLP:
         return [self.in_dim] + self.layer_sizes
 
     def packed_floats(self):
-        return sum(_pad16(i) * _pad16(o) + _pad16(o) for i, o in zip(self.dims()[:-1], self.dims()[1:]))
+        return sum(2 * _pad16(i) * _pad16(o) + _pad16(o) for i, o in zip(self.dims()[:-1], self.dims()[1:]))
 
     def fill_desc(self, desc, packed_ptr):
         desc.num_layers = len(self.layer_sizes)

@@ -64,6 +64,8 @@ class GRevNetTrainer:
         self._keep = None
         self._offsets = None
         self._ws = None
+        self._aux = None         # second HIP stream: the weight-gradient GEMMs overlap the backward walk
+        self.overlap_weight_grads = True
 
     # ---- parameter arena ---------------------------------------------------------------------
     def _ensure_arena(self, hdim, device):
@@ -160,11 +162,16 @@ class GRevNetTrainer:
         ws_bytes = lib.gnf_backward_workspace_bytes(n, d, C.byref(flow))
         if self._ws is None or self._ws.numel() < ws_bytes or self._ws.device != dev:
             self._ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
+        if self.overlap_weight_grads and (self._aux is None or self._aux.device != dev):
+            self._aux = torch.cuda.Stream(device=dev)
+        if not self.overlap_weight_grads:
+            self._aux = None
         state = z_graph.nodes.clone()                             # z in, x (reconstructed) out
         with torch.cuda.device(dev):
             _abi.check(lib.gnf_grevnet_backward_f32(C.byref(csr.desc), C.byref(csr_t.desc), C.byref(flow),
                                                     C.byref(self._grad_flow), _abi.ptr(state), state.stride(0), d,
-                                                    _abi.ptr(self._ws), ws_bytes, _abi.stream_ptr(dev)),
+                                                    _abi.ptr(self._ws), ws_bytes, _abi.stream_ptr(dev),
+                                                    C.c_void_p(self._aux.cuda_stream if self._aux is not None else 0)),
                        "gnf_grevnet_backward_f32")
         num_nodes = float(n)
         return {"z_graph": z_graph, "reconstruction": state, "log_det_jacobian": logdet, "log_prob_zs": log_prob_zs,

@@ -206,10 +206,13 @@ int gnf_pred_adj_f32(const float* z, int64_t ld, int32_t D, const int32_t* n_nod
  *   grad   a GnfFlow of the same shape whose W[j]/b[j] point at the GRADIENT buffers ([in,out] / [out],
  *          overwritten; with weight_sharing the T uses of a net are summed); packed/attn ignored
  *   z      in: f(x) as left by gnf_grevnet_f32(GNF_FORWARD); out: x again (the reconstruction)
+ *   aux_stream  NULL, or a second stream: the weight-gradient GEMMs of a half-step then overlap the next
+ *          half-step's fused kernel (fork / join by events; everything is complete on `stream` order)
  * Attention GNNs: GNF_EUNSUPPORTED.  ws: gnf_backward_workspace_bytes(n_nodes, D, flow). */
 size_t gnf_backward_workspace_bytes(int64_t n_nodes, int32_t D, const GnfFlow* flow);
 int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFlow* flow, const GnfFlow* grad,
-                             float* z, int64_t ld, int32_t D, void* ws, size_t ws_bytes, gnf_stream_t stream);
+                             float* z, int64_t ld, int32_t D, void* ws, size_t ws_bytes, gnf_stream_t stream,
+                             gnf_stream_t aux_stream);
 
 /* Re-pack EVERY net of a flow (W/b -> `packed`, nets with packed == NULL skipped) in a handful of
  * launches; call after an optimiser step.  Nothing in the reference (weight pre-pack). */

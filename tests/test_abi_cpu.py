@@ -42,12 +42,13 @@ def _mlp(dims, fake_ptr=0x1000):
 def test_packed_floats_host_computation():
     lib = _abi.lib()
     m = _mlp([32, 256, 256, 256, 256, 32])
-    want = 32 * 256 + 256 + 3 * (256 * 256 + 256) + 256 * 32 + 32
+    # per layer: W fragments + W^T fragments (backward) + bias
+    want = 2 * 32 * 256 + 256 + 3 * (2 * 256 * 256 + 256) + 2 * 256 * 32 + 32
     assert lib.gnf_packed_floats(C.byref(m)) == want
     m = _mlp([1, 16, 1])                     # D=2 reference default: widths pad to 16
-    assert lib.gnf_packed_floats(C.byref(m)) == (16 * 16 + 16) * 2
+    assert lib.gnf_packed_floats(C.byref(m)) == (2 * 16 * 16 + 16) * 2
     m = _mlp([50, 100, 50])                  # D=100: 50 -> 64, 100 -> 112
-    assert lib.gnf_packed_floats(C.byref(m)) == 64 * 112 + 112 + 112 * 64 + 64
+    assert lib.gnf_packed_floats(C.byref(m)) == 2 * 64 * 112 + 112 + 2 * 112 * 64 + 64
 
 
 def test_workspace_sizes_are_monotone():

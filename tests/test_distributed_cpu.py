@@ -85,3 +85,59 @@ def test_all_reduce_is_identity_without_process_group():
     assert torch.equal(out, s)
     asm = assemble_from_sums(s)
     assert float(asm["log_prob_xs"]) == 3.0 and float(asm["log_prob_xs_per_node"]) == 0.75
+
+
+def _grad_worker(rank, world, port, ret):
+    """Data-parallel training: total_loss is a sum over nodes, so the batch gradient is the SUM of the shard
+    gradients (one flat all-reduce, GRevNetTrainer.all_reduce_gradients).  The shard gradients come from the
+    oracle here (the product has no CPU compute path)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import gnf_oracle as O
+        from gnf_amd.sharding import shard_graph_ids
+        from gnf_amd.train import GRevNetTrainer
+        d = np.load(os.path.join(ROOT, "data", "community_medium.npz"))
+        rng = np.random.default_rng(4321)
+        ids = rng.choice(168, size=6, replace=True)
+        nn_all, ne_all = d["n_node"][ids], d["n_edge"][ids]
+        dim, t = 4, 1
+        x_all = rng.standard_normal((int(nn_all.sum()), dim))
+        p = O.make_grevnet_params(9, dim // 2, 8, 2, t, final_scale=0.5)
+        noff = np.concatenate([[0], np.cumsum(nn_all)])
+        mine = shard_graph_ids(nn_all, ne_all, world)[rank]
+        rows = np.concatenate([np.arange(noff[i], noff[i + 1]) for i in mine])
+        nn, ne, s, r = O.batch_graphs(d["n_node"], d["n_edge"], d["senders"], d["receivers"], ids[mine])
+        res = O.loss_and_grads(s, r, int(nn.sum()), x_all[rows], p, t)
+        flat = np.concatenate([a.ravel() for kind in ("s", "t") for half in res["grads"][kind] for net in half
+                               for wb in net for a in wb])
+        tr = GRevNetTrainer(None)
+        tr.grad = torch.tensor(flat)                            # the arena the all-reduce runs over
+        tr.all_reduce_gradients()
+        ret[rank] = tr.grad.numpy().copy()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_gradient_all_reduce_matches_single_process():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_grad_worker, args=(world, port, ret), nprocs=world, join=True)
+    from oracle import gnf_oracle as O
+    d = np.load(os.path.join(ROOT, "data", "community_medium.npz"))
+    rng = np.random.default_rng(4321)
+    ids = rng.choice(168, size=6, replace=True)
+    nn, ne, s, r = O.batch_graphs(d["n_node"], d["n_edge"], d["senders"], d["receivers"], ids)
+    x = rng.standard_normal((int(nn.sum()), 4))
+    p = O.make_grevnet_params(9, 2, 8, 2, 1, final_scale=0.5)
+    res = O.loss_and_grads(s, r, int(nn.sum()), x, p, 1)
+    flat = np.concatenate([a.ravel() for kind in ("s", "t") for half in res["grads"][kind] for net in half
+                           for wb in net for a in wb])
+    for rank in range(world):
+        np.testing.assert_allclose(ret[rank], flat, atol=1e-9)

@@ -150,3 +150,58 @@ def test_sharding_is_balanced_and_complete(community_medium):
     assert shard_graph_ids(nn, ne, 8)[3].tolist() == shards[3].tolist()             # deterministic
     one = shard_graph_ids(nn[:3], ne[:3], 8)                                         # fewer graphs than ranks
     assert sum(len(s) for s in one) == 3
+
+
+# ---- embedding-chunk format of the data-backed trainer (train_grevnet_with_data.py:145-271) ----------
+def _write_chunks(tmp_path, sizes_per_file, d=6, seed=0):
+    from gnf_amd import datasets as D
+    rng = np.random.default_rng(seed)
+    allz, alln = [], []
+    for k, sizes in enumerate(sizes_per_file):
+        z = rng.standard_normal((int(np.sum(sizes)), d))
+        D.write_embedding_chunk(str(tmp_path / f"chunk_{k}.pkl"), z, sizes)
+        allz.append(z)
+        alln.append(np.asarray(sizes, np.int32))
+    return allz, alln
+
+
+def test_fixed_chunk_reader_batches_and_file_rollover(tmp_path):
+    import os
+    from gnf_amd import datasets as D
+    _write_chunks(tmp_path, [[3, 4, 5, 2, 6], [2, 2, 7, 1]])
+    ds = D.GrevnetDatasetFixed(str(tmp_path), 2)
+    order = os.listdir(str(tmp_path))
+    import pickle
+    first = pickle.load(open(tmp_path / order[0], "rb"))
+    z, n = ds.train_batch()
+    np.testing.assert_array_equal(n, first[1][:2])
+    np.testing.assert_array_equal(z, first[0][:int(first[1][:2].sum())])
+    z, n = ds.train_batch()
+    np.testing.assert_array_equal(n, first[1][2:4])
+    if len(first[1]) == 5:      # the odd graph at the end of a chunk is dropped, next file opened
+        second = pickle.load(open(tmp_path / order[1], "rb"))
+        z, n = ds.train_batch()
+        np.testing.assert_array_equal(n, second[1][:2])
+        np.testing.assert_array_equal(z, second[0][:int(second[1][:2].sum())])
+
+
+def test_variable_chunk_reader_respects_max_nodes(tmp_path):
+    from gnf_amd import datasets as D
+    allz, alln = _write_chunks(tmp_path, [[3, 4, 5, 2, 6, 1, 1]])
+    ds = D.GrevnetDatasetVariable(str(tmp_path), max_nodes=10)
+    z, n = ds.train_batch()
+    np.testing.assert_array_equal(n, [3, 4])            # 3 + 4 + 5 >= 10 stops before the third graph
+    assert z.shape == (7, 6)
+    z, n = ds.train_batch()
+    np.testing.assert_array_equal(n, [5, 2])            # 5 + 2 + 6 >= 10
+    np.testing.assert_array_equal(z, allz[0][7:14])
+
+
+def test_transform_example_is_fully_connected_with_self_loops():
+    from gnf_amd import datasets as D
+    z = np.arange(5 * 4, dtype=np.float32).reshape(5, 4)
+    g = D.transform_example(z, [2, 3])
+    assert g.n_edge.tolist() == [4, 9]
+    pairs = set(zip(g.senders.tolist(), g.receivers.tolist()))
+    assert pairs == {(a, b) for a in (0, 1) for b in (0, 1)} | {(a, b) for a in (2, 3, 4) for b in (2, 3, 4)}
+    assert g.nodes.shape == (5, 4) and g.edges.shape[0] == 13

@@ -59,8 +59,11 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "gemm"])
 @pytest.mark.parametrize("case", CASES, ids=[f"D{c[0]}_L{c[1]}_K{c[2]}_T{c[3]}_{c[4]}_{c[5]}{'_ws' if c[8] else ''}" for c in CASES])
-def test_gradients_vs_oracle(grid_small, case):
+def test_gradients_vs_oracle(grid_small, case, fused):
+    """fused: the LDS-resident backward kernel (gnf_fused_bwd.hip, needs the packed weights); gemm: the generic
+    GEMM building blocks (what layers too wide for LDS run)."""
     from gnf_amd.train import GRevNetTrainer
     d, latent, k, t, agg, combine, eps, act, ws = case
     hp = dict(D=d, latent=latent, K=k, T=t, agg=agg, combine=combine, epsilon=eps, activation=act, weight_sharing=ws)
@@ -72,6 +75,7 @@ def test_gradients_vs_oracle(grid_small, case):
                               final_scale=0.3 if agg == "mean" else 0.1)
     ref = O.loss_and_grads(s, r, n, x, p, t, ws, agg=agg, combine=combine, epsilon=eps, activation=act)
     net = make_product_grevnet(hp, p)
+    net.fused = fused
     tr = GRevNetTrainer(net)
     graph = graph_from_arrays(nn, ne, s, r, x, DEV)
     out = tr.loss_and_grads(graph)
