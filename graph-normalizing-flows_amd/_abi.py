@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 GNF_MAX_LAYERS = 8
-GNF_ABI_VERSION = 3
+GNF_ABI_VERSION = 4
 
 GNF_AGG_SUM, GNF_AGG_MEAN = 0, 1
 GNF_COMBINE_EPS, GNF_COMBINE_CONCAT = 0, 1
@@ -47,9 +47,16 @@ class GnfGnnSpec(C.Structure):
                 ("activation", C.c_int32), ("alpha", C.c_float)]
 
 
+class GnfBatchNorm(C.Structure):
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("moving_mean", C.c_void_p),
+                ("moving_variance", C.c_void_p), ("batch_mean", C.c_void_p), ("batch_variance", C.c_void_p),
+                ("epsilon", C.c_float), ("reserved", C.c_int32)]
+
+
 class GnfFlow(C.Structure):
     _fields_ = [("num_timesteps", C.c_int32), ("weight_sharing", C.c_int32),
-                ("s_nets", C.POINTER(GnfMlp)), ("t_nets", C.POINTER(GnfMlp)), ("gnn", GnfGnnSpec)]
+                ("s_nets", C.POINTER(GnfMlp)), ("t_nets", C.POINTER(GnfMlp)), ("gnn", GnfGnnSpec),
+                ("bns", C.POINTER(GnfBatchNorm))]
 
 
 _SIGNATURES = {

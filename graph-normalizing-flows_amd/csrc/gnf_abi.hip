@@ -115,9 +115,10 @@ static int validate_pair(const GnfMlp* s, const GnfMlp* t, const GnfGnnSpec* g, 
 WorkspacePlan plan_workspace(int64_t n_nodes, int32_t H, const GnfMlp* net, int32_t combine,
                              int64_t n_halfsteps) {
     WorkspacePlan p;
-    p.partial_stride = coupling_blocks_max(n_nodes);
+    p.partial_stride = partials_per_halfstep(n_nodes);
     p.n_halfsteps = n_halfsteps;
-    size_t pb = (size_t)(n_halfsteps * p.partial_stride + kMaxGaussBlocks) * sizeof(double);
+    p.bn_offset = (size_t)(n_halfsteps * p.partial_stride + kMaxGaussBlocks);
+    size_t pb = (p.bn_offset + (size_t)kBnBlocksMax * (size_t)H * 2) * sizeof(double);
     p.partial_bytes = (pb + 255) / 256 * 256;
     int lmax = 1;
     if (net)
@@ -327,6 +328,11 @@ int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld
         set_error("gnf_grevnet_f32: FORWARD needs a device sums[2] buffer");
         return GNF_EINVAL;
     }
+    if (flow->bns)
+        for (int q = 0; q < 2 * T; ++q) {
+            rc = validate_bn(&flow->bns[q], direction, "gnf_grevnet_f32", q);
+            if (rc) return rc;
+        }
     const int64_t n = csr->n_nodes;
     if (n > 0 && (!x || !ws)) {
         set_error("gnf_grevnet_f32: null x/ws");
@@ -349,6 +355,12 @@ int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld
         if (direction == GNF_FORWARD) {
             for (int i = 0; i < T; ++i) {  // gnn.py:309-338
                 for (int half = 0; half < 2; ++half) {
+                    if (flow->bns) {  // gnn.py:310-313, 325-328: normalise the conditioning half first
+                        rc = launch_bn_normalize(&flow->bns[half * T + i], half == 0 ? half0 : half1, ld, n, H,
+                                                 partials + p.bn_offset, partials + used, st);
+                        if (rc) return rc;
+                        used += 1;
+                    }
                     int32_t np_ = 0;
                     HalfStep hs{csr->rowptr, csr->col, n, half == 0 ? half0 : half1,
                                 half == 0 ? half1 : half0, ld, H, GNF_FORWARD, flow->gnn,
@@ -370,6 +382,10 @@ int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld
                     rc = run_half(hs, scratch, st);
                     if (rc) return rc;
                     // partial slots are reused: the inverse pass has no log-det (gnn.py:343-373)
+                    if (flow->bns) {  // gnn.py:356-358, 369-371: bn.forward on the conditioning half afterwards
+                        rc = launch_bn_denormalize(&flow->bns[half * T + i], half == 0 ? half0 : half1, ld, n, H, st);
+                        if (rc) return rc;
+                    }
                 }
             }
         }

@@ -1,0 +1,169 @@
+// Batch-norm bijector inside the flow: make_batch_norm() = tfb.BatchNormalization(
+// batchnorm_layer=tf.layers.BatchNormalization(axis=-1, gamma_constraint=relu+1e-6), training=True)
+// (gnn.py:260-263), applied to the conditioning half before each half-step of f (gnn.py:310-313,325-328)
+// and undone after each half-step of g (gnn.py:356-358,369-371).
+//
+// Semantics restated from tensorflow-probability 0.7 / tf.layers (third party, absent here: UNPINNED):
+//   f:  bn.inverse(x)  = (x - mean_B) / sqrt(var_B + eps) * gamma + beta      mean_B, var_B: moments of THIS batch
+//                         over the node axis (tf.nn.moments: biased variance), training=True
+//       bn.inverse_log_det_jacobian(x, event_ndims=2) = N * sum_f (log gamma_f - 0.5 log(var_B,f + eps))
+//                         (the bijector's ildj is the per-node scalar; event_ndims=2 sums it over the N nodes)
+//   g:  bn.forward(z)  = (z - beta) / gamma * sqrt(moving_var + eps) + moving_mean      (the MOVING statistics)
+// The moving averages themselves are updated by the training step (UPDATE_OPS, run_grevnet.py:360), not here:
+// the batch moments are handed back through GnfBatchNorm.batch_mean / batch_variance.
+#include "gnf_common.h"
+
+namespace gnf {
+
+static constexpr int kBnRows = 64;  // rows per workgroup of the two passes
+
+// pass 1: per-workgroup column sums and sums of squares (fp64), fixed order
+__global__ __launch_bounds__(256) void k_bn_stats(const float* __restrict__ x, int64_t ld, int64_t n, int H,
+                                                  int64_t rows_per_block, double* __restrict__ part) {
+    __shared__ double sh[2][256];
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    const int tid = threadIdx.x;
+    for (int c0 = 0; c0 < H; c0 += 256) {
+        const int w = H - c0 < 256 ? H - c0 : 256;  // columns of this pass
+        const int lanes = 256 / w;                   // row lanes per column
+        const int c = tid % w, rs = tid / w;
+        double s = 0.0, q = 0.0;
+        if (rs < lanes)
+            for (int64_t r = r0 + rs; r < r1; r += lanes) {
+                const double v = (double)x[r * ld + c0 + c];
+                s += v;
+                q += v * v;
+            }
+        sh[0][tid] = s;
+        sh[1][tid] = q;
+        __syncthreads();
+        if (tid < w) {
+            double ts = 0.0, tq = 0.0;
+            for (int k = 0; k < lanes; ++k) {
+                ts += sh[0][k * w + tid];
+                tq += sh[1][k * w + tid];
+            }
+            part[((int64_t)blockIdx.x * H + c0 + tid) * 2 + 0] = ts;
+            part[((int64_t)blockIdx.x * H + c0 + tid) * 2 + 1] = tq;
+        }
+        __syncthreads();
+    }
+}
+
+// pass 2: every workgroup re-reduces the (few) partials, normalises its rows in place; workgroup 0 also
+// writes the log-det term and the batch moments.
+__global__ __launch_bounds__(256) void k_bn_apply(float* __restrict__ x, int64_t ld, int64_t n, int H,
+                                                  int64_t rows_per_block, const double* __restrict__ part, int nparts,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  float eps, float* __restrict__ batch_mean,
+                                                  float* __restrict__ batch_var, double* __restrict__ logdet_slot) {
+    extern __shared__ float ss[];  // scale[H] | shift[H]
+    __shared__ double red[256];
+    float* scale = ss;
+    float* shift = ss + H;
+    const int tid = threadIdx.x;
+    double ld_local = 0.0;
+    for (int c = tid; c < H; c += 256) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < nparts; ++b) {
+            s += part[((int64_t)b * H + c) * 2 + 0];
+            q += part[((int64_t)b * H + c) * 2 + 1];
+        }
+        const double mean = s / (double)n;
+        double var = q / (double)n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float g = gamma[c];
+        const float sc = g / sqrtf((float)var + eps);
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        ld_local += log((double)g) - 0.5 * log(var + (double)eps);
+        if (blockIdx.x == 0) {
+            if (batch_mean) batch_mean[c] = (float)mean;
+            if (batch_var) batch_var[c] = (float)var;
+        }
+    }
+    if (blockIdx.x == 0) {
+        red[tid] = ld_local;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) *logdet_slot = (double)n * red[0];
+    }
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    const int64_t tot = (r1 - r0) * H;
+    for (int64_t i = tid; i < tot; i += 256) {
+        const int64_t r = r0 + i / H;
+        const int c = (int)(i % H);
+        float* p = x + r * ld + c;
+        *p = *p * scale[c] + shift[c];
+    }
+}
+
+// g direction: z <- (z - beta) / gamma * sqrt(moving_var + eps) + moving_mean
+__global__ __launch_bounds__(256) void k_bn_denorm(float* __restrict__ z, int64_t ld, int64_t n, int H,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   const float* __restrict__ mmean, const float* __restrict__ mvar,
+                                                   float eps) {
+    const int64_t tot = n * H;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / H;
+        const int c = (int)(i % H);
+        float* p = z + r * ld + c;
+        *p = (*p - beta[c]) / gamma[c] * sqrtf(mvar[c] + eps) + mmean[c];
+    }
+}
+
+int bn_blocks(int64_t n, int64_t* rows_per_block) {
+    int64_t rpb = kBnRows;
+    int64_t blocks = (n + rpb - 1) / rpb;
+    if (blocks > kBnBlocksMax) {
+        rpb = (n + kBnBlocksMax - 1) / kBnBlocksMax;
+        blocks = (n + rpb - 1) / rpb;
+    }
+    if (blocks < 1) blocks = 1;
+    *rows_per_block = rpb;
+    return (int)blocks;
+}
+
+int launch_bn_normalize(const GnfBatchNorm* bn, float* x, int64_t ld, int64_t n, int32_t H, double* part,
+                        double* logdet_slot, hipStream_t st) {
+    if (n == 0) return GNF_OK;
+    int64_t rpb;
+    const int blocks = bn_blocks(n, &rpb);
+    hipLaunchKernelGGL(k_bn_stats, dim3(blocks), dim3(256), 0, st, x, ld, n, H, rpb, part);
+    GNF_LAUNCH_CHECK("k_bn_stats");
+    hipLaunchKernelGGL(k_bn_apply, dim3(blocks), dim3(256), 2 * H * sizeof(float), st, x, ld, n, H, rpb, part,
+                       blocks, bn->gamma, bn->beta, bn->epsilon, bn->batch_mean, bn->batch_variance, logdet_slot);
+    GNF_LAUNCH_CHECK("k_bn_apply");
+    return GNF_OK;
+}
+
+int launch_bn_denormalize(const GnfBatchNorm* bn, float* z, int64_t ld, int64_t n, int32_t H, hipStream_t st) {
+    if (n == 0) return GNF_OK;
+    int64_t blocks = (n * H + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_bn_denorm, dim3((unsigned)blocks), dim3(256), 0, st, z, ld, n, H, bn->gamma, bn->beta,
+                       bn->moving_mean, bn->moving_variance, bn->epsilon);
+    GNF_LAUNCH_CHECK("k_bn_denorm");
+    return GNF_OK;
+}
+
+int validate_bn(const GnfBatchNorm* bn, int direction, const char* what, int q) {
+    if (!bn->gamma || !bn->beta || (direction == GNF_INVERSE && (!bn->moving_mean || !bn->moving_variance))) {
+        set_error("%s: batch-norm %d has null gamma / beta%s", what, q,
+                  direction == GNF_INVERSE ? " / moving statistics" : "");
+        return GNF_EINVAL;
+    }
+    if (!(bn->epsilon > 0.f)) {
+        set_error("%s: batch-norm %d epsilon must be > 0", what, q);
+        return GNF_EINVAL;
+    }
+    return GNF_OK;
+}
+
+}  // namespace gnf

@@ -50,8 +50,11 @@ struct HalfStep {
 // [ fp64 partial sums | float scratch of the layered path ]
 static constexpr int kFinalizeBlock = 256;
 static constexpr int kMaxGaussBlocks = 1024;
+static constexpr int kBnBlocksMax = 256;  // workgroups of the batch-norm moment pass
 
 inline int64_t coupling_blocks_max(int64_t n_nodes) { return (n_nodes + 15) / 16 + 1; }
+// per half-step: the coupling partials + one slot for the batch-norm log-det term
+inline int64_t partials_per_halfstep(int64_t n_nodes) { return coupling_blocks_max(n_nodes) + 1; }
 
 // layered path: ping-pong activation buffers per net x two nets side by side (grouped GEMM launches)
 static constexpr int kLayeredActBufs = 4;
@@ -59,7 +62,8 @@ static constexpr int kLayeredActBufs = 4;
 struct WorkspacePlan {
     int64_t partial_stride;  // doubles per half-step
     int64_t n_halfsteps;
-    size_t partial_bytes;    // (n_halfsteps * stride + kMaxGaussBlocks) * 8, 256-aligned
+    size_t partial_bytes;    // (n_halfsteps * stride + kMaxGaussBlocks + batch-norm moment partials) * 8, 256-aligned
+    size_t bn_offset;        // doubles: start of the batch-norm moment partials inside the fp64 region
     size_t scratch_floats;   // layered path activations (+ attention front-end region at its end)
     size_t base_floats;      // offset of the attention region inside the scratch
     size_t total_bytes;
@@ -94,6 +98,12 @@ int launch_half_bwd_fused(const int32_t* rowptr, const int32_t* col, int64_t n, 
                           const GnfMlp* s, const GnfMlp* t, const float* x_cond, float* y_upd, int64_t ld,
                           float* g_upd, int64_t ldg, int32_t H, float* h0_out, float* const* hin, int64_t ldh,
                           float* const* dP, int64_t lddp, float* const* gst, float* const* dh0, hipStream_t st);
+
+// batch-norm bijector (gnf_bn.hip)
+int validate_bn(const GnfBatchNorm* bn, int direction, const char* what, int q);
+int launch_bn_normalize(const GnfBatchNorm* bn, float* x, int64_t ld, int64_t n, int32_t H, double* part,
+                        double* logdet_slot, hipStream_t st);
+int launch_bn_denormalize(const GnfBatchNorm* bn, float* z, int64_t ld, int64_t n, int32_t H, hipStream_t st);
 
 int validate_mlp(const GnfMlp* m, const char* what);
 int validate_flow_call(const GnfCsr* csr, const GnfFlow* flow, int64_t ld, int32_t D, const char* what);

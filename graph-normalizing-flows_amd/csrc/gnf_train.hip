@@ -386,12 +386,126 @@ __global__ __launch_bounds__(256) void k_aggregate_bwd(const int32_t* __restrict
     }
 }
 
+// ---- batch-norm bijector, backwards (forward: gnf_bn.hip) ------------------------------------------------
+// y = (x - mu) / sigma * gamma + beta with the batch moments mu, var (sigma = sqrt(var + eps)) and the
+// log-det term N * sum_f(log gamma_f - 0.5 log(var_f + eps)) inside L = -(log_prob_zs + logdet).  tf.gradients
+// differentiates THROUGH the moments (they are functions of x).  With xh = (y - beta) / gamma, Gy = dL/dy:
+//   dbeta = sum_n Gy          dgamma = sum_n Gy xh - N / gamma
+//   dx    = [ gamma Gy - mean_n(gamma Gy) - xh mean_n(gamma Gy xh) + xh ] / sigma        (+xh: from 0.5 N log(var + eps))
+//   x     = xh sigma + mu                                                              (the state, rebuilt)
+__global__ __launch_bounds__(256) void k_bn_bwd_stats(const float* __restrict__ y, int64_t ld,
+                                                      const float* __restrict__ gy, int64_t ldg, int64_t n, int H,
+                                                      int64_t rows_per_block, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, double* __restrict__ part) {
+    __shared__ double sh[2][256];
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    const int tid = threadIdx.x;
+    for (int c0 = 0; c0 < H; c0 += 256) {
+        const int w = H - c0 < 256 ? H - c0 : 256;
+        const int lanes = 256 / w;
+        const int c = tid % w, rs = tid / w;
+        double s = 0.0, q = 0.0;
+        if (rs < lanes) {
+            const float ig = 1.f / gamma[c0 + c], b = beta[c0 + c];
+            for (int64_t r = r0 + rs; r < r1; r += lanes) {
+                const double gv = (double)gy[r * ldg + c0 + c];
+                const double xh = (double)((y[r * ld + c0 + c] - b) * ig);
+                s += gv;
+                q += gv * xh;
+            }
+        }
+        sh[0][tid] = s;
+        sh[1][tid] = q;
+        __syncthreads();
+        if (tid < w) {
+            double ts = 0.0, tq = 0.0;
+            for (int k = 0; k < lanes; ++k) {
+                ts += sh[0][k * w + tid];
+                tq += sh[1][k * w + tid];
+            }
+            part[((int64_t)blockIdx.x * H + c0 + tid) * 2 + 0] = ts;
+            part[((int64_t)blockIdx.x * H + c0 + tid) * 2 + 1] = tq;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(float* __restrict__ y, int64_t ld, float* __restrict__ gy,
+                                                      int64_t ldg, int64_t n, int H, int64_t rows_per_block,
+                                                      const double* __restrict__ part, int nparts,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ bmean, const float* __restrict__ bvar,
+                                                      float eps, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      int accumulate) {
+    extern __shared__ float ss[];  // per column: m1 = mean(gamma Gy), m2 = mean(gamma Gy xh), gamma, beta, sigma, mu
+    float* m1 = ss;
+    float* m2 = ss + H;
+    float* sg = ss + 2 * H;
+    float* sb = ss + 3 * H;
+    float* ssig = ss + 4 * H;
+    float* smu = ss + 5 * H;
+    const int tid = threadIdx.x;
+    for (int c = tid; c < H; c += 256) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < nparts; ++b) {
+            s += part[((int64_t)b * H + c) * 2 + 0];
+            q += part[((int64_t)b * H + c) * 2 + 1];
+        }
+        const float g = gamma[c];
+        m1[c] = (float)(s / (double)n) * g;
+        m2[c] = (float)(q / (double)n) * g;
+        sg[c] = g;
+        sb[c] = beta[c];
+        ssig[c] = sqrtf(bvar[c] + eps);
+        smu[c] = bmean[c];
+        if (blockIdx.x == 0) {
+            const float db = (float)s;
+            const float dg = (float)(q - (double)n / (double)g);
+            dbeta[c] = accumulate ? dbeta[c] + db : db;
+            dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+        }
+    }
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    const int64_t tot = (r1 - r0) * H;
+    for (int64_t i = tid; i < tot; i += 256) {
+        const int64_t r = r0 + i / H;
+        const int c = (int)(i % H);
+        float* py = y + r * ld + c;
+        float* pg = gy + r * ldg + c;
+        const float xh = (*py - sb[c]) / sg[c];
+        const float sig = ssig[c];
+        *pg = (sg[c] * *pg - m1[c] - xh * m2[c] + xh) / sig;
+        *py = xh * sig + smu[c];
+    }
+}
+
+static int launch_bn_backward(const GnfBatchNorm* bn, const GnfBatchNorm* gbn, float* y, int64_t ld, float* gy,
+                              int64_t ldg, int64_t n, int32_t H, double* part, hipStream_t st) {
+    int64_t rpb = 64;
+    int64_t blocks = (n + rpb - 1) / rpb;
+    if (blocks > kBnBlocksMax) {
+        rpb = (n + kBnBlocksMax - 1) / kBnBlocksMax;
+        blocks = (n + rpb - 1) / rpb;
+    }
+    hipLaunchKernelGGL(k_bn_bwd_stats, dim3((unsigned)blocks), dim3(256), 0, st, y, ld, gy, ldg, n, H, rpb, bn->gamma,
+                       bn->beta, part);
+    GNF_LAUNCH_CHECK("k_bn_bwd_stats");
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)blocks), dim3(256), 6 * H * sizeof(float), st, y, ld, gy, ldg, n,
+                       H, rpb, part, (int)blocks, bn->gamma, bn->beta, bn->batch_mean, bn->batch_variance, bn->epsilon,
+                       const_cast<float*>(gbn->gamma), const_cast<float*>(gbn->beta), 0);
+    GNF_LAUNCH_CHECK("k_bn_bwd_apply");
+    return GNF_OK;
+}
+
 // ---- workspace ---------------------------------------------------------------------------------
 struct BwdPlan {
     int K, in0, lmax, H, chunks;
     int64_t n, kchunk;
     int64_t wsum, osum;  // sum_j I_j * O_j, sum_j O_j of one net
-    size_t g, invdeg, h0, acts, st, gst, dpb, dh0, wslab, bslab, total;  // float offsets
+    size_t g, invdeg, bnpart, h0, acts, st, gst, dpb, dh0, wslab, bslab, total;  // float offsets
     size_t set_stride;  // the dW operands (h0, acts, gst, dpb) exist twice: half-step k's dW GEMM may run on the
                         // auxiliary stream while half-step k-1's fused kernel already refills the other set
 };
@@ -427,6 +541,7 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net) {
     size_t off = 0;
     p.g = off, off += al64((size_t)n * D);
     p.invdeg = off, off += al64((size_t)n);
+    p.bnpart = off, off += al64((size_t)kBnBlocksMax * (size_t)p.H * 4);  // fp64 pairs of the batch-norm backward
     p.st = off, off += 2 * al64((size_t)n * p.H);
     p.dh0 = off, off += 2 * al64((size_t)n * p.in0);
     p.wslab = off, off += 2 * al64((size_t)chunks * p.wsum);
@@ -804,6 +919,21 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 }
         }
     }
+    if (flow->bns) {
+        if (!grad->bns) {
+            set_error("gnf_grevnet_backward_f32: the flow has batch-norm bijectors, grad->bns is NULL");
+            return GNF_EINVAL;
+        }
+        for (int q = 0; q < 2 * T; ++q) {
+            rc = validate_bn(&flow->bns[q], GNF_FORWARD, "gnf_grevnet_backward_f32", q);
+            if (rc) return rc;
+            if (!flow->bns[q].batch_mean || !flow->bns[q].batch_variance || !grad->bns[q].gamma || !grad->bns[q].beta) {
+                set_error("gnf_grevnet_backward_f32: batch-norm %d needs the batch moments of the forward pass "
+                          "(batch_mean / batch_variance) and gradient buffers (grad->bns[].gamma / beta)", q);
+                return GNF_EINVAL;
+            }
+        }
+    }
     const int64_t n = csr->n_nodes;
     hipStream_t st = (hipStream_t)stream;
     if (n_nets == 0) return GNF_OK;
@@ -822,6 +952,11 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                     GNF_HIP_TRY(hipMemsetAsync(const_cast<float*>(gm->W[j]), 0, sizeof(float) * gm->dims[j] * gm->dims[j + 1], st));
                     GNF_HIP_TRY(hipMemsetAsync(const_cast<float*>(gm->b[j]), 0, sizeof(float) * gm->dims[j + 1], st));
                 }
+            }
+        if (flow->bns)
+            for (int q = 0; q < 2 * T; ++q) {
+                GNF_HIP_TRY(hipMemsetAsync(const_cast<float*>(grad->bns[q].gamma), 0, sizeof(float) * H, st));
+                GNF_HIP_TRY(hipMemsetAsync(const_cast<float*>(grad->bns[q].beta), 0, sizeof(float) * H, st));
             }
         return GNF_OK;
     }
@@ -889,6 +1024,11 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             }
             ++step;
             if (rc) return rc;
+            if (flow->bns) {  // the bijector sat in front of this half-step (gnn.py:310-313, 325-328)
+                rc = launch_bn_backward(&flow->bns[half * T + i], &grad->bns[half * T + i], z + co, ld, g + co, D, n, H,
+                                        reinterpret_cast<double*>(wsf + p.bnpart), st);
+                if (rc) return rc;
+            }
         }
     for (int q = 0; q < 2; ++q)  // join: the gradients are complete on `stream`
         if (aux && ev_done[q]) GNF_HIP_TRY(hipStreamWaitEvent(st, ev_done[q], 0));

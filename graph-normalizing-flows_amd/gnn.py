@@ -9,7 +9,8 @@ Differences a reference user will notice (all deliberate):
     "leaky_relu") where the reference passes `tf.unsorted_segment_*` / `tf.nn.*`.
   * parameters are explicit: `mlp.get_params()` / `mlp.set_params([(W, b), ...])`, `W` is [in, out]
     like snt.Linear; call `grevnet.repack()` after mutating weight tensors in place.
-  * `use_batch_norm=True` raises (deferred).
+  * `use_batch_norm=True`: the bijectors are `grevnet.bns[half][i]` (`BatchNormBijector`: gamma, beta,
+    moving_mean, moving_variance tensors); TFP-0.7 semantics restated.
   * there is no CPU fallback: without libgnf_hip.so / a HIP device every call raises GnfError.
 """
 import ctypes as C
@@ -402,6 +403,74 @@ def get_gnns(num_timesteps, make_gnn_fn):            # gnn.py:266-267
 
 
 # ----------------------------------------------------------------------------------------------
+# make_batch_norm (gnn.py:260-263)
+# ----------------------------------------------------------------------------------------------
+class BatchNormBijector:
+    """tfb.BatchNormalization(batchnorm_layer=tf.layers.BatchNormalization(axis=-1,
+    gamma_constraint=lambda x: relu(x) + 1e-6), training=True): variables gamma (ones), beta (zeros),
+    moving_mean (zeros), moving_variance (ones), epsilon 1e-3, momentum 0.99 (tf.layers defaults), created at
+    first connection.  The arithmetic runs inside gnf_grevnet_f32 (GnfBatchNorm); this object owns the
+    variables, the batch moments of the last f(), and the moving-average / constraint updates a training step
+    applies (UPDATE_OPS + the optimizer's constraint projection)."""
+    epsilon = 1e-3
+    momentum = 0.99
+
+    def __init__(self):
+        self.gamma = self.beta = self.moving_mean = self.moving_variance = None
+        self.batch_mean = self.batch_variance = None
+        self.version = 0
+
+    def ensure_built(self, hdim, device):
+        if self.gamma is None:
+            self.gamma = torch.ones(hdim)
+            self.beta = torch.zeros(hdim)
+            self.moving_mean = torch.zeros(hdim)
+            self.moving_variance = torch.ones(hdim)
+            self.version += 1
+        if self.gamma.shape[0] != hdim:
+            raise ValueError(f"batch norm built for width {self.gamma.shape[0]}, connected to {hdim}")
+        if self.gamma.device != torch.device(device) or self.batch_mean is None:
+            for k in ("gamma", "beta", "moving_mean", "moving_variance"):
+                setattr(self, k, getattr(self, k).to(device=device, dtype=torch.float32).contiguous())
+            self.batch_mean = torch.zeros(hdim, dtype=torch.float32, device=device)
+            self.batch_variance = torch.ones(hdim, dtype=torch.float32, device=device)
+            self.version += 1
+        return self
+
+    def set_params(self, d):
+        for k in ("gamma", "beta", "moving_mean", "moving_variance"):
+            v = d[k]
+            v = torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).to(torch.float32).contiguous()
+            setattr(self, k, v)
+        self.batch_mean = None
+        self.version += 1
+
+    def get_params(self):
+        return {k: getattr(self, k).detach().cpu().numpy().copy()
+                for k in ("gamma", "beta", "moving_mean", "moving_variance")}
+
+    def fill_desc(self, desc):
+        desc.gamma, desc.beta = self.gamma.data_ptr(), self.beta.data_ptr()
+        desc.moving_mean, desc.moving_variance = self.moving_mean.data_ptr(), self.moving_variance.data_ptr()
+        desc.batch_mean, desc.batch_variance = self.batch_mean.data_ptr(), self.batch_variance.data_ptr()
+        desc.epsilon = self.epsilon
+
+    def update_moving_statistics(self):
+        """tf.layers.BatchNormalization's UPDATE_OPS with the moments of the last f():
+        moving <- moving * momentum + batch * (1 - momentum)."""
+        self.moving_mean.mul_(self.momentum).add_(self.batch_mean, alpha=1.0 - self.momentum)
+        self.moving_variance.mul_(self.momentum).add_(self.batch_variance, alpha=1.0 - self.momentum)
+
+    def apply_gamma_constraint(self):
+        """gamma_constraint = relu(x) + 1e-6, projected after an optimizer update."""
+        self.gamma.clamp_(min=0.0).add_(1e-6)
+
+
+def make_batch_norm():                                # gnn.py:260-263
+    return BatchNormBijector()
+
+
+# ----------------------------------------------------------------------------------------------
 # GRevNet (gnn.py:273-381)
 # ----------------------------------------------------------------------------------------------
 class GRevNet:
@@ -416,10 +485,10 @@ class GRevNet:
         else:                                         # gnn.py:288-296
             self.s = [get_gnns(num_timesteps, make_gnn_fn), get_gnns(num_timesteps, make_gnn_fn)]
             self.t = [get_gnns(num_timesteps, make_gnn_fn), get_gnns(num_timesteps, make_gnn_fn)]
-        if use_batch_norm:
-            raise NotImplementedError("use_batch_norm=True (tfb.BatchNormalization, gnn.py:260-263) is not "
-                                      "part of the MI355X hot path yet (SURVEY.md 8f #2)")
-        self.use_batch_norm = False
+        self.use_batch_norm = bool(use_batch_norm)
+        # gnn.py:298-299: one bijector per half-step, created whether or not it is used
+        self.bns = [[make_batch_norm() for _ in range(self.num_timesteps)],
+                    [make_batch_norm() for _ in range(self.num_timesteps)]]
         self.name = name
         self._cache = None       # (key, flow desc, keep-alive objects)
         self.fused = True        # False: hide the packed weights -> the layered (generic) kernels run
@@ -456,6 +525,10 @@ class GRevNet:
                     blk._mlp.set_params(net["mlp"])
                 else:
                     blk._mlp.set_params(net)
+        if "bn" in params and params["bn"] is not None:   # [[{gamma, beta, moving_mean, moving_variance}]*T]*2
+            for half in range(2):
+                for i in range(self.num_timesteps):
+                    self.bns[half][i].set_params(params["bn"][half][i])
         self._cache = None
         return self
 
@@ -466,6 +539,8 @@ class GRevNet:
                      else b._mlp.get_params()) for b in self.blocks(kind)]
             t = self.num_timesteps
             out[kind] = flat if self.weight_sharing else [flat[:t], flat[t:]]
+        if self.use_batch_norm and self.bns[0] and self.bns[0][0].gamma is not None:
+            out["bn"] = [[b.get_params() for b in half] for half in self.bns]
         return out
 
     def repack(self):
@@ -482,8 +557,9 @@ class GRevNet:
         s_mlps = [m.ensure_built(b0.in_dim(hdim), device) for m in self.mlps("s")]
         t_mlps = [m.ensure_built(b0.in_dim(hdim), device) for m in self.mlps("t")]
         attn_descs = [b.attn_desc(hdim, device) for b in blocks]          # None for message-passing blocks
+        bn_list = [b.ensure_built(hdim, device) for half in self.bns for b in half] if self.use_batch_norm else []
         key = (str(device), hdim, bool(self.fused), tuple(m.version for m in s_mlps + t_mlps),
-               tuple(b.attn_version() for b in blocks))
+               tuple(b.attn_version() for b in blocks), tuple(b.version for b in bn_list))
         if self._cache is not None and self._cache[0] == key:
             return self._cache[1]
         n = len(s_mlps)
@@ -509,10 +585,15 @@ class GRevNet:
                         _abi.check(lib.gnf_pack_mlp(C.byref(arr[q]), C.c_void_p(packed.data_ptr() + 4 * off), st),
                                    "gnf_pack_mlp")
                     off += m.packed_floats()
+        bn_arr = None
+        if bn_list:
+            bn_arr = (_abi.GnfBatchNorm * len(bn_list))()
+            for q, b in enumerate(bn_list):       # index half*T + i
+                b.fill_desc(bn_arr[q])
         flow = _abi.GnfFlow(self.num_timesteps, int(self.weight_sharing),
                             C.cast(s_arr, C.POINTER(_abi.GnfMlp)), C.cast(t_arr, C.POINTER(_abi.GnfMlp)),
-                            b0.spec())
-        self._cache = (key, flow, (s_arr, t_arr, attn_arr, packed, s_mlps, t_mlps, blocks))
+                            b0.spec(), C.cast(bn_arr, C.POINTER(_abi.GnfBatchNorm)) if bn_arr is not None else None)
+        self._cache = (key, flow, (s_arr, t_arr, attn_arr, packed, s_mlps, t_mlps, blocks, bn_arr, bn_list))
         return flow
 
     def _run(self, graph, direction, sums_out=None):

@@ -1,7 +1,8 @@
 """Multi-GPU data parallelism for the hot path (new functionality named by BASELINE.json's
 north_star; the reference is single-device).
 
-A batch is a block-diagonal union of independent graphs, and with use_batch_norm=False the only
+A batch is a block-diagonal union of independent graphs, and with use_batch_norm=False (with it, the
+batch-norm moments are per shard, as in ordinary data-parallel batch norm) the only
 cross-graph quantities of the path are three batch-wide sums: log_prob_zs, log_det_jacobian
 (gnn.py:322,337; run_grevnet.py:294) and sum(n_node) (run_grevnet.py:298).  So: whole graphs ->
 ranks (balanced), weights replicated, each rank runs the single-GPU path on its shard, and ONE

@@ -42,8 +42,9 @@ def get_learning_rate(timestep, max_lr, ramp_up=1000, hold_steady=2000, const_mu
 
 
 class GRevNetTrainer:
-    """total_loss, its gradient and the Adam update for one GRevNet (message-passing GNNs; the attention
-    GNN family has no backward pass yet and raises GnfError / GNF_EUNSUPPORTED).
+    """total_loss, its gradient and the Adam update for one GRevNet (message-passing GNNs with or without the
+    batch-norm bijectors; the attention GNN family has no backward pass yet and raises GnfError /
+    GNF_EUNSUPPORTED).
 
     Hyper-parameters default to the drivers' flags (run_grevnet.py:114-131): lr 1e-4, beta1 0.9,
     beta2 0.9, epsilon 1e-8, exponential lr decay (1000 steps, 0.96), no clipping."""
@@ -64,6 +65,7 @@ class GRevNetTrainer:
         self._keep = None
         self._offsets = None
         self._ws = None
+        self._bns = []
         self._aux = None         # second HIP stream: the weight-gradient GEMMs overlap the backward walk
         self.overlap_weight_grads = True
 
@@ -74,10 +76,13 @@ class GRevNetTrainer:
         if self.theta is not None and self.theta.device == torch.device(device):
             return
         mlps = net.mlps("s") + net.mlps("t")
+        bns = [b for half in net.bns for b in half] if net.use_batch_norm else []   # index half*T + i
         sizes = []
         for m in mlps:
             for (w, b) in m.params:
                 sizes += [w.numel(), b.numel()]
+        for b in bns:                                 # trainable: gamma, beta (the moving statistics are not)
+            sizes += [b.gamma.numel(), b.beta.numel()]
         total = sum(sizes)
         theta = torch.empty(total, dtype=torch.float32, device=device)
         off, bounds = 0, [0]
@@ -95,6 +100,16 @@ class GRevNetTrainer:
                 views.append((wv, bv))
             m.params = views                          # the MLP now reads / is updated through the arena
             m.version += 1
+        self._bn_off = off
+        for b in bns:
+            for name in ("gamma", "beta"):
+                old = getattr(b, name)
+                view = theta[off:off + old.numel()]
+                view.copy_(old)
+                setattr(b, name, view)
+                off += old.numel()
+                bounds.append(off)
+            b.version += 1
         net._cache = None
         self.theta = theta
         self.grad = torch.zeros_like(theta)
@@ -116,9 +131,19 @@ class GRevNetTrainer:
                     arr[q].b[j] = self.grad.data_ptr() + 4 * off
                     off += b.numel()
         spec = net.blocks("s")[0].spec()
+        gbn = None
+        if bns:
+            gbn = (_abi.GnfBatchNorm * len(bns))()
+            for q, b in enumerate(bns):
+                gbn[q].gamma = self.grad.data_ptr() + 4 * off
+                off += b.gamma.numel()
+                gbn[q].beta = self.grad.data_ptr() + 4 * off
+                off += b.beta.numel()
         self._grad_flow = _abi.GnfFlow(net.num_timesteps, int(net.weight_sharing),
-                                       C.cast(gs, C.POINTER(_abi.GnfMlp)), C.cast(gt, C.POINTER(_abi.GnfMlp)), spec)
-        self._keep = (gs, gt)
+                                       C.cast(gs, C.POINTER(_abi.GnfMlp)), C.cast(gt, C.POINTER(_abi.GnfMlp)), spec,
+                                       C.cast(gbn, C.POINTER(_abi.GnfBatchNorm)) if gbn is not None else None)
+        self._keep = (gs, gt, gbn)
+        self._bns = bns
 
     def named_gradients(self):
         """Gradients in the oracle / fixture container layout ({"s": [[mlp]*T, [mlp]*T], "t": ...}; mlp =
@@ -138,6 +163,13 @@ class GRevNetTrainer:
                 flat.append(layers)
             t = net.num_timesteps
             out[kind] = flat if net.weight_sharing else [flat[:t], flat[t:]]
+        if self._bns:
+            t, h = net.num_timesteps, self._bns[0].gamma.numel()
+            flat = []
+            for _ in self._bns:
+                flat.append({"gamma": g[off:off + h].copy(), "beta": g[off + h:off + 2 * h].copy()})
+                off += 2 * h
+            out["bn"] = [flat[:t], flat[t:]]
         return out
 
     # ---- compute_gradients ---------------------------------------------------------------------
@@ -209,6 +241,9 @@ class GRevNetTrainer:
             flow = self.net._flow(h, dev)
             if self.net.fused:
                 _abi.check(lib.gnf_pack_flow(C.byref(flow), st), "gnf_pack_flow")
+        for b in self._bns:        # gamma_constraint projection (gnn.py:261-262) + UPDATE_OPS (run_grevnet.py:360)
+            b.apply_gamma_constraint()
+            b.update_moving_statistics()
         self.global_step = t
 
     def all_reduce_gradients(self, group=None):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GNF_ABI_VERSION 3
+#define GNF_ABI_VERSION 4
 #define GNF_MAX_LAYERS 8 /* Linear layers per MLP (gnn.py:165-166 builds num_layers of them) */
 
 typedef void* gnf_stream_t; /* hipStream_t */
@@ -108,12 +108,34 @@ typedef struct GnfGnnSpec {
  * GnfMlp descriptors: 2*T entries indexed [half*T + i] (weight_sharing = 0, gnn.py:288-296) or 2
  * entries indexed [half] (weight_sharing = 1, gnn.py:284-286).  half 0 nets read columns [0,D/2)
  * and update [D/2,D); half 1 nets the reverse (gnn.py:320-338). */
+/* One batch-norm bijector of the flow: make_batch_norm() (gnn.py:260-263) = tfb.BatchNormalization(
+ * tf.layers.BatchNormalization(axis=-1, gamma_constraint=relu + 1e-6), training=True).  All pointers are
+ * device fp32 [D/2].  GNF_FORWARD (f) normalises the conditioning half with THIS batch's moments over the
+ * node axis and adds N * sum_f(log gamma_f - 0.5 log(var_f + epsilon)) to the log-det (gnn.py:310-313,
+ * 325-328); the moments are handed back in batch_mean / batch_variance (may be NULL) for the moving-average
+ * update the training step runs (UPDATE_OPS, run_grevnet.py:360).  GNF_INVERSE (g) de-normalises with the
+ * MOVING statistics (bn.forward, gnn.py:356-358, 369-371).  TFP-0.7 / tf.layers semantics restated from
+ * the upstream sources (absent here: unpinned). */
+typedef struct GnfBatchNorm {
+    const float* gamma;
+    const float* beta;
+    const float* moving_mean;
+    const float* moving_variance;
+    float* batch_mean;
+    float* batch_variance;
+    float epsilon; /* tf.layers.BatchNormalization default 1e-3 */
+    int32_t reserved;
+} GnfBatchNorm;
+
 typedef struct GnfFlow {
     int32_t num_timesteps; /* T */
     int32_t weight_sharing;
     const GnfMlp* s_nets; /* host */
     const GnfMlp* t_nets; /* host */
     GnfGnnSpec gnn;
+    /* ABI v4: NULL (use_batch_norm=False), or host array of 2*T bijectors indexed [half*T + i] - one per
+     * half-step even with weight sharing (gnn.py:298-299) */
+    const GnfBatchNorm* bns;
 } GnfFlow;
 
 int gnf_abi_version(void);
@@ -205,6 +227,9 @@ int gnf_pred_adj_f32(const float* z, int64_t ld, int32_t D, const int32_t* n_nod
  *   flow   the nets, exactly as passed to gnf_grevnet_f32 (raw W/b are read; `packed` is ignored)
  *   grad   a GnfFlow of the same shape whose W[j]/b[j] point at the GRADIENT buffers ([in,out] / [out],
  *          overwritten; with weight_sharing the T uses of a net are summed); packed/attn ignored
+ *          With batch-norm bijectors (flow->bns): grad->bns[q].gamma / .beta point at their gradient buffers,
+ *          and flow->bns[q].batch_mean / batch_variance must still hold the moments of the forward pass
+ *          (tf.gradients differentiates through the batch moments and through the bijector's log-det term).
  *   z      in: f(x) as left by gnf_grevnet_f32(GNF_FORWARD); out: x again (the reconstruction)
  *   aux_stream  NULL, or a second stream: the weight-gradient GEMMs of a half-step then overlap the next
  *          half-step's fused kernel (fork / join by events; everything is complete on `stream` order)

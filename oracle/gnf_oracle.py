@@ -145,17 +145,52 @@ class Fp64Dense:
         h = np.concatenate([x, agg], axis=1) if self.combine == "concat" else self.eps * x + agg
         return self.mlp(h, layers)
 
+    @staticmethod
+    def bn_inverse(x, bn):
+        """bn.inverse + bn.inverse_log_det_jacobian(x, 2) of make_batch_norm() (gnn.py:260-263, 310-313) in
+        training mode.  Restated from tensorflow-probability 0.7 `bijectors/batch_normalization.py` and
+        tf.layers.BatchNormalization (third party, absent: UNPINNED):
+          _normalize:  (x - mean_B) / sqrt(var_B + eps) * gamma + beta, moments of this batch over axis 0 (biased)
+          _inverse_log_det_jacobian: sum_f log gamma_f - 0.5 sum_f log(var_B,f + eps)  (a scalar), which
+          Bijector._reduce_jacobian_det_over_event sums over the extra event dimension (event_ndims = 2): x N."""
+        eps = float(bn.get("epsilon", 1e-3))
+        mean = x.mean(axis=0)
+        var = x.var(axis=0)
+        gamma, beta = np.asarray(bn["gamma"], np.float64), np.asarray(bn["beta"], np.float64)
+        y = (x - mean) / np.sqrt(var + eps) * gamma + beta
+        ildj = x.shape[0] * float(np.sum(np.log(gamma)) - 0.5 * np.sum(np.log(var + eps)))
+        return y, ildj, mean, var
+
+    @staticmethod
+    def bn_forward(z, bn):
+        """bn.forward (gnn.py:356-358): _de_normalize with the MOVING statistics."""
+        eps = float(bn.get("epsilon", 1e-3))
+        gamma, beta = np.asarray(bn["gamma"], np.float64), np.asarray(bn["beta"], np.float64)
+        mm, mv = np.asarray(bn["moving_mean"], np.float64), np.asarray(bn["moving_variance"], np.float64)
+        return (z - beta) / gamma * np.sqrt(mv + eps) + mm
+
     def f(self, x, params, num_timesteps, weight_sharing=False):
-        """gnn.py:304-341 (use_batch_norm=False).  Returns (z[N,D], logdet scalar)."""
+        """gnn.py:304-341.  Returns (z[N,D], logdet scalar).  params["bn"] ([[bn]*T]*2) switches on
+        use_batch_norm; the batch moments of every bijector are left in self.last_bn_moments."""
         x = np.asarray(x, np.float64)
         hdim = x.shape[1] // 2
         x0, x1 = x[:, :hdim].copy(), x[:, hdim:].copy()
         logdet = 0.0
+        bns = params.get("bn")
+        self.last_bn_moments = {}
         for i in range(num_timesteps):
+            if bns is not None:
+                x0, ildj, m, v = self.bn_inverse(x0, bns[0][i])
+                self.last_bn_moments[(0, i)] = (m, v)
+                logdet += ildj
             s = self.gnn(x0, _net(params, "s", 0, i, weight_sharing))
             t = self.gnn(x0, _net(params, "t", 0, i, weight_sharing))
             logdet += float(np.sum(s))
             x1 = x1 * np.exp(s) + t
+            if bns is not None:
+                x1, ildj, m, v = self.bn_inverse(x1, bns[1][i])
+                self.last_bn_moments[(1, i)] = (m, v)
+                logdet += ildj
             s = self.gnn(x1, _net(params, "s", 1, i, weight_sharing))
             t = self.gnn(x1, _net(params, "t", 1, i, weight_sharing))
             logdet += float(np.sum(s))
@@ -163,16 +198,22 @@ class Fp64Dense:
         return np.concatenate([x0, x1], axis=1), logdet
 
     def g(self, z, params, num_timesteps, weight_sharing=False):
-        """gnn.py:343-373 (use_batch_norm=False).  Returns x[N,D]."""
+        """gnn.py:343-373.  Returns x[N,D].  With params["bn"]: s, t come from the still-normalised half,
+        which is then de-normalised with the moving statistics (gnn.py:356-358, 369-371)."""
         z = np.asarray(z, np.float64)
         hdim = z.shape[1] // 2
         z0, z1 = z[:, :hdim].copy(), z[:, hdim:].copy()
+        bns = params.get("bn")
         for i in reversed(range(num_timesteps)):
             s = self.gnn(z1, _net(params, "s", 1, i, weight_sharing))
             t = self.gnn(z1, _net(params, "t", 1, i, weight_sharing))
+            if bns is not None:
+                z1 = self.bn_forward(z1, bns[1][i])
             z0 = (z0 - t) * np.exp(-s)
             s = self.gnn(z0, _net(params, "s", 0, i, weight_sharing))
             t = self.gnn(z0, _net(params, "t", 0, i, weight_sharing))
+            if bns is not None:
+                z0 = self.bn_forward(z0, bns[0][i])
             z1 = (z1 - t) * np.exp(-s)
         return np.concatenate([z0, z1], axis=1)
 
@@ -210,6 +251,8 @@ class Fp32Gather:
     def prep_params(self, params):
         """numpy -> torch once, outside any timed region."""
         def conv(m):
+            if isinstance(m, dict) and "gamma" in m:          # a batch-norm bijector
+                return {k: (self.to_t(v) if k != "epsilon" else v) for k, v in m.items()}
             if isinstance(m, dict) and "attn" in m:
                 a = dict(m["attn"])
                 for key in ("wq", "wk", "wv", "wo"):
@@ -274,16 +317,40 @@ class Fp32Gather:
         h = torch.cat([x, agg], dim=1) if self.combine == "concat" else self.eps * x + agg
         return self.mlp(h, layers)
 
+    def bn_inverse(self, x, bn):
+        """Same bijector in the TF op order: tf.nn.moments (mean, then mean of squared differences),
+        tf.nn.batch_normalization ((x - mean) * rsqrt(var + eps) * gamma + beta)."""
+        torch = self.torch
+        eps = float(bn.get("epsilon", 1e-3))
+        mean = x.mean(dim=0, keepdim=True)
+        var = ((x - mean) ** 2).mean(dim=0, keepdim=True)
+        inv = torch.rsqrt(var + eps) * bn["gamma"]
+        y = x * inv + (bn["beta"] - mean * inv)
+        ildj = x.shape[0] * (torch.log(bn["gamma"]).sum() - 0.5 * torch.log(var + eps).sum())
+        return y, ildj
+
+    def bn_forward(self, z, bn):
+        torch = self.torch
+        eps = float(bn.get("epsilon", 1e-3))
+        return (z - bn["beta"]) / bn["gamma"] * torch.sqrt(bn["moving_variance"] + eps) + bn["moving_mean"]
+
     def f(self, x, params, num_timesteps, weight_sharing=False):
         torch = self.torch
         hdim = x.shape[1] // 2
         x0, x1 = x[:, :hdim], x[:, hdim:]                             # tf.split
         logdet = torch.zeros((), dtype=self.dtype)
+        bns = params.get("bn")
         for i in range(num_timesteps):
+            if bns is not None:
+                x0, ildj = self.bn_inverse(x0, bns[0][i])
+                logdet = logdet + ildj
             s = self.gnn(x0, _net(params, "s", 0, i, weight_sharing))
             t = self.gnn(x0, _net(params, "t", 0, i, weight_sharing))
             logdet = logdet + s.sum()
             x1 = x1 * torch.exp(s) + t
+            if bns is not None:
+                x1, ildj = self.bn_inverse(x1, bns[1][i])
+                logdet = logdet + ildj
             s = self.gnn(x1, _net(params, "s", 1, i, weight_sharing))
             t = self.gnn(x1, _net(params, "t", 1, i, weight_sharing))
             logdet = logdet + s.sum()
@@ -294,12 +361,17 @@ class Fp32Gather:
         torch = self.torch
         hdim = z.shape[1] // 2
         z0, z1 = z[:, :hdim], z[:, hdim:]
+        bns = params.get("bn")
         for i in reversed(range(num_timesteps)):
             s = self.gnn(z1, _net(params, "s", 1, i, weight_sharing))
             t = self.gnn(z1, _net(params, "t", 1, i, weight_sharing))
+            if bns is not None:
+                z1 = self.bn_forward(z1, bns[1][i])
             z0 = (z0 - t) * torch.exp(-s)
             s = self.gnn(z0, _net(params, "s", 0, i, weight_sharing))
             t = self.gnn(z0, _net(params, "t", 0, i, weight_sharing))
+            if bns is not None:
+                z0 = self.bn_forward(z0, bns[0][i])
             z1 = (z1 - t) * torch.exp(-s)
         return torch.cat([z0, z1], dim=1)
 
@@ -330,6 +402,11 @@ def loss_and_grads(senders, receivers, n_total, x, params, num_timesteps, weight
     leaves = []
 
     def mark(m):
+        if isinstance(m, dict) and "gamma" in m:          # batch-norm bijector: gamma and beta are trainable
+            out = dict(m)
+            for k in ("gamma", "beta"):
+                out[k] = m[k].clone().requires_grad_(True)
+            return out
         if isinstance(m, list) and m and isinstance(m[0], tuple):
             out = []
             for (w, b) in m:
@@ -348,6 +425,8 @@ def loss_and_grads(senders, receivers, n_total, x, params, num_timesteps, weight
     total_loss.backward()
 
     def grads_of(m):
+        if isinstance(m, dict) and "gamma" in m:
+            return {"gamma": m["gamma"].grad.numpy().copy(), "beta": m["beta"].grad.numpy().copy()}
         if isinstance(m, list) and m and isinstance(m[0], tuple):
             return [(w.grad.numpy().copy(), b.grad.numpy().copy()) for (w, b) in m]
         return [grads_of(q) for q in m]
@@ -414,6 +493,19 @@ def make_grevnet_params(seed, hdim, latent, num_layers, num_timesteps, combine="
         return {"s": [one(), one()], "t": [one(), one()]}
     return {"s": [[one() for _ in range(num_timesteps)] for _ in range(2)],
             "t": [[one() for _ in range(num_timesteps)] for _ in range(2)]}
+
+
+def make_bn_params(seed, hdim, num_timesteps):
+    """Non-trivial batch-norm variables for tests (the reference initialises gamma=1, beta=0, moving_mean=0,
+    moving_variance=1; trained values are what matters for parity)."""
+    rng = np.random.default_rng(seed)
+
+    def one():
+        return {"gamma": rng.uniform(0.5, 1.5, hdim).astype(np.float32),
+                "beta": (0.2 * rng.standard_normal(hdim)).astype(np.float32),
+                "moving_mean": (0.3 * rng.standard_normal(hdim)).astype(np.float32),
+                "moving_variance": rng.uniform(0.5, 2.0, hdim).astype(np.float32), "epsilon": 1e-3}
+    return [[one() for _ in range(num_timesteps)] for _ in range(2)]
 
 
 def make_attn_net_params(rng, hdim, latent, num_layers, num_heads=8, kq_dim=10, v_dim=10, out_dim=80,

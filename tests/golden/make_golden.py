@@ -122,6 +122,50 @@ def main_attn():
               f"logdet={res['log_det_jacobian']:.4f} -> {os.path.getsize(path)} B")
 
 
+def main_bn():
+    """use_batch_norm=True (gnn.py:260-263, 310-313): the message-passing flow of cfg2 with a batch-norm
+    bijector in front of every half-step (non-trivial gamma / beta / moving statistics).  x_roundtrip = g(z)
+    uses the MOVING statistics, so it is NOT x."""
+    name, ds, d, latent, k, t = "bn_small_community", "community_medium", 16, 32, 3, 2
+    n_node, n_edge, sl, rl = load(ds)
+    rng = np.random.default_rng(12345)
+    ids = rng.choice(int(0.8 * len(n_node)), size=8, replace=True).tolist()
+    nn, ne, s, r = O.batch_graphs(n_node, n_edge, sl, rl, ids)
+    n = int(nn.sum())
+    x = (rng.standard_normal((n, d)) * 1.7 + 0.4).astype(np.float32)
+    p = O.make_grevnet_params(2026, d // 2, latent, k, t, final_scale=0.5)
+    p["bn"] = O.make_bn_params(2027, d // 2, t)
+    o64 = O.Fp64Dense(s, r, n)
+    res = o64.log_prob(x, p, t)
+    o32 = O.Fp32Gather(s, r, n)
+    r32 = o32.log_prob(o32.to_t(x), o32.prep_params(p), t)
+    assert abs(res["log_prob_xs_per_node"] - r32["log_prob_xs_per_node"]) < 2e-5, name
+    assert np.abs(r32["z"].numpy() - res["z"]).max() < 5e-5, name
+    xr = o64.g(res["z"], p, t)
+    blob = dict(n_node=nn, n_edge=ne, senders=s, receivers=r, x=x, D=d, latent=latent, K=k, T=t,
+                agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu", weight_sharing=False,
+                use_batch_norm=True, z=res["z"], logdet=res["log_det_jacobian"], log_prob_zs=res["log_prob_zs"],
+                log_prob_xs=res["log_prob_xs"], log_prob_xs_per_node=res["log_prob_xs_per_node"], x_roundtrip=xr)
+    for kind in ("s", "t"):
+        for half in range(2):
+            for i, mlp in enumerate(p[kind][half]):
+                for j, (w, b) in enumerate(mlp):
+                    blob[f"w_{kind}_{half}_{i}_{j}"] = w
+                    blob[f"b_{kind}_{half}_{i}_{j}"] = b
+    for half in range(2):
+        for i in range(t):
+            for key in ("gamma", "beta", "moving_mean", "moving_variance"):
+                blob[f"bn_{half}_{i}_{key}"] = p["bn"][half][i][key]
+            m, v = o64.last_bn_moments[(half, i)]
+            blob[f"bn_{half}_{i}_batch_mean"] = m
+            blob[f"bn_{half}_{i}_batch_variance"] = v
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **blob)
+    print(f"{name}: N={n} E={len(s)} per-node log-prob={res['log_prob_xs_per_node']:.6f} "
+          f"logdet={res['log_det_jacobian']:.4f} -> {os.path.getsize(path)} B")
+
+
 if __name__ == "__main__":
     main()
     main_attn()
+    main_bn()

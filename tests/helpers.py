@@ -6,6 +6,7 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDEN_CASES = ["cfg1_grid_small_d2", "cfg1_grid_small_d8", "cfg2_small_community", "sum_concat_relu_shared"]
 ATTN_GOLDEN_CASES = ["attn_cfg1_grid_small", "attn_small_community_noconcat_div"]
+BN_GOLDEN_CASES = ["bn_small_community"]
 ATTN_KEYS = ("num_heads", "kq_dim", "v_dim", "out_dim", "concat", "kq_dim_division", "residual")
 
 
@@ -42,6 +43,12 @@ def load_golden(name):
                     nets.append({"attn": a, "mlp": mlp})
             halves.append(nets[0] if ws else nets)
         params[kind] = halves
+    if "use_batch_norm" in g and bool(g["use_batch_norm"]):
+        params["bn"] = [[{key: g[f"bn_{half}_{i}_{key}"] for key in ("gamma", "beta", "moving_mean", "moving_variance")}
+                         for i in range(t)] for half in range(2)]
+        for half in range(2):
+            for i in range(t):
+                params["bn"][half][i]["epsilon"] = 1e-3
     g["params"] = params
     return g
 
@@ -62,7 +69,8 @@ def make_product_grevnet(hp, params):
         mk = partial(gnn.sum_concat_then_mlp_gnn if hp["agg"] == "sum" else gnn.avg_concat_then_mlp_gnn, mk_mlp)
     else:
         mk = partial(gnn.sum_then_mlp_gnn if hp["agg"] == "sum" else gnn.avg_then_mlp_gnn, mk_mlp, hp["epsilon"])
-    net = gnn.GRevNet(mk, hp["T"], hp["D"], use_batch_norm=False, weight_sharing=hp["weight_sharing"])
+    net = gnn.GRevNet(mk, hp["T"], hp["D"], use_batch_norm=bool(params is not None and params.get("bn")),
+                      weight_sharing=hp["weight_sharing"])
     if params is not None:
         net.set_params(params)
     return net

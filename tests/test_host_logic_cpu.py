@@ -102,8 +102,10 @@ def test_reference_shaped_structure():
     assert blk._mlp.layer_sizes == [32, 32, 32, 32, 4] and blk._mlp.alpha == pytest.approx(0.2)
     shared = gnn.GRevNet(mk, 3, 8, weight_sharing=True)
     assert len(shared.s) == 2 and isinstance(shared.s[0], gnn.NodeBlockGNN)          # gnn.py:284-286
-    with pytest.raises(NotImplementedError):
-        gnn.GRevNet(mk, 3, 8, use_batch_norm=True)
+    bn_net = gnn.GRevNet(mk, 3, 8, use_batch_norm=True)                            # gnn.py:298-299
+    assert bn_net.use_batch_norm and len(bn_net.bns) == 2 and len(bn_net.bns[1]) == 3
+    assert isinstance(bn_net.bns[0][0], gnn.BatchNormBijector) and bn_net.bns[0][0].epsilon == 1e-3
+    assert len(net.bns[0]) == 3 and not net.use_batch_norm                          # created even when unused
     c = gnn.sum_concat_then_mlp_gnn(mk_mlp)._node_block
     assert isinstance(c, gnn.ConcatThenMLPBlock) and c.in_dim(4) == 8
     assert gnn.EDGE_BLOCK_OPT == {"use_edges": False, "use_receiver_nodes": False, "use_sender_nodes": True,

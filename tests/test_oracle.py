@@ -339,3 +339,83 @@ def test_clippers():
     np.testing.assert_allclose(O.clip_by_value(g, -1.0, 5.0), [-1.0, 0.5, 5.0])
     np.testing.assert_allclose(O.clip_by_norm(g, 100.0), g)                       # below the norm: untouched
     np.testing.assert_allclose(np.linalg.norm(O.clip_by_norm(g, 2.0)), 2.0)
+
+
+# ---- batch-norm bijector inside the flow (gnn.py:260-263, 310-313, 356-358) -------------------------------
+def test_bn_bijector_hand_computed():
+    """Two nodes, one feature: x = (0, 2) -> mean 1, biased var 1; y = (x - 1)/sqrt(1 + eps) * gamma + beta;
+    ildj(event_ndims=2) = N * (log gamma - 0.5 log(1 + eps))."""
+    bn = {"gamma": np.array([1.5]), "beta": np.array([0.25]), "moving_mean": np.array([3.0]),
+          "moving_variance": np.array([4.0]), "epsilon": 1e-3}
+    x = np.array([[0.0], [2.0]])
+    y, ildj, mean, var = O.Fp64Dense.bn_inverse(x, bn)
+    np.testing.assert_allclose(mean, [1.0])
+    np.testing.assert_allclose(var, [1.0])
+    np.testing.assert_allclose(y[:, 0], np.array([-1.0, 1.0]) / math.sqrt(1.001) * 1.5 + 0.25, rtol=1e-14)
+    assert abs(ildj - 2 * (math.log(1.5) - 0.5 * math.log(1.001))) < 1e-14
+    # bn.forward uses the MOVING statistics: (z - beta) / gamma * sqrt(4 + eps) + 3
+    z = np.array([[0.25], [1.75]])
+    np.testing.assert_allclose(O.Fp64Dense.bn_forward(z, bn)[:, 0], np.array([0.0, 1.0]) * math.sqrt(4.001) + 3.0)
+
+
+def test_bn_flow_dual_agreement_and_round_trip(grid_small):
+    n_node, n_edge, sl, rl = grid_small
+    nn, ne, s, r = O.batch_graphs(n_node, n_edge, sl, rl, [6, 0, 3])
+    n = int(nn.sum())
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((n, 8)) * 2 - 1).astype(np.float32)
+    t = 2
+    p = O.make_grevnet_params(11, 4, 16, 3, t, final_scale=0.5)
+    p["bn"] = O.make_bn_params(12, 4, t)
+    o64 = O.Fp64Dense(s, r, n)
+    a = o64.log_prob(x, p, t)
+    o32 = O.Fp32Gather(s, r, n)
+    b = o32.log_prob(o32.to_t(x), o32.prep_params(p), t)
+    assert abs(a["log_prob_xs_per_node"] - b["log_prob_xs_per_node"]) < 2e-5
+    np.testing.assert_allclose(b["z"].numpy(), a["z"], atol=5e-5)
+    # the two directions are inverses of each other exactly when the moving statistics equal the batch moments
+    q = {k: v for k, v in p.items()}
+    q["bn"] = [[dict(p["bn"][h][i], moving_mean=o64.last_bn_moments[(h, i)][0],
+                     moving_variance=o64.last_bn_moments[(h, i)][1]) for i in range(t)] for h in range(2)]
+    np.testing.assert_allclose(o64.g(a["z"], q, t), x, atol=1e-9)
+    assert np.abs(o64.g(a["z"], p, t) - x).max() > 1e-2      # ... and not with other moving statistics
+    # with use_batch_norm the log-det has the N * sum(log gamma - 0.5 log(var + eps)) terms on top of sum(s)
+    plain = {k: v for k, v in p.items() if k != "bn"}
+    assert abs(a["log_det_jacobian"] - o64.log_prob(x, plain, t)["log_det_jacobian"]) > 1.0
+
+
+def test_gradient_oracle_with_batch_norm_matches_finite_differences():
+    """tf.gradients differentiates through the batch moments and the bijector's log-det term; so does autograd
+    over the torch restatement; central differences of the numpy dense form agree."""
+    import copy
+    s, r, n = tiny_graph()
+    t = 2
+    p = _params_f64(O.make_grevnet_params(3, 2, 6, 3, t, final_scale=0.5))
+    p["bn"] = [[{k: (np.asarray(v, np.float64) if k != "epsilon" else v) for k, v in b.items()} for b in half]
+               for half in O.make_bn_params(4, 2, t)]
+    x = np.random.default_rng(0).standard_normal((n, 4)) * 2 + 1
+    res = O.loss_and_grads(s, r, n, x, p, t)
+    dense = O.Fp64Dense(s, r, n)
+
+    def loss(pp):
+        return -dense.log_prob(x, pp, t)["log_prob_xs"]
+
+    assert abs(res["total_loss"] - loss(p)) < 1e-9
+    eps = 1e-6
+    for (half, i, key) in [(0, 0, "gamma"), (1, 1, "beta"), (1, 0, "gamma"), (0, 1, "beta")]:
+        for c in range(2):
+            pp = copy.deepcopy(p)
+            pp["bn"][half][i][key][c] += eps
+            lp = loss(pp)
+            pp["bn"][half][i][key][c] -= 2 * eps
+            lm = loss(pp)
+            assert abs((lp - lm) / (2 * eps) - res["grads"]["bn"][half][i][key][c]) < 1e-6
+    for (kind, half, i, j) in [("s", 0, 0, 0), ("t", 1, 1, 2)]:       # MLP weights upstream of a bijector
+        w = p[kind][half][i][j][0]
+        for idx in [(0, 1), (1, 0)]:
+            pp = copy.deepcopy(p)
+            pp[kind][half][i][j][0][idx] += eps
+            lp = loss(pp)
+            pp[kind][half][i][j][0][idx] -= 2 * eps
+            lm = loss(pp)
+            assert abs((lp - lm) / (2 * eps) - res["grads"][kind][half][i][j][0][idx]) < 1e-6

@@ -450,3 +450,62 @@ def test_pred_adj_decoder_after_sampling(community_medium):
     # thresholded adjacency is symmetric (what train_grevnet_with_data.py:532-540 turns into graphs)
     adj = (blocks[2] > 0.5)
     assert bool((adj == adj.T).all())
+
+
+# ---- batch-norm bijector (TFP-0.7 semantics restated, unpinned) ---------------------------
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "layered"])
+def test_batch_norm_flow_matches_golden(fused):
+    from helpers import BN_GOLDEN_CASES
+    g = load_golden(BN_GOLDEN_CASES[0])
+    hp = {k: g[k] for k in ("D", "latent", "K", "T", "agg", "combine", "epsilon", "activation", "weight_sharing")}
+    net = make_product_grevnet(hp, g["params"])
+    assert net.use_batch_norm
+    net.fused = fused
+    graph = graph_from_arrays(g["n_node"], g["n_edge"], g["senders"], g["receivers"], g["x"], DEV)
+    out = _run_forward(net, graph)
+    n = g["x"].shape[0]
+    np.testing.assert_allclose(out["z_graph"].nodes.cpu().numpy(), g["z"], atol=3e-4, rtol=3e-4)
+    assert abs(float(out["log_det_jacobian"]) - float(g["logdet"])) <= 1e-4 * n
+    assert abs(float(out["log_prob_xs_per_node"]) - float(g["log_prob_xs_per_node"])) <= 1e-4
+    # the batch moments every bijector saw come back for the moving-average update
+    for half in range(2):
+        for i in range(g["T"]):
+            bn = net.bns[half][i]
+            np.testing.assert_allclose(bn.batch_mean.cpu().numpy(), g[f"bn_{half}_{i}_batch_mean"], atol=2e-5)
+            np.testing.assert_allclose(bn.batch_variance.cpu().numpy(), g[f"bn_{half}_{i}_batch_variance"],
+                                       rtol=2e-5, atol=2e-5)
+    # sampling direction: de-normalisation with the MOVING statistics
+    x_back = net(out["z_graph"], inverse=False).nodes.cpu().numpy()
+    np.testing.assert_allclose(x_back, g["x_roundtrip"], atol=1e-3, rtol=1e-3)
+    # input untouched
+    np.testing.assert_array_equal(graph.nodes.cpu().numpy(), g["x"])
+
+
+def test_batch_norm_round_trip_after_moving_average_converges(community_medium):
+    """With the moving statistics set to the batch moments g(f(x)) = x; update_moving_statistics moves them
+    there geometrically (momentum 0.99), as UPDATE_OPS does during training."""
+    hp = dict(HP_DEFAULT, D=8, latent=32, K=3, T=2)
+    nn, ne, s, r = _batch(community_medium, [3, 50, 77, 12])
+    n = int(nn.sum())
+    rng = np.random.default_rng(9)
+    x = (rng.standard_normal((n, 8)) * 3 + 2).astype(np.float32)
+    p = O.make_grevnet_params(21, 4, 32, 3, 2, final_scale=0.4)
+    p["bn"] = O.make_bn_params(22, 4, 2)
+    net = make_product_grevnet(hp, p)
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    zg, _ = net(graph, inverse=True)
+    bn = net.bns[0][0]
+    mm0 = bn.moving_mean.clone()
+    bn.update_moving_statistics()
+    torch.testing.assert_close(bn.moving_mean, mm0 * 0.99 + bn.batch_mean * 0.01)
+    for half in net.bns:
+        for b in half:
+            b.moving_mean.copy_(b.batch_mean)
+            b.moving_variance.copy_(b.batch_variance)
+    back = net(zg, inverse=False).nodes.cpu().numpy()
+    np.testing.assert_allclose(back, x, atol=2e-4, rtol=2e-4)
+    # isolated statistics: a single-node-feature column that is constant has variance 0 -> epsilon keeps it finite
+    xc = x.copy()
+    xc[:, 0] = 1.0
+    out = _run_forward(net, graph_from_arrays(nn, ne, s, r, xc, DEV))
+    assert np.isfinite(float(out["log_prob_xs_per_node"]))

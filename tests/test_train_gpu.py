@@ -212,3 +212,55 @@ def test_attention_backward_is_refused(grid_small):
     graph = graph_from_arrays(g["n_node"], g["n_edge"], g["senders"], g["receivers"], g["x"], DEV)
     with pytest.raises(_abi.GnfError):
         GRevNetTrainer(net).loss_and_grads(graph)
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "gemm"])
+def test_gradients_with_batch_norm_vs_oracle(grid_small, fused):
+    """use_batch_norm=True (the drivers' default, run_grevnet.py:90): gradients of the MLP weights AND of every
+    bijector's gamma / beta; the reversible walk also undoes the normalisation (reconstruction = x)."""
+    from gnf_amd.train import GRevNetTrainer
+    hp = dict(D=8, latent=32, K=3, T=2, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu",
+              weight_sharing=False)
+    nn, ne, s, r = _batch(grid_small, list(range(12)))
+    n = int(nn.sum())
+    rng = np.random.default_rng(31)
+    x = (rng.standard_normal((n, 8)) * 1.5 + 0.5).astype(np.float32)
+    p = O.make_grevnet_params(8, 4, 32, 3, 2, final_scale=0.3)
+    p["bn"] = O.make_bn_params(9, 4, 2)
+    ref = O.loss_and_grads(s, r, n, x, p, 2)
+    net = make_product_grevnet(hp, p)
+    net.fused = fused
+    tr = GRevNetTrainer(net)
+    out = tr.loss_and_grads(graph_from_arrays(nn, ne, s, r, x, DEV))
+    torch.cuda.synchronize()
+    assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
+    np.testing.assert_allclose(out["reconstruction"].cpu().numpy(), x, atol=3e-4, rtol=3e-4)
+    got = tr.named_gradients()
+    _check_grads(got, ref["grads"], False)
+    for half in range(2):
+        for i in range(2):
+            for key in ("gamma", "beta"):
+                a, b = got["bn"][half][i][key], ref["grads"]["bn"][half][i][key]
+                assert np.abs(a - b).max() <= 3e-4 * np.abs(b).max() + 1e-4, (half, i, key, a, b)
+
+
+def test_training_with_batch_norm_updates_moving_statistics(grid_small):
+    from gnf_amd.train import GRevNetTrainer
+    hp = dict(D=8, latent=32, K=3, T=2, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu",
+              weight_sharing=False)
+    nn, ne, s, r = _batch(grid_small, list(range(12)))
+    n = int(nn.sum())
+    x = (np.random.default_rng(0).standard_normal((n, 8)) * 2 + 1).astype(np.float32)
+    p = O.make_grevnet_params(4, 4, 32, 3, 2, final_scale=0.3)
+    p["bn"] = O.make_bn_params(5, 4, 2)
+    net = make_product_grevnet(hp, p)
+    tr = GRevNetTrainer(net, lr=3e-3, use_lr_decay=False)
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    mm0 = p["bn"][0][0]["moving_mean"].copy()
+    losses = [float(tr.step(graph)["loss_per_node"]) for _ in range(25)]
+    assert losses[-1] < losses[0] - 0.05, losses
+    bn = net.bns[0][0]
+    assert float(bn.gamma.min()) > 0.0                                       # the constraint projection
+    # first bijector sees the raw data every step: its batch mean is the data mean, the moving mean crept towards it
+    want = mm0 * 0.99 ** 25 + x[:, :4].mean(axis=0) * (1 - 0.99 ** 25)
+    np.testing.assert_allclose(bn.moving_mean.cpu().numpy(), want, atol=1e-4)
