@@ -56,6 +56,13 @@ WORKLOADS = {
     # one training iteration of run_grevnet.py:440-447 per step: forward + reversible backward + Adam + re-pack
     "config2_train": dict(desc="community_medium, TRAINING step (fwd + reversible backward + Adam)",
                           dataset="graph_rnn_community_medium", graphs=64, hp={}, inverse=False, fc=False, train=True),
+    # the drivers' DEFAULT flags together: dm_self_attn GNN + use_batch_norm=True, one training iteration per step
+    "default_flags_train": dict(desc="community_medium, TRAINING step with the drivers' default GNN (dm_self_attn) and use_batch_norm=True",
+                                dataset="graph_rnn_community_medium", graphs=64,
+                                hp=dict(activation="relu", use_batch_norm=True,
+                                        attn=dict(num_heads=8, kq_dim=10, v_dim=10, out_dim=80, concat=True,
+                                                  kq_dim_division=False, residual=False)),
+                                inverse=False, fc=False, train=True),
 }
 WORKLOAD = WORKLOADS["config2"]
 WEIGHT_SEED = 99
@@ -120,7 +127,12 @@ def make_params(seed, hp, final_scale):
     def net():
         return {"attn": attn_weights(), "mlp": mlp()} if att else mlp()
 
-    return {"s": [[net() for _ in range(t)] for _ in range(2)], "t": [[net() for _ in range(t)] for _ in range(2)]}
+    out = {"s": [[net() for _ in range(t)] for _ in range(2)], "t": [[net() for _ in range(t)] for _ in range(2)]}
+    if hp.get("use_batch_norm"):   # the reference's initial values (tf.layers.BatchNormalization defaults)
+        out["bn"] = [[{"gamma": np.ones(h, np.float32), "beta": np.zeros(h, np.float32),
+                       "moving_mean": np.zeros(h, np.float32), "moving_variance": np.ones(h, np.float32)}
+                      for _ in range(t)] for _ in range(2)]
+    return out
 
 
 def make_batch(n_gpus, rank, seed=12345):

@@ -96,8 +96,14 @@ int64_t packed_floats(const GnfMlp* mlp);
 bool fused_bwd_supported(const GnfMlp* s, const GnfMlp* t);
 int launch_half_bwd_fused(const int32_t* rowptr, const int32_t* col, int64_t n, const GnfGnnSpec& gnn,
                           const GnfMlp* s, const GnfMlp* t, const float* x_cond, float* y_upd, int64_t ld,
-                          float* g_upd, int64_t ldg, int32_t H, float* h0_out, float* const* hin, int64_t ldh,
-                          float* const* dP, int64_t lddp, float* const* gst, float* const* dh0, hipStream_t st);
+                          float* g_upd, int64_t ldg, int32_t H, float* h0_out, const float* const* h0_in, float* const* hin,
+                          int64_t ldh, float* const* dP, int64_t lddp, float* const* gst, float* const* dh0,
+                          hipStream_t st);
+// attention front-end, backwards (gnf_attn_bwd.hip)
+int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t in0, const int32_t* rowptr,
+                         const int32_t* col, const int32_t* rowptr_t, const int32_t* col_t, const float* const* qkv,
+                         const float* const* dh0, const float* const* gst, float* const* dqkv, float* const* agg,
+                         float* const* dagg, float* const* stats, float* g_cond, int64_t ldg, hipStream_t st);
 
 // batch-norm bijector (gnf_bn.hip)
 int validate_bn(const GnfBatchNorm* bn, int direction, const char* what, int q);

@@ -33,12 +33,14 @@ struct BwdArgs {
     float* y_upd;
     float* g_upd;
     float* h0_out;
+    const float* h0_in[2];  // attention GNNs: the layer-0 input of each net comes from the attention front-end
     float* gst[2];
     const float* bias[2];
     int32_t tab[kRows][16];
     int64_t ld, ldg;
     int32_t n_nodes, n_tiles, H, in0, K, LS, bias_tot, bias_tot2, mld;
     int32_t mean, concat, act;
+    int32_t residual;  // attention block with residual: s, t = MLP(h0) + x_cond (gnn.py:547-548)
     float eps, alpha;
 };
 
@@ -153,7 +155,16 @@ __global__ __launch_bounds__(kBwdThreads) void k_half_bwd_fused(const BwdArgs a)
     }
     __syncthreads();
     // ---- A: aggregate + combine (same arithmetic and order as the forward kernel) ----------------
-    {
+    if (a.h0_in[0] != nullptr) {
+        const int in0p = a.tab[0][0] * 16;
+        for (int idx = tid; idx < TM * in0p; idx += kBwdThreads) {
+            const int rl = idx / in0p, c = idx - rl * in0p;
+            const int r = row0 + rl;
+            const bool live = r < a.n_nodes && c < a.in0;
+            buf(0, 0)[rl * LS + c] = live ? a.h0_in[0][(int64_t)r * a.in0 + c] : 0.f;
+            buf(1, 0)[rl * LS + c] = live ? a.h0_in[1][(int64_t)r * a.in0 + c] : 0.f;
+        }
+    } else {
         const int seg_beg = s_rowptr[0];
         const int seg_len = s_rowptr[TM] - seg_beg;
         const bool staged = seg_len <= kBwdColCap;
@@ -269,7 +280,12 @@ __global__ __launch_bounds__(kBwdThreads) void k_half_bwd_fused(const BwdArgs a)
             const int r = row0 + rl;
             float gs = 0.f, gt = 0.f;
             if (r < a.n_nodes && f < H) {
-                const float sv = s_lds[rl * LS + f], tv = t_lds[rl * LS + f];
+                float sv = s_lds[rl * LS + f], tv = t_lds[rl * LS + f];
+                if (a.residual) {
+                    const float xr = a.x_cond[(int64_t)r * a.ld + f];
+                    sv += xr;
+                    tv += xr;
+                }
                 float* py = a.y_upd + (int64_t)r * a.ld + f;
                 float* pg = a.g_upd + (int64_t)r * a.ldg + f;
                 const float yv = *py, gv = *pg;
@@ -313,7 +329,7 @@ static size_t bwd_lds_bytes(const GnfMlp* m) {
 }
 
 bool fused_bwd_supported(const GnfMlp* s, const GnfMlp* t) {
-    if (!s->packed || !t->packed || s->attn || t->attn) return false;
+    if (!s->packed || !t->packed) return false;
     if (s->num_layers != t->num_layers) return false;
     for (int j = 0; j <= s->num_layers; ++j)
         if (s->dims[j] != t->dims[j]) return false;
@@ -324,8 +340,9 @@ bool fused_bwd_supported(const GnfMlp* s, const GnfMlp* t) {
 // shared), dP[.][j] = dL/d(pre-activation of layer j) for j <= K-2; dh0: [net] = dL/dh0.
 int launch_half_bwd_fused(const int32_t* rowptr, const int32_t* col, int64_t n, const GnfGnnSpec& gnn,
                           const GnfMlp* s, const GnfMlp* t, const float* x_cond, float* y_upd, int64_t ld,
-                          float* g_upd, int64_t ldg, int32_t H, float* h0_out, float* const* hin, int64_t ldh,
-                          float* const* dP, int64_t lddp, float* const* gst, float* const* dh0, hipStream_t st) {
+                          float* g_upd, int64_t ldg, int32_t H, float* h0_out, const float* const* h0_in, float* const* hin,
+                          int64_t ldh, float* const* dP, int64_t lddp, float* const* gst, float* const* dh0,
+                          hipStream_t st) {
     if (n == 0) return GNF_OK;
     const int K = s->num_layers;
     BwdArgs a;
@@ -336,6 +353,9 @@ int launch_half_bwd_fused(const int32_t* rowptr, const int32_t* col, int64_t n, 
     a.y_upd = y_upd;
     a.g_upd = g_upd;
     a.h0_out = h0_out;
+    a.h0_in[0] = h0_in ? h0_in[0] : nullptr;
+    a.h0_in[1] = h0_in ? h0_in[1] : nullptr;
+    a.residual = (s->attn && s->attn->residual) ? 1 : 0;
     a.gst[0] = gst[0];
     a.gst[1] = gst[1];
     a.ld = ld;

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(kGemmThreads) void k_gemm(GemmJob j0, GemmJob j1, G
 
 // Grouped split-K launch: up to kMaxGroup GEMMs of different M x N (the dW of every layer of both nets of
 // a half-step) over the same K = node axis, in one grid.  blockIdx.z = job * chunks + chunk.
-static constexpr int kMaxGroup = 2 * GNF_MAX_LAYERS;
+static constexpr int kMaxGroup = 2 * (GNF_MAX_LAYERS + 4);  // per net: K layers (+ Wq, Wk, Wv, Wo of an attention block)
 struct GroupedGemm {
     GemmJob job[kMaxGroup];
     int64_t lda[kMaxGroup], ldb[kMaxGroup];
@@ -311,12 +311,17 @@ __global__ __launch_bounds__(256) void k_copy_rows(const float* __restrict__ src
 __global__ __launch_bounds__(256) void k_coupling_bwd(const float* __restrict__ s, const float* __restrict__ t,
                                                       float* __restrict__ y, int64_t ldy, float* __restrict__ g,
                                                       int64_t ldg, float* __restrict__ gs, float* __restrict__ gt,
-                                                      int64_t n, int H) {
+                                                      int64_t n, int H, const float* __restrict__ xres, int64_t ldx) {
     const int64_t total = n * H;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / H;
         const int f = (int)(i - r * H);
-        const float sv = s[i], tv = t[i];
+        float sv = s[i], tv = t[i];
+        if (xres) {  // residual attention block: s, t = MLP(h0) + x_cond (gnn.py:547-548)
+            const float xr = xres[r * ldx + f];
+            sv += xr;
+            tv += xr;
+        }
         const float yv = y[r * ldy + f], gv = g[r * ldg + f];
         const float d = yv - tv;
         y[r * ldy + f] = d * expf(-sv);   // the half-step's input, gnn.py:359,372
@@ -504,10 +509,15 @@ static int launch_bn_backward(const GnfBatchNorm* bn, const GnfBatchNorm* gbn, f
 struct BwdPlan {
     int K, in0, lmax, H, chunks;
     int64_t n, kchunk;
-    int64_t wsum, osum;  // sum_j I_j * O_j, sum_j O_j of one net
-    size_t g, invdeg, bnpart, h0, acts, st, gst, dpb, dh0, wslab, bslab, total;  // float offsets
-    size_t set_stride;  // the dW operands (h0, acts, gst, dpb) exist twice: half-step k's dW GEMM may run on the
-                        // auxiliary stream while half-step k-1's fused kernel already refills the other set
+    int64_t wsum, osum;  // floats of dW / db slabs per chunk, both nets, attention weights included
+    // attention geometry (0 when the nets are message-passing GNNs)
+    int nh, kq, vd, C, P, NV;
+    // float offsets.  single: g, invdeg, bnpart, st, wslab, bslab, qkv, dagg, stats;  per set: the rest
+    size_t g, invdeg, bnpart, st, wslab, bslab, qkv, dagg, stats;
+    size_t h0, h0b, acts, gst, dpb, dh0, xc, dqkv, agg;
+    size_t set_stride;  // the dW operands exist twice: half-step k's dW GEMMs may run on the auxiliary stream while
+                        // half-step k-1's kernels already refill the other set
+    size_t total;
 };
 
 static inline size_t al64(size_t v) { return (v + 63) / 64 * 64; }  // keep every region 256-byte aligned
@@ -520,14 +530,24 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net) {
     p.K = net->num_layers;
     p.in0 = net->dims[0];
     int lmax = 1;
+    int64_t wsum = 0, osum = 0;
     for (int j = 0; j < p.K; ++j) {
         if (j >= 1) lmax = lmax > net->dims[j] ? lmax : net->dims[j];
-        p.wsum += (int64_t)net->dims[j] * net->dims[j + 1];
-        p.osum += net->dims[j + 1];
+        wsum += (int64_t)net->dims[j] * net->dims[j + 1];
+        osum += net->dims[j + 1];
     }
+    if (net->attn) {
+        const GnfAttn* at = net->attn;
+        p.nh = at->num_heads, p.kq = at->kq_dim, p.vd = at->v_dim, p.C = at->out_dim;
+        p.P = 2 * p.nh * p.kq + p.vd;
+        p.NV = p.nh * p.vd;
+        wsum += (int64_t)p.H * p.P + (int64_t)p.NV * p.C;
+    }
+    p.wsum = 2 * wsum;
+    p.osum = 2 * osum;
     p.lmax = lmax;
-    // split of the node axis for dW: every layer of both nets goes out in ONE grouped launch, so a few
-    // chunks already fill the chip; fewer chunks = fewer slabs to write and reduce
+    // split of the node axis for dW: every weight gradient of the half-step goes out in ONE grouped launch, so a
+    // few chunks already fill the chip; fewer chunks = fewer slabs to write and reduce
     int64_t chunks = (n + 255) / 256;
     if (chunks > 32) chunks = 32;
     if (chunks < 1) chunks = 1;
@@ -543,14 +563,21 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net) {
     p.invdeg = off, off += al64((size_t)n);
     p.bnpart = off, off += al64((size_t)kBnBlocksMax * (size_t)p.H * 4);  // fp64 pairs of the batch-norm backward
     p.st = off, off += 2 * al64((size_t)n * p.H);
-    p.dh0 = off, off += 2 * al64((size_t)n * p.in0);
-    p.wslab = off, off += 2 * al64((size_t)chunks * p.wsum);
-    p.bslab = off, off += 2 * al64((size_t)chunks * p.osum);
+    p.wslab = off, off += al64((size_t)chunks * p.wsum);
+    p.bslab = off, off += al64((size_t)chunks * p.osum);
+    p.qkv = off, off += 2 * al64((size_t)n * p.P);
+    p.dagg = off, off += 2 * al64((size_t)n * p.NV);
+    p.stats = off, off += 2 * al64((size_t)n * 3 * p.nh);
     const size_t set0 = off;
     p.h0 = off, off += al64((size_t)n * p.in0);
+    p.h0b = off, off += net->attn ? al64((size_t)n * p.in0) : 0;  // attention: one layer-0 input per net
     p.acts = off, off += 2 * nk1 * al64((size_t)n * lmax);   // [net][j = 1..K-1]: input of layer j
     p.gst = off, off += 2 * al64((size_t)n * p.H);           // dP of the last layer (g_s, g_t)
     p.dpb = off, off += 2 * nk1 * al64((size_t)n * lmax);    // [net][j = 0..K-2]: dP_j = dL/d(pre-activation of layer j)
+    p.dh0 = off, off += 2 * al64((size_t)n * p.in0);
+    p.xc = off, off += net->attn ? al64((size_t)n * p.H) : 0;  // the conditioning half as the attention dW GEMMs read it
+    p.dqkv = off, off += 2 * al64((size_t)n * p.P);
+    p.agg = off, off += 2 * al64((size_t)n * p.NV);
     p.set_stride = off - set0;
     off += p.set_stride;                                      // second set
     p.total = off;
@@ -561,59 +588,135 @@ static const GnfMlp* pick_net(const GnfFlow* f, const GnfMlp* nets, int half, in
     return f->weight_sharing ? &nets[half] : &nets[half * f->num_timesteps + i];
 }
 
-// dW_j = h_j^T dP_j and db_j = colsum(dP_j) for every layer of both nets: one grouped split-K GEMM launch
-// into per-chunk slabs + one fixed-order reduce launch into the gradient buffers.
-static int launch_weight_grads(const BwdPlan& p, const GnfMlp* const* nets, const GnfMlp* const* grads,
-                               bool accumulate, const float* const* hin /*[net*K + j]*/,
-                               const int64_t* ldh, const float* const* dP /*[net*K + j]*/, const int64_t* lddp,
-                               float* ws, hipStream_t st) {
+// Buffers of one half-step, resolved for one operand set.
+struct BwdOperands {
+    float* hin[2 * GNF_MAX_LAYERS];   // [net * K + j]: input of layer j
+    float* dPs[2 * GNF_MAX_LAYERS];   // [net * K + j]: dL/d(pre-activation of layer j)
+    int64_t ldh[2 * GNF_MAX_LAYERS], lddp[2 * GNF_MAX_LAYERS];
+    float* gst[2];
+    float* dh0[2];
+    float* h0[2];                     // message passing: both point at the shared h0
+    float* stb[2];                    // s, t of the recompute (generic path)
+    float* xc;
+    float* dqkv[2];
+    float* agg[2];
+    float* qkv[2];
+    float* dagg[2];
+    float* stats[2];
+};
+
+static BwdOperands bwd_operands(const BwdPlan& p, float* ws, int set, bool attn) {
+    BwdOperands o;
+    memset(&o, 0, sizeof(o));
+    const int64_t n = p.n;
     const int K = p.K;
+    float* wss = ws + (size_t)set * p.set_stride;
+    const size_t act_sz = al64((size_t)n * p.lmax);
+    o.h0[0] = wss + p.h0;
+    o.h0[1] = attn ? wss + p.h0b : o.h0[0];
+    o.gst[0] = wss + p.gst;
+    o.gst[1] = wss + p.gst + al64((size_t)n * p.H);
+    o.dh0[0] = wss + p.dh0;
+    o.dh0[1] = wss + p.dh0 + al64((size_t)n * p.in0);
+    o.stb[0] = ws + p.st;
+    o.stb[1] = ws + p.st + al64((size_t)n * p.H);
+    o.xc = wss + p.xc;
+    for (int q = 0; q < 2; ++q) {
+        o.dqkv[q] = wss + p.dqkv + q * al64((size_t)n * p.P);
+        o.agg[q] = wss + p.agg + q * al64((size_t)n * p.NV);
+        o.qkv[q] = ws + p.qkv + (size_t)q * n * p.P;   // launch_attn_front's layout: net q at scratch + q * n * P
+        o.dagg[q] = ws + p.dagg + q * al64((size_t)n * p.NV);
+        o.stats[q] = ws + p.stats + q * al64((size_t)n * 3 * p.nh);
+        for (int j = 0; j < K; ++j) {
+            const int e = q * K + j;
+            o.hin[e] = j == 0 ? o.h0[q] : wss + p.acts + ((size_t)q * (K - 1) + (j - 1)) * act_sz;
+            o.ldh[e] = j == 0 ? p.in0 : p.lmax;
+            o.dPs[e] = j == K - 1 ? o.gst[q] : wss + p.dpb + ((size_t)q * (K - 1) + j) * act_sz;
+            o.lddp[e] = j == K - 1 ? p.H : p.lmax;
+        }
+    }
+    return o;
+}
+
+// Every weight gradient of a half-step: dW = A^T B over the node axis (A, B row-major [nodes, *]) and, where
+// gb != NULL, db = colsum(B).  One grouped split-K GEMM launch into per-chunk slabs + one fixed-order reduce
+// launch into the gradient buffers.
+struct WGJob {
+    const float* A;
+    int64_t lda;
+    const float* B;
+    int64_t ldb;
+    int32_t M, N;
+    float* gw;
+    float* gb;
+};
+
+static int launch_weight_grads(const BwdPlan& p, const WGJob* jobs, int nj, bool accumulate, float* ws,
+                               hipStream_t st) {
     GroupedGemm gg;
     GroupedReduce gr;
     memset(&gg, 0, sizeof(gg));
     memset(&gr, 0, sizeof(gr));
     int maxM = 1, maxN = 1;
     int64_t maxred = 1;
-    for (int q = 0; q < 2; ++q) {
-        float* wsl = ws + p.wslab + q * al64((size_t)p.chunks * p.wsum);
-        float* bsl = ws + p.bslab + q * al64((size_t)p.chunks * p.osum);
-        int64_t woff = 0, boff = 0;
-        for (int j = 0; j < K; ++j) {
-            const int I = nets[q]->dims[j], O = nets[q]->dims[j + 1];
-            const int e = q * K + j;
-            gg.job[e] = GemmJob{hin[e], dP[e], wsl + p.chunks * woff, nullptr, bsl + p.chunks * boff};
-            gg.lda[e] = ldh[e];
-            gg.ldb[e] = lddp[e];
-            gg.M[e] = I;
-            gg.N[e] = O;
-            gr.job[e] = ReduceJob{wsl + p.chunks * woff, bsl + p.chunks * boff, const_cast<float*>(grads[q]->W[j]),
-                                  const_cast<float*>(grads[q]->b[j])};
-            gr.nw[e] = (int64_t)I * O;
-            gr.nb[e] = O;
-            maxM = maxM > I ? maxM : I;
-            maxN = maxN > O ? maxN : O;
-            maxred = maxred > (int64_t)I * O + O ? maxred : (int64_t)I * O + O;
-            woff += (int64_t)I * O;
-            boff += O;
-        }
+    int64_t woff = 0, boff = 0;
+    for (int e = 0; e < nj; ++e) {
+        const WGJob& j = jobs[e];
+        float* wsl = ws + p.wslab + (size_t)p.chunks * woff;
+        float* bsl = j.gb ? ws + p.bslab + (size_t)p.chunks * boff : nullptr;
+        gg.job[e] = GemmJob{j.A, j.B, wsl, nullptr, bsl};
+        gg.lda[e] = j.lda;
+        gg.ldb[e] = j.ldb;
+        gg.M[e] = j.M;
+        gg.N[e] = j.N;
+        gr.job[e] = ReduceJob{wsl, bsl, j.gw, j.gb};
+        gr.nw[e] = (int64_t)j.M * j.N;
+        gr.nb[e] = j.gb ? j.N : 0;
+        maxM = maxM > j.M ? maxM : j.M;
+        maxN = maxN > j.N ? maxN : j.N;
+        const int64_t red = (int64_t)j.M * j.N + (j.gb ? j.N : 0);
+        maxred = maxred > red ? maxred : red;
+        woff += (int64_t)j.M * j.N;
+        if (j.gb) boff += j.N;
     }
     gg.K = p.n;
     gg.kchunk = p.kchunk;
     gg.chunks = p.chunks;
     gr.chunks = p.chunks;
     gr.accumulate = accumulate ? 1 : 0;
-    dim3 grid((unsigned)((maxN + TGN - 1) / TGN), (unsigned)((maxM + TGM - 1) / TGM), (unsigned)(2 * K * p.chunks));
+    dim3 grid((unsigned)((maxN + TGN - 1) / TGN), (unsigned)((maxM + TGM - 1) / TGM), (unsigned)(nj * p.chunks));
     hipLaunchKernelGGL(k_gemm_dw_grouped, grid, dim3(kGemmThreads), 0, st, gg);
     GNF_LAUNCH_CHECK("k_gemm_dw_grouped");
-    hipLaunchKernelGGL(k_reduce_grouped, dim3((unsigned)((maxred + 255) / 256), (unsigned)(2 * K)), dim3(256), 0, st, gr);
+    hipLaunchKernelGGL(k_reduce_grouped, dim3((unsigned)((maxred + 255) / 256), (unsigned)nj), dim3(256), 0, st, gr);
     GNF_LAUNCH_CHECK("k_reduce_grouped");
     return GNF_OK;
 }
 
-static int launch_aggregate_bwd(const BwdPlan& p, const GnfCsr* csr, const GnfCsr* csr_t, const GnfGnnSpec& gnn,
-                                const float* invdeg, const float* dh0s, const float* dh0t, float* g_cond, int64_t ldg,
-                                hipStream_t st) {
-    (void)csr;
+// job list of one half-step: the K layers of both nets, then the four attention matrices of both nets
+static int weight_grad_jobs(const BwdPlan& p, const BwdOperands& o, const GnfMlp* const* nets,
+                            const GnfMlp* const* grads, WGJob* jobs) {
+    const int K = p.K;
+    int nj = 0;
+    for (int q = 0; q < 2; ++q)
+        for (int j = 0; j < K; ++j) {
+            const int e = q * K + j;
+            jobs[nj++] = WGJob{o.hin[e], o.ldh[e], o.dPs[e], o.lddp[e], nets[q]->dims[j], nets[q]->dims[j + 1],
+                               const_cast<float*>(grads[q]->W[j]), const_cast<float*>(grads[q]->b[j])};
+        }
+    if (nets[0]->attn)
+        for (int q = 0; q < 2; ++q) {
+            const GnfAttn* ga = grads[q]->attn;
+            const int nq = p.nh * p.kq, off = nets[q]->attn->concat ? p.H : 0;
+            jobs[nj++] = WGJob{o.xc, p.H, o.dqkv[q], p.P, p.H, nq, const_cast<float*>(ga->Wq), nullptr};
+            jobs[nj++] = WGJob{o.xc, p.H, o.dqkv[q] + nq, p.P, p.H, nq, const_cast<float*>(ga->Wk), nullptr};
+            jobs[nj++] = WGJob{o.xc, p.H, o.dqkv[q] + 2 * nq, p.P, p.H, p.vd, const_cast<float*>(ga->Wv), nullptr};
+            jobs[nj++] = WGJob{o.agg[q], p.NV, o.dh0[q] + off, p.in0, p.NV, p.C, const_cast<float*>(ga->Wo), nullptr};
+        }
+    return nj;
+}
+
+static int launch_aggregate_bwd(const BwdPlan& p, const GnfCsr* csr_t, const GnfGnnSpec& gnn, const float* invdeg,
+                                const float* dh0s, const float* dh0t, float* g_cond, int64_t ldg, hipStream_t st) {
     const int H = p.H;
     const bool vec4 = (H % 4 == 0) && (p.in0 % 4 == 0) && (ldg % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(dh0s) | reinterpret_cast<uintptr_t>(dh0t) |
@@ -634,123 +737,56 @@ static int launch_aggregate_bwd(const BwdPlan& p, const GnfCsr* csr, const GnfCs
     return GNF_OK;
 }
 
-// Generic (any layer width) backward of one half-step out of GEMM building blocks.
-static int backward_half(const BwdPlan& p, const GnfCsr* csr, const GnfCsr* csr_t, const GnfGnnSpec& gnn,
-                         const GnfMlp* const* nets, const GnfMlp* const* grads, bool accumulate, float* x_cond,
-                         float* y_upd, int64_t ld, float* g_cond, float* g_upd, int64_t ldg, float* ws,
-                         hipStream_t st) {
+// Generic (any layer width) recompute + coupling + dP chain of one half-step out of GEMM building blocks:
+// o.h0[q] holds the layer-0 inputs on entry; on exit o.hin / o.dPs / o.gst / o.dh0 are filled, y and g updated.
+static int mlp_backward_generic(const BwdPlan& p, const BwdOperands& o, const GnfGnnSpec& gnn, const GnfMlp* const* nets,
+                                const float* x_cond, float* y_upd, int64_t ld, float* g_upd, int64_t ldg,
+                                hipStream_t st) {
     const int64_t n = p.n;
-    const int K = p.K, H = p.H, in0 = p.in0;
-    const int64_t lmax = p.lmax;
-    float* h0 = ws + p.h0;
-    const size_t act_sz = al64((size_t)n * lmax);
-    auto act = [&](int net, int j) -> float* {  // output of layer j-1 = input of layer j (j >= 1)
-        return ws + p.acts + ((size_t)net * (K - 1) + (j - 1)) * act_sz;
-    };
-    auto dpb = [&](int net, int j) -> float* {  // dP_j, j <= K-2
-        return ws + p.dpb + ((size_t)net * (K - 1) + j) * act_sz;
-    };
-    float* stb[2] = {ws + p.st, ws + p.st + al64((size_t)n * H)};
-    float* gst[2] = {ws + p.gst, ws + p.gst + al64((size_t)n * H)};
-    float* dh0[2] = {ws + p.dh0, ws + p.dh0 + al64((size_t)n * in0)};
-    int rc = launch_aggregate(csr->rowptr, csr->col, n, x_cond, ld, H, gnn.agg == GNF_AGG_MEAN,
-                              gnn.combine == GNF_COMBINE_CONCAT ? 1 : 0, gnn.epsilon, h0, in0, st);
-    if (rc) return rc;
-    // ---- recompute the two MLPs, keeping every layer output ------------------------------------
-    for (int j = 0; j < K; ++j) {
+    const int K = p.K, H = p.H;
+    int rc;
+    for (int j = 0; j < K; ++j) {  // recompute the two MLPs, keeping every layer output
         const int I = nets[0]->dims[j], O = nets[0]->dims[j + 1];
         const bool last = j == K - 1;
         GemmJob jobs[2];
         for (int q = 0; q < 2; ++q)
-            jobs[q] = GemmJob{j == 0 ? h0 : act(q, j), nets[q]->W[j], last ? stb[q] : act(q, j + 1), nets[q]->b[j], nullptr};
+            jobs[q] = GemmJob{o.hin[q * K + j], nets[q]->W[j], last ? o.stb[q] : o.hin[q * K + j + 1], nets[q]->b[j], nullptr};
         GemmShape sh;
         memset(&sh, 0, sizeof(sh));
-        sh.lda = j == 0 ? in0 : lmax;
+        sh.lda = o.ldh[j];
         sh.ldb = O;
-        sh.ldc = last ? H : lmax;
+        sh.ldc = last ? H : p.lmax;
         sh.M = n, sh.K = I, sh.N = O, sh.chunks = 1, sh.kchunk = TGK;
         sh.act = gnn.activation, sh.alpha = gnn.alpha, sh.apply_act = last ? 0 : 1;
         rc = launch_gemm<OPND_KC, OPND_MC, EPI_BIAS_ACT>(jobs, 2, sh, st);
         if (rc) return rc;
     }
-    // ---- coupling ------------------------------------------------------------------------------
     {
+        const bool res = nets[0]->attn && nets[0]->attn->residual;
         int64_t blocks = (n * H + 255) / 256;
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(k_coupling_bwd, dim3((unsigned)blocks), dim3(256), 0, st, stb[0], stb[1], y_upd, ld,
-                           g_upd, ldg, gst[0], gst[1], n, H);
+        hipLaunchKernelGGL(k_coupling_bwd, dim3((unsigned)blocks), dim3(256), 0, st, o.stb[0], o.stb[1], y_upd, ld,
+                           g_upd, ldg, o.gst[0], o.gst[1], n, H, res ? x_cond : nullptr, ld);
         GNF_LAUNCH_CHECK("k_coupling_bwd");
     }
-    // ---- dP chain, last layer to first:  dP_{j-1} = (dP_j W_j^T) * act'(h_j)   [nodes, O] x [O, I] -----
-    const float* hin[kMaxGroup];
-    const float* dPs[kMaxGroup];
-    int64_t ldh[kMaxGroup], lddp[kMaxGroup];
-    for (int q = 0; q < 2; ++q)
-        for (int j = 0; j < K; ++j) {
-            hin[q * K + j] = j == 0 ? h0 : act(q, j);
-            ldh[q * K + j] = j == 0 ? in0 : lmax;
-            dPs[q * K + j] = j == K - 1 ? gst[q] : dpb(q, j);
-            lddp[q * K + j] = j == K - 1 ? H : lmax;
-        }
-    for (int j = K - 1; j >= 0; --j) {
+    for (int j = K - 1; j >= 0; --j) {  // dP_{j-1} = (dP_j W_j^T) * act'(h_j)   [nodes, O] x [O, I]
         const int I = nets[0]->dims[j], O = nets[0]->dims[j + 1];
         GemmJob jobs[2];
         for (int q = 0; q < 2; ++q)
-            jobs[q] = GemmJob{dPs[q * K + j], nets[q]->W[j], j == 0 ? dh0[q] : dpb(q, j - 1),
-                              j == 0 ? nullptr : act(q, j), nullptr};
+            jobs[q] = GemmJob{o.dPs[q * K + j], nets[q]->W[j], j == 0 ? o.dh0[q] : o.dPs[q * K + j - 1],
+                              j == 0 ? nullptr : o.hin[q * K + j], nullptr};
         GemmShape sh;
         memset(&sh, 0, sizeof(sh));
-        sh.lda = lddp[j];
+        sh.lda = o.lddp[j];
         sh.ldb = O;
-        sh.ldc = j == 0 ? in0 : lmax;
-        sh.ldaux = lmax;
+        sh.ldc = j == 0 ? p.in0 : p.lmax;
+        sh.ldaux = p.lmax;
         sh.M = n, sh.K = O, sh.N = I, sh.chunks = 1, sh.kchunk = TGK;
         sh.act = gnn.activation, sh.alpha = gnn.alpha;
         rc = launch_gemm<OPND_KC, OPND_KC, EPI_MASK>(jobs, 2, sh, st);
         if (rc) return rc;
     }
-    rc = launch_weight_grads(p, nets, grads, accumulate, hin, ldh, dPs, lddp, ws, st);
-    if (rc) return rc;
-    return launch_aggregate_bwd(p, csr, csr_t, gnn, ws + p.invdeg, dh0[0], dh0[1], g_cond, ldg, st);
-}
-
-// The same half-step with the LDS-resident fused kernel (gnf_fused_bwd.hip) in place of the 2K + 2K GEMM launches.
-// `set` picks one of the two dW operand sets.  The weight gradients (grouped GEMM + reduce) are off the
-// critical path of the backward walk - the next half-step only needs g - so with an auxiliary stream they
-// overlap the next half-step's fused kernel, which leaves a third of the CUs idle on a 64-graph batch.
-struct BwdOperands {
-    float* hin[kMaxGroup];
-    float* dPs[kMaxGroup];
-    const float* hin_c[kMaxGroup];
-    const float* dPs_c[kMaxGroup];
-    int64_t ldh[kMaxGroup], lddp[kMaxGroup];
-    float* gst[2];
-    float* dh0[2];
-    float* h0;
-};
-
-static BwdOperands bwd_operands(const BwdPlan& p, float* ws, int set) {
-    BwdOperands o;
-    const int64_t n = p.n;
-    const int K = p.K;
-    float* wss = ws + (size_t)set * p.set_stride;
-    const size_t act_sz = al64((size_t)n * p.lmax);
-    o.h0 = wss + p.h0;
-    o.gst[0] = wss + p.gst;
-    o.gst[1] = wss + p.gst + al64((size_t)n * p.H);
-    o.dh0[0] = ws + p.dh0;
-    o.dh0[1] = ws + p.dh0 + al64((size_t)n * p.in0);
-    for (int q = 0; q < 2; ++q)
-        for (int j = 0; j < K; ++j) {
-            const int e = q * K + j;
-            o.hin[e] = j == 0 ? o.h0 : wss + p.acts + ((size_t)q * (K - 1) + (j - 1)) * act_sz;
-            o.ldh[e] = j == 0 ? p.in0 : p.lmax;
-            o.dPs[e] = j == K - 1 ? o.gst[q] : wss + p.dpb + ((size_t)q * (K - 1) + j) * act_sz;
-            o.lddp[e] = j == K - 1 ? p.H : p.lmax;
-            o.hin_c[e] = o.hin[e];
-            o.dPs_c[e] = o.dPs[e];
-        }
-    return o;
+    return GNF_OK;
 }
 
 // ---- multi-tensor re-pack (after an optimiser step every net's MFMA fragment copy is stale) ----------
@@ -903,9 +939,10 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     for (int q = 0; q < n_nets; ++q) {
         const GnfMlp* pairs[2][2] = {{&flow->s_nets[q], &grad->s_nets[q]}, {&flow->t_nets[q], &grad->t_nets[q]}};
         for (auto& pr : pairs) {
-            if (pr[0]->attn) {
-                set_error("gnf_grevnet_backward_f32: attention GNNs have no backward pass yet");
-                return GNF_EUNSUPPORTED;
+            if (pr[0]->attn && (!pr[1]->attn || !pr[1]->attn->Wq || !pr[1]->attn->Wk || !pr[1]->attn->Wv ||
+                                !pr[1]->attn->Wo)) {
+                set_error("gnf_grevnet_backward_f32: grad net %d needs a GnfAttn with Wq / Wk / Wv / Wo gradient buffers", q);
+                return GNF_EINVAL;
             }
             if (pr[1]->num_layers != pr[0]->num_layers ||
                 memcmp(pr[1]->dims, pr[0]->dims, sizeof(int32_t) * (pr[0]->num_layers + 1))) {
@@ -952,6 +989,15 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                     GNF_HIP_TRY(hipMemsetAsync(const_cast<float*>(gm->W[j]), 0, sizeof(float) * gm->dims[j] * gm->dims[j + 1], st));
                     GNF_HIP_TRY(hipMemsetAsync(const_cast<float*>(gm->b[j]), 0, sizeof(float) * gm->dims[j + 1], st));
                 }
+                if (gm->attn) {
+                    const GnfAttn* fa = (kind ? &flow->t_nets[q] : &flow->s_nets[q])->attn;
+                    const size_t nq = (size_t)fa->num_heads * fa->kq_dim;
+                    GNF_HIP_TRY(hipMemsetAsync(const_cast<float*>(gm->attn->Wq), 0, sizeof(float) * H * nq, st));
+                    GNF_HIP_TRY(hipMemsetAsync(const_cast<float*>(gm->attn->Wk), 0, sizeof(float) * H * nq, st));
+                    GNF_HIP_TRY(hipMemsetAsync(const_cast<float*>(gm->attn->Wv), 0, sizeof(float) * H * fa->v_dim, st));
+                    GNF_HIP_TRY(hipMemsetAsync(const_cast<float*>(gm->attn->Wo), 0,
+                                               sizeof(float) * fa->num_heads * fa->v_dim * fa->out_dim, st));
+                }
             }
         if (flow->bns)
             for (int q = 0; q < 2 * T; ++q) {
@@ -994,33 +1040,62 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             used[half] = true;
             const int co = half == 0 ? 0 : H, uo = half == 0 ? H : 0;
             static const bool no_fused = getenv("GNF_BWD_GENERIC") != nullptr;  // developer A/B switch
-            if (!no_fused && fused_bwd_supported(nets[0], nets[1])) {
-                const int set = step & 1;
-                const BwdOperands o = bwd_operands(p, wsf, set);
-                // this set's previous reader (the dW GEMM of two half-steps ago) must be done
-                if (aux && ev_done[set]) GNF_HIP_TRY(hipStreamWaitEvent(st, ev_done[set], 0));
-                rc = launch_half_bwd_fused(csr->rowptr, csr->col, n, flow->gnn, nets[0], nets[1], z + co, z + uo, ld,
-                                           g + uo, D, H, o.h0, o.hin, p.lmax, o.dPs, p.lmax, o.gst, o.dh0, st);
+            const bool attn = nets[0]->attn != nullptr;
+            const bool fused = !no_fused && fused_bwd_supported(nets[0], nets[1]);
+            const int set = step & 1;
+            const BwdOperands o = bwd_operands(p, wsf, set, attn);
+            float* x_cond = z + co;
+            // this set's previous reader (the dW GEMMs of two half-steps ago) must be done
+            if (aux && ev_done[set]) GNF_HIP_TRY(hipStreamWaitEvent(st, ev_done[set], 0));
+            // ---- layer-0 inputs -------------------------------------------------------------------------
+            if (attn) {   // recompute the attention front-end of both nets (q | k | v kept for the way back)
+                const GnfAttn* at[2] = {nets[0]->attn, nets[1]->attn};
+                rc = launch_attn_front(csr->rowptr, csr->col, n, x_cond, ld, H, at, 2, p.in0, o.qkv[0], o.h0, st);
                 if (rc) return rc;
-                // the message-passing backward is on the critical path (the next half-step's coupling reads g):
-                // it goes first; the weight gradients fork off behind it
-                rc = launch_aggregate_bwd(p, csr, csr_t, flow->gnn, wsf + p.invdeg, o.dh0[0], o.dh0[1], g + co, D, st);
+                int64_t blocks = (n * H + 255) / 256;
+                if (blocks > 4096) blocks = 4096;
+                hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)blocks), dim3(256), 0, st, x_cond, ld, o.xc, (int64_t)H, n, H);
+                GNF_LAUNCH_CHECK("k_copy_rows");
+            } else if (!fused) {
+                rc = launch_aggregate(csr->rowptr, csr->col, n, x_cond, ld, H, flow->gnn.agg == GNF_AGG_MEAN,
+                                      flow->gnn.combine == GNF_COMBINE_CONCAT ? 1 : 0, flow->gnn.epsilon, o.h0[0], p.in0, st);
                 if (rc) return rc;
+            }
+            // ---- recompute + coupling + dP chain -------------------------------------------------------------
+            if (fused) {
+                const float* h0c[2] = {o.h0[0], o.h0[1]};
+                rc = launch_half_bwd_fused(csr->rowptr, csr->col, n, flow->gnn, nets[0], nets[1], x_cond, z + uo, ld,
+                                           g + uo, D, H, o.h0[0], attn ? h0c : nullptr, o.hin, p.lmax, o.dPs, p.lmax,
+                                           o.gst, o.dh0, st);
+            } else {
+                rc = mlp_backward_generic(p, o, flow->gnn, nets, x_cond, z + uo, ld, g + uo, D, st);
+            }
+            if (rc) return rc;
+            // ---- dL/dx_cond: on the critical path (the next half-step's coupling reads g), so it goes first -----
+            if (attn) {
+                const GnfAttn* at[2] = {nets[0]->attn, nets[1]->attn};
+                rc = launch_attn_backward(at, n, H, p.in0, csr->rowptr, csr->col, csr_t->rowptr, csr_t->col, o.qkv, o.dh0,
+                                          o.gst, o.dqkv, o.agg, o.dagg, o.stats, g + co, D, st);
+            } else {
+                rc = launch_aggregate_bwd(p, csr_t, flow->gnn, wsf + p.invdeg, o.dh0[0], o.dh0[1], g + co, D, st);
+            }
+            if (rc) return rc;
+            // ---- weight gradients fork off behind it ------------------------------------------------------------
+            {
                 hipStream_t wst = st;
                 if (aux) {
                     GNF_HIP_TRY(hipEventRecord(ev_ready, st));
                     GNF_HIP_TRY(hipStreamWaitEvent(aux, ev_ready, 0));
                     wst = aux;
                 }
-                rc = launch_weight_grads(p, nets, grads, acc, o.hin_c, o.ldh, o.dPs_c, o.lddp, wsf, wst);
+                WGJob jobs[kMaxGroup];
+                const int nj = weight_grad_jobs(p, o, nets, grads, jobs);
+                rc = launch_weight_grads(p, jobs, nj, acc, wsf, wst);
                 if (rc) return rc;
                 if (aux) {
                     GNF_HIP_TRY(hipEventRecord(g_ev[set], aux));
                     ev_done[set] = g_ev[set];
                 }
-            } else {
-                rc = backward_half(p, csr, csr_t, flow->gnn, nets, grads, acc, z + co, z + uo, ld, g + co, g + uo, D,
-                                   wsf, st);
             }
             ++step;
             if (rc) return rc;

@@ -43,8 +43,7 @@ def get_learning_rate(timestep, max_lr, ramp_up=1000, hold_steady=2000, const_mu
 
 class GRevNetTrainer:
     """total_loss, its gradient and the Adam update for one GRevNet (message-passing GNNs with or without the
-    batch-norm bijectors; the attention GNN family has no backward pass yet and raises GnfError /
-    GNF_EUNSUPPORTED).
+    batch-norm bijectors, and the edge-list attention GNN: every variable the reference's optimizer would see).
 
     Hyper-parameters default to the drivers' flags (run_grevnet.py:114-131): lr 1e-4, beta1 0.9,
     beta2 0.9, epsilon 1e-8, exponential lr decay (1000 steps, 0.96), no clipping."""
@@ -66,6 +65,7 @@ class GRevNetTrainer:
         self._offsets = None
         self._ws = None
         self._bns = []
+        self._attn_blocks = []
         self._aux = None         # second HIP stream: the weight-gradient GEMMs overlap the backward walk
         self.overlap_weight_grads = True
 
@@ -76,11 +76,15 @@ class GRevNetTrainer:
         if self.theta is not None and self.theta.device == torch.device(device):
             return
         mlps = net.mlps("s") + net.mlps("t")
+        blocks = net.blocks("s") + net.blocks("t")
+        attn_blocks = [b for b in blocks if getattr(b, "attn_params", None) is not None]
         bns = [b for half in net.bns for b in half] if net.use_batch_norm else []   # index half*T + i
         sizes = []
         for m in mlps:
             for (w, b) in m.params:
                 sizes += [w.numel(), b.numel()]
+        for blk in attn_blocks:                       # attention front-end: wq, wk, wv, wo
+            sizes += [blk.attn_params[k].numel() for k in ("wq", "wk", "wv", "wo")]
         for b in bns:                                 # trainable: gamma, beta (the moving statistics are not)
             sizes += [b.gamma.numel(), b.beta.numel()]
         total = sum(sizes)
@@ -100,6 +104,18 @@ class GRevNetTrainer:
                 views.append((wv, bv))
             m.params = views                          # the MLP now reads / is updated through the arena
             m.version += 1
+        self._attn_off = off
+        for blk in attn_blocks:
+            views = {}
+            for k in ("wq", "wk", "wv", "wo"):
+                old = blk.attn_params[k]
+                view = theta[off:off + old.numel()].view_as(old)
+                view.copy_(old)
+                views[k] = view
+                off += old.numel()
+                bounds.append(off)
+            blk.attn_params = views
+            blk._attn_version += 1
         self._bn_off = off
         for b in bns:
             for name in ("gamma", "beta"):
@@ -130,6 +146,19 @@ class GRevNetTrainer:
                     off += w.numel()
                     arr[q].b[j] = self.grad.data_ptr() + 4 * off
                     off += b.numel()
+        gattn = None
+        if attn_blocks:                               # gradient GnfAttn per net, hung off the gradient GnfMlp
+            gattn = (_abi.GnfAttn * len(attn_blocks))()
+            for q, blk in enumerate(attn_blocks):     # order: s nets then t nets, like `blocks`
+                ga = gattn[q]
+                ga.num_heads, ga.kq_dim, ga.v_dim, ga.out_dim = blk.num_heads, blk.kq_dim, blk.v_dim, blk.concat_heads_output_dim
+                ptrs = []
+                for k in ("wq", "wk", "wv", "wo"):
+                    ptrs.append(self.grad.data_ptr() + 4 * off)
+                    off += blk.attn_params[k].numel()
+                ga.Wq, ga.Wk, ga.Wv, ga.Wo = ptrs
+                arr = gs if q < n else gt
+                arr[q % n].attn = C.cast(C.byref(gattn, q * C.sizeof(_abi.GnfAttn)), C.POINTER(_abi.GnfAttn))
         spec = net.blocks("s")[0].spec()
         gbn = None
         if bns:
@@ -142,8 +171,9 @@ class GRevNetTrainer:
         self._grad_flow = _abi.GnfFlow(net.num_timesteps, int(net.weight_sharing),
                                        C.cast(gs, C.POINTER(_abi.GnfMlp)), C.cast(gt, C.POINTER(_abi.GnfMlp)), spec,
                                        C.cast(gbn, C.POINTER(_abi.GnfBatchNorm)) if gbn is not None else None)
-        self._keep = (gs, gt, gbn)
+        self._keep = (gs, gt, gbn, gattn)
         self._bns = bns
+        self._attn_blocks = attn_blocks
 
     def named_gradients(self):
         """Gradients in the oracle / fixture container layout ({"s": [[mlp]*T, [mlp]*T], "t": ...}; mlp =
@@ -163,6 +193,21 @@ class GRevNetTrainer:
                 flat.append(layers)
             t = net.num_timesteps
             out[kind] = flat if net.weight_sharing else [flat[:t], flat[t:]]
+        if self._attn_blocks:      # attention nets: {"attn": {wq, wk, wv, wo}, "mlp": [...]} like the parameter container
+            per_block = []
+            for blk in self._attn_blocks:
+                d = {}
+                for k in ("wq", "wk", "wv", "wo"):
+                    w = blk.attn_params[k]
+                    d[k] = g[off:off + w.numel()].reshape(tuple(w.shape)).copy()
+                    off += w.numel()
+                per_block.append(d)
+            nb = len(net.mlps("s"))
+            for ki, kind in enumerate(("s", "t")):
+                flat = out[kind] if net.weight_sharing else out[kind][0] + out[kind][1]
+                wrapped = [{"attn": per_block[ki * nb + q], "mlp": mlp} for q, mlp in enumerate(flat)]
+                t = net.num_timesteps
+                out[kind] = wrapped if net.weight_sharing else [wrapped[:t], wrapped[t:]]
         if self._bns:
             t, h = net.num_timesteps, self._bns[0].gamma.numel()
             flat = []

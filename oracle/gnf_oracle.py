@@ -402,6 +402,11 @@ def loss_and_grads(senders, receivers, n_total, x, params, num_timesteps, weight
     leaves = []
 
     def mark(m):
+        if isinstance(m, dict) and "attn" in m:           # attention net: wq, wk, wv, wo and the MLP are trainable
+            a = dict(m["attn"])
+            for k in ("wq", "wk", "wv", "wo"):
+                a[k] = a[k].clone().requires_grad_(True)
+            return {"attn": a, "mlp": mark(m["mlp"])}
         if isinstance(m, dict) and "gamma" in m:          # batch-norm bijector: gamma and beta are trainable
             out = dict(m)
             for k in ("gamma", "beta"):
@@ -425,6 +430,9 @@ def loss_and_grads(senders, receivers, n_total, x, params, num_timesteps, weight
     total_loss.backward()
 
     def grads_of(m):
+        if isinstance(m, dict) and "attn" in m:
+            return {"attn": {k: m["attn"][k].grad.numpy().copy() for k in ("wq", "wk", "wv", "wo")},
+                    "mlp": grads_of(m["mlp"])}
         if isinstance(m, dict) and "gamma" in m:
             return {"gamma": m["gamma"].grad.numpy().copy(), "beta": m["beta"].grad.numpy().copy()}
         if isinstance(m, list) and m and isinstance(m[0], tuple):

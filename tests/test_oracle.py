@@ -419,3 +419,43 @@ def test_gradient_oracle_with_batch_norm_matches_finite_differences():
             pp[kind][half][i][j][0][idx] -= 2 * eps
             lm = loss(pp)
             assert abs((lp - lm) / (2 * eps) - res["grads"][kind][half][i][j][0][idx]) < 1e-6
+
+
+def test_gradient_oracle_attention_matches_finite_differences():
+    """Attention nets: wq, wk, wv, wo gradients (autograd of the edge-list restatement) vs central differences of
+    the dense masked-softmax restatement; a duplicated edge is in the graph on purpose."""
+    import copy
+    s = np.array([0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 0, 1, 1], np.int32)
+    r = np.array([0, 1, 2, 3, 4, 1, 2, 3, 4, 0, 2, 3, 3], np.int32)
+    n, t = 5, 2
+    raw = O.make_attn_grevnet_params(7, 2, 6, 2, t, num_heads=3, kq_dim=4, v_dim=3, out_dim=5, final_scale=0.5)
+
+    def f64(p):
+        if isinstance(p, tuple):
+            return tuple(np.asarray(a, np.float64) for a in p)
+        if isinstance(p, dict):
+            return {k: (f64(v) if isinstance(v, (list, tuple, dict, np.ndarray)) else v) for k, v in p.items()}
+        if isinstance(p, np.ndarray):
+            return p.astype(np.float64)
+        return [f64(q) for q in p]
+
+    p = f64(raw)
+    x = np.random.default_rng(0).standard_normal((n, 4))
+    res = O.loss_and_grads(s, r, n, x, p, t, activation="relu")
+    dense = O.Fp64Dense(s, r, n, activation="relu")
+
+    def loss(pp):
+        return -dense.log_prob(x, pp, t)["log_prob_xs"]
+
+    assert abs(res["total_loss"] - loss(p)) < 1e-9
+    eps = 1e-6
+    for (kind, half, i) in [("s", 1, 0), ("t", 0, 1)]:
+        for key in ("wq", "wk", "wv", "wo"):
+            w = p[kind][half][i]["attn"][key]
+            for idx in [(0, 0), (1, 2), (w.shape[0] - 1, w.shape[1] - 1)]:
+                pp = copy.deepcopy(p)
+                pp[kind][half][i]["attn"][key][idx] += eps
+                lp = loss(pp)
+                pp[kind][half][i]["attn"][key][idx] -= 2 * eps
+                lm = loss(pp)
+                assert abs((lp - lm) / (2 * eps) - res["grads"][kind][half][i]["attn"][key][idx]) < 1e-6

@@ -201,17 +201,80 @@ def test_training_loop_reduces_loss_and_keeps_packed_weights_fresh(grid_small):
     np.testing.assert_allclose(w_new[big], w_ref[big], atol=2e-5)
 
 
-def test_attention_backward_is_refused(grid_small):
-    from gnf_amd import _abi
+def _flat_attn(grads, ws):
+    for kind in ("s", "t"):
+        nets = grads[kind] if ws else grads[kind][0] + grads[kind][1]
+        for q, net in enumerate(nets):
+            for key in ("wq", "wk", "wv", "wo"):
+                yield f"{kind}[{q}].{key}", net["attn"][key]
+            for j, (w, b) in enumerate(net["mlp"]):
+                yield f"{kind}[{q}].W{j}", w
+                yield f"{kind}[{q}].b{j}", b
+
+
+ATTN_TRAIN_CASES = [
+    # D, latent, K, T, heads, kq, v, C, concat, division, residual, weight sharing
+    (64, 64, 3, 2, 8, 10, 10, 80, True, False, False, False),     # the drivers' default head geometry
+    (8, 24, 2, 2, 3, 4, 5, 6, False, True, False, True),          # no concat, scaled logits, weight sharing
+    (12, 32, 3, 1, 2, 7, 3, 9, True, False, True, False),         # residual
+]
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "gemm"])
+@pytest.mark.parametrize("case", ATTN_TRAIN_CASES, ids=[f"D{c[0]}_h{c[4]}_kq{c[5]}_v{c[6]}_C{c[7]}" for c in ATTN_TRAIN_CASES])
+def test_attention_gradients_vs_oracle(community_medium, case, fused):
+    """The drivers' default GNN (run_grevnet.py:56,199-211) trains: gradients of wq, wk, wv, wo and of the MLP
+    behind the attention front-end vs the autograd oracle (itself pinned by finite differences)."""
     from gnf_amd.train import GRevNetTrainer
-    from helpers import load_golden
-    g = load_golden("attn_cfg1_grid_small")
-    hp = dict(D=g["D"], latent=g["latent"], K=g["K"], T=g["T"], agg=g["agg"], combine=g["combine"],
-              epsilon=g["epsilon"], activation=g["activation"], weight_sharing=g["weight_sharing"], attn=g["attn"])
-    net = make_product_grevnet(hp, g["params"])
-    graph = graph_from_arrays(g["n_node"], g["n_edge"], g["senders"], g["receivers"], g["x"], DEV)
-    with pytest.raises(_abi.GnfError):
-        GRevNetTrainer(net).loss_and_grads(graph)
+    d, latent, k, t, nh, kq, vd, c, concat, div, res, ws = case
+    attn = dict(num_heads=nh, kq_dim=kq, v_dim=vd, out_dim=c, concat=concat, kq_dim_division=div, residual=res)
+    hp = dict(D=d, latent=latent, K=k, T=t, agg="mean", combine="agg", epsilon=0.0, activation="relu",
+              weight_sharing=ws, attn=attn)
+    nn, ne, s, r = _batch(community_medium, [3, 50, 77, 12, 100])
+    n = int(nn.sum())
+    rng = np.random.default_rng(d + nh)
+    x = (rng.standard_normal((n, d)) * (0.3 if res else 1.0)).astype(np.float32)
+    p = O.make_attn_grevnet_params(d + 1, d // 2, latent, k, t, weight_sharing=ws, final_scale=0.3, **attn)
+    ref = O.loss_and_grads(s, r, n, x, p, t, ws, activation="relu")
+    net = make_product_grevnet(hp, p)
+    net.fused = fused
+    tr = GRevNetTrainer(net)
+    out = tr.loss_and_grads(graph_from_arrays(nn, ne, s, r, x, DEV))
+    torch.cuda.synchronize()
+    assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
+    np.testing.assert_allclose(out["reconstruction"].cpu().numpy(), x, atol=3e-4, rtol=3e-4)
+    for (name, a), (_, b) in zip(_flat_attn(tr.named_gradients(), ws), _flat_attn(ref["grads"], ws)):
+        tol = 5e-4 * float(np.abs(b).max()) + 1e-5
+        err = float(np.abs(a - b).max())
+        assert err <= tol, f"{name}: max err {err:.3e} > {tol:.3e} (max|g| {np.abs(b).max():.3e})"
+
+
+def test_training_loop_with_the_default_gnn_and_batch_norm(community_medium):
+    """The drivers' defaults together (attention GNN + use_batch_norm=True): a few iterations reduce the loss."""
+    from gnf_amd.train import GRevNetTrainer
+    attn = dict(num_heads=8, kq_dim=10, v_dim=10, out_dim=80, concat=True, kq_dim_division=False, residual=False)
+    hp = dict(D=16, latent=64, K=3, T=2, agg="mean", combine="agg", epsilon=0.0, activation="relu",
+              weight_sharing=False, attn=attn)
+    nn, ne, s, r = _batch(community_medium, [3, 50, 77, 12, 100])
+    n = int(nn.sum())
+    x = (np.random.default_rng(0).standard_normal((n, 16)) * 2 + 1).astype(np.float32)
+    p = O.make_attn_grevnet_params(17, 8, 64, 3, 2, final_scale=0.3, **attn)
+    p["bn"] = O.make_bn_params(18, 8, 2)
+    net = make_product_grevnet(hp, p)
+    tr = GRevNetTrainer(net, lr=2e-3, use_lr_decay=False)
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    ref = O.loss_and_grads(s, r, n, x, p, 2, activation="relu")
+    first = tr.loss_and_grads(graph)
+    torch.cuda.synchronize()
+    assert abs(float(first["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
+    got = tr.named_gradients()
+    for key in ("wq", "wo"):
+        a, b = got["t"][1][0]["attn"][key], ref["grads"]["t"][1][0]["attn"][key]
+        assert np.abs(a - b).max() <= 5e-4 * np.abs(b).max() + 1e-5
+    np.testing.assert_allclose(got["bn"][0][1]["gamma"], ref["grads"]["bn"][0][1]["gamma"],
+                               atol=5e-4 * np.abs(ref["grads"]["bn"][0][1]["gamma"]).max() + 1e-4)
+    losses = [float(tr.step(graph)["loss_per_node"]) for _ in range(25)]
+    assert losses[-1] < losses[0] - 0.05, losses
 
 
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "gemm"])
