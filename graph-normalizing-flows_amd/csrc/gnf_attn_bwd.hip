@@ -12,8 +12,8 @@
 //   dWq = x^T dq, dWk = x^T dk, dWv = x^T dv                             (grouped dW GEMM, gnf_train.hip)
 // The sender-side pass needs no edge ids: it recomputes w[e,h] from the per-(receiver, head) softmax max and
 // normaliser the receiver-side pass leaves in `stats`, and reads dagg per receiver.
-// One wave per row; lanes run over the row's edges (tiles of 64), components are wave-reduced.  Correctness
-// first: these kernels are latency-bound like their forward twins.
+// One wave per row, lanes along the feature axis (coalesced row reads, nothing of the edge list staged in
+// LDS); per-(edge, head) scalars through segmented sums in a small per-wave scratch.
 #include "gnf_common.h"
 
 namespace gnf {
@@ -46,148 +46,234 @@ __device__ __forceinline__ float wave_max(float x) {
 }
 
 static constexpr int kRowsPerBlock = 4;  // one wave per row
+static constexpr int kG = 4;             // edges handled together (loads of the group are all in flight at once)
+static constexpr int kMaxF = 4;          // feature registers per lane: widths up to 64 * kMaxF
 
+// Lanes run along the FEATURE axis (every row read is coalesced and nothing of the edge list is staged in LDS);
+// the per-(edge, head) scalars come from segmented sums through a small per-wave LDS scratch:
+//   pq[g][c] = q . k products, pd[g][i] = dagg . v products  ->  lane t = (g, h) sums its head's segment.
+// per-wave scratch (floats): pq [kG][nq] | pd [kG][NV] | hw [kG][nh] | hd [kG][nh] | red [kG][3 nh]
+__host__ __device__ inline int attn_bwd_wave_floats(int nq, int NV, int nh) { return kG * (nq + NV + 5 * nh); }
+
+// Receiver side.  Two sweeps over the row's incoming edges: softmax statistics by the online (running-max)
+// recurrence, then the outputs, each recomputing the logits from the (cache-resident) sender rows: any
+// degree, no per-edge storage.
 __global__ __launch_bounds__(256) void k_attn_bwd_recv(const AttnBwdArgs a) {
-    extern __shared__ float sm[];  // Wo [NV][C] | per wave: dnew [C] | dagg [NV]
-    const int net = blockIdx.y;
-    const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd, C = a.C;
-    float* wo = sm;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* dnew = wo + NV * C + wave * (C + NV);
-    float* dagg = dnew + C;
-    for (int i = tid; i < NV * C; i += 256) wo[i] = a.Wo[net][i];
-    __syncthreads();
-    const int r = blockIdx.x * kRowsPerBlock + wave;
-    if (r >= a.n) return;
-    const float* qkv = a.qkv[net];
-    const int off = a.concat ? a.H : 0;
-    for (int c = lane; c < C; c += 64) dnew[c] = a.dh0[net][(int64_t)r * a.in0 + off + c];
-    __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < NV; i += 64) {
-        float s = 0.f;
-        for (int c = 0; c < C; ++c) s += dnew[c] * wo[i * C + c];
-        dagg[i] = s;
-        a.dagg[net][(int64_t)r * NV + i] = s;
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int beg = a.rowptr[r], end = a.rowptr[r + 1];
-    const float* krow = qkv + (int64_t)r * P + nq;
-    for (int h = 0; h < nh; ++h) {
-        const float* kh = krow + h * kq;
-        auto logit_of = [&](int s) -> float {
-            const float* qh = qkv + (int64_t)s * P + h * kq;
-            float d = 0.f;
-            for (int j = 0; j < kq; ++j) d += qh[j] * kh[j];
-            return d * a.scale;
-        };
-        auto dw_of = [&](int s) -> float {
-            const float* vs = qkv + (int64_t)s * P + 2 * nq;
-            float d = 0.f;
-            for (int j = 0; j < vd; ++j) d += dagg[h * vd + j] * vs[j];
-            return d;
-        };
-        // pass A: max;  pass B: normaliser and sum exp * dw
-        float m = -INFINITY;
-        for (int e0 = beg; e0 < end; e0 += 64) {
-            const int e = e0 + lane;
-            m = fmaxf(m, e < end ? logit_of(a.col[e]) : -INFINITY);
-        }
-        m = wave_max(m);
-        float z = 0.f, s1 = 0.f;
-        for (int e0 = beg; e0 < end; e0 += 64) {
-            const int e = e0 + lane;
-            if (e < end) {
-                const int s = a.col[e];
-                const float ex = expf(logit_of(s) - m);
-                z += ex;
-                s1 += ex * dw_of(s);
-            }
-        }
-        z = wave_sum(z);
-        s1 = wave_sum(s1);
-        const float sumw = end > beg ? s1 / z : 0.f;
-        if (lane == 0) {
-            float* st = a.stats[net] + (int64_t)r * 3 * nh;
-            st[h] = m;
-            st[nh + h] = z;
-            st[2 * nh + h] = sumw;
-        }
-        // pass C: dk[r, h, :] and agg[r, h, :]
-        for (int j0 = 0; j0 < (kq > vd ? kq : vd); ++j0) {
-            float dk = 0.f, ag = 0.f;
-            for (int e0 = beg; e0 < end; e0 += 64) {
-                const int e = e0 + lane;
-                if (e < end) {
-                    const int s = a.col[e];
-                    const float w = expf(logit_of(s) - m) / z;
-                    if (j0 < kq) dk += w * (dw_of(s) - sumw) * a.scale * qkv[(int64_t)s * P + h * kq + j0];
-                    if (j0 < vd) ag += w * qkv[(int64_t)s * P + 2 * nq + j0];
-                }
-            }
-            dk = wave_sum(dk);
-            ag = wave_sum(ag);
-            if (lane == 0) {
-                if (j0 < kq) a.dqkv[net][(int64_t)r * P + nq + h * kq + j0] = dk;
-                if (j0 < vd) a.agg[net][(int64_t)r * NV + h * vd + j0] = ag;
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_attn_bwd_send(const AttnBwdArgs a) {
+    extern __shared__ float sm[];
     const int net = blockIdx.y;
     const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int u = blockIdx.x * kRowsPerBlock + wave;
-    if (u >= a.n) return;
+    const int r = blockIdx.x * kRowsPerBlock + wave;
+    if (r >= a.n) return;
+    float* pq = sm + wave * attn_bwd_wave_floats(nq, NV, nh);
+    float* pd = pq + kG * nq;
+    float* hw = pd + kG * NV;
+    float* hd = hw + kG * nh;
+    float* red = hd + kG * nh;
+    const float* qkv = a.qkv[net];
+    const float* daggr = a.dagg[net] + (int64_t)r * NV;
+    const int beg = a.rowptr[r], end = a.rowptr[r + 1];
+    float kreg[kMaxF], dreg[kMaxF], dk[kMaxF], ag[kMaxF];
+#pragma unroll
+    for (int u = 0; u < kMaxF; ++u) {
+        const int c = lane + 64 * u;
+        kreg[u] = c < nq ? qkv[(int64_t)r * P + nq + c] : 0.f;
+        dreg[u] = c < NV ? daggr[c] : 0.f;
+        dk[u] = 0.f;
+        ag[u] = 0.f;
+    }
+    const int G = 64 / nh < kG ? 64 / nh : kG;  // (edge slot, head) pairs fit one wave
+    const int tg = lane / nh, th = lane - tg * nh;  // this lane's (slot, head) when lane < G * nh
+    const bool head_lane = lane < G * nh;
+    float m_run = -INFINITY, z_run = 0.f, s1_run = 0.f;  // per (slot, head) partials
+    float m_h = 0.f, z_h = 1.f, sw_h = 0.f;               // per head, valid on every lane after each sweep
+    for (int sweep = 1; sweep < 3; ++sweep) {
+        for (int e0 = beg; e0 < end; e0 += G) {
+            float qv[kG][kMaxF], vv[kG][kMaxF];
+#pragma unroll
+            for (int g = 0; g < kG; ++g) {
+                const int e = e0 + g < end ? e0 + g : end - 1;
+                const int s_ = a.col[e];
+#pragma unroll
+                for (int u = 0; u < kMaxF; ++u) {
+                    const int c = lane + 64 * u;
+                    qv[g][u] = (g < G && c < nq) ? qkv[(int64_t)s_ * P + c] : 0.f;
+                    vv[g][u] = (g < G && c < NV) ? qkv[(int64_t)s_ * P + 2 * nq + c % vd] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < kG; ++g)
+#pragma unroll
+                for (int u = 0; u < kMaxF; ++u) {
+                    const int c = lane + 64 * u;
+                    if (g < G && c < nq) pq[g * nq + c] = qv[g][u] * kreg[u];
+                    if (g < G && c < NV) pd[g * NV + c] = dreg[u] * vv[g][u];
+                }
+            __builtin_amdgcn_wave_barrier();
+            float lg = -INFINITY, dw = 0.f;
+            const bool live = head_lane && e0 + tg < end;
+            if (live) {
+                float s0 = 0.f, s1 = 0.f;
+                for (int j = 0; j < kq; ++j) s0 += pq[tg * nq + th * kq + j];
+                for (int j = 0; j < vd; ++j) s1 += pd[tg * NV + th * vd + j];
+                lg = s0 * a.scale;
+                dw = s1;
+            }
+            if (sweep == 1) {
+                if (live) {  // online softmax: rescale the running sums when the maximum moves
+                    const float mn = fmaxf(m_run, lg);
+                    const float sc = expf(m_run - mn), ex = expf(lg - mn);
+                    z_run = z_run * sc + ex;
+                    s1_run = s1_run * sc + ex * dw;
+                    m_run = mn;
+                }
+            } else {
+                if (head_lane) {
+                    const float w = live ? expf(lg - m_h) / z_h : 0.f;
+                    hw[tg * nh + th] = w;
+                    hd[tg * nh + th] = w * (dw - sw_h);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int g = 0; g < kG; ++g)
+#pragma unroll
+                    for (int u = 0; u < kMaxF; ++u) {
+                        const int c = lane + 64 * u;
+                        if (g < G && c < nq) dk[u] += hd[g * nh + c / kq] * qv[g][u];
+                        if (g < G && c < NV) ag[u] += hw[g * nh + c / vd] * vv[g][u];
+                    }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // combine the slot partials per head and broadcast to the (slot, head) lanes
+        if (sweep == 1) {
+            __builtin_amdgcn_wave_barrier();
+            if (head_lane) {
+                red[tg * nh + th] = m_run;
+                red[G * nh + tg * nh + th] = z_run;
+                red[2 * G * nh + tg * nh + th] = s1_run;
+            }
+            __builtin_amdgcn_wave_barrier();
+            float m = -INFINITY, z = 0.f, s1 = 0.f;
+            if (head_lane) {
+                for (int g = 0; g < G; ++g) m = fmaxf(m, red[g * nh + th]);
+                for (int g = 0; g < G; ++g) {
+                    const float mg = red[g * nh + th];
+                    const float sc = mg == -INFINITY ? 0.f : expf(mg - m);
+                    z += red[G * nh + g * nh + th] * sc;
+                    s1 += red[2 * G * nh + g * nh + th] * sc;
+                }
+            }
+            m_h = m;
+            z_h = end > beg ? z : 1.f;
+            sw_h = end > beg ? s1 / z : 0.f;
+            if (lane < nh) {
+                float* st = a.stats[net] + (int64_t)r * 3 * nh;
+                st[lane] = m_h;
+                st[nh + lane] = z_h;
+                st[2 * nh + lane] = sw_h;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kMaxF; ++u) {
+        const int c = lane + 64 * u;
+        if (c < nq) a.dqkv[net][(int64_t)r * P + nq + c] = dk[u] * a.scale;
+        if (c < NV) a.agg[net][(int64_t)r * NV + c] = ag[u];
+    }
+}
+
+// Sender side: ONE pass over the out-edges; the softmax weight of every edge is rebuilt from the receiver's
+// statistics.  dv is accumulated per (head, component) and folded over the heads at the end.
+__global__ __launch_bounds__(256) void k_attn_bwd_send(const AttnBwdArgs a) {
+    extern __shared__ float sm[];
+    const int net = blockIdx.y;
+    const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u_ = blockIdx.x * kRowsPerBlock + wave;
+    if (u_ >= a.n) return;
+    float* pq = sm + wave * attn_bwd_wave_floats(nq, NV, nh);
+    float* pd = pq + kG * nq;
+    float* hw = pd + kG * NV;
+    float* hd = hw + kG * nh;
     const float* qkv = a.qkv[net];
     const float* dagg = a.dagg[net];
     const float* stats = a.stats[net];
-    const int beg = a.rowptr_t[u], end = a.rowptr_t[u + 1];
-    const float* qrow = qkv + (int64_t)u * P;
-    const float* vrow = qrow + 2 * nq;
-    // per-edge softmax weight and dlogit, recomputed from the receiver's statistics
-    auto edge = [&](int r, int h, float* w_out) -> float {
-        const float* qh = qrow + h * kq;
-        const float* kr = qkv + (int64_t)r * P + nq + h * kq;
-        float d = 0.f;
-        for (int j = 0; j < kq; ++j) d += qh[j] * kr[j];
-        const float* st = stats + (int64_t)r * 3 * nh;
-        const float w = expf(d * a.scale - st[h]) / st[nh + h];
-        float dw = 0.f;
-        for (int j = 0; j < vd; ++j) dw += dagg[(int64_t)r * NV + h * vd + j] * vrow[j];
-        *w_out = w;
-        return w * (dw - st[2 * nh + h]);
-    };
-    for (int h = 0; h < nh; ++h)
-        for (int j0 = 0; j0 < kq; ++j0) {
-            float dq = 0.f;
-            for (int e0 = beg; e0 < end; e0 += 64) {
-                const int e = e0 + lane;
-                if (e < end) {
-                    const int r = a.col_t[e];
-                    float w;
-                    dq += edge(r, h, &w) * a.scale * qkv[(int64_t)r * P + nq + h * kq + j0];
-                }
+    const int beg = a.rowptr_t[u_], end = a.rowptr_t[u_ + 1];
+    float qreg[kMaxF], vreg[kMaxF], dq[kMaxF], dvp[kMaxF];
+#pragma unroll
+    for (int u = 0; u < kMaxF; ++u) {
+        const int c = lane + 64 * u;
+        qreg[u] = c < nq ? qkv[(int64_t)u_ * P + c] : 0.f;
+        vreg[u] = c < NV ? qkv[(int64_t)u_ * P + 2 * nq + c % vd] : 0.f;
+        dq[u] = 0.f;
+        dvp[u] = 0.f;
+    }
+    const int G = 64 / nh < kG ? 64 / nh : kG;
+    const int tg = lane / nh, th = lane - tg * nh;
+    const bool head_lane = lane < G * nh;
+    for (int e0 = beg; e0 < end; e0 += G) {
+        float kv[kG][kMaxF], dv_[kG][kMaxF], st_m = 0.f, st_z = 1.f, st_s = 0.f;
+#pragma unroll
+        for (int g = 0; g < kG; ++g) {
+            const int e = e0 + g < end ? e0 + g : end - 1;
+            const int r = a.col_t[e];
+#pragma unroll
+            for (int u = 0; u < kMaxF; ++u) {
+                const int c = lane + 64 * u;
+                kv[g][u] = (g < G && c < nq) ? qkv[(int64_t)r * P + nq + c] : 0.f;
+                dv_[g][u] = (g < G && c < NV) ? dagg[(int64_t)r * NV + c] : 0.f;
             }
-            dq = wave_sum(dq);
-            if (lane == 0) a.dqkv[net][(int64_t)u * P + h * kq + j0] = dq;
-        }
-    for (int j0 = 0; j0 < vd; ++j0) {  // v is shared by the heads: one sum over (edge, head)
-        float dv = 0.f;
-        for (int e0 = beg; e0 < end; e0 += 64) {
-            const int e = e0 + lane;
-            if (e < end) {
-                const int r = a.col_t[e];
-                for (int h = 0; h < nh; ++h) {
-                    float w;
-                    edge(r, h, &w);
-                    dv += w * dagg[(int64_t)r * NV + h * vd + j0];
-                }
+            if (head_lane && tg == g) {
+                const float* st = stats + (int64_t)r * 3 * nh;
+                st_m = st[th];
+                st_z = st[nh + th];
+                st_s = st[2 * nh + th];
             }
         }
-        dv = wave_sum(dv);
-        if (lane == 0) a.dqkv[net][(int64_t)u * P + 2 * nq + j0] = dv;
+#pragma unroll
+        for (int g = 0; g < kG; ++g)
+#pragma unroll
+            for (int u = 0; u < kMaxF; ++u) {
+                const int c = lane + 64 * u;
+                if (g < G && c < nq) pq[g * nq + c] = qreg[u] * kv[g][u];
+                if (g < G && c < NV) pd[g * NV + c] = dv_[g][u] * vreg[u];
+            }
+        __builtin_amdgcn_wave_barrier();
+        if (head_lane) {
+            float w = 0.f, dl = 0.f;
+            if (e0 + tg < end) {
+                float s0 = 0.f, s1 = 0.f;
+                for (int j = 0; j < kq; ++j) s0 += pq[tg * nq + th * kq + j];
+                for (int j = 0; j < vd; ++j) s1 += pd[tg * NV + th * vd + j];
+                w = expf(s0 * a.scale - st_m) / st_z;
+                dl = w * (s1 - st_s);
+            }
+            hw[tg * nh + th] = w;
+            hd[tg * nh + th] = dl;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < kG; ++g)
+#pragma unroll
+            for (int u = 0; u < kMaxF; ++u) {
+                const int c = lane + 64 * u;
+                if (g < G && c < nq) dq[u] += hd[g * nh + c / kq] * kv[g][u];
+                if (g < G && c < NV) dvp[u] += hw[g * nh + c / vd] * dv_[g][u];
+            }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int u = 0; u < kMaxF; ++u) {
+        const int c = lane + 64 * u;
+        if (c < nq) a.dqkv[net][(int64_t)u_ * P + c] = dq[u] * a.scale;
+        if (c < NV) pd[c] = dvp[u];  // fold the heads: dv[j] = sum_h dvp[h * vd + j]
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < vd; j += 64) {
+        float s = 0.f;
+        for (int h = 0; h < nh; ++h) s += pd[h * vd + j];
+        a.dqkv[net][(int64_t)u_ * P + 2 * nq + j] = s;
     }
 }
 
@@ -205,30 +291,58 @@ struct AttnDxArgs {
     int32_t n, H, nq, v, in0, concat;
 };
 
+static constexpr int kDxRows = 8;  // rows per workgroup
+
 __global__ __launch_bounds__(256) void k_attn_bwd_dx(const AttnDxArgs a) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)a.n * a.H) return;
-    const int64_t r = i / a.H;
-    const int f = (int)(i - r * a.H);
-    const int P = 2 * a.nq + a.v;
-    float acc = 0.f;
+    extern __shared__ float sm[];  // Wcat [H][P + 1] (Wq | Wk | Wv of one net) | dqkv rows [kDxRows][P]
+    const int P = 2 * a.nq + a.v, P1 = P + 1, H = a.H;
+    float* wl = sm;
+    float* dl = wl + H * P1;
+    const int tid = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * kDxRows;
+    const int rows = (int)((a.n - row0) < kDxRows ? (a.n - row0) : kDxRows);
     for (int net = 0; net < 2; ++net) {
-        const float* d = a.dqkv[net] + r * P;
-        const float* wq = a.Wq[net] + (int64_t)f * a.nq;
-        const float* wk = a.Wk[net] + (int64_t)f * a.nq;
-        const float* wv = a.Wv[net] + (int64_t)f * a.v;
-        float s = 0.f;
-        for (int c = 0; c < a.nq; ++c) s += d[c] * wq[c] + d[a.nq + c] * wk[c];
-        for (int c = 0; c < a.v; ++c) s += d[2 * a.nq + c] * wv[c];
-        if (a.concat) s += a.dh0[net][r * a.in0 + f];
-        if (a.gst[net]) s += a.gst[net][r * a.H + f];
-        acc += s;
+        __syncthreads();
+        for (int base = 0; base < H * P; base += 256 * 8) {  // loads first, stores after
+            float reg[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i0 = base + tid + q * 256;
+                const int i = i0 < H * P ? i0 : 0;
+                const int f = i / P, c = i - f * P;
+                if (c < a.nq)
+                    reg[q] = a.Wq[net][(int64_t)f * a.nq + c];
+                else if (c < 2 * a.nq)
+                    reg[q] = a.Wk[net][(int64_t)f * a.nq + (c - a.nq)];
+                else
+                    reg[q] = a.Wv[net][(int64_t)f * a.v + (c - 2 * a.nq)];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = base + tid + q * 256;
+                if (i < H * P) wl[(i / P) * P1 + (i % P)] = reg[q];
+            }
+        }
+        for (int i = tid; i < rows * P; i += 256) dl[i] = a.dqkv[net][row0 * P + i];
+        __syncthreads();
+        for (int i = tid; i < rows * H; i += 256) {
+            const int rl = i / H, f = i - rl * H;
+            const float* d = dl + rl * P;
+            const float* w = wl + f * P1;
+            float s = 0.f;
+#pragma unroll 16
+            for (int c = 0; c < P; ++c) s += d[c] * w[c];
+            const int64_t r = row0 + rl;
+            if (a.concat) s += a.dh0[net][r * a.in0 + f];
+            if (a.gst[net]) s += a.gst[net][r * H + f];
+            a.g[r * a.ldg + f] += s;
+        }
     }
-    a.g[r * a.ldg + f] += acc;
 }
 
 // at[2]: the two attention blocks; qkv: [2][N, P] forward projections (launch_attn_front's scratch);
-// dh0 / gst: per net;  dqkv / agg: per net outputs kept for the dW GEMMs;  dagg / stats: scratch.
+// dh0 / gst: per net;  dqkv / agg: per net outputs kept for the dW GEMMs;  dagg = dnew Wo^T [N, heads*v]
+// (computed by the caller with the matrix-core GEMM);  stats: scratch.
 int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t in0, const int32_t* rowptr,
                          const int32_t* col, const int32_t* rowptr_t, const int32_t* col_t, const float* const* qkv,
                          const float* const* dh0, const float* const* gst, float* const* dqkv, float* const* agg,
@@ -258,22 +372,27 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
     a.concat = a0->concat ? 1 : 0;
     a.in0 = in0;
     a.scale = a0->kq_dim_division ? 1.f / sqrtf((float)a0->kq_dim) : 1.f;
-    const int NV = a.nh * a.v;
-    const size_t lds = ((size_t)NV * a.C + (size_t)kRowsPerBlock * (a.C + NV)) * sizeof(float);
-    if (lds > 160 * 1024) {
-        set_error("attention backward needs %zu bytes of LDS for Wo: unsupported", lds);
+    const int NV = a.nh * a.v, nq = a.nh * a.kq, P = 2 * nq + a.v;
+    if (nq > 64 * kMaxF || NV > 64 * kMaxF || a.nh > 64) {
+        set_error("attention backward supports heads*kq_dim, heads*v_dim <= %d and heads <= 64", 64 * kMaxF);
+        return GNF_EUNSUPPORTED;
+    }
+    const size_t lds = (size_t)kRowsPerBlock * attn_bwd_wave_floats(nq, NV, a.nh) * sizeof(float);
+    const size_t lds_x = ((size_t)H * (P + 1) + (size_t)kDxRows * P) * sizeof(float);
+    if (lds_x > 160 * 1024) {
+        set_error("attention backward needs %zu bytes of LDS: head geometry unsupported", lds_x);
         return GNF_EUNSUPPORTED;
     }
     static bool attr_set = false;
     if (!attr_set) {
-        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_recv),
+        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dx),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const dim3 grid((unsigned)((n + kRowsPerBlock - 1) / kRowsPerBlock), 2);
     hipLaunchKernelGGL(k_attn_bwd_recv, grid, dim3(256), lds, st, a);
     GNF_LAUNCH_CHECK("k_attn_bwd_recv");
-    hipLaunchKernelGGL(k_attn_bwd_send, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_attn_bwd_send, grid, dim3(256), lds, st, a);
     GNF_LAUNCH_CHECK("k_attn_bwd_send");
     AttnDxArgs d;
     for (int q = 0; q < 2; ++q) {
@@ -292,7 +411,7 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
     d.v = a.v;
     d.in0 = in0;
     d.concat = a.concat;
-    hipLaunchKernelGGL(k_attn_bwd_dx, dim3((unsigned)((n * H + 255) / 256)), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_attn_bwd_dx, dim3((unsigned)((n + kDxRows - 1) / kDxRows)), dim3(256), lds_x, st, d);
     GNF_LAUNCH_CHECK("k_attn_bwd_dx");
     return GNF_OK;
 }

@@ -15,7 +15,7 @@
 
 namespace gnf {
 
-static constexpr int kBnRows = 64;  // rows per workgroup of the two passes
+static constexpr int kBnRows = 16;  // rows per workgroup of the normalising pass
 
 // pass 1: per-workgroup column sums and sums of squares (fp64), fixed order
 __global__ __launch_bounds__(256) void k_bn_stats(const float* __restrict__ x, int64_t ld, int64_t n, int H,
@@ -66,9 +66,20 @@ __global__ __launch_bounds__(256) void k_bn_apply(float* __restrict__ x, int64_t
     double ld_local = 0.0;
     for (int c = tid; c < H; c += 256) {
         double s = 0.0, q = 0.0;
-        for (int b = 0; b < nparts; ++b) {
-            s += part[((int64_t)b * H + c) * 2 + 0];
-            q += part[((int64_t)b * H + c) * 2 + 1];
+        for (int b0 = 0; b0 < nparts; b0 += 8) {  // eight partial pairs in flight, summed in order
+            double ps[8], pq_[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int b = b0 + k < nparts ? b0 + k : nparts - 1;
+                ps[k] = part[((int64_t)b * H + c) * 2 + 0];
+                pq_[k] = part[((int64_t)b * H + c) * 2 + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (b0 + k < nparts) {
+                    s += ps[k];
+                    q += pq_[k];
+                }
         }
         const double mean = s / (double)n;
         double var = q / (double)n - mean * mean;
@@ -118,8 +129,9 @@ __global__ __launch_bounds__(256) void k_bn_denorm(float* __restrict__ z, int64_
     }
 }
 
+// moment pass: few large row chunks (each workgroup's partial is re-read by every workgroup of the second pass)
 int bn_blocks(int64_t n, int64_t* rows_per_block) {
-    int64_t rpb = kBnRows;
+    int64_t rpb = 256;
     int64_t blocks = (n + rpb - 1) / rpb;
     if (blocks > kBnBlocksMax) {
         rpb = (n + kBnBlocksMax - 1) / kBnBlocksMax;
@@ -137,7 +149,9 @@ int launch_bn_normalize(const GnfBatchNorm* bn, float* x, int64_t ld, int64_t n,
     const int blocks = bn_blocks(n, &rpb);
     hipLaunchKernelGGL(k_bn_stats, dim3(blocks), dim3(256), 0, st, x, ld, n, H, rpb, part);
     GNF_LAUNCH_CHECK("k_bn_stats");
-    hipLaunchKernelGGL(k_bn_apply, dim3(blocks), dim3(256), 2 * H * sizeof(float), st, x, ld, n, H, rpb, part,
+    const int64_t arows = kBnRows;
+    const int64_t ablocks = (n + arows - 1) / arows;
+    hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)ablocks), dim3(256), 2 * H * sizeof(float), st, x, ld, n, H, arows, part,
                        blocks, bn->gamma, bn->beta, bn->epsilon, bn->batch_mean, bn->batch_variance, logdet_slot);
     GNF_LAUNCH_CHECK("k_bn_apply");
     return GNF_OK;

@@ -453,9 +453,20 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(float* __restrict__ y, int
     const int tid = threadIdx.x;
     for (int c = tid; c < H; c += 256) {
         double s = 0.0, q = 0.0;
-        for (int b = 0; b < nparts; ++b) {
-            s += part[((int64_t)b * H + c) * 2 + 0];
-            q += part[((int64_t)b * H + c) * 2 + 1];
+        for (int b0 = 0; b0 < nparts; b0 += 8) {  // eight partial pairs in flight, summed in order
+            double ps[8], pq_[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int b = b0 + k < nparts ? b0 + k : nparts - 1;
+                ps[k] = part[((int64_t)b * H + c) * 2 + 0];
+                pq_[k] = part[((int64_t)b * H + c) * 2 + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (b0 + k < nparts) {
+                    s += ps[k];
+                    q += pq_[k];
+                }
         }
         const float g = gamma[c];
         m1[c] = (float)(s / (double)n) * g;
@@ -489,7 +500,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(float* __restrict__ y, int
 
 static int launch_bn_backward(const GnfBatchNorm* bn, const GnfBatchNorm* gbn, float* y, int64_t ld, float* gy,
                               int64_t ldg, int64_t n, int32_t H, double* part, hipStream_t st) {
-    int64_t rpb = 64;
+    int64_t rpb = 256;  // moment pass: few large chunks;  rewrite pass: many small ones
     int64_t blocks = (n + rpb - 1) / rpb;
     if (blocks > kBnBlocksMax) {
         rpb = (n + kBnBlocksMax - 1) / kBnBlocksMax;
@@ -498,8 +509,10 @@ static int launch_bn_backward(const GnfBatchNorm* bn, const GnfBatchNorm* gbn, f
     hipLaunchKernelGGL(k_bn_bwd_stats, dim3((unsigned)blocks), dim3(256), 0, st, y, ld, gy, ldg, n, H, rpb, bn->gamma,
                        bn->beta, part);
     GNF_LAUNCH_CHECK("k_bn_bwd_stats");
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)blocks), dim3(256), 6 * H * sizeof(float), st, y, ld, gy, ldg, n,
-                       H, rpb, part, (int)blocks, bn->gamma, bn->beta, bn->batch_mean, bn->batch_variance, bn->epsilon,
+    const int64_t arows = 16;
+    const int64_t ablocks = (n + arows - 1) / arows;
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)ablocks), dim3(256), 6 * H * sizeof(float), st, y, ld, gy, ldg, n,
+                       H, arows, part, (int)blocks, bn->gamma, bn->beta, bn->batch_mean, bn->batch_variance, bn->epsilon,
                        const_cast<float*>(gbn->gamma), const_cast<float*>(gbn->beta), 0);
     GNF_LAUNCH_CHECK("k_bn_bwd_apply");
     return GNF_OK;
@@ -1074,6 +1087,17 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             // ---- dL/dx_cond: on the critical path (the next half-step's coupling reads g), so it goes first -----
             if (attn) {
                 const GnfAttn* at[2] = {nets[0]->attn, nets[1]->attn};
+                {   // dagg = dnew Wo^T   [nodes, C] x [C, heads*v]  (Wo is [heads*v, C]: rows = output columns)
+                    const int off = at[0]->concat ? H : 0;
+                    GemmJob jobs[2];
+                    for (int q = 0; q < 2; ++q) jobs[q] = GemmJob{o.dh0[q] + off, at[q]->Wo, o.dagg[q], nullptr, nullptr};
+                    GemmShape sh;
+                    memset(&sh, 0, sizeof(sh));
+                    sh.lda = p.in0, sh.ldb = p.C, sh.ldc = p.NV;
+                    sh.M = n, sh.K = p.C, sh.N = p.NV, sh.chunks = 1, sh.kchunk = TGK;
+                    rc = launch_gemm<OPND_KC, OPND_KC, EPI_MASK>(jobs, 2, sh, st);
+                    if (rc) return rc;
+                }
                 rc = launch_attn_backward(at, n, H, p.in0, csr->rowptr, csr->col, csr_t->rowptr, csr_t->col, o.qkv, o.dh0,
                                           o.gst, o.dqkv, o.agg, o.dagg, o.stats, g + co, D, st);
             } else {

@@ -249,6 +249,28 @@ def test_attention_gradients_vs_oracle(community_medium, case, fused):
         assert err <= tol, f"{name}: max err {err:.3e} > {tol:.3e} (max|g| {np.abs(b).max():.3e})"
 
 
+def test_attention_gradients_high_degree_rows():
+    """Complete topology with a 70-node graph: rows with more than 64 in / out edges take the kernels' general
+    (edge-tiled) path, the 9-node graph next to it the LDS-resident one."""
+    from gnf_amd.datasets import senders_receivers
+    from gnf_amd.train import GRevNetTrainer
+    attn = dict(num_heads=2, kq_dim=3, v_dim=4, out_dim=6, concat=True, kq_dim_division=True, residual=False)
+    hp = dict(D=6, latent=16, K=2, T=1, agg="mean", combine="agg", epsilon=0.0, activation="relu",
+              weight_sharing=False, attn=attn)
+    n_node = np.array([70, 9], np.int32)
+    s, r, ne = senders_receivers(n_node)
+    n = int(n_node.sum())
+    x = np.random.default_rng(3).standard_normal((n, 6)).astype(np.float32)
+    p = O.make_attn_grevnet_params(5, 3, 16, 2, 1, final_scale=0.3, **attn)
+    ref = O.loss_and_grads(s, r, n, x, p, 1, activation="relu")
+    tr = GRevNetTrainer(make_product_grevnet(hp, p))
+    out = tr.loss_and_grads(graph_from_arrays(n_node, ne, s, r, x, DEV))
+    torch.cuda.synchronize()
+    assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
+    for (name, a), (_, b) in zip(_flat_attn(tr.named_gradients(), False), _flat_attn(ref["grads"], False)):
+        assert np.abs(a - b).max() <= 5e-4 * np.abs(b).max() + 1e-5, name
+
+
 def test_training_loop_with_the_default_gnn_and_batch_norm(community_medium):
     """The drivers' defaults together (attention GNN + use_batch_norm=True): a few iterations reduce the loss."""
     from gnf_amd.train import GRevNetTrainer
