@@ -249,29 +249,13 @@ static int launch_gemm(const GemmJob* jobs, int nj, const GemmShape& sh, hipStre
     return GNF_OK;
 }
 
-// G[e] (+)= sum over chunks of slab[chunk][e]   (fixed order).  blockIdx.y = job.
+// G[e] (+)= sum over chunks of slab[chunk][e]   (fixed order)
 struct ReduceJob {
     const float* wslab;
     const float* bslab;
     float* gw;
     float* gb;
 };
-__global__ __launch_bounds__(256) void k_reduce_slabs(ReduceJob j0, ReduceJob j1, int64_t nw, int nb, int chunks,
-                                                      int accumulate) {
-    const ReduceJob job = blockIdx.y ? j1 : j0;
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e < nw) {
-        float s = 0.f;
-        for (int c = 0; c < chunks; ++c) s += job.wslab[(int64_t)c * nw + e];
-        job.gw[e] = accumulate ? job.gw[e] + s : s;
-    } else if (e < nw + nb) {
-        const int i = (int)(e - nw);
-        float s = 0.f;
-        for (int c = 0; c < chunks; ++c) s += job.bslab[(int64_t)c * nb + i];
-        job.gb[i] = accumulate ? job.gb[i] + s : s;
-    }
-}
-
 struct GroupedReduce {
     ReduceJob job[kMaxGroup];
     int64_t nw[kMaxGroup];
@@ -561,8 +545,9 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net) {
     p.lmax = lmax;
     // split of the node axis for dW: every weight gradient of the half-step goes out in ONE grouped launch, so a
     // few chunks already fill the chip; fewer chunks = fewer slabs to write and reduce
-    int64_t chunks = (n + 255) / 256;
-    if (chunks > 32) chunks = 32;
+    static const int chunk_rows = getenv("GNF_DW_CHUNK") ? atoi(getenv("GNF_DW_CHUNK")) : 256;  // developer knob
+    int64_t chunks = (n + chunk_rows - 1) / chunk_rows;
+    if (chunks > 64) chunks = 64;
     if (chunks < 1) chunks = 1;
     int64_t kchunk = (n + chunks - 1) / chunks;
     kchunk = (kchunk + TGK - 1) / TGK * TGK;
