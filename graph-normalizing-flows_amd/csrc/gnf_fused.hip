@@ -320,10 +320,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
     }
     for (int i = tid + kBiasRegs * kFusedThreads; i < bias_all; i += kFusedThreads)  // very wide nets only
         bias_lds[i] = i < a.bias_tot ? bsrc0[i] : bsrc1[i - a.bias_tot];
-    // ---- A: aggregate + combine into the layer-0 input of each net ----------------------------
-    // The tile's CSR slice is staged in LDS first (rowptr[row0..row0+TM], then the contiguous col
-    // segment, both coalesced), so that the neighbour-row gathers are independent loads issued 8 at a
-    // time instead of a rowptr -> col -> x chain of dependent global round trips per thread.
+    // ---- A: aggregate + combine into the layer-0 input of each net (tile_aggregate, gnf_fused_dev.h) ----
     GNF_PSTAMP(2);
     __syncthreads();
     GNF_PSTAMP(3);
@@ -338,72 +335,9 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
             if (NETS == 2) buf(1, 0)[rl * LS + c] = live ? a.h0[1][(int64_t)r * a.in0 + c] : 0.f;
         }
     } else {
-    const int seg_beg = s_rowptr[0];
-    const int seg_len = s_rowptr[TM] - seg_beg;
-#ifdef GNF_NO_STAGE_CSR
-    const bool staged = false;
-#else
-    const bool staged = seg_len <= kColCap;  // workgroup-uniform
-#endif
-    if (staged)
-        for (int i = tid; i < seg_len; i += kFusedThreads) s_col[i] = a.col[seg_beg + i];
-    __syncthreads();
-    GNF_PSTAMP(4);
-    {
-        const int in0p = a.ipg[0] * 16;
-        // sum of x_cond[nbr, f] over the incoming edges [beg, end) of one node, in edge order
-        auto gather = [&](int beg, int end, const float* xf, auto colat) -> float {
-            float s = 0.f;
-#ifndef GNF_ABL_NOAGG
-            int e = beg;
-            for (; e + 8 <= end; e += 8) {  // 8 independent row reads in flight
-                int ci[8];
-                float vv[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) ci[q] = colat(e + q);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) vv[q] = xf[(int64_t)ci[q] * a.ld];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) s += vv[q];
-            }
-            if (e < end) {  // up to 7 left: still issued together (indices clamped, adds predicated)
-                int ci[7];
-                float vv[7];
-#pragma unroll
-                for (int q = 0; q < 7; ++q) ci[q] = colat(e + q < end ? e + q : end - 1);
-#pragma unroll
-                for (int q = 0; q < 7; ++q) vv[q] = xf[(int64_t)ci[q] * a.ld];
-#pragma unroll
-                for (int q = 0; q < 7; ++q)
-                    if (e + q < end) s += vv[q];
-            }
-#endif
-            return s;
-        };
-        for (int idx = tid; idx < TM * in0p; idx += kFusedThreads) {
-            const int rl = idx / in0p, c = idx - rl * in0p;
-            const int r = row0 + rl;
-            float v = 0.f;
-            if (r < a.n_nodes && c < a.in0) {
-                const int f = c < H ? c : c - H;
-                if (a.concat && c < H) {
-                    v = a.x_cond[(int64_t)r * a.ld + f];
-                } else {
-                    const int beg = s_rowptr[rl], end = s_rowptr[rl + 1];
-                    const float* xf = a.x_cond + f;
-                    float s = staged ? gather(beg, end, xf, [&](int e) { return s_col[e - seg_beg]; })
-                                     : gather(beg, end, xf, [&](int e) { return a.col[e]; });
-                    if (a.mean) {
-                        const int cnt = end - beg;
-                        s = s / (float)(cnt > 1 ? cnt : 1);
-                    }
-                    v = a.concat ? s : a.eps * a.x_cond[(int64_t)r * a.ld + f] + s;
-                }
-            }
-            buf(0, 0)[rl * LS + c] = v;
-            if (NETS == 2) buf(1, 0)[rl * LS + c] = v;
-        }
-    }
+        const TileAgg ta{a.col, a.x_cond, a.ld, a.n_nodes, row0, H, a.in0, a.ipg[0] * 16, a.mean, a.concat, a.eps};
+        tile_aggregate<TM, kFusedThreads, kColCap>(ta, s_rowptr, s_col, buf(0, 0), NETS == 2 ? buf(1, 0) : nullptr, LS,
+                                                   nullptr, tid);
     }  // message-passing prologue
     GNF_STAMP(1);
     __syncthreads();

@@ -165,63 +165,8 @@ __global__ __launch_bounds__(kBwdThreads) void k_half_bwd_fused(const BwdArgs a)
             buf(1, 0)[rl * LS + c] = live ? a.h0_in[1][(int64_t)r * a.in0 + c] : 0.f;
         }
     } else {
-        const int seg_beg = s_rowptr[0];
-        const int seg_len = s_rowptr[TM] - seg_beg;
-        const bool staged = seg_len <= kBwdColCap;
-        if (staged)
-            for (int i = tid; i < seg_len; i += kBwdThreads) s_col[i] = a.col[seg_beg + i];
-        __syncthreads();
-        const int in0p = a.tab[0][0] * 16;
-        auto gather = [&](int beg, int end, const float* xf, auto colat) -> float {
-            float s = 0.f;
-            int e = beg;
-            for (; e + 8 <= end; e += 8) {
-                int ci[8];
-                float vv[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) ci[q] = colat(e + q);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) vv[q] = xf[(int64_t)ci[q] * a.ld];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) s += vv[q];
-            }
-            if (e < end) {
-                int ci[7];
-                float vv[7];
-#pragma unroll
-                for (int q = 0; q < 7; ++q) ci[q] = colat(e + q < end ? e + q : end - 1);
-#pragma unroll
-                for (int q = 0; q < 7; ++q) vv[q] = xf[(int64_t)ci[q] * a.ld];
-#pragma unroll
-                for (int q = 0; q < 7; ++q)
-                    if (e + q < end) s += vv[q];
-            }
-            return s;
-        };
-        for (int idx = tid; idx < TM * in0p; idx += kBwdThreads) {
-            const int rl = idx / in0p, c = idx - rl * in0p;
-            const int r = row0 + rl;
-            float v = 0.f;
-            if (r < a.n_nodes && c < a.in0) {
-                const int f = c < H ? c : c - H;
-                if (a.concat && c < H) {
-                    v = a.x_cond[(int64_t)r * a.ld + f];
-                } else {
-                    const int beg = s_rowptr[rl], end = s_rowptr[rl + 1];
-                    const float* xf = a.x_cond + f;
-                    float s = staged ? gather(beg, end, xf, [&](int e) { return s_col[e - seg_beg]; })
-                                     : gather(beg, end, xf, [&](int e) { return a.col[e]; });
-                    if (a.mean) {
-                        const int cnt = end - beg;
-                        s = s / (float)(cnt > 1 ? cnt : 1);
-                    }
-                    v = a.concat ? s : a.eps * a.x_cond[(int64_t)r * a.ld + f] + s;
-                }
-                a.h0_out[(int64_t)r * a.in0 + c] = v;
-            }
-            buf(0, 0)[rl * LS + c] = v;
-            buf(1, 0)[rl * LS + c] = v;
-        }
+        const TileAgg ta{a.col, a.x_cond, a.ld, a.n_nodes, row0, H, a.in0, a.tab[0][0] * 16, a.mean, a.concat, a.eps};
+        tile_aggregate<TM, kBwdThreads, kBwdColCap>(ta, s_rowptr, s_col, buf(0, 0), buf(1, 0), LS, a.h0_out, tid);
     }
     __syncthreads();
 

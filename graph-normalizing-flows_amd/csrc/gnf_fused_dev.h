@@ -220,4 +220,89 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
 
 
 
+// ---- A: aggregate + combine of one node tile into the layer-0 input (shared by the forward and backward
+// kernels; same arithmetic and order as gnn.py:103-104,117-118,123 | 108-109) ----------------------------
+// The tile's CSR slice is staged in LDS first (the caller has put rowptr[row0 .. row0+TM] into s_rowptr;
+// the contiguous col segment follows here, coalesced), so that the neighbour-row gathers are independent
+// loads issued 8 at a time instead of a rowptr -> col -> x chain of dependent global round trips per
+// thread.  Writes buf0 (and buf1 when non-NULL) [TM][LS] and, when h0_out != NULL, the true [n, in0] rows.
+struct TileAgg {
+    const int32_t* col;
+    const float* x_cond;
+    int64_t ld;
+    int n_nodes, row0, H, in0, in0p, mean, concat;
+    float eps;
+};
+
+template <int TM, int NTHR, int COLCAP>
+__device__ __forceinline__ void tile_aggregate(const TileAgg& t, const int* __restrict__ s_rowptr, int* __restrict__ s_col,
+                                               float* __restrict__ buf0, float* __restrict__ buf1, int LS,
+                                               float* __restrict__ h0_out, int tid) {
+    const int seg_beg = s_rowptr[0];
+    const int seg_len = s_rowptr[TM] - seg_beg;
+#ifdef GNF_NO_STAGE_CSR
+    const bool staged = false;
+#else
+    const bool staged = seg_len <= COLCAP;  // workgroup-uniform
+#endif
+    if (staged)
+        for (int i = tid; i < seg_len; i += NTHR) s_col[i] = t.col[seg_beg + i];
+    __syncthreads();
+    GNF_PSTAMP(4);
+    // sum of x_cond[nbr, f] over the incoming edges [beg, end) of one node, in edge order
+    auto gather = [&](int beg, int end, const float* xf, auto colat) -> float {
+        float s = 0.f;
+#ifndef GNF_ABL_NOAGG
+        int e = beg;
+        for (; e + 8 <= end; e += 8) {  // 8 independent row reads in flight
+            int ci[8];
+            float vv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ci[q] = colat(e + q);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) vv[q] = xf[(int64_t)ci[q] * t.ld];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += vv[q];
+        }
+        if (e < end) {  // up to 7 left: still issued together (indices clamped, adds predicated)
+            int ci[7];
+            float vv[7];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) ci[q] = colat(e + q < end ? e + q : end - 1);
+#pragma unroll
+            for (int q = 0; q < 7; ++q) vv[q] = xf[(int64_t)ci[q] * t.ld];
+#pragma unroll
+            for (int q = 0; q < 7; ++q)
+                if (e + q < end) s += vv[q];
+        }
+#endif
+        return s;
+    };
+    const int H = t.H, in0p = t.in0p;
+    for (int idx = tid; idx < TM * in0p; idx += NTHR) {
+        const int rl = idx / in0p, c = idx - rl * in0p;
+        const int r = t.row0 + rl;
+        float v = 0.f;
+        if (r < t.n_nodes && c < t.in0) {
+            const int f = c < H ? c : c - H;
+            if (t.concat && c < H) {
+                v = t.x_cond[(int64_t)r * t.ld + f];
+            } else {
+                const int beg = s_rowptr[rl], end = s_rowptr[rl + 1];
+                const float* xf = t.x_cond + f;
+                float s = staged ? gather(beg, end, xf, [&](int e) { return s_col[e - seg_beg]; })
+                                 : gather(beg, end, xf, [&](int e) { return t.col[e]; });
+                if (t.mean) {
+                    const int cnt = end - beg;
+                    s = s / (float)(cnt > 1 ? cnt : 1);
+                }
+                v = t.concat ? s : t.eps * t.x_cond[(int64_t)r * t.ld + f] + s;
+            }
+            if (h0_out) h0_out[(int64_t)r * t.in0 + c] = v;
+        }
+        buf0[rl * LS + c] = v;
+        if (buf1) buf1[rl * LS + c] = v;
+    }
+}
+
 }  // namespace gnf

@@ -683,7 +683,8 @@ static int launch_weight_grads(const BwdPlan& p, const WGJob* jobs, int nj, bool
     gr.chunks = p.chunks;
     gr.accumulate = accumulate ? 1 : 0;
     dim3 grid((unsigned)((maxN + TGN - 1) / TGN), (unsigned)((maxM + TGM - 1) / TGM), (unsigned)(nj * p.chunks));
-    hipLaunchKernelGGL(k_gemm_dw_grouped, grid, dim3(kGemmThreads), 0, st, gg);
+    static const int lds_pad = getenv("GNF_DW_LDS_PAD") ? atoi(getenv("GNF_DW_LDS_PAD")) : 0;  // developer knob
+    hipLaunchKernelGGL(k_gemm_dw_grouped, grid, dim3(kGemmThreads), (size_t)lds_pad, st, gg);
     GNF_LAUNCH_CHECK("k_gemm_dw_grouped");
     hipLaunchKernelGGL(k_reduce_grouped, dim3((unsigned)((maxred + 255) / 256), (unsigned)nj), dim3(256), 0, st, gr);
     GNF_LAUNCH_CHECK("k_reduce_grouped");

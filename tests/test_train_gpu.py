@@ -299,20 +299,21 @@ def test_training_loop_with_the_default_gnn_and_batch_norm(community_medium):
     assert losses[-1] < losses[0] - 0.05, losses
 
 
+@pytest.mark.parametrize("ws", [False, True], ids=["", "weight_sharing"])
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "gemm"])
-def test_gradients_with_batch_norm_vs_oracle(grid_small, fused):
+def test_gradients_with_batch_norm_vs_oracle(grid_small, fused, ws):
     """use_batch_norm=True (the drivers' default, run_grevnet.py:90): gradients of the MLP weights AND of every
     bijector's gamma / beta; the reversible walk also undoes the normalisation (reconstruction = x)."""
     from gnf_amd.train import GRevNetTrainer
     hp = dict(D=8, latent=32, K=3, T=2, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu",
-              weight_sharing=False)
+              weight_sharing=ws)
     nn, ne, s, r = _batch(grid_small, list(range(12)))
     n = int(nn.sum())
     rng = np.random.default_rng(31)
     x = (rng.standard_normal((n, 8)) * 1.5 + 0.5).astype(np.float32)
-    p = O.make_grevnet_params(8, 4, 32, 3, 2, final_scale=0.3)
+    p = O.make_grevnet_params(8, 4, 32, 3, 2, weight_sharing=ws, final_scale=0.3)
     p["bn"] = O.make_bn_params(9, 4, 2)
-    ref = O.loss_and_grads(s, r, n, x, p, 2)
+    ref = O.loss_and_grads(s, r, n, x, p, 2, ws)
     net = make_product_grevnet(hp, p)
     net.fused = fused
     tr = GRevNetTrainer(net)
@@ -321,7 +322,7 @@ def test_gradients_with_batch_norm_vs_oracle(grid_small, fused):
     assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
     np.testing.assert_allclose(out["reconstruction"].cpu().numpy(), x, atol=3e-4, rtol=3e-4)
     got = tr.named_gradients()
-    _check_grads(got, ref["grads"], False)
+    _check_grads(got, ref["grads"], ws)
     for half in range(2):
         for i in range(2):
             for key in ("gamma", "beta"):
