@@ -207,3 +207,25 @@ def test_transform_example_is_fully_connected_with_self_loops():
     pairs = set(zip(g.senders.tolist(), g.receivers.tolist()))
     assert pairs == {(a, b) for a in (0, 1) for b in (0, 1)} | {(a, b) for a in (2, 3, 4) for b in (2, 3, 4)}
     assert g.nodes.shape == (5, 4) and g.edges.shape[0] == 13
+
+
+def test_synthetic_datasets_mirror_the_reference_generators():
+    """grevnet_synthetic_data.py: complete digraph with self loops (n^2 edges, the self loop last in every
+    row as networkx lists it), moons / mixture-of-Gaussians features, every dataset name of DATASETS_MAP."""
+    import random
+    from gnf_amd import grevnet_synthetic_data as S
+    assert set(S.DATASETS_MAP) == {"moons_100", "moons_10", "moons_6", "mom_6_10", "mom_6_10_20", "mog_4", "mog_6",
+                                   "mog_9", "mog_4_rotate", "mog_4_6", "mog_4_9"}
+    s, r = S.fully_connected_edge_list(3)
+    assert list(zip(s.tolist(), r.tolist())) == [(0, 1), (0, 2), (0, 0), (1, 0), (1, 2), (1, 1), (2, 0), (2, 1), (2, 2)]
+    random.seed(1)
+    np.random.seed(1)
+    dd = S.DATASETS_MAP["mom_6_10"].get_next_batch_data_dicts(5)
+    assert all(d["n_node"] in (6, 10) and d["n_edge"] == d["n_node"] ** 2 and d["nodes"].shape == (d["n_node"], 2)
+               for d in dd)
+    g = S.DATASETS_MAP["mog_4"].get_next_batch(3)
+    assert g.nodes.shape == (12, 2) and g.n_edge.tolist() == [16, 16, 16]
+    assert int(g.senders.max()) == 11 and int(g.receivers.min()) == 0      # global node ids after batching
+    # mixture of Gaussians: one point near each of the four offsets
+    pts = g.nodes[:4].numpy()
+    assert sorted(np.sign(pts).astype(int).tolist()) == sorted([[-1, 1], [1, 1], [-1, -1], [1, -1]])
