@@ -350,3 +350,17 @@ def test_training_with_batch_norm_updates_moving_statistics(grid_small):
     # first bijector sees the raw data every step: its batch mean is the data mean, the moving mean crept towards it
     want = mm0 * 0.99 ** 25 + x[:, :4].mean(axis=0) * (1 - 0.99 ** 25)
     np.testing.assert_allclose(bn.moving_mean.cpu().numpy(), want, atol=1e-4)
+
+
+def test_randomised_parity_sweep():
+    """tools/fuzz_parity.py: random flow hyper-parameters (message passing / attention, batch norm, weight sharing,
+    K = 1..4, odd widths) x random ragged batches (isolated nodes, duplicated / directed edges, complete graphs, a
+    high-degree star) through forward, inverse and gradients on both kernel paths vs the float64 oracle."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    results = [fz.run_case(i, 20260928) for i in range(24)]
+    assert sum(r.startswith("ok") for r in results) >= 20, results
