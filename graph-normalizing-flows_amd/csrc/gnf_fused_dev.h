@@ -74,8 +74,11 @@ struct EpiArgs {
     int64_t dld;
     int width;                 // true (unpadded) output width of the layer
     int row0, n_nodes;
-    unsigned char* mask;       // LDS [TM][mld] bytes: written in mode 0, read in mode 1 (NULL: no mask)
-    int mld;
+    // act' as one bit per element: for every (M-tile m, accumulator row r, 16-column tile) the 64-lane ballot of
+    // "activation > 0" in the accumulator layout (lane = 16 * (row >> 2 & 3) + column).  The backward layer that
+    // produces dL/dh_j has exactly the layout the forward layer that produced h_j had, so it tests its own lane's bit.
+    unsigned long long* mask;  // LDS [MT * 4][mld] words, written in mode 0, read in mode 1 (NULL: no mask)
+    int mld;                   // 16-column tiles per mask row
     float act_slope;           // act' on the negative side (alpha, or 0 for relu)
 };
 
@@ -204,12 +207,17 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
                 if (EPI == EPI_PLAIN) {
                     out_lds[rl * LS + col] = fmaxf(v, slope * v);
                 } else {
+                    const int word = (4 * m + r) * ea.mld + nt0 + ts * b;
                     float o;
                     if (ea.mode == 0) {
                         o = fmaxf(v, slope * v);
-                        if (ea.mask) ea.mask[rl * ea.mld + col] = o > 0.f ? 1 : 0;
+                        if (ea.mask) {
+                            const unsigned long long bal = __ballot(o > 0.f);
+                            if (lane == 0) ea.mask[word] = bal;
+                        }
                     } else {
-                        o = (ea.mask == nullptr || ea.mask[rl * ea.mld + col]) ? v : v * ea.act_slope;
+                        const bool keep = ea.mask == nullptr || ((ea.mask[word] >> lane) & 1ull);
+                        o = keep ? v : v * ea.act_slope;
                     }
                     out_lds[rl * LS + col] = o;
                     if (ea.dump && ea.row0 + rl < ea.n_nodes && col < ea.width)
