@@ -228,16 +228,25 @@ struct GroupedGemm {
     int64_t K, kchunk;
     int32_t chunks;
 };
-__global__ __launch_bounds__(kGemmThreads) void k_gemm_dw_grouped(const GroupedGemm g) {
-    const int jz = blockIdx.z / g.chunks, chunk = blockIdx.z - jz * g.chunks;
+// 1-D grid, XCD-aware: workgroup b runs on XCD b % 8, and the tiles of one (job, chunk) - which share the chunk's
+// two operand panels - are all given to the same XCD (z % 8), so each panel is pulled into ONE L2 instead of eight
+// (PMC before: 14 % L2 hit rate, 109 MiB fetched per dispatch for 46 MiB of operands).
+__global__ __launch_bounds__(kGemmThreads) void k_gemm_dw_grouped(const GroupedGemm g, int gx, int gy, int nz) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per_z = gx * gy;
+    const int zi = slot / per_z, t = slot - zi * per_z;
+    const int z = xcd + 8 * zi;
+    if (z >= nz) return;
+    const int bx = t % gx, by = t / gx;
+    const int jz = z / g.chunks, chunk = z - jz * g.chunks;
     const int M = g.M[jz], N = g.N[jz];
-    if ((int)blockIdx.x * TGN >= N || (int)blockIdx.y * TGM >= M) return;  // grid covers the largest job
+    if (bx * TGN >= N || by * TGM >= M) return;  // the tile grid covers the largest job
     GemmShape sh;
     sh.lda = g.lda[jz], sh.ldb = g.ldb[jz], sh.ldc = N, sh.ldaux = 0;
     sh.M = M, sh.K = g.K, sh.N = N, sh.chunks = g.chunks, sh.kchunk = g.kchunk;
     sh.act = 0, sh.alpha = 0.f, sh.apply_act = 0;
     const GemmJob job = g.job[jz];
-    gemm_tile<OPND_MC, OPND_MC, EPI_SLAB>(job, sh, blockIdx.x, blockIdx.y, chunk);
+    gemm_tile<OPND_MC, OPND_MC, EPI_SLAB>(job, sh, bx, by, chunk);
 }
 
 template <int AK, int BK, int EPI>
@@ -682,8 +691,9 @@ static int launch_weight_grads(const BwdPlan& p, const WGJob* jobs, int nj, bool
     gg.chunks = p.chunks;
     gr.chunks = p.chunks;
     gr.accumulate = accumulate ? 1 : 0;
-    dim3 grid((unsigned)((maxN + TGN - 1) / TGN), (unsigned)((maxM + TGM - 1) / TGM), (unsigned)(nj * p.chunks));
-    hipLaunchKernelGGL(k_gemm_dw_grouped, grid, dim3(kGemmThreads), 0, st, gg);
+    const int gx = (maxN + TGN - 1) / TGN, gy = (maxM + TGM - 1) / TGM, nz = nj * p.chunks;
+    const unsigned blocks = 8u * (unsigned)((nz + 7) / 8) * (unsigned)(gx * gy);
+    hipLaunchKernelGGL(k_gemm_dw_grouped, dim3(blocks), dim3(kGemmThreads), 0, st, gg, gx, gy, nz);
     GNF_LAUNCH_CHECK("k_gemm_dw_grouped");
     hipLaunchKernelGGL(k_reduce_grouped, dim3((unsigned)((maxred + 255) / 256), (unsigned)nj), dim3(256), 0, st, gr);
     GNF_LAUNCH_CHECK("k_reduce_grouped");
