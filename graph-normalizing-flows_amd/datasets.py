@@ -84,8 +84,45 @@ class GraphDataset:
         return data_dicts_to_graphs_tuple(self.all.data_dicts(self.sample_ids(batch_size, "test"), self._features),
                                           device)
 
+    def get_random_test_batch(self, batch_size, device=None):            # graph_data.py:109-111
+        return self.get_next_test_batch(batch_size, device)
+
+    def full_n_nodes(self):                                              # graph_data.py:89-96
+        return [int(n) for n in self.all.n_node]
+
     def train_n_nodes(self):
         return [int(self.all.n_node[i]) for i in self.train_ids]
+
+    def test_n_nodes(self):
+        return [int(self.all.n_node[i]) for i in self.test_ids]
+
+
+class OverfitGraphDataset(GraphDataset):
+    """graph_data.py:125-203: train on a handful of graphs.  The train split is sorted by node count; either
+    the `num_graphs` smallest graphs, or the first graph of every size listed in `graph_sizes`, repeated
+    cyclically up to max(num_graphs, train_batch_size) entries (subset_graphs, graph_data.py:157-177); batches are
+    then drawn from that list exactly like GraphDataset's (uniformly with replacement, graph_data.py:194-203).
+    full / train / test_n_nodes all describe the subset, as in the reference (graph_data.py:147-154)."""
+
+    def __init__(self, dataset_name, num_graphs, train_batch_size, node_embedding_dim, graph_sizes=None,
+                 gaussian_scale=1.0, seed=12345):
+        super().__init__(dataset_name, node_embedding_dim, gaussian_scale, seed)
+        order = sorted(self.train_ids.tolist(), key=lambda i: int(self.all.n_node[i]))   # stable, like list.sort
+        if graph_sizes:
+            first = {}
+            for i in order:
+                first.setdefault(int(self.all.n_node[i]), i)
+            subset = [first[int(sz)] for sz in graph_sizes]                              # KeyError like the reference
+        else:
+            subset = order[:int(num_graphs)]
+        want = max(int(num_graphs), int(train_batch_size))
+        self.train_ids = np.array([subset[k % len(subset)] for k in range(want)], dtype=np.int64)
+
+    def full_n_nodes(self):
+        return self.train_n_nodes()
+
+    def test_n_nodes(self):
+        return self.train_n_nodes()
 
 
 def fully_connected_edges(n):

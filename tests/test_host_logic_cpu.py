@@ -229,3 +229,19 @@ def test_synthetic_datasets_mirror_the_reference_generators():
     # mixture of Gaussians: one point near each of the four offsets
     pts = g.nodes[:4].numpy()
     assert sorted(np.sign(pts).astype(int).tolist()) == sorted([[-1, 1], [1, 1], [-1, -1], [1, -1]])
+
+
+def test_overfit_graph_dataset_subset_rules():
+    """graph_data.py:125-177: smallest graphs of the train split (or the first graph of each requested size),
+    cycled up to max(num_graphs, train_batch_size)."""
+    from gnf_amd import datasets as D
+    full = D.GraphDataset("graph_rnn_community_medium", 4)
+    sizes = sorted(full.train_n_nodes())
+    ds = D.OverfitGraphDataset("graph_rnn_community_medium", 3, 8, 4)
+    assert len(ds.train_ids) == 8 and sorted(set(ds.train_n_nodes())) == sorted(set(sizes[:3]))
+    assert ds.full_n_nodes() == ds.train_n_nodes() == ds.test_n_nodes()
+    g = ds.get_next_train_batch(5)
+    assert set(g.n_node.tolist()) <= set(sizes[:3]) and g.nodes.shape[1] == 4
+    want = [sizes[0], sizes[-1]]
+    ds2 = D.OverfitGraphDataset("graph_rnn_community_medium", 2, 2, 4, graph_sizes=want)
+    assert ds2.train_n_nodes() == want
