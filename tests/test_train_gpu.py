@@ -42,8 +42,11 @@ def _flat(grads, ws):
 
 
 def _check_grads(got, ref, ws, scale=3e-4):
+    # a gradient that is zero by cancellation (the last bias of a t-net in front of a batch-norm bijector: the
+    # bijector removes the mean again) is judged against the flow's overall gradient scale
+    gmax = max(float(np.abs(b).max()) for _, b in _flat(ref, ws))
     for (name, a), (_, b) in zip(_flat(got, ws), _flat(ref, ws)):
-        tol = scale * float(np.abs(b).max()) + 1e-5
+        tol = scale * float(np.abs(b).max()) + 1e-5 + 1e-6 * gmax
         err = float(np.abs(a - b).max())
         assert err <= tol, f"{name}: max err {err:.3e} > {tol:.3e} (max|g| {np.abs(b).max():.3e})"
 
@@ -364,3 +367,27 @@ def test_randomised_parity_sweep():
     spec.loader.exec_module(fz)
     results = [fz.run_case(i, 20260928) for i in range(24)]
     assert sum(r.startswith("ok") for r in results) >= 20, results
+
+
+def test_gradients_on_a_batch_with_more_tiles_than_cus(community_medium):
+    """> 256 sixteen-node tiles: the fused backward kernel switches to 32-node workgroups (and the forward kernel
+    to its (2, 2) shape); gradients still match the oracle, with and without batch norm."""
+    from gnf_amd.train import GRevNetTrainer
+    hp = dict(D=16, latent=48, K=3, T=2, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu",
+              weight_sharing=False)
+    rng = np.random.default_rng(11)
+    nn, ne, s, r = _batch(community_medium, rng.choice(168, size=110, replace=True))
+    n = int(nn.sum())
+    assert (n + 15) // 16 > 256
+    x = rng.standard_normal((n, 16)).astype(np.float32)
+    for use_bn in (False, True):
+        p = O.make_grevnet_params(13, 8, 48, 3, 2, final_scale=0.3)
+        if use_bn:
+            p["bn"] = O.make_bn_params(14, 8, 2)
+        ref = O.loss_and_grads(s, r, n, x, p, 2)
+        tr = GRevNetTrainer(make_product_grevnet(hp, p))
+        out = tr.loss_and_grads(graph_from_arrays(nn, ne, s, r, x, DEV))
+        torch.cuda.synchronize()
+        assert abs(float(out["loss_per_node"]) - ref["total_loss"] / n) <= 1e-4
+        np.testing.assert_allclose(out["reconstruction"].cpu().numpy(), x, atol=3e-4, rtol=3e-4)
+        _check_grads(tr.named_gradients(), ref["grads"], False, scale=1e-3)
