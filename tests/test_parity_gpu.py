@@ -8,6 +8,7 @@ Tolerances (stated, fp32 path vs float64 oracle):
   integer work (CSR) bit-exact
 """
 import ctypes as C
+import os
 from functools import partial
 
 import numpy as np
@@ -570,3 +571,34 @@ def test_config5_full_size_properties():
     assert float((zl.nodes - zg.nodes).abs().max()) <= 2e-3
     zg2, ld2 = net(graph, inverse=True)
     assert torch.equal(zg2.nodes, zg.nodes) and float(ld2) == float(ld)
+
+
+def test_rccl_backend_initialises_and_reduces_on_this_box():
+    """One-rank RCCL communicator on the real GPU: the exact calls of bench.py's N > 1 path (init_process_group
+    with the "nccl" backend bound to the device, the 3 x fp64 all-reduce, barrier, the MAX all-reduce of the elapsed
+    time).  Multi-rank behaviour is covered by the gloo world_size-2 tests; this one proves the RCCL library loads
+    and runs collectives in this environment."""
+    import socket
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        sums = torch.tensor([1.5, -2.25, 42.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        dist.barrier()
+        t = torch.tensor([0.125], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        grad = torch.arange(1000, dtype=torch.float32, device=dev)
+        dist.all_reduce(grad, op=dist.ReduceOp.SUM)          # the flat gradient all-reduce of the training step
+        torch.cuda.synchronize()
+        assert sums.tolist() == [1.5, -2.25, 42.0] and float(t[0]) == 0.125 and float(grad[999]) == 999.0
+    finally:
+        dist.destroy_process_group()
