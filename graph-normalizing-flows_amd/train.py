@@ -291,6 +291,40 @@ class GRevNetTrainer:
             b.update_moving_statistics()
         self.global_step = t
 
+    # ---- checkpoint / resume (the drivers use tf.train.Saver, run_grevnet.py:379, 449-453) ---------------------
+    def state_dict(self):
+        """Everything a resumed run needs: parameters, Adam moments, step counter, batch-norm moving statistics."""
+        if self.theta is None:
+            raise _abi.GnfError("state_dict(): run a step (or loss_and_grads) first so that the variables exist")
+        return {"theta": self.theta.detach().cpu(), "m": self.m.detach().cpu(), "v": self.v.detach().cpu(),
+                "global_step": self.global_step,
+                "bn_moving": [(b.moving_mean.detach().cpu(), b.moving_variance.detach().cpu()) for b in self._bns]}
+
+    def load_state_dict(self, state):
+        if self.theta is None:
+            raise _abi.GnfError("load_state_dict(): connect the trainer first (run loss_and_grads on a batch)")
+        if state["theta"].numel() != self.theta.numel():
+            raise ValueError(f"checkpoint has {state['theta'].numel()} parameters, the flow has {self.theta.numel()}")
+        self.theta.copy_(state["theta"])
+        self.m.copy_(state["m"])
+        self.v.copy_(state["v"])
+        self.global_step = int(state["global_step"])
+        for b, (mm, mv) in zip(self._bns, state["bn_moving"]):
+            b.moving_mean.copy_(mm)
+            b.moving_variance.copy_(mv)
+        lib = _abi.lib()
+        dev = self.theta.device
+        with torch.cuda.device(dev):            # the matrix-core weight copies follow the restored parameters
+            flow = self.net._flow(self.net.mlps("s")[0].layer_sizes[-1], dev)
+            if self.net.fused:
+                _abi.check(lib.gnf_pack_flow(C.byref(flow), _abi.stream_ptr(dev)), "gnf_pack_flow")
+
+    def save_checkpoint(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load_checkpoint(self, path):
+        self.load_state_dict(torch.load(path, map_location="cpu"))
+
     def all_reduce_gradients(self, group=None):
         """Data parallelism: total_loss is a SUM over nodes (run_grevnet.py:295), so the gradient of the global
         batch is the sum of the shard gradients: one flat all-reduce of the whole gradient vector."""

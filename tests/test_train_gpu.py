@@ -391,3 +391,30 @@ def test_gradients_on_a_batch_with_more_tiles_than_cus(community_medium):
         assert abs(float(out["loss_per_node"]) - ref["total_loss"] / n) <= 1e-4
         np.testing.assert_allclose(out["reconstruction"].cpu().numpy(), x, atol=3e-4, rtol=3e-4)
         _check_grads(tr.named_gradients(), ref["grads"], False, scale=1e-3)
+
+
+def test_checkpoint_resume_reproduces_the_run(grid_small, tmp_path):
+    """save_checkpoint after 3 steps, load into a freshly built trainer: parameters, Adam moments, step counter and
+    batch-norm moving statistics come back, and the next step is bitwise the same as in the uninterrupted run."""
+    from gnf_amd.train import GRevNetTrainer
+    hp = dict(D=8, latent=32, K=3, T=2, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu",
+              weight_sharing=False)
+    nn, ne, s, r = _batch(grid_small, list(range(12)))
+    n = int(nn.sum())
+    x = np.random.default_rng(0).standard_normal((n, 8)).astype(np.float32)
+    p = O.make_grevnet_params(4, 4, 32, 3, 2, final_scale=0.3)
+    p["bn"] = O.make_bn_params(5, 4, 2)
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    a = GRevNetTrainer(make_product_grevnet(hp, p), lr=1e-3)
+    for _ in range(3):
+        a.step(graph)
+    a.save_checkpoint(str(tmp_path / "ckpt.pt"))
+    la = float(a.step(graph)["total_loss"])
+    b = GRevNetTrainer(make_product_grevnet(hp, p), lr=1e-3)
+    b.loss_and_grads(graph)                       # connect (creates the variables), then restore
+    b.load_checkpoint(str(tmp_path / "ckpt.pt"))
+    assert b.global_step == 3
+    lb = float(b.step(graph)["total_loss"])
+    assert la == lb
+    torch.testing.assert_close(a.theta, b.theta, rtol=0, atol=0)
+    torch.testing.assert_close(a.net.bns[1][0].moving_variance, b.net.bns[1][0].moving_variance, rtol=0, atol=0)
