@@ -103,6 +103,8 @@ def main():
             print(f"log det jacobian: {float(v['log_det_jacobian']):.4f}")
             print(f"original mean {graph.nodes.mean(0).cpu().numpy()} std dev {graph.nodes.std(0).cpu().numpy()}")
             print(f"transformed mean {z.mean(0).cpu().numpy()} std dev {z.std(0).cpu().numpy()}")
+            print(f"device memory: {torch.cuda.memory_allocated(dev) / 2**20:.1f} MiB allocated, "
+                  f"{torch.cuda.max_memory_allocated(dev) / 2**20:.1f} MiB peak")
             if not np.isfinite(float(v["total_loss"])):
                 raise SystemExit("loss is not finite")
     out = sample(grevnet, dataset.get_next_batch(F.train_batch_size, dev))     # run_grevnet.py:304-311
