@@ -5,6 +5,7 @@ dicts (grevnet_synthetic_data.py:28-43); `get_next_batch` returns this package's
 networkx is not needed: the complete digraph's edge list is written directly, in networkx's edge order
 (complete_graph(create_using=DiGraph) + add_edges_from(zip(r, r)): adjacency iteration, self loop last in
 every row)."""
+import functools
 import random
 from functools import partial
 
@@ -17,17 +18,22 @@ GAUSSIAN_MEAN = [0, 0]
 GAUSSIAN_COV = [[1, 0], [0, 1]]
 
 
+@functools.lru_cache(maxsize=64)
+def _fully_connected_edge_list(num_nodes):
+    m = np.arange(num_nodes, dtype=np.int32)
+    grid = np.tile(m, (num_nodes, 1))
+    off_diag = grid[grid != m[:, None]].reshape(num_nodes, num_nodes - 1)
+    receivers = np.concatenate([off_diag, m[:, None]], axis=1).ravel()      # the self loop was added last
+    senders = np.repeat(m, num_nodes)
+    senders.setflags(write=False)
+    receivers.setflags(write=False)
+    return senders, receivers
+
+
 def fully_connected_edge_list(num_nodes):
-    """Edges of fully_connected_nx_graph (grevnet_synthetic_data.py:17-21) in `g.edges()` order."""
-    senders, receivers = [], []
-    for u in range(num_nodes):
-        for v in range(num_nodes):
-            if v != u:
-                senders.append(u)
-                receivers.append(v)
-        senders.append(u)          # the self loop was added last
-        receivers.append(u)
-    return np.asarray(senders, np.int32), np.asarray(receivers, np.int32)
+    """Edges of fully_connected_nx_graph (grevnet_synthetic_data.py:17-21) in `g.edges()` order: for every node u
+    its out-edges to v != u ascending, then the self loop (cached per size; read-only arrays)."""
+    return _fully_connected_edge_list(int(num_nodes))
 
 
 class SyntheticDataset:
