@@ -360,7 +360,7 @@ int validate_attn(const GnfAttn* at, const GnfMlp* mlp, int32_t H, const char* w
 template <int KQM, int VDM, bool WIN>
 __device__ __forceinline__ void attn_fwd_thread(const AttnArgs& a, const float* __restrict__ qkv, int r, int h,
                                                 const float* win, int win_lo, int WS, const int* cols, int col_base,
-                                                float* agg_row) {
+                                                bool v2, float* agg_row) {
     const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd;
     float kreg[KQM], ag[VDM];
 #pragma unroll
@@ -369,22 +369,24 @@ __device__ __forceinline__ void attn_fwd_thread(const AttnArgs& a, const float* 
     for (int j = 0; j < VDM; ++j) ag[j] = 0.f;
     float m = -INFINITY, z = 0.f;
     const int beg = a.rowptr[r], end = a.rowptr[r + 1];
-    for (int e = beg; e < end; ++e) {
-        const int s_ = cols[e - col_base];  // LDS slice (col_base = first edge of the tile) or the global array (0)
-        float lg = 0.f, vv[VDM];
+    // edges four at a time: the four column indices, then the four rows, are independent loads issued together;
+    // only the softmax recurrence is sequential (a thread walking its row one edge at a time waits for
+    // col -> row -> arithmetic on every edge)
+    auto fetch = [&](int s_, float (&qq)[KQM], float (&vv)[VDM]) {
         if (WIN) {
             const float* row = win + (s_ - win_lo) * WS;
-#pragma unroll
-            for (int j = 0; j < KQM; ++j) lg += (j < kq ? row[h * kq + j] : 0.f) * kreg[j];
-#pragma unroll
-            for (int j = 0; j < VDM; ++j) vv[j] = j < vd ? row[nq + j] : 0.f;
+            load_row<KQM>(row + h * kq, kq, v2, qq);
+            load_row<VDM>(row + nq, vd, v2, vv);
         } else {
             const float* row = qkv + (int64_t)s_ * P;
-#pragma unroll
-            for (int j = 0; j < KQM; ++j) lg += (j < kq ? row[h * kq + j] : 0.f) * kreg[j];
-#pragma unroll
-            for (int j = 0; j < VDM; ++j) vv[j] = j < vd ? row[2 * nq + j] : 0.f;
+            load_row<KQM>(row + h * kq, kq, v2, qq);
+            load_row<VDM>(row + 2 * nq, vd, v2, vv);
         }
+    };
+    auto update = [&](const float (&qq)[KQM], const float (&vv)[VDM]) {
+        float lg = 0.f;
+#pragma unroll
+        for (int j = 0; j < KQM; ++j) lg += qq[j] * kreg[j];
         lg *= a.scale;
         const float mn = fmaxf(m, lg);
         const float sc = __expf(m - mn), pe = __expf(lg - mn);
@@ -392,6 +394,22 @@ __device__ __forceinline__ void attn_fwd_thread(const AttnArgs& a, const float* 
 #pragma unroll
         for (int j = 0; j < VDM; ++j) ag[j] = ag[j] * sc + pe * vv[j];
         m = mn;
+    };
+    int e = beg;
+    for (; e + 4 <= end; e += 4) {
+        int s4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s4[u] = cols[e + u - col_base];
+        float qq[4][KQM], vv[4][VDM];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fetch(s4[u], qq[u], vv[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) update(qq[u], vv[u]);
+    }
+    for (; e < end; ++e) {
+        float qq[KQM], vv[VDM];
+        fetch(cols[e - col_base], qq, vv);
+        update(qq, vv);
     }
     const float inv = end > beg ? 1.f / z : 0.f;
 #pragma unroll
@@ -399,9 +417,20 @@ __device__ __forceinline__ void attn_fwd_thread(const AttnArgs& a, const float* 
         if (j < vd) agg_row[h * vd + j] = ag[j] * inv;
 }
 
+#ifdef GNF_ATTN_TRACE  // developer build: cycle stamps of workgroup 0 / thread 0 at the phase boundaries
+__device__ unsigned long long g_attn_trace[16];
+#define GNF_ATRACE(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_attn_trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int gnf_debug_read_attn_trace(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_trace), sizeof(unsigned long long) * 16);
+}
+#else
+#define GNF_ATRACE(i)
+#endif
+
 template <int KQM, int VDM>
 __global__ __launch_bounds__(512) void k_attn_fwd_rows(const AttnArgs a, int win_cap) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    GNF_ATRACE(0);
     const int net = blockIdx.y;
     const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd, C = a.C, H = a.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -412,7 +441,7 @@ __global__ __launch_bounds__(512) void k_attn_fwd_rows(const AttnArgs a, int win
     float* agg_s = wo + NV * C;                            // [64][NV + 1]
     int* s_col = reinterpret_cast<int*>(agg_s + kRowsTile * (NV + 1));  // [kRowsColCap]
     float* win = reinterpret_cast<float*>(s_col + kRowsColCap);          // [cap][WS]
-    const int WS = nq + vd + 1;
+    const int WS = (nq + vd + 2) & ~1;  // even: rows stay 8-byte aligned
     if (tid <= kRowsTile) {
         const int r = row0 + tid;
         s_rp[tid] = a.rowptr[r < a.n_nodes ? r : a.n_nodes];
@@ -434,38 +463,60 @@ __global__ __launch_bounds__(512) void k_attn_fwd_rows(const AttnArgs a, int win
         }
     }
     __syncthreads();
+    GNF_ATRACE(1);
     const float* qkv = a.qkv[net];
     const int lo = stage_window(a.col, s_rp, kRowsTile, s_hdr, win_cap, tid, 512, [&](int lo_, int cnt) {
         window_copy(win, WS, cnt, nq + vd, tid, 512, [&](int rr, int c) {
             return qkv[(int64_t)(lo_ + rr) * P + (c < nq ? c : nq + c)];   // q at [0, nq), v at [2 nq, 2 nq + vd)
         });
     });
+    GNF_ATRACE(2);
     const bool cols_in_lds = stage_cols(a.col, s_rp, kRowsTile, s_col, kRowsColCap, tid, 512);
     __syncthreads();
+    GNF_ATRACE(3);
     const int* cols = cols_in_lds ? s_col : a.col;
     const int col_base = cols_in_lds ? s_rp[0] : 0;
     const int r = row0 + lane;
     if (wave < nh && r < a.n_nodes) {
+        // 8-byte reads when every row segment is even-sized and 8-byte aligned (window base / qkv base and row stride)
+        const bool even = ((kq | vd | nq) & 1) == 0;
         if (lo >= 0)
-            attn_fwd_thread<KQM, VDM, true>(a, qkv, r, wave, win, lo, WS, cols, col_base, agg_s + lane * (NV + 1));
+            attn_fwd_thread<KQM, VDM, true>(a, qkv, r, wave, win, lo, WS, cols, col_base,
+                                            even && (reinterpret_cast<uintptr_t>(win) & 7) == 0, agg_s + lane * (NV + 1));
         else
-            attn_fwd_thread<KQM, VDM, false>(a, qkv, r, wave, win, 0, WS, cols, col_base, agg_s + lane * (NV + 1));
+            attn_fwd_thread<KQM, VDM, false>(a, qkv, r, wave, win, 0, WS, cols, col_base,
+                                             even && (reinterpret_cast<uintptr_t>(qkv) & 7) == 0, agg_s + lane * (NV + 1));
     }
+    GNF_ATRACE(4);
     __syncthreads();
+    GNF_ATRACE(5);
     // output projection new = agg Wo (Wo broadcast from LDS, agg row per lane) and h0 = [x || new] | new
     float* h0 = a.h0[net];
     const int off = a.concat ? H : 0;
     if (r < a.n_nodes) {
+        // wave w takes the contiguous columns [w * cw, (w + 1) * cw): per agg element one LDS read of it and a run of
+        // consecutive Wo values (broadcast), instead of two LDS reads per multiply-add
         const float* ar = agg_s + lane * (NV + 1);
-        for (int c = wave; c < C; c += 8) {
-            float acc = 0.f;
-#pragma unroll 8
-            for (int i = 0; i < NV; ++i) acc += ar[i] * wo[i * C + c];
-            h0[(int64_t)r * a.in0 + off + c] = acc;
+        const int cw = (C + 7) / 8;
+        for (int c0 = wave * cw; c0 < C && c0 < (wave + 1) * cw; c0 += 10) {
+            float acc[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+            const int nc = C - c0 < (wave + 1) * cw - c0 ? C - c0 : (wave + 1) * cw - c0;
+            for (int i = 0; i < NV; ++i) {
+                const float av = ar[i];
+                const float* wrow = wo + i * C + c0;
+#pragma unroll
+                for (int k = 0; k < 10; ++k) acc[k] += av * (k < nc ? wrow[k] : 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 10; ++k)
+                if (k < nc) h0[(int64_t)r * a.in0 + off + c0 + k] = acc[k];
         }
         if (a.concat)
             for (int f = wave; f < H; f += 8) h0[(int64_t)r * a.in0 + f] = a.x[(int64_t)r * a.ldx + f];
     }
+    GNF_ATRACE(6);
 }
 
 size_t attn_scratch_floats(const GnfAttn* at, int64_t n_nodes, int32_t in0) {
@@ -536,8 +587,8 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
         const int NV = a.nh * a.v, nq = a.nh * a.kq;
         const size_t fixed = (size_t)(kRowsTile + 1 + 3 + kRowsColCap) * sizeof(int) +
                              ((size_t)NV * a.C + (size_t)kRowsTile * (NV + 1)) * sizeof(float);
-        if (fixed + 64 * (size_t)(nq + a.v + 1) * sizeof(float) <= (size_t)kRowsLdsBudget) {
-            const int cap = (int)((kRowsLdsBudget - fixed) / ((size_t)(nq + a.v + 1) * sizeof(float)));
+        if (fixed + 64 * (size_t)(nq + a.v + 2) * sizeof(float) <= (size_t)kRowsLdsBudget) {
+            const int cap = (int)((kRowsLdsBudget - fixed) / ((size_t)(nq + a.v + 2) * sizeof(float)));
             static bool attr_set3 = false;
             if (!attr_set3) {
                 GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_fwd_rows<10, 10>),

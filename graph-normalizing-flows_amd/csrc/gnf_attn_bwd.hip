@@ -394,7 +394,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_send(const AttnBwdArgs a, int 
 // ------------------------------------------------------------------------------------------------
 template <int KQM, int VDM, bool WIN>
 __device__ __forceinline__ void attn_recv_thread(const AttnBwdArgs& a, int net, int r, int h, const float* win,
-                                                 int win_lo, int WS, const int* cols, int col_base) {
+                                                 int win_lo, int WS, const int* cols, int col_base, bool v2) {
     const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
     const float* qkv = a.qkv[net];
     float kreg[KQM], dreg[VDM];
@@ -413,20 +413,44 @@ __device__ __forceinline__ void attn_recv_thread(const AttnBwdArgs& a, int net, 
         }
     };
     float m = -INFINITY, z = 0.f, s1 = 0.f;
-    for (int e = beg; e < end; ++e) {
+    // edges four at a time: column indices and rows of a chunk are independent loads issued together; only the
+    // recurrences are sequential
+    auto fetch = [&](int s_, float (&qv)[KQM], float (&vv)[VDM]) {
         const float *qrow, *vrow;
-        row_of(cols[e - col_base], qrow, vrow);
+        row_of(s_, qrow, vrow);
+        load_row<KQM>(qrow, kq, v2, qv);
+        load_row<VDM>(vrow, vd, v2, vv);
+    };
+    auto stat = [&](const float (&qv)[KQM], const float (&vv)[VDM]) {
         float lg = 0.f, dw = 0.f;
 #pragma unroll
-        for (int j = 0; j < KQM; ++j) lg += (j < kq ? qrow[j] : 0.f) * kreg[j];
+        for (int j = 0; j < KQM; ++j) lg += qv[j] * kreg[j];
 #pragma unroll
-        for (int j = 0; j < VDM; ++j) dw += (j < vd ? vrow[j] : 0.f) * dreg[j];
+        for (int j = 0; j < VDM; ++j) dw += vv[j] * dreg[j];
         lg *= a.scale;
         const float mn = fmaxf(m, lg);
         const float sc = __expf(m - mn), pe = __expf(lg - mn);
         z = z * sc + pe;
         s1 = s1 * sc + pe * dw;
         m = mn;
+    };
+    {
+        int e = beg;
+        for (; e + 4 <= end; e += 4) {
+            int s4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s4[u] = cols[e + u - col_base];
+            float qv[4][KQM], vv[4][VDM];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fetch(s4[u], qv[u], vv[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) stat(qv[u], vv[u]);
+        }
+        for (; e < end; ++e) {
+            float qv[KQM], vv[VDM];
+            fetch(cols[e - col_base], qv, vv);
+            stat(qv, vv);
+        }
     }
     const float sumw = end > beg ? s1 / z : 0.f;
     const float zz = end > beg ? z : 1.f;
@@ -441,26 +465,36 @@ __device__ __forceinline__ void attn_recv_thread(const AttnBwdArgs& a, int net, 
     for (int j = 0; j < KQM; ++j) dk[j] = 0.f;
 #pragma unroll
     for (int j = 0; j < VDM; ++j) ag[j] = 0.f;
-    for (int e = beg; e < end; ++e) {
-        const float *qrow, *vrow;
-        row_of(cols[e - col_base], qrow, vrow);
-        float lg = 0.f, dw = 0.f, qv[KQM], vv[VDM];
+    auto accum = [&](const float (&qv)[KQM], const float (&vv)[VDM]) {
+        float lg = 0.f, dw = 0.f;
 #pragma unroll
-        for (int j = 0; j < KQM; ++j) {
-            qv[j] = j < kq ? qrow[j] : 0.f;
-            lg += qv[j] * kreg[j];
-        }
+        for (int j = 0; j < KQM; ++j) lg += qv[j] * kreg[j];
 #pragma unroll
-        for (int j = 0; j < VDM; ++j) {
-            vv[j] = j < vd ? vrow[j] : 0.f;
-            dw += vv[j] * dreg[j];
-        }
+        for (int j = 0; j < VDM; ++j) dw += vv[j] * dreg[j];
         const float w = __expf(lg * a.scale - m) / zz;
         const float dl = w * (dw - sumw);
 #pragma unroll
         for (int j = 0; j < KQM; ++j) dk[j] += dl * qv[j];
 #pragma unroll
         for (int j = 0; j < VDM; ++j) ag[j] += w * vv[j];
+    };
+    {
+        int e = beg;
+        for (; e + 4 <= end; e += 4) {
+            int s4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s4[u] = cols[e + u - col_base];
+            float qv[4][KQM], vv[4][VDM];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fetch(s4[u], qv[u], vv[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) accum(qv[u], vv[u]);
+        }
+        for (; e < end; ++e) {
+            float qv[KQM], vv[VDM];
+            fetch(cols[e - col_base], qv, vv);
+            accum(qv, vv);
+        }
     }
 #pragma unroll
     for (int j = 0; j < KQM; ++j)
@@ -481,7 +515,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_recv_rows(const AttnBwdArgs a,
     int* s_hdr = s_rp + kRowsTile + 1;
     int* s_col = s_hdr + 3;
     float* win = reinterpret_cast<float*>(s_col + kRowsColCap);
-    const int WS = nq + vd + 1;
+    const int WS = (nq + vd + 2) & ~1;  // even: rows stay 8-byte aligned
     if (tid <= kRowsTile) {
         const int r = row0 + tid;
         s_rp[tid] = a.rowptr[r < a.n ? r : a.n];
@@ -499,17 +533,20 @@ __global__ __launch_bounds__(512) void k_attn_bwd_recv_rows(const AttnBwdArgs a,
     const int col_base = cols_in_lds ? s_rp[0] : 0;
     const int r = row0 + lane;
     if (wave < nh && r < a.n) {
+        const bool even = ((kq | vd | nq) & 1) == 0;
         if (lo >= 0)
-            attn_recv_thread<KQM, VDM, true>(a, net, r, wave, win, lo, WS, cols, col_base);
+            attn_recv_thread<KQM, VDM, true>(a, net, r, wave, win, lo, WS, cols, col_base,
+                                             even && (reinterpret_cast<uintptr_t>(win) & 7) == 0);
         else
-            attn_recv_thread<KQM, VDM, false>(a, net, r, wave, win, 0, WS, cols, col_base);
+            attn_recv_thread<KQM, VDM, false>(a, net, r, wave, win, 0, WS, cols, col_base,
+                                              even && (reinterpret_cast<uintptr_t>(qkv) & 7) == 0);
     }
 }
 
 // sender side: window rows = the receivers' k | dagg (row stride WS); their softmax statistics from global memory
 template <int KQM, int VDM, bool WIN>
 __device__ __forceinline__ void attn_send_thread(const AttnBwdArgs& a, int net, int u_, int h, const float* win,
-                                                 int win_lo, int WS, const int* cols, int col_base, float* dvp_out) {
+                                                 int win_lo, int WS, const int* cols, int col_base, bool v2, float* dvp_out) {
     const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
     const float* qkv = a.qkv[net];
     const float* dagg = a.dagg[net];
@@ -526,8 +563,7 @@ __device__ __forceinline__ void attn_send_thread(const AttnBwdArgs& a, int net, 
         dvp[j] = 0.f;
     }
     const int beg = a.rowptr_t[u_], end = a.rowptr_t[u_ + 1];
-    for (int e = beg; e < end; ++e) {
-        const int r = cols[e - col_base];
+    auto fetch = [&](int r, float (&kv)[KQM], float (&dv_)[VDM], float (&st3)[3]) {
         const float *krow, *drow;
         if (WIN) {
             krow = win + (r - win_lo) * WS + h * kq;
@@ -537,24 +573,42 @@ __device__ __forceinline__ void attn_send_thread(const AttnBwdArgs& a, int net, 
             drow = dagg + (int64_t)r * NV + h * vd;
         }
         const float* st = stats + (int64_t)r * 3 * nh;
-        const float st_m = st[h], st_z = st[nh + h], st_s = st[2 * nh + h];
-        float lg = 0.f, dw = 0.f, kv[KQM], dv_[VDM];
+        st3[0] = st[h];
+        st3[1] = st[nh + h];
+        st3[2] = st[2 * nh + h];
+        load_row<KQM>(krow, kq, v2, kv);
+        load_row<VDM>(drow, vd, v2, dv_);
+    };
+    auto accum = [&](const float (&kv)[KQM], const float (&dv_)[VDM], const float (&st3)[3]) {
+        float lg = 0.f, dw = 0.f;
 #pragma unroll
-        for (int j = 0; j < KQM; ++j) {
-            kv[j] = j < kq ? krow[j] : 0.f;
-            lg += kv[j] * qreg[j];
-        }
+        for (int j = 0; j < KQM; ++j) lg += kv[j] * qreg[j];
 #pragma unroll
-        for (int j = 0; j < VDM; ++j) {
-            dv_[j] = j < vd ? drow[j] : 0.f;
-            dw += dv_[j] * vreg[j];
-        }
-        const float w = __expf(lg * a.scale - st_m) / st_z;
-        const float dl = w * (dw - st_s);
+        for (int j = 0; j < VDM; ++j) dw += dv_[j] * vreg[j];
+        const float w = __expf(lg * a.scale - st3[0]) / st3[1];
+        const float dl = w * (dw - st3[2]);
 #pragma unroll
         for (int j = 0; j < KQM; ++j) dq[j] += dl * kv[j];
 #pragma unroll
         for (int j = 0; j < VDM; ++j) dvp[j] += w * dv_[j];
+    };
+    {
+        int e = beg;
+        for (; e + 4 <= end; e += 4) {  // four edges' loads in flight together
+            int r4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r4[u] = cols[e + u - col_base];
+            float kv[4][KQM], dv_[4][VDM], st3[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fetch(r4[u], kv[u], dv_[u], st3[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) accum(kv[u], dv_[u], st3[u]);
+        }
+        for (; e < end; ++e) {
+            float kv[KQM], dv_[VDM], st3[3];
+            fetch(cols[e - col_base], kv, dv_, st3);
+            accum(kv, dv_, st3);
+        }
     }
 #pragma unroll
     for (int j = 0; j < KQM; ++j)
@@ -574,7 +628,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_send_rows(const AttnBwdArgs a,
     int* s_hdr = s_rp + kRowsTile + 1;
     int* s_col = s_hdr + 3;
     float* win = reinterpret_cast<float*>(s_col + kRowsColCap);
-    const int WS = nq + NV + 1;
+    const int WS = (nq + NV + 2) & ~1;  // even: rows stay 8-byte aligned
     if (tid <= kRowsTile) {
         const int r = row0 + tid;
         s_rp[tid] = a.rowptr_t[r < a.n ? r : a.n];
@@ -596,10 +650,13 @@ __global__ __launch_bounds__(512) void k_attn_bwd_send_rows(const AttnBwdArgs a,
 #pragma unroll
     for (int j = 0; j < VDM; ++j) dvp[j] = 0.f;
     if (wave < nh && u_ < a.n) {
+        const bool even = ((kq | vd | nq | NV) & 1) == 0;
         if (lo >= 0)
-            attn_send_thread<KQM, VDM, true>(a, net, u_, wave, win, lo, WS, cols, col_base, dvp);
+            attn_send_thread<KQM, VDM, true>(a, net, u_, wave, win, lo, WS, cols, col_base,
+                                             even && (reinterpret_cast<uintptr_t>(win) & 7) == 0, dvp);
         else
-            attn_send_thread<KQM, VDM, false>(a, net, u_, wave, win, 0, WS, cols, col_base, dvp);
+            attn_send_thread<KQM, VDM, false>(a, net, u_, wave, win, 0, WS, cols, col_base,
+                                              even && ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(dagg)) & 7) == 0, dvp);
     }
     // v is shared by the heads: dv[u, :] = sum over the head waves (through the LDS region the window occupied)
     __syncthreads();
@@ -737,10 +794,10 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
     static const bool lane_feature = getenv("GNF_ATTN_LANE_FEATURE") != nullptr;  // developer A/B switch
     if (!lane_feature && a.nh <= kRowsMaxHeads && a.kq <= 32 && a.v <= 32) {
         const size_t fixed_r = (size_t)(kRowsTile + 1 + 3 + kRowsColCap) * sizeof(int);
-        const int capr = (int)((kRowsLdsBudget - fixed_r) / ((size_t)(nq + a.v + 1) * sizeof(float)));
-        const int caps = (int)((kRowsLdsBudget - fixed_r) / ((size_t)(nq + NV + 1) * sizeof(float)));
+        const int capr = (int)((kRowsLdsBudget - fixed_r) / ((size_t)(nq + a.v + 2) * sizeof(float)));
+        const int caps = (int)((kRowsLdsBudget - fixed_r) / ((size_t)(nq + NV + 2) * sizeof(float)));
         // the sender pass re-uses the window region for its head reduction: 8 x 64 x VDM floats must fit
-        if (capr >= 64 && (size_t)caps * (nq + NV + 1) >= (size_t)8 * 64 * 32) {
+        if (capr >= 64 && (size_t)caps * (nq + NV) >= (size_t)8 * 64 * 32) {
             static bool attr_set2 = false;
             if (!attr_set2) {
                 const void* ks[4] = {reinterpret_cast<const void*>(k_attn_bwd_recv_rows<10, 10>),

@@ -21,10 +21,18 @@ __device__ __forceinline__ int stage_window(const int32_t* __restrict__ col, con
     __syncthreads();
     const int e0 = s_rp[0], e1 = s_rp[nrows];
     int lo = 0x7fffffff, hi = -1;
-    for (int e = e0 + tid; e < e1; e += nthr) {
-        const int c = col[e];
-        lo = c < lo ? c : lo;
-        hi = c > hi ? c : hi;
+    for (int base = e0; base < e1; base += nthr * 8) {  // eight loads in flight per thread (a load-compare loop is one
+        int reg[8];                                     // memory round trip per iteration)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = base + tid + q * nthr;
+            reg[q] = col[e < e1 ? e : e1 - 1];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            lo = reg[q] < lo ? reg[q] : lo;
+            hi = reg[q] > hi ? reg[q] : hi;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         const int l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
@@ -83,6 +91,38 @@ __device__ __forceinline__ bool stage_cols(const int32_t* __restrict__ col, cons
         }
     }
     return true;
+}
+
+// out[0 .. NM) <- p[0 .. cnt), zero beyond.  v2 (block-uniform): p is 8-byte aligned and cnt even -> 8-byte reads (half the
+// LDS / memory instructions of the edge loops, which are issue-bound on dense graphs).
+typedef float f32x2_attn __attribute__((ext_vector_type(2)));
+template <int NM>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, int cnt, bool v2, float (&out)[NM]) {
+    if (cnt == NM) {  // the width the instance was built for (block-uniform): no per-element predicates
+        if (v2) {
+#pragma unroll
+            for (int j = 0; j + 1 < NM; j += 2) {
+                const f32x2_attn t = *reinterpret_cast<const f32x2_attn*>(p + j);
+                out[j] = t[0];
+                out[j + 1] = t[1];
+            }
+            if (NM & 1) out[NM - 1] = p[NM - 1];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NM; ++j) out[j] = p[j];
+        }
+    } else if (v2) {
+#pragma unroll
+        for (int j = 0; j < NM; j += 2) {
+            f32x2_attn t = {0.f, 0.f};
+            if (j < cnt) t = *reinterpret_cast<const f32x2_attn*>(p + j);
+            out[j] = t[0];
+            if (j + 1 < NM) out[j + 1] = t[1];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NM; ++j) out[j] = j < cnt ? p[j] : 0.f;
+    }
 }
 
 // thread = (row, head) kernels: wave w = head w, lane = row inside the 64-row tile
