@@ -334,6 +334,35 @@ def main():
         rebuild = {"ms_per_step": round(1e3 * dt / nreb, 4), "value": round(n_global * HP["T"] * nreb / dt, 1),
                    "note": "gnf_build_csr (5 small kernels) + torch allocations inside every step"}
 
+    # ---- secondary figure: the PCIe-inclusive rate.  The C ABI takes device pointers, but the reference's drivers
+    # hand every batch over as host arrays (feed_dict of a GraphsTuple, run_grevnet.py:440-447): here the batch's
+    # nodes / senders / receivers / n_node / n_edge start in pinned host memory every step, are uploaded, the CSR
+    # is rebuilt on device, then the same forward runs.  Never the headline value.
+    host_fed = None
+    if not inverse and world == 1 and trainer is None:
+        from gnf_amd.graphs import clear_csr_cache
+        fields = ("nodes", "senders", "receivers", "n_node", "n_edge")
+        pinned = {f: getattr(graph, f).cpu().pin_memory() for f in fields}
+        nfed = max(10, min(50, args.steps))
+
+        def fed_step(i):
+            g2 = graph._replace(**{f: pinned[f].to(dev, non_blocking=True) for f in fields})
+            _, s3 = forward_shard_sums(net, g2, sums3)
+            host[i].copy_(s3, non_blocking=True)
+        for i in range(3):
+            fed_step(0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(nfed):
+            fed_step(args.warmup + args.steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        clear_csr_cache()
+        up = sum(int(v.numel()) * v.element_size() for v in pinned.values())
+        host_fed = {"ms_per_step": round(1e3 * dt / nfed, 4), "value": round(n_global * HP["T"] * nfed / dt, 1),
+                    "uploaded_bytes_per_step": up,
+                    "note": "GraphsTuple fields in pinned host memory each step: upload + gnf_build_csr + forward"}
+
     # ---- secondary figure: independent forwards on TWO HIP streams.  A 64-graph batch fills 170 of the 256 CUs
     # (one 16-node tile per CU); evaluation of many batches (the steps here are independent of each
     # other) can use the idle third of the chip by keeping two batches in flight.  Not the headline protocol
@@ -463,6 +492,7 @@ def main():
         "log_prob_xs_per_node": last["log_prob_xs_per_node"],
         "with_csr_rebuild_each_step": rebuild,
         "two_streams": two_streams,
+        "host_fed": host_fed,
         "roofline": roofline,
         "kernel_a": kernel_a,
     }
