@@ -94,6 +94,7 @@ int64_t packed_floats(const GnfMlp* mlp);
 
 // fused backward half-step (gnf_fused_bwd.hip)
 bool fused_bwd_supported(const GnfMlp* s, const GnfMlp* t);
+void fused_bwd_launch_shape(const GnfMlp* s, int64_t n, int64_t* tiles, size_t* lds);
 int launch_half_bwd_fused(const int32_t* rowptr, const int32_t* col, int64_t n, const GnfGnnSpec& gnn,
                           const GnfMlp* s, const GnfMlp* t, const float* x_cond, float* y_upd, int64_t ld,
                           float* g_upd, int64_t ldg, int32_t H, float* h0_out, const float* const* h0_in, float* const* hin,

@@ -314,6 +314,13 @@ bool fused_bwd_supported(const GnfMlp* s, const GnfMlp* t) {
     return bwd_lds_bytes(s, 1) <= (size_t)kBwdLdsLimit;
 }
 
+// grid and LDS bytes launch_half_bwd_fused will use for n nodes (the dW launch is sized around them)
+void fused_bwd_launch_shape(const GnfMlp* s, int64_t n, int64_t* tiles, size_t* lds) {
+    const int MT = ((n + 15) / 16 > 256 && bwd_lds_bytes(s, 2) <= (size_t)kBwdLdsLimit) ? 2 : 1;
+    *tiles = (n + 16 * MT - 1) / (16 * MT);
+    *lds = bwd_lds_bytes(s, MT);
+}
+
 // hin / dP: [net * K + j] global buffers the dW GEMM will read: hin[.][j] = input of layer j (j >= 1; h0 is
 // shared), dP[.][j] = dL/d(pre-activation of layer j) for j <= K-2; dh0: [net] = dL/dh0.
 int launch_half_bwd_fused(const int32_t* rowptr, const int32_t* col, int64_t n, const GnfGnnSpec& gnn,

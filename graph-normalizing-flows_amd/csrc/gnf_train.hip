@@ -19,7 +19,9 @@
 // (tf.train.AdamOptimizer, run_grevnet.py:352-356) and the two gradient clippers (run_grevnet.py:363-373).
 #include "gnf_common.h"
 
+#include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 
 namespace gnf {
@@ -54,13 +56,13 @@ struct GemmShape {
 
 // One R x C tile (C contiguous) of a row-major matrix -> registers (U float4 per thread), zero filled
 // outside [rlim, clim).
-template <int R, int C, int U>
+template <int R, int C, int U, int NT = kGemmThreads>
 __device__ __forceinline__ void tile_fetch(const float* __restrict__ base, int64_t ld, int64_t rlim, int64_t clim,
                                            bool vec, int tid, f32x4_t (&v)[U]) {
     constexpr int C4 = C / 4;
 #pragma unroll
     for (int q = 0; q < U; ++q) {
-        const int u = tid + q * kGemmThreads;
+        const int u = tid + q * NT;
         const int r = u / C4, c = (u % C4) * 4;
         f32x4_t w = {0.f, 0.f, 0.f, 0.f};
         if (r < rlim && c < clim) {
@@ -78,12 +80,12 @@ __device__ __forceinline__ void tile_fetch(const float* __restrict__ base, int64
     }
 }
 
-template <int R, int C, int U>
+template <int R, int C, int U, int NT = kGemmThreads>
 __device__ __forceinline__ void tile_stash(float* __restrict__ lds, int tid, const f32x4_t (&v)[U]) {
     constexpr int C4 = C / 4;
 #pragma unroll
     for (int q = 0; q < U; ++q) {
-        const int u = tid + q * kGemmThreads;
+        const int u = tid + q * NT;
         const int r = u / C4, c = (u % C4) * 4;
         *reinterpret_cast<f32x4_t*>(lds + r * (C + 4) + c) = v[q];
     }
@@ -249,6 +251,305 @@ __global__ __launch_bounds__(kGemmThreads) void k_gemm_dw_grouped(const GroupedG
     gemm_tile<OPND_MC, OPND_MC, EPI_SLAB>(job, sh, bx, by, chunk);
 }
 
+// ---- wide split-K weight-gradient GEMM -----------------------------------------------------------------------
+// Same contract as k_gemm_dw_grouped (slabs + column sums per node chunk), built to run at FULL matrix-core rate with
+// ONE workgroup per CU: 128 x 128 output tile, 4 waves each owning 64 x 64 (4 x 4 MFMA tiles, 64 accumulator
+// registers), BK = 32 = 128 MFMAs per wave per step (~1.7 us) behind which the next step's eight float4 loads per
+// thread are in flight; two LDS stages, one barrier per step.  With few, long workgroups the launch can be sized to
+// the CUs the fused backward kernel leaves idle (see launch_weight_grads).
+static constexpr int WGM = 128, WGN = 128, WGK = 32;
+static constexpr int kWideThreads = 256;
+static constexpr int kWideLd = WGM + 4;
+static constexpr int kWideStage = 2 * WGK * kWideLd;  // floats: A tile then B tile
+static constexpr size_t kWideLdsMin = (size_t)2 * kWideStage * sizeof(float);
+// cache policy of the operand loads (A/B switch; streaming / non-temporal hints measured no different from the default)
+#ifndef GNF_DW_LOAD_POLICY
+#define GNF_DW_LOAD_POLICY 0
+#endif
+static constexpr int kWideLoadPolicy = GNF_DW_LOAD_POLICY;
+
+struct WideGemm {
+    GemmJob job[kMaxGroup];  // largest first
+    int64_t lda[kMaxGroup], ldb[kMaxGroup];
+    int32_t M[kMaxGroup], N[kMaxGroup];
+    int32_t unit_base[kMaxGroup + 1];  // prefix sums of workgroups (128 x 128 tiles x node chunks) per job
+    int32_t gx[kMaxGroup];
+    int32_t chunks[kMaxGroup];         // split of the node axis, per job: light jobs are cut less often
+    int32_t kchunk[kMaxGroup];         // rows per chunk, a multiple of WGK
+    int64_t K;
+    int32_t njobs;
+};
+
+// One BK = 32 step of a wave's MTW x NTW block of MFMA tiles.  A wave is alone on its SIMD here and issues in order,
+// so everything that is not an MFMA has to sit BETWEEN MFMAs to be free (an instruction placed behind a run of MFMAs
+// waits for all of them to issue): after every MFMA one other instruction is slotted in - first the LDS fragment
+// loads of k-slice ks + 2 (three register sets), then the `piece`s the caller hands in (16 of them: the LDS writes of
+// the next step's operand tiles and the global loads of the step after).  Order pinned with sched_barrier.
+// cs[n] += this lane's B fragments: the column sums of B (the bias gradient) fall out of the registers.
+// acc += a (x) b with the accumulator pinned to ONE AGPR tuple: through the builtin the register allocator gave the
+// loop-carried accumulators a different tuple at the end of the step than at its start and paid ~100 moves per step.
+// (No software hazard here: an accumulator is touched again 16 MFMAs later, and read out only after the last barrier.)
+__device__ __forceinline__ void mfma_inplace(f32x4_t& c, float a, float b) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+struct WideLayout {
+    bool along_n, along_m;  // 1 x 4 waves of 32 x 32 along N / 4 x 1 along M / (neither) 2 x 2 waves of 64 x 64
+};
+__host__ __device__ inline WideLayout wide_layout(int m_left, int n_left) {  // extents of the tile inside the matrix
+    WideLayout l;
+    l.along_n = m_left <= 32;
+    l.along_m = !l.along_n && n_left <= 32;
+    return l;
+}
+
+template <int MTW, int NTW, typename Piece>
+__device__ __forceinline__ void wide_compute(const float* __restrict__ As, const float* __restrict__ Bs,
+                                             f32x4_t (&acc)[4][4], float (&cs)[4], int wm, int wn, int lrow, int lgrp,
+                                             Piece&& piece) {
+    constexpr int NS = WGK / 4, NL = MTW + NTW;
+    float a[3][MTW], b[3][NTW];
+    const float* ap = As + 4 * lgrp * kWideLd + wm + lrow;
+    const float* bp = Bs + 4 * lgrp * kWideLd + wn + lrow;
+    auto load1 = [&](int ks, int i) {  // slice ks: k rows 16 * (ks / 4) + 4 * lgrp + (ks % 4)
+        const int row = 16 * (ks >> 2) + (ks & 3);
+        if (i < MTW)
+            a[ks % 3][i] = ap[row * kWideLd + 16 * i];
+        else
+            b[ks % 3][i - MTW] = bp[row * kWideLd + 16 * (i - MTW)];
+    };
+#pragma unroll
+    for (int i = 0; i < NL; ++i) load1(0, i);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) load1(1, i);
+    __builtin_amdgcn_sched_barrier(0);
+    int pc = 0;  // pieces handed out so far (a constant everywhere once the loops are unrolled)
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+        int li = 0;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                mfma_inplace(acc[m][n], a[ks % 3][m], b[ks % 3][n]);
+                if (ks + 2 < NS && li < NL)
+                    load1(ks + 2, li++);
+                else if (ks >= 1 && pc < 16)
+                    piece(pc++);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        if (ks + 2 < NS)
+            for (; li < NL; ++li) load1(ks + 2, li);  // narrow blocks: more loads than MFMA slots
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) cs[n] += b[ks % 3][n];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (; pc < 16; ++pc) piece(pc);
+}
+
+#ifdef GNF_DW_TRACE  // developer build: s_memtime ticks of workgroup 0 / thread 0, summed per phase
+__device__ unsigned long long g_dw_trace[8];
+#define GNF_DWT(i, t0) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); g_dw_trace[i] += t1_ - t0; t0 = t1_; } } while (0)
+extern "C" int gnf_debug_read_dw_trace(unsigned long long* out, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dw_trace), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {0};
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dw_trace), z, sizeof(z));
+    }
+    return rc;
+}
+#else
+#define GNF_DWT(i, t0)
+#endif
+
+// workgroup barrier that only waits for this wave's LDS traffic (not for the global loads in flight)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// BUF: every operand is 16-byte aligned with a row pitch that is a multiple of 4 floats -> the tiles are read with
+// buffer loads through a descriptor that ends at the chunk's last row: rows past the chunk come back as zeros by the
+// hardware range check (on the VGPR offset), so the fetch is branch-free and can be cut into the pieces wide_compute
+// interleaves; tiles past the chunk's end are fetched and stashed like any other (zeros, never read).  Columns past
+// M / N read whatever follows in the row; they only reach accumulators that are never stored.  The generic path
+// (any pitch / alignment) keeps the bounds-checked fetch in front of the MFMA block.
+template <bool BUF>
+__global__ __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_gemm_dw_wide(const WideGemm g) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+#ifdef GNF_DW_TRACE
+    unsigned long long tt0 = __builtin_amdgcn_s_memtime();
+#endif
+    // a workgroup takes unit blockIdx.x (a chunk of one of the costliest tiles; those are cut equal) and then, strided,
+    // its share of the cheap units that follow them in the list
+    for (int u = blockIdx.x; u < g.unit_base[g.njobs]; u += gridDim.x) {
+    int j = 0;
+    while (j + 1 < g.njobs && u >= g.unit_base[j + 1]) ++j;
+    const int lu = u - g.unit_base[j];
+    const int nchunk = g.chunks[j];
+    const int lt = lu / nchunk, chunk = lu - lt * nchunk;
+    const int gxj = g.gx[j];
+    const int bx = lt % gxj, by = lt / gxj;
+    const int M = g.M[j], N = g.N[j];
+    const int64_t lda = g.lda[j], ldb = g.ldb[j];
+    const GemmJob job = g.job[j];
+    const int m0 = by * WGM, n0 = bx * WGN;
+    const int64_t kbeg = (int64_t)chunk * g.kchunk[j];
+    const int64_t kend = kbeg + g.kchunk[j] < g.K ? kbeg + g.kchunk[j] : g.K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    // the four waves tile the 128 x 128 block 2 x 2 (64 x 64 each) - or, when the tile is a thin strip (a layer with few
+    // inputs or outputs), 1 x 4 / 4 x 1 blocks of 32 x 32 along the long side, so that all four SIMDs have work
+    const WideLayout lay = wide_layout(M - m0, N - n0);
+    const int wm = lay.along_n ? 0 : (lay.along_m ? wave * 32 : (wave & 1) * 64);
+    const int wn = lay.along_n ? wave * 32 : (lay.along_m ? 0 : (wave >> 1) * 64);
+    const int wext = (lay.along_n || lay.along_m) ? 32 : 64;
+    int mt = (M - m0 - wm + 15) / 16, nt = (N - n0 - wn + 15) / 16;  // MFMA tiles of this wave that hold anything
+    mt = mt < 0 ? 0 : (mt > wext / 16 ? wext / 16 : mt);
+    nt = nt < 0 ? 0 : (nt > wext / 16 ? wext / 16 : nt);
+    const int shape = (mt == 0 || nt == 0) ? 0 : (((mt > 2 ? 4 : mt) << 4) | (nt > 2 ? 4 : nt));
+    const bool avec = (lda % 4 == 0) && (reinterpret_cast<uintptr_t>(job.A) % 16 == 0);
+    const bool bvec = (ldb % 4 == 0) && (reinterpret_cast<uintptr_t>(job.B) % 16 == 0);
+    const bool want_cs = job.aux_out != nullptr && by == 0 && wm == 0;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};  // this lane's share of the column sums of B, columns wn + 16 n + lrow
+
+    // operand tiles in flight: 4 + 4 float4 per thread.  Thread t moves rows (t >> 5) + 8 q, columns 4 (t & 31) ..
+    f32x4_t av[4], bv[4];
+    const int64_t krows = kend > kbeg ? kend - kbeg : 0;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(job.A + kbeg * lda + m0), 0, BUF ? (int)((krows * lda - m0) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(job.B + kbeg * ldb + n0), 0, BUF ? (int)((krows * ldb - n0) * 4) : 0, 0x00020000);
+    const int va = ((tid >> 5) * (int)lda + (tid & 31) * 4) * 4, vb = ((tid >> 5) * (int)ldb + (tid & 31) * 4) * 4;
+    const int qa = 8 * (int)lda * 4, qb = 8 * (int)ldb * 4;         // bytes between a thread's q-th and (q+1)-th row
+    const int lw = (tid >> 5) * kWideLd + (tid & 31) * 4;           // LDS float offset of the thread's q = 0 float4
+    auto fetch_buf = [&](int voa, int vob, int q, bool b_side) {
+        if (!b_side)
+            av[q] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ra, voa + q * qa, 0, kWideLoadPolicy));
+        else
+            bv[q] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rb, vob + q * qb, 0, kWideLoadPolicy));
+    };
+    auto stash1 = [&](float* stage, int q, bool b_side) {
+        float* d = stage + (b_side ? WGK * kWideLd : 0) + lw + q * 8 * kWideLd;
+        *reinterpret_cast<f32x4_t*>(d) = b_side ? bv[q] : av[q];
+    };
+    auto fetch_any = [&](int64_t k0) {
+        if (BUF) {
+            const int voa = va + (int)(k0 - kbeg) * (int)lda * 4, vob = vb + (int)(k0 - kbeg) * (int)ldb * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fetch_buf(voa, vob, q, false), fetch_buf(voa, vob, q, true);
+        } else {
+            tile_fetch<WGK, WGM, 4, kWideThreads>(job.A + k0 * lda + m0, lda, kend - k0, M - m0, avec, tid, av);
+            tile_fetch<WGK, WGN, 4, kWideThreads>(job.B + k0 * ldb + n0, ldb, kend - k0, N - n0, bvec, tid, bv);
+        }
+    };
+    auto stash_all = [&](float* stage) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stash1(stage, q, false), stash1(stage, q, true);
+    };
+
+    int cur = 0;
+    if (BUF || kbeg < kend) {
+        fetch_any(kbeg);
+        stash_all(wl);
+        if (BUF || kbeg + WGK < kend) fetch_any(kbeg + WGK);  // stays in flight into step 0
+    }
+    lds_barrier();
+    GNF_DWT(5, tt0);
+    // The K loop exists once per block shape (dispatch OUTSIDE the loop: with the switch inside, the accumulators
+    // crossed it in VGPRs and were copied to and from the AGPRs the MFMAs use on every step - 128 moves per step).
+    auto k_loop = [&](auto mtw_c, auto ntw_c) {
+        constexpr int MTW = decltype(mtw_c)::value, NTW = decltype(ntw_c)::value;
+        for (int64_t k0 = kbeg; k0 < kend; k0 += WGK) {
+#ifdef GNF_DW_TRACE
+            unsigned long long tt = __builtin_amdgcn_s_memtime();
+#endif
+            const float* As = wl + cur * kWideStage;
+            const float* Bs = As + WGK * kWideLd;
+            float* nstage = wl + (cur ^ 1) * kWideStage;
+            // the registers hold the tiles of step k0 + WGK: they go to the other stage, then receive step k0 + 2 WGK
+            if (!BUF) {
+                if (k0 + WGK < kend) stash_all(nstage);
+                if (k0 + 2 * WGK < kend) fetch_any(k0 + 2 * WGK);
+            }
+            GNF_DWT(0, tt);
+            const int voa = va + (int)(k0 + 2 * WGK - kbeg) * (int)lda * 4, vob = vb + (int)(k0 + 2 * WGK - kbeg) * (int)ldb * 4;
+            auto piece = [&](int i) {
+                if (!BUF) return;
+                if (i < 8)
+                    stash1(nstage, i & 3, i >= 4);
+                else
+                    fetch_buf(voa, vob, i & 3, i >= 12);
+            };
+            if constexpr (MTW > 0) {
+                wide_compute<MTW, NTW>(As, Bs, acc, cs, wm, wn, lrow, lgrp, piece);
+            } else {  // nothing of this wave's block lies inside the matrix; its share of the tile traffic remains
+#pragma unroll
+                for (int i = 0; i < 16; ++i) piece(i);
+            }
+            GNF_DWT(2, tt);
+            lds_barrier();
+            GNF_DWT(4, tt);
+            cur ^= 1;
+#ifdef GNF_DW_TRACE
+            if (blockIdx.x == 0 && threadIdx.x == 0) g_dw_trace[7] += 1;
+#endif
+        }
+    };
+    // partial blocks round up to 1 / 2 / 4 tiles (the stages are zero filled beyond M, N)
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I4 = std::integral_constant<int, 4>;
+    switch (shape) {
+        case 0x44: k_loop(I4{}, I4{}); break;
+        case 0x42: k_loop(I4{}, I2{}); break;
+        case 0x41: k_loop(I4{}, I1{}); break;
+        case 0x24: k_loop(I2{}, I4{}); break;
+        case 0x22: k_loop(I2{}, I2{}); break;
+        case 0x21: k_loop(I2{}, I1{}); break;
+        case 0x14: k_loop(I1{}, I4{}); break;
+        case 0x12: k_loop(I1{}, I2{}); break;
+        case 0x11: k_loop(I1{}, I1{}); break;
+        default: k_loop(I0{}, I0{}); break;
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs have left the pipe before acc is read
+#ifdef GNF_DW_TRACE
+    tt0 = __builtin_amdgcn_s_memtime();
+#endif
+    // accumulator layout: col = lane & 15, row = 4 * (lane >> 4) + r
+    float* __restrict__ Cp = job.C + (int64_t)chunk * M * N;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int gc = n0 + wn + 16 * n + lrow;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gr = m0 + wm + 16 * m + 4 * lgrp + r;
+                if (16 * m < wext && 16 * n < wext && gr < M && gc < N) Cp[(int64_t)gr * N + gc] = acc[m][n][r];
+            }
+        }
+    if (want_cs) {  // the four lane groups hold the four k-residues of every column
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            float v = cs[n];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int gc = n0 + wn + 16 * n + lrow;
+            if (lgrp == 0 && 16 * n < wext && gc < N) job.aux_out[(int64_t)chunk * N + gc] = v;
+        }
+    }
+#ifdef GNF_DW_TRACE
+    __builtin_amdgcn_s_waitcnt(0);
+    GNF_DWT(6, tt0);
+#endif
+    }  // units of this workgroup
+}
+
 template <int AK, int BK, int EPI>
 static int launch_gemm(const GemmJob* jobs, int nj, const GemmShape& sh, hipStream_t st) {
     if (sh.M == 0 || sh.N == 0) return GNF_OK;
@@ -269,22 +570,24 @@ struct GroupedReduce {
     ReduceJob job[kMaxGroup];
     int64_t nw[kMaxGroup];
     int32_t nb[kMaxGroup];
-    int32_t chunks, accumulate;
+    int32_t chunks[kMaxGroup];
+    int32_t accumulate;
 };
 __global__ __launch_bounds__(256) void k_reduce_grouped(const GroupedReduce g) {
     const int j = blockIdx.y;
     const ReduceJob job = g.job[j];
     const int64_t nw = g.nw[j];
     const int nb = g.nb[j];
+    const int nchunk = g.chunks[j];
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e < nw) {
         float s = 0.f;
-        for (int c = 0; c < g.chunks; ++c) s += job.wslab[(int64_t)c * nw + e];
+        for (int c = 0; c < nchunk; ++c) s += job.wslab[(int64_t)c * nw + e];
         job.gw[e] = g.accumulate ? job.gw[e] + s : s;
     } else if (e < nw + nb) {
         const int i = (int)(e - nw);
         float s = 0.f;
-        for (int c = 0; c < g.chunks; ++c) s += job.bslab[(int64_t)c * nb + i];
+        for (int c = 0; c < nchunk; ++c) s += job.bslab[(int64_t)c * nb + i];
         job.gb[i] = g.accumulate ? job.gb[i] + s : s;
     }
 }
@@ -658,8 +961,51 @@ struct WGJob {
     float* gb;
 };
 
-static int launch_weight_grads(const BwdPlan& p, const WGJob* jobs, int nj, bool accumulate, float* ws,
-                               hipStream_t st) {
+// How the dW launch is shaped.  max_units == 0: the 128 x 64 grouped kernel over the plan's chunks (many short
+// workgroups that share CUs with whatever else runs).  max_units > 0: the wide kernel in at most that many
+// workgroups, each asking for `lds` bytes of LDS - unless the cut this allows would take longer than `budget_us`,
+// in which case the grouped kernel runs after all.
+struct DwPolicy {
+    int max_units;
+    size_t lds;
+    double budget_us;
+};
+
+// The fused backward kernel of the NEXT half-step runs beside this half-step's dW GEMMs (one 16-node tile per
+// workgroup, one workgroup per CU by its LDS footprint).  While it leaves CUs idle (config-2 batch: 170 tiles on 256
+// CUs) the dW launch is sized to exactly those: long, equal workgroups, no more of them than there are idle CUs on
+// every XCD (workgroups are dealt round-robin to the 8 XCDs of 32 CUs), with enough LDS padding that none fits beside
+// a backward workgroup.  The backward kernel (the critical path) then runs undisturbed and the weight gradients
+// finish inside its shadow.  One workgroup too many is costly - a backward workgroup that finds no CU waits for a whole
+// dW workgroup - hence the strict cap.  Without enough idle CUs to finish in the backward kernel's time, the grouped
+// kernel's many short workgroups spread the contention evenly instead.
+static DwPolicy dw_policy(const GnfMlp* net, int64_t bwd_tiles, size_t bwd_lds) {
+    static const char* env_g = getenv("GNF_DW_GROUPED");  // developer A/B switches
+    static const char* env_u = getenv("GNF_DW_WIDE_UNITS");
+    static const char* env_l = getenv("GNF_DW_WIDE_LDS");
+    DwPolicy pol{0, kWideLdsMin, 0.0};
+    if (env_g) return pol;
+    if (bwd_tiles > 0 && bwd_tiles <= 192 && bwd_lds > 80 * 1024) {
+        // workgroups are dealt round-robin to 32 shader engines of 8 CUs: no engine may get more exclusive workgroups
+        // (backward + dW) than it has CUs, or a backward workgroup waits for a whole dW workgroup (measured: the
+        // backward kernel then takes 150 instead of 84 us every other half-step)
+        pol.max_units = 32 * (8 - (int)((bwd_tiles + 31) / 32));
+        const size_t excl = (size_t)160 * 1024 - bwd_lds + 1024;
+        if (excl > pol.lds) pol.lds = excl;
+        // what the backward kernel takes: recompute + dP chain = 2 x 2 nets x 16 rows x sum(d_j d_j+1) MACs per tile at
+        // ~60 % of a CU's fp32 matrix rate (measured: 84 us at 5 x 256-wide layers)
+        double macs = 0.0;
+        for (int j = 0; j < net->num_layers; ++j) macs += (double)net->dims[j] * net->dims[j + 1];
+        // the alternative (grouped kernel sharing every CU) stretches the backward kernel by ~1.3 x
+        pol.budget_us = 1.4 * (2.0 * 2.0 * 16.0 * macs * 2.0) / (614e9 * 0.6) * 1e6 + 10.0;
+    }
+    if (env_u) pol.max_units = atoi(env_u), pol.budget_us = 1e30;
+    if (env_l && (size_t)atol(env_l) >= kWideLdsMin) pol.lds = (size_t)atol(env_l);
+    return pol;
+}
+
+static int launch_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob* jobs, int nj, bool accumulate,
+                               float* ws, hipStream_t st) {
     GroupedGemm gg;
     GroupedReduce gr;
     memset(&gg, 0, sizeof(gg));
@@ -689,12 +1035,128 @@ static int launch_weight_grads(const BwdPlan& p, const WGJob* jobs, int nj, bool
     gg.K = p.n;
     gg.kchunk = p.kchunk;
     gg.chunks = p.chunks;
-    gr.chunks = p.chunks;
+    for (int e = 0; e < nj; ++e) gr.chunks[e] = p.chunks;
     gr.accumulate = accumulate ? 1 : 0;
-    const int gx = (maxN + TGN - 1) / TGN, gy = (maxM + TGM - 1) / TGM, nz = nj * p.chunks;
-    const unsigned blocks = 8u * (unsigned)((nz + 7) / 8) * (unsigned)(gx * gy);
-    hipLaunchKernelGGL(k_gemm_dw_grouped, dim3(blocks), dim3(kGemmThreads), 0, st, gg, gx, gy, nz);
-    GNF_LAUNCH_CHECK("k_gemm_dw_grouped");
+    // ---- wide kernel: cut every job along the node axis so that the workgroups carry about equal MFMA work --------
+    bool wide = pol.max_units > 0 && p.n > 0;
+    WideGemm wg;
+    int units = 0;
+    int64_t max_kchunk = WGK;
+    if (wide) {
+        memset(&wg, 0, sizeof(wg));
+        // MFMA tiles per k-slice of the busiest wave of a job's busiest tile (what one step of such a workgroup costs;
+        // 16 for a full 128 x 128 tile), rounded the way the kernel rounds (1 / 2 / 4 MFMA tiles per side)
+        auto side = [](int len) {
+            const int t16 = (len + 15) / 16;
+            return t16 > 2 ? 4 : t16;
+        };
+        int cost[kMaxGroup], tiles_of[kMaxGroup], order[kMaxGroup], cj[kMaxGroup];
+        for (int e = 0; e < nj; ++e) {
+            const int mt_ = jobs[e].M < WGM ? jobs[e].M : WGM, nt_ = jobs[e].N < WGN ? jobs[e].N : WGN;
+            const WideLayout l = wide_layout(mt_, nt_);
+            const int wext = (l.along_n || l.along_m) ? 32 : 64;
+            cost[e] = side(mt_ < wext ? mt_ : wext) * side(nt_ < wext ? nt_ : wext);
+            tiles_of[e] = ((jobs[e].M + WGM - 1) / WGM) * ((jobs[e].N + WGN - 1) / WGN);
+            order[e] = e;
+        }
+        for (int a = 1; a < nj; ++a) {  // insertion sort, costliest tiles first (stable): they are dispatched first
+            const int v = order[a];
+            int b = a - 1;
+            while (b >= 0 && cost[order[b]] < cost[v]) order[b + 1] = order[b], --b;
+            order[b + 1] = v;
+        }
+        // The costliest jobs (the hidden-layer matrices) give the launch its grid: the smallest per-workgroup work T (in
+        // rows of a full tile) whose cut of THEM fits max_units; candidates n / k.  Cheaper jobs (thin first / last
+        // layers, attention projections) are cut into about as many units as there are workgroups and ride behind.
+        const int cmax = nj > 0 ? cost[order[0]] : 16;
+        int heavy_tiles = 0, light_tiles = 0;
+        for (int e = 0; e < nj; ++e) (cost[e] == cmax ? heavy_tiles : light_tiles) += tiles_of[e];
+        int c_heavy = 0;
+        for (int k = p.chunks; k >= 1; --k)
+            if ((int64_t)k * heavy_tiles <= pol.max_units) { c_heavy = k; break; }
+        int grid = 0, c_light = 1;
+        double est_us = 1e30;
+        if (c_heavy > 0) {
+            int64_t kc = (p.n + c_heavy - 1) / c_heavy;
+            kc = (kc + WGK - 1) / WGK * WGK;
+            c_heavy = (int)((p.n + kc - 1) / kc);
+            grid = c_heavy * heavy_tiles;
+            bool light_own = false;  // room for the cheap units as workgroups of their own?
+            if (light_tiles > 0) {
+                light_own = grid + light_tiles <= pol.max_units;
+                c_light = light_own ? (pol.max_units - grid) / light_tiles : grid / light_tiles;
+                c_light = c_light < 1 ? 1 : (c_light > p.chunks ? p.chunks : c_light);
+            }
+            // a step of a full tile (32 rows) takes ~2.1 us at one workgroup per CU (measured); + launch, prologue and
+            // epilogue of every unit
+            const double heavy_us = (double)cmax / 16.0 * (double)kc / 32.0 * 2.1 + 6.0;
+            double light_us = 0.0;
+            for (int e = 0; e < nj; ++e)
+                if (cost[e] != cmax)
+                    light_us += tiles_of[e] * c_light * ((double)cost[e] / 16.0 * (double)p.n / c_light / 32.0 * 2.1 + 4.0);
+            est_us = light_own ? heavy_us : heavy_us + light_us / grid;
+            if (light_own) grid += light_tiles * c_light;  // an upper bound; the exact count follows below
+        }
+        if (grid == 0 || est_us > pol.budget_us) wide = false;
+        static const bool dbg = getenv("GNF_DW_DEBUG") != nullptr;
+        if (dbg) {
+            static int shown = 0;
+            if (shown++ < 2)
+                fprintf(stderr, "[gnf dW] n=%lld max_units=%d heavy_tiles=%d (cost %d/16) light_tiles=%d c_heavy=%d c_light=%d grid=%d "
+                        "est %.1f us budget %.1f us lds %zu -> %s\n", (long long)p.n, pol.max_units, heavy_tiles, cmax, light_tiles,
+                        c_heavy, c_light, grid, est_us, pol.budget_us, pol.lds, wide ? "wide" : "grouped");
+        }
+        for (int q = 0; q < nj && wide; ++q) {
+            const int e = order[q];
+            wg.job[q] = gg.job[e];
+            wg.lda[q] = gg.lda[e], wg.ldb[q] = gg.ldb[e];
+            wg.M[q] = gg.M[e], wg.N[q] = gg.N[e];
+            wg.gx[q] = (gg.N[e] + WGN - 1) / WGN;
+            int64_t c = cost[e] == cmax ? c_heavy : c_light;
+            int64_t kc = (p.n + c - 1) / c;
+            kc = (kc + WGK - 1) / WGK * WGK;
+            c = (p.n + kc - 1) / kc;
+            cj[e] = (int)c;
+            wg.chunks[q] = (int32_t)c;
+            wg.kchunk[q] = (int32_t)kc;
+            max_kchunk = max_kchunk > kc ? max_kchunk : kc;
+            wg.unit_base[q] = units;
+            units += tiles_of[e] * (int)c;
+        }
+        if (wide) {
+            for (int e = 0; e < nj; ++e) gr.chunks[e] = cj[e];
+            wg.unit_base[nj] = units;
+            wg.K = p.n, wg.njobs = nj;
+            units = grid < units ? grid : units;  // workgroups; units past the grid are picked up by stride
+        }
+    }
+    if (wide) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_wide<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_wide<false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        // buffer path: byte offsets inside a chunk (+ the two tiles fetched past its end) stay below 2^31.  Rows need
+        // not be 16-byte aligned: buffer_load_dwordx4 only asks for dword alignment (the attention projections have
+        // 170-float rows)
+        static const bool no_buf = getenv("GNF_DW_NO_BUF") != nullptr;
+        bool buf = !no_buf;
+        for (int e = 0; e < nj; ++e)
+            buf = buf && (max_kchunk + 4 * WGK) * (jobs[e].lda > jobs[e].ldb ? jobs[e].lda : jobs[e].ldb) * 4 < ((int64_t)1 << 31);
+        if (buf)
+            hipLaunchKernelGGL(k_gemm_dw_wide<true>, dim3((unsigned)units), dim3(kWideThreads), pol.lds, st, wg);
+        else
+            hipLaunchKernelGGL(k_gemm_dw_wide<false>, dim3((unsigned)units), dim3(kWideThreads), pol.lds, st, wg);
+        GNF_LAUNCH_CHECK("k_gemm_dw_wide");
+    } else {
+        const int gx = (maxN + TGN - 1) / TGN, gy = (maxM + TGM - 1) / TGM, nz = nj * p.chunks;
+        const unsigned blocks = 8u * (unsigned)((nz + 7) / 8) * (unsigned)(gx * gy);
+        hipLaunchKernelGGL(k_gemm_dw_grouped, dim3(blocks), dim3(kGemmThreads), 0, st, gg, gx, gy, nz);
+        GNF_LAUNCH_CHECK("k_gemm_dw_grouped");
+    }
     hipLaunchKernelGGL(k_reduce_grouped, dim3((unsigned)((maxred + 255) / 256), (unsigned)nj), dim3(256), 0, st, gr);
     GNF_LAUNCH_CHECK("k_reduce_grouped");
     return GNF_OK;
@@ -1109,7 +1571,12 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 }
                 WGJob jobs[kMaxGroup];
                 const int nj = weight_grad_jobs(p, o, nets, grads, jobs);
-                rc = launch_weight_grads(p, jobs, nj, acc, wsf, wst);
+                int64_t bwd_tiles = 0;
+                size_t bwd_lds = 0;
+                // (attention nets: the edge kernels of the next half-step want every CU; the grouped kernel's short
+                // workgroups share with them better - measured 7.8 vs 8.4 ms per step)
+                if (fused && !attn) fused_bwd_launch_shape(nets[0], n, &bwd_tiles, &bwd_lds);
+                rc = launch_weight_grads(p, dw_policy(nets[0], bwd_tiles, bwd_lds), jobs, nj, acc, wsf, wst);
                 if (rc) return rc;
                 if (aux) {
                     GNF_HIP_TRY(hipEventRecord(g_ev[set], aux));

@@ -15,6 +15,7 @@ Learning-rate schedules of the drivers: `exponential_decay` (run_grevnet.py:341-
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -67,7 +68,7 @@ class GRevNetTrainer:
         self._bns = []
         self._attn_blocks = []
         self._aux = None         # second HIP stream: the weight-gradient GEMMs overlap the backward walk
-        self.overlap_weight_grads = True
+        self.overlap_weight_grads = os.environ.get("GNF_TRAIN_NO_OVERLAP") is None   # developer A/B switch
 
     # ---- parameter arena ---------------------------------------------------------------------
     def _ensure_arena(self, hdim, device):
