@@ -258,7 +258,9 @@ __global__ __launch_bounds__(kGemmThreads) void k_gemm_dw_grouped(const GroupedG
 // thread are in flight; two LDS stages, one barrier per step.  With few, long workgroups the launch can be sized to
 // the CUs the fused backward kernel leaves idle (see launch_weight_grads).
 static constexpr int WGM = 128, WGN = 128, WGK = 32;
-static constexpr int kWideThreads = 256;
+static constexpr int kWideThreads = 512;  // 8 waves: two per SIMD, each fills the other's issue gaps
+static constexpr int kWideQ = WGK * 32 / kWideThreads;  // float4 per thread and operand tile
+static constexpr int kWidePieces = 4 * kWideQ;
 static constexpr int kWideLd = WGM + 4;
 static constexpr int kWideStage = 2 * WGK * kWideLd;  // floats: A tile then B tile
 static constexpr size_t kWideLdsMin = (size_t)2 * kWideStage * sizeof(float);
@@ -294,7 +296,7 @@ __device__ __forceinline__ void mfma_inplace(f32x4_t& c, float a, float b) {
 }
 
 struct WideLayout {
-    bool along_n, along_m;  // 1 x 4 waves of 32 x 32 along N / 4 x 1 along M / (neither) 2 x 2 waves of 64 x 64
+    bool along_n, along_m;  // 1 x 8 waves of 32 x 16 along N / 8 x 1 of 16 x 32 along M / (neither) 4 x 2 waves of 32 x 64
 };
 __host__ __device__ inline WideLayout wide_layout(int m_left, int n_left) {  // extents of the tile inside the matrix
     WideLayout l;
@@ -334,7 +336,7 @@ __device__ __forceinline__ void wide_compute(const float* __restrict__ As, const
                 mfma_inplace(acc[m][n], a[ks % 3][m], b[ks % 3][n]);
                 if (ks + 2 < NS && li < NL)
                     load1(ks + 2, li++);
-                else if (ks >= 1 && pc < 16)
+                else if (ks >= 1 && pc < kWidePieces)
                     piece(pc++);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -344,7 +346,7 @@ __device__ __forceinline__ void wide_compute(const float* __restrict__ As, const
         for (int n = 0; n < NTW; ++n) cs[n] += b[ks % 3][n];
         __builtin_amdgcn_sched_barrier(0);
     }
-    for (; pc < 16; ++pc) piece(pc);
+    for (; pc < kWidePieces; ++pc) piece(pc);
 }
 
 #ifdef GNF_DW_TRACE  // developer build: s_memtime ticks of workgroup 0 / thread 0, summed per phase
@@ -372,7 +374,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // M / N read whatever follows in the row; they only reach accumulators that are never stored.  The generic path
 // (any pitch / alignment) keeps the bounds-checked fetch in front of the MFMA block.
 template <bool BUF>
-__global__ __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_gemm_dw_wide(const WideGemm g) {
+__global__ __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_dw_wide(const WideGemm g) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
 #ifdef GNF_DW_TRACE
     unsigned long long tt0 = __builtin_amdgcn_s_memtime();
@@ -395,15 +397,15 @@ __global__ __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(1,
     const int64_t kend = kbeg + g.kchunk[j] < g.K ? kbeg + g.kchunk[j] : g.K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, lgrp = lane >> 4;
-    // the four waves tile the 128 x 128 block 2 x 2 (64 x 64 each) - or, when the tile is a thin strip (a layer with few
-    // inputs or outputs), 1 x 4 / 4 x 1 blocks of 32 x 32 along the long side, so that all four SIMDs have work
+    // the eight waves tile the 128 x 128 block 4 x 2 (32 x 64 each) - or, when the tile is a thin strip (a layer with
+    // few inputs or outputs), 1 x 8 / 8 x 1 blocks along the long side, so that every SIMD has work
     const WideLayout lay = wide_layout(M - m0, N - n0);
-    const int wm = lay.along_n ? 0 : (lay.along_m ? wave * 32 : (wave & 1) * 64);
-    const int wn = lay.along_n ? wave * 32 : (lay.along_m ? 0 : (wave >> 1) * 64);
-    const int wext = (lay.along_n || lay.along_m) ? 32 : 64;
+    const int wext_m = lay.along_m ? 16 : 32, wext_n = lay.along_n ? 16 : (lay.along_m ? 32 : 64);
+    const int wm = lay.along_n ? 0 : (lay.along_m ? wave * 16 : (wave & 3) * 32);
+    const int wn = lay.along_n ? wave * 16 : (lay.along_m ? 0 : (wave >> 2) * 64);
     int mt = (M - m0 - wm + 15) / 16, nt = (N - n0 - wn + 15) / 16;  // MFMA tiles of this wave that hold anything
-    mt = mt < 0 ? 0 : (mt > wext / 16 ? wext / 16 : mt);
-    nt = nt < 0 ? 0 : (nt > wext / 16 ? wext / 16 : nt);
+    mt = mt < 0 ? 0 : (mt > wext_m / 16 ? wext_m / 16 : mt);
+    nt = nt < 0 ? 0 : (nt > wext_n / 16 ? wext_n / 16 : nt);
     const int shape = (mt == 0 || nt == 0) ? 0 : (((mt > 2 ? 4 : mt) << 4) | (nt > 2 ? 4 : nt));
     const bool avec = (lda % 4 == 0) && (reinterpret_cast<uintptr_t>(job.A) % 16 == 0);
     const bool bvec = (ldb % 4 == 0) && (reinterpret_cast<uintptr_t>(job.B) % 16 == 0);
@@ -417,14 +419,15 @@ __global__ __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(1,
     float cs[4] = {0.f, 0.f, 0.f, 0.f};  // this lane's share of the column sums of B, columns wn + 16 n + lrow
 
     // operand tiles in flight: 4 + 4 float4 per thread.  Thread t moves rows (t >> 5) + 8 q, columns 4 (t & 31) ..
-    f32x4_t av[4], bv[4];
+    f32x4_t av[kWideQ], bv[kWideQ];
     const int64_t krows = kend > kbeg ? kend - kbeg : 0;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(job.A + kbeg * lda + m0), 0, BUF ? (int)((krows * lda - m0) * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(job.B + kbeg * ldb + n0), 0, BUF ? (int)((krows * ldb - n0) * 4) : 0, 0x00020000);
+    constexpr int kRowsPass = kWideThreads / 32;  // rows one pass of the workgroup covers
     const int va = ((tid >> 5) * (int)lda + (tid & 31) * 4) * 4, vb = ((tid >> 5) * (int)ldb + (tid & 31) * 4) * 4;
-    const int qa = 8 * (int)lda * 4, qb = 8 * (int)ldb * 4;         // bytes between a thread's q-th and (q+1)-th row
+    const int qa = kRowsPass * (int)lda * 4, qb = kRowsPass * (int)ldb * 4;         // bytes between a thread's q-th and (q+1)-th row
     const int lw = (tid >> 5) * kWideLd + (tid & 31) * 4;           // LDS float offset of the thread's q = 0 float4
     auto fetch_buf = [&](int voa, int vob, int q, bool b_side) {
         if (!b_side)
@@ -433,22 +436,22 @@ __global__ __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(1,
             bv[q] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rb, vob + q * qb, 0, kWideLoadPolicy));
     };
     auto stash1 = [&](float* stage, int q, bool b_side) {
-        float* d = stage + (b_side ? WGK * kWideLd : 0) + lw + q * 8 * kWideLd;
+        float* d = stage + (b_side ? WGK * kWideLd : 0) + lw + q * kRowsPass * kWideLd;
         *reinterpret_cast<f32x4_t*>(d) = b_side ? bv[q] : av[q];
     };
     auto fetch_any = [&](int64_t k0) {
         if (BUF) {
             const int voa = va + (int)(k0 - kbeg) * (int)lda * 4, vob = vb + (int)(k0 - kbeg) * (int)ldb * 4;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) fetch_buf(voa, vob, q, false), fetch_buf(voa, vob, q, true);
+            for (int q = 0; q < kWideQ; ++q) fetch_buf(voa, vob, q, false), fetch_buf(voa, vob, q, true);
         } else {
-            tile_fetch<WGK, WGM, 4, kWideThreads>(job.A + k0 * lda + m0, lda, kend - k0, M - m0, avec, tid, av);
-            tile_fetch<WGK, WGN, 4, kWideThreads>(job.B + k0 * ldb + n0, ldb, kend - k0, N - n0, bvec, tid, bv);
+            tile_fetch<WGK, WGM, kWideQ, kWideThreads>(job.A + k0 * lda + m0, lda, kend - k0, M - m0, avec, tid, av);
+            tile_fetch<WGK, WGN, kWideQ, kWideThreads>(job.B + k0 * ldb + n0, ldb, kend - k0, N - n0, bvec, tid, bv);
         }
     };
     auto stash_all = [&](float* stage) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) stash1(stage, q, false), stash1(stage, q, true);
+        for (int q = 0; q < kWideQ; ++q) stash1(stage, q, false), stash1(stage, q, true);
     };
 
     int cur = 0;
@@ -479,16 +482,16 @@ __global__ __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(1,
             const int voa = va + (int)(k0 + 2 * WGK - kbeg) * (int)lda * 4, vob = vb + (int)(k0 + 2 * WGK - kbeg) * (int)ldb * 4;
             auto piece = [&](int i) {
                 if (!BUF) return;
-                if (i < 8)
-                    stash1(nstage, i & 3, i >= 4);
+                if (i < 2 * kWideQ)
+                    stash1(nstage, i % kWideQ, i >= kWideQ);
                 else
-                    fetch_buf(voa, vob, i & 3, i >= 12);
+                    fetch_buf(voa, vob, i % kWideQ, i >= 3 * kWideQ);
             };
             if constexpr (MTW > 0) {
                 wide_compute<MTW, NTW>(As, Bs, acc, cs, wm, wn, lrow, lgrp, piece);
             } else {  // nothing of this wave's block lies inside the matrix; its share of the tile traffic remains
 #pragma unroll
-                for (int i = 0; i < 16; ++i) piece(i);
+                for (int i = 0; i < kWidePieces; ++i) piece(i);
             }
             GNF_DWT(2, tt);
             lds_barrier();
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(1,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gr = m0 + wm + 16 * m + 4 * lgrp + r;
-                if (16 * m < wext && 16 * n < wext && gr < M && gc < N) Cp[(int64_t)gr * N + gc] = acc[m][n][r];
+                if (16 * m < wext_m && 16 * n < wext_n && gr < M && gc < N) Cp[(int64_t)gr * N + gc] = acc[m][n][r];
             }
         }
     if (want_cs) {  // the four lane groups hold the four k-residues of every column
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(1,
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
             const int gc = n0 + wn + 16 * n + lrow;
-            if (lgrp == 0 && 16 * n < wext && gc < N) job.aux_out[(int64_t)chunk * N + gc] = v;
+            if (lgrp == 0 && 16 * n < wext_n && gc < N) job.aux_out[(int64_t)chunk * N + gc] = v;
         }
     }
 #ifdef GNF_DW_TRACE
@@ -1054,8 +1057,8 @@ static int launch_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJo
         for (int e = 0; e < nj; ++e) {
             const int mt_ = jobs[e].M < WGM ? jobs[e].M : WGM, nt_ = jobs[e].N < WGN ? jobs[e].N : WGN;
             const WideLayout l = wide_layout(mt_, nt_);
-            const int wext = (l.along_n || l.along_m) ? 32 : 64;
-            cost[e] = side(mt_ < wext ? mt_ : wext) * side(nt_ < wext ? nt_ : wext);
+            const int wext_m = l.along_m ? 16 : 32, wext_n = l.along_n ? 16 : (l.along_m ? 32 : 64);
+            cost[e] = 2 * side(mt_ < wext_m ? mt_ : wext_m) * side(nt_ < wext_n ? nt_ : wext_n);  // two waves per SIMD
             tiles_of[e] = ((jobs[e].M + WGM - 1) / WGM) * ((jobs[e].N + WGN - 1) / WGN);
             order[e] = e;
         }
@@ -1541,6 +1544,15 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 rc = mlp_backward_generic(p, o, flow->gnn, nets, x_cond, z + uo, ld, g + uo, D, st);
             }
             if (rc) return rc;
+            // message passing: the weight gradients only read what the fused kernel has just written, so their stream
+            // forks HERE, before the scatter of dL/dx_cond (with an attention front-end they also read its backward
+            // pass and fork after it)
+            static const bool late_fork = getenv("GNF_DW_LATE_FORK") != nullptr;  // developer A/B switch
+            const bool early_fork = aux && !attn && !late_fork;
+            if (early_fork) {
+                GNF_HIP_TRY(hipEventRecord(ev_ready, st));
+                GNF_HIP_TRY(hipStreamWaitEvent(aux, ev_ready, 0));
+            }
             // ---- dL/dx_cond: on the critical path (the next half-step's coupling reads g), so it goes first -----
             if (attn) {
                 const GnfAttn* at[2] = {nets[0]->attn, nets[1]->attn};
@@ -1565,8 +1577,10 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             {
                 hipStream_t wst = st;
                 if (aux) {
-                    GNF_HIP_TRY(hipEventRecord(ev_ready, st));
-                    GNF_HIP_TRY(hipStreamWaitEvent(aux, ev_ready, 0));
+                    if (!early_fork) {
+                        GNF_HIP_TRY(hipEventRecord(ev_ready, st));
+                        GNF_HIP_TRY(hipStreamWaitEvent(aux, ev_ready, 0));
+                    }
                     wst = aux;
                 }
                 WGJob jobs[kMaxGroup];

@@ -17,6 +17,7 @@ for v in "$@"; do
     grouped) run $v GNF_DW_GROUPED=1 ;;
     grouped_serial) run $v GNF_DW_GROUPED=1 GNF_TRAIN_NO_OVERLAP=1 ;;
     auto) run $v X=1 ;;
+    latefork) run $v GNF_DW_LATE_FORK=1 ;;
     lib_*) run $v GNF_LIB_PATH=$R/graph-normalizing-flows_amd/variants/libgnf_${v#lib_}.so ;;
     auto_serial) run $v GNF_TRAIN_NO_OVERLAP=1 ;;
     units*_serial) c=${v#units}; c=${c%_serial}; run $v GNF_TRAIN_NO_OVERLAP=1 GNF_DW_WIDE_UNITS=$c ;;
