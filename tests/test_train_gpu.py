@@ -393,6 +393,30 @@ def test_gradients_on_a_batch_with_more_tiles_than_cus(community_medium):
         _check_grads(tr.named_gradients(), ref["grads"], False, scale=1e-3)
 
 
+DW_MODES = [
+    ({}, ""),                                                     # what the library picks by itself
+    ({"GNF_DW_GROUPED": "1"}, ""),                                # the 128 x 64 grouped kernel
+    ({"GNF_DW_WIDE_UNITS": "8"}, ""),                             # few workgroups: cheap units ride behind, strided
+    ({"GNF_DW_WIDE_UNITS": "200"}, "ws"),                         # many node chunks per job + accumulating reduce
+    ({"GNF_DW_WIDE_UNITS": "24", "GNF_DW_NO_BUF": "1"}, ""),      # bounds-checked generic tile fetch
+    ({"GNF_DW_WIDE_UNITS": "40", "GNF_TRAIN_NO_OVERLAP": "1"}, "ws"),
+]
+
+
+@pytest.mark.parametrize("env,arg", DW_MODES, ids=["auto", "grouped", "wide8", "wide200_ws", "wide24_nobuf", "wide40_serial_ws"])
+def test_weight_gradient_kernel_launch_shapes(env, arg):
+    """The dW GEMM has several launch shapes chosen per batch; the switches are read once per
+    process, so each shape runs tools/dw_modes_check.py (gradients of a ~900-node batch with ragged layer widths vs
+    the oracle, 1e-3 of each tensor's max) in its own interpreter."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dw_modes_check.py")] + ([arg] if arg else []),
+                       env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "dw-modes-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
 def test_checkpoint_resume_reproduces_the_run(grid_small, tmp_path):
     """save_checkpoint after 3 steps, load into a freshly built trainer: parameters, Adam moments, step counter and
     batch-norm moving statistics come back, and the next step is bitwise the same as in the uninterrupted run."""
