@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 GNF_MAX_LAYERS = 8
-GNF_ABI_VERSION = 4
+GNF_ABI_VERSION = 5
 
 GNF_AGG_SUM, GNF_AGG_MEAN = 0, 1
 GNF_COMBINE_EPS, GNF_COMBINE_CONCAT = 0, 1
@@ -53,10 +53,15 @@ class GnfBatchNorm(C.Structure):
                 ("epsilon", C.c_float), ("reserved", C.c_int32)]
 
 
+# ABI v5: int hook(void* ctx, double* device_buf, int64_t count, gnf_stream_t stream) - in-place SUM all-reduce
+BN_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
 class GnfFlow(C.Structure):
     _fields_ = [("num_timesteps", C.c_int32), ("weight_sharing", C.c_int32),
                 ("s_nets", C.POINTER(GnfMlp)), ("t_nets", C.POINTER(GnfMlp)), ("gnn", GnfGnnSpec),
-                ("bns", C.POINTER(GnfBatchNorm))]
+                ("bns", C.POINTER(GnfBatchNorm)),
+                ("bn_allreduce", BN_ALLREDUCE_FN), ("bn_allreduce_ctx", C.c_void_p), ("bn_sync_buf", C.c_void_p)]
 
 
 _SIGNATURES = {

@@ -356,7 +356,7 @@ int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld
             for (int i = 0; i < T; ++i) {  // gnn.py:309-338
                 for (int half = 0; half < 2; ++half) {
                     if (flow->bns) {  // gnn.py:310-313, 325-328: normalise the conditioning half first
-                        rc = launch_bn_normalize(&flow->bns[half * T + i], half == 0 ? half0 : half1, ld, n, H,
+                        rc = launch_bn_normalize(flow, &flow->bns[half * T + i], half == 0 ? half0 : half1, ld, n, H,
                                                  partials + p.bn_offset, partials + used, st);
                         if (rc) return rc;
                         used += 1;

@@ -51,13 +51,48 @@ __global__ __launch_bounds__(256) void k_bn_stats(const float* __restrict__ x, i
     }
 }
 
+// cross-rank moments: the partials of this rank summed (same fixed order as pass 2) into out[H][2], the node count
+// behind them; `copy` (nullable) receives the same pairs and stays local.
+__global__ __launch_bounds__(256) void k_bn_fold(const double* __restrict__ part, int nparts, int H, int64_t n,
+                                                 double* __restrict__ out, double* __restrict__ copy) {
+    for (int c = threadIdx.x; c < H; c += 256) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < nparts; ++b) {
+            s += part[((int64_t)b * H + c) * 2 + 0];
+            q += part[((int64_t)b * H + c) * 2 + 1];
+        }
+        out[2 * c + 0] = s;
+        out[2 * c + 1] = q;
+        if (copy) copy[2 * c + 0] = s, copy[2 * c + 1] = q;
+    }
+    if (threadIdx.x == 0) out[2 * H] = (double)n;
+}
+
+int bn_sync_exchange(const GnfFlow* flow, const double* part, int nparts, int64_t n, int32_t H, double* local_copy,
+                     hipStream_t st) {
+    if (!flow->bn_sync_buf) {
+        set_error("GnfFlow.bn_allreduce is set but bn_sync_buf is NULL (needs 2*(D/2)+1 doubles of device memory)");
+        return GNF_EINVAL;
+    }
+    hipLaunchKernelGGL(k_bn_fold, dim3(1), dim3(256), 0, st, part, nparts, H, n, flow->bn_sync_buf, local_copy);
+    GNF_LAUNCH_CHECK("k_bn_fold");
+    const int rc = flow->bn_allreduce(flow->bn_allreduce_ctx, flow->bn_sync_buf, 2 * (int64_t)H + 1, (gnf_stream_t)st);
+    if (rc != 0) {
+        set_error("GnfFlow.bn_allreduce hook failed with %d", rc);
+        return GNF_EINVAL;
+    }
+    return GNF_OK;
+}
+
 // pass 2: every workgroup re-reduces the (few) partials, normalises its rows in place; workgroup 0 also
-// writes the log-det term and the batch moments.
+// writes the log-det term and the batch moments.  n_moments (nullable, device): the node count the moments are
+// over when the partials are cross-rank sums (the log-det term still counts THIS rank's n nodes).
 __global__ __launch_bounds__(256) void k_bn_apply(float* __restrict__ x, int64_t ld, int64_t n, int H,
                                                   int64_t rows_per_block, const double* __restrict__ part, int nparts,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                   float eps, float* __restrict__ batch_mean,
-                                                  float* __restrict__ batch_var, double* __restrict__ logdet_slot) {
+                                                  float* __restrict__ batch_var, double* __restrict__ logdet_slot,
+                                                  const double* __restrict__ n_moments) {
     extern __shared__ float ss[];  // scale[H] | shift[H]
     __shared__ double red[256];
     float* scale = ss;
@@ -81,8 +116,9 @@ __global__ __launch_bounds__(256) void k_bn_apply(float* __restrict__ x, int64_t
                     q += pq_[k];
                 }
         }
-        const double mean = s / (double)n;
-        double var = q / (double)n - mean * mean;
+        const double nm = n_moments ? *n_moments : (double)n;
+        const double mean = s / nm;
+        double var = q / nm - mean * mean;
         if (var < 0.0) var = 0.0;
         const float g = gamma[c];
         const float sc = g / sqrtf((float)var + eps);
@@ -142,17 +178,26 @@ int bn_blocks(int64_t n, int64_t* rows_per_block) {
     return (int)blocks;
 }
 
-int launch_bn_normalize(const GnfBatchNorm* bn, float* x, int64_t ld, int64_t n, int32_t H, double* part,
-                        double* logdet_slot, hipStream_t st) {
+int launch_bn_normalize(const GnfFlow* flow, const GnfBatchNorm* bn, float* x, int64_t ld, int64_t n, int32_t H,
+                        double* part, double* logdet_slot, hipStream_t st) {
     if (n == 0) return GNF_OK;
     int64_t rpb;
-    const int blocks = bn_blocks(n, &rpb);
+    int blocks = bn_blocks(n, &rpb);
     hipLaunchKernelGGL(k_bn_stats, dim3(blocks), dim3(256), 0, st, x, ld, n, H, rpb, part);
     GNF_LAUNCH_CHECK("k_bn_stats");
+    const double* n_moments = nullptr;
+    if (flow->bn_allreduce) {  // the moments of the whole batch, not of this rank's shard
+        const int rc = bn_sync_exchange(flow, part, blocks, n, H, nullptr, st);
+        if (rc) return rc;
+        part = flow->bn_sync_buf;
+        blocks = 1;
+        n_moments = flow->bn_sync_buf + 2 * (int64_t)H;
+    }
     const int64_t arows = kBnRows;
     const int64_t ablocks = (n + arows - 1) / arows;
     hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)ablocks), dim3(256), 2 * H * sizeof(float), st, x, ld, n, H, arows, part,
-                       blocks, bn->gamma, bn->beta, bn->epsilon, bn->batch_mean, bn->batch_variance, logdet_slot);
+                       blocks, bn->gamma, bn->beta, bn->epsilon, bn->batch_mean, bn->batch_variance, logdet_slot,
+                       n_moments);
     GNF_LAUNCH_CHECK("k_bn_apply");
     return GNF_OK;
 }

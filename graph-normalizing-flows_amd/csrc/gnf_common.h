@@ -108,8 +108,12 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
 
 // batch-norm bijector (gnf_bn.hip)
 int validate_bn(const GnfBatchNorm* bn, int direction, const char* what, int q);
-int launch_bn_normalize(const GnfBatchNorm* bn, float* x, int64_t ld, int64_t n, int32_t H, double* part,
-                        double* logdet_slot, hipStream_t st);
+// cross-rank moments (GnfFlow.bn_allreduce): fold the per-workgroup partials into flow->bn_sync_buf (and, when
+// local_copy != NULL, into a second copy that stays local), then call the hook.  part: [nparts][H][2] doubles.
+int bn_sync_exchange(const GnfFlow* flow, const double* part, int nparts, int64_t n, int32_t H, double* local_copy,
+                     hipStream_t st);
+int launch_bn_normalize(const GnfFlow* flow, const GnfBatchNorm* bn, float* x, int64_t ld, int64_t n, int32_t H,
+                        double* part, double* logdet_slot, hipStream_t st);
 int launch_bn_denormalize(const GnfBatchNorm* bn, float* z, int64_t ld, int64_t n, int32_t H, hipStream_t st);
 
 int validate_mlp(const GnfMlp* m, const char* what);

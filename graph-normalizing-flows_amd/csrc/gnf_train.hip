@@ -741,7 +741,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(float* __restrict__ y, int
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ bmean, const float* __restrict__ bvar,
                                                       float eps, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                      int accumulate) {
+                                                      int accumulate, const double* __restrict__ gsum,
+                                                      const double* __restrict__ n_moments) {
     extern __shared__ float ss[];  // per column: m1 = mean(gamma Gy), m2 = mean(gamma Gy xh), gamma, beta, sigma, mu
     float* m1 = ss;
     float* m2 = ss + H;
@@ -768,8 +769,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(float* __restrict__ y, int
                 }
         }
         const float g = gamma[c];
-        m1[c] = (float)(s / (double)n) * g;
-        m2[c] = (float)(q / (double)n) * g;
+        // the means in dx are over the whole batch (cross-rank sums when gsum != NULL); d gamma / d beta below are
+        // THIS rank's share - the gradient all-reduce adds the shares up
+        const double nm = n_moments ? *n_moments : (double)n;
+        const double sg_ = gsum ? gsum[2 * c + 0] : s, qg_ = gsum ? gsum[2 * c + 1] : q;
+        m1[c] = (float)(sg_ / nm) * g;
+        m2[c] = (float)(qg_ / nm) * g;
         sg[c] = g;
         sb[c] = beta[c];
         ssig[c] = sqrtf(bvar[c] + eps);
@@ -797,8 +802,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(float* __restrict__ y, int
     }
 }
 
-static int launch_bn_backward(const GnfBatchNorm* bn, const GnfBatchNorm* gbn, float* y, int64_t ld, float* gy,
-                              int64_t ldg, int64_t n, int32_t H, double* part, hipStream_t st) {
+static int launch_bn_backward(const GnfFlow* flow, const GnfBatchNorm* bn, const GnfBatchNorm* gbn, float* y, int64_t ld,
+                              float* gy, int64_t ldg, int64_t n, int32_t H, double* part, hipStream_t st) {
     int64_t rpb = 256;  // moment pass: few large chunks;  rewrite pass: many small ones
     int64_t blocks = (n + rpb - 1) / rpb;
     if (blocks > kBnBlocksMax) {
@@ -808,11 +813,21 @@ static int launch_bn_backward(const GnfBatchNorm* bn, const GnfBatchNorm* gbn, f
     hipLaunchKernelGGL(k_bn_bwd_stats, dim3((unsigned)blocks), dim3(256), 0, st, y, ld, gy, ldg, n, H, rpb, bn->gamma,
                        bn->beta, part);
     GNF_LAUNCH_CHECK("k_bn_bwd_stats");
+    const double *gsum = nullptr, *n_moments = nullptr;
+    if (flow->bn_allreduce) {  // sum G, sum G x^ over the whole batch; this rank's own sums stay behind the partials
+        double* local = part + (size_t)kBnBlocksMax * H * 2;
+        const int rc = bn_sync_exchange(flow, part, (int)blocks, n, H, local, st);
+        if (rc) return rc;
+        part = local;
+        blocks = 1;
+        gsum = flow->bn_sync_buf;
+        n_moments = flow->bn_sync_buf + 2 * (int64_t)H;
+    }
     const int64_t arows = 16;
     const int64_t ablocks = (n + arows - 1) / arows;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)ablocks), dim3(256), 6 * H * sizeof(float), st, y, ld, gy, ldg, n,
                        H, arows, part, (int)blocks, bn->gamma, bn->beta, bn->batch_mean, bn->batch_variance, bn->epsilon,
-                       const_cast<float*>(gbn->gamma), const_cast<float*>(gbn->beta), 0);
+                       const_cast<float*>(gbn->gamma), const_cast<float*>(gbn->beta), 0, gsum, n_moments);
     GNF_LAUNCH_CHECK("k_bn_bwd_apply");
     return GNF_OK;
 }
@@ -874,7 +889,7 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net) {
     size_t off = 0;
     p.g = off, off += al64((size_t)n * D);
     p.invdeg = off, off += al64((size_t)n);
-    p.bnpart = off, off += al64((size_t)kBnBlocksMax * (size_t)p.H * 4);  // fp64 pairs of the batch-norm backward
+    p.bnpart = off, off += al64(((size_t)kBnBlocksMax + 1) * (size_t)p.H * 4);  // fp64 pairs of the batch-norm backward (+ one row: this rank's sums under cross-rank moments)
     p.st = off, off += 2 * al64((size_t)n * p.H);
     p.wslab = off, off += al64((size_t)chunks * p.wsum);
     p.bslab = off, off += al64((size_t)chunks * p.osum);
@@ -1600,7 +1615,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             ++step;
             if (rc) return rc;
             if (flow->bns) {  // the bijector sat in front of this half-step (gnn.py:310-313, 325-328)
-                rc = launch_bn_backward(&flow->bns[half * T + i], &grad->bns[half * T + i], z + co, ld, g + co, D, n, H,
+                rc = launch_bn_backward(flow, &flow->bns[half * T + i], &grad->bns[half * T + i], z + co, ld, g + co, D, n, H,
                                         reinterpret_cast<double*>(wsf + p.bnpart), st);
                 if (rc) return rc;
             }

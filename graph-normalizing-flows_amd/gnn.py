@@ -475,7 +475,13 @@ def make_batch_norm():                                # gnn.py:260-263
 # ----------------------------------------------------------------------------------------------
 class GRevNet:
     def __init__(self, make_gnn_fn, num_timesteps, node_embedding_dim, use_batch_norm=False,
-                 weight_sharing=False, name="GRevNet"):
+                 weight_sharing=False, name="GRevNet", sync_batch_norm=False):
+        # sync_batch_norm (not in the reference, which is single-device): under graph sharding with
+        # torch.distributed, take the bijectors' batch moments over ALL ranks' nodes (one small all-reduce per
+        # bijector call through GnfFlow.bn_allreduce), so that N ranks reproduce what one device computes for the
+        # whole batch (gnn.py:310-313).  False: per-shard moments, no extra collective.
+        self.sync_batch_norm = bool(sync_batch_norm)
+        self.bn_process_group = None   # torch.distributed group of the cross-rank moments (None: the default group)
         self.num_timesteps = int(num_timesteps)
         self.weight_sharing = bool(weight_sharing)
         self.node_embedding_dim = node_embedding_dim  # accepted and unused, as in gnn.py:277
@@ -558,8 +564,9 @@ class GRevNet:
         t_mlps = [m.ensure_built(b0.in_dim(hdim), device) for m in self.mlps("t")]
         attn_descs = [b.attn_desc(hdim, device) for b in blocks]          # None for message-passing blocks
         bn_list = [b.ensure_built(hdim, device) for half in self.bns for b in half] if self.use_batch_norm else []
+        sync = self._bn_sync_world() if bn_list else 0
         key = (str(device), hdim, bool(self.fused), tuple(m.version for m in s_mlps + t_mlps),
-               tuple(b.attn_version() for b in blocks), tuple(b.version for b in bn_list))
+               tuple(b.attn_version() for b in blocks), tuple(b.version for b in bn_list), sync)
         if self._cache is not None and self._cache[0] == key:
             return self._cache[1]
         n = len(s_mlps)
@@ -593,8 +600,35 @@ class GRevNet:
         flow = _abi.GnfFlow(self.num_timesteps, int(self.weight_sharing),
                             C.cast(s_arr, C.POINTER(_abi.GnfMlp)), C.cast(t_arr, C.POINTER(_abi.GnfMlp)),
                             b0.spec(), C.cast(bn_arr, C.POINTER(_abi.GnfBatchNorm)) if bn_arr is not None else None)
-        self._cache = (key, flow, (s_arr, t_arr, attn_arr, packed, s_mlps, t_mlps, blocks, bn_arr, bn_list))
+        hook_keep = None
+        if sync > 1:   # cross-rank batch moments: the library fills sync_buf, calls back, reads the reduced sums
+            import torch.distributed as dist
+            sync_buf = torch.zeros(2 * hdim + 1, dtype=torch.float64, device=device)
+            group = self.bn_process_group
+
+            def _hook(_ctx, _buf, _count, _stream):
+                try:   # SUM over ranks, ordered on the current stream (the one the library call was given)
+                    dist.all_reduce(sync_buf, group=group)
+                    return 0
+                except Exception as exc:   # never raise through the C frame
+                    import sys
+                    print(f"[gnf] bn_allreduce hook failed: {exc!r}", file=sys.stderr)
+                    return -1
+            cb = _abi.BN_ALLREDUCE_FN(_hook)
+            flow.bn_allreduce = cb
+            flow.bn_sync_buf = sync_buf.data_ptr()
+            hook_keep = (cb, sync_buf)
+        self._cache = (key, flow, (s_arr, t_arr, attn_arr, packed, s_mlps, t_mlps, blocks, bn_arr, bn_list, hook_keep))
         return flow
+
+    def _bn_sync_world(self):
+        """World size the batch-norm moments are taken over (1: this process only)."""
+        if not (self.use_batch_norm and self.sync_batch_norm):
+            return 1
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1
+        return dist.get_world_size(self.bn_process_group)
 
     def _run(self, graph, direction, sums_out=None):
         lib = _abi.lib()
@@ -607,6 +641,9 @@ class GRevNet:
         dev = x.device
         out = x.to(torch.float32).clone(memory_format=torch.contiguous_format)  # TF ops are functional
         flow = self._flow(d // 2, dev)
+        if n == 0 and self._bn_sync_world() > 1:
+            raise ValueError("sync_batch_norm: a rank with an empty shard cannot take part in the cross-rank moments "
+                             "(every rank must make the same sequence of all-reduce calls)")
         csr = csr_of(graph)
         ws_bytes = lib.gnf_workspace_bytes(n, d, C.byref(flow))
         ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)

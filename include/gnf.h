@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GNF_ABI_VERSION 4
+#define GNF_ABI_VERSION 5
 #define GNF_MAX_LAYERS 8 /* Linear layers per MLP (gnn.py:165-166 builds num_layers of them) */
 
 typedef void* gnf_stream_t; /* hipStream_t */
@@ -136,6 +136,18 @@ typedef struct GnfFlow {
     /* ABI v4: NULL (use_batch_norm=False), or host array of 2*T bijectors indexed [half*T + i] - one per
      * half-step even with weight sharing (gnn.py:298-299) */
     const GnfBatchNorm* bns;
+    /* ABI v5: cross-rank batch statistics.  The reference runs on ONE device, so its bijector sees the moments of the
+     * whole batch (gnn.py:310-313).  Under graph sharding (one rank per GPU) each rank holds a part of the batch: with
+     * bn_allreduce == NULL the moments are per shard (ordinary data-parallel batch norm); with a hook they are the
+     * whole batch's again.  Per bijector call the library puts this rank's [sum_f, sum-of-squares_f] pairs (f < D/2,
+     * interleaved) followed by its node count into bn_sync_buf (2*(D/2)+1 doubles of device memory, caller-owned),
+     * calls bn_allreduce(ctx, bn_sync_buf, 2*(D/2)+1, stream) - which must enqueue an in-place SUM all-reduce of that
+     * buffer over the ranks, ordered on `stream` (ncclAllReduce on it, or torch.distributed on the current stream) and
+     * return 0 - and normalises with the reduced moments; the backward pass does the same with its two sums.  Every
+     * rank must make the same sequence of calls (a rank with an empty shard cannot take part). */
+    int (*bn_allreduce)(void* ctx, double* device_buf, int64_t count, gnf_stream_t stream);
+    void* bn_allreduce_ctx;
+    double* bn_sync_buf;
 } GnfFlow;
 
 int gnf_abi_version(void);

@@ -417,6 +417,57 @@ def test_weight_gradient_kernel_launch_shapes(env, arg):
     assert r.returncode == 0 and "dw-modes-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
+def test_cross_rank_batch_norm_moments_two_ranks_one_gpu():
+    """GRevNet(sync_batch_norm=True) / GnfFlow.bn_allreduce (ABI v5): two ranks on this GPU (gloo), half of the graphs
+    each, reproduce the single-process whole-batch z (bitwise in practice), loss, batch moments and - after the
+    gradient all-reduce - gradients; per-shard moments do not (tools/sync_bn_check.py)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "sync_bn_check.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "sync-bn-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_batch_norm_allreduce_hook_contract(grid_small):
+    """The C-ABI side of the hook on one rank: a missing bn_sync_buf and a failing hook are reported, an identity
+    hook (one rank: the sums are already the whole batch's) gives exactly the result of the hook-less path."""
+    import ctypes as C
+    from gnf_amd import _abi
+    hp = dict(D=8, latent=32, K=2, T=2, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu",
+              weight_sharing=False)
+    nn, ne, s, r = _batch(grid_small, list(range(8)))
+    n = int(nn.sum())
+    x = (np.random.default_rng(2).standard_normal((n, 8)) * 1.2).astype(np.float32)
+    p = O.make_grevnet_params(8, 4, 32, 2, 2, final_scale=0.3)
+    p["bn"] = O.make_bn_params(9, 4, 2)
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    net = make_product_grevnet(hp, p)
+    z_ref, ld_ref = net(graph, inverse=True)
+    calls = []
+    rc = [0]
+
+    def hook(ctx, buf, count, stream):
+        calls.append(int(count))
+        return rc[0]
+    cb = _abi.BN_ALLREDUCE_FN(hook)
+    flow = net._flow(4, torch.device(DEV))          # the cached descriptor the next calls use
+    flow.bn_allreduce = cb
+    with pytest.raises(_abi.GnfError, match="bn_sync_buf"):
+        net(graph, inverse=True)
+    buf = torch.zeros(2 * 4 + 1, dtype=torch.float64, device=DEV)
+    flow.bn_sync_buf = buf.data_ptr()
+    z, ld = net(graph, inverse=True)
+    torch.cuda.synchronize()
+    assert calls == [9] * 4                          # one exchange per bijector call: 2 T half-steps
+    assert torch.equal(z.nodes, z_ref.nodes) and float(ld) == float(ld_ref)
+    assert float(buf[8]) == n                        # [sum, sum of squares] x 4 features, then the node count
+    rc[0] = -7
+    with pytest.raises(_abi.GnfError, match="hook failed"):
+        net(graph, inverse=True)
+    flow.bn_allreduce = _abi.BN_ALLREDUCE_FN()       # back to NULL
+    flow.bn_sync_buf = None
+
+
 def test_checkpoint_resume_reproduces_the_run(grid_small, tmp_path):
     """save_checkpoint after 3 steps, load into a freshly built trainer: parameters, Adam moments, step counter and
     batch-norm moving statistics come back, and the next step is bitwise the same as in the uninterrupted run."""
