@@ -258,6 +258,9 @@ def main():
     n_local, e_local = int(graph.nodes.shape[0]), int(graph.senders.shape[0])
     net = make_product_grevnet(HP, params)
     net.fused = not args.layered
+    # batch-norm workloads under sharding: the bijectors take their moments over the whole (global) batch like the
+    # single-device reference does (one small all-reduce per bijector call)
+    net.sync_batch_norm = bool(HP.get("use_batch_norm")) and world > 1
 
     from gnf_amd.graphs import build_csr_device
     build_csr_device(graph)                  # warm (first-call kernel load), then time one build
