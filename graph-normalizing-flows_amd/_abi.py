@@ -61,11 +61,13 @@ class GnfFlow(C.Structure):
     _fields_ = [("num_timesteps", C.c_int32), ("weight_sharing", C.c_int32),
                 ("s_nets", C.POINTER(GnfMlp)), ("t_nets", C.POINTER(GnfMlp)), ("gnn", GnfGnnSpec),
                 ("bns", C.POINTER(GnfBatchNorm)),
-                ("bn_allreduce", BN_ALLREDUCE_FN), ("bn_allreduce_ctx", C.c_void_p), ("bn_sync_buf", C.c_void_p)]
+                ("bn_allreduce", BN_ALLREDUCE_FN), ("bn_allreduce_ctx", C.c_void_p), ("bn_sync_buf", C.c_void_p),
+                ("attn_stash", C.c_void_p), ("attn_stash_bytes", C.c_size_t)]
 
 
 _SIGNATURES = {
     "gnf_abi_version": (C.c_int, []),
+    "gnf_attn_stash_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.POINTER(GnfFlow)]),
     "gnf_last_error": (C.c_char_p, []),
     "gnf_packed_floats": (C.c_int64, [C.POINTER(GnfMlp)]),
     "gnf_pack_mlp": (C.c_int, [C.POINTER(GnfMlp), C.c_void_p, C.c_void_p]),

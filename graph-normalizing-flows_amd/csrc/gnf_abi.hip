@@ -184,6 +184,11 @@ extern "C" {
 
 int gnf_abi_version(void) { return GNF_ABI_VERSION; }
 
+size_t gnf_attn_stash_bytes(int64_t n_nodes, int32_t D, const GnfFlow* flow) {
+    if (n_nodes <= 0 || D < 2 || !flow || !flow->s_nets || flow->num_timesteps <= 0) return 0;
+    return (size_t)2 * flow->num_timesteps * attn_stash_slot_floats(flow, n_nodes) * sizeof(float);
+}
+
 const char* gnf_last_error(void) { return g_err; }
 
 int64_t gnf_packed_floats(const GnfMlp* mlp) {
@@ -350,6 +355,17 @@ int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld
     float* half0 = x;       // columns [0, H)
     float* half1 = x + H;   // columns [H, D)
     int64_t used = 0;       // partial slots written so far (packed densely, fixed order)
+    // the forward pass leaves every half-step's attention front-end in the caller's stash for the backward pass
+    const size_t stash_slot = attn_stash_slot_floats(flow, n);
+    float* stash = nullptr;
+    if (direction == GNF_FORWARD && flow->attn_stash && stash_slot > 0) {
+        if (flow->attn_stash_bytes < (size_t)2 * T * stash_slot * sizeof(float)) {
+            set_error("gnf_grevnet_f32: attn_stash %zu < %zu bytes", flow->attn_stash_bytes,
+                      (size_t)2 * T * stash_slot * sizeof(float));
+            return GNF_EWORKSPACE;
+        }
+        stash = flow->attn_stash;
+    }
 
     if (n > 0) {
         if (direction == GNF_FORWARD) {
@@ -365,7 +381,8 @@ int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld
                     HalfStep hs{csr->rowptr, csr->col, n, half == 0 ? half0 : half1,
                                 half == 0 ? half1 : half0, ld, H, GNF_FORWARD, flow->gnn,
                                 pick(flow, flow->s_nets, half, i), pick(flow, flow->t_nets, half, i),
-                                partials + used, &np_};
+                                partials + used, &np_,
+                                stash ? stash + (size_t)(2 * i + half) * stash_slot : nullptr};
                     rc = run_half(hs, scratch, st);
                     if (rc) return rc;
                     used += np_;
@@ -378,7 +395,7 @@ int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld
                     HalfStep hs{csr->rowptr, csr->col, n, half == 0 ? half0 : half1,
                                 half == 0 ? half1 : half0, ld, H, GNF_INVERSE, flow->gnn,
                                 pick(flow, flow->s_nets, half, i), pick(flow, flow->t_nets, half, i),
-                                partials + used, &np_};
+                                partials + used, &np_, nullptr};
                     rc = run_half(hs, scratch, st);
                     if (rc) return rc;
                     // partial slots are reused: the inverse pass has no log-det (gnn.py:343-373)

@@ -525,6 +525,12 @@ size_t attn_scratch_floats(const GnfAttn* at, int64_t n_nodes, int32_t in0) {
     return 2 * (size_t)n_nodes * (P + (size_t)in0);
 }
 
+size_t attn_stash_slot_floats(const GnfFlow* flow, int64_t n_nodes) {
+    const GnfMlp* net = flow && flow->s_nets ? &flow->s_nets[0] : nullptr;
+    if (!net || !net->attn || n_nodes <= 0) return 0;
+    return attn_scratch_floats(net->attn, n_nodes, net->dims[0]);
+}
+
 // nets: 1 or 2 attention blocks sharing x / topology; writes h0[q] ([N, in0]) for each.
 int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, const float* x, int64_t ldx,
                       int32_t H, const GnfAttn* const* at, int nets, int32_t in0, float* scratch,

@@ -44,7 +44,11 @@ struct HalfStep {
     const GnfMlp* t_net;  // host
     double* partials;     // device: one fp64 partial sum(s) per workgroup of the epilogue kernel
     int32_t* n_partials;  // host out: how many partials this launch writes
+    float* attn_region;   // NULL: the attention front-end works in the scratch; else q | k | v and h0 of both nets go
+                          // here (a slot of GnfFlow.attn_stash) and stay for the backward pass
 };
+// floats of one half-step's slot in GnfFlow.attn_stash ( = attn_scratch_floats: [2][n][P] q|k|v, then [2][n][in0] h0)
+size_t attn_stash_slot_floats(const GnfFlow* flow, int64_t n_nodes);
 
 // ---- layout of the caller-provided workspace --------------------------------------------------
 // [ fp64 partial sums | float scratch of the layered path ]

@@ -570,7 +570,8 @@ int launch_attn_pair(const HalfStep& hs, float* scratch, float** h0_pair, hipStr
     int lmax = lmax_of(hs.s_net);
     const int lt = lmax_of(hs.t_net);
     lmax = lmax > lt ? lmax : lt;
-    float* region = scratch + (size_t)n * (size_t)(in0 + kLayeredActBufs * lmax + 2 * hs.H);
+    float* region = hs.attn_region ? hs.attn_region
+                                   : scratch + (size_t)n * (size_t)(in0 + kLayeredActBufs * lmax + 2 * hs.H);
     const GnfAttn* a0 = hs.s_net->attn;
     const size_t P = 2 * (size_t)a0->num_heads * a0->kq_dim + a0->v_dim;
     h0_pair[0] = region + 2 * (size_t)n * P;

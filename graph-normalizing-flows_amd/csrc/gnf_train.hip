@@ -1469,6 +1469,12 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
         return GNF_EWORKSPACE;
     }
     const int H = D / 2;
+    const size_t stash_slot = attn_stash_slot_floats(flow, n);
+    if (flow->attn_stash && stash_slot > 0 && flow->attn_stash_bytes < (size_t)2 * T * stash_slot * sizeof(float)) {
+        set_error("gnf_grevnet_backward_f32: attn_stash %zu < %zu bytes", flow->attn_stash_bytes,
+                  (size_t)2 * T * stash_slot * sizeof(float));
+        return GNF_EWORKSPACE;
+    }
     if (n == 0) {  // an empty batch has zero gradient
         for (int q = 0; q < n_nets; ++q)
             for (int kind = 0; kind < 2; ++kind) {
@@ -1531,15 +1537,28 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             const bool attn = nets[0]->attn != nullptr;
             const bool fused = !no_fused && fused_bwd_supported(nets[0], nets[1]);
             const int set = step & 1;
-            const BwdOperands o = bwd_operands(p, wsf, set, attn);
+            BwdOperands o = bwd_operands(p, wsf, set, attn);
+            // attention front-end left behind by the forward pass (GnfFlow.attn_stash): q | k | v and the layer-0
+            // inputs of both nets are read from the half-step's slot instead of being recomputed
+            const bool stashed = attn && stash_slot > 0 && flow->attn_stash != nullptr;
+            if (stashed) {
+                float* slot = flow->attn_stash + (size_t)(2 * i + half) * stash_slot;
+                for (int q = 0; q < 2; ++q) {
+                    o.qkv[q] = slot + (size_t)q * n * p.P;
+                    o.h0[q] = slot + 2 * (size_t)n * p.P + (size_t)q * n * p.in0;
+                    o.hin[q * p.K] = o.h0[q];
+                }
+            }
             float* x_cond = z + co;
             // this set's previous reader (the dW GEMMs of two half-steps ago) must be done
             if (aux && ev_done[set]) GNF_HIP_TRY(hipStreamWaitEvent(st, ev_done[set], 0));
             // ---- layer-0 inputs -------------------------------------------------------------------------
             if (attn) {   // recompute the attention front-end of both nets (q | k | v kept for the way back)
                 const GnfAttn* at[2] = {nets[0]->attn, nets[1]->attn};
-                rc = launch_attn_front(csr->rowptr, csr->col, n, x_cond, ld, H, at, 2, p.in0, o.qkv[0], o.h0, st);
-                if (rc) return rc;
+                if (!stashed) {
+                    rc = launch_attn_front(csr->rowptr, csr->col, n, x_cond, ld, H, at, 2, p.in0, o.qkv[0], o.h0, st);
+                    if (rc) return rc;
+                }
                 int64_t blocks = (n * H + 255) / 256;
                 if (blocks > 4096) blocks = 4096;
                 hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)blocks), dim3(256), 0, st, x_cond, ld, o.xc, (int64_t)H, n, H);

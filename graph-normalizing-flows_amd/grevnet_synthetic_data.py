@@ -53,10 +53,36 @@ class SyntheticDataset:
         return data_dicts_to_graphs_tuple(self.get_next_batch_data_dicts(batch_size), device)
 
 
+@functools.lru_cache(maxsize=None)
+def _moons_template(n_samples):
+    """The noise-free, unshuffled point set of sklearn.datasets.make_moons(n_samples): outer half circle first,
+    then the inner one (read-only [n, 2] float64)."""
+    n_out = n_samples // 2
+    n_in = n_samples - n_out
+    t_out, t_in = np.linspace(0, np.pi, n_out), np.linspace(0, np.pi, n_in)
+    x = np.vstack([np.append(np.cos(t_out), 1 - np.cos(t_in)), np.append(np.sin(t_out), 1 - np.sin(t_in) - 0.5)]).T
+    x.setflags(write=False)
+    return x
+
+
+def make_moons(n_samples, noise, seed):
+    """sklearn.datasets.make_moons(n_samples, shuffle=True, noise=noise, random_state=seed)[0], restated: the same
+    point set, the same RandomState draws in the same order (one shuffle of arange(n), then one normal(scale=noise)
+    of shape [n, 2]) - identical arrays (tests/test_host_logic_cpu.py checks against sklearn), without sklearn's
+    parameter validation, which cost 1 ms per graph (32 graphs per batch: more host time than the GPU needs for the
+    whole training iteration)."""
+    rs = np.random.RandomState(seed)
+    idx = np.arange(n_samples)
+    rs.shuffle(idx)
+    x = _moons_template(int(n_samples))[idx]
+    if noise is not None:
+        x += rs.normal(scale=noise, size=x.shape)
+    return x
+
+
 def moons_sample(n_samples, noise=0.05):
-    from sklearn import datasets
-    return n_samples, datasets.make_moons(n_samples=n_samples, shuffle=True, noise=noise,
-                                          random_state=random.randrange(MAX_SEED))[0].astype(np.float32)
+    # grevnet_synthetic_data.py:50-56: make_moons(..., random_state=random.randrange(MAX_SEED))[0].astype(np.float32)
+    return n_samples, make_moons(n_samples, noise, random.randrange(MAX_SEED)).astype(np.float32)
 
 
 def mom_sample(n_samples_choices, noise=0.05):

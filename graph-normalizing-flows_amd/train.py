@@ -20,6 +20,7 @@ import os
 import torch
 
 from . import _abi
+from .gnn import _touch as _gnn_touch
 from .flow import LN_2PI
 from .graphs import csr_of
 
@@ -67,6 +68,8 @@ class GRevNetTrainer:
         self._ws = None
         self._bns = []
         self._attn_blocks = []
+        self._stash = None       # attention front-end stash (uint8 device buffer), see loss_and_grads
+        self.stash_attention = os.environ.get("GNF_TRAIN_NO_STASH") is None   # developer A/B switch
         self._aux = None         # second HIP stream: the weight-gradient GEMMs overlap the backward walk
         self.overlap_weight_grads = os.environ.get("GNF_TRAIN_NO_OVERLAP") is None   # developer A/B switch
 
@@ -105,6 +108,7 @@ class GRevNetTrainer:
                 views.append((wv, bv))
             m.params = views                          # the MLP now reads / is updated through the arena
             m.version += 1
+            _gnn_touch()
         self._attn_off = off
         for blk in attn_blocks:
             views = {}
@@ -117,6 +121,7 @@ class GRevNetTrainer:
                 bounds.append(off)
             blk.attn_params = views
             blk._attn_version += 1
+            _gnn_touch()
         self._bn_off = off
         for b in bns:
             for name in ("gamma", "beta"):
@@ -127,6 +132,7 @@ class GRevNetTrainer:
                 off += old.numel()
                 bounds.append(off)
             b.version += 1
+            _gnn_touch()
         net._cache = None
         self.theta = theta
         self.grad = torch.zeros_like(theta)
@@ -230,6 +236,23 @@ class GRevNetTrainer:
         n, d = x.shape
         dev = x.device
         self._ensure_arena(d // 2, dev)
+        # attention GNNs: the forward pass leaves every half-step's front-end (q | k | v, layer-0 inputs) in a stash
+        # the backward pass reads instead of recomputing it (memory for time: 2T slots; stash_attention=False keeps
+        # the fully reversible, recompute-everything walk)
+        fwd_flow = net._flow(d // 2, dev)
+        stash_bytes = lib.gnf_attn_stash_bytes(n, d, C.byref(fwd_flow)) if self.stash_attention else 0
+        if stash_bytes:
+            if self._stash is None or self._stash.numel() < stash_bytes or self._stash.device != dev:
+                self._stash = torch.empty(stash_bytes, dtype=torch.uint8, device=dev)
+            fwd_flow.attn_stash, fwd_flow.attn_stash_bytes = self._stash.data_ptr(), stash_bytes
+        try:
+            return self._loss_and_grads(graph, n, d, dev)
+        finally:   # plain forward calls of the same net must not write into (or rely on) the stash
+            fwd_flow.attn_stash, fwd_flow.attn_stash_bytes = None, 0
+
+    def _loss_and_grads(self, graph, n, d, dev):
+        lib = _abi.lib()
+        net = self.net
         z_graph, _ = net(graph, inverse=True)                     # f: fused forward kernels
         sums = net.last_sums
         logdet = sums[0]

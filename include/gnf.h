@@ -148,9 +148,19 @@ typedef struct GnfFlow {
     int (*bn_allreduce)(void* ctx, double* device_buf, int64_t count, gnf_stream_t stream);
     void* bn_allreduce_ctx;
     double* bn_sync_buf;
+    /* ABI v5: optional stash of the attention front-end (attention GNNs only; NULL = none).  The reversible backward
+     * pass recomputes every half-step's activations from the reconstructed inputs; for the attention front-end
+     * (q | k | v projections, edge softmax, attended values: the costliest part of such a half-step) that recompute
+     * can be traded for memory: gnf_grevnet_f32(GNF_FORWARD) then leaves each half-step's q | k | v and layer-0 inputs
+     * of both nets in attn_stash, and gnf_grevnet_backward_f32 - called next with the SAME flow, graph and the z that
+     * forward produced - reads them instead of recomputing.  gnf_attn_stash_bytes() sizes it (2T slots). */
+    float* attn_stash;
+    size_t attn_stash_bytes;
 } GnfFlow;
 
 int gnf_abi_version(void);
+/* Bytes of GnfFlow.attn_stash for n_nodes nodes of width D (0 when the flow's nets have no attention front-end). */
+size_t gnf_attn_stash_bytes(int64_t n_nodes, int32_t D, const GnfFlow* flow);
 const char* gnf_last_error(void); /* thread-local, valid until the next failing call on this thread */
 
 /* Number of floats gnf_pack_mlp writes for this MLP (host computation, no device access). */

@@ -245,3 +245,17 @@ def test_overfit_graph_dataset_subset_rules():
     want = [sizes[0], sizes[-1]]
     ds2 = D.OverfitGraphDataset("graph_rnn_community_medium", 2, 2, 4, graph_sizes=want)
     assert ds2.train_n_nodes() == want
+
+
+def test_make_moons_is_sklearns_stream():
+    """grevnet_synthetic_data.py:50-56 draws its features with sklearn.datasets.make_moons(..., random_state=seed);
+    the mirror restates that generator (same point set, same RandomState draws in the same order) to shed sklearn's
+    per-call parameter validation - the arrays must be IDENTICAL for every size / seed / noise."""
+    datasets = pytest.importorskip("sklearn.datasets")
+    from gnf_amd import grevnet_synthetic_data as G
+    for n in (4, 6, 7, 33, 100):
+        for seed in (0, 5, 123456, 2 ** 31 - 1):
+            for noise in (0.05, None, 0.3):
+                a = G.make_moons(n, noise, seed)
+                b = datasets.make_moons(n_samples=n, shuffle=True, noise=noise, random_state=seed)[0]
+                assert np.array_equal(a, b), (n, seed, noise)
