@@ -83,7 +83,9 @@ def main():
         tmp = tempfile.TemporaryDirectory()
         F.train_data_dir = tmp.name
         make_chunks(F.train_data_dir, 3, 10 * F.train_batch_size, F.node_embedding_dim, rng)
-    data = D.GrevnetDatasetFixed(F.train_data_dir, F.train_batch_size, F.train_epochs)
+    # sort_files: the reference consumes the chunks in os.listdir order, which differs from one temporary directory
+    # to the next (and with it the whole loss curve); sorted here so that a run of this demo is reproducible
+    data = D.GrevnetDatasetFixed(F.train_data_dir, F.train_batch_size, F.train_epochs, sort_files=True)
 
     make_mlp_fn = partial(gnn.make_mlp_model, F.latent_dim, F.node_embedding_dim / 2, F.num_layers,
                           activation=gnn.relu, l2_regularizer_weight=0.000001, bias_init_stddev=F.bias_init_stddev)

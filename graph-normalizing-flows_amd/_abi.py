@@ -98,7 +98,8 @@ _SIGNATURES = {
     "gnf_adam_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_void_p]),
     "gnf_clip_by_value_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p]),
-    "gnf_clip_by_norm_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p]),
+    "gnf_clip_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "gnf_clip_by_norm_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gnf_gauss_sumsq_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p,
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
 }

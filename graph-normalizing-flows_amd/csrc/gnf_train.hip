@@ -1396,6 +1396,43 @@ __global__ __launch_bounds__(256) void k_clip_norm(float* __restrict__ g, const 
     for (int64_t i = beg + threadIdx.x; i < end; i += 256) g[i] *= scale;
 }
 
+// The same in two passes with kClipSlices workgroups per tensor (a 2048 x 2048 gradient in ONE workgroup took 10 ms):
+// pass 1: fp64 sum of squares of slice s of tensor t -> part[t][s];  pass 2: every slice's workgroup adds the
+// tensor's partials in slice order (the same number in every workgroup) and scales its slice.
+static constexpr int kClipSlices = 64;
+__device__ __forceinline__ void clip_slice(const int64_t* __restrict__ offsets, int64_t& lo, int64_t& hi) {
+    const int64_t beg = offsets[blockIdx.y], len = offsets[blockIdx.y + 1] - beg;
+    const int64_t per = (len + kClipSlices - 1) / kClipSlices;
+    lo = beg + (int64_t)blockIdx.x * per;
+    hi = lo + per < beg + len ? lo + per : beg + len;
+}
+__global__ __launch_bounds__(256) void k_clip_norm_part(const float* __restrict__ g, const int64_t* __restrict__ offsets,
+                                                        double* __restrict__ part) {
+    __shared__ double red[256];
+    int64_t lo, hi;
+    clip_slice(offsets, lo, hi);
+    double s = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) s += (double)g[i] * (double)g[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.y * kClipSlices + blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void k_clip_norm_scale(float* __restrict__ g, const int64_t* __restrict__ offsets,
+                                                         const double* __restrict__ part, float clip) {
+    int64_t lo, hi;
+    clip_slice(offsets, lo, hi);
+    if (lo >= hi) return;
+    double tot = 0.0;
+    for (int q = 0; q < kClipSlices; ++q) tot += part[(int64_t)blockIdx.y * kClipSlices + q];
+    const float nrm = (float)sqrt(tot);
+    const float scale = clip / fmaxf(nrm, clip);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) g[i] *= scale;
+}
+
 }  // namespace gnf
 
 using namespace gnf;
@@ -1687,14 +1724,31 @@ int gnf_clip_by_value_f32(float* g, int64_t n, float lo, float hi, gnf_stream_t 
     return GNF_OK;
 }
 
-int gnf_clip_by_norm_f32(float* g, const int64_t* offsets, int32_t n_tensors, float clip_norm, gnf_stream_t stream) {
+size_t gnf_clip_workspace_bytes(int32_t n_tensors) {
+    return n_tensors > 0 ? (size_t)n_tensors * kClipSlices * sizeof(double) : 0;
+}
+
+int gnf_clip_by_norm_f32(float* g, const int64_t* offsets, int32_t n_tensors, float clip_norm, void* ws, size_t ws_bytes,
+                         gnf_stream_t stream) {
     if (n_tensors < 0 || (n_tensors > 0 && (!g || !offsets)) || !(clip_norm > 0.f)) {
         set_error("gnf_clip_by_norm_f32: bad arguments");
         return GNF_EINVAL;
     }
     if (n_tensors == 0) return GNF_OK;
-    hipLaunchKernelGGL(k_clip_norm, dim3((unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, g, offsets, clip_norm);
-    GNF_LAUNCH_CHECK("k_clip_norm");
+    if (!ws) {  // no scratch: one workgroup per tensor (fine for small tensors)
+        hipLaunchKernelGGL(k_clip_norm, dim3((unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, g, offsets, clip_norm);
+        GNF_LAUNCH_CHECK("k_clip_norm");
+        return GNF_OK;
+    }
+    if (ws_bytes < gnf_clip_workspace_bytes(n_tensors)) {
+        set_error("gnf_clip_by_norm_f32: workspace %zu < %zu bytes", ws_bytes, gnf_clip_workspace_bytes(n_tensors));
+        return GNF_EWORKSPACE;
+    }
+    const dim3 grid(kClipSlices, (unsigned)n_tensors);
+    hipLaunchKernelGGL(k_clip_norm_part, grid, dim3(256), 0, (hipStream_t)stream, g, offsets, (double*)ws);
+    GNF_LAUNCH_CHECK("k_clip_norm_part");
+    hipLaunchKernelGGL(k_clip_norm_scale, grid, dim3(256), 0, (hipStream_t)stream, g, offsets, (const double*)ws, clip_norm);
+    GNF_LAUNCH_CHECK("k_clip_norm_scale");
     return GNF_OK;
 }
 

@@ -236,9 +236,12 @@ class GrevnetDatasetFixed:
     supply a whole batch its tail is dropped and the next file is opened (as the reference does).
     `train_epochs` is FLAGS.train_epochs (the file list is repeated that many times)."""
 
-    def __init__(self, train_data_dir, train_batch_size, train_epochs=1):
+    def __init__(self, train_data_dir, train_batch_size, train_epochs=1, sort_files=False):
         import os
-        self.files = os.listdir(train_data_dir) * int(train_epochs)
+        # os.listdir order, like the reference: unspecified, it changes from one directory to the next.
+        # sort_files=True (not in the reference) makes a run reproducible.
+        files = sorted(os.listdir(train_data_dir)) if sort_files else os.listdir(train_data_dir)
+        self.files = files * int(train_epochs)
         self.file_ind = 0
         self.prev_graph_ind = 0
         self.prev_node_embedding_ind = 0
@@ -270,9 +273,9 @@ class GrevnetDatasetVariable:
     """train_grevnet_with_data.py:183-234: as many consecutive graphs as fit UNDER max_nodes per batch; the
     batch that reaches the end of a chunk is returned short and the next file is opened."""
 
-    def __init__(self, train_data_dir, max_nodes):
+    def __init__(self, train_data_dir, max_nodes, sort_files=False):
         import os
-        self.files = os.listdir(train_data_dir)
+        self.files = sorted(os.listdir(train_data_dir)) if sort_files else os.listdir(train_data_dir)
         self.file_ind = 0
         self.graph_ind = 0
         self.prev_graph_ind = 0

@@ -68,6 +68,7 @@ class GRevNetTrainer:
         self._ws = None
         self._bns = []
         self._attn_blocks = []
+        self._clip_ws = None     # scratch of the two-pass clip_by_norm
         self._stash = None       # attention front-end stash (uint8 device buffer), see loss_and_grads
         self.stash_attention = os.environ.get("GNF_TRAIN_NO_STASH") is None   # developer A/B switch
         self._aux = None         # second HIP stream: the weight-gradient GEMMs overlap the backward walk
@@ -301,9 +302,12 @@ class GRevNetTrainer:
                 _abi.check(lib.gnf_clip_by_value_f32(_abi.ptr(self.grad), n, self.clip_lo, self.clip_hi, st),
                            "gnf_clip_by_value_f32")
             if self.clip_by_norm:
-                _abi.check(lib.gnf_clip_by_norm_f32(_abi.ptr(self.grad), _abi.ptr(self._offsets),
-                                                    self._offsets.numel() - 1, self.clip_norm, st),
-                           "gnf_clip_by_norm_f32")
+                nt = self._offsets.numel() - 1
+                cb = lib.gnf_clip_workspace_bytes(nt)
+                if self._clip_ws is None or self._clip_ws.numel() < cb or self._clip_ws.device != dev:
+                    self._clip_ws = torch.empty(max(cb, 8), dtype=torch.uint8, device=dev)
+                _abi.check(lib.gnf_clip_by_norm_f32(_abi.ptr(self.grad), _abi.ptr(self._offsets), nt, self.clip_norm,
+                                                    _abi.ptr(self._clip_ws), cb, st), "gnf_clip_by_norm_f32")
             _abi.check(lib.gnf_adam_f32(_abi.ptr(self.theta), _abi.ptr(self.grad), _abi.ptr(self.m), _abi.ptr(self.v),
                                         n, lr_t, self.beta1, self.beta2, self.epsilon, st), "gnf_adam_f32")
             h = self.net.mlps("s")[0].layer_sizes[-1]

@@ -273,8 +273,12 @@ int gnf_adam_f32(float* w, const float* g, float* m, float* v, int64_t n, float 
 /* tf.clip_by_value on a flat gradient (run_grevnet.py:363-367). */
 int gnf_clip_by_value_f32(float* g, int64_t n, float lo, float hi, gnf_stream_t stream);
 /* tf.clip_by_norm per gradient tensor (run_grevnet.py:369-372): tensor i = g[offsets[i] .. offsets[i+1])
- * (offsets: device int64[n_tensors + 1]) is scaled by clip_norm / max(||t||_2, clip_norm). */
-int gnf_clip_by_norm_f32(float* g, const int64_t* offsets, int32_t n_tensors, float clip_norm, gnf_stream_t stream);
+ * (offsets: device int64[n_tensors + 1]) is scaled by clip_norm / max(||t||_2, clip_norm).
+ * ws: NULL (one workgroup per tensor: fine for small tensors) or gnf_clip_workspace_bytes(n_tensors) bytes of device
+ * scratch (ABI v5: 64 workgroups per tensor in two passes; a 2048 x 2048 gradient in one workgroup takes 10 ms). */
+size_t gnf_clip_workspace_bytes(int32_t n_tensors);
+int gnf_clip_by_norm_f32(float* g, const int64_t* offsets, int32_t n_tensors, float clip_norm, void* ws, size_t ws_bytes,
+                         gnf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -161,12 +161,17 @@ def test_adam_and_clipping_vs_oracle():
     # clip by norm per tensor (three tensors of very different sizes, one of them empty)
     bounds = np.array([0, 10, 10, 70000, n], np.int64)
     off = torch.tensor(bounds, device=DEV)
-    gn = g.clone()
-    _abi.check(lib.gnf_clip_by_norm_f32(_abi.ptr(gn), _abi.ptr(off), len(bounds) - 1, 10.0, st), "clip norm")
-    got = gn.cpu().numpy()
-    for a, b in zip(bounds[:-1], bounds[1:]):
-        if b > a:
-            np.testing.assert_allclose(got[a:b], O.clip_by_norm(g0[a:b], 10.0), rtol=3e-6, atol=1e-7)
+    nt = len(bounds) - 1
+    cws = torch.empty(lib.gnf_clip_workspace_bytes(nt), dtype=torch.uint8, device=DEV)
+    for ws_ptr, ws_bytes in ((None, 0), (_abi.ptr(cws), cws.numel())):   # one workgroup per tensor / two-pass sliced
+        gn = g.clone()
+        _abi.check(lib.gnf_clip_by_norm_f32(_abi.ptr(gn), _abi.ptr(off), nt, 10.0, ws_ptr, ws_bytes, st), "clip norm")
+        got = gn.cpu().numpy()
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            if b > a:
+                np.testing.assert_allclose(got[a:b], O.clip_by_norm(g0[a:b], 10.0), rtol=3e-6, atol=1e-7)
+    with pytest.raises(_abi.GnfError, match="workspace"):
+        _abi.check(lib.gnf_clip_by_norm_f32(_abi.ptr(gn), _abi.ptr(off), nt, 10.0, _abi.ptr(cws), 8, st), "clip norm")
 
 
 def test_training_loop_reduces_loss_and_keeps_packed_weights_fresh(grid_small):
