@@ -77,6 +77,8 @@ WorkspacePlan plan_workspace(int64_t n_nodes, int32_t H, const GnfMlp* net, int3
 
 // ---- launchers (each returns GNF_OK / GNF_E*) --------------------------------------------------
 bool fused_supported(const HalfStep& hs);
+bool fused_fits_lds(const GnfMlp* m);      // forward kernel, smallest shape
+bool fused_bwd_fits_lds(const GnfMlp* m);  // backward kernel
 int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st);
 // coupling epilogue from global s / t [N, H] buffers (writes hs.partials, *hs.n_partials)
 int launch_coupling(const float* s, const float* t, const HalfStep& hs, const float* xres, hipStream_t st);

@@ -445,6 +445,9 @@ static size_t fused_lds_bytes(const GnfMlp* m, int MT, int NETS) {
            (GNF_MAX_LAYERS * 8 + kRowptrPad + kColCap) * sizeof(int);
 }
 
+// does any shape of the fused forward kernel hold this MLP's activations in LDS? (else its packed copy is never read)
+bool fused_fits_lds(const GnfMlp* m) { return fused_lds_bytes(m, 1, 1) <= (size_t)kLdsLimit; }
+
 bool fused_supported(const HalfStep& hs) {
     const GnfMlp *s = hs.s_net, *t = hs.t_net;
     if (!s->packed || !t->packed) return false;

@@ -306,6 +306,8 @@ static size_t bwd_lds_bytes(const GnfMlp* m, int MT) {
            (size_t)2 * (K > 1 ? K - 1 : 0) * (MT * 4) * mld * sizeof(unsigned long long);
 }
 
+bool fused_bwd_fits_lds(const GnfMlp* m) { return bwd_lds_bytes(m, 1) <= (size_t)kBwdLdsLimit; }
+
 bool fused_bwd_supported(const GnfMlp* s, const GnfMlp* t) {
     if (!s->packed || !t->packed) return false;
     if (s->num_layers != t->num_layers) return false;

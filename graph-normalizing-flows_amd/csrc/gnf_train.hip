@@ -233,13 +233,19 @@ struct GroupedGemm {
 // 1-D grid, XCD-aware: workgroup b runs on XCD b % 8, and the tiles of one (job, chunk) - which share the chunk's
 // two operand panels - are all given to the same XCD (z % 8), so each panel is pulled into ONE L2 instead of eight
 // (PMC before: 14 % L2 hit rate, 109 MiB fetched per dispatch for 46 MiB of operands).
-__global__ __launch_bounds__(kGemmThreads) void k_gemm_dw_grouped(const GroupedGemm g, int gx, int gy, int nz) {
+// With few (job, chunk) pairs and many tiles each (wide layers: 6 pairs of 512 tiles), a pair's tile grid is cut into
+// `groups` bands of `rpg` tile rows (tiles of a row share the A panel) and the bands are what is dealt to the XCDs -
+// otherwise 6 pairs would occupy 6 of the 8 XCDs.
+__global__ __launch_bounds__(kGemmThreads) void k_gemm_dw_grouped(const GroupedGemm g, int gx, int gy, int nz, int groups,
+                                                                  int rpg) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int per_z = gx * gy;
-    const int zi = slot / per_z, t = slot - zi * per_z;
-    const int z = xcd + 8 * zi;
+    const int per_v = gx * rpg;
+    const int vi = slot / per_v, t = slot - vi * per_v;
+    const int v = xcd + 8 * vi;
+    const int z = v / groups, band = v - z * groups;
     if (z >= nz) return;
-    const int bx = t % gx, by = t / gx;
+    const int bx = t % gx, by = band * rpg + t / gx;
+    if (by >= gy) return;
     const int jz = z / g.chunks, chunk = z - jz * g.chunks;
     const int M = g.M[jz], N = g.N[jz];
     if (bx * TGN >= N || by * TGM >= M) return;  // the tile grid covers the largest job
@@ -878,6 +884,15 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net) {
     // (measured on the config-2 batch: chunks of 64 / 128 / 256 / 512 nodes give 3.11 / 2.94 / 2.94 / 2.99 ms per step)
     int64_t chunks = (n + 255) / 256;
     if (chunks > 64) chunks = 64;
+    {   // ... but no more than it takes to put ~4 workgroups on every CU: wide layers have the tiles already (2048-wide:
+        // 3072 tiles per chunk - a second chunk only added 200 MB of slab traffic per half-step)
+        int64_t tiles = 0;
+        for (int j = 0; j < p.K; ++j)
+            tiles += (int64_t)((net->dims[j] + TGM - 1) / TGM) * ((net->dims[j + 1] + TGN - 1) / TGN);
+        tiles *= 2;
+        const int64_t enough = (1024 + tiles - 1) / (tiles > 0 ? tiles : 1);
+        if (chunks > enough) chunks = enough;
+    }
     if (chunks < 1) chunks = 1;
     int64_t kchunk = (n + chunks - 1) / chunks;
     kchunk = (kchunk + TGK - 1) / TGK * TGK;
@@ -1171,8 +1186,13 @@ static int launch_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJo
         GNF_LAUNCH_CHECK("k_gemm_dw_wide");
     } else {
         const int gx = (maxN + TGN - 1) / TGN, gy = (maxM + TGM - 1) / TGM, nz = nj * p.chunks;
-        const unsigned blocks = 8u * (unsigned)((nz + 7) / 8) * (unsigned)(gx * gy);
-        hipLaunchKernelGGL(k_gemm_dw_grouped, dim3(blocks), dim3(kGemmThreads), 0, st, gg, gx, gy, nz);
+        int groups = nz >= 32 ? 1 : (32 + nz - 1) / nz;   // enough bands that every XCD gets several
+        if (groups > gy) groups = gy;
+        const int rpg = (gy + groups - 1) / groups;
+        groups = (gy + rpg - 1) / rpg;
+        const int nv = nz * groups;
+        const unsigned blocks = 8u * (unsigned)((nv + 7) / 8) * (unsigned)(gx * rpg);
+        hipLaunchKernelGGL(k_gemm_dw_grouped, dim3(blocks), dim3(kGemmThreads), 0, st, gg, gx, gy, nz, groups, rpg);
         GNF_LAUNCH_CHECK("k_gemm_dw_grouped");
     }
     hipLaunchKernelGGL(k_reduce_grouped, dim3((unsigned)((maxred + 255) / 256), (unsigned)nj), dim3(256), 0, st, gr);
@@ -1334,6 +1354,9 @@ static int pack_flow(const GnfFlow* flow, hipStream_t st) {
         for (int q = 0; q < n_nets; ++q) {
             const GnfMlp* m = kind ? &flow->t_nets[q] : &flow->s_nets[q];
             if (!m->packed) continue;
+            // layers too wide for LDS never run the fused kernels: nothing reads their fragment-order copy (at the
+            // data-backed trainer's 2048-wide layers the re-pack was 1.1 ms per step and 1.5 GB)
+            if (!fused_fits_lds(m) && !fused_bwd_fits_lds(m)) continue;
             int64_t woff = 0, boff = 0;
             for (int j = 0; j < m->num_layers; ++j) boff += (int64_t)pad16i(m->dims[j]) * pad16i(m->dims[j + 1]);
             int64_t toff = boff;
