@@ -167,7 +167,9 @@ __global__ __launch_bounds__(256) void k_bn_denorm(float* __restrict__ z, int64_
 
 // moment pass: few large row chunks (each workgroup's partial is re-read by every workgroup of the second pass)
 int bn_blocks(int64_t n, int64_t* rows_per_block) {
-    int64_t rpb = 256;
+    // small batches: 32-row chunks (a 440-node batch in two 256-row workgroups spent 75 us walking its rows one after
+    // the other); the chunk grows once there would be more than kBnBlocksMax partials
+    int64_t rpb = 32;
     int64_t blocks = (n + rpb - 1) / rpb;
     if (blocks > kBnBlocksMax) {
         rpb = (n + kBnBlocksMax - 1) / kBnBlocksMax;

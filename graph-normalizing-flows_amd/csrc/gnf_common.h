@@ -112,6 +112,11 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
                          const float* const* dh0, const float* const* gst, float* const* dqkv, float* const* agg,
                          float* const* dagg, float* const* stats, float* g_cond, int64_t ldg, hipStream_t st);
 
+// thin y = act(x W + b) through the split-K generic GEMM (gnf_train.hip); 1 = not thin, the caller runs its own kernel
+int launch_linear_splitk(const float* const* x, int64_t ldx, const float* const* W, const float* const* b, float* const* y,
+                         int64_t ldy, int nj, int64_t n, int32_t I, int32_t O, int act, float alpha, int apply_act,
+                         float* const* sk, size_t sk_floats, hipStream_t st);
+
 // batch-norm bijector (gnf_bn.hip)
 int validate_bn(const GnfBatchNorm* bn, int direction, const char* what, int q);
 // cross-rank moments (GnfFlow.bn_allreduce): fold the per-workgroup partials into flow->bn_sync_buf (and, when

@@ -94,13 +94,22 @@ __device__ __forceinline__ void tile_stash(float* __restrict__ lds, int tid, con
 // C[M, N] = A . B.  128 x 64 output tile per workgroup, BK = 32, 8 waves (wave w: rows (w & 3) * 32,
 // columns (w >> 2) * 32, 2 x 2 MFMA tiles); the next k-tile is fetched into registers while the matrix
 // cores work on the current one.  blockIdx.z = job * chunks + chunk.
-template <int AK, int BK, int EPI>
+// BUF: the operand tiles are fetched with buffer loads whose descriptor ends at the operand's last valid row, so rows
+// past it come back as zeros by the hardware range check and the fetch has no branch (the bounds-checked tile_fetch
+// below compiles to ~450 instructions with vmcnt(0) waits inside its scalar tails).  Columns past the valid width are
+// NOT zeroed by the range check: for an MC operand they are output columns that are never stored; for a KC operand
+// they are the reduction tail, and the lane's offset is pushed out of range instead (needs K % 4 == 0).
+template <int AK, int BK, int EPI, bool BUF = false>
 __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& sh, const int bx, const int by,
                                           const int chunk) {
     constexpr int AR = AK == OPND_KC ? TGM : TGK, AC = AK == OPND_KC ? TGK : TGM;  // LDS tile rows x cols
     constexpr int BR = BK == OPND_KC ? TGN : TGK, BC = BK == OPND_KC ? TGK : TGN;
-    __shared__ __attribute__((aligned(16))) float As[AR * (AC + 4)];
-    __shared__ __attribute__((aligned(16))) float Bs[BR * (BC + 4)];
+    // two LDS stages: the next k-tile is written into the other stage behind this one's MFMAs - ONE barrier per step and
+    // nothing waits for a stage to drain (with a single stage every step stalled twice; at a few hundred rows there is
+    // one workgroup per CU and nothing else to fill those stalls)
+    constexpr int kAs = AR * (AC + 4), kBs = BR * (BC + 4);
+    __shared__ __attribute__((aligned(16))) float As2[2 * kAs];
+    __shared__ __attribute__((aligned(16))) float Bs2[2 * kBs];
     const int64_t m0 = (int64_t)by * TGM;
     const int n0 = bx * TGN;
     const int64_t kbeg = (int64_t)chunk * sh.kchunk;
@@ -126,7 +135,39 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
     float colsum = 0.f;  // EPI_SLAB: sum over this chunk's k of B[k][n0 + tid]
 
     f32x4_t av[2], bvr[1];
+    // buffer path: descriptors over [tile's first row .. operand's last valid row], per-thread byte offsets of its float4s
+    constexpr int AC4 = AC / 4, BC4 = BC / 4;
+    const int64_t a_rows = AK == OPND_KC ? sh.M - m0 : kend - kbeg, b_rows = BK == OPND_KC ? (int64_t)sh.N - n0 : kend - kbeg;
+    const float* a_base = AK == OPND_KC ? job.A + m0 * sh.lda : job.A + kbeg * sh.lda + m0;
+    const float* b_base = BK == OPND_KC ? job.B + (int64_t)n0 * sh.ldb : job.B + kbeg * sh.ldb + n0;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a_base), 0, BUF && a_rows > 0 ? (int)((a_rows * sh.lda - (AK == OPND_KC ? 0 : m0)) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(b_base), 0, BUF && b_rows > 0 ? (int)((b_rows * sh.ldb - (BK == OPND_KC ? 0 : n0)) * 4) : 0, 0x00020000);
+    const int ar = tid / AC4, ac = (tid % AC4) * 4, br = tid / BC4, bc = (tid % BC4) * 4;
+    const int va0 = (ar * (int)sh.lda + ac) * 4, va1 = ((ar + kGemmThreads / AC4) * (int)sh.lda + ac) * 4;
+    const int vb0 = (br * (int)sh.ldb + bc) * 4;
+    constexpr int kOut = 0x7fffffff;  // beyond any descriptor: the load returns zeros
     auto fetch = [&](int64_t k0) {
+        if (BUF) {
+            if (AK == OPND_KC) {  // columns are k: offset by k0, lanes past the reduction length read nothing
+                const int ko = (int)k0 * 4;
+                const bool in = k0 + ac < kend;
+                av[0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ra, in ? va0 + ko : kOut, 0, 0));
+                av[1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ra, in ? va1 + ko : kOut, 0, 0));
+            } else {              // rows are k: offset by whole rows, rows past the chunk are out of range by themselves
+                const int ko = (int)(k0 - kbeg) * (int)sh.lda * 4;
+                av[0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ra, va0 + ko, 0, 0));
+                av[1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ra, va1 + ko, 0, 0));
+            }
+            if (BK == OPND_KC) {
+                const bool in = k0 + bc < kend;
+                bvr[0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rb, in ? vb0 + (int)k0 * 4 : kOut, 0, 0));
+            } else {
+                bvr[0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rb, vb0 + (int)(k0 - kbeg) * (int)sh.ldb * 4, 0, 0));
+            }
+            return;
+        }
         if (AK == OPND_KC)
             tile_fetch<AR, AC, 2>(job.A + m0 * sh.lda + k0, sh.lda, sh.M - m0, kend - k0, avec, tid, av);
         else
@@ -136,13 +177,18 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
         else
             tile_fetch<BR, BC, 1>(job.B + k0 * sh.ldb + n0, sh.ldb, kend - k0, sh.N - n0, bvec, tid, bvr);
     };
-    if (kbeg < kend) fetch(kbeg);
+    int cur = 0;
+    if (kbeg < kend) {
+        fetch(kbeg);
+        tile_stash<AR, AC, 2>(As2, tid, av);
+        tile_stash<BR, BC, 1>(Bs2, tid, bvr);
+    }
+    __syncthreads();
     for (int64_t k0 = kbeg; k0 < kend; k0 += TGK) {
-        __syncthreads();  // previous tile fully consumed
-        tile_stash<AR, AC, 2>(As, tid, av);
-        tile_stash<BR, BC, 1>(Bs, tid, bvr);
-        __syncthreads();
-        if (k0 + TGK < kend) fetch(k0 + TGK);
+        const bool more = k0 + TGK < kend;
+        if (more) fetch(k0 + TGK);  // in flight behind this step's MFMAs
+        const float* As = As2 + cur * kAs;
+        const float* Bs = Bs2 + cur * kBs;
         if (EPI == EPI_SLAB && BK == OPND_MC) {
             if (by == 0 && tid < TGN) {
 #pragma unroll 8
@@ -182,6 +228,12 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
                     for (int m = 0; m < 2; ++m)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][q], b[n][q], acc[m][n], 0, 0, 0);
         }
+        if (more) {
+            tile_stash<AR, AC, 2>(As2 + (cur ^ 1) * kAs, tid, av);
+            tile_stash<BR, BC, 1>(Bs2 + (cur ^ 1) * kBs, tid, bvr);
+        }
+        __syncthreads();
+        cur ^= 1;
     }
     // accumulator layout: col = lane & 15, row = 4 * (lane >> 4) + r
     float* __restrict__ Cp = job.C;
@@ -213,11 +265,21 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
         job.aux_out[(int64_t)chunk * sh.N + n0 + tid] = colsum;
 }
 
-template <int AK, int BK, int EPI>
+template <int AK, int BK, int EPI, bool BUF>
 __global__ __launch_bounds__(kGemmThreads) void k_gemm(GemmJob j0, GemmJob j1, GemmShape sh) {
     const int jz = blockIdx.z / sh.chunks, chunk = blockIdx.z - jz * sh.chunks;
     const GemmJob job = jz ? j1 : j0;
-    gemm_tile<AK, BK, EPI>(job, sh, blockIdx.x, blockIdx.y, chunk);
+    gemm_tile<AK, BK, EPI, BUF>(job, sh, blockIdx.x, blockIdx.y, chunk);
+}
+
+// may the operands of a GEMM go through the buffer path? (32-bit byte offsets; a KC operand's reduction length in whole
+// float4s; GNF_GEMM_NO_BUF: developer A/B switch)
+static bool gemm_buf_ok(int ak, int bk, int64_t a_rows, int64_t lda, int64_t b_rows, int64_t ldb, int64_t K) {
+    static const bool off = getenv("GNF_GEMM_NO_BUF") != nullptr;
+    if (off) return false;
+    if ((a_rows + 256) * lda * 4 >= ((int64_t)1 << 31) || (b_rows + 256) * ldb * 4 >= ((int64_t)1 << 31)) return false;
+    if ((ak == OPND_KC || bk == OPND_KC) && K % 4 != 0) return false;
+    return true;
 }
 
 // Grouped split-K launch: up to kMaxGroup GEMMs of different M x N (the dW of every layer of both nets of
@@ -236,6 +298,7 @@ struct GroupedGemm {
 // With few (job, chunk) pairs and many tiles each (wide layers: 6 pairs of 512 tiles), a pair's tile grid is cut into
 // `groups` bands of `rpg` tile rows (tiles of a row share the A panel) and the bands are what is dealt to the XCDs -
 // otherwise 6 pairs would occupy 6 of the 8 XCDs.
+template <bool BUF>
 __global__ __launch_bounds__(kGemmThreads) void k_gemm_dw_grouped(const GroupedGemm g, int gx, int gy, int nz, int groups,
                                                                   int rpg) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -254,7 +317,7 @@ __global__ __launch_bounds__(kGemmThreads) void k_gemm_dw_grouped(const GroupedG
     sh.M = M, sh.K = g.K, sh.N = N, sh.chunks = g.chunks, sh.kchunk = g.kchunk;
     sh.act = 0, sh.alpha = 0.f, sh.apply_act = 0;
     const GemmJob job = g.job[jz];
-    gemm_tile<OPND_MC, OPND_MC, EPI_SLAB>(job, sh, bx, by, chunk);
+    gemm_tile<OPND_MC, OPND_MC, EPI_SLAB, BUF>(job, sh, bx, by, chunk);
 }
 
 // ---- wide split-K weight-gradient GEMM -----------------------------------------------------------------------
@@ -559,13 +622,96 @@ __global__ __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(2,
     }  // units of this workgroup
 }
 
+// Thin outputs with a long reduction (a 2048 -> 100 layer on a 440-node batch: 16 tiles, 64 k-steps each, 80 us on 16
+// CUs): the reduction is split over `chunks` workgroups per tile into slabs, and this kernel sums the slabs in chunk
+// order and applies the epilogue the unsplit kernel would have applied.
+template <int EPI>
+__global__ __launch_bounds__(256) void k_splitk_epilogue(GemmJob j0, GemmJob j1, const float* s0, const float* s1,
+                                                         int chunks, GemmShape sh) {
+    const GemmJob job = blockIdx.y ? j1 : j0;
+    const float* __restrict__ slab = blockIdx.y ? s1 : s0;
+    const int64_t mn = sh.M * sh.N;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= mn) return;
+    const int64_t m = e / sh.N;
+    const int n = (int)(e - m * sh.N);
+    float v = 0.f;
+    for (int c = 0; c < chunks; ++c) v += slab[(int64_t)c * mn + e];
+    if (EPI == EPI_BIAS_ACT) {
+        v += job.aux[n];
+        if (sh.apply_act) v = (sh.act == GNF_ACT_RELU) ? fmaxf(v, 0.f) : fmaxf(v, sh.alpha * v);
+    } else if (EPI == EPI_MASK) {
+        if (job.aux) {
+            const float h = job.aux[m * sh.ldaux + n];
+            const float slope = (sh.act == GNF_ACT_RELU) ? 0.f : sh.alpha;
+            v = h > 0.f ? v : v * slope;
+        }
+    }
+    job.C[m * sh.ldc + n] = v;
+}
+
+// sk[q] (nullable): scratch of sk_floats floats for job q's slabs when the launch is thin enough to be split
 template <int AK, int BK, int EPI>
-static int launch_gemm(const GemmJob* jobs, int nj, const GemmShape& sh, hipStream_t st) {
+static int launch_gemm(const GemmJob* jobs, int nj, const GemmShape& sh, hipStream_t st, float* const* sk = nullptr,
+                       size_t sk_floats = 0) {
     if (sh.M == 0 || sh.N == 0) return GNF_OK;
+    {
+        const int64_t tiles = (int64_t)((sh.N + TGN - 1) / TGN) * ((sh.M + TGM - 1) / TGM) * nj;
+        static const bool no_split = getenv("GNF_GEMM_NO_SPLITK") != nullptr;  // developer A/B switch
+        if (sk && sk[0] && sk[nj - 1] && !no_split && EPI != EPI_SLAB && sh.chunks == 1 && tiles < 96 && sh.K >= 512) {
+            int64_t chunks = 256 / tiles;
+            if (chunks > 16) chunks = 16;
+            if (chunks > sh.K / 128) chunks = sh.K / 128;
+            while (chunks > 1 && (size_t)chunks * sh.M * sh.N > sk_floats) --chunks;
+            if (chunks > 1) {
+                GemmShape s2 = sh;
+                s2.kchunk = ((sh.K + chunks - 1) / chunks + TGK - 1) / TGK * TGK;
+                s2.chunks = (int32_t)((sh.K + s2.kchunk - 1) / s2.kchunk);
+                s2.ldc = sh.N;
+                GemmJob sj[2];
+                for (int q = 0; q < nj; ++q) sj[q] = GemmJob{jobs[q].A, jobs[q].B, sk[q], nullptr, nullptr};
+                dim3 grid((unsigned)((sh.N + TGN - 1) / TGN), (unsigned)((sh.M + TGM - 1) / TGM), (unsigned)(nj * s2.chunks));
+                const bool buf = gemm_buf_ok(AK, BK, AK == OPND_KC ? sh.M : sh.K, sh.lda, BK == OPND_KC ? (int64_t)sh.N : sh.K, sh.ldb, sh.K) &&
+                                 (AK != OPND_KC && BK != OPND_KC ? true : s2.kchunk % 4 == 0);
+                if (buf)
+                    hipLaunchKernelGGL((k_gemm<AK, BK, EPI_SLAB, true>), grid, dim3(kGemmThreads), 0, st, sj[0], sj[nj - 1], s2);
+                else
+                    hipLaunchKernelGGL((k_gemm<AK, BK, EPI_SLAB, false>), grid, dim3(kGemmThreads), 0, st, sj[0], sj[nj - 1], s2);
+                GNF_LAUNCH_CHECK("k_gemm (split-K)");
+                dim3 eg((unsigned)((sh.M * sh.N + 255) / 256), (unsigned)nj);
+                hipLaunchKernelGGL((k_splitk_epilogue<EPI>), eg, dim3(256), 0, st, jobs[0], jobs[nj - 1], (const float*)sk[0],
+                                   (const float*)sk[nj - 1], (int)s2.chunks, sh);
+                GNF_LAUNCH_CHECK("k_splitk_epilogue");
+                return GNF_OK;
+            }
+        }
+    }
     dim3 grid((unsigned)((sh.N + TGN - 1) / TGN), (unsigned)((sh.M + TGM - 1) / TGM), (unsigned)(nj * sh.chunks));
-    hipLaunchKernelGGL((k_gemm<AK, BK, EPI>), grid, dim3(kGemmThreads), 0, st, jobs[0], jobs[nj - 1], sh);
+    const bool buf = gemm_buf_ok(AK, BK, AK == OPND_KC ? sh.M : sh.K, sh.lda, BK == OPND_KC ? (int64_t)sh.N : sh.K, sh.ldb, sh.K);
+    if (buf)
+        hipLaunchKernelGGL((k_gemm<AK, BK, EPI, true>), grid, dim3(kGemmThreads), 0, st, jobs[0], jobs[nj - 1], sh);
+    else
+        hipLaunchKernelGGL((k_gemm<AK, BK, EPI, false>), grid, dim3(kGemmThreads), 0, st, jobs[0], jobs[nj - 1], sh);
     GNF_LAUNCH_CHECK("k_gemm");
     return GNF_OK;
+}
+
+// y = act(x W + b) for up to two nets sharing shapes, through the split-K path above when the layer is thin
+// (gnf_layered.hip hands its free ping-pong activation buffer in as scratch); returns 1 when the layer is not thin
+// enough to bother - the caller then runs its own kernel.
+int launch_linear_splitk(const float* const* x, int64_t ldx, const float* const* W, const float* const* b, float* const* y,
+                         int64_t ldy, int nj, int64_t n, int32_t I, int32_t O, int act, float alpha, int apply_act,
+                         float* const* sk, size_t sk_floats, hipStream_t st) {
+    const int64_t tiles = (int64_t)((O + TGN - 1) / TGN) * ((n + TGM - 1) / TGM) * nj;
+    if (tiles >= 96 || I < 512 || n == 0 || (size_t)2 * n * O > sk_floats) return 1;
+    GemmJob jobs[2];
+    for (int q = 0; q < nj; ++q) jobs[q] = GemmJob{x[q], W[q], y[q], b[q], nullptr};
+    GemmShape sh;
+    memset(&sh, 0, sizeof(sh));
+    sh.lda = ldx, sh.ldb = O, sh.ldc = ldy;
+    sh.M = n, sh.K = I, sh.N = O, sh.chunks = 1, sh.kchunk = TGK;
+    sh.act = act, sh.alpha = alpha, sh.apply_act = apply_act;
+    return launch_gemm<OPND_KC, OPND_MC, EPI_BIAS_ACT>(jobs, nj, sh, st, sk, sk_floats);
 }
 
 // G[e] (+)= sum over chunks of slab[chunk][e]   (fixed order)
@@ -810,7 +956,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(float* __restrict__ y, int
 
 static int launch_bn_backward(const GnfFlow* flow, const GnfBatchNorm* bn, const GnfBatchNorm* gbn, float* y, int64_t ld,
                               float* gy, int64_t ldg, int64_t n, int32_t H, double* part, hipStream_t st) {
-    int64_t rpb = 256;  // moment pass: few large chunks;  rewrite pass: many small ones
+    int64_t rpb = 32;   // moment pass: 32-row chunks while that stays under kBnBlocksMax partials, larger beyond
     int64_t blocks = (n + rpb - 1) / rpb;
     if (blocks > kBnBlocksMax) {
         rpb = (n + kBnBlocksMax - 1) / kBnBlocksMax;
@@ -846,7 +992,8 @@ struct BwdPlan {
     // attention geometry (0 when the nets are message-passing GNNs)
     int nh, kq, vd, C, P, NV;
     // float offsets.  single: g, invdeg, bnpart, st, wslab, bslab, qkv, dagg, stats;  per set: the rest
-    size_t g, invdeg, bnpart, st, wslab, bslab, qkv, dagg, stats;
+    size_t g, invdeg, bnpart, st, wslab, bslab, qkv, dagg, stats, splitk;
+    size_t splitk_each;  // floats of split-K scratch per net
     size_t h0, h0b, acts, gst, dpb, dh0, xc, dqkv, agg;
     size_t set_stride;  // the dW operands exist twice: half-step k's dW GEMMs may run on the auxiliary stream while
                         // half-step k-1's kernels already refill the other set
@@ -911,6 +1058,10 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net) {
     p.qkv = off, off += 2 * al64((size_t)n * p.P);
     p.dagg = off, off += 2 * al64((size_t)n * p.NV);
     p.stats = off, off += 2 * al64((size_t)n * 3 * p.nh);
+    // slabs of the split-K path of thin generic-path GEMMs (launch_gemm): only launches with < 96 tiles take it, i.e.
+    // fewer than 48 row tiles per net and one or two column tiles; 16 chunks at most
+    p.splitk_each = al64((size_t)16 * (size_t)(n < 48 * TGM ? n : 48 * TGM) * (size_t)(2 * TGN));
+    p.splitk = off, off += 2 * p.splitk_each;
     const size_t set0 = off;
     p.h0 = off, off += al64((size_t)n * p.in0);
     p.h0b = off, off += net->attn ? al64((size_t)n * p.in0) : 0;  // attention: one layer-0 input per net
@@ -1070,6 +1221,7 @@ static int launch_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJo
     gg.chunks = p.chunks;
     for (int e = 0; e < nj; ++e) gr.chunks[e] = p.chunks;
     gr.accumulate = accumulate ? 1 : 0;
+    bool direct = false;  // gradients written by the GEMM itself (single chunk): no reduce launch
     // ---- wide kernel: cut every job along the node axis so that the workgroups carry about equal MFMA work --------
     bool wide = pol.max_units > 0 && p.n > 0;
     WideGemm wg;
@@ -1192,9 +1344,20 @@ static int launch_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJo
         groups = (gy + rpg - 1) / rpg;
         const int nv = nz * groups;
         const unsigned blocks = 8u * (unsigned)((nv + 7) / 8) * (unsigned)(gx * rpg);
-        hipLaunchKernelGGL(k_gemm_dw_grouped, dim3(blocks), dim3(kGemmThreads), 0, st, gg, gx, gy, nz, groups, rpg);
+        if (p.chunks == 1 && !accumulate) {  // one chunk: its "slab" IS the gradient - written in place, no reduce pass
+            for (int e = 0; e < nj; ++e) gg.job[e].C = jobs[e].gw, gg.job[e].aux_out = jobs[e].gb;
+            direct = true;
+        }
+        bool gbuf = true;
+        for (int e = 0; e < nj; ++e)
+            gbuf = gbuf && gemm_buf_ok(OPND_MC, OPND_MC, p.kchunk, jobs[e].lda, p.kchunk, jobs[e].ldb, p.n);
+        if (gbuf)
+            hipLaunchKernelGGL(k_gemm_dw_grouped<true>, dim3(blocks), dim3(kGemmThreads), 0, st, gg, gx, gy, nz, groups, rpg);
+        else
+            hipLaunchKernelGGL(k_gemm_dw_grouped<false>, dim3(blocks), dim3(kGemmThreads), 0, st, gg, gx, gy, nz, groups, rpg);
         GNF_LAUNCH_CHECK("k_gemm_dw_grouped");
     }
+    if (direct) return GNF_OK;
     hipLaunchKernelGGL(k_reduce_grouped, dim3((unsigned)((maxred + 255) / 256), (unsigned)nj), dim3(256), 0, st, gr);
     GNF_LAUNCH_CHECK("k_reduce_grouped");
     return GNF_OK;
@@ -1248,11 +1411,12 @@ static int launch_aggregate_bwd(const BwdPlan& p, const GnfCsr* csr_t, const Gnf
 // Generic (any layer width) recompute + coupling + dP chain of one half-step out of GEMM building blocks:
 // o.h0[q] holds the layer-0 inputs on entry; on exit o.hin / o.dPs / o.gst / o.dh0 are filled, y and g updated.
 static int mlp_backward_generic(const BwdPlan& p, const BwdOperands& o, const GnfGnnSpec& gnn, const GnfMlp* const* nets,
-                                const float* x_cond, float* y_upd, int64_t ld, float* g_upd, int64_t ldg,
+                                const float* x_cond, float* y_upd, int64_t ld, float* g_upd, int64_t ldg, float* ws,
                                 hipStream_t st) {
     const int64_t n = p.n;
     const int K = p.K, H = p.H;
     int rc;
+    float* const sk[2] = {ws + p.splitk, ws + p.splitk + p.splitk_each};
     for (int j = 0; j < K; ++j) {  // recompute the two MLPs, keeping every layer output
         const int I = nets[0]->dims[j], O = nets[0]->dims[j + 1];
         const bool last = j == K - 1;
@@ -1266,7 +1430,7 @@ static int mlp_backward_generic(const BwdPlan& p, const BwdOperands& o, const Gn
         sh.ldc = last ? H : p.lmax;
         sh.M = n, sh.K = I, sh.N = O, sh.chunks = 1, sh.kchunk = TGK;
         sh.act = gnn.activation, sh.alpha = gnn.alpha, sh.apply_act = last ? 0 : 1;
-        rc = launch_gemm<OPND_KC, OPND_MC, EPI_BIAS_ACT>(jobs, 2, sh, st);
+        rc = launch_gemm<OPND_KC, OPND_MC, EPI_BIAS_ACT>(jobs, 2, sh, st, sk, p.splitk_each);
         if (rc) return rc;
     }
     {
@@ -1291,7 +1455,7 @@ static int mlp_backward_generic(const BwdPlan& p, const BwdOperands& o, const Gn
         sh.ldaux = p.lmax;
         sh.M = n, sh.K = O, sh.N = I, sh.chunks = 1, sh.kchunk = TGK;
         sh.act = gnn.activation, sh.alpha = gnn.alpha;
-        rc = launch_gemm<OPND_KC, OPND_KC, EPI_MASK>(jobs, 2, sh, st);
+        rc = launch_gemm<OPND_KC, OPND_KC, EPI_MASK>(jobs, 2, sh, st, sk, p.splitk_each);
         if (rc) return rc;
     }
     return GNF_OK;
@@ -1635,7 +1799,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                                            g + uo, D, H, o.h0[0], attn ? h0c : nullptr, o.hin, p.lmax, o.dPs, p.lmax,
                                            o.gst, o.dh0, st);
             } else {
-                rc = mlp_backward_generic(p, o, flow->gnn, nets, x_cond, z + uo, ld, g + uo, D, st);
+                rc = mlp_backward_generic(p, o, flow->gnn, nets, x_cond, z + uo, ld, g + uo, D, wsf, st);
             }
             if (rc) return rc;
             // message passing: the weight gradients only read what the fused kernel has just written, so their stream
