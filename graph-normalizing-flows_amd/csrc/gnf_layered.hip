@@ -438,7 +438,7 @@ static int run_mlps(const GnfMlp* const* nets, int nj, const float* const* h0, i
         }
         const int64_t lddst = last ? ldout : ldbuf;
         const int I = m->dims[j], O = m->dims[j + 1];
-        if (last && j >= 1 && I >= 512 && O >= 32) {
+        if (last && j >= 1 && I >= 512) {
             // thin output behind a wide layer (2048 -> 100 on a few hundred nodes: 16 tiles x 64 k-steps): split-K
             // through the generic GEMM, slabs in the ping-pong buffer this layer leaves free
             const float* xin[2];

@@ -398,6 +398,38 @@ def test_gradients_on_a_batch_with_more_tiles_than_cus(community_medium):
         _check_grads(tr.named_gradients(), ref["grads"], False, scale=1e-3)
 
 
+def test_thin_layers_behind_wide_ones_take_the_split_k_path(grid_small):
+    """640-wide hidden layers on a ~100-node batch: the 640 -> H output layer (forward and recompute) and the first
+    layer's dX GEMM have a handful of tiles and a long reduction, which the generic path splits over the reduction
+    (launch_gemm split-K + k_splitk_epilogue; the layered forward borrows its free ping-pong buffer for the slabs).
+    Forward, inverse and every gradient against the oracle, with and without batch norm."""
+    from gnf_amd.train import GRevNetTrainer
+    hp = dict(D=24, latent=640, K=3, T=2, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu",
+              weight_sharing=False)
+    nn, ne, s, r = _batch(grid_small, list(range(10)))
+    n = int(nn.sum())
+    rng = np.random.default_rng(17)
+    x = (rng.standard_normal((n, 24)) * 0.8).astype(np.float32)
+    for use_bn in (False, True):
+        p = O.make_grevnet_params(21, 12, 640, 3, 2, final_scale=0.3)
+        if use_bn:
+            p["bn"] = O.make_bn_params(22, 12, 2)
+        ref = O.loss_and_grads(s, r, n, x, p, 2)
+        net = make_product_grevnet(hp, p)
+        net.fused = False                         # layered forward + generic (GEMM) backward
+        graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+        tr = GRevNetTrainer(net)
+        out = tr.loss_and_grads(graph)
+        torch.cuda.synchronize()
+        assert abs(float(out["loss_per_node"]) - ref["total_loss"] / n) <= 1e-4
+        np.testing.assert_allclose(out["reconstruction"].cpu().numpy(), x, atol=3e-4, rtol=3e-4)
+        _check_grads(tr.named_gradients(), ref["grads"], False, scale=1e-3)
+        if not use_bn:                            # g(f(x)) = x through the layered inverse (moving stats aside)
+            z, _ = net(graph, inverse=True)
+            back = net(z, inverse=False)
+            np.testing.assert_allclose(back.nodes.cpu().numpy(), x, atol=3e-4, rtol=3e-4)
+
+
 DW_MODES = [
     ({}, ""),                                                     # what the library picks by itself
     ({"GNF_DW_GROUPED": "1"}, ""),                                # the 128 x 64 grouped kernel
