@@ -212,6 +212,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--layered", action="store_true", help="run the generic layered kernels instead of the fused one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary legs (CSR rebuild per step, host_fed, two_streams): what the rocprofv3 "
+                         "summaries under profiles/ are taken with, so that a kernel's average is the timed region's")
     ap.add_argument("--sync-each-step", action="store_true", help="latency mode: host waits for every step's scalar")
     ap.add_argument("--kernel-timing-steps", type=int, default=10)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="config2")
@@ -324,7 +327,7 @@ def main():
     # ---- secondary figure: the same step when the batch's topology is new every step (training loop
     # of run_grevnet.py:440-447 draws a fresh batch per step): CSR rebuilt on device inside the step
     rebuild = None
-    if not inverse and world == 1 and trainer is None:
+    if not inverse and world == 1 and trainer is None and not args.no_secondary:
         from gnf_amd.graphs import clear_csr_cache
         nreb = max(10, min(50, args.steps))
         torch.cuda.synchronize()
@@ -342,7 +345,7 @@ def main():
     # nodes / senders / receivers / n_node / n_edge start in pinned host memory every step, are uploaded, the CSR
     # is rebuilt on device, then the same forward runs.  Never the headline value.
     host_fed = None
-    if not inverse and world == 1 and trainer is None:
+    if not inverse and world == 1 and trainer is None and not args.no_secondary:
         from gnf_amd.graphs import clear_csr_cache
         fields = ("nodes", "senders", "receivers", "n_node", "n_edge")
         pinned = {f: getattr(graph, f).cpu().pin_memory() for f in fields}
@@ -371,7 +374,7 @@ def main():
     # other) can use the idle third of the chip by keeping two batches in flight.  Not the headline protocol
     # (one batch at a time); reported next to it.
     two_streams = None
-    if not inverse and world == 1 and trainer is None:
+    if not inverse and world == 1 and trainer is None and not args.no_secondary:
         streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         bufs = [torch.zeros(3, dtype=torch.float64, device=dev) for _ in streams]
         host2 = torch.zeros(args.steps, 3, dtype=torch.float64).pin_memory()
