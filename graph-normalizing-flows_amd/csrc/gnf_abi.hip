@@ -310,7 +310,7 @@ int gnf_coupling_half_f32(const GnfCsr* csr, const GnfMlp* s_net, const GnfMlp* 
     hipStream_t st = (hipStream_t)stream;
     int32_t nparts = 0;
     HalfStep hs{csr->rowptr, csr->col, csr->n_nodes, x_cond, x_upd, ld, H, direction, *gnn,
-                s_net, t_net, (double*)ws, &nparts};
+                s_net, t_net, (double*)ws, &nparts, nullptr, csr->n_edges};
     rc = run_half(hs, (float*)((char*)ws + p.partial_bytes), st);
     if (rc) return rc;
     if (logdet_accum)
@@ -382,7 +382,7 @@ int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld
                                 half == 0 ? half1 : half0, ld, H, GNF_FORWARD, flow->gnn,
                                 pick(flow, flow->s_nets, half, i), pick(flow, flow->t_nets, half, i),
                                 partials + used, &np_,
-                                stash ? stash + (size_t)(2 * i + half) * stash_slot : nullptr};
+                                stash ? stash + (size_t)(2 * i + half) * stash_slot : nullptr, csr->n_edges};
                     rc = run_half(hs, scratch, st);
                     if (rc) return rc;
                     used += np_;
@@ -395,7 +395,7 @@ int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld
                     HalfStep hs{csr->rowptr, csr->col, n, half == 0 ? half0 : half1,
                                 half == 0 ? half1 : half0, ld, H, GNF_INVERSE, flow->gnn,
                                 pick(flow, flow->s_nets, half, i), pick(flow, flow->t_nets, half, i),
-                                partials + used, &np_, nullptr};
+                                partials + used, &np_, nullptr, csr->n_edges};
                     rc = run_half(hs, scratch, st);
                     if (rc) return rc;
                     // partial slots are reused: the inverse pass has no log-det (gnn.py:343-373)

@@ -46,6 +46,7 @@ struct HalfStep {
     int32_t* n_partials;  // host out: how many partials this launch writes
     float* attn_region;   // NULL: the attention front-end works in the scratch; else q | k | v and h0 of both nets go
                           // here (a slot of GnfFlow.attn_stash) and stay for the backward pass
+    int64_t n_edges;      // 0: unknown (only used to pick between kernel generations by mean degree)
 };
 // floats of one half-step's slot in GnfFlow.attn_stash ( = attn_scratch_floats: [2][n][P] q|k|v, then [2][n][in0] h0)
 size_t attn_stash_slot_floats(const GnfFlow* flow, int64_t n_nodes);
@@ -134,7 +135,7 @@ int validate_attn(const GnfAttn* at, const GnfMlp* mlp, int32_t H, const char* w
 size_t attn_scratch_floats(const GnfAttn* at, int64_t n_nodes, int32_t in0);
 int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, const float* x, int64_t ldx,
                       int32_t H, const GnfAttn* const* at, int nets, int32_t in0, float* scratch,
-                      float* const* h0_out, hipStream_t st);
+                      float* const* h0_out, hipStream_t st, int64_t n_edges = 0);
 // dst[r, 0:W) += src[r, 0:W)
 int launch_add_rows(float* dst, int64_t ldd, const float* src, int64_t lds_, int64_t n, int32_t W, hipStream_t st);
 

@@ -1780,7 +1780,8 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             if (attn) {   // recompute the attention front-end of both nets (q | k | v kept for the way back)
                 const GnfAttn* at[2] = {nets[0]->attn, nets[1]->attn};
                 if (!stashed) {
-                    rc = launch_attn_front(csr->rowptr, csr->col, n, x_cond, ld, H, at, 2, p.in0, o.qkv[0], o.h0, st);
+                    rc = launch_attn_front(csr->rowptr, csr->col, n, x_cond, ld, H, at, 2, p.in0, o.qkv[0], o.h0, st,
+                                           csr->n_edges);
                     if (rc) return rc;
                 }
                 int64_t blocks = (n * H + 255) / 256;
