@@ -228,11 +228,13 @@ ATTN_TRAIN_CASES = [
 ]
 
 
+@pytest.mark.parametrize("stash", [True, False], ids=["stash", "recompute"])
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "gemm"])
 @pytest.mark.parametrize("case", ATTN_TRAIN_CASES, ids=[f"D{c[0]}_h{c[4]}_kq{c[5]}_v{c[6]}_C{c[7]}" for c in ATTN_TRAIN_CASES])
-def test_attention_gradients_vs_oracle(community_medium, case, fused):
+def test_attention_gradients_vs_oracle(community_medium, case, fused, stash):
     """The drivers' default GNN (run_grevnet.py:56,199-211) trains: gradients of wq, wk, wv, wo and of the MLP
-    behind the attention front-end vs the autograd oracle (itself pinned by finite differences)."""
+    behind the attention front-end vs the autograd oracle (itself pinned by finite differences) - with the
+    front-end stashed by the forward pass (GnfFlow.attn_stash, the default) and recomputed by the backward walk."""
     from gnf_amd.train import GRevNetTrainer
     d, latent, k, t, nh, kq, vd, c, concat, div, res, ws = case
     attn = dict(num_heads=nh, kq_dim=kq, v_dim=vd, out_dim=c, concat=concat, kq_dim_division=div, residual=res)
@@ -247,8 +249,10 @@ def test_attention_gradients_vs_oracle(community_medium, case, fused):
     net = make_product_grevnet(hp, p)
     net.fused = fused
     tr = GRevNetTrainer(net)
+    tr.stash_attention = stash
     out = tr.loss_and_grads(graph_from_arrays(nn, ne, s, r, x, DEV))
     torch.cuda.synchronize()
+    assert (tr._stash is not None) == stash
     assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
     np.testing.assert_allclose(out["reconstruction"].cpu().numpy(), x, atol=3e-4, rtol=3e-4)
     for (name, a), (_, b) in zip(_flat_attn(tr.named_gradients(), ws), _flat_attn(ref["grads"], ws)):
