@@ -252,7 +252,7 @@ def main():
     from gnf_amd import _abi
     from gnf_amd.flow import forward_shard_sums, log_prob_from_sums
     from gnf_amd.graphs import csr_of, data_dicts_to_graphs_tuple
-    from gnf_amd.sharding import all_reduce_shard_sums
+    from gnf_amd.sharding import all_reduce_shard_sums, all_reduce_shard_sums_async
     _abi.lib()
 
     dicts, n_global, e_global = make_batch(world, rank)
@@ -290,16 +290,33 @@ def main():
         if inverse:   # config 4: sampling direction g (gnn.py:343-373); no scalar comes back
             net(graph, inverse=False)
             return
-        _, s3 = forward_shard_sums(net, graph, sums3)
         if world > 1:
+            # two alternating sum buffers: batch i's 3-scalar all-reduce runs on RCCL's stream while batch i + 1 is
+            # already computing; its result is read (stream-ordered wait, pinned-host copy) one step later
+            buf = sums_pair[i & 1]
+            _, s3 = forward_shard_sums(net, graph, buf)
             s3[2] = float(n_local)           # all-reduce sums in place: restore this rank's count first
-            all_reduce_shard_sums(s3)
-        host[i].copy_(s3, non_blocking=True)
+            pending.append((all_reduce_shard_sums_async(s3), s3, i))
+            if len(pending) > 1 or args.sync_each_step:
+                drain(1 if not args.sync_each_step else len(pending))
+        else:
+            _, s3 = forward_shard_sums(net, graph, sums3)
+            host[i].copy_(s3, non_blocking=True)
         if args.sync_each_step:
             torch.cuda.current_stream().synchronize()
 
+    sums_pair = [torch.zeros(3, dtype=torch.float64, device=dev) for _ in range(2)]
+    pending = []
+
+    def drain(count):
+        for _ in range(min(count, len(pending))):
+            work, t, j = pending.pop(0)
+            work.wait()
+            host[j].copy_(t, non_blocking=True)
+
     for i in range(args.warmup):
         step(i)
+    drain(len(pending))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -307,6 +324,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    drain(len(pending))                      # inside the timed region: every batch's log-prob has reached the host buffer
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -491,7 +509,7 @@ def main():
                                + (", fully connected topology" if WORKLOAD["fc"] else ", sparse topology+self loops"),
                    "nodes_total": n_global, "edges_total": e_global, "nodes_rank0": n_local, "edges_rank0": e_local,
                    "weights": f"N(0,2/(fan_in+fan_out)), seed {WEIGHT_SEED}, last layer x{FINAL_SCALE}",
-                   "parallelism": f"graph-shard dp{world}, 1 all-reduce of 3xfp64 per step" if world > 1 else "single GPU",
+                   "parallelism": f"graph-shard dp{world}, 1 all-reduce of 3xfp64 per step (async: overlapped with the next batch's forward)" if world > 1 else "single GPU",
                    "path": "fused MFMA half-step kernel" if net.fused else "layered kernels",
                    "csr": f"built on device once per batch before the timed region (gnf_build_csr: {csr_ms:.3f} ms wall incl. host launch), cached",
                    "host_sync": "every step" if args.sync_each_step else "results copied to pinned host memory each step; one sync at end"},
