@@ -47,7 +47,14 @@ def _worker(rank, world, port, ret):
         res = O.Fp64Dense(s, r, int(nn.sum())).log_prob(x_all[rows], p, t)
         sums = torch.tensor([res["log_det_jacobian"], float((res["z"] ** 2).sum()), float(nn.sum())],
                             dtype=torch.float64)
+        # the pipelined form bench.py uses: two batches' reductions in flight, read one step later
+        from gnf_amd.sharding import all_reduce_shard_sums_async
+        pair = [sums.clone(), sums.clone() * 2.0]
+        works = [all_reduce_shard_sums_async(t_) for t_ in pair]
         all_reduce_shard_sums(sums)                             # the single collective
+        for w_ in works:
+            w_.wait()
+        assert torch.equal(pair[0], sums) and torch.equal(pair[1], sums * 2.0)
         out = log_prob_from_sums(sums.tolist(), dim)
         ret[rank] = (out["log_prob_xs_per_node"], out["num_nodes"], len(mine))
     finally:
@@ -83,6 +90,9 @@ def test_all_reduce_is_identity_without_process_group():
     s = torch.tensor([1.0, 2.0, 4.0], dtype=torch.float64)
     out = all_reduce_shard_sums(s.clone())
     assert torch.equal(out, s)
+    from gnf_amd.sharding import all_reduce_shard_sums_async
+    t = s.clone()
+    assert all_reduce_shard_sums_async(t).wait() and torch.equal(t, s)
     asm = assemble_from_sums(s)
     assert float(asm["log_prob_xs"]) == 3.0 and float(asm["log_prob_xs_per_node"]) == 0.75
 
