@@ -438,23 +438,29 @@ static int run_mlps(const GnfMlp* const* nets, int nj, const float* const* h0, i
         }
         const int64_t lddst = last ? ldout : ldbuf;
         const int I = m->dims[j], O = m->dims[j + 1];
-        if (last && j >= 1 && I >= 512) {
-            // thin output behind a wide layer (2048 -> 100 on a few hundred nodes: 16 tiles x 64 k-steps): split-K
-            // through the generic GEMM, slabs in the ping-pong buffer this layer leaves free
+        if ((I >= 32 && O >= 32) || (last && j >= 1 && I >= 512)) {
+            // matrix-core layers run through the generic GEMM tile (gnf_train.hip); a thin output behind a wide layer
+            // (2048 -> 100 on a few hundred nodes: 16 tiles x 64 k-steps) is split over the reduction there, its
+            // slabs in the ping-pong buffer the LAST layer leaves free
             const float* xin[2];
             const float *wq[2], *bq[2];
             float* yq[2];
-            float* sk[2];
+            float* sk[2] = {nullptr, nullptr};
             for (int q = 0; q < nj; ++q) {
                 xin[q] = in[q], wq[q] = nets[q]->W[j], bq[q] = nets[q]->b[j], yq[q] = dst[q];
-                sk[q] = (j & 1) ? bufB[q] : bufA[q];
+                if (last && j >= 1) sk[q] = (j & 1) ? bufB[q] : bufA[q];
             }
-            const int rc = launch_linear_splitk(xin, ldin, wq, bq, yq, lddst, nj, n, I, O, g.activation, g.alpha, 0, sk,
-                                                (size_t)n * (size_t)ldbuf, st);
+            const int rc = launch_linear_splitk(xin, ldin, wq, bq, yq, lddst, nj, n, I, O, g.activation, g.alpha,
+                                                last ? 0 : 1, sk, (size_t)n * (size_t)ldbuf, st);
             if (rc < 0) return rc;
-            if (rc == 0) break;  // done (it was the last layer)
+            if (rc == 0) {
+                in[0] = dst[0];
+                in[1] = dst[1];
+                ldin = lddst;
+                continue;
+            }
         }
-        if (I >= 32 && O >= 32) {  // matrix cores once the layer is GEMM-shaped
+        if (I >= 32 && O >= 32) {  // (A/B switch) gnf_layered.hip's own matrix-core kernel
             LinJob jobs[2];
             bool vec = (I % 4 == 0) && (O % 4 == 0) && (ldin % 4 == 0);
             for (int q = 0; q < 2; ++q) {

@@ -696,14 +696,19 @@ static int launch_gemm(const GemmJob* jobs, int nj, const GemmShape& sh, hipStre
     return GNF_OK;
 }
 
-// y = act(x W + b) for up to two nets sharing shapes, through the split-K path above when the layer is thin
-// (gnf_layered.hip hands its free ping-pong activation buffer in as scratch); returns 1 when the layer is not thin
-// enough to bother - the caller then runs its own kernel.
+// y = act(x W + b) for up to two nets sharing shapes: the layered forward path's matrix-core layers run through the
+// same GEMM tile as the generic backward (split over the reduction when the layer is thin and the caller has a free
+// ping-pong activation buffer to lend as slab scratch; sk may be NULL).  Returns 1 only under the A/B switch that
+// sends ordinary layers back to gnf_layered.hip's own kernel.
 int launch_linear_splitk(const float* const* x, int64_t ldx, const float* const* W, const float* const* b, float* const* y,
                          int64_t ldy, int nj, int64_t n, int32_t I, int32_t O, int act, float alpha, int apply_act,
                          float* const* sk, size_t sk_floats, hipStream_t st) {
-    const int64_t tiles = (int64_t)((O + TGN - 1) / TGN) * ((n + TGM - 1) / TGM) * nj;
-    if (tiles >= 96 || I < 512 || n == 0 || (size_t)2 * n * O > sk_floats) return 1;
+    if (n == 0) return GNF_OK;
+    static const bool own_kernel = getenv("GNF_LAYERED_OWN_GEMM") != nullptr;  // developer A/B switch: k_linear_mfma
+    if (own_kernel) {
+        const int64_t tiles = (int64_t)((O + TGN - 1) / TGN) * ((n + TGM - 1) / TGM) * nj;
+        if (tiles >= 96 || I < 512 || !sk || (size_t)2 * n * O > sk_floats) return 1;
+    }
     GemmJob jobs[2];
     for (int q = 0; q < nj; ++q) jobs[q] = GemmJob{x[q], W[q], y[q], b[q], nullptr};
     GemmShape sh;
