@@ -28,6 +28,21 @@ namespace gnf {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+#ifdef GNF_DW_TRACE  // developer build: s_memtime ticks of workgroup 0 / thread 0, summed per phase
+__device__ unsigned long long g_dw_trace[8];
+#define GNF_DWT(i, t0) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); g_dw_trace[i] += t1_ - t0; t0 = t1_; } } while (0)
+extern "C" int gnf_debug_read_dw_trace(unsigned long long* out, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dw_trace), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {0};
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dw_trace), z, sizeof(z));
+    }
+    return rc;
+}
+#else
+#define GNF_DWT(i, t0)
+#endif
+
 static constexpr int TGM = 128, TGN = 64, TGK = 32;
 static constexpr int kGemmThreads = 512;
 
@@ -185,8 +200,12 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
     }
     __syncthreads();
     for (int64_t k0 = kbeg; k0 < kend; k0 += TGK) {
+#ifdef GNF_DW_TRACE
+        unsigned long long tt = __builtin_amdgcn_s_memtime();
+#endif
         const bool more = k0 + TGK < kend;
         if (more) fetch(k0 + TGK);  // in flight behind this step's MFMAs
+        GNF_DWT(0, tt);
         const float* As = As2 + cur * kAs;
         const float* Bs = Bs2 + cur * kBs;
         if (EPI == EPI_SLAB && BK == OPND_MC) {
@@ -228,12 +247,18 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
                     for (int m = 0; m < 2; ++m)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][q], b[n][q], acc[m][n], 0, 0, 0);
         }
+        GNF_DWT(2, tt);
         if (more) {
             tile_stash<AR, AC, 2>(As2 + (cur ^ 1) * kAs, tid, av);
             tile_stash<BR, BC, 1>(Bs2 + (cur ^ 1) * kBs, tid, bvr);
         }
+        GNF_DWT(3, tt);
         __syncthreads();
+        GNF_DWT(4, tt);
         cur ^= 1;
+#ifdef GNF_DW_TRACE
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_dw_trace[7] += 1;
+#endif
     }
     // accumulator layout: col = lane & 15, row = 4 * (lane >> 4) + r
     float* __restrict__ Cp = job.C;
@@ -418,20 +443,6 @@ __device__ __forceinline__ void wide_compute(const float* __restrict__ As, const
     for (; pc < kWidePieces; ++pc) piece(pc);
 }
 
-#ifdef GNF_DW_TRACE  // developer build: s_memtime ticks of workgroup 0 / thread 0, summed per phase
-__device__ unsigned long long g_dw_trace[8];
-#define GNF_DWT(i, t0) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); g_dw_trace[i] += t1_ - t0; t0 = t1_; } } while (0)
-extern "C" int gnf_debug_read_dw_trace(unsigned long long* out, int reset) {
-    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dw_trace), sizeof(unsigned long long) * 8);
-    if (reset) {
-        unsigned long long z[8] = {0};
-        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dw_trace), z, sizeof(z));
-    }
-    return rc;
-}
-#else
-#define GNF_DWT(i, t0)
-#endif
 
 // workgroup barrier that only waits for this wave's LDS traffic (not for the global loads in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
