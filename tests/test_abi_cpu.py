@@ -135,3 +135,25 @@ def test_missing_library_raises(monkeypatch, tmp_path):
     monkeypatch.setattr(_abi, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_abi.GnfError):
         _abi.lib()
+
+
+def test_abi_v5_size_helpers_are_host_computations():
+    """gnf_clip_workspace_bytes / gnf_attn_stash_bytes touch no device: 64 fp64 partials per tensor; the stash is
+    zero without an attention front-end and 2T slots of 2 n (P + in0) floats with one."""
+    lib = _abi.lib()
+    assert lib.gnf_clip_workspace_bytes(0) == 0
+    assert lib.gnf_clip_workspace_bytes(7) == 7 * 64 * 8
+    s = (_abi.GnfMlp * 2)(_mlp([8, 32, 8]), _mlp([8, 32, 8]))
+    flow = _abi.GnfFlow(3, 1, C.cast(s, C.POINTER(_abi.GnfMlp)), C.cast(s, C.POINTER(_abi.GnfMlp)),
+                        _abi.GnfGnnSpec(1, 0, 1.0, 1, 0.2))
+    assert lib.gnf_attn_stash_bytes(100, 16, C.byref(flow)) == 0          # message-passing nets: nothing to stash
+    at = _abi.GnfAttn()
+    at.num_heads, at.kq_dim, at.v_dim, at.out_dim = 4, 5, 6, 12
+    sa = (_abi.GnfMlp * 2)(_mlp([20, 32, 8]), _mlp([20, 32, 8]))
+    for m in sa:
+        m.attn = C.pointer(at)
+    fa = _abi.GnfFlow(3, 1, C.cast(sa, C.POINTER(_abi.GnfMlp)), C.cast(sa, C.POINTER(_abi.GnfMlp)),
+                      _abi.GnfGnnSpec(1, 0, 1.0, 1, 0.2))
+    p = 2 * 4 * 5 + 6
+    assert lib.gnf_attn_stash_bytes(100, 16, C.byref(fa)) == 2 * 3 * (2 * 100 * (p + 20)) * 4
+    assert lib.gnf_attn_stash_bytes(0, 16, C.byref(fa)) == 0
