@@ -290,6 +290,215 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
         job.aux_out[(int64_t)chunk * sh.N + n0 + tid] = colsum;
 }
 
+// ---- the same tile with LDS-direct loads ------------------------------------------------------------------------
+// `buffer_load_dword[x4] ... lds` writes a wave's 64 elements straight into LDS (lane l -> M0 base + l * size): no
+// register staging, no ds_write, and a load can stay in flight for as many k-steps as there are LDS stages.  The
+// tiles are kept in LDS in MFMA FRAGMENT ORDER - one 1 KB block per (16-row tile, 16-k group): for a KC operand
+// ([row][k]) lane (r = l & 15, g = l >> 4) fetches the float4 X[row0 + 16 i + r][k0 + 16 kg + 4 g ..] with ONE dwordx4
+// load and later reads exactly that float4 back as its fragment of four k-slices (ds_read_b128, conflict-free by
+// construction); for an MC operand ([k][col]) the four k-slices sit in four rows, so block (i, kg) is four 256-byte
+// sub-blocks filled by dword loads.  Three stages: at step t the loads of tile t + 2 are issued right after the one
+// barrier of the step (which also says: everybody is done with the stage they overwrite), a wave waits for its OWN
+// loads of tile t with s_waitcnt vmcnt(L) - L loads per wave and tile, the loads of tile t + 1 stay in flight.
+// The loads are inline asm: through the builtin the compiler's wait-count pass makes every LDS read wait for ALL
+// LDS-direct loads in flight (it cannot tell the stages apart), which serialises exactly what this is for.  Loads are
+// issued unconditionally (tiles past the reduction are out of the descriptor's range: zeros) so that L is a constant.
+__device__ __forceinline__ void lds_load_x4(__amdgpu_buffer_rsrc_t r, int voff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(r), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ void lds_load_x1(__amdgpu_buffer_rsrc_t r, int voff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dword %0, %1, 0 offen lds" ::"v"(voff), "s"(r), "s"(lds_byte_addr) : "memory");
+}
+
+static constexpr int kLdStages = 3;
+static constexpr int kLdStageFloats = (TGM + TGN) * TGK;  // 4096 (A) + 2048 (B)
+static constexpr size_t kLdLdsBytes = (size_t)kLdStages * kLdStageFloats * sizeof(float);
+
+template <int AK, int BK, int EPI>
+__device__ __forceinline__ void gemm_tile_ld(const GemmJob& job, const GemmShape& sh, const int bx, const int by,
+                                             const int chunk) {
+    extern __shared__ __attribute__((aligned(16))) float ld_lds[];
+    const int64_t m0 = (int64_t)by * TGM;
+    const int n0 = bx * TGN;
+    const int64_t kbeg = (int64_t)chunk * sh.kchunk;
+    const int64_t kend = (EPI == EPI_SLAB) ? (kbeg + sh.kchunk < sh.K ? kbeg + sh.kchunk : sh.K) : sh.K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    const int wm = (wave & 3) * 32, wn = (wave >> 2) * 32;
+    constexpr int kOut = 0x7fffffff;
+    // loads per wave and tile: KC operand = one dwordx4 per block, MC operand = four dwords per block;
+    // A has 16 blocks (2 per wave), B has 8 (1 per wave)
+    constexpr int L = (AK == OPND_KC ? 2 : 8) + (BK == OPND_KC ? 1 : 4);
+
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float bv = 0.f;
+            if (EPI == EPI_BIAS_ACT) {
+                const int gc = n0 + wn + 16 * b + lrow;
+                bv = gc < sh.N ? job.aux[gc] : 0.f;
+            }
+            acc[m][b] = f32x4_t{bv, bv, bv, bv};
+        }
+    float cs[2] = {0.f, 0.f};  // EPI_SLAB: this lane's share of the column sums of B (columns wn + 16 n + lrow)
+
+    const int64_t a_rows = AK == OPND_KC ? sh.M - m0 : kend - kbeg, b_rows = BK == OPND_KC ? (int64_t)sh.N - n0 : kend - kbeg;
+    const float* a_base = AK == OPND_KC ? job.A + m0 * sh.lda : job.A + kbeg * sh.lda + m0;
+    const float* b_base = BK == OPND_KC ? job.B + (int64_t)n0 * sh.ldb : job.B + kbeg * sh.ldb + n0;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a_base), 0, a_rows > 0 ? (int)((a_rows * sh.lda - (AK == OPND_KC ? 0 : m0)) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(b_base), 0, b_rows > 0 ? (int)((b_rows * sh.ldb - (BK == OPND_KC ? 0 : n0)) * 4) : 0, 0x00020000);
+    const int lda = (int)sh.lda, ldb = (int)sh.ldb;
+    // lane part of the byte offsets:  KC: row lrow, k 4 lgrp;   MC: k row 4 lgrp, column lrow
+    const int va = AK == OPND_KC ? (lrow * lda + 4 * lgrp) * 4 : (4 * lgrp * lda + lrow) * 4;
+    const int vb = BK == OPND_KC ? (lrow * ldb + 4 * lgrp) * 4 : (4 * lgrp * ldb + lrow) * 4;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ld_lds;
+
+    // issue this wave's share of tile `t` (k0 = kbeg + 32 t) into stage `stage`
+    auto issue = [&](int64_t k0, int stage) {
+        const unsigned sa = lds0 + (unsigned)(stage * kLdStageFloats) * 4, sb = sa + TGM * TGK * 4;
+        {   // A: blocks (i = wave, kg = 0, 1)
+            const int i = wave;
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg) {
+                const unsigned blk = sa + (unsigned)((i * 2 + kg) * 1024);
+                if (AK == OPND_KC) {
+                    const bool in = k0 + 16 * kg + 4 * lgrp < kend;
+                    lds_load_x4(ra, in ? va + (16 * i * lda + 16 * kg) * 4 + (int)k0 * 4 : kOut, blk);
+                } else {
+                    const int kr = (int)(k0 - kbeg) + 16 * kg;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) lds_load_x1(ra, va + ((kr + q) * lda + 16 * i) * 4, blk + q * 256);
+                }
+            }
+        }
+        {   // B: block (j = wave >> 1, kg = wave & 1)
+            const int j = wave >> 1, kg = wave & 1;
+            const unsigned blk = sb + (unsigned)((j * 2 + kg) * 1024);
+            if (BK == OPND_KC) {
+                const bool in = k0 + 16 * kg + 4 * lgrp < kend;
+                lds_load_x4(rb, in ? vb + (16 * j * ldb + 16 * kg) * 4 + (int)k0 * 4 : kOut, blk);
+            } else {
+                const int kr = (int)(k0 - kbeg) + 16 * kg;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) lds_load_x1(rb, vb + ((kr + q) * ldb + 16 * j) * 4, blk + q * 256);
+            }
+        }
+    };
+    auto compute = [&](int stage) {
+        const float* As = ld_lds + stage * kLdStageFloats;
+        const float* Bs = As + TGM * TGK;
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            float a[2][4], b[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const float* blk = As + (((wm >> 4) + m) * 2 + kg) * 256;
+                if (AK == OPND_KC) {
+                    const f32x4_t t = *reinterpret_cast<const f32x4_t*>(blk + lane * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[m][q] = t[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[m][q] = blk[q * 64 + lane];
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const float* blk = Bs + (((wn >> 4) + n) * 2 + kg) * 256;
+                if (BK == OPND_KC) {
+                    const f32x4_t t = *reinterpret_cast<const f32x4_t*>(blk + lane * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b[n][q] = t[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b[n][q] = blk[q * 64 + lane];
+                }
+                if (EPI == EPI_SLAB) cs[n] += (b[n][0] + b[n][1]) + (b[n][2] + b[n][3]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][q], b[n][q], acc[m][n], 0, 0, 0);
+        }
+    };
+
+    issue(kbeg, 0);
+    issue(kbeg + TGK, 1);
+    int st_cur = 0, st_nxt = 2;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += TGK) {
+        // tile k0 (this wave's loads: all but the L newest) has landed; the barrier extends that to every wave's loads
+        // and tells us that everybody has finished reading the stage about to be refilled
+#ifdef GNF_DW_TRACE
+        unsigned long long tt = __builtin_amdgcn_s_memtime();
+#endif
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        GNF_DWT(3, tt);
+        asm volatile("s_barrier" ::: "memory");
+        GNF_DWT(4, tt);
+        issue(k0 + 2 * TGK, st_nxt);
+        GNF_DWT(0, tt);
+        compute(st_cur);
+        GNF_DWT(2, tt);
+#ifdef GNF_DW_TRACE
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_dw_trace[7] += 1;
+#endif
+        st_cur = st_cur == kLdStages - 1 ? 0 : st_cur + 1;
+        st_nxt = st_nxt == kLdStages - 1 ? 0 : st_nxt + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still be writing LDS when the workgroup retires
+
+    // accumulator layout: col = lane & 15, row = 4 * (lane >> 4) + r
+    float* __restrict__ Cp = job.C;
+    if (EPI == EPI_SLAB) Cp += (int64_t)chunk * sh.M * sh.N;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int gc = n0 + wn + 16 * b + lrow;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gr = m0 + wm + 16 * m + 4 * lgrp + r;
+                if (gr < sh.M && gc < sh.N) {
+                    float v = acc[m][b][r];
+                    if (EPI == EPI_BIAS_ACT) {
+                        if (sh.apply_act) v = (sh.act == GNF_ACT_RELU) ? fmaxf(v, 0.f) : fmaxf(v, sh.alpha * v);
+                    } else if (EPI == EPI_MASK) {
+                        if (job.aux) {  // act'(pre) read off the stored activation: h > 0 <=> pre > 0
+                            const float h = job.aux[gr * sh.ldaux + gc];
+                            const float slope = (sh.act == GNF_ACT_RELU) ? 0.f : sh.alpha;
+                            v = h > 0.f ? v : v * slope;
+                        }
+                    }
+                    Cp[gr * sh.ldc + gc] = v;
+                }
+            }
+        }
+    if (EPI == EPI_SLAB && BK == OPND_MC && job.aux_out && by == 0 && wm == 0) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {  // the four lane groups hold the four k-residues of every column
+            float v = cs[n];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int gc = n0 + wn + 16 * n + lrow;
+            if (lgrp == 0 && gc < sh.N) job.aux_out[(int64_t)chunk * sh.N + gc] = v;
+        }
+    }
+}
+
+template <int AK, int BK, int EPI>
+__global__ __launch_bounds__(kGemmThreads) void k_gemm_ld(GemmJob j0, GemmJob j1, GemmShape sh) {
+    const int jz = blockIdx.z / sh.chunks, chunk = blockIdx.z - jz * sh.chunks;
+    const GemmJob job = jz ? j1 : j0;
+    gemm_tile_ld<AK, BK, EPI>(job, sh, blockIdx.x, blockIdx.y, chunk);
+}
+
 template <int AK, int BK, int EPI, bool BUF>
 __global__ __launch_bounds__(kGemmThreads) void k_gemm(GemmJob j0, GemmJob j1, GemmShape sh) {
     const int jz = blockIdx.z / sh.chunks, chunk = blockIdx.z - jz * sh.chunks;
@@ -661,6 +870,30 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(GemmJob j0, GemmJob j1,
     job.C[m * sh.ldc + n] = v;
 }
 
+template <int AK, int BK, int EPI>
+static int launch_k_gemm_ld(dim3 grid, hipStream_t st, const GemmJob& j0, const GemmJob& j1, const GemmShape& sh) {
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_ld<AK, BK, EPI>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdLdsBytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gemm_ld<AK, BK, EPI>), grid, dim3(kGemmThreads), kLdLdsBytes, st, j0, j1, sh);
+    GNF_LAUNCH_CHECK("k_gemm_ld");
+    return GNF_OK;
+}
+// Measured (MI355X, end of round 1) and therefore OFF unless GNF_GEMM_LDS_DIRECT=all: the LDS-direct tile does what it
+// was built for - the wait for a tile's loads drops from ~1050 to ~100 cycles per k-step - but ISSUING the loads then
+// takes 1600 cycles per step: the texture-address unit is the bottleneck either way (720 cycles for three dwordx4
+// loads on the register path), and an MC operand needs four dword loads per block (a fragment's four k-slices sit in
+// four rows), twice the instructions.  wide_fc 10.4 -> 10.8 ms, the 2048-wide trainer 12.0 -> 13.0 ms per iteration;
+// KC x KC alone (the dX GEMM, all dwordx4) is a wash (47 vs 50 us).  Next: a swizzled dwordx4 layout for MC operands.
+static bool gemm_ld_on(int ak, int bk) {
+    static const char* env = getenv("GNF_GEMM_LDS_DIRECT");  // developer A/B switch: "all"
+    (void)ak, (void)bk;
+    return env && env[0] == 'a';
+}
+
 // sk[q] (nullable): scratch of sk_floats floats for job q's slabs when the launch is thin enough to be split
 template <int AK, int BK, int EPI>
 static int launch_gemm(const GemmJob* jobs, int nj, const GemmShape& sh, hipStream_t st, float* const* sk = nullptr,
@@ -684,7 +917,10 @@ static int launch_gemm(const GemmJob* jobs, int nj, const GemmShape& sh, hipStre
                 dim3 grid((unsigned)((sh.N + TGN - 1) / TGN), (unsigned)((sh.M + TGM - 1) / TGM), (unsigned)(nj * s2.chunks));
                 const bool buf = gemm_buf_ok(AK, BK, AK == OPND_KC ? sh.M : sh.K, sh.lda, BK == OPND_KC ? (int64_t)sh.N : sh.K, sh.ldb, sh.K) &&
                                  (AK != OPND_KC && BK != OPND_KC ? true : s2.kchunk % 4 == 0);
-                if (buf)
+                if (buf && gemm_ld_on(AK, BK)) {
+                    const int rc = launch_k_gemm_ld<AK, BK, EPI_SLAB>(grid, st, sj[0], sj[nj - 1], s2);
+                    if (rc) return rc;
+                } else if (buf)
                     hipLaunchKernelGGL((k_gemm<AK, BK, EPI_SLAB, true>), grid, dim3(kGemmThreads), 0, st, sj[0], sj[nj - 1], s2);
                 else
                     hipLaunchKernelGGL((k_gemm<AK, BK, EPI_SLAB, false>), grid, dim3(kGemmThreads), 0, st, sj[0], sj[nj - 1], s2);
@@ -699,6 +935,7 @@ static int launch_gemm(const GemmJob* jobs, int nj, const GemmShape& sh, hipStre
     }
     dim3 grid((unsigned)((sh.N + TGN - 1) / TGN), (unsigned)((sh.M + TGM - 1) / TGM), (unsigned)(nj * sh.chunks));
     const bool buf = gemm_buf_ok(AK, BK, AK == OPND_KC ? sh.M : sh.K, sh.lda, BK == OPND_KC ? (int64_t)sh.N : sh.K, sh.ldb, sh.K);
+    if (buf && gemm_ld_on(AK, BK)) return launch_k_gemm_ld<AK, BK, EPI>(grid, st, jobs[0], jobs[nj - 1], sh);
     if (buf)
         hipLaunchKernelGGL((k_gemm<AK, BK, EPI, true>), grid, dim3(kGemmThreads), 0, st, jobs[0], jobs[nj - 1], sh);
     else
