@@ -109,24 +109,43 @@ __global__ __launch_bounds__(kCsrBlock) void k_csr_fill(const int32_t* __restric
         for (int i = threadIdx.x; i <= ng; i += kCsrBlock) rp[i] = rowptr[n0 + i] - base;
         for (int i = threadIdx.x; i < ng; i += kCsrBlock) cur[i] = 0;
         __syncthreads();
-        for (int e = threadIdx.x; e < eg; e += kCsrBlock) {
-            const int r = receivers[e0 + e] - n0;
-            const int pos = atomicAdd(&cur[r], 1);
-            eid[rp[r] + pos] = e;
+        for (int eb = 0; eb < eg; eb += 8 * kCsrBlock) {  // eight receiver loads in flight per thread, then the atomics
+            int rr[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = eb + u * kCsrBlock + threadIdx.x;
+                rr[u] = e < eg ? receivers[e0 + e] - n0 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (rr[u] >= 0) {
+                    const int pos = atomicAdd(&cur[rr[u]], 1);
+                    eid[rp[rr[u]] + pos] = eb + u * kCsrBlock + threadIdx.x;
+                }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < ng; i += kCsrBlock) {
-            const int beg = rp[i], end = rp[i + 1];
-            for (int a = beg + 1; a < end; ++a) {  // insertion sort by edge id (rows are short)
-                const int key = eid[a];
-                int b = a - 1;
-                while (b >= beg && eid[b] > key) {
-                    eid[b + 1] = eid[b];
-                    --b;
+        // the atomics above put a row's edges in any order: restore edge order by RANK - one wave per row, a lane per
+        // entry counts the row's smaller edge ids (every lane reads the same LDS word: a broadcast) and writes its sender
+        // straight to its final slot.  (One thread insertion-sorting a whole row took 231 us on the complete 100-node
+        // graphs of the drivers' default dataset: 100 rows of 100 entries per workgroup.)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int i = wave; i < ng; i += kCsrBlock / 64) {
+            const int beg = rp[i], d = rp[i + 1] - beg;
+            for (int a = lane; a < d; a += 64) {
+                const int key = eid[beg + a];
+                const int snd = senders[e0 + key];  // in flight while the rank is counted
+                int rank = 0;
+                int b = 0;
+                for (; b + 16 <= d; b += 16) {  // sixteen LDS reads in flight (one at a time: ~100 cycles each, 133 us)
+                    int v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = eid[beg + b + u];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) rank += v[u] < key ? 1 : 0;
                 }
-                eid[b + 1] = key;
+                for (; b < d; ++b) rank += eid[beg + b] < key ? 1 : 0;
+                col[base + beg + rank] = snd;
             }
-            for (int a = beg; a < end; ++a) col[base + a] = senders[e0 + eid[a]];
         }
     } else {
         // slow path: one thread per receiver walks the graph's edge slice in order (tiles staged in LDS)
