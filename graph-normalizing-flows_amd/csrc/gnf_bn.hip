@@ -167,9 +167,12 @@ __global__ __launch_bounds__(256) void k_bn_denorm(float* __restrict__ z, int64_
 
 // moment pass: few large row chunks (each workgroup's partial is re-read by every workgroup of the second pass)
 int bn_blocks(int64_t n, int64_t* rows_per_block) {
-    // small batches: 32-row chunks (a 440-node batch in two 256-row workgroups spent 75 us walking its rows one after
-    // the other); the chunk grows once there would be more than kBnBlocksMax partials
-    int64_t rpb = 32;
+    // about sixteen chunks, at least 32 rows each: few enough partials that the second pass (every workgroup adds them
+    // up again, one after the other) stays short, enough workgroups that the moment pass is not two workgroups walking
+    // 256 rows each (75 us on a 440-node batch); with 32-row chunks throughout, a 3200-node batch had 100 partials and
+    // the second pass went from 10 to 25 us
+    int64_t rpb = (n + 15) / 16;
+    if (rpb < 32) rpb = 32;
     int64_t blocks = (n + rpb - 1) / rpb;
     if (blocks > kBnBlocksMax) {
         rpb = (n + kBnBlocksMax - 1) / kBnBlocksMax;

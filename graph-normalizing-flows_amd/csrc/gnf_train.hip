@@ -1209,7 +1209,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(float* __restrict__ y, int
 
 static int launch_bn_backward(const GnfFlow* flow, const GnfBatchNorm* bn, const GnfBatchNorm* gbn, float* y, int64_t ld,
                               float* gy, int64_t ldg, int64_t n, int32_t H, double* part, hipStream_t st) {
-    int64_t rpb = 32;   // moment pass: 32-row chunks while that stays under kBnBlocksMax partials, larger beyond
+    int64_t rpb = (n + 15) / 16;  // about sixteen chunks of at least 32 rows (see bn_blocks in gnf_bn.hip)
+    if (rpb < 32) rpb = 32;
     int64_t blocks = (n + rpb - 1) / rpb;
     if (blocks > kBnBlocksMax) {
         rpb = (n + kBnBlocksMax - 1) / kBnBlocksMax;
