@@ -264,6 +264,13 @@ def test_device_csr_build_is_bit_exact(community_medium, grid_small):
     perm = np.random.default_rng(9).permutation(len(ring_s))
     cases.append((np.array([m], np.int32), np.array([len(ring_s)], np.int32),
                   ring_s[perm].astype(np.int32), ring_r[perm].astype(np.int32)))
+    # rows longer than a wave (rank pass in several strides) with the edge list shuffled and 300 duplicated edges
+    s5, r5, _ = senders_receivers(np.array([90], np.int32))
+    dup = np.random.default_rng(4).integers(0, len(s5), size=300)
+    s5, r5 = np.concatenate([s5, s5[dup]]), np.concatenate([r5, r5[dup]])
+    perm5 = np.random.default_rng(5).permutation(len(s5))
+    cases.append((np.array([90], np.int32), np.array([len(s5)], np.int32), s5[perm5].astype(np.int32),
+                  r5[perm5].astype(np.int32)))
     for nn, ne, s, r in cases:
         n = int(nn.sum())
         g = graph_from_arrays(nn, ne, s, r, np.zeros((n, 2), np.float32), DEV)
