@@ -219,6 +219,9 @@ __global__ __launch_bounds__(kBwdThreads) void k_half_bwd_fused(const BwdArgs a)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 float* dump = reinterpret_cast<float*>(ptr_of(row, 12 + 2 * q));
+#ifdef GNF_ABL_NODUMP  // timing ablation only (wrong gradients): what the dW operand dumps cost
+                dump = nullptr;
+#endif
                 if (dump == nullptr) continue;
                 const float* src = buf(q, pp);
                 if (((width | (int)dld) & 3) == 0 && (reinterpret_cast<uintptr_t>(dump) & 15) == 0) {
