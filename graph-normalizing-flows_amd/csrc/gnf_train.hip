@@ -583,6 +583,13 @@ struct WideGemm {
     int32_t kchunk[kMaxGroup];         // rows per chunk, a multiple of WGK
     int64_t K;
     int32_t njobs;
+    // stream-K over the costliest jobs (sk_q > 0): their tiles x k-steps form ONE axis of sk_tiles * sk_steps steps, cut
+    // into equal runs of sk_q steps, one run per workgroup (a run may end one tile and begin the next: at most two
+    // items per workgroup since sk_q <= sk_steps).  The pieces of a tile are its slabs, numbered in workgroup order;
+    // chunks[j] = the largest piece count among job j's tiles, and the workgroup holding a tile's piece 0 zero-fills
+    // the slabs that tile does not reach, so the reduce can add chunks[j] slabs everywhere.  Jobs 0 .. sk_jobs-1.
+    int32_t sk_q, sk_steps, sk_tiles, sk_jobs;
+    int32_t sk_light_base;  // first unit of the jobs cut the uniform way (they ride behind, strided)
 };
 
 // One BK = 32 step of a wave's MTW x NTW block of MFMA tiles.  A wave is alone on its SIMD here and issues in order,
@@ -670,20 +677,49 @@ __global__ __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(2,
 #endif
     // a workgroup takes unit blockIdx.x (a chunk of one of the costliest tiles; those are cut equal) and then, strided,
     // its share of the cheap units that follow them in the list
-    for (int u = blockIdx.x; u < g.unit_base[g.njobs]; u += gridDim.x) {
-    int j = 0;
-    while (j + 1 < g.njobs && u >= g.unit_base[j + 1]) ++j;
-    const int lu = u - g.unit_base[j];
-    const int nchunk = g.chunks[j];
-    const int lt = lu / nchunk, chunk = lu - lt * nchunk;
+    for (int it = 0;; ++it) {
+    int j = 0, lt, chunk, zero_from = 0, zero_to = 0;
+    int64_t kbeg, kend;
+    if (g.sk_q > 0 && it < 2) {  // stream-K: this workgroup's run [a, b) of the costliest jobs' step axis
+        const int64_t total = (int64_t)g.sk_tiles * g.sk_steps;
+        const int64_t a = (int64_t)blockIdx.x * g.sk_q, b = a + g.sk_q < total ? a + g.sk_q : total;
+        if (a >= b) continue;
+        const int t0 = (int)(a / g.sk_steps);
+        const int64_t e0 = b < (int64_t)(t0 + 1) * g.sk_steps ? b : (int64_t)(t0 + 1) * g.sk_steps;
+        int t;
+        int64_t s0, s1;
+        if (it == 0) {
+            t = t0, s0 = a - (int64_t)t0 * g.sk_steps, s1 = e0 - (int64_t)t0 * g.sk_steps;
+        } else {
+            if (b <= e0) continue;
+            t = t0 + 1, s0 = 0, s1 = b - e0;
+        }
+        while (j + 1 < g.sk_jobs && t >= g.unit_base[j + 1]) ++j;  // unit_base of these jobs counts TILES
+        lt = t - g.unit_base[j];
+        const int first_w = (int)(((int64_t)t * g.sk_steps) / g.sk_q);
+        const int last_w = (int)((((int64_t)(t + 1) * g.sk_steps) - 1) / g.sk_q);
+        chunk = (int)blockIdx.x - first_w;
+        kbeg = s0 * WGK;
+        kend = s1 * WGK < g.K ? s1 * WGK : g.K;
+        if (chunk == 0) zero_from = last_w - first_w + 1, zero_to = g.chunks[j];
+    } else {
+        const int first = g.sk_q > 0 ? g.sk_light_base : 0;
+        const int u = first + (int)blockIdx.x + (it - (g.sk_q > 0 ? 2 : 0)) * (int)gridDim.x;
+        if (u >= g.unit_base[g.njobs]) break;
+        j = g.sk_q > 0 ? g.sk_jobs : 0;
+        while (j + 1 < g.njobs && u >= g.unit_base[j + 1]) ++j;
+        const int lu = u - g.unit_base[j];
+        const int nchunk = g.chunks[j];
+        lt = lu / nchunk, chunk = lu - lt * nchunk;
+        kbeg = (int64_t)chunk * g.kchunk[j];
+        kend = kbeg + g.kchunk[j] < g.K ? kbeg + g.kchunk[j] : g.K;
+    }
     const int gxj = g.gx[j];
     const int bx = lt % gxj, by = lt / gxj;
     const int M = g.M[j], N = g.N[j];
     const int64_t lda = g.lda[j], ldb = g.ldb[j];
     const GemmJob job = g.job[j];
     const int m0 = by * WGM, n0 = bx * WGN;
-    const int64_t kbeg = (int64_t)chunk * g.kchunk[j];
-    const int64_t kend = kbeg + g.kchunk[j] < g.K ? kbeg + g.kchunk[j] : g.K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, lgrp = lane >> 4;
     // the eight waves tile the 128 x 128 block 4 x 2 (32 x 64 each) - or, when the tile is a thin strip (a layer with
@@ -835,11 +871,32 @@ __global__ __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(2,
             if (lgrp == 0 && 16 * n < wext_n && gc < N) job.aux_out[(int64_t)chunk * N + gc] = v;
         }
     }
+    for (int zs = zero_from; zs < zero_to; ++zs) {  // stream-K: the slabs this tile has no piece for
+        float* __restrict__ Zp = job.C + (int64_t)zs * M * N;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int gc = n0 + wn + 16 * n + lrow;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gr = m0 + wm + 16 * m + 4 * lgrp + r;
+                    if (16 * m < wext_m && 16 * n < wext_n && gr < M && gc < N) Zp[(int64_t)gr * N + gc] = 0.f;
+                }
+            }
+        if (want_cs) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int gc = n0 + wn + 16 * n + lrow;
+                if (lgrp == 0 && 16 * n < wext_n && gc < N) job.aux_out[(int64_t)zs * N + gc] = 0.f;
+            }
+        }
+    }
 #ifdef GNF_DW_TRACE
     __builtin_amdgcn_s_waitcnt(0);
     GNF_DWT(6, tt0);
 #endif
-    }  // units of this workgroup
+    }  // items of this workgroup
 }
 
 // Thin outputs with a long reduction (a 2048 -> 100 layer on a 440-node batch: 16 tiles, 64 k-steps each, 80 us on 16
@@ -1536,6 +1593,38 @@ static int launch_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJo
             est_us = light_own ? heavy_us : heavy_us + light_us / grid;
             if (light_own) grid += light_tiles * c_light;  // an upper bound; the exact count follows below
         }
+        // ---- stream-K for the costliest jobs: equal runs of k-steps across tile boundaries instead of whole chunks ----
+        // (24 tiles on 64 workgroups is 2.67 workgroups per tile: cut in whole chunks that is 2 per tile = 48 busy
+        // workgroups with 43 steps each; as one axis of 24 x 85 steps it is 64 workgroups with 32 steps each)
+        static const bool no_sk = getenv("GNF_DW_NO_STREAMK") != nullptr;  // developer A/B switch
+        const int sk_steps = (int)((p.n + WGK - 1) / WGK);
+        int sk_q = 0, sk_grid = 0, sk_cmax = 0;
+        if (!no_sk && c_heavy > 0 && heavy_tiles > 0 && heavy_tiles <= pol.max_units && sk_steps >= 8) {
+            sk_grid = pol.max_units;
+            const int64_t total_steps = (int64_t)heavy_tiles * sk_steps;
+            sk_q = (int)((total_steps + sk_grid - 1) / sk_grid);
+            if (sk_q < 4) sk_q = 4;
+            sk_grid = (int)((total_steps + sk_q - 1) / sk_q);
+            for (int t = 0; t < heavy_tiles; ++t) {  // pieces of tile t = workgroups whose run touches it
+                const int c = (int)(((int64_t)(t + 1) * sk_steps - 1) / sk_q - ((int64_t)t * sk_steps) / sk_q + 1);
+                sk_cmax = sk_cmax > c ? sk_cmax : c;
+            }
+            const double sk_us = (double)cmax / 16.0 * sk_q * 2.0 + 2 * 4.0 + 2.0;
+            double light_us = 0.0;
+            int cl = light_tiles > 0 ? sk_grid / light_tiles : 1;
+            cl = cl < 1 ? 1 : (cl > p.chunks ? p.chunks : cl);
+            for (int e = 0; e < nj; ++e)
+                if (cost[e] != cmax)
+                    light_us += tiles_of[e] * cl * ((double)cost[e] / 16.0 * (double)p.n / cl / 32.0 * 2.1 + 4.0);
+            const double sk_est = sk_us + light_us / sk_grid;
+            if (sk_q > sk_steps || sk_cmax > p.chunks || sk_est >= est_us) {
+                sk_q = 0;  // not better than whole chunks (or the slabs were not planned for that many pieces)
+            } else {
+                est_us = sk_est;
+                c_light = cl;
+                grid = sk_grid;
+            }
+        }
         if (grid == 0 || est_us > pol.budget_us) wide = false;
         static const bool dbg = getenv("GNF_DW_DEBUG") != nullptr;
         if (dbg) {
@@ -1544,13 +1633,27 @@ static int launch_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJo
                 fprintf(stderr, "[gnf dW] n=%lld max_units=%d heavy_tiles=%d (cost %d/16) light_tiles=%d c_heavy=%d c_light=%d grid=%d "
                         "est %.1f us budget %.1f us lds %zu -> %s\n", (long long)p.n, pol.max_units, heavy_tiles, cmax, light_tiles,
                         c_heavy, c_light, grid, est_us, pol.budget_us, pol.lds, wide ? "wide" : "grouped");
+            if (shown <= 2 && sk_q > 0)
+                fprintf(stderr, "[gnf dW] stream-K: %d steps per tile, runs of %d steps, %d workgroups, up to %d pieces per tile\n",
+                        sk_steps, sk_q, sk_grid, sk_cmax);
         }
+        int sk_jobs = 0;
         for (int q = 0; q < nj && wide; ++q) {
             const int e = order[q];
             wg.job[q] = gg.job[e];
             wg.lda[q] = gg.lda[e], wg.ldb[q] = gg.ldb[e];
             wg.M[q] = gg.M[e], wg.N[q] = gg.N[e];
             wg.gx[q] = (gg.N[e] + WGN - 1) / WGN;
+            if (sk_q > 0 && cost[e] == cmax) {  // stream-K job: unit_base counts its tiles, chunks = slabs to reduce
+                cj[e] = sk_cmax;
+                wg.chunks[q] = sk_cmax;
+                wg.kchunk[q] = (int32_t)((int64_t)sk_q * WGK);
+                max_kchunk = max_kchunk > (int64_t)sk_q * WGK ? max_kchunk : (int64_t)sk_q * WGK;
+                wg.unit_base[q] = units;
+                units += tiles_of[e];
+                sk_jobs = q + 1;
+                continue;
+            }
             int64_t c = cost[e] == cmax ? c_heavy : c_light;
             int64_t kc = (p.n + c - 1) / c;
             kc = (kc + WGK - 1) / WGK * WGK;
@@ -1566,7 +1669,13 @@ static int launch_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJo
             for (int e = 0; e < nj; ++e) gr.chunks[e] = cj[e];
             wg.unit_base[nj] = units;
             wg.K = p.n, wg.njobs = nj;
-            units = grid < units ? grid : units;  // workgroups; units past the grid are picked up by stride
+            if (sk_q > 0) {
+                wg.sk_q = sk_q, wg.sk_steps = sk_steps, wg.sk_tiles = heavy_tiles, wg.sk_jobs = sk_jobs;
+                wg.sk_light_base = wg.unit_base[sk_jobs];
+                units = grid;
+            } else {
+                units = grid < units ? grid : units;  // workgroups; units past the grid are picked up by stride
+            }
         }
     }
     if (wide) {

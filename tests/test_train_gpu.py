@@ -441,13 +441,16 @@ DW_MODES = [
     ({"GNF_DW_WIDE_UNITS": "200"}, "ws"),                         # many node chunks per job + accumulating reduce
     ({"GNF_DW_WIDE_UNITS": "24", "GNF_DW_NO_BUF": "1"}, ""),      # bounds-checked generic tile fetch
     ({"GNF_DW_WIDE_UNITS": "40", "GNF_TRAIN_NO_OVERLAP": "1"}, "ws"),
+    ({"GNF_DW_WIDE_UNITS": "24", "GNF_DW_NO_STREAMK": "1"}, ""),  # whole chunks instead of stream-K runs
+    ({"GNF_DW_WIDE_UNITS": "13"}, "ws"),                          # stream-K with an odd workgroup count
     ({"GNF_BWD_GENERIC": "1"}, ""),                               # generic (GEMM) backward: buffer-descriptor tile fetch
     ({"GNF_BWD_GENERIC": "1", "GNF_GEMM_LDS_DIRECT": "all"}, ""), # ... through the LDS-direct (fragment-order) tile
     ({"GNF_BWD_GENERIC": "1", "GNF_GEMM_NO_BUF": "1"}, "ws"),     # ... through the bounds-checked fetch
 ]
 
 
-@pytest.mark.parametrize("env,arg", DW_MODES, ids=["auto", "grouped", "wide8", "wide200_ws", "wide24_nobuf", "wide40_serial_ws", "generic_bwd",
+@pytest.mark.parametrize("env,arg", DW_MODES, ids=["auto", "grouped", "wide8", "wide200_ws", "wide24_nobuf", "wide40_serial_ws", "wide24_chunks",
+                              "wide13_streamk_ws", "generic_bwd",
                               "generic_bwd_lds_direct", "generic_bwd_nobuf_ws"])
 def test_weight_gradient_kernel_launch_shapes(env, arg):
     """The dW GEMM has several launch shapes chosen per batch; the switches are read once per
