@@ -71,6 +71,27 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 
 PEAK_HBM_GBS = 8000.0
 
 
+def kernel_source_stamp():
+    """sha256 over the kernel sources + the ABI header: what a profile under profiles/ was taken on.  (There is no
+    .git on the GPU box, so the stamp is content-based.)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "graph-normalizing-flows_amd", "csrc")
+    for p in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))) + \
+            [os.path.join(ROOT, "include", "gnf.h")]:
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def percentiles(ms):
+    a = np.sort(np.asarray(ms, np.float64))
+    return {"p50_ms": round(float(np.percentile(a, 50)), 4), "p95_ms": round(float(np.percentile(a, 95)), 4),
+            "mean_ms": round(float(a.mean()), 4), "min_ms": round(float(a[0]), 4), "max_ms": round(float(a[-1]), 4),
+            "iterations": int(a.size)}
+
+
 def algorithmic_half_step(n, e, hp):
     """flops and minimum HBM bytes of ONE fused coupling half-step launch."""
     h, l, k = hp["D"] // 2, hp["latent"], hp["K"]
@@ -154,9 +175,17 @@ def make_batch(n_gpus, rank, seed=12345):
     if WORKLOAD["fc"]:
         pool = D.with_fully_connected_topology(pool)
     nn, ne = pool.n_node[ids], pool.n_edge[ids]
-    mine = ids[shard_graph_ids(nn, ne, n_gpus)[rank]]
-    rng = np.random.default_rng(seed + 1000 + rank)
-    dicts = pool.data_dicts(mine, lambda n: rng.standard_normal((n, HP["D"])).astype(np.float32))
+    mine = shard_graph_ids(nn, ne, n_gpus)[rank]           # positions in the global batch, ascending
+    # node features belong to the GLOBAL batch (drawn in batch order from one stream), so that N ranks hold exactly
+    # the batch one rank would: the all-reduced log-prob of an N-rank run equals a 1-rank run over 64*N graphs
+    rng = np.random.default_rng(seed + 1000)
+    mine_set, feats = set(mine.tolist()), {}
+    for pos, n in enumerate(nn):
+        f = rng.standard_normal((int(n), HP["D"])).astype(np.float32)
+        if pos in mine_set:
+            feats[pos] = f
+    it = iter([feats[p] for p in mine])
+    dicts = pool.data_dicts(ids[mine], lambda n: next(it))
     return dicts, int(nn.sum()), int(ne.sum())
 
 
@@ -190,16 +219,19 @@ def cpu_baseline(dicts, params, budget_s=15.0, min_iters=3, warm=1):
     res = None
     for _ in range(warm):
         res = o.log_prob(x, pt, HP["T"])
-    iters, t0 = 0, time.perf_counter()
+    iters, t0, per_iter = 0, time.perf_counter(), []
     while True:
+        t1 = time.perf_counter()
         res = o.log_prob(x, pt, HP["T"])
         iters += 1
         dt = time.perf_counter() - t0
+        per_iter.append(1e3 * (time.perf_counter() - t1))
         if iters >= min_iters and (dt >= budget_s or iters >= 200):
             break
     torch.set_num_threads(max_thr)
+    pc = percentiles(per_iter)
     return {"value": n * HP["T"] * iters / dt, "unit": "node-updates/s", "cores": best_thr,
-            "kind": "port", "ms_per_step": 1e3 * dt / iters,
+            "kind": "port", "ms_per_step": 1e3 * dt / iters, "p50_ms": pc["p50_ms"], "p95_ms": pc["p95_ms"],
             "sample": f"{iters} forwards of the same rank-0 batch (N={n} nodes, T={HP['T']}) in {dt:.1f}s, "
                       f"torch-CPU fp32 restatement of gnn.py in reference op order; thread sweep "
                       f"[{' '.join(sweep)}] -> {best_thr} threads; os.cpu_count()={os.cpu_count()}"}, res
@@ -218,12 +250,15 @@ def main():
     ap.add_argument("--sync-each-step", action="store_true", help="latency mode: host waits for every step's scalar")
     ap.add_argument("--kernel-timing-steps", type=int, default=10)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="config2")
+    ap.add_argument("--graphs-per-gpu", type=int, default=0,
+                    help="override the workload's graphs per rank (tests: one rank over the batch that N ranks shard)")
+    ap.add_argument("--latency-steps", type=int, default=200, help="iterations of the p50/p95 leg (0: skip)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + GNF_BENCH_ONE_DEVICE=1 runs several ranks on ONE GPU to exercise the N>1 logic")
     args = ap.parse_args()
     global WORKLOAD, GRAPHS_PER_GPU
     WORKLOAD = WORKLOADS[args.workload]
-    GRAPHS_PER_GPU = WORKLOAD["graphs"]
+    GRAPHS_PER_GPU = args.graphs_per_gpu or WORKLOAD["graphs"]
     HP.update(WORKLOAD["hp"])
     inverse = WORKLOAD["inverse"]
 
@@ -366,11 +401,27 @@ def main():
     if not inverse and world == 1 and trainer is None and not args.no_secondary:
         from gnf_amd.graphs import clear_csr_cache
         fields = ("nodes", "senders", "receivers", "n_node", "n_edge")
-        pinned = {f: getattr(graph, f).cpu().pin_memory() for f in fields}
+        # ONE packed pinned staging buffer and ONE device landing buffer, both allocated once: a batch is one
+        # host-to-device copy (the five separate small copies + per-step allocations of the first version made this
+        # figure vary by 4x between boxes); the GraphsTuple fields are typed views into the landing buffer
+        parts, off = {}, 0
+        for f in fields:
+            t = getattr(graph, f)
+            nb = t.numel() * t.element_size()
+            parts[f] = (off, nb, t.dtype, tuple(t.shape))
+            off += (nb + 255) // 256 * 256
+        stage = torch.empty(off, dtype=torch.uint8).pin_memory()
+        land = torch.empty(off, dtype=torch.uint8, device=dev)
+        for f in fields:
+            o_, nb, _, _ = parts[f]
+            stage[o_:o_ + nb].copy_(getattr(graph, f).cpu().contiguous().view(torch.uint8).reshape(-1))
+        views = {f: land[o_:o_ + nb].view(dt).reshape(shape) for f, (o_, nb, dt, shape) in parts.items()}
+        g2 = graph._replace(**views)
         nfed = max(10, min(50, args.steps))
 
         def fed_step(i):
-            g2 = graph._replace(**{f: pinned[f].to(dev, non_blocking=True) for f in fields})
+            land.copy_(stage, non_blocking=True)
+            clear_csr_cache()                      # the topology is "new": rebuild the CSR on device
             _, s3 = forward_shard_sums(net, g2, sums3)
             host[i].copy_(s3, non_blocking=True)
         for i in range(3):
@@ -382,10 +433,10 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
         clear_csr_cache()
-        up = sum(int(v.numel()) * v.element_size() for v in pinned.values())
+        up = sum(nb for (_, nb, _, _) in parts.values())
         host_fed = {"ms_per_step": round(1e3 * dt / nfed, 4), "value": round(n_global * HP["T"] * nfed / dt, 1),
                     "uploaded_bytes_per_step": up,
-                    "note": "GraphsTuple fields in pinned host memory each step: upload + gnf_build_csr + forward"}
+                    "note": "GraphsTuple fields packed in ONE pinned host buffer each step: one upload + gnf_build_csr + forward"}
 
     # ---- secondary figure: independent forwards on TWO HIP streams.  A 64-graph batch fills 170 of the 256 CUs
     # (one 16-node tile per CU); evaluation of many batches (the steps here are independent of each
@@ -419,6 +470,73 @@ def main():
         two_streams = {"ms_per_step": round(1e3 * dt / args.steps, 4), "value": round(n_global * HP["T"] * args.steps / dt, 1),
                        "results_identical_to_single_stream": same,
                        "note": "same forwards, two batches in flight on two HIP streams (throughput mode)"}
+
+    # ---- steady-state p50 / p95 per step, "inputs in memory -> scalar log-prob on the host":
+    # every iteration is closed by a stream synchronise (latency mode), >= 10 warm-ups, args.latency_steps iterations
+    latency = None
+    if not inverse and world == 1 and trainer is None and args.latency_steps > 0:
+        cur = torch.cuda.current_stream()
+        for i in range(10):
+            step(args.warmup)
+            cur.synchronize()
+        lat = []
+        for i in range(args.latency_steps):
+            t1 = time.perf_counter()
+            step(args.warmup)
+            cur.synchronize()
+            lat.append(1e3 * (time.perf_counter() - t1))
+        latency = dict(percentiles(lat), mode="one batch at a time, host waits for each step's scalars (sync per step)")
+
+    # ---- the same step replayed from a captured HIP graph (one hipGraphLaunch per step instead of ~20 launches):
+    # removes the host's launch work from the loop; the device-side kernel boundaries stay
+    graph_replay = None
+    if not inverse and world == 1 and trainer is None and not args.no_secondary:
+        gs3 = torch.zeros(3, dtype=torch.float64, device=dev)
+        gs3[2] = float(n_local)
+        ghost = torch.zeros(1, 3, dtype=torch.float64).pin_memory()
+        torch.cuda.synchronize()
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            forward_shard_sums(net, graph, gs3)
+            ghost[0].copy_(gs3, non_blocking=True)
+        for _ in range(5):
+            cg.replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            cg.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        same = abs(log_prob_from_sums(ghost[0].tolist(), HP["D"])["log_prob_xs_per_node"] - last["log_prob_xs_per_node"]) == 0.0
+        graph_replay = {"ms_per_step": round(1e3 * dt / args.steps, 4), "value": round(n_global * HP["T"] * args.steps / dt, 1),
+                        "results_identical_to_eager": bool(same),
+                        "note": "torch.cuda.graph capture of gnf_grevnet_f32 + the pinned-host copy, replayed per step"}
+        del cg
+
+    # ---- BASELINE.md section 4, config 2 secondary: the same batch topology at D = 100 (run_gnn.py:111; H = 50 is not
+    # a multiple of 16: padded fragments)
+    d100 = None
+    if args.workload == "config2" and world == 1 and not args.no_secondary and not args.layered:
+        hp100 = dict(HP, D=100)
+        rng100 = np.random.default_rng(77)
+        g100 = graph.replace(nodes=torch.as_tensor(rng100.standard_normal((n_local, 100)).astype(np.float32)).to(dev))
+        net100 = make_product_grevnet(hp100, make_params(WEIGHT_SEED, hp100, FINAL_SCALE))
+        s100 = torch.zeros(3, dtype=torch.float64, device=dev)
+        for _ in range(5):
+            forward_shard_sums(net100, g100, s100)
+        torch.cuda.synchronize()
+        n100 = max(20, min(100, args.steps))
+        t1 = time.perf_counter()
+        for _ in range(n100):
+            forward_shard_sums(net100, g100, s100)
+            host[0].copy_(s100, non_blocking=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        f100, _ = algorithmic_half_step(n_local, e_local, hp100)
+        d100 = {"ms_per_step": round(1e3 * dt / n100, 4), "value": round(n_global * HP["T"] * n100 / dt, 1),
+                "frac_of_fp32_matrix_peak_end_to_end": round(f100 * 2 * HP["T"] / (dt / n100) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
+                "note": "D=100 (H=50): same graphs, weights seed 99; unpadded algorithmic flops"}
+        del net100, g100
 
     # ---- dominant-kernel timing with HIP events on the launch stream (one event pair per launch) ----
     import ctypes as C
@@ -477,19 +595,26 @@ def main():
 
     flops, abytes = algorithmic_half_step(n_local, e_local, HP)
     # HBM-side bytes per launch come from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
-    # correction + WRITE_SIZE; tools/profile_r1.sh + tools/summarize_profile.py): PMC counters cannot be
+    # correction + WRITE_SIZE; tools/profile.sh + tools/summarize_profile.py): PMC counters cannot be
     # collected from inside this process.  Only quoted for the workload they were measured on.
-    traffic = None
+    traffic, traffic_note = None, "no PMC pass recorded for this workload"
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if args.workload == "config2" and net.fused and "k_half_fused" in pm.get("kernel", ""):
-            traffic = round(pm["traffic_bytes_per_launch"])
+        if args.workload == "config2" and net.fused:
+            if pm.get("source_stamp") == kernel_source_stamp():
+                traffic = round(pm["traffic_bytes_per_launch"])
+                traffic_note = (f"HBM-side bytes per launch of {pm.get('kernel')} from profiles/pmc_traffic.json "
+                                f"(rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE passes, tag {pm.get('tag')}, "
+                                f"kernel sources {pm.get('source_stamp')} = this build)")
+            else:
+                traffic_note = (f"profiles/pmc_traffic.json was taken on kernel sources {pm.get('source_stamp')}, this build is "
+                                f"{kernel_source_stamp()}: not quoted (re-run tools/profile.sh)")
     except (OSError, ValueError, KeyError):
         pass
     achieved_tflops = flops / (kernel_us * 1e-6) / 1e12
     roofline = {"bound": "mfma", "achieved": round(achieved_tflops, 3), "peak": PEAK_FP32_MATRIX_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "HBM-side bytes per launch from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
+                "traffic_note": traffic_note,
                 "kernel": ("one coupling half-step = k_half_fused (+ k_coupling when one net per workgroup), HIP events "
                            "around the 2T back-to-back launches / 2T") if net.fused else
                           "layered half-step (aggregate + 2K x k_linear + k_coupling)",
@@ -514,6 +639,10 @@ def main():
                    "csr": f"built on device once per batch before the timed region (gnf_build_csr: {csr_ms:.3f} ms wall incl. host launch), cached",
                    "host_sync": "every step" if args.sync_each_step else "results copied to pinned host memory each step; one sync at end"},
         "log_prob_xs_per_node": last["log_prob_xs_per_node"],
+        "steps_landed_on_host": int((host[args.warmup:args.warmup + args.steps, 2] != 0).sum()) if trainer is None and not inverse else None,
+        "latency": latency,
+        "graph_replay": graph_replay,
+        "secondary_D100": d100,
         "with_csr_rebuild_each_step": rebuild,
         "two_streams": two_streams,
         "host_fed": host_fed,

@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 from gnf_amd import gnn                                              # noqa: E402
 from gnf_amd.flow import sample                                      # noqa: E402
 from gnf_amd.grevnet_synthetic_data import DATASETS_MAP              # noqa: E402
-from gnf_amd.train import GRevNetTrainer, get_learning_rate          # noqa: E402
+from gnf_amd.train import GRevNetTrainer                             # noqa: E402
 
 
 def main():
@@ -91,8 +91,10 @@ def main():
     t0 = time.perf_counter()
     for iteration in range(F.num_train_iters + 1):
         graph = dataset.get_next_batch(F.train_batch_size, dev)
-        lr = (get_learning_rate(iteration, F.lr, F.lr_schedule_ramp_up, F.lr_schedule_hold)
-              if F.use_lr_schedule else None)
+        lr = None
+        if F.use_lr_schedule:   # --use_lr_schedule (utils.py:93-105): warm-up to --lr, plateau, then --lr / sqrt(steps past it)
+            past = iteration - F.lr_schedule_hold
+            lr = F.lr * (min(1.0, iteration / F.lr_schedule_ramp_up) if past <= 0 else past ** -0.5)
         v = trainer.step(graph, learning_rate=lr)
         if iteration % F.log_every_n_steps == 0:
             z = v["z_graph"].nodes

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 GNF_MAX_LAYERS = 8
-GNF_ABI_VERSION = 5
+GNF_ABI_VERSION = 6
 
 GNF_AGG_SUM, GNF_AGG_MEAN = 0, 1
 GNF_COMBINE_EPS, GNF_COMBINE_CONCAT = 0, 1
@@ -67,6 +67,8 @@ class GnfFlow(C.Structure):
 
 _SIGNATURES = {
     "gnf_abi_version": (C.c_int, []),
+    "gnf_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
+    "gnf_get_option": (C.c_int64, [C.c_char_p]),
     "gnf_attn_stash_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.POINTER(GnfFlow)]),
     "gnf_last_error": (C.c_char_p, []),
     "gnf_packed_floats": (C.c_int64, [C.POINTER(GnfMlp)]),
@@ -125,7 +127,21 @@ def lib():
         if handle.gnf_abi_version() != GNF_ABI_VERSION:
             raise GnfError(f"libgnf_hip.so ABI {handle.gnf_abi_version()} != binding {GNF_ABI_VERSION}")
         _lib = handle
+        # developer convenience of THIS binding (the library itself never reads the environment):
+        # GNF_OPTIONS="dw_grouped=1,force_shape=21" -> gnf_set_option calls, for tools/ and the launch-shape tests
+        for item in filter(None, os.environ.get("GNF_OPTIONS", "").split(",")):
+            name, _, val = item.partition("=")
+            set_option(name.strip(), int(val or 1))
     return _lib
+
+
+def set_option(name, value):
+    """gnf_set_option: process-wide developer option of the library (0 = automatic)."""
+    check(lib().gnf_set_option(name.encode(), int(value)), f"gnf_set_option({name})")
+
+
+def get_option(name):
+    return int(lib().gnf_get_option(name.encode()))
 
 
 def check(rc, what):

@@ -11,6 +11,20 @@ namespace gnf {
 
 static thread_local char g_err[512] = "";
 
+std::atomic<int64_t> g_options[OPT_COUNT];  // zero-initialised: every option "auto"
+
+static const char* const kOptionNames[OPT_COUNT] = {
+    "force_shape",     "whole_flow",     "attn_edge_tiled",  "attn_rows",    "attn_lane_feature", "gemm_no_buf",
+    "gemm_lds_direct", "gemm_no_splitk", "layered_own_gemm", "dw_grouped",   "dw_wide_units",     "dw_wide_lds",
+    "dw_no_streamk",   "dw_no_buf",      "dw_debug",         "dw_late_fork", "bwd_generic"};
+
+static int option_index(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!strcmp(name, kOptionNames[i])) return i;
+    return -1;
+}
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -183,6 +197,25 @@ using namespace gnf;
 extern "C" {
 
 int gnf_abi_version(void) { return GNF_ABI_VERSION; }
+
+int gnf_set_option(const char* name, int64_t value) {
+    const int i = option_index(name);
+    if (i < 0) {
+        set_error("gnf_set_option: unknown option '%s'", name ? name : "(null)");
+        return GNF_EINVAL;
+    }
+    g_options[i].store(value, std::memory_order_relaxed);
+    return GNF_OK;
+}
+
+int64_t gnf_get_option(const char* name) {
+    const int i = option_index(name);
+    if (i < 0) {
+        set_error("gnf_get_option: unknown option '%s'", name ? name : "(null)");
+        return GNF_EINVAL;
+    }
+    return g_options[i].load(std::memory_order_relaxed);
+}
 
 size_t gnf_attn_stash_bytes(int64_t n_nodes, int32_t D, const GnfFlow* flow) {
     if (n_nodes <= 0 || D < 2 || !flow || !flow->s_nets || flow->num_timesteps <= 0) return 0;

@@ -573,14 +573,11 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
         set_error("attention projection needs %zu bytes of LDS (H=%d x %zu projected columns): unsupported", proj_lds, H, P);
         return GNF_EUNSUPPORTED;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    GNF_ONCE_PER_DEVICE(
         GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_proj<0, 0, 0>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_proj<8, 10, 10>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
     const bool ref_default = a.nh == 8 && a.kq == 10 && a.v == 10;  // run_grevnet.py:74-76
     const dim3 pgrid((unsigned)((n + kProjRows - 1) / kProjRows), nets);
     if (ref_default)
@@ -588,8 +585,8 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
     else
         hipLaunchKernelGGL((k_attn_proj<0, 0, 0>), pgrid, dim3(256), proj_lds, st, a);
     GNF_LAUNCH_CHECK("k_attn_proj");
-    static const bool old_attn = getenv("GNF_ATTN_EDGE_TILED") != nullptr;  // developer A/B switches
-    static const bool rows_always = getenv("GNF_ATTN_ROWS") != nullptr;
+    const bool old_attn = opt(OPT_ATTN_EDGE_TILED) != 0;  // developer A/B switches (gnf_set_option)
+    const bool rows_always = opt(OPT_ATTN_ROWS) != 0;
     // sparse batches (mean in-degree under ~24: the config-2 batch has 12) are 8 % faster through the edge-tiled kernel;
     // the rows kernel wins by 4.5 x on the complete graphs of the drivers' default dataset (degree 100)
     const bool sparse = !rows_always && n_edges > 0 && n_edges < 24 * n;
@@ -599,14 +596,11 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
                              ((size_t)NV * a.C + (size_t)kRowsTile * (NV + 1)) * sizeof(float);
         if (fixed + 64 * (size_t)(nq + a.v + 2) * sizeof(float) <= (size_t)kRowsLdsBudget) {
             const int cap = (int)((kRowsLdsBudget - fixed) / ((size_t)(nq + a.v + 2) * sizeof(float)));
-            static bool attr_set3 = false;
-            if (!attr_set3) {
+            GNF_ONCE_PER_DEVICE(
                 GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_fwd_rows<10, 10>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_fwd_rows<32, 32>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_set3 = true;
-            }
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
             const dim3 rgrid((unsigned)((n + kRowsTile - 1) / kRowsTile), nets);
             if (a.kq <= 10 && a.v <= 10)
                 hipLaunchKernelGGL((k_attn_fwd_rows<10, 10>), rgrid, dim3(512), (size_t)kRowsLdsBudget, st, a, cap);
@@ -629,14 +623,11 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
         set_error("attention tile needs %zu bytes of LDS: unsupported head configuration", agg_lds);
         return GNF_EUNSUPPORTED;
     }
-    static bool attr_set2 = false;
-    if (!attr_set2) {
+    GNF_ONCE_PER_DEVICE(
         GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_agg<0, 0, 0, 0>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_agg<8, 10, 10, 80>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set2 = true;
-    }
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
     const dim3 agrid((unsigned)((n + RB - 1) / RB), nets);
     if (ref_default && a.C == 80)  // + attn_concat_heads_output_dim = 80 (run_grevnet.py:77)
         hipLaunchKernelGGL((k_attn_agg<8, 10, 10, 80>), agrid, dim3(threads), agg_lds, st, a, RB);

@@ -781,32 +781,26 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
         set_error("attention backward: head geometry needs more LDS than a CU has");
         return GNF_EUNSUPPORTED;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    GNF_ONCE_PER_DEVICE(
         GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dx),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         const void* ks[6] = {reinterpret_cast<const void*>(k_attn_bwd_recv<1>), reinterpret_cast<const void*>(k_attn_bwd_recv<2>),
                              reinterpret_cast<const void*>(k_attn_bwd_recv<4>), reinterpret_cast<const void*>(k_attn_bwd_send<1>),
                              reinterpret_cast<const void*>(k_attn_bwd_send<2>), reinterpret_cast<const void*>(k_attn_bwd_send<4>)};
-        for (const void* k : ks) GNF_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
-    static const bool lane_feature = getenv("GNF_ATTN_LANE_FEATURE") != nullptr;  // developer A/B switch
+        for (const void* k : ks) GNF_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+    const bool lane_feature = opt(OPT_ATTN_LANE_FEATURE) != 0;  // developer A/B switch (gnf_set_option)
     if (!lane_feature && a.nh <= kRowsMaxHeads && a.kq <= 32 && a.v <= 32) {
         const size_t fixed_r = (size_t)(kRowsTile + 1 + 3 + kRowsColCap) * sizeof(int);
         const int capr = (int)((kRowsLdsBudget - fixed_r) / ((size_t)(nq + a.v + 2) * sizeof(float)));
         const int caps = (int)((kRowsLdsBudget - fixed_r) / ((size_t)(nq + NV + 2) * sizeof(float)));
         // the sender pass re-uses the window region for its head reduction: 8 x 64 x VDM floats must fit
         if (capr >= 64 && (size_t)caps * (nq + NV) >= (size_t)8 * 64 * 32) {
-            static bool attr_set2 = false;
-            if (!attr_set2) {
+            GNF_ONCE_PER_DEVICE(
                 const void* ks[4] = {reinterpret_cast<const void*>(k_attn_bwd_recv_rows<10, 10>),
                                      reinterpret_cast<const void*>(k_attn_bwd_recv_rows<32, 32>),
                                      reinterpret_cast<const void*>(k_attn_bwd_send_rows<10, 10>),
                                      reinterpret_cast<const void*>(k_attn_bwd_send_rows<32, 32>)};
-                for (const void* k : ks) GNF_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_set2 = true;
-            }
+                for (const void* k : ks) GNF_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
             const dim3 rgrid((unsigned)((n + kRowsTile - 1) / kRowsTile), 2);
             if (a.kq <= 10 && a.v <= 10) {
                 hipLaunchKernelGGL((k_attn_bwd_recv_rows<10, 10>), rgrid, dim3(512), (size_t)kRowsLdsBudget, st, a, capr);

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "gnf.h"
+#include "gnf_options.h"
 
 namespace gnf {
 

@@ -224,12 +224,8 @@ int gnf_build_csr(const int32_t* senders, const int32_t* receivers, const int32_
     hipLaunchKernelGGL(k_rowptr_scan, dim3(1), dim3(kCsrBlock), 0, st, deg, rowptr, n_nodes);
     GNF_LAUNCH_CHECK("k_rowptr_scan");
     if (n_graphs > 0 && n_edges > 0) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_csr_fill),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFillLds));
-            attr_set = true;
-        }
+        GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_csr_fill),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFillLds)));
         hipLaunchKernelGGL(k_csr_fill, dim3((unsigned)n_graphs), dim3(kCsrBlock), kFillLds, st, senders,
                            receivers, node_off, edge_off, rowptr, col);
         GNF_LAUNCH_CHECK("k_csr_fill");

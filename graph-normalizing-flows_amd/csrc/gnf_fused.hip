@@ -463,7 +463,7 @@ bool fused_supported(const HalfStep& hs) {
 //                                one 16-node tile per CU
 //   (*,1) one net per workgroup + k_coupling: never faster at these widths, but its LDS footprint is
 //         half, which keeps layers up to 1024 wide on the fused path.
-// GNF_FORCE_SHAPE=<MT><NETS> (e.g. 21) is a developer override for A/B runs.
+// gnf_set_option("force_shape", <MT><NETS>) (e.g. 21) is a developer override for A/B runs.
 static void choose_shape(const HalfStep& hs, int* mt, int* nets) {
     const GnfMlp* s = hs.s_net;
     const int64_t tiles16 = (hs.n_nodes + 15) / 16;
@@ -476,9 +476,8 @@ static void choose_shape(const HalfStep& hs, int* mt, int* nets) {
     } else if (tiles16 > 256 && fits(2, 1)) {
         m = 2, n = 1;
     }
-    static const char* force = getenv("GNF_FORCE_SHAPE");
-    if (force && force[0] && force[1]) {
-        const int fm = force[0] - '0', fn = force[1] - '0';
+    if (const int64_t force = opt(OPT_FORCE_SHAPE)) {
+        const int fm = (int)(force / 10), fn = (int)(force % 10);
         if ((fm == 1 || fm == 2) && (fn == 1 || fn == 2) && fits(fm, fn)) m = fm, n = fn;
     }
     *mt = m;
@@ -487,12 +486,8 @@ static void choose_shape(const HalfStep& hs, int* mt, int* nets) {
 
 template <int MT, int NETS>
 static int launch_shape(const FusedArgs& a, unsigned grid, size_t lds, hipStream_t st) {
-    static bool attr_set = false;  // one process per GPU: a single device per process
-    if (!attr_set) {
-        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_fused<MT, NETS>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
-        attr_set = true;
-    }
+    GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_fused<MT, NETS>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit)));
     hipLaunchKernelGGL((k_half_fused<MT, NETS>), dim3(grid), dim3(kFusedThreads), lds, st, a);
     GNF_LAUNCH_CHECK("k_half_fused");
     return GNF_OK;

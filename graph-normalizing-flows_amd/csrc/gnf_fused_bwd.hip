@@ -415,14 +415,11 @@ int launch_half_bwd_fused(const int32_t* rowptr, const int32_t* col, int64_t n, 
     const int MT = ((n + 15) / 16 > 256 && bwd_lds_bytes(s, 2) <= (size_t)kBwdLdsLimit) ? 2 : 1;
     const int64_t tiles = (n + 16 * MT - 1) / (16 * MT);
     a.n_tiles = (int32_t)tiles;
-    static bool attr_set = false;
-    if (!attr_set) {
+    GNF_ONCE_PER_DEVICE(
         GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_bwd_fused<1>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLdsLimit));
         GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_bwd_fused<2>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLdsLimit));
-        attr_set = true;
-    }
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLdsLimit)));
     if (MT == 2)
         hipLaunchKernelGGL(k_half_bwd_fused<2>, dim3((unsigned)tiles), dim3(kBwdThreads), bwd_lds_bytes(s, 2), st, a);
     else

@@ -1,0 +1,53 @@
+// Process-wide developer options of libgnf_hip.so and the per-device one-time setup helper.
+//
+// The library never reads the environment.  Everything that used to be an A/B environment switch is a named
+// integer here, 0 (= "let the library decide") unless gnf_set_option() changed it; the launch paths read the
+// table with relaxed atomic loads, so changing an option between two calls is well defined.  The table and the
+// per-device "dynamic LDS attribute already raised" bitmaps below are the only state the library keeps.
+#pragma once
+#include <atomic>
+#include <stdint.h>
+
+#include <hip/hip_runtime.h>
+
+namespace gnf {
+
+enum OptionId {
+    OPT_FORCE_SHAPE = 0,     // fused forward workgroup shape <MT><NETS>, e.g. 21; 0 = by batch size
+    OPT_WHOLE_FLOW,          // 0 auto (persistent whole-flow kernel when the batch fits one tile per CU), 1 never, 2 always when legal
+    OPT_ATTN_EDGE_TILED,     // attention forward: always the edge-tiled kernel
+    OPT_ATTN_ROWS,           // attention forward: always the rows kernel
+    OPT_ATTN_LANE_FEATURE,   // attention backward: lane-per-feature kernels instead of the rows kernels
+    OPT_GEMM_NO_BUF,         // generic GEMM: bounds-checked fetch instead of buffer descriptors
+    OPT_GEMM_LDS_DIRECT,     // generic GEMM: LDS-direct tile (measured slower; parity-tested)
+    OPT_GEMM_NO_SPLITK,      // generic GEMM: never split thin launches over the reduction
+    OPT_LAYERED_OWN_GEMM,    // layered forward: k_linear_mfma instead of the shared GEMM tile
+    OPT_DW_GROUPED,          // weight gradients: always the grouped kernel
+    OPT_DW_WIDE_UNITS,       // weight gradients: wide kernel with this many workgroups
+    OPT_DW_WIDE_LDS,         // ... and this LDS request per workgroup (bytes)
+    OPT_DW_NO_STREAMK,       // ... whole chunks instead of stream-K runs
+    OPT_DW_NO_BUF,           // ... bounds-checked fetch
+    OPT_DW_DEBUG,            // print the dW launch plan to stderr (first two launches)
+    OPT_DW_LATE_FORK,        // fork the dW stream behind the dL/dx scatter
+    OPT_BWD_GENERIC,         // backward pass through the generic GEMM path even where the fused kernel fits
+    OPT_COUNT
+};
+
+extern std::atomic<int64_t> g_options[OPT_COUNT];
+inline int64_t opt(OptionId id) { return g_options[id].load(std::memory_order_relaxed); }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only: BODY runs once per device
+// (a lost race runs it twice, which is harmless), keyed by the call site.
+#define GNF_ONCE_PER_DEVICE(...)                                                     \
+    do {                                                                               \
+        static std::atomic<uint64_t> once_mask_{0};                                    \
+        int once_dev_ = 0;                                                             \
+        (void)hipGetDevice(&once_dev_);                                                \
+        const uint64_t once_bit_ = 1ull << (once_dev_ & 63);                           \
+        if (!(once_mask_.load(std::memory_order_acquire) & once_bit_)) {               \
+            __VA_ARGS__;                                                               \
+            once_mask_.fetch_or(once_bit_, std::memory_order_release);                 \
+        }                                                                              \
+    } while (0)
+
+}  // namespace gnf

@@ -507,10 +507,9 @@ __global__ __launch_bounds__(kGemmThreads) void k_gemm(GemmJob j0, GemmJob j1, G
 }
 
 // may the operands of a GEMM go through the buffer path? (32-bit byte offsets; a KC operand's reduction length in whole
-// float4s; GNF_GEMM_NO_BUF: developer A/B switch)
+// float4s; gemm_no_buf: developer A/B option)
 static bool gemm_buf_ok(int ak, int bk, int64_t a_rows, int64_t lda, int64_t b_rows, int64_t ldb, int64_t K) {
-    static const bool off = getenv("GNF_GEMM_NO_BUF") != nullptr;
-    if (off) return false;
+    if (opt(OPT_GEMM_NO_BUF)) return false;
     if ((a_rows + 256) * lda * 4 >= ((int64_t)1 << 31) || (b_rows + 256) * ldb * 4 >= ((int64_t)1 << 31)) return false;
     if ((ak == OPND_KC || bk == OPND_KC) && K % 4 != 0) return false;
     return true;
@@ -929,26 +928,21 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(GemmJob j0, GemmJob j1,
 
 template <int AK, int BK, int EPI>
 static int launch_k_gemm_ld(dim3 grid, hipStream_t st, const GemmJob& j0, const GemmJob& j1, const GemmShape& sh) {
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_ld<AK, BK, EPI>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdLdsBytes));
-        attr_set = true;
-    }
+    GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_ld<AK, BK, EPI>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdLdsBytes)));
     hipLaunchKernelGGL((k_gemm_ld<AK, BK, EPI>), grid, dim3(kGemmThreads), kLdLdsBytes, st, j0, j1, sh);
     GNF_LAUNCH_CHECK("k_gemm_ld");
     return GNF_OK;
 }
-// Measured (MI355X, end of round 1) and therefore OFF unless GNF_GEMM_LDS_DIRECT=all: the LDS-direct tile does what it
+// Measured (MI355X, end of round 1) and therefore OFF unless gnf_set_option("gemm_lds_direct", 1): the LDS-direct tile does what it
 // was built for - the wait for a tile's loads drops from ~1050 to ~100 cycles per k-step - but ISSUING the loads then
 // takes 1600 cycles per step: the texture-address unit is the bottleneck either way (720 cycles for three dwordx4
 // loads on the register path), and an MC operand needs four dword loads per block (a fragment's four k-slices sit in
 // four rows), twice the instructions.  wide_fc 10.4 -> 10.8 ms, the 2048-wide trainer 12.0 -> 13.0 ms per iteration;
 // KC x KC alone (the dX GEMM, all dwordx4) is a wash (47 vs 50 us).  Next: a swizzled dwordx4 layout for MC operands.
 static bool gemm_ld_on(int ak, int bk) {
-    static const char* env = getenv("GNF_GEMM_LDS_DIRECT");  // developer A/B switch: "all"
     (void)ak, (void)bk;
-    return env && env[0] == 'a';
+    return opt(OPT_GEMM_LDS_DIRECT) != 0;  // developer A/B option
 }
 
 // sk[q] (nullable): scratch of sk_floats floats for job q's slabs when the launch is thin enough to be split
@@ -958,7 +952,7 @@ static int launch_gemm(const GemmJob* jobs, int nj, const GemmShape& sh, hipStre
     if (sh.M == 0 || sh.N == 0) return GNF_OK;
     {
         const int64_t tiles = (int64_t)((sh.N + TGN - 1) / TGN) * ((sh.M + TGM - 1) / TGM) * nj;
-        static const bool no_split = getenv("GNF_GEMM_NO_SPLITK") != nullptr;  // developer A/B switch
+        const bool no_split = opt(OPT_GEMM_NO_SPLITK) != 0;  // developer A/B option
         if (sk && sk[0] && sk[nj - 1] && !no_split && EPI != EPI_SLAB && sh.chunks == 1 && tiles < 96 && sh.K >= 512) {
             int64_t chunks = 256 / tiles;
             if (chunks > 16) chunks = 16;
@@ -1009,7 +1003,7 @@ int launch_linear_splitk(const float* const* x, int64_t ldx, const float* const*
                          int64_t ldy, int nj, int64_t n, int32_t I, int32_t O, int act, float alpha, int apply_act,
                          float* const* sk, size_t sk_floats, hipStream_t st) {
     if (n == 0) return GNF_OK;
-    static const bool own_kernel = getenv("GNF_LAYERED_OWN_GEMM") != nullptr;  // developer A/B switch: k_linear_mfma
+    const bool own_kernel = opt(OPT_LAYERED_OWN_GEMM) != 0;  // developer A/B option: k_linear_mfma
     if (own_kernel) {
         const int64_t tiles = (int64_t)((O + TGN - 1) / TGN) * ((n + TGM - 1) / TGM) * nj;
         if (tiles >= 96 || I < 512 || !sk || (size_t)2 * n * O > sk_floats) return 1;
@@ -1475,9 +1469,7 @@ struct DwPolicy {
 // dW workgroup - hence the strict cap.  Without enough idle CUs to finish in the backward kernel's time, the grouped
 // kernel's many short workgroups spread the contention evenly instead.
 static DwPolicy dw_policy(const GnfMlp* net, int64_t bwd_tiles, size_t bwd_lds) {
-    static const char* env_g = getenv("GNF_DW_GROUPED");  // developer A/B switches
-    static const char* env_u = getenv("GNF_DW_WIDE_UNITS");
-    static const char* env_l = getenv("GNF_DW_WIDE_LDS");
+    const int64_t env_g = opt(OPT_DW_GROUPED), env_u = opt(OPT_DW_WIDE_UNITS), env_l = opt(OPT_DW_WIDE_LDS);  // developer A/B options
     DwPolicy pol{0, kWideLdsMin, 0.0};
     if (env_g) return pol;
     if (bwd_tiles > 0 && bwd_tiles <= 192 && bwd_lds > 80 * 1024) {
@@ -1494,8 +1486,8 @@ static DwPolicy dw_policy(const GnfMlp* net, int64_t bwd_tiles, size_t bwd_lds) 
         // the alternative (grouped kernel sharing every CU) stretches the backward kernel by ~1.3 x
         pol.budget_us = 1.4 * (2.0 * 2.0 * 16.0 * macs * 2.0) / (614e9 * 0.6) * 1e6 + 10.0;
     }
-    if (env_u) pol.max_units = atoi(env_u), pol.budget_us = 1e30;
-    if (env_l && (size_t)atol(env_l) >= kWideLdsMin) pol.lds = (size_t)atol(env_l);
+    if (env_u > 0) pol.max_units = (int)env_u, pol.budget_us = 1e30;
+    if (env_l > 0 && (size_t)env_l >= kWideLdsMin) pol.lds = (size_t)env_l;
     return pol;
 }
 
@@ -1596,7 +1588,7 @@ static int launch_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJo
         // ---- stream-K for the costliest jobs: equal runs of k-steps across tile boundaries instead of whole chunks ----
         // (24 tiles on 64 workgroups is 2.67 workgroups per tile: cut in whole chunks that is 2 per tile = 48 busy
         // workgroups with 43 steps each; as one axis of 24 x 85 steps it is 64 workgroups with 32 steps each)
-        static const bool no_sk = getenv("GNF_DW_NO_STREAMK") != nullptr;  // developer A/B switch
+        const bool no_sk = opt(OPT_DW_NO_STREAMK) != 0;  // developer A/B option
         const int sk_steps = (int)((p.n + WGK - 1) / WGK);
         int sk_q = 0, sk_grid = 0, sk_cmax = 0;
         if (!no_sk && c_heavy > 0 && heavy_tiles > 0 && heavy_tiles <= pol.max_units && sk_steps >= 8) {
@@ -1626,10 +1618,10 @@ static int launch_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJo
             }
         }
         if (grid == 0 || est_us > pol.budget_us) wide = false;
-        static const bool dbg = getenv("GNF_DW_DEBUG") != nullptr;
-        if (dbg) {
-            static int shown = 0;
-            if (shown++ < 2)
+        if (opt(OPT_DW_DEBUG)) {
+            static std::atomic<int> shown_ctr{0};
+            const int shown = shown_ctr.fetch_add(1) + 1;
+            if (shown <= 2)
                 fprintf(stderr, "[gnf dW] n=%lld max_units=%d heavy_tiles=%d (cost %d/16) light_tiles=%d c_heavy=%d c_light=%d grid=%d "
                         "est %.1f us budget %.1f us lds %zu -> %s\n", (long long)p.n, pol.max_units, heavy_tiles, cmax, light_tiles,
                         c_heavy, c_light, grid, est_us, pol.budget_us, pol.lds, wide ? "wide" : "grouped");
@@ -1679,19 +1671,15 @@ static int launch_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJo
         }
     }
     if (wide) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        GNF_ONCE_PER_DEVICE(
             GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_wide<true>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_wide<false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
         // buffer path: byte offsets inside a chunk (+ the two tiles fetched past its end) stay below 2^31.  Rows need
         // not be 16-byte aligned: buffer_load_dwordx4 only asks for dword alignment (the attention projections have
         // 170-float rows)
-        static const bool no_buf = getenv("GNF_DW_NO_BUF") != nullptr;
-        bool buf = !no_buf;
+        bool buf = opt(OPT_DW_NO_BUF) == 0;
         for (int e = 0; e < nj; ++e)
             buf = buf && (max_kchunk + 4 * WGK) * (jobs[e].lda > jobs[e].ldb ? jobs[e].lda : jobs[e].ldb) * 4 < ((int64_t)1 << 31);
         if (buf)
@@ -2100,16 +2088,22 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             GNF_LAUNCH_CHECK("k_invdeg");
         }
     }
-    // fork / join events of the weight-gradient stream: three flag-only events per process, made on first use
-    // (the one piece of state this library keeps; they hold no memory)
+    // fork / join events of the weight-gradient stream: three flag-only events owned by THIS call (created on the
+    // current device, destroyed when the call returns - hipEventDestroy defers the release until the recorded work has
+    // completed), so concurrent callers, other devices and stream capture never share one
     hipStream_t aux = (hipStream_t)aux_stream;
     if (aux == st) aux = nullptr;
-    static hipEvent_t g_ev[2] = {nullptr, nullptr}, ev_ready = nullptr;
-    if (aux && !ev_ready) {
-        GNF_HIP_TRY(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
-        GNF_HIP_TRY(hipEventCreateWithFlags(&g_ev[0], hipEventDisableTiming));
-        GNF_HIP_TRY(hipEventCreateWithFlags(&g_ev[1], hipEventDisableTiming));
-    }
+    struct CallEvents {
+        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+        ~CallEvents() {
+            for (hipEvent_t e : ev)
+                if (e) (void)hipEventDestroy(e);
+        }
+    } call_events;
+    if (aux)
+        for (hipEvent_t& e : call_events.ev) GNF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipEvent_t* const g_ev = call_events.ev;
+    const hipEvent_t ev_ready = call_events.ev[2];
     hipEvent_t ev_done[2] = {nullptr, nullptr};
     int step = 0;
     bool used[2] = {false, false};  // weight sharing: the T uses of a net accumulate
@@ -2120,7 +2114,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             const bool acc = flow->weight_sharing && used[half];
             used[half] = true;
             const int co = half == 0 ? 0 : H, uo = half == 0 ? H : 0;
-            static const bool no_fused = getenv("GNF_BWD_GENERIC") != nullptr;  // developer A/B switch
+            const bool no_fused = opt(OPT_BWD_GENERIC) != 0;  // developer A/B option
             const bool attn = nets[0]->attn != nullptr;
             const bool fused = !no_fused && fused_bwd_supported(nets[0], nets[1]);
             const int set = step & 1;
@@ -2169,7 +2163,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             // message passing: the weight gradients only read what the fused kernel has just written, so their stream
             // forks HERE, before the scatter of dL/dx_cond (with an attention front-end they also read its backward
             // pass and fork after it)
-            static const bool late_fork = getenv("GNF_DW_LATE_FORK") != nullptr;  // developer A/B switch
+            const bool late_fork = opt(OPT_DW_LATE_FORK) != 0;  // developer A/B option
             const bool early_fork = aux && !attn && !late_fork;
             if (early_fork) {
                 GNF_HIP_TRY(hipEventRecord(ev_ready, st));

@@ -227,90 +227,86 @@ def write_embedding_chunk(path, node_embeddings, n_node):
 def _read_embedding_chunk(path):
     import pickle
     with open(path, "rb") as f:
-        d = pickle.load(f)
-    return d[0], d[1], np.cumsum(d[1])
+        node_embeddings, n_node = pickle.load(f)[:2]
+    return node_embeddings, np.asarray(n_node)
 
 
-class GrevnetDatasetFixed:
-    """train_grevnet_with_data.py:145-180: fixed number of graphs per batch; when the current chunk cannot
-    supply a whole batch its tail is dropped and the next file is opened (as the reference does).
+def plan_fixed_batches(n_node, batch_size):
+    """Graph ranges [lo, hi) of one chunk for a fixed number of graphs per batch: whole batches only - the graphs
+    left over at the end of a chunk are dropped (train_grevnet_with_data.py:163-176 moves on to the next file as
+    soon as the current one cannot supply `train_batch_size` more graphs)."""
+    whole = len(n_node) // batch_size
+    return [(k * batch_size, (k + 1) * batch_size) for k in range(whole)]
+
+
+def plan_variable_batches(n_node, max_nodes):
+    """Graph ranges [lo, hi) of one chunk for batches of consecutive graphs holding FEWER than max_nodes nodes
+    (strict, train_grevnet_with_data.py:221): a batch closes in front of the first graph that would reach the
+    limit; the range that runs into the end of the chunk is emitted short (:201-219)."""
+    out, lo, total = [], 0, 0
+    for g, n in enumerate(n_node):
+        if total + int(n) >= max_nodes:
+            out.append((lo, g))
+            lo, total = g, 0
+            # the graph that did not fit opens the next batch - unless it cannot fit in ANY batch
+            if int(n) >= max_nodes:
+                raise ValueError(f"graph {g} has {int(n)} nodes: never fits under max_nodes={max_nodes} "
+                                 "(the reference would hand out empty batches forever)")
+        total += int(n)
+    out.append((lo, len(n_node)))
+    return out
+
+
+class _ChunkBatches:
+    """Batches out of a directory of embedding chunks: the files are visited once in order, each chunk is cut by
+    `plan` into graph ranges, a batch is (node_embeddings[rows of the range], n_node[range]).  Running past the
+    last file raises IndexError, like the reference's `self.files[self.file_ind]`."""
+
+    def __init__(self, directory, files, plan):
+        import os
+        self._paths = [os.path.join(directory, f) for f in files]
+        self.files = list(files)
+        self._plan = plan
+        self._batches = self._generate()
+
+    def _generate(self):
+        for self.file_ind, path in enumerate(self._paths):
+            emb, n_node = _read_embedding_chunk(path)
+            row_end = np.concatenate([[0], np.cumsum(n_node)])
+            for lo, hi in self._plan(n_node):
+                yield emb[row_end[lo]:row_end[hi]], n_node[lo:hi]
+
+    def train_batch(self):
+        try:
+            return next(self._batches)
+        except StopIteration:
+            raise IndexError(f"{type(self).__name__}: out of training files (the reference raises IndexError too)") from None
+
+
+def _chunk_files(directory, sort_files):
+    import os
+    # os.listdir order, like the reference: unspecified, it changes from one directory to the next.
+    # sort_files=True (not in the reference) makes a run reproducible.
+    return sorted(os.listdir(directory)) if sort_files else os.listdir(directory)
+
+
+class GrevnetDatasetFixed(_ChunkBatches):
+    """train_grevnet_with_data.py:145-180: `train_batch_size` graphs per batch, chunk tails dropped;
     `train_epochs` is FLAGS.train_epochs (the file list is repeated that many times)."""
 
     def __init__(self, train_data_dir, train_batch_size, train_epochs=1, sort_files=False):
-        import os
-        # os.listdir order, like the reference: unspecified, it changes from one directory to the next.
-        # sort_files=True (not in the reference) makes a run reproducible.
-        files = sorted(os.listdir(train_data_dir)) if sort_files else os.listdir(train_data_dir)
-        self.files = files * int(train_epochs)
-        self.file_ind = 0
-        self.prev_graph_ind = 0
-        self.prev_node_embedding_ind = 0
         self.train_batch_size = int(train_batch_size)
-        self.train_data_dir = train_data_dir
-        self._os = os
-        self.node_embeddings, self.n_node, self.n_node_cs = _read_embedding_chunk(
-            os.path.join(train_data_dir, self.files[self.file_ind]))
-
-    def train_batch(self):
-        new_ind = self.prev_graph_ind + self.train_batch_size
-        if new_ind > len(self.n_node):
-            self.file_ind += 1
-            if self.file_ind >= len(self.files):
-                raise IndexError("GrevnetDatasetFixed: out of training files (the reference raises IndexError too)")
-            self.node_embeddings, self.n_node, self.n_node_cs = _read_embedding_chunk(
-                self._os.path.join(self.train_data_dir, self.files[self.file_ind]))
-            self.prev_graph_ind = 0
-            self.prev_node_embedding_ind = 0
-            new_ind = self.train_batch_size
-        node_embeddings = self.node_embeddings[self.prev_node_embedding_ind:self.n_node_cs[new_ind - 1]]
-        n_node = self.n_node[self.prev_graph_ind:new_ind]
-        self.prev_graph_ind = new_ind
-        self.prev_node_embedding_ind = self.n_node_cs[new_ind - 1]
-        return node_embeddings, n_node
+        super().__init__(train_data_dir, _chunk_files(train_data_dir, sort_files) * int(train_epochs),
+                         lambda n_node: plan_fixed_batches(n_node, self.train_batch_size))
 
 
-class GrevnetDatasetVariable:
-    """train_grevnet_with_data.py:183-234: as many consecutive graphs as fit UNDER max_nodes per batch; the
-    batch that reaches the end of a chunk is returned short and the next file is opened."""
+class GrevnetDatasetVariable(_ChunkBatches):
+    """train_grevnet_with_data.py:183-234: consecutive graphs up to (not reaching) max_nodes per batch."""
 
     def __init__(self, train_data_dir, max_nodes, sort_files=False):
-        import os
-        self.files = sorted(os.listdir(train_data_dir)) if sort_files else os.listdir(train_data_dir)
-        self.file_ind = 0
-        self.graph_ind = 0
-        self.prev_graph_ind = 0
-        self.prev_node_embedding_ind = 0
         self.max_nodes = int(max_nodes)
-        self.train_data_dir = train_data_dir
-        self._os = os
-        self.node_embeddings, self.n_node, self.n_node_cs = _read_embedding_chunk(
-            os.path.join(train_data_dir, self.files[self.file_ind]))
-
-    def train_batch(self):
-        total_nodes = 0
-        while True:
-            if self.graph_ind >= len(self.n_node):
-                node_embeddings = self.node_embeddings[self.prev_node_embedding_ind:self.n_node_cs[self.graph_ind - 1]]
-                n_node = self.n_node[self.prev_graph_ind:self.graph_ind]
-                self.file_ind += 1
-                self.prev_graph_ind = 0
-                self.graph_ind = 0
-                self.prev_node_embedding_ind = 0
-                if self.file_ind >= len(self.files):
-                    raise IndexError("GrevnetDatasetVariable: out of training files (the reference raises IndexError too)")
-                self.node_embeddings, self.n_node, self.n_node_cs = _read_embedding_chunk(
-                    self._os.path.join(self.train_data_dir, self.files[self.file_ind]))
-                return node_embeddings, n_node
-            if total_nodes + self.n_node[self.graph_ind] < self.max_nodes:
-                total_nodes += self.n_node[self.graph_ind]
-                self.graph_ind += 1
-            else:
-                break
-        node_embeddings = self.node_embeddings[self.prev_node_embedding_ind:self.n_node_cs[self.graph_ind - 1]]
-        n_node = self.n_node[self.prev_graph_ind:self.graph_ind]
-        self.prev_graph_ind = self.graph_ind
-        self.prev_node_embedding_ind = self.n_node_cs[self.graph_ind - 1]
-        return node_embeddings, n_node
+        super().__init__(train_data_dir, _chunk_files(train_data_dir, sort_files),
+                         lambda n_node: plan_variable_batches(n_node, self.max_nodes))
 
 
 def transform_example(node_embeddings, n_node, device=None):

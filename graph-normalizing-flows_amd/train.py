@@ -10,12 +10,11 @@ views into it, in snt.Linear's own [in, out] layout), the gradient, and Adam's t
 the same layout: the optimiser is one elementwise launch over the whole model, and the data-parallel
 gradient exchange is one flat all-reduce (RCCL over xGMI), not one collective per variable.
 
-Learning-rate schedules of the drivers: `exponential_decay` (run_grevnet.py:341-347) and
-`get_learning_rate` (utils.py:93-105) are restated as host functions.
+The drivers' default learning-rate schedule, `exponential_decay` (run_grevnet.py:341-347), is a host function here;
+any other schedule is the caller's business (`step(graph, learning_rate=...)`).
 """
 import ctypes as C
 import math
-import os
 
 import torch
 
@@ -31,16 +30,6 @@ def exponential_decay(learning_rate, global_step, decay_steps, decay_rate, stair
     if staircase:
         p = math.floor(p)
     return learning_rate * decay_rate ** p
-
-
-def get_learning_rate(timestep, max_lr, ramp_up=1000, hold_steady=2000, const_multiple=3):
-    """utils.py:93-105: linear ramp-up, hold, then 1/sqrt decay."""
-    if timestep < ramp_up:
-        return timestep * max_lr / ramp_up
-    if timestep <= hold_steady:
-        return max_lr
-    sqrt_diff = math.sqrt(timestep - hold_steady)
-    return min(1 / sqrt_diff, const_multiple / sqrt_diff) * max_lr
 
 
 class GRevNetTrainer:
@@ -70,9 +59,9 @@ class GRevNetTrainer:
         self._attn_blocks = []
         self._clip_ws = None     # scratch of the two-pass clip_by_norm
         self._stash = None       # attention front-end stash (uint8 device buffer), see loss_and_grads
-        self.stash_attention = os.environ.get("GNF_TRAIN_NO_STASH") is None   # developer A/B switch
+        self.stash_attention = True          # False: recompute the attention front-end in the backward walk
         self._aux = None         # second HIP stream: the weight-gradient GEMMs overlap the backward walk
-        self.overlap_weight_grads = os.environ.get("GNF_TRAIN_NO_OVERLAP") is None   # developer A/B switch
+        self.overlap_weight_grads = True     # False: no auxiliary stream for the weight-gradient GEMMs
 
     # ---- parameter arena ---------------------------------------------------------------------
     def _ensure_arena(self, hdim, device):

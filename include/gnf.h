@@ -9,10 +9,17 @@
  *
  * Conventions
  *   - plain C types only; every pointer that is not marked "host" is a DEVICE pointer into memory
- *     owned by the caller (torch tensors' data_ptr()).  The library allocates nothing persistent and
- *     keeps no global state besides a thread-local error string.
+ *     owned by the caller (torch tensors' data_ptr()).  The library allocates nothing persistent.  Its
+ *     only state: a thread-local error string, the table of developer options behind gnf_set_option
+ *     (all 0 = automatic by default; the library never reads the environment) and, per device, the
+ *     one-time "dynamic LDS limit raised" marks of its kernels.  Several host threads, several devices
+ *     in one process (hipSetDevice before the call, as for any HIP library) and several streams may
+ *     call concurrently.
  *   - every entry point is asynchronous on the caller's stream (hipStream_t passed as void*), does
- *     no host synchronisation, and is legal inside hipGraph stream capture.
+ *     no host synchronisation, and is legal inside hipGraph stream capture once each kernel it
+ *     launches has run once outside a capture on that device (the first launch raises the kernel's
+ *     dynamic-LDS limit with hipFuncSetAttribute): tests/test_graph_capture_gpu.py captures
+ *     gnf_grevnet_f32 (both directions) and gnf_grevnet_backward_f32 and replays them bitwise.
  *   - return 0 on success, a negative GNF_E* code on failure; gnf_last_error() gives the message.
  *     Nothing throws across the boundary.
  *   - node features live in ONE row-major [N, D] fp32 buffer with leading dimension ld >= D; the two
@@ -32,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GNF_ABI_VERSION 5
+#define GNF_ABI_VERSION 6
 #define GNF_MAX_LAYERS 8 /* Linear layers per MLP (gnn.py:165-166 builds num_layers of them) */
 
 typedef void* gnf_stream_t; /* hipStream_t */
@@ -159,6 +166,14 @@ typedef struct GnfFlow {
 } GnfFlow;
 
 int gnf_abi_version(void);
+/* ABI v6: developer options (kernel-generation A/B switches and launch-shape overrides that tools/ and the parity tests
+ * use to reach every code path).  value 0 = automatic.  Names: force_shape (<MT><NETS>, e.g. 21), whole_flow (1 = never
+ * take the persistent whole-flow forward kernel, 2 = take it whenever legal), attn_edge_tiled, attn_rows,
+ * attn_lane_feature, gemm_no_buf, gemm_lds_direct, gemm_no_splitk, layered_own_gemm, dw_grouped, dw_wide_units,
+ * dw_wide_lds, dw_no_streamk, dw_no_buf, dw_debug, dw_late_fork, bwd_generic.  Process-wide, relaxed atomics: takes effect
+ * for calls made after it returns.  Unknown name: GNF_EINVAL.  Nothing in the reference corresponds to these. */
+int gnf_set_option(const char* name, int64_t value);
+int64_t gnf_get_option(const char* name);
 /* Bytes of GnfFlow.attn_stash for n_nodes nodes of width D (0 when the flow's nets have no attention front-end). */
 size_t gnf_attn_stash_bytes(int64_t n_nodes, int32_t D, const GnfFlow* flow);
 const char* gnf_last_error(void); /* thread-local, valid until the next failing call on this thread */
@@ -212,7 +227,8 @@ int gnf_coupling_half_f32(const GnfCsr* csr, const GnfMlp* s_net, const GnfMlp* 
  *   FORWARD  = GRevNet.f (gnn.py:304-341): x -> z; sums[0] = log_det_jacobian, sums[1] = sum(z^2)
  *              (the data term of run_grevnet.py:292-294), both device fp64, written (not accumulated).
  *   INVERSE  = GRevNet.g (gnn.py:343-373): z -> x; sums may be NULL (nothing written).
- * use_batch_norm=False only. */
+ * With flow->bns != NULL (use_batch_norm=True) every half-step of f is preceded by its batch-norm bijector
+ * (gnn.py:310-313, 325-328) and every half-step of g followed by it (gnn.py:356-358, 369-371); see GnfBatchNorm. */
 int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld, int32_t D,
                     int32_t direction, double* sums, void* ws, size_t ws_bytes, gnf_stream_t stream);
 
@@ -255,7 +271,8 @@ int gnf_pred_adj_f32(const float* z, int64_t ld, int32_t D, const int32_t* n_nod
  *   z      in: f(x) as left by gnf_grevnet_f32(GNF_FORWARD); out: x again (the reconstruction)
  *   aux_stream  NULL, or a second stream: the weight-gradient GEMMs of a half-step then overlap the next
  *          half-step's fused kernel (fork / join by events; everything is complete on `stream` order)
- * Attention GNNs: GNF_EUNSUPPORTED.  ws: gnf_backward_workspace_bytes(n_nodes, D, flow). */
+ * Message-passing and attention GNNs, with or without batch-norm bijectors.
+ * ws: gnf_backward_workspace_bytes(n_nodes, D, flow). */
 size_t gnf_backward_workspace_bytes(int64_t n_nodes, int32_t D, const GnfFlow* flow);
 int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFlow* flow, const GnfFlow* grad,
                              float* z, int64_t ld, int32_t D, void* ws, size_t ws_bytes, gnf_stream_t stream,

@@ -1,0 +1,229 @@
+"""BASELINE configs at their STATED batch sizes on one MI355X, against the float64 oracle.
+
+  config 2  community_medium, 64 graphs (the benchmarked launch: 170 node tiles, XCD remap) - whole batch vs the oracle
+  config 3  community_medium, 512 graphs "sharded 8 ways": whole batch vs the oracle, and the 8 shards of
+            shard_graph_ids (what 8 ranks would run) add up to the batch sums
+  config 5  ego stand-in, D = 256, T = 16: (i) the hyper-parameters vs the oracle on 8 graphs, forward and
+            inverse; (ii) 1024 graphs (230k nodes): round trip, bitwise re-run, 8-shard additivity, and the
+            graphs with the worst round-trip error re-run through the oracle
+
+Tolerances are DERIVED, not picked: the float32 CPU restatement of the reference (oracle.Fp32Gather: same
+algorithm, same precision, reference op order) is run on the same inputs, its own deviation from the float64
+restatement / its own round-trip error is the conditioning of the flow on those inputs, and the HIP path has
+to stay within `SLACK` of it (different summation orders: MFMA k-order vs BLAS blocking).  The per-node
+log-prob bar of BASELINE.json (1e-4) is absolute.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import graph_from_arrays, make_product_grevnet
+from oracle import gnf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SLACK = 6.0       # HIP fp32 error <= SLACK x (CPU fp32 restatement's error on the same inputs) + FLOOR
+FLOOR = 2e-6      # a few ulp of O(1) values
+
+HP_DEFAULT = dict(D=64, latent=256, K=5, T=8, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu",
+                  weight_sharing=False)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu_and_native_lib():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from gnf_amd import _abi
+    _abi.lib()
+
+
+def _oracles(hp, s, r, n):
+    kw = dict(agg=hp["agg"], combine=hp["combine"], epsilon=hp["epsilon"], activation=hp["activation"])
+    return O.Fp32Gather(s, r, n, dtype=torch.float64, **kw), O.Fp32Gather(s, r, n, **kw)
+
+
+def _conditioning(hp, s, r, n, x, p):
+    """float64 reference + what float32 arithmetic costs on THESE inputs (the CPU restatement's own errors)."""
+    o64, o32 = _oracles(hp, s, r, n)
+    t = hp["T"]
+    p64, p32 = o64.prep_params(p), o32.prep_params(p)
+    ref = o64.log_prob(o64.to_t(x), p64, t)
+    r32 = o32.log_prob(o32.to_t(x), p32, t)
+    back32 = o32.g(r32["z"], p32, t)
+    return {
+        "ref": ref, "o64": o64, "p64": p64,
+        "z_err32": float((r32["z"].double() - ref["z"]).abs().max()),
+        "rt_err32": float((back32 - o32.to_t(x)).abs().max()),
+        "lp_err32": abs(r32["log_prob_xs_per_node"] - ref["log_prob_xs_per_node"]),
+    }
+
+
+def _graph_rows(nn):
+    off = np.concatenate([[0], np.cumsum(nn)])
+    return off
+
+
+def _bench_batch():
+    """Exactly bench.py's config-2 batch, weights and features (N = 2718, E = 32202)."""
+    import bench
+    dicts, n, e = bench.make_batch(1, 0)
+    params = bench.make_params(bench.WEIGHT_SEED, dict(bench.HP), bench.FINAL_SCALE)
+    from gnf_amd.graphs import data_dicts_to_graphs_tuple
+    return data_dicts_to_graphs_tuple(dicts), params, dict(bench.HP)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "layered"])
+def test_config2_full_batch_vs_fp64_oracle(fused):
+    g_cpu, p, hp = _bench_batch()
+    assert g_cpu.nodes.shape[0] == 2718 and g_cpu.senders.shape[0] == 32202      # the bench line's workload
+    x = g_cpu.nodes.numpy()
+    s, r = g_cpu.senders.numpy(), g_cpu.receivers.numpy()
+    n = x.shape[0]
+    c = _conditioning(hp, s, r, n, x, p)
+    ref = c["ref"]
+    net = make_product_grevnet(hp, p)
+    net.fused = fused
+    from gnf_amd.flow import log_prob_terms
+    graph = graph_from_arrays(g_cpu.n_node.numpy(), g_cpu.n_edge.numpy(), s, r, x, DEV)
+    out = log_prob_terms(net, graph)
+    torch.cuda.synchronize()
+    for key in ("log_prob_xs_per_node", "log_prob_zs_per_node", "log_det_jacobian_per_node"):
+        assert abs(float(out[key]) - ref[key]) <= 1e-4, key
+    z = out["z_graph"].nodes.cpu().double()
+    z_err = float((z - ref["z"]).abs().max())
+    assert z_err <= SLACK * c["z_err32"] + FLOOR, (z_err, c["z_err32"])
+    # inverse on the oracle's latent: g(z_ref) vs the oracle's g, and the device round trip
+    zin = torch.as_tensor(ref["z"].numpy().astype(np.float32))
+    xg = net(graph.replace(nodes=zin.to(DEV)), inverse=False).nodes.cpu().double()
+    want = c["o64"].g(zin.double(), c["p64"], hp["T"])
+    assert float((xg - want).abs().max()) <= SLACK * c["rt_err32"] + FLOOR
+    back = net(out["z_graph"], inverse=False).nodes
+    rt = float((back - graph.nodes).abs().max())
+    assert rt <= SLACK * c["rt_err32"] + FLOOR, (rt, c["rt_err32"])
+
+
+def test_config3_512_graphs_vs_oracle_and_8_shards(community_medium):
+    """community_medium batch = 512 (bench.py --gpus 8 global batch: 64 graphs per rank), on ONE device:
+    the whole batch vs the oracle, then the 8 shards 8 ranks would run."""
+    from gnf_amd.flow import log_prob_terms
+    from gnf_amd.sharding import assemble_from_sums, shard_graph_ids
+    hp = dict(HP_DEFAULT)
+    n_node, n_edge, sl, rl = community_medium
+    rng = np.random.default_rng(12345)
+    ids = rng.choice(168, size=512, replace=True)
+    nn, ne, s, r = O.batch_graphs(n_node, n_edge, sl, rl, ids)
+    n = int(nn.sum())
+    x = rng.standard_normal((n, hp["D"])).astype(np.float32)
+    p = O.make_grevnet_params(99, 32, 256, 5, 8, final_scale=0.25)
+    c = _conditioning(hp, s, r, n, x, p)
+    net = make_product_grevnet(hp, p)
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    full = log_prob_terms(net, graph)
+    torch.cuda.synchronize()
+    assert abs(float(full["log_prob_xs_per_node"]) - c["ref"]["log_prob_xs_per_node"]) <= 1e-4
+    z_err = float((full["z_graph"].nodes.cpu().double() - c["ref"]["z"]).abs().max())
+    assert z_err <= SLACK * c["z_err32"] + FLOOR, (z_err, c["z_err32"])
+    back = net(full["z_graph"], inverse=False).nodes
+    assert float((back - graph.nodes).abs().max()) <= SLACK * c["rt_err32"] + FLOOR
+    again = log_prob_terms(net, graph)                       # fixed-order reductions: bitwise on a re-run
+    assert torch.equal(again["z_graph"].nodes, full["z_graph"].nodes)
+    assert float(again["log_det_jacobian"]) == float(full["log_det_jacobian"])
+    # the 8 shards of the multi-GPU path, one after the other on this device
+    off = _graph_rows(nn)
+    shards = shard_graph_ids(nn, ne, 8)
+    assert sorted(np.concatenate(shards).tolist()) == list(range(512))
+    loads = [int(nn[sh].sum()) for sh in shards]
+    assert max(loads) - min(loads) <= 60                     # greedy LPT: within one graph of each other
+    total = torch.zeros(3, dtype=torch.float64, device=DEV)
+    for sh in shards:
+        rows = np.concatenate([np.arange(off[i], off[i + 1]) for i in sh])
+        n2, e2, s2, r2 = O.batch_graphs(n_node, n_edge, sl, rl, ids[sh])
+        total += log_prob_terms(net, graph_from_arrays(n2, e2, s2, r2, x[rows], DEV))["shard_sums"]
+    asm = assemble_from_sums(total)
+    assert float(asm["num_nodes"]) == float(n)
+    assert abs(float(asm["log_prob_xs_per_node"]) - float(full["log_prob_xs_per_node"])) <= 1e-6
+    assert abs(float(asm["log_prob_xs_per_node"]) - c["ref"]["log_prob_xs_per_node"]) <= 1e-4
+
+
+HP_CFG5 = dict(HP_DEFAULT, D=256, T=16)
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "layered"])
+def test_config5_hyper_parameters_vs_oracle(fused):
+    """D = 256 (H = 128: the layer-0 GEMM is 128 wide), L = 256, K = 5, T = 16 on 8 ego stand-in graphs."""
+    from gnf_amd import datasets as D
+    from gnf_amd.flow import log_prob_terms
+    from gnf_amd.graphs import data_dicts_to_graphs_tuple
+    hp = dict(HP_CFG5)
+    pool = D.synthetic_ego(8, seed=4242)
+    rng = np.random.default_rng(11)
+    g_cpu = data_dicts_to_graphs_tuple(pool.data_dicts(np.arange(8), lambda n: rng.standard_normal((n, 256)).astype(np.float32)))
+    x, s, r = g_cpu.nodes.numpy(), g_cpu.senders.numpy(), g_cpu.receivers.numpy()
+    n = x.shape[0]
+    p = O.make_grevnet_params(99, 128, 256, 5, 16, final_scale=0.25)
+    c = _conditioning(hp, s, r, n, x, p)
+    net = make_product_grevnet(hp, p)
+    net.fused = fused
+    graph = graph_from_arrays(g_cpu.n_node.numpy(), g_cpu.n_edge.numpy(), s, r, x, DEV)
+    out = log_prob_terms(net, graph)
+    torch.cuda.synchronize()
+    for key in ("log_prob_xs_per_node", "log_prob_zs_per_node", "log_det_jacobian_per_node"):
+        assert abs(float(out[key]) - c["ref"][key]) <= 1e-4, key
+    z_err = float((out["z_graph"].nodes.cpu().double() - c["ref"]["z"]).abs().max())
+    assert z_err <= SLACK * c["z_err32"] + FLOOR, (z_err, c["z_err32"])
+    zs = rng.standard_normal((n, 256)).astype(np.float32)           # inverse on an independent latent sample
+    xg = net(graph.replace(nodes=torch.as_tensor(zs).to(DEV)), inverse=False).nodes.cpu().double()
+    want = c["o64"].g(torch.as_tensor(zs).double(), c["p64"], 16)
+    o32 = _oracles(hp, s, r, n)[1]
+    g_err32 = float((o32.g(torch.as_tensor(zs), o32.prep_params(p), 16).double() - want).abs().max())
+    assert float((xg - want).abs().max()) <= SLACK * g_err32 + FLOOR
+
+
+def test_config5_1024_graphs_properties_and_worst_graphs_vs_oracle():
+    """BASELINE config 5 at its stated batch (1024 graphs, ~230k nodes, D = 256, T = 16) on one device."""
+    from gnf_amd import datasets as D
+    from gnf_amd.flow import forward_shard_sums, log_prob_from_sums
+    from gnf_amd.graphs import data_dicts_to_graphs_tuple
+    from gnf_amd.sharding import shard_graph_ids
+    hp = dict(HP_CFG5)
+    b = 1024
+    pool = D.synthetic_ego(b, seed=12345)
+    rng = np.random.default_rng(8)
+    g_cpu = data_dicts_to_graphs_tuple(pool.data_dicts(np.arange(b), lambda n: rng.standard_normal((n, 256)).astype(np.float32)))
+    nn, ne = g_cpu.n_node.numpy(), g_cpu.n_edge.numpy()
+    n = int(nn.sum())
+    assert n > 200_000
+    p = O.make_grevnet_params(99, 128, 256, 5, 16, final_scale=0.25)
+    net = make_product_grevnet(hp, p)
+    graph = graph_from_arrays(nn, ne, g_cpu.senders.numpy(), g_cpu.receivers.numpy(), g_cpu.nodes.numpy(), DEV)
+    z, sums = forward_shard_sums(net, graph)
+    sums = sums.clone()
+    back = net(graph.replace(nodes=z), inverse=False).nodes
+    z2, sums2 = forward_shard_sums(net, graph)
+    torch.cuda.synchronize()
+    assert torch.equal(z2, z) and torch.equal(sums2, sums)           # bitwise re-run
+    full = log_prob_from_sums(sums.tolist(), 256)
+    # 8 shards (what 8 ranks run) add up to the batch sums
+    off = _graph_rows(nn)
+    total = torch.zeros(3, dtype=torch.float64, device=DEV)
+    x_all = g_cpu.nodes.numpy()
+    for sh in shard_graph_ids(nn, ne, 8):
+        it = iter([x_all[off[i]:off[i + 1]] for i in sh])
+        sub = data_dicts_to_graphs_tuple(pool.data_dicts(sh, lambda _n: next(it)), DEV)
+        total += forward_shard_sums(net, sub)[1]
+    asm = log_prob_from_sums(total.tolist(), 256)
+    assert asm["num_nodes"] == float(n)
+    assert abs(asm["log_prob_xs_per_node"] - full["log_prob_xs_per_node"]) <= 1e-6
+    # round-trip error per graph; the worst graphs (and two arbitrary ones) go through the oracle
+    err = (back - graph.nodes).abs().max(dim=1).values.cpu().numpy()
+    per_graph = np.array([err[off[i]:off[i + 1]].max() for i in range(b)])
+    worst = list(np.argsort(-per_graph)[:4]) + [0, b // 2]
+    zc = z.cpu()
+    for gi in worst:
+        nloc, sl, rl = pool.graph(gi)
+        xs = x_all[off[gi]:off[gi + 1]]
+        c = _conditioning(hp, sl, rl, nloc, xs, p)
+        assert per_graph[gi] <= SLACK * c["rt_err32"] + FLOOR, (gi, per_graph[gi], c["rt_err32"])
+        z_err = float((zc[off[gi]:off[gi + 1]].double() - c["ref"]["z"]).abs().max())
+        assert z_err <= SLACK * c["z_err32"] + FLOOR, (gi, z_err, c["z_err32"])
+    assert per_graph.max() == per_graph[worst[0]]

@@ -434,18 +434,18 @@ def test_thin_layers_behind_wide_ones_take_the_split_k_path(grid_small):
             np.testing.assert_allclose(back.nodes.cpu().numpy(), x, atol=3e-4, rtol=3e-4)
 
 
-DW_MODES = [
+DW_MODES = [   # (gnf_set_option values, dw_modes_check.py flags)
     ({}, ""),                                                     # what the library picks by itself
-    ({"GNF_DW_GROUPED": "1"}, ""),                                # the 128 x 64 grouped kernel
-    ({"GNF_DW_WIDE_UNITS": "8"}, ""),                             # few workgroups: cheap units ride behind, strided
-    ({"GNF_DW_WIDE_UNITS": "200"}, "ws"),                         # many node chunks per job + accumulating reduce
-    ({"GNF_DW_WIDE_UNITS": "24", "GNF_DW_NO_BUF": "1"}, ""),      # bounds-checked generic tile fetch
-    ({"GNF_DW_WIDE_UNITS": "40", "GNF_TRAIN_NO_OVERLAP": "1"}, "ws"),
-    ({"GNF_DW_WIDE_UNITS": "24", "GNF_DW_NO_STREAMK": "1"}, ""),  # whole chunks instead of stream-K runs
-    ({"GNF_DW_WIDE_UNITS": "13"}, "ws"),                          # stream-K with an odd workgroup count
-    ({"GNF_BWD_GENERIC": "1"}, ""),                               # generic (GEMM) backward: buffer-descriptor tile fetch
-    ({"GNF_BWD_GENERIC": "1", "GNF_GEMM_LDS_DIRECT": "all"}, ""), # ... through the LDS-direct (fragment-order) tile
-    ({"GNF_BWD_GENERIC": "1", "GNF_GEMM_NO_BUF": "1"}, "ws"),     # ... through the bounds-checked fetch
+    ({"dw_grouped": 1}, ""),                                      # the 128 x 64 grouped kernel
+    ({"dw_wide_units": 8}, ""),                                   # few workgroups: cheap units ride behind, strided
+    ({"dw_wide_units": 200}, "ws"),                               # many node chunks per job + accumulating reduce
+    ({"dw_wide_units": 24, "dw_no_buf": 1}, ""),                  # bounds-checked generic tile fetch
+    ({"dw_wide_units": 40}, "ws,serial"),                         # no auxiliary stream
+    ({"dw_wide_units": 24, "dw_no_streamk": 1}, ""),              # whole chunks instead of stream-K runs
+    ({"dw_wide_units": 13}, "ws"),                                # stream-K with an odd workgroup count
+    ({"bwd_generic": 1}, ""),                                     # generic (GEMM) backward: buffer-descriptor tile fetch
+    ({"bwd_generic": 1, "gemm_lds_direct": 1}, ""),               # ... through the LDS-direct (fragment-order) tile
+    ({"bwd_generic": 1, "gemm_no_buf": 1}, "ws"),                 # ... through the bounds-checked fetch
 ]
 
 
@@ -453,13 +453,14 @@ DW_MODES = [
                               "wide13_streamk_ws", "generic_bwd",
                               "generic_bwd_lds_direct", "generic_bwd_nobuf_ws"])
 def test_weight_gradient_kernel_launch_shapes(env, arg):
-    """The dW GEMM has several launch shapes chosen per batch; the switches are read once per
-    process, so each shape runs tools/dw_modes_check.py (gradients of a ~900-node batch with ragged layer widths vs
-    the oracle, 1e-3 of each tensor's max) in its own interpreter."""
+    """The dW GEMM has several launch shapes chosen per batch; each forced shape (developer
+    options of the library, gnf_set_option, handed to the child through the binding's GNF_OPTIONS variable) runs
+    tools/dw_modes_check.py (gradients of a ~900-node batch with ragged layer widths vs the oracle, 1e-3 of each
+    tensor's max) in its own interpreter so that no option leaks into the other tests."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     e = dict(os.environ)
-    e.update(env)
+    e["GNF_OPTIONS"] = ",".join(f"{k}={v}" for k, v in env.items())
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "dw_modes_check.py")] + ([arg] if arg else []),
                        env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "dw-modes-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

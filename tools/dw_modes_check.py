@@ -1,6 +1,6 @@
-"""Gradient parity of one mid-size batch under whatever dW launch shape the environment forces (GNF_DW_GROUPED,
-GNF_DW_WIDE_UNITS, GNF_DW_NO_BUF are read once per process, hence a script: tests/test_train_gpu.py runs it in
-sub-processes).  Ragged layer widths exercise partial 128 x 128 tiles, thin strips (1 x 8 / 8 x 1 wave layouts),
+"""Gradient parity of one mid-size batch under whatever dW launch shape the library options force (GNF_OPTIONS=
+"dw_grouped=1,..." -> gnf_set_option through the binding; a script so that tests/test_train_gpu.py can run every
+shape in its own process).  argv[1]: comma list of "ws" (weight sharing), "serial" (no auxiliary dW stream).  Ragged layer widths exercise partial 128 x 128 tiles, thin strips (1 x 8 / 8 x 1 wave layouts),
 several node chunks per job and cheap units riding behind the costly ones; weight sharing exercises the
 accumulating reduce.  Prints 'dw-modes-ok' on success."""
 import os, sys
@@ -12,7 +12,8 @@ from helpers import graph_from_arrays, make_product_grevnet
 from gnf_amd.train import GRevNetTrainer
 from gnf_amd.datasets import senders_receivers
 
-ws = len(sys.argv) > 1 and sys.argv[1] == "ws"
+flags = sys.argv[1].split(",") if len(sys.argv) > 1 else []
+ws = "ws" in flags
 rng = np.random.default_rng(5)
 n_node = rng.integers(9, 17, size=72).astype(np.int32)          # ~900 nodes: 4 node chunks in the plan
 s, r, ne = senders_receivers(n_node)
@@ -24,6 +25,7 @@ p = O.make_grevnet_params(21, D // 2, L, K, T, final_scale=0.3, weight_sharing=w
 ref = O.loss_and_grads(s, r, n, x, p, T, weight_sharing=ws, **kw)
 net = make_product_grevnet(dict(D=D, latent=L, K=K, T=T, weight_sharing=ws, **kw), p)
 tr = GRevNetTrainer(net)
+tr.overlap_weight_grads = "serial" not in flags
 out = tr.loss_and_grads(graph_from_arrays(n_node, ne, s, r, x, "cuda:0"))
 torch.cuda.synchronize()
 assert abs(float(out["loss_per_node"]) - ref["total_loss"] / n) <= 1e-4

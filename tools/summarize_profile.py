@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn a tools/profile_r1.sh output directory (gpurun_out/prof_<tag>) into the small text files that
+"""Turn a tools/profile.sh output directory (gpurun_out/prof_<tag>) into the small text files that
 are committed under profiles/: per-kernel stats of the --kernel-trace --stats run, mean PMC counters of
 the dominant kernel per pass, and the HBM traffic per launch with the gfx950 FETCH_SIZE correction
 (MI355X_MICROARCH.md section HBM: FETCH_SIZE under-reports a wide coalesced read stream by exactly 2x;
@@ -17,7 +17,7 @@ def main(src, tag, dst):
     lines = []
     ks = os.path.join(src, "trace", "kt_kernel_stats.csv")
     rows = list(csv.DictReader(open(ks)))
-    lines.append(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline   ({tag})")
+    lines.append(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-secondary --latency-steps 0   ({tag})")
     lines.append(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'min_us':>9} {'max_us':>9} {'pct':>6}  kernel")
     for r in rows:
         lines.append(f"{int(r['Calls']):7d} {float(r['TotalDurationNs'])/1e3:12.1f} {float(r['AverageNs'])/1e3:10.3f} "
@@ -35,7 +35,12 @@ def main(src, tag, dst):
         for k, v in agg.items():
             pmc[k] = sum(v) / len(v)
             lines.append(f"{pmc[k]:18.1f}  n={len(v):4d}  {k}")
-    out = {"tag": tag, "kernel": dom}
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    stamp_file = os.path.join(src, "source_stamp.txt")   # written on the GPU box by tools/profile.sh
+    stamp = open(stamp_file).read().strip() if os.path.exists(stamp_file) else bench.kernel_source_stamp()
+    out = {"tag": tag, "kernel": dom, "source_stamp": stamp}
+    lines.append(f"# kernel sources stamp (bench.kernel_source_stamp): {out['source_stamp']}")
     if "FETCH_SIZE" in pmc:
         out["fetch_bytes_per_launch"] = pmc["FETCH_SIZE"] * 1024 * 2      # gfx950 correction x2
         out["write_bytes_per_launch"] = pmc.get("WRITE_SIZE", 0.0) * 1024
