@@ -72,16 +72,14 @@ PEAK_HBM_GBS = 8000.0
 
 
 def kernel_source_stamp():
-    """sha256 over the kernel sources + the ABI header: what a profile under profiles/ was taken on.  (There is no
-    .git on the GPU box, so the stamp is content-based.)"""
-    import glob
+    """sha256 over the sources of the dominant kernel (k_half_fused: gnf_fused.hip + gnf_fused_dev.h): what the PMC
+    passes under profiles/ were taken on.  (There is no .git on the GPU box, so the stamp is content-based.)"""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "graph-normalizing-flows_amd", "csrc")
-    for p in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))) + \
-            [os.path.join(ROOT, "include", "gnf.h")]:
-        h.update(os.path.basename(p).encode())
-        h.update(open(p, "rb").read())
+    for name in ("gnf_fused.hip", "gnf_fused_dev.h"):
+        h.update(name.encode())
+        h.update(open(os.path.join(csrc, name), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -312,6 +310,8 @@ def main():
     sums3 = torch.zeros(3, dtype=torch.float64, device=dev)
     sums3[2] = float(n_local)
     host = torch.zeros(args.steps + args.warmup + 1, 3, dtype=torch.float64).pin_memory()
+    host[:, 2] = float(n_local)          # single-GPU steps write [logdet, sum z^2] of step i into host[i, :2] directly
+    host[:, :2] = float("nan")           # "not landed" marker
 
     trainer = None
     if WORKLOAD.get("train"):
@@ -335,8 +335,9 @@ def main():
             if len(pending) > 1 or args.sync_each_step:
                 drain(1 if not args.sync_each_step else len(pending))
         else:
-            _, s3 = forward_shard_sums(net, graph, sums3)
-            host[i].copy_(s3, non_blocking=True)
+            # one GPU: the final reduction kernel writes the two batch scalars straight into this step's row of the
+            # pinned host buffer (device-visible host memory; no device-to-host copy node behind the flow)
+            forward_shard_sums(net, graph, host[i])
         if args.sync_each_step:
             torch.cuda.current_stream().synchronize()
 
@@ -639,7 +640,7 @@ def main():
                    "csr": f"built on device once per batch before the timed region (gnf_build_csr: {csr_ms:.3f} ms wall incl. host launch), cached",
                    "host_sync": "every step" if args.sync_each_step else "results copied to pinned host memory each step; one sync at end"},
         "log_prob_xs_per_node": last["log_prob_xs_per_node"],
-        "steps_landed_on_host": int((host[args.warmup:args.warmup + args.steps, 2] != 0).sum()) if trainer is None and not inverse else None,
+        "steps_landed_on_host": int(torch.isfinite(host[args.warmup:args.warmup + args.steps, :2]).all(dim=1).sum()) if trainer is None and not inverse else None,
         "latency": latency,
         "graph_replay": graph_replay,
         "secondary_D100": d100,

@@ -89,6 +89,8 @@ _SIGNATURES = {
                                         C.c_void_p]),
     "gnf_grevnet_f32": (C.c_int, [C.POINTER(GnfCsr), C.POINTER(GnfFlow), C.c_void_p, C.c_int64,
                                   C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gnf_grevnet_from_f32": (C.c_int, [C.POINTER(GnfCsr), C.POINTER(GnfFlow), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                       C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gnf_pred_adj_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gnf_pred_adj_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

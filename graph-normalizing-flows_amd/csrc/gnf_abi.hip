@@ -14,7 +14,7 @@ static thread_local char g_err[512] = "";
 std::atomic<int64_t> g_options[OPT_COUNT];  // zero-initialised: every option "auto"
 
 static const char* const kOptionNames[OPT_COUNT] = {
-    "force_shape",     "whole_flow",     "attn_edge_tiled",  "attn_rows",    "attn_lane_feature", "gemm_no_buf",
+    "force_shape",     "flow_no_oop",    "attn_edge_tiled",  "attn_rows",    "attn_lane_feature", "gemm_no_buf",
     "gemm_lds_direct", "gemm_no_splitk", "layered_own_gemm", "dw_grouped",   "dw_wide_units",     "dw_wide_lds",
     "dw_no_streamk",   "dw_no_buf",      "dw_debug",         "dw_late_fork", "bwd_generic"};
 
@@ -353,8 +353,18 @@ int gnf_coupling_half_f32(const GnfCsr* csr, const GnfMlp* s_net, const GnfMlp* 
 
 int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld, int32_t D,
                     int32_t direction, double* sums, void* ws, size_t ws_bytes, gnf_stream_t stream) {
+    return gnf_grevnet_from_f32(csr, flow, nullptr, 0, x, ld, D, direction, sums, ws, ws_bytes, stream);
+}
+
+int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_src, int64_t ld_src, float* x, int64_t ld,
+                         int32_t D, int32_t direction, double* sums, void* ws, size_t ws_bytes, gnf_stream_t stream) {
     int rc = validate_flow_call(csr, flow, ld, D, "gnf_grevnet_f32");
     if (rc) return rc;
+    if (x_src == x) x_src = nullptr;
+    if (x_src && ld_src < D) {
+        set_error("gnf_grevnet_from_f32: ld_src=%lld < D=%d", (long long)ld_src, D);
+        return GNF_ESHAPE;
+    }
     if (direction != GNF_FORWARD && direction != GNF_INVERSE) {
         set_error("gnf_grevnet_f32: direction=%d", direction);
         return GNF_EINVAL;
@@ -388,6 +398,35 @@ int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld
     float* half0 = x;       // columns [0, H)
     float* half1 = x + H;   // columns [H, D)
     int64_t used = 0;       // partial slots written so far (packed densely, fixed order)
+    // Out of place (x_src -> x): the first half-step of the walk reads the source buffer and writes the destination
+    // (its conditioning rows copied on the way) when the fused both-nets kernel runs it; otherwise one copy pass
+    // up front and the in-place walk.  A batch-norm bijector in front of the first half-step rewrites the
+    // conditioning half in place, so such flows copy first too.
+    bool first_oop = false;
+    if (x_src && n > 0) {
+        if (T > 0 && ld_src == ld && !(direction == GNF_FORWARD && flow->bns) && !opt(OPT_FLOW_NO_OOP)) {
+            const int h0_ = direction == GNF_FORWARD ? 0 : 1, i0_ = direction == GNF_FORWARD ? 0 : T - 1;
+            HalfStep probe{csr->rowptr, csr->col, n, x, x, ld, H, direction, flow->gnn,
+                           pick(flow, flow->s_nets, h0_, i0_), pick(flow, flow->t_nets, h0_, i0_), nullptr, nullptr,
+                           nullptr, csr->n_edges};
+            first_oop = fused_supports_oop(probe);
+        }
+        if (!first_oop) {
+            rc = launch_copy_rows(x_src, ld_src, x, ld, n, D, st);
+            if (rc) return rc;
+        }
+    }
+    bool first = true;
+    auto mark_first = [&](HalfStep& hs, int half) {
+        if (!first) return;
+        first = false;
+        if (first_oop) {
+            const int co = half == 0 ? 0 : H, uo = half == 0 ? H : 0;
+            hs.x_cond = x_src + co;
+            hs.x_upd_src = x_src + uo;
+            hs.cond_copy = x + co;
+        }
+    };
     // the forward pass leaves every half-step's attention front-end in the caller's stash for the backward pass
     const size_t stash_slot = attn_stash_slot_floats(flow, n);
     float* stash = nullptr;
@@ -416,6 +455,7 @@ int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld
                                 pick(flow, flow->s_nets, half, i), pick(flow, flow->t_nets, half, i),
                                 partials + used, &np_,
                                 stash ? stash + (size_t)(2 * i + half) * stash_slot : nullptr, csr->n_edges};
+                    mark_first(hs, half);
                     rc = run_half(hs, scratch, st);
                     if (rc) return rc;
                     used += np_;
@@ -429,6 +469,7 @@ int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld
                                 half == 0 ? half1 : half0, ld, H, GNF_INVERSE, flow->gnn,
                                 pick(flow, flow->s_nets, half, i), pick(flow, flow->t_nets, half, i),
                                 partials + used, &np_, nullptr, csr->n_edges};
+                    mark_first(hs, half);
                     rc = run_half(hs, scratch, st);
                     if (rc) return rc;
                     // partial slots are reused: the inverse pass has no log-det (gnn.py:343-373)
@@ -442,6 +483,9 @@ int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld
     }
     if (direction == GNF_FORWARD) {
         double* gpart = partials + 2 * (int64_t)(T > 0 ? T : 1) * p.partial_stride;
+        // (measured and dropped, tools/ab_options.py: k_gauss + k_finalize merged into one launch whose last-arriving
+        // workgroup runs the final reduction - the release / ticket / acquire hand-off costs 1 us more than the launch
+        // boundary it removes)
         int32_t ng = 0;
         if (n > 0) {
             rc = launch_gauss_partials(x, n, D, ld, gpart, &ng, st);

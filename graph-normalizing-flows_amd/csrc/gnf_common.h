@@ -48,7 +48,15 @@ struct HalfStep {
     float* attn_region;   // NULL: the attention front-end works in the scratch; else q | k | v and h0 of both nets go
                           // here (a slot of GnfFlow.attn_stash) and stay for the backward pass
     int64_t n_edges;      // 0: unknown (only used to pick between kernel generations by mean degree)
+    // out-of-place first half-step of a flow (the caller's functional x -> z without a separate copy pass): when
+    // x_src != NULL the conditioning half is read from x_src + cond_off, the old value of the updated half from
+    // x_src + upd_off (same leading dimension ld), and the launch also copies its rows of the conditioning half into
+    // cond_copy (= the destination buffer's conditioning half).  Only the fused both-nets kernel implements it
+    // (fused_supports_oop); everything else copies first.
+    const float* x_upd_src = nullptr;
+    float* cond_copy = nullptr;
 };
+bool fused_supports_oop(const HalfStep& hs);
 // floats of one half-step's slot in GnfFlow.attn_stash ( = attn_scratch_floats: [2][n][P] q|k|v, then [2][n][in0] h0)
 size_t attn_stash_slot_floats(const GnfFlow* flow, int64_t n_nodes);
 
@@ -97,6 +105,7 @@ int launch_gauss_partials(const float* z, int64_t n_nodes, int32_t D, int64_t ld
 // out[0] (+)= sum of a[0..na) ; out[1] = sum of b[0..nb)   (fixed order, fp64, single workgroup)
 int launch_finalize(const double* a, int64_t na, const double* b, int64_t nb, double* out,
                     int accumulate_a, int write_b, hipStream_t st);
+int launch_copy_rows(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t n, int32_t W, hipStream_t st);
 int launch_pack_mlp(const GnfMlp* mlp, float* packed, hipStream_t st);
 int64_t packed_floats(const GnfMlp* mlp);
 

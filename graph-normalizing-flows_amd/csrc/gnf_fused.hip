@@ -115,6 +115,8 @@ struct FusedArgs {
     const int32_t* col;
     const float* x_cond;
     float* x_upd;
+    const float* x_upd_src;              // old value of the updated half (= x_upd, or the source buffer of an out-of-place first step)
+    float* cond_copy;                    // NULL, or where this tile's rows of the conditioning half are copied to (out-of-place first step)
     double* partials;
     float* st_out[2];                    // NETS = 1: global [N, H] scratch for s (0) and t (1)
     const float* h0[2];                  // precomputed layer-0 input per net ([N, in0], attention GNNs) or NULL
@@ -137,6 +139,7 @@ struct FusedArgs {
 };
 
 #ifdef GNF_TRACE  // developer build only: per-wave cycle stamps of workgroup 0
+#define GNF_TRACE_GLOBALS 1
 __device__ unsigned long long g_trace[8][16];
 __device__ unsigned long long g_stage[8][40];  // per-stage stamps of the traced layer
 __device__ int g_trace_layer = 1;
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
             if (NETS == 2) buf(1, 0)[rl * LS + c] = live ? a.h0[1][(int64_t)r * a.in0 + c] : 0.f;
         }
     } else {
-        const TileAgg ta{a.col, a.x_cond, a.ld, a.n_nodes, row0, H, a.in0, a.ipg[0] * 16, a.mean, a.concat, a.eps};
+        const TileAgg ta{a.col, a.x_cond, a.ld, a.n_nodes, row0, H, a.in0, a.ipg[0] * 16, a.mean, a.concat, a.eps, a.cond_copy};
         tile_aggregate<TM, kFusedThreads, kColCap>(ta, s_rowptr, s_col, buf(0, 0), NETS == 2 ? buf(1, 0) : nullptr, LS,
                                                    nullptr, tid);
     }  // message-passing prologue
@@ -399,9 +402,8 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
                     sv += xr;
                     tv += xr;
                 }
-                float* px = a.x_upd + (int64_t)r * a.ld + f;
-                const float xv = *px;
-                *px = a.inverse ? (xv - tv) * expf(-sv) : xv * expf(sv) + tv;
+                const float xv = a.x_upd_src[(int64_t)r * a.ld + f];
+                a.x_upd[(int64_t)r * a.ld + f] = a.inverse ? (xv - tv) * expf(-sv) : xv * expf(sv) + tv;
                 local += (double)sv;
             }
         }
@@ -448,6 +450,8 @@ static size_t fused_lds_bytes(const GnfMlp* m, int MT, int NETS) {
 // does any shape of the fused forward kernel hold this MLP's activations in LDS? (else its packed copy is never read)
 bool fused_fits_lds(const GnfMlp* m) { return fused_lds_bytes(m, 1, 1) <= (size_t)kLdsLimit; }
 
+static void choose_shape(const HalfStep& hs, int* mt, int* nets);
+
 bool fused_supported(const HalfStep& hs) {
     const GnfMlp *s = hs.s_net, *t = hs.t_net;
     if (!s->packed || !t->packed) return false;
@@ -455,6 +459,15 @@ bool fused_supported(const HalfStep& hs) {
     for (int j = 0; j <= s->num_layers; ++j)
         if (s->dims[j] != t->dims[j]) return false;
     return fused_lds_bytes(s, 1, 1) <= (size_t)kLdsLimit;
+}
+
+// may this half-step run out of place (HalfStep.x_upd_src / cond_copy)?  Only the both-nets-per-workgroup kernel
+// gathers, copies and updates in one launch; attention nets take their layer-0 input from the front-end kernels.
+bool fused_supports_oop(const HalfStep& hs) {
+    if (!fused_supported(hs) || hs.s_net->attn) return false;
+    int mt, nets;
+    choose_shape(hs, &mt, &nets);
+    return nets == 2;
 }
 
 // (MT, NETS) choice, from measurements on MI355X at L=256, K=5 (profiles/):
@@ -504,6 +517,8 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
     a.col = hs.col;
     a.x_cond = hs.x_cond;
     a.x_upd = hs.x_upd;
+    a.x_upd_src = hs.x_upd_src ? hs.x_upd_src : hs.x_upd;
+    a.cond_copy = hs.cond_copy;
     a.partials = hs.partials;
     // NETS = 1 scratch: s [N,H] | t [N,H] at the head of the float scratch
     a.st_out[0] = scratch;
@@ -555,6 +570,10 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
         if (rc) return rc;
         *hs.n_partials = (int32_t)tiles;
         return GNF_OK;
+    }
+    if (hs.x_upd_src || hs.cond_copy) {
+        set_error("internal: out-of-place half-step on the one-net-per-workgroup shape (fused_supports_oop is false there)");
+        return GNF_EINVAL;
     }
     const unsigned grid = (unsigned)(8 * ((tiles + 3) / 4));  // 4 tile slots x 2 nets per group of 8 blocks
     rc = MT == 2 ? launch_shape<2, 1>(a, grid, lds, st) : launch_shape<1, 1>(a, grid, lds, st);

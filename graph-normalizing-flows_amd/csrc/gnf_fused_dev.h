@@ -91,7 +91,7 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
     constexpr int R = PF + 1;  // register ring: PF stages in flight + the one being consumed
     const int lrow = lane & 15, lgrp = lane >> 4;
     const int ipg = c.ipg, nt0 = c.nt0;
-#ifdef GNF_TRACE
+#ifdef GNF_TRACE_GLOBALS  // set by gnf_fused.hip in -DGNF_TRACE builds (the stamps live there)
     const bool trace_on = c.layer == g_trace_layer;
 #endif
     GNF_STAGE_STAMP(0);
@@ -240,12 +240,15 @@ struct TileAgg {
     int64_t ld;
     int n_nodes, row0, H, in0, in0p, mean, concat;
     float eps;
+    float* cond_copy = nullptr;  // NULL, or [n, H] destination (leading dimension ld) for the tile's own x_cond rows
 };
 
+// The gather itself.  s_rowptr[0 .. TM] and - when the segment is short enough (seg_len <= COLCAP) - s_col[0 .. seg_len)
+// must already be in LDS and visible (barrier behind the staging stores).
 template <int TM, int NTHR, int COLCAP>
-__device__ __forceinline__ void tile_aggregate(const TileAgg& t, const int* __restrict__ s_rowptr, int* __restrict__ s_col,
-                                               float* __restrict__ buf0, float* __restrict__ buf1, int LS,
-                                               float* __restrict__ h0_out, int tid) {
+__device__ __forceinline__ void tile_gather(const TileAgg& t, const int* __restrict__ s_rowptr, const int* __restrict__ s_col,
+                                            float* __restrict__ buf0, float* __restrict__ buf1, int LS,
+                                            float* __restrict__ h0_out, int tid) {
     const int seg_beg = s_rowptr[0];
     const int seg_len = s_rowptr[TM] - seg_beg;
 #ifdef GNF_NO_STAGE_CSR
@@ -253,10 +256,6 @@ __device__ __forceinline__ void tile_aggregate(const TileAgg& t, const int* __re
 #else
     const bool staged = seg_len <= COLCAP;  // workgroup-uniform
 #endif
-    if (staged)
-        for (int i = tid; i < seg_len; i += NTHR) s_col[i] = t.col[seg_beg + i];
-    __syncthreads();
-    GNF_PSTAMP(4);
     // sum of x_cond[nbr, f] over the incoming edges [beg, end) of one node, in edge order
     auto gather = [&](int beg, int end, const float* xf, auto colat) -> float {
         float s = 0.f;
@@ -295,6 +294,7 @@ __device__ __forceinline__ void tile_aggregate(const TileAgg& t, const int* __re
             const int f = c < H ? c : c - H;
             if (t.concat && c < H) {
                 v = t.x_cond[(int64_t)r * t.ld + f];
+                if (t.cond_copy) t.cond_copy[(int64_t)r * t.ld + f] = v;
             } else {
                 const int beg = s_rowptr[rl], end = s_rowptr[rl + 1];
                 const float* xf = t.x_cond + f;
@@ -304,13 +304,35 @@ __device__ __forceinline__ void tile_aggregate(const TileAgg& t, const int* __re
                     const int cnt = end - beg;
                     s = s / (float)(cnt > 1 ? cnt : 1);
                 }
-                v = t.concat ? s : t.eps * t.x_cond[(int64_t)r * t.ld + f] + s;
+                if (t.concat) {
+                    v = s;
+                } else {
+                    const float xc = t.x_cond[(int64_t)r * t.ld + f];
+                    if (t.cond_copy) t.cond_copy[(int64_t)r * t.ld + f] = xc;
+                    v = t.eps * xc + s;
+                }
             }
             if (h0_out) h0_out[(int64_t)r * t.in0 + c] = v;
         }
         buf0[rl * LS + c] = v;
         if (buf1) buf1[rl * LS + c] = v;
     }
+}
+
+// staging of the col segment (after the caller has put rowptr[row0 .. row0+TM] into s_rowptr and synchronised) + gather
+template <int TM, int NTHR, int COLCAP>
+__device__ __forceinline__ void tile_aggregate(const TileAgg& t, const int* __restrict__ s_rowptr, int* __restrict__ s_col,
+                                               float* __restrict__ buf0, float* __restrict__ buf1, int LS,
+                                               float* __restrict__ h0_out, int tid) {
+    const int seg_beg = s_rowptr[0];
+    const int seg_len = s_rowptr[TM] - seg_beg;
+#ifndef GNF_NO_STAGE_CSR
+    if (seg_len <= COLCAP)
+        for (int i = tid; i < seg_len; i += NTHR) s_col[i] = t.col[seg_beg + i];
+#endif
+    __syncthreads();
+    GNF_PSTAMP(4);
+    tile_gather<TM, NTHR, COLCAP>(t, s_rowptr, s_col, buf0, buf1, LS, h0_out, tid);
 }
 
 }  // namespace gnf

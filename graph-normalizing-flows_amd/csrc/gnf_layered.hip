@@ -409,6 +409,25 @@ __global__ __launch_bounds__(kFinalizeBlock) void k_finalize(const double* __res
     }
 }
 
+__global__ __launch_bounds__(256) void k_copy_rows2(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst,
+                                                    int64_t ldd, int64_t n, int W) {
+    const int64_t total = n * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / W;
+        const int f = (int)(i - r * W);
+        dst[r * ldd + f] = src[r * lds_ + f];
+    }
+}
+
+int launch_copy_rows(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t n, int32_t W, hipStream_t st) {
+    if (n == 0) return GNF_OK;
+    int64_t blocks = (n * W + 1023) / 1024;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_copy_rows2, dim3((unsigned)blocks), dim3(256), 0, st, src, lds_, dst, ldd, n, W);
+    GNF_LAUNCH_CHECK("k_copy_rows");
+    return GNF_OK;
+}
+
 int launch_finalize(const double* a, int64_t na, const double* b, int64_t nb, double* out,
                     int accumulate_a, int write_b, hipStream_t st) {
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinalizeBlock), 0, st, a, na, b, nb, out,

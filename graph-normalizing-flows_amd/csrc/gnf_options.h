@@ -14,7 +14,7 @@ namespace gnf {
 
 enum OptionId {
     OPT_FORCE_SHAPE = 0,     // fused forward workgroup shape <MT><NETS>, e.g. 21; 0 = by batch size
-    OPT_WHOLE_FLOW,          // 0 auto (persistent whole-flow kernel when the batch fits one tile per CU), 1 never, 2 always when legal
+    OPT_FLOW_NO_OOP,         // out-of-place flows: always copy first, then walk in place (A/B of the fused first step)
     OPT_ATTN_EDGE_TILED,     // attention forward: always the edge-tiled kernel
     OPT_ATTN_ROWS,           // attention forward: always the rows kernel
     OPT_ATTN_LANE_FEATURE,   // attention backward: lane-per-feature kernels instead of the rows kernels

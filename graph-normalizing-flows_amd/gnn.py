@@ -668,7 +668,12 @@ class GRevNet:
             raise ValueError(f"nodes must be [N, D] with even D (tf.split, gnn.py:306); got {tuple(x.shape)}")
         n, d = x.shape
         dev = x.device
-        out = x.to(torch.float32).clone(memory_format=torch.contiguous_format)  # TF ops are functional
+        # TF ops are functional: the result goes to a NEW buffer; the library reads `src` and writes `out`
+        # (gnf_grevnet_from_f32: no separate copy pass where the fused kernel runs the first half-step)
+        src = x.to(torch.float32)
+        if src.stride(1) != 1 and n > 0:
+            src = src.contiguous()
+        out = torch.empty((n, d), dtype=torch.float32, device=dev)
         flow = self._flow(d // 2, dev)
         if n == 0 and self._bn_sync_world() > 1:
             raise ValueError("sync_batch_norm: a rank with an empty shard cannot take part in the cross-rank moments "
@@ -681,9 +686,9 @@ class GRevNet:
             # sums_out: caller-owned fp64 buffer whose first two slots receive [logdet, sum z^2]
             sums = sums_out if sums_out is not None else torch.empty(2, dtype=torch.float64, device=dev)
         with torch.cuda.device(dev):
-            _abi.check(lib.gnf_grevnet_f32(C.byref(csr.desc), C.byref(flow), _abi.ptr(out), out.stride(0), d,
-                                           direction, _abi.ptr(sums), _abi.ptr(ws), ws_bytes,
-                                           _abi.stream_ptr(dev)), "gnf_grevnet_f32")
+            _abi.check(lib.gnf_grevnet_from_f32(C.byref(csr.desc), C.byref(flow), _abi.ptr(src), src.stride(0) if n else d,
+                                                _abi.ptr(out), d, d, direction, _abi.ptr(sums), _abi.ptr(ws), ws_bytes,
+                                                _abi.stream_ptr(dev)), "gnf_grevnet_f32")
         return out, sums
 
     # ---- the reference's methods --------------------------------------------------------------

@@ -167,8 +167,8 @@ typedef struct GnfFlow {
 
 int gnf_abi_version(void);
 /* ABI v6: developer options (kernel-generation A/B switches and launch-shape overrides that tools/ and the parity tests
- * use to reach every code path).  value 0 = automatic.  Names: force_shape (<MT><NETS>, e.g. 21), whole_flow (1 = never
- * take the persistent whole-flow forward kernel, 2 = take it whenever legal), attn_edge_tiled, attn_rows,
+ * use to reach every code path).  value 0 = automatic.  Names: force_shape (<MT><NETS>, e.g. 21), flow_no_oop,
+ * (out-of-place flows copy first instead of running the first half-step out of place), attn_edge_tiled, attn_rows,
  * attn_lane_feature, gemm_no_buf, gemm_lds_direct, gemm_no_splitk, layered_own_gemm, dw_grouped, dw_wide_units,
  * dw_wide_lds, dw_no_streamk, dw_no_buf, dw_debug, dw_late_fork, bwd_generic.  Process-wide, relaxed atomics: takes effect
  * for calls made after it returns.  Unknown name: GNF_EINVAL.  Nothing in the reference corresponds to these. */
@@ -231,6 +231,12 @@ int gnf_coupling_half_f32(const GnfCsr* csr, const GnfMlp* s_net, const GnfMlp* 
  * (gnn.py:310-313, 325-328) and every half-step of g followed by it (gnn.py:356-358, 369-371); see GnfBatchNorm. */
 int gnf_grevnet_f32(const GnfCsr* csr, const GnfFlow* flow, float* x, int64_t ld, int32_t D,
                     int32_t direction, double* sums, void* ws, size_t ws_bytes, gnf_stream_t stream);
+/* ABI v6: the same, out of place - what the reference's functional TF graph does (GRevNet.f / .g return NEW tensors,
+ * gnn.py:340-341, 373; the input graph stays intact): reads x_src[N, D] (leading dimension ld_src), leaves the result in
+ * x[N, D].  x_src == NULL or x_src == x: in place.  The first coupling half-step reads the source and writes the
+ * destination directly where the fused kernel runs it (no separate copy pass); otherwise one copy, then in place. */
+int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_src, int64_t ld_src, float* x, int64_t ld,
+                         int32_t D, int32_t direction, double* sums, void* ws, size_t ws_bytes, gnf_stream_t stream);
 
 /* Kernel D alone: *out = sum_{n,j} z[n,j]^2 in fp64 (device).  log_prob_zs =
  * -0.5 * (*out) - 0.5 * D * ln(2*pi) * N   (tfd.MultivariateNormalDiag(0,1).log_prob summed,
