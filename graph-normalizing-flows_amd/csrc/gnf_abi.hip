@@ -139,7 +139,10 @@ WorkspacePlan plan_workspace(int64_t n_nodes, int32_t H, const GnfMlp* net, int3
         for (int j = 1; j < net->num_layers; ++j) lmax = lmax > net->dims[j] ? lmax : net->dims[j];
     const int in0 = net ? net->dims[0] : ((combine == GNF_COMBINE_CONCAT) ? 2 * H : H);
     p.base_floats = (size_t)n_nodes * (size_t)(in0 + kLayeredActBufs * lmax + 2 * H);
-    p.scratch_floats = p.base_floats + attn_scratch_floats(net ? net->attn : nullptr, n_nodes, in0);
+    p.attn_pack_offset = p.base_floats + attn_scratch_floats(net ? net->attn : nullptr, n_nodes, in0);
+    p.attn_pack_per_net = net ? (attn_pack_floats(net->attn, H) + 63) / 64 * 64 : 0;
+    // (every net of the call: at most 2 per half-step and kind; weight sharing needs fewer)
+    p.scratch_floats = p.attn_pack_offset + p.attn_pack_per_net * (size_t)(4 * (n_halfsteps > 0 ? n_halfsteps : 1));
     p.total_bytes = p.partial_bytes + p.scratch_floats * sizeof(float);
     return p;
 }
@@ -416,6 +419,29 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
             if (rc) return rc;
         }
     }
+    // attention nets on a sparse batch: the weights of every net go into fragment order ONCE per call (one small launch)
+    // and the one-launch front-end of gnf_attn_front.hip runs per half-step (developer options attn_edge_tiled /
+    // attn_rows keep the two-launch kernels)
+    const float* attn_pack = nullptr;
+    if (n > 0 && n_nets > 0 && flow->s_nets[0].attn && csr->n_edges > 0 && csr->n_edges < 24 * n &&
+        !opt(OPT_ATTN_EDGE_TILED) && !opt(OPT_ATTN_ROWS) && attn_front_fused_ok(flow->s_nets[0].attn, H)) {
+        const GnfAttn* all[2 * 64];
+        if (2 * n_nets <= 128) {
+            for (int q = 0; q < n_nets; ++q) {
+                all[q] = flow->s_nets[q].attn;
+                all[n_nets + q] = flow->t_nets[q].attn;
+            }
+            rc = launch_attn_pack(all, 2 * n_nets, H, scratch + p.attn_pack_offset, st);
+            if (rc) return rc;
+            attn_pack = scratch + p.attn_pack_offset;
+        }
+    }
+    auto mark_attn = [&](HalfStep& hs, int half, int i) {
+        if (!attn_pack) return;
+        const int q = flow->weight_sharing ? half : half * T + i;
+        hs.attn_packed[0] = attn_pack + (size_t)q * p.attn_pack_per_net;
+        hs.attn_packed[1] = attn_pack + (size_t)(n_nets + q) * p.attn_pack_per_net;
+    };
     bool first = true;
     auto mark_first = [&](HalfStep& hs, int half) {
         if (!first) return;
@@ -456,6 +482,7 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
                                 partials + used, &np_,
                                 stash ? stash + (size_t)(2 * i + half) * stash_slot : nullptr, csr->n_edges};
                     mark_first(hs, half);
+                    mark_attn(hs, half, i);
                     rc = run_half(hs, scratch, st);
                     if (rc) return rc;
                     used += np_;
@@ -470,6 +497,7 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
                                 pick(flow, flow->s_nets, half, i), pick(flow, flow->t_nets, half, i),
                                 partials + used, &np_, nullptr, csr->n_edges};
                     mark_first(hs, half);
+                    mark_attn(hs, half, i);
                     rc = run_half(hs, scratch, st);
                     if (rc) return rc;
                     // partial slots are reused: the inverse pass has no log-det (gnn.py:343-373)

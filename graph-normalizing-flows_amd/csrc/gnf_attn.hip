@@ -534,7 +534,7 @@ size_t attn_stash_slot_floats(const GnfFlow* flow, int64_t n_nodes) {
 // nets: 1 or 2 attention blocks sharing x / topology; writes h0[q] ([N, in0]) for each.
 int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, const float* x, int64_t ldx,
                       int32_t H, const GnfAttn* const* at, int nets, int32_t in0, float* scratch,
-                      float* const* h0_out, hipStream_t st, int64_t n_edges) {
+                      float* const* h0_out, hipStream_t st, int64_t n_edges, bool need_qkv, const float* const* packed) {
     if (n == 0) return GNF_OK;
     const GnfAttn* a0 = at[0];
     for (int q = 1; q < nets; ++q)
@@ -546,6 +546,13 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
         }
     AttnArgs a;
     const size_t P = 2 * (size_t)a0->num_heads * a0->kq_dim + a0->v_dim;
+    // sparse batches (mean in-degree under ~24: the config-2 batch has 12): ONE launch, projections on the matrix
+    // cores per tile (gnf_attn_front.hip); dense batches (complete graphs) keep the per-node projection below
+    if (packed && packed[0] && n_edges > 0 && n_edges < 24 * n && attn_front_fused_ok(a0, H)) {
+        float* qkv_ptr[2] = {scratch, scratch + (size_t)(nets > 1 ? 1 : 0) * n * P};
+        return launch_attn_front_fused(rowptr, col, n, x, ldx, H, at, nets, in0, packed, need_qkv ? qkv_ptr : nullptr,
+                                       h0_out, st);
+    }
     for (int q = 0; q < 2; ++q) {
         const GnfAttn* t = at[q < nets ? q : 0];
         a.Wq[q] = t->Wq;

@@ -55,6 +55,8 @@ struct HalfStep {
     // (fused_supports_oop); everything else copies first.
     const float* x_upd_src = nullptr;
     float* cond_copy = nullptr;
+    // attention nets: fragment-order copies of this half-step's two attention blocks (launch_attn_pack), or NULL
+    const float* attn_packed[2] = {nullptr, nullptr};
 };
 bool fused_supports_oop(const HalfStep& hs);
 // floats of one half-step's slot in GnfFlow.attn_stash ( = attn_scratch_floats: [2][n][P] q|k|v, then [2][n][in0] h0)
@@ -78,6 +80,8 @@ struct WorkspacePlan {
     int64_t n_halfsteps;
     size_t partial_bytes;    // (n_halfsteps * stride + kMaxGaussBlocks + batch-norm moment partials) * 8, 256-aligned
     size_t bn_offset;        // doubles: start of the batch-norm moment partials inside the fp64 region
+    size_t attn_pack_offset; // floats: fragment-order attention weights of every net of the call, behind the attention region
+    size_t attn_pack_per_net;
     size_t scratch_floats;   // layered path activations (+ attention front-end region at its end)
     size_t base_floats;      // offset of the attention region inside the scratch
     size_t total_bytes;
@@ -143,9 +147,18 @@ int validate_flow_call(const GnfCsr* csr, const GnfFlow* flow, int64_t ld, int32
 // attention front-end (gnf_attn.hip)
 int validate_attn(const GnfAttn* at, const GnfMlp* mlp, int32_t H, const char* what);
 size_t attn_scratch_floats(const GnfAttn* at, int64_t n_nodes, int32_t in0);
+// need_qkv: the caller reads the per-node q | k | v block of `scratch` afterwards (backward pass, attention stash)
 int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, const float* x, int64_t ldx,
                       int32_t H, const GnfAttn* const* at, int nets, int32_t in0, float* scratch,
-                      float* const* h0_out, hipStream_t st, int64_t n_edges = 0);
+                      float* const* h0_out, hipStream_t st, int64_t n_edges = 0, bool need_qkv = true,
+                      const float* const* packed = nullptr);
+// one-launch front-end for sparse batches (gnf_attn_front.hip), weights pre-packed into fragment order once per flow call
+bool attn_front_fused_ok(const GnfAttn* at, int32_t H);
+size_t attn_pack_floats(const GnfAttn* at, int32_t H);
+int launch_attn_pack(const GnfAttn* const* at, int count, int32_t H, float* out, hipStream_t st);
+int launch_attn_front_fused(const int32_t* rowptr, const int32_t* col, int64_t n, const float* x, int64_t ldx, int32_t H,
+                            const GnfAttn* const* at, int nets, int32_t in0, const float* const* packed,
+                            float* const* qkv_out, float* const* h0_out, hipStream_t st);
 // dst[r, 0:W) += src[r, 0:W)
 int launch_add_rows(float* dst, int64_t ldd, const float* src, int64_t lds_, int64_t n, int32_t W, hipStream_t st);
 

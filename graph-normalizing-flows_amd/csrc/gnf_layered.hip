@@ -618,7 +618,8 @@ int launch_attn_pair(const HalfStep& hs, float* scratch, float** h0_pair, hipStr
     h0_pair[0] = region + 2 * (size_t)n * P;
     h0_pair[1] = h0_pair[0] + (size_t)n * in0;
     const GnfAttn* at[2] = {hs.s_net->attn, hs.t_net->attn};
-    return launch_attn_front(hs.rowptr, hs.col, n, hs.x_cond, hs.ld, hs.H, at, 2, in0, region, h0_pair, st, hs.n_edges);
+    return launch_attn_front(hs.rowptr, hs.col, n, hs.x_cond, hs.ld, hs.H, at, 2, in0, region, h0_pair, st, hs.n_edges,
+                             /*need_qkv=*/hs.attn_region != nullptr, hs.attn_packed);
 }
 
 int launch_coupling(const float* sbuf, const float* tbuf, const HalfStep& hs, const float* xres, hipStream_t st) {

@@ -122,7 +122,10 @@ def pred_adj(gnn_output, distance_fn=scaled_hacky_sigmoid_l2, max_nodes_per_grap
     n_node_host = gnn_output.n_node.cpu().tolist()          # sizes the output (the reference syncs here too)
     b = len(n_node_host)
     total = sum(n * n for n in n_node_host)
-    cap = int(max_nodes_per_graph) if max_nodes_per_graph is not None else (max(n_node_host) if b else 0)
+    largest = max(n_node_host) if b else 0
+    cap = int(max_nodes_per_graph) if max_nodes_per_graph is not None else largest
+    if cap < largest:   # the launch covers `cap` rows per graph: a smaller bound would leave blocks unwritten
+        raise ValueError(f"max_nodes_per_graph={cap} is below the largest graph of the batch ({largest} nodes)")
     dev = z.device
     out = torch.empty(max(total, 1), dtype=torch.float32, device=dev)
     off = torch.empty(b + 1, dtype=torch.int64, device=dev)

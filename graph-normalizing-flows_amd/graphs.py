@@ -65,6 +65,29 @@ def data_dicts_to_graphs_tuple(data_dicts, device=None):
     return g.to(device) if device is not None else g
 
 
+def check_graphs_tuple(graph):
+    """Host-side structural check of a hand-built GraphsTuple (batches made by data_dicts_to_graphs_tuple are
+    valid by construction): graph g's edges are the g-th n_edge slice of senders / receivers and both endpoints lie
+    inside graph g's node range - the block-diagonal layout gnf_build_csr relies on (it indexes per-graph LDS
+    histograms with `receiver - node_offset[g]` and does NOT re-check on the device).  Raises ValueError.
+    Synchronises (copies the index tensors to the host): call it once per dataset, not per step."""
+    n_node = graph.n_node.detach().cpu().numpy().astype(np.int64)
+    n_edge = graph.n_edge.detach().cpu().numpy().astype(np.int64)
+    s = graph.senders.detach().cpu().numpy().astype(np.int64)
+    r = graph.receivers.detach().cpu().numpy().astype(np.int64)
+    if n_node.sum() != graph.nodes.shape[0] or n_edge.sum() != len(s) or len(s) != len(r):
+        raise ValueError(f"GraphsTuple: sum(n_node)={n_node.sum()} vs {graph.nodes.shape[0]} nodes, "
+                         f"sum(n_edge)={n_edge.sum()} vs {len(s)} senders / {len(r)} receivers")
+    lo = np.repeat(np.concatenate([[0], np.cumsum(n_node)[:-1]]), n_edge)
+    hi = np.repeat(np.cumsum(n_node), n_edge)
+    bad = (s < lo) | (s >= hi) | (r < lo) | (r >= hi)
+    if bad.any():
+        e = int(np.flatnonzero(bad)[0])
+        raise ValueError(f"GraphsTuple: edge {e} ({int(s[e])} -> {int(r[e])}) leaves its graph's node range "
+                         f"[{int(lo[e])}, {int(hi[e])}): {int(bad.sum())} such edges")
+    return True
+
+
 def graphs_tuple_from_edge_lists(n_node, n_edge, senders_local, receivers_local, graph_ids, nodes,
                                  device=None):
     """Batch graphs stored as concatenated LOCAL edge lists (the data/*.npz format)."""
@@ -137,7 +160,8 @@ _CSR_CACHE_MAX = 16
 
 
 def csr_of(graph, by_sender=False):
-    """CSR of a GraphsTuple, cached on the identity of its senders/receivers tensors."""
+    """CSR of a GraphsTuple, cached on the identity of its senders/receivers tensors: the index tensors of a
+    batch must not be edited in place afterwards (make a new tensor, or call clear_csr_cache())."""
     key = (graph.senders.data_ptr(), graph.receivers.data_ptr(), int(graph.senders.shape[0]),
            int(graph.nodes.shape[0]), str(graph.senders.device), bool(by_sender))
     hit = _CSR_CACHE.get(key)

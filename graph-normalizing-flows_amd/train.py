@@ -60,6 +60,8 @@ class GRevNetTrainer:
         self._clip_ws = None     # scratch of the two-pass clip_by_norm
         self._stash = None       # attention front-end stash (uint8 device buffer), see loss_and_grads
         self.stash_attention = True          # False: recompute the attention front-end in the backward walk
+        self._arena_versions = None   # version counters of every parameter container when the arena was (re)built
+        self._arena_epoch = -1
         self._aux = None         # second HIP stream: the weight-gradient GEMMs overlap the backward walk
         self.overlap_weight_grads = True     # False: no auxiliary stream for the weight-gradient GEMMs
 
@@ -67,12 +69,25 @@ class GRevNetTrainer:
     def _ensure_arena(self, hdim, device):
         net = self.net
         net._flow(hdim, device)                      # builds lazily-initialised MLPs (Sonnet-style first connect)
-        if self.theta is not None and self.theta.device == torch.device(device):
-            return
+        from .gnn import _EPOCH
+        if self.theta is not None and self.theta.device == torch.device(device) and self._arena_epoch == _EPOCH[0]:
+            return                                   # no parameter container anywhere was touched since the arena was built
         mlps = net.mlps("s") + net.mlps("t")
         blocks = net.blocks("s") + net.blocks("t")
         attn_blocks = [b for b in blocks if getattr(b, "attn_params", None) is not None]
         bns = [b for half in net.bns for b in half] if net.use_batch_norm else []   # index half*T + i
+
+        def versions():
+            return (tuple(m.version for m in mlps), tuple(b.attn_version() for b in blocks), tuple(b.version for b in bns))
+        if self.theta is not None and self.theta.device == torch.device(device):
+            # the parameter containers were last (re)bound by this trainer: nothing to do.  Otherwise somebody called
+            # set_params / set_attn_params (or moved the net) since: their tensors live OUTSIDE theta, so Adam would go on
+            # updating a vector nothing reads - re-seat the arena on the new values (Adam moments kept when the
+            # model size is unchanged)
+            if self._arena_versions == versions():
+                self._arena_epoch = _EPOCH[0]
+                return
+        old_m, old_v = self.m, self.v
         sizes = []
         for m in mlps:
             for (w, b) in m.params:
@@ -126,8 +141,9 @@ class GRevNetTrainer:
         net._cache = None
         self.theta = theta
         self.grad = torch.zeros_like(theta)
-        self.m = torch.zeros_like(theta)
-        self.v = torch.zeros_like(theta)
+        keep = old_m is not None and old_m.numel() == total and old_m.device == theta.device
+        self.m = old_m if keep else torch.zeros_like(theta)
+        self.v = old_v if keep else torch.zeros_like(theta)
         self._offsets = torch.tensor(bounds, dtype=torch.int64, device=device)
         # gradient flow descriptor: same shapes, W / b pointing into self.grad
         n = len(net.mlps("s"))
@@ -171,6 +187,8 @@ class GRevNetTrainer:
         self._keep = (gs, gt, gbn, gattn)
         self._bns = bns
         self._attn_blocks = attn_blocks
+        self._arena_versions = versions()            # as left by the re-binding above
+        self._arena_epoch = _EPOCH[0]
 
     def named_gradients(self):
         """Gradients in the oracle / fixture container layout ({"s": [[mlp]*T, [mlp]*T], "t": ...}; mlp =

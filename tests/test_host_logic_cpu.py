@@ -259,3 +259,19 @@ def test_make_moons_is_sklearns_stream():
                 a = G.make_moons(n, noise, seed)
                 b = datasets.make_moons(n_samples=n, shuffle=True, noise=noise, random_state=seed)[0]
                 assert np.array_equal(a, b), (n, seed, noise)
+
+
+def test_check_graphs_tuple_rejects_cross_graph_edges_and_bad_counts():
+    """gnf_build_csr trusts the block-diagonal layout; check_graphs_tuple is the host-side validation for
+    hand-built batches."""
+    import torch
+    from gnf_amd.graphs import GraphsTuple, check_graphs_tuple, data_dicts_to_graphs_tuple
+    good = data_dicts_to_graphs_tuple([{"nodes": np.zeros((3, 2)), "senders": [0, 1, 2], "receivers": [1, 2, 0]},
+                                       {"nodes": np.zeros((2, 2)), "senders": [0, 1], "receivers": [1, 0]}])
+    assert check_graphs_tuple(good)
+    cross = good.replace(senders=torch.tensor([0, 1, 2, 3, 2], dtype=torch.int32))      # last edge: node 2 is in graph 0
+    with pytest.raises(ValueError, match="leaves its graph"):
+        check_graphs_tuple(cross)
+    short = good.replace(n_edge=torch.tensor([3, 1], dtype=torch.int32))
+    with pytest.raises(ValueError, match="sum\\(n_edge\\)"):
+        check_graphs_tuple(short)

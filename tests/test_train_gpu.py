@@ -542,3 +542,39 @@ def test_checkpoint_resume_reproduces_the_run(grid_small, tmp_path):
     assert la == lb
     torch.testing.assert_close(a.theta, b.theta, rtol=0, atol=0)
     torch.testing.assert_close(a.net.bns[1][0].moving_variance, b.net.bns[1][0].moving_variance, rtol=0, atol=0)
+
+
+def test_set_params_after_training_started_reseats_the_arena(grid_small):
+    """ADVICE r1: parameters replaced with set_params() after the first step live outside the trainer's flat arena;
+    the trainer must notice and re-seat the arena on them (Adam would otherwise keep updating a dead copy)."""
+    from gnf_amd.train import GRevNetTrainer
+    hp = dict(D=8, latent=16, K=2, T=2, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu",
+              weight_sharing=False)
+    nn, ne, s, r = _batch(grid_small, list(range(6)))
+    n = int(nn.sum())
+    x = np.random.default_rng(0).standard_normal((n, 8)).astype(np.float32)
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    p1 = O.make_grevnet_params(1, 4, 16, 2, 2, final_scale=0.3)
+    p2 = O.make_grevnet_params(2, 4, 16, 2, 2, final_scale=0.3)
+    net = make_product_grevnet(hp, p1)
+    tr = GRevNetTrainer(net, lr=1e-3, use_lr_decay=False)
+    tr.step(graph)
+    net.set_params(p2)                                  # new tensors, outside tr.theta
+    out = tr.loss_and_grads(graph)
+    ref = O.loss_and_grads(s, r, n, x, p2, 2)
+    assert abs(float(out["total_loss"]) - ref["total_loss"]) / n <= 1e-4      # the forward reads p2 ...
+    w_first = net.mlps("s")[0].params[0][0]
+    lo = tr.theta.data_ptr()
+    assert lo <= w_first.data_ptr() < lo + 4 * tr.theta.numel()               # ... and p2 now lives inside the arena
+    before = w_first.clone()
+    tr.apply_gradients()
+    torch.cuda.synchronize()
+    assert float((w_first - before).abs().max()) > 0                         # Adam moves the tensors the kernels read
+
+
+def test_pred_adj_rejects_a_launch_bound_below_the_largest_graph():
+    from gnf_amd.flow import pred_adj
+    z = np.zeros((12, 4), np.float32)
+    g = graph_from_arrays([5, 7], [0, 0], np.zeros(0, np.int32), np.zeros(0, np.int32), z, DEV)
+    with pytest.raises(ValueError, match="below the largest graph"):
+        pred_adj(g, max_nodes_per_graph=6)
