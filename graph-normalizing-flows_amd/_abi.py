@@ -99,6 +99,7 @@ _SIGNATURES = {
                                            C.POINTER(GnfFlow), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
                                            C.c_size_t, C.c_void_p, C.c_void_p]),
     "gnf_pack_flow": (C.c_int, [C.POINTER(GnfFlow), C.c_void_p]),
+    "gnf_bn_post_step_f32": (C.c_int, [C.POINTER(GnfFlow), C.c_int32, C.c_float, C.c_void_p]),
     "gnf_adam_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_void_p]),
     "gnf_clip_by_value_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p]),

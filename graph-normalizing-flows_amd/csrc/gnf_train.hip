@@ -1300,14 +1300,26 @@ struct BwdPlan {
     size_t g, invdeg, bnpart, st, wslab, bslab, qkv, dagg, stats, splitk;
     size_t splitk_each;  // floats of split-K scratch per net
     size_t h0, h0b, acts, gst, dpb, dh0, xc, dqkv, agg;
-    size_t set_stride;  // the dW operands exist twice: half-step k's dW GEMMs may run on the auxiliary stream while
-                        // half-step k-1's kernels already refill the other set
+    int n_sets;
+    size_t set_stride;  // the dW operands exist n_sets times: half-step k's dW GEMMs run on the auxiliary stream while
+                        // half-steps k+1, k+2 refill the other sets (with two sets the walk waited ~10 us per half-step
+                        // for the dW launch of two half-steps earlier to release the set it was about to refill)
     size_t total;
 };
 
 static inline size_t al64(size_t v) { return (v + 63) / 64 * 64; }  // keep every region 256-byte aligned
+// Operand sets of the dW GEMMs.  A set written by half-step k's backward kernel is read by its dW GEMMs on the auxiliary
+// stream; before a later half-step may refill it, the main stream has to wait for that dW launch.  Three sets: the wait
+// always finds its event fired.  (Measured, profiles/r2u_train_timeline.txt: each event record / wait between two
+// dependent kernels shows as ~6 us of command-processor latency in the rocprofv3 timeline, fired or not - but one set
+// per half-step, i.e. no wait on the main stream at all, changed nothing in the step time (2.41 vs 2.38 ms), and a
+// captured-graph replay of the whole step is 2 % faster than eager launches: the gaps belong to the cross-queue
+// dependency itself, not to the host or to the wait packets.  The generic code below still takes any set count.)
+static constexpr int kBwdMaxSets = 64;
+static constexpr int kBwdSetsDefault = 3;
 
-static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net) {
+// n_sets: operand sets (one per half-step of the walk, capped: see kBwdMaxSets)
+static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net, int n_sets) {
     BwdPlan p;
     memset(&p, 0, sizeof(p));
     p.n = n;
@@ -1378,7 +1390,11 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net) {
     p.dqkv = off, off += 2 * al64((size_t)n * p.P);
     p.agg = off, off += 2 * al64((size_t)n * p.NV);
     p.set_stride = off - set0;
-    off += p.set_stride;                                      // second set
+    // ... as long as the sets stay within ~4 GiB (large batches: the kernels are long, the event latency is noise)
+    const int64_t fit = (int64_t)(((size_t)1 << 30) / (p.set_stride ? p.set_stride : 1));  // 2^30 floats
+    if (n_sets > fit) n_sets = (int)fit;
+    p.n_sets = n_sets < 3 ? 3 : (n_sets > kBwdMaxSets ? kBwdMaxSets : n_sets);
+    off += (size_t)(p.n_sets - 1) * p.set_stride;             // the other sets
     p.total = off;
     return p;
 }
@@ -1979,7 +1995,7 @@ extern "C" {
 
 size_t gnf_backward_workspace_bytes(int64_t n_nodes, int32_t D, const GnfFlow* flow) {
     if (n_nodes < 0 || D < 2 || (D & 1) || !flow || !flow->s_nets) return 0;
-    return plan_backward(n_nodes, D, &flow->s_nets[0]).total * sizeof(float);
+    return plan_backward(n_nodes, D, &flow->s_nets[0], kBwdSetsDefault).total * sizeof(float);
 }
 
 int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFlow* flow, const GnfFlow* grad,
@@ -2037,7 +2053,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     const int64_t n = csr->n_nodes;
     hipStream_t st = (hipStream_t)stream;
     if (n_nets == 0) return GNF_OK;
-    const BwdPlan p = plan_backward(n, D, &flow->s_nets[0]);
+    const BwdPlan p = plan_backward(n, D, &flow->s_nets[0], kBwdSetsDefault);
     if (n > 0 && (!z || !ws || ws_bytes < p.total * sizeof(float))) {
         set_error("gnf_grevnet_backward_f32: workspace %zu < %zu bytes (or null z/ws)", ws_bytes,
                   p.total * sizeof(float));
@@ -2088,23 +2104,28 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             GNF_LAUNCH_CHECK("k_invdeg");
         }
     }
-    // fork / join events of the weight-gradient stream: three flag-only events owned by THIS call (created on the
-    // current device, destroyed when the call returns - hipEventDestroy defers the release until the recorded work has
-    // completed), so concurrent callers, other devices and stream capture never share one
+    // fork / join events of the weight-gradient stream: flag-only events owned by THIS call (created on the current
+    // device, destroyed when the call returns - hipEventDestroy defers the release until the recorded work has
+    // completed), so concurrent callers, other devices and stream capture never share one.  ev[0]: "this half-step's
+    // operands are ready" (recorded on the main stream, waited for by the auxiliary one); ev[1 + set]: "the dW launch
+    // that read operand set `set` is done" - needed before a set is refilled (flows with more half-steps than sets) and,
+    // for the last launch, as the final join.
     hipStream_t aux = (hipStream_t)aux_stream;
     if (aux == st) aux = nullptr;
+    const bool reuse_sets = 2 * T > p.n_sets;
     struct CallEvents {
-        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+        hipEvent_t ev[kBwdMaxSets + 1] = {};
         ~CallEvents() {
             for (hipEvent_t e : ev)
                 if (e) (void)hipEventDestroy(e);
         }
     } call_events;
     if (aux)
-        for (hipEvent_t& e : call_events.ev) GNF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    hipEvent_t* const g_ev = call_events.ev;
-    const hipEvent_t ev_ready = call_events.ev[2];
-    hipEvent_t ev_done[2] = {nullptr, nullptr};
+        for (int q = 0; q < (reuse_sets ? p.n_sets + 1 : 2); ++q)
+            GNF_HIP_TRY(hipEventCreateWithFlags(&call_events.ev[q], hipEventDisableTiming));
+    const hipEvent_t ev_ready = call_events.ev[0];
+    hipEvent_t ev_done[kBwdMaxSets] = {};
+    hipEvent_t ev_last = nullptr;
     int step = 0;
     bool used[2] = {false, false};  // weight sharing: the T uses of a net accumulate
     for (int i = T - 1; i >= 0; --i)
@@ -2117,7 +2138,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             const bool no_fused = opt(OPT_BWD_GENERIC) != 0;  // developer A/B option
             const bool attn = nets[0]->attn != nullptr;
             const bool fused = !no_fused && fused_bwd_supported(nets[0], nets[1]);
-            const int set = step & 1;
+            const int set = step % p.n_sets;
             BwdOperands o = bwd_operands(p, wsf, set, attn);
             // attention front-end left behind by the forward pass (GnfFlow.attn_stash): q | k | v and the layer-0
             // inputs of both nets are read from the half-step's slot instead of being recomputed
@@ -2131,8 +2152,8 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 }
             }
             float* x_cond = z + co;
-            // this set's previous reader (the dW GEMMs of two half-steps ago) must be done
-            if (aux && ev_done[set]) GNF_HIP_TRY(hipStreamWaitEvent(st, ev_done[set], 0));
+            // this set's previous reader (the dW GEMMs of n_sets half-steps ago) must be done
+            if (aux && reuse_sets && ev_done[set]) GNF_HIP_TRY(hipStreamWaitEvent(st, ev_done[set], 0));
             // ---- layer-0 inputs -------------------------------------------------------------------------
             if (attn) {   // recompute the attention front-end of both nets (q | k | v kept for the way back)
                 const GnfAttn* at[2] = {nets[0]->attn, nets[1]->attn};
@@ -2208,9 +2229,11 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 if (fused && !attn) fused_bwd_launch_shape(nets[0], n, &bwd_tiles, &bwd_lds);
                 rc = launch_weight_grads(p, dw_policy(nets[0], bwd_tiles, bwd_lds), jobs, nj, acc, wsf, wst);
                 if (rc) return rc;
-                if (aux) {
-                    GNF_HIP_TRY(hipEventRecord(g_ev[set], aux));
-                    ev_done[set] = g_ev[set];
+                if (aux && (reuse_sets || step == 2 * T - 1)) {
+                    hipEvent_t e = call_events.ev[1 + (reuse_sets ? set : 0)];
+                    GNF_HIP_TRY(hipEventRecord(e, aux));
+                    ev_done[set] = e;
+                    ev_last = e;
                 }
             }
             ++step;
@@ -2221,8 +2244,54 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 if (rc) return rc;
             }
         }
-    for (int q = 0; q < 2; ++q)  // join: the gradients are complete on `stream`
-        if (aux && ev_done[q]) GNF_HIP_TRY(hipStreamWaitEvent(st, ev_done[q], 0));
+    // join: the auxiliary stream runs its launches in order, so the last one's event covers them all
+    if (aux && ev_last) GNF_HIP_TRY(hipStreamWaitEvent(st, ev_last, 0));
+    return GNF_OK;
+}
+
+// After an optimiser step, for every batch-norm bijector of the flow in ONE launch (was 4 torch elementwise launches
+// per bijector): the gamma_constraint projection relu(gamma) + 1e-6 (gnn.py:261-262) and tf.layers' UPDATE_OPS
+// moving <- moving * momentum + batch * (1 - momentum) (run_grevnet.py:360).
+struct BnPostBatch {
+    GnfBatchNorm bn[48];
+    int32_t H;
+    float momentum;
+};
+__global__ __launch_bounds__(256) void k_bn_post_step(const BnPostBatch b) {
+    const GnfBatchNorm bn = b.bn[blockIdx.x];
+    float* gamma = const_cast<float*>(bn.gamma);
+    float* mm = const_cast<float*>(bn.moving_mean);
+    float* mv = const_cast<float*>(bn.moving_variance);
+    for (int f = threadIdx.x; f < b.H; f += 256) {
+        gamma[f] = fmaxf(gamma[f], 0.f) + 1e-6f;
+        mm[f] = mm[f] * b.momentum + bn.batch_mean[f] * (1.f - b.momentum);
+        mv[f] = mv[f] * b.momentum + bn.batch_variance[f] * (1.f - b.momentum);
+    }
+}
+
+int gnf_bn_post_step_f32(const GnfFlow* flow, int32_t H, float momentum, gnf_stream_t stream) {
+    if (!flow || H < 1 || !(momentum >= 0.f && momentum <= 1.f)) {
+        set_error("gnf_bn_post_step_f32: bad arguments");
+        return GNF_EINVAL;
+    }
+    if (!flow->bns) return GNF_OK;
+    const int total = 2 * flow->num_timesteps;
+    for (int q = 0; q < total; ++q) {
+        const GnfBatchNorm& bn = flow->bns[q];
+        if (!bn.gamma || !bn.moving_mean || !bn.moving_variance || !bn.batch_mean || !bn.batch_variance) {
+            set_error("gnf_bn_post_step_f32: bijector %d has a null pointer", q);
+            return GNF_EINVAL;
+        }
+    }
+    for (int base = 0; base < total; base += 48) {
+        BnPostBatch b;
+        const int nb = total - base < 48 ? total - base : 48;
+        for (int q = 0; q < nb; ++q) b.bn[q] = flow->bns[base + q];
+        b.H = H;
+        b.momentum = momentum;
+        hipLaunchKernelGGL(k_bn_post_step, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, b);
+        GNF_LAUNCH_CHECK("k_bn_post_step");
+    }
     return GNF_OK;
 }
 

@@ -32,6 +32,37 @@ def exponential_decay(learning_rate, global_step, decay_steps, decay_rate, stair
     return learning_rate * decay_rate ** p
 
 
+class _StepTerms(dict):
+    """values_map of a training iteration (run_grevnet.py:290-302).  The two batch sums come out of the flow as device
+    fp64 scalars; every derived scalar (log_prob_zs, total_loss, the *_per_node values ...) is a few 0-d torch
+    operations that are only launched when somebody asks for the value (a training loop that logs every n-th step
+    pays for them every n-th step, not ~10 small launches per iteration)."""
+    _DERIVED = ("log_det_jacobian", "log_prob_zs", "log_prob_xs", "total_loss", "loss_per_node", "log_prob_xs_per_node",
+                "log_prob_zs_per_node", "log_det_jacobian_per_node")
+
+    def __init__(self, z_graph, reconstruction, sums, n, d):
+        super().__init__(z_graph=z_graph, reconstruction=reconstruction, num_nodes=float(n), sums=sums)
+        self._n, self._d = float(n), int(d)
+
+    def __missing__(self, key):
+        if key not in self._DERIVED:
+            raise KeyError(key)
+        sums, n = dict.__getitem__(self, "sums"), self._n
+        logdet = sums[0]
+        log_prob_zs = -0.5 * sums[1] - 0.5 * self._d * LN_2PI * n
+        log_prob_xs = log_prob_zs + logdet
+        vals = {"log_det_jacobian": logdet, "log_prob_zs": log_prob_zs, "log_prob_xs": log_prob_xs,
+                "total_loss": -log_prob_xs, "loss_per_node": -log_prob_xs / n, "log_prob_xs_per_node": log_prob_xs / n,
+                "log_prob_zs_per_node": log_prob_zs / n, "log_det_jacobian_per_node": logdet / n}
+        return vals[key]   # not cached: `sums` may be rewritten in place (captured-graph replay)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._DERIVED
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+
 class GRevNetTrainer:
     """total_loss, its gradient and the Adam update for one GRevNet (message-passing GNNs with or without the
     batch-norm bijectors, and the edge-list attention GNN: every variable the reference's optimizer would see).
@@ -261,11 +292,9 @@ class GRevNetTrainer:
     def _loss_and_grads(self, graph, n, d, dev):
         lib = _abi.lib()
         net = self.net
-        z_graph, _ = net(graph, inverse=True)                     # f: fused forward kernels
-        sums = net.last_sums
-        logdet = sums[0]
-        log_prob_zs = -0.5 * sums[1] - 0.5 * d * LN_2PI * n
-        log_prob_xs = log_prob_zs + logdet
+        z, sums = net._run(graph, _abi.GNF_FORWARD)               # f: fused forward kernels
+        net.last_sums = sums
+        z_graph = graph.replace(nodes=z)
         flow = net._flow(d // 2, dev)
         csr, csr_t = csr_of(graph), csr_of(graph, by_sender=True)
         ws_bytes = lib.gnf_backward_workspace_bytes(n, d, C.byref(flow))
@@ -282,11 +311,7 @@ class GRevNetTrainer:
                                                     _abi.ptr(self._ws), ws_bytes, _abi.stream_ptr(dev),
                                                     C.c_void_p(self._aux.cuda_stream if self._aux is not None else 0)),
                        "gnf_grevnet_backward_f32")
-        num_nodes = float(n)
-        return {"z_graph": z_graph, "reconstruction": state, "log_det_jacobian": logdet, "log_prob_zs": log_prob_zs,
-                "log_prob_xs": log_prob_xs, "total_loss": -log_prob_xs, "num_nodes": num_nodes,
-                "loss_per_node": -log_prob_xs / num_nodes, "log_prob_xs_per_node": log_prob_xs / num_nodes,
-                "log_prob_zs_per_node": log_prob_zs / num_nodes, "log_det_jacobian_per_node": logdet / num_nodes}
+        return _StepTerms(z_graph, state, sums, n, d)
 
     # ---- apply_gradients -----------------------------------------------------------------------
     def current_learning_rate(self):
@@ -321,9 +346,8 @@ class GRevNetTrainer:
             flow = self.net._flow(h, dev)
             if self.net.fused:
                 _abi.check(lib.gnf_pack_flow(C.byref(flow), st), "gnf_pack_flow")
-        for b in self._bns:        # gamma_constraint projection (gnn.py:261-262) + UPDATE_OPS (run_grevnet.py:360)
-            b.apply_gamma_constraint()
-            b.update_moving_statistics()
+            if self._bns:          # gamma_constraint projection (gnn.py:261-262) + UPDATE_OPS (run_grevnet.py:360), one launch
+                _abi.check(lib.gnf_bn_post_step_f32(C.byref(flow), h, self._bns[0].momentum, st), "gnf_bn_post_step_f32")
         self.global_step = t
 
     # ---- checkpoint / resume (the drivers use tf.train.Saver, run_grevnet.py:379, 449-453) ---------------------

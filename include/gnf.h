@@ -288,6 +288,13 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
  * launches; call after an optimiser step.  Nothing in the reference (weight pre-pack). */
 int gnf_pack_flow(const GnfFlow* flow, gnf_stream_t stream);
 
+/* ABI v6: what follows the optimiser step for the batch-norm bijectors of a flow, all 2T of them in one launch:
+ * gamma <- relu(gamma) + 1e-6 (the gamma_constraint of make_batch_norm, gnn.py:261-262, which TF projects after
+ * apply_gradients) and the moving-average update tf.layers.BatchNormalization registers in UPDATE_OPS
+ * (run_grevnet.py:360): moving <- moving * momentum + batch * (1 - momentum), with the batch moments the last
+ * gnf_grevnet_f32(GNF_FORWARD) left in batch_mean / batch_variance.  H = D/2.  No-op without bijectors. */
+int gnf_bn_post_step_f32(const GnfFlow* flow, int32_t H, float momentum, gnf_stream_t stream);
+
 /* tf.train.AdamOptimizer.apply_gradients on one flat fp32 parameter vector (run_grevnet.py:352-356, 375):
  *   m <- b1 m + (1-b1) g;  v <- b2 v + (1-b2) g^2;  w <- w - lr_t m / (sqrt(v) + epsilon)
  * lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) is computed by the caller (TF does it on the host side too). */
