@@ -14,7 +14,7 @@ static thread_local char g_err[512] = "";
 std::atomic<int64_t> g_options[OPT_COUNT];  // zero-initialised: every option "auto"
 
 static const char* const kOptionNames[OPT_COUNT] = {
-    "force_shape",     "flow_no_oop",    "attn_edge_tiled",  "attn_rows",    "attn_lane_feature", "gemm_no_buf",
+    "force_shape",     "fused_variant",  "flow_no_oop",    "attn_edge_tiled",  "attn_rows",    "attn_lane_feature", "gemm_no_buf",
     "gemm_lds_direct", "gemm_no_splitk", "layered_own_gemm", "dw_grouped",   "dw_wide_units",     "dw_wide_lds",
     "dw_no_streamk",   "dw_no_buf",      "dw_debug",         "dw_late_fork", "bwd_generic"};
 

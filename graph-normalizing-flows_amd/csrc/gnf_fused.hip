@@ -135,6 +135,7 @@ struct FusedArgs {
     int32_t bias_tot;  // floats of bias per net in LDS
     int32_t mean, concat, act, inverse;
     int32_t residual;  // attention block with residual: s, t += x_cond (gnn.py:547-548)
+    int32_t variant;   // developer A/B bits (gnf_set_option("fused_variant", ...)); 0 = shipped behaviour
     float eps, alpha;
 };
 
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
     GNF_STAMP(0);
     // ---- weights of the first chunk start streaming before anything else -----------------------
     f32x4 b_pre[kPF][4];
-    prefetch_chunk(cur, WPN, voff, b_pre);
+    prefetch_chunk(cur, WPN, voff, b_pre, MT == 1 && !(a.variant & 1));
     GNF_PSTAMP(0);
     // ---- every independent global read of the prologue is ISSUED before any is consumed: rowptr of
     // the tile, the biases (<= 8 floats per thread in registers), the layer table - one memory round
@@ -361,14 +362,18 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
             const WChunk nxt = next_chunk(c);
             const WChunk nx = nxt.layer < a.K ? nxt : c;  // no next chunk: harmless re-load
             const float* bl = bias_lds + nl * a.bias_tot + c.boff;
+            constexpr bool kThin = MT == 1;  // the thin-chunk form keeps 32 fragments in registers: one M-tile only
+            const bool thin_ok = kThin && !(a.variant & 1);
             if (c.nv >= 4)
-                mlp_chunk<MT, 4>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre);
+                mlp_chunk<MT, 4>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, EpiArgs{}, thin_ok);
             else if (c.nv == 3)
-                mlp_chunk<MT, 3>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre);
+                mlp_chunk<MT, 3>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, EpiArgs{}, thin_ok);
             else if (c.nv == 2)
-                mlp_chunk<MT, 2>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre);
+                mlp_chunk<MT, 2>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, EpiArgs{}, thin_ok);
+            else if (kThin && thin_ok && chunk_is_thin(c))
+                mlp_chunk_thin(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre);
             else
-                mlp_chunk<MT, 1>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre);
+                mlp_chunk<MT, 1>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, EpiArgs{}, thin_ok);
             cur = nxt;
         }
         pp ^= 1;
@@ -517,6 +522,7 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
     a.col = hs.col;
     a.x_cond = hs.x_cond;
     a.x_upd = hs.x_upd;
+    a.variant = (int32_t)opt(OPT_FUSED_VARIANT);
     a.x_upd_src = hs.x_upd_src ? hs.x_upd_src : hs.x_upd;
     a.cond_copy = hs.cond_copy;
     a.partials = hs.partials;

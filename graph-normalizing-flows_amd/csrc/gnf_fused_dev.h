@@ -47,9 +47,27 @@ static constexpr int kPF = GNF_PF;
 // Issue the loads of the first kPF stages of chunk c into b_pre (4 tile slots; slots >= c.nv repeat the
 // last valid tile).  Called one round BEFORE the previous chunk ends - and before the prologue for
 // the first chunk - so that a layer never starts by waiting a full L2 round trip for its weights.
-__device__ __forceinline__ void prefetch_chunk(const WChunk& c, int ts, int voff, f32x4 (&b_pre)[kPF][4]) {
+// A THIN chunk (one column tile, at most kThinStages k-groups: the 256 -> 32 output layer of the reference's MLPs) has
+// only 4 MFMAs per stage to hide a weight load behind; its prefetch uses the four tile slots for four consecutive
+// STAGES instead of repeating the one tile (stages 0 .. 4 kPF - 1), and mlp_chunk_thin requests the remaining stages at
+// once on entry: one exposed round trip per layer instead of one per stage.
+static constexpr int kThinStages = 16;
+__device__ __forceinline__ bool chunk_is_thin(const WChunk& c) { return c.nv == 1 && c.ipg <= kThinStages; }
+
+__device__ __forceinline__ void prefetch_chunk(const WChunk& c, int ts, int voff, f32x4 (&b_pre)[kPF][4],
+                                               bool thin_ok = false) {
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.wbase), 0, (int)c.wbytes, 0x00020000);
+    if (thin_ok && chunk_is_thin(c)) {  // wave-uniform
+#pragma unroll
+        for (int u = 0; u < kPF; ++u)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int s = 4 * u + b, kn = s < c.ipg ? s : c.ipg - 1;
+                b_pre[u][b] = GNF_LOAD_B(rsrc, voff, (kn * c.ont + c.nt0) * 1024);
+            }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < kPF; ++u) {
         const int kn = u < c.ipg ? u : c.ipg - 1;
@@ -82,11 +100,50 @@ struct EpiArgs {
     float act_slope;           // act' on the negative side (alpha, or 0 for relu)
 };
 
+// One-tile chunk with every stage's operands in flight before the first MFMA (see chunk_is_thin).  Same arithmetic and
+// the same k order as mlp_chunk<1, 1>: bitwise the same result.  b_pre holds stages 0 .. 4 kPF - 1 (thin packing).
+__device__ __forceinline__ void mlp_chunk_thin(const float* __restrict__ in_lds, int LS, const WChunk& c, const WChunk& nx,
+                                               int ts, const float* __restrict__ bias_lds, float* __restrict__ out_lds,
+                                               float slope, int lane, f32x4 (&b_pre)[kPF][4]) {
+    constexpr int NS = kThinStages, NP = 4 * kPF;
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    const int ipg = c.ipg;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.wbase), 0, (int)c.wbytes, 0x00020000);
+    const int voff = lane * 16;
+    f32x4 bst[NS], ast[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s < NP)
+            bst[s] = b_pre[s / 4][s % 4];
+        else
+            bst[s] = GNF_LOAD_B(rsrc, voff, ((s < ipg ? s : ipg - 1) * c.ont + c.nt0) * 1024);
+    }
+    const float* arow = in_lds + lrow * LS + 4 * lgrp;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) ast[s] = *reinterpret_cast<const f32x4*>(arow + 16 * (s < ipg ? s : ipg - 1));
+    const float bias = bias_lds[16 * c.nt0 + lrow];
+    f32x4 acc = {bias, bias, bias, bias};
+    prefetch_chunk(nx, ts, voff, b_pre, true);  // (b_pre was copied above)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        if (s < ipg) {  // wave-uniform
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ast[s][q], bst[s][q], acc, 0, 0, 0);
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float v = acc[r];
+        out_lds[(4 * lgrp + r) * LS + 16 * c.nt0 + lrow] = fmaxf(v, slope * v);
+    }
+}
+
 template <int MT, int NV, int EPI = EPI_PLAIN>
 __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int LS, const WChunk& c,
                                           const WChunk& nx, int ts, const float* __restrict__ bias_lds,
                                           float* __restrict__ out_lds, float slope, int lane,
-                                          f32x4 (&b_pre)[kPF][4], const EpiArgs& ea = EpiArgs{}) {
+                                          f32x4 (&b_pre)[kPF][4], const EpiArgs& ea = EpiArgs{}, bool thin_ok = false) {
     constexpr int PF = kPF;
     constexpr int R = PF + 1;  // register ring: PF stages in flight + the one being consumed
     const int lrow = lane & 15, lgrp = lane >> 4;
@@ -174,12 +231,12 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
         }
         // the next chunk's first stages go out one round early: they land while the last round's
         // MFMAs, the output write-back and the layer barrier are in progress
-        prefetch_chunk(nx, ts, voff, b_pre);
+        prefetch_chunk(nx, ts, voff, b_pre, thin_ok);
         __builtin_amdgcn_sched_barrier(0);
         GNF_ROUND(kg0)
         kg0 += R;
     } else {
-        prefetch_chunk(nx, ts, voff, b_pre);
+        prefetch_chunk(nx, ts, voff, b_pre, thin_ok);
         __builtin_amdgcn_sched_barrier(0);
     }
     // tail: the last ipg % R stages are already in flight in slots 0 .. rem-1

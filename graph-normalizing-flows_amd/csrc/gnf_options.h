@@ -14,6 +14,7 @@ namespace gnf {
 
 enum OptionId {
     OPT_FORCE_SHAPE = 0,     // fused forward workgroup shape <MT><NETS>, e.g. 21; 0 = by batch size
+    OPT_FUSED_VARIANT,       // fused forward kernel: A/B bits of in-kernel experiments (0 = shipped behaviour)
     OPT_FLOW_NO_OOP,         // out-of-place flows: always copy first, then walk in place (A/B of the fused first step)
     OPT_ATTN_EDGE_TILED,     // attention forward: always the edge-tiled kernel
     OPT_ATTN_ROWS,           // attention forward: always the rows kernel
