@@ -4,7 +4,8 @@ the committed golden fixtures.  Run on a real MI355X:  python -m pytest tests -m
 Tolerances (stated, fp32 path vs float64 oracle):
   per-node log-prob  |delta| <= 1e-4        (BASELINE.json north_star)
   z elementwise      atol 2e-4 + rtol 2e-4  (fp32 rounding through 2*T*K chained GEMMs + exp)
-  round trip         max|g(f(x)) - x| <= 2e-3 at fp32 for the deepest flows, 1e-4 for shallow ones
+  round trip         max|g(f(x)) - x| <= 5e-5 on the full-size configs (measured 2e-6 .. 6e-6; the CPU float32 restatement of
+                     the reference has 2.4e-6 on the config-2 batch; tests/test_fullsize_gpu.py derives the bound from it)
   integer work (CSR) bit-exact
 """
 import ctypes as C
@@ -220,15 +221,15 @@ def test_round_trip_at_full_size(community_medium):
     graph = graph_from_arrays(nn, ne, s, r, x, DEV)
     zg, ld = net(graph, inverse=True)
     back = net(zg, inverse=False).nodes
-    assert float((back - graph.nodes).abs().max()) <= 2e-3
+    assert float((back - graph.nodes).abs().max()) <= 5e-5
     z2, _ = net(net(graph, inverse=False), inverse=True)
-    assert float((z2.nodes - graph.nodes).abs().max()) <= 2e-3
+    assert float((z2.nodes - graph.nodes).abs().max()) <= 5e-5
     lay = make_product_grevnet(hp, p)
     lay.fused = False
     zl, ldl = lay(graph, inverse=True)
     torch.cuda.synchronize()
-    assert abs(float(ld) - float(ldl)) / n <= 2e-5
-    assert float((zl.nodes - zg.nodes).abs().max()) <= 1e-3
+    assert abs(float(ld) - float(ldl)) / n <= 2e-6
+    assert float((zl.nodes - zg.nodes).abs().max()) <= 5e-5
     # reproducibility: bitwise identical on a re-run (fixed-order reductions, no atomics)
     zg2, ld2 = net(graph, inverse=True)
     assert torch.equal(zg2.nodes, zg.nodes) and float(ld2) == float(ld)
@@ -536,7 +537,7 @@ def test_config4_full_size_inverse_round_trip():
     net = make_product_grevnet(hp, p)
     xg = net(graph, inverse=False)                       # sampling direction first (config 4)
     zb, _ = net(xg, inverse=True)
-    assert float((zb.nodes - graph.nodes).abs().max()) <= 3e-3
+    assert float((zb.nodes - graph.nodes).abs().max()) <= 5e-5
     full = log_prob_terms(net, graph)
     lay = make_product_grevnet(hp, p)
     lay.fused = False
@@ -569,13 +570,13 @@ def test_config5_full_size_properties():
     net = make_product_grevnet(hp, p)
     zg, ld = net(graph, inverse=True)
     back = net(zg, inverse=False).nodes
-    assert float((back - graph.nodes).abs().max()) <= 5e-3
+    assert float((back - graph.nodes).abs().max()) <= 1e-4
     lay = make_product_grevnet(hp, p)
     lay.fused = False
     zl, ldl = lay(graph, inverse=True)
     n = graph.nodes.shape[0]
-    assert abs(float(ld) - float(ldl)) / n <= 5e-5
-    assert float((zl.nodes - zg.nodes).abs().max()) <= 2e-3
+    assert abs(float(ld) - float(ldl)) / n <= 5e-6
+    assert float((zl.nodes - zg.nodes).abs().max()) <= 1e-4
     zg2, ld2 = net(graph, inverse=True)
     assert torch.equal(zg2.nodes, zg.nodes) and float(ld2) == float(ld)
 
