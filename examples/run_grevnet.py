@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--attn_concat_heads_output_dim", type=int, default=80)
     ap.add_argument("--no_attn_concat", action="store_true")
     ap.add_argument("--attn_residual", action="store_true")
+    ap.add_argument("--attn_layer_norm", action="store_true")
     ap.add_argument("--no_batch_norm", action="store_true")
     ap.add_argument("--dataset", default="moons_100", choices=sorted(DATASETS_MAP))
     ap.add_argument("--train_batch_size", type=int, default=32)
@@ -76,7 +77,7 @@ def main():
     make_gnn_fn = {
         "dm_self_attn": partial(gnn.dm_self_attn_gnn, kq_dim=F.attn_kq_dim, v_dim=F.attn_v_dim, make_mlp_fn=mlp(gnn.relu),
                                 num_heads=F.attn_num_heads, concat_heads_output_dim=F.attn_concat_heads_output_dim,
-                                concat=not F.no_attn_concat, residual=F.attn_residual, layer_norm=False),
+                                concat=not F.no_attn_concat, residual=F.attn_residual, layer_norm=F.attn_layer_norm),
         "avg_then_mlp": partial(gnn.avg_then_mlp_gnn, mlp(gnn.leaky_relu), F.gnn_avg_then_mlp_epsilon),
         "avg_concat_then_mlp": partial(gnn.avg_concat_then_mlp_gnn, mlp(gnn.leaky_relu)),
         "sum_concat_then_mlp": partial(gnn.sum_concat_then_mlp_gnn, mlp(gnn.leaky_relu)),

@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--no_batch_norm", action="store_true")
     ap.add_argument("--weight_sharing", action="store_true")
     ap.add_argument("--attn_type", default="avg_then_mlp", choices=["avg_then_mlp", "dm_attn"])
+    ap.add_argument("--use_layer_norm", action="store_true")
     ap.add_argument("--attn_kq_dim", type=int, default=10)
     ap.add_argument("--attn_v_dim", type=int, default=10)
     ap.add_argument("--attn_num_heads", type=int, default=8)
@@ -93,7 +94,7 @@ def main():
         "avg_then_mlp": partial(gnn.avg_then_mlp_gnn, make_mlp_fn, 1.0),
         "dm_attn": partial(gnn.dm_self_attn_gnn, kq_dim=F.attn_kq_dim, v_dim=F.attn_v_dim, make_mlp_fn=make_mlp_fn,
                            num_heads=F.attn_num_heads, concat_heads_output_dim=F.attn_concat_heads_output_dim,
-                           kq_dim_division=True, layer_norm=False),
+                           kq_dim_division=True, layer_norm=F.use_layer_norm),
     }[F.attn_type]
     grevnet = gnn.GRevNet(make_gnn_fn, F.num_coupling_layers, F.node_embedding_dim,
                           use_batch_norm=not F.no_batch_norm, weight_sharing=F.weight_sharing)

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 GNF_MAX_LAYERS = 8
-GNF_ABI_VERSION = 6
+GNF_ABI_VERSION = 7
 
 GNF_AGG_SUM, GNF_AGG_MEAN = 0, 1
 GNF_COMBINE_EPS, GNF_COMBINE_CONCAT = 0, 1
@@ -32,8 +32,8 @@ class GnfCsr(C.Structure):
 class GnfAttn(C.Structure):
     _fields_ = [("num_heads", C.c_int32), ("kq_dim", C.c_int32), ("v_dim", C.c_int32), ("out_dim", C.c_int32),
                 ("concat", C.c_int32), ("kq_dim_division", C.c_int32), ("residual", C.c_int32),
-                ("reserved", C.c_int32), ("Wq", C.c_void_p), ("Wk", C.c_void_p), ("Wv", C.c_void_p),
-                ("Wo", C.c_void_p)]
+                ("layer_norm", C.c_int32), ("Wq", C.c_void_p), ("Wk", C.c_void_p), ("Wv", C.c_void_p),
+                ("Wo", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p)]
 
 
 class GnfMlp(C.Structure):

@@ -107,6 +107,10 @@ static int validate_pair(const GnfMlp* s, const GnfMlp* t, const GnfGnnSpec* g, 
         if (rc) return rc;
         rc = validate_attn(t->attn, t, H, "t_net");
         if (rc) return rc;
+        if (memcmp(s->attn, t->attn, 8 * sizeof(int32_t))) {  // one make_gnn_fn builds both nets (gnn.py:288-296)
+            set_error("s_net and t_net attention front-ends must have identical hyper-parameters");
+            return GNF_ESHAPE;
+        }
     }
     if (s->num_layers != t->num_layers || memcmp(s->dims, t->dims, sizeof(int32_t) * (s->num_layers + 1))) {
         // one make_gnn_fn builds both nets of a coupling (gnn.py:288-296): identical layer widths

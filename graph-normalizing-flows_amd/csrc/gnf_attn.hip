@@ -345,6 +345,10 @@ int validate_attn(const GnfAttn* at, const GnfMlp* mlp, int32_t H, const char* w
         set_error("%s: residual needs MLP output width == H", what);
         return GNF_ESHAPE;
     }
+    if (at->layer_norm && (!at->ln_gamma || !at->ln_beta)) {
+        set_error("%s: layer_norm needs ln_gamma and ln_beta", what);
+        return GNF_EINVAL;
+    }
     return GNF_OK;
 }
 

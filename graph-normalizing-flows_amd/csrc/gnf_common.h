@@ -159,6 +159,26 @@ int launch_attn_pack(const GnfAttn* const* at, int count, int32_t H, float* out,
 int launch_attn_front_fused(const int32_t* rowptr, const int32_t* col, int64_t n, const float* x, int64_t ldx, int32_t H,
                             const GnfAttn* const* at, int nets, int32_t in0, const float* const* packed,
                             float* const* qkv_out, float* const* h0_out, hipStream_t st);
+// snt.LayerNorm over the feature axis of a block's output (gnn.py:550-552), one or two [N, W] blocks per launch:
+//   u = in (+ xres);  y = (u - mean_f u) / sqrt(var_f u + GNF_LN_EPS) * gamma + beta   (biased variance)
+// y may alias in.  u (may be NULL, may alias in; leading dimension ldin) keeps the un-normalised rows for the backward pass.
+struct LnJob {
+    const float* in;
+    float* y;
+    float* u;
+    const float* gamma;
+    const float* beta;
+};
+struct LnArgs {
+    LnJob job[2];
+    int64_t ldin, ldy;
+    const float* xres;  // residual rows added first (gnn.py:547-548), or NULL
+    int64_t ldx;
+    int64_t n;
+    int32_t W;
+};
+int launch_layer_norm(const LnArgs& a, int nets, hipStream_t st);
+int launch_half_layer_norm(const HalfStep& hs, float* sbuf, float* tbuf, const float* xres, hipStream_t st);
 // dst[r, 0:W) += src[r, 0:W)
 int launch_add_rows(float* dst, int64_t ldd, const float* src, int64_t lds_, int64_t n, int32_t W, hipStream_t st);
 

@@ -498,6 +498,9 @@ static void choose_shape(const HalfStep& hs, int* mt, int* nets) {
         const int fm = (int)(force / 10), fn = (int)(force % 10);
         if ((fm == 1 || fm == 2) && (fn == 1 || fn == 2) && fits(fm, fn)) m = fm, n = fn;
     }
+    // blocks that end in snt.LayerNorm (gnn.py:550-552): the normalisation needs whole rows of s and t before the
+    // coupling, which the one-net-per-workgroup shape already hands over through the global scratch
+    if (s->attn && s->attn->layer_norm) n = 1;
     *mt = m;
     *nets = n;
 }
@@ -584,6 +587,10 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
     const unsigned grid = (unsigned)(8 * ((tiles + 3) / 4));  // 4 tile slots x 2 nets per group of 8 blocks
     rc = MT == 2 ? launch_shape<2, 1>(a, grid, lds, st) : launch_shape<1, 1>(a, grid, lds, st);
     if (rc) return rc;
+    if (s->attn && s->attn->layer_norm) {
+        rc = launch_half_layer_norm(hs, a.st_out[0], a.st_out[1], nullptr, st);
+        if (rc) return rc;
+    }
     return launch_coupling(a.st_out[0], a.st_out[1], hs, nullptr, st);  // residual already added above
 }
 

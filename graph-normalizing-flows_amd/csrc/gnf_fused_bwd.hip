@@ -313,6 +313,7 @@ bool fused_bwd_fits_lds(const GnfMlp* m) { return bwd_lds_bytes(m, 1) <= (size_t
 
 bool fused_bwd_supported(const GnfMlp* s, const GnfMlp* t) {
     if (!s->packed || !t->packed) return false;
+    if (s->attn && s->attn->layer_norm) return false;  // snt.LayerNorm after the MLP: the generic path differentiates it
     if (s->num_layers != t->num_layers) return false;
     for (int j = 0; j <= s->num_layers; ++j)
         if (s->dims[j] != t->dims[j]) return false;

@@ -9,6 +9,7 @@
 //   linear    : gnn.py:159-180 (snt.nets.MLP)
 //   coupling  : gnn.py:322-323,337-338 (forward) / gnn.py:359,372 (inverse)
 //   gauss     : run_grevnet.py:292-294
+#include <cstring>
 #include "gnf_common.h"
 
 namespace gnf {
@@ -529,6 +530,44 @@ int launch_add_rows(float* dst, int64_t ldd, const float* src, int64_t lds_, int
     return GNF_OK;
 }
 
+// One wave per row, lanes along the features (three passes over a row that stays in L1/L2: mean, centred variance,
+// normalise - the two-pass variance is what tf.nn.moments computes).
+__global__ __launch_bounds__(256) void k_layer_norm(const LnArgs a) {
+    const LnJob j = a.job[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int W = a.W;
+    const float inv_w = 1.f / (float)W;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < a.n; r += (int64_t)gridDim.x * 4) {
+        const float* in = j.in + r * a.ldin;
+        const float* xr = a.xres ? a.xres + r * a.ldx : nullptr;
+        float sum = 0.f;
+        for (int f = lane; f < W; f += 64) sum += in[f] + (xr ? xr[f] : 0.f);
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        const float mean = sum * inv_w;
+        float sq = 0.f;
+        for (int f = lane; f < W; f += 64) {
+            const float d = in[f] + (xr ? xr[f] : 0.f) - mean;
+            sq = fmaf(d, d, sq);
+        }
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+        const float rstd = 1.f / sqrtf(sq * inv_w + GNF_LN_EPS);
+        for (int f = lane; f < W; f += 64) {
+            const float u = in[f] + (xr ? xr[f] : 0.f);
+            j.y[r * a.ldy + f] = (u - mean) * rstd * j.gamma[f] + j.beta[f];
+            if (j.u) j.u[r * a.ldin + f] = u;
+        }
+    }
+}
+
+int launch_layer_norm(const LnArgs& a, int nets, hipStream_t st) {
+    if (a.n == 0) return GNF_OK;
+    int64_t blocks = (a.n + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_layer_norm, dim3((unsigned)blocks, (unsigned)nets), dim3(256), 0, st, a);
+    GNF_LAUNCH_CHECK("k_layer_norm");
+    return GNF_OK;
+}
+
 static int lmax_of(const GnfMlp* m) {
     int lmax = 1;
     for (int j = 1; j < m->num_layers; ++j) lmax = lmax > m->dims[j] ? lmax : m->dims[j];
@@ -560,8 +599,33 @@ int launch_gnn_layered(const int32_t* rowptr, const int32_t* col, int64_t n, con
         rc = run_mlps(&mlp, 1, &h0c, in0, &bufA, &bufB, lmax, &out, ldo, n, g, st);
     }
     if (rc) return rc;
+    if (mlp->attn && mlp->attn->layer_norm) {  // residual add folded into the normalisation's first read
+        LnArgs a;
+        memset(&a, 0, sizeof(a));
+        a.job[0] = LnJob{out, out, nullptr, mlp->attn->ln_gamma, mlp->attn->ln_beta};
+        a.ldin = a.ldy = ldo;
+        a.xres = mlp->attn->residual ? x : nullptr;
+        a.ldx = ldx;
+        a.n = n;
+        a.W = mlp->dims[mlp->num_layers];
+        return launch_layer_norm(a, 1, st);
+    }
     if (mlp->attn && mlp->attn->residual) return launch_add_rows(out, ldo, x, ldx, n, H, st);
     return GNF_OK;
+}
+
+// s, t [N, H] (dense) of a half-step whose blocks end in snt.LayerNorm: normalised in place, both nets in one launch
+int launch_half_layer_norm(const HalfStep& hs, float* sbuf, float* tbuf, const float* xres, hipStream_t st) {
+    LnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.job[0] = LnJob{sbuf, sbuf, nullptr, hs.s_net->attn->ln_gamma, hs.s_net->attn->ln_beta};
+    a.job[1] = LnJob{tbuf, tbuf, nullptr, hs.t_net->attn->ln_gamma, hs.t_net->attn->ln_beta};
+    a.ldin = a.ldy = hs.H;
+    a.xres = xres;
+    a.ldx = hs.ld;
+    a.n = hs.n_nodes;
+    a.W = hs.H;
+    return launch_layer_norm(a, 2, st);
 }
 
 // scratch layout (floats): h0 [N,in0] | bufA,bufB (s) | bufA,bufB (t) | s [N,H] | t [N,H] | attention region: qkv x2, h0_s, h0_t
@@ -600,6 +664,11 @@ int launch_half_layered(const HalfStep& hs, float* scratch, hipStream_t st) {
     }
     if (rc) return rc;
     const bool res = hs.s_net->attn && hs.s_net->attn->residual;
+    if (hs.s_net->attn && hs.s_net->attn->layer_norm) {
+        rc = launch_half_layer_norm(hs, sbuf, tbuf, res ? hs.x_cond : nullptr, st);
+        if (rc) return rc;
+        return launch_coupling(sbuf, tbuf, hs, nullptr, st);
+    }
     return launch_coupling(sbuf, tbuf, hs, res ? hs.x_cond : nullptr, st);
 }
 

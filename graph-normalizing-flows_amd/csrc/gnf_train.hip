@@ -1297,7 +1297,7 @@ struct BwdPlan {
     // attention geometry (0 when the nets are message-passing GNNs)
     int nh, kq, vd, C, P, NV;
     // float offsets.  single: g, invdeg, bnpart, st, wslab, bslab, qkv, dagg, stats;  per set: the rest
-    size_t g, invdeg, bnpart, st, wslab, bslab, qkv, dagg, stats, splitk;
+    size_t g, invdeg, bnpart, st, wslab, bslab, qkv, dagg, stats, splitk, lny, lnpart;
     size_t splitk_each;  // floats of split-K scratch per net
     size_t h0, h0b, acts, gst, dpb, dh0, xc, dqkv, agg;
     int n_sets;
@@ -1315,6 +1315,7 @@ static inline size_t al64(size_t v) { return (v + 63) / 64 * 64; }  // keep ever
 // per half-step, i.e. no wait on the main stream at all, changed nothing in the step time (2.41 vs 2.38 ms), and a
 // captured-graph replay of the whole step is 2 % faster than eager launches: the gaps belong to the cross-queue
 // dependency itself, not to the host or to the wait packets.  The generic code below still takes any set count.)
+static constexpr int kLnBwdRows = 64;  // rows per workgroup of the layer-norm backward kernel
 static constexpr int kBwdMaxSets = 64;
 static constexpr int kBwdSetsDefault = 3;
 
@@ -1379,6 +1380,10 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net, int n_sets
     // fewer than 48 row tiles per net and one or two column tiles; 16 chunks at most
     p.splitk_each = al64((size_t)16 * (size_t)(n < 48 * TGM ? n : 48 * TGM) * (size_t)(2 * TGN));
     p.splitk = off, off += 2 * p.splitk_each;
+    if (net->attn && net->attn->layer_norm) {  // snt.LayerNorm outputs (s, t) + per-workgroup partials of d gamma / d beta
+        p.lny = off, off += 2 * al64((size_t)n * p.H);
+        p.lnpart = off, off += al64((size_t)((n + kLnBwdRows - 1) / kLnBwdRows) * 4 * (size_t)p.H);
+    }
     const size_t set0 = off;
     p.h0 = off, off += al64((size_t)n * p.in0);
     p.h0b = off, off += net->attn ? al64((size_t)n * p.in0) : 0;  // attention: one layer-0 input per net
@@ -1777,9 +1782,91 @@ static int launch_aggregate_bwd(const BwdPlan& p, const GnfCsr* csr_t, const Gnf
 
 // Generic (any layer width) recompute + coupling + dP chain of one half-step out of GEMM building blocks:
 // o.h0[q] holds the layer-0 inputs on entry; on exit o.hin / o.dPs / o.gst / o.dh0 are filled, y and g updated.
+// snt.LayerNorm backwards (gnn.py:550-552), y = xhat gamma + beta with xhat = (u - mean) rstd over the W features of a row:
+//   g_u = rstd (gamma g_y - mean_f(gamma g_y) - xhat mean_f(gamma g_y xhat)),  d gamma = sum_r g_y xhat,  d beta = sum_r g_y
+// One wave per row (lanes along the features); g_y [N, W] is overwritten with g_u; a workgroup owns kLnBwdRows rows and
+// leaves its share of d gamma / d beta in part[block][net][2][W] (fixed order: per wave over its rows, then wave 0..3).
+struct LnBwdJob {
+    const float* u;      // un-normalised rows [N, W]
+    float* g;            // in: dL/dy, out: dL/du
+    const float* gamma;
+};
+struct LnBwdArgs {
+    LnBwdJob job[2];
+    float* part;
+    int64_t n;
+    int32_t W;
+};
+__global__ __launch_bounds__(256) void k_layer_norm_bwd(const LnBwdArgs a) {
+    extern __shared__ float ln_acc[];  // [4 waves][2][W]
+    const LnBwdJob j = a.job[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int W = a.W;
+    const float inv_w = 1.f / (float)W;
+    float* accg = ln_acc + (size_t)wave * 2 * W;
+    float* accb = accg + W;
+    for (int f = lane; f < W; f += 64) accg[f] = 0.f, accb[f] = 0.f;
+    const int64_t row0 = (int64_t)blockIdx.x * kLnBwdRows;
+    for (int rl = wave; rl < kLnBwdRows; rl += 4) {
+        const int64_t r = row0 + rl;
+        if (r >= a.n) break;
+        const float* u = j.u + r * W;
+        float* g = j.g + r * W;
+        float sum = 0.f;
+        for (int f = lane; f < W; f += 64) sum += u[f];
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        const float mean = sum * inv_w;
+        float sq = 0.f;
+        for (int f = lane; f < W; f += 64) {
+            const float d = u[f] - mean;
+            sq = fmaf(d, d, sq);
+        }
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+        const float rstd = 1.f / sqrtf(sq * inv_w + GNF_LN_EPS);
+        float sa = 0.f, sb = 0.f;
+        for (int f = lane; f < W; f += 64) {
+            const float xh = (u[f] - mean) * rstd, gy = g[f], gg = j.gamma[f] * gy;
+            sa += gg;
+            sb = fmaf(gg, xh, sb);
+            accg[f] = fmaf(gy, xh, accg[f]);
+            accb[f] += gy;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            sa += __shfl_xor(sa, off, 64);
+            sb += __shfl_xor(sb, off, 64);
+        }
+        sa *= inv_w, sb *= inv_w;
+        for (int f = lane; f < W; f += 64) {
+            const float xh = (u[f] - mean) * rstd;
+            g[f] = rstd * (j.gamma[f] * g[f] - sa - xh * sb);
+        }
+    }
+    __syncthreads();
+    float* out = a.part + ((size_t)blockIdx.x * 2 + blockIdx.y) * 2 * W;
+    for (int i = threadIdx.x; i < 2 * W; i += 256)
+        out[i] = ((ln_acc[i] + ln_acc[2 * W + i]) + ln_acc[4 * W + i]) + ln_acc[6 * W + i];
+}
+
+// d gamma / d beta of both nets: fixed-order sum of the workgroup partials
+struct LnGradArgs {
+    float* gamma[2];
+    float* beta[2];
+    const float* part;
+    int32_t nblk, W, accumulate;
+};
+__global__ __launch_bounds__(256) void k_layer_norm_grad(const LnGradArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // [net][2][W]
+    if (i >= 4 * a.W) return;
+    const int net = i / (2 * a.W), k = (i - net * 2 * a.W) / a.W, f = i - (net * 2 + k) * a.W;
+    float s = 0.f;
+    for (int b = 0; b < a.nblk; ++b) s += a.part[((size_t)b * 2 + net) * 2 * a.W + (size_t)k * a.W + f];
+    float* dst = (k ? a.beta[net] : a.gamma[net]) + f;
+    *dst = a.accumulate ? *dst + s : s;
+}
+
 static int mlp_backward_generic(const BwdPlan& p, const BwdOperands& o, const GnfGnnSpec& gnn, const GnfMlp* const* nets,
-                                const float* x_cond, float* y_upd, int64_t ld, float* g_upd, int64_t ldg, float* ws,
-                                hipStream_t st) {
+                                const GnfMlp* const* grads, bool acc, const float* x_cond, float* y_upd, int64_t ld,
+                                float* g_upd, int64_t ldg, float* ws, hipStream_t st) {
     const int64_t n = p.n;
     const int K = p.K, H = p.H;
     int rc;
@@ -1800,13 +1887,52 @@ static int mlp_backward_generic(const BwdPlan& p, const BwdOperands& o, const Gn
         rc = launch_gemm<OPND_KC, OPND_MC, EPI_BIAS_ACT>(jobs, 2, sh, st, sk, p.splitk_each);
         if (rc) return rc;
     }
+    const bool lnorm = nets[0]->attn && nets[0]->attn->layer_norm;
     {
         const bool res = nets[0]->attn && nets[0]->attn->residual;
+        const float* sv[2] = {o.stb[0], o.stb[1]};
+        if (lnorm) {  // s, t = LayerNorm(MLP(h0) (+ x_cond)): normalised rows to the side, u = MLP(h0) (+ x_cond) kept in place
+            float* lny[2] = {ws + p.lny, ws + p.lny + al64((size_t)n * H)};
+            LnArgs a;
+            memset(&a, 0, sizeof(a));
+            for (int q = 0; q < 2; ++q) {
+                a.job[q] = LnJob{o.stb[q], lny[q], o.stb[q], nets[q]->attn->ln_gamma, nets[q]->attn->ln_beta};
+                sv[q] = lny[q];
+            }
+            a.ldin = a.ldy = H;
+            a.xres = res ? x_cond : nullptr;
+            a.ldx = ld;
+            a.n = n;
+            a.W = H;
+            rc = launch_layer_norm(a, 2, st);
+            if (rc) return rc;
+        }
         int64_t blocks = (n * H + 255) / 256;
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(k_coupling_bwd, dim3((unsigned)blocks), dim3(256), 0, st, o.stb[0], o.stb[1], y_upd, ld,
-                           g_upd, ldg, o.gst[0], o.gst[1], n, H, res ? x_cond : nullptr, ld);
+        hipLaunchKernelGGL(k_coupling_bwd, dim3((unsigned)blocks), dim3(256), 0, st, sv[0], sv[1], y_upd, ld,
+                           g_upd, ldg, o.gst[0], o.gst[1], n, H, res && !lnorm ? x_cond : nullptr, ld);
         GNF_LAUNCH_CHECK("k_coupling_bwd");
+    }
+    if (lnorm) {  // g_s, g_t: dL/d(normalised rows) -> dL/du in place; d gamma, d beta
+        const int nblk = (int)((n + kLnBwdRows - 1) / kLnBwdRows);
+        LnBwdArgs a;
+        memset(&a, 0, sizeof(a));
+        for (int q = 0; q < 2; ++q) a.job[q] = LnBwdJob{o.stb[q], o.gst[q], nets[q]->attn->ln_gamma};
+        a.part = ws + p.lnpart;
+        a.n = n;
+        a.W = H;
+        hipLaunchKernelGGL(k_layer_norm_bwd, dim3((unsigned)nblk, 2), dim3(256), (size_t)8 * H * sizeof(float), st, a);
+        GNF_LAUNCH_CHECK("k_layer_norm_bwd");
+        LnGradArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        for (int q = 0; q < 2; ++q) {
+            ga.gamma[q] = const_cast<float*>(grads[q]->attn->ln_gamma);
+            ga.beta[q] = const_cast<float*>(grads[q]->attn->ln_beta);
+        }
+        ga.part = ws + p.lnpart;
+        ga.nblk = nblk, ga.W = H, ga.accumulate = acc ? 1 : 0;
+        hipLaunchKernelGGL(k_layer_norm_grad, dim3((unsigned)((4 * H + 255) / 256)), dim3(256), 0, st, ga);
+        GNF_LAUNCH_CHECK("k_layer_norm_grad");
     }
     for (int j = K - 1; j >= 0; --j) {  // dP_{j-1} = (dP_j W_j^T) * act'(h_j)   [nodes, O] x [O, I]
         const int I = nets[0]->dims[j], O = nets[0]->dims[j + 1];
@@ -2023,6 +2149,10 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 set_error("gnf_grevnet_backward_f32: grad net %d needs a GnfAttn with Wq / Wk / Wv / Wo gradient buffers", q);
                 return GNF_EINVAL;
             }
+            if (pr[0]->attn && pr[0]->attn->layer_norm && (!pr[1]->attn->ln_gamma || !pr[1]->attn->ln_beta)) {
+                set_error("gnf_grevnet_backward_f32: grad net %d needs ln_gamma / ln_beta gradient buffers (layer_norm)", q);
+                return GNF_EINVAL;
+            }
             if (pr[1]->num_layers != pr[0]->num_layers ||
                 memcmp(pr[1]->dims, pr[0]->dims, sizeof(int32_t) * (pr[0]->num_layers + 1))) {
                 set_error("gnf_grevnet_backward_f32: grad net %d has other layer widths than the flow's", q);
@@ -2082,6 +2212,10 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                     GNF_HIP_TRY(hipMemsetAsync(const_cast<float*>(gm->attn->Wv), 0, sizeof(float) * H * fa->v_dim, st));
                     GNF_HIP_TRY(hipMemsetAsync(const_cast<float*>(gm->attn->Wo), 0,
                                                sizeof(float) * fa->num_heads * fa->v_dim * fa->out_dim, st));
+                    if (fa->layer_norm) {
+                        GNF_HIP_TRY(hipMemsetAsync(const_cast<float*>(gm->attn->ln_gamma), 0, sizeof(float) * H, st));
+                        GNF_HIP_TRY(hipMemsetAsync(const_cast<float*>(gm->attn->ln_beta), 0, sizeof(float) * H, st));
+                    }
                 }
             }
         if (flow->bns)
@@ -2178,7 +2312,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                                            g + uo, D, H, o.h0[0], attn ? h0c : nullptr, o.hin, p.lmax, o.dPs, p.lmax,
                                            o.gst, o.dh0, st);
             } else {
-                rc = mlp_backward_generic(p, o, flow->gnn, nets, x_cond, z + uo, ld, g + uo, D, wsf, st);
+                rc = mlp_backward_generic(p, o, flow->gnn, nets, grads, acc, x_cond, z + uo, ld, g + uo, D, wsf, st);
             }
             if (rc) return rc;
             // message passing: the weight gradients only read what the fused kernel has just written, so their stream

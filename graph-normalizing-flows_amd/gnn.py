@@ -269,16 +269,16 @@ class DMSelfAttentionMLP(_NodeBlock):
     self-attention over the incoming edges of every node, heads concatenated and projected to
     `concat_heads_output_dim`, optionally concatenated with the node's own features, then the MLP.
     It is a GNN module by itself (the reference does not wrap it in NodeBlockGNN, gnn.py:556-573).
-    `layer_norm=True` is not supported.  Weights (all [in, out], no bias, gnn.py:509-540):
+    Weights (all [in, out], no bias, gnn.py:509-540):
     wq, wk [H, heads*kq], wv [H, v], wo [heads*v, C]; created at first connection like Sonnet does
-    (xavier-uniform for q/k/v, gnn.py:504-506; Sonnet's default 1/sqrt(fan_in) truncated normal for wo)."""
+    (xavier-uniform for q/k/v, gnn.py:504-506; Sonnet's default 1/sqrt(fan_in) truncated normal for wo).
+    `layer_norm=True` (gnn.py:550-552, snt.LayerNorm over the block's output) adds ln_gamma (ones) and ln_beta
+    (zeros) of the MLP's output width; both are trained."""
     combine = _abi.GNF_COMBINE_EPS   # unused by attention nets
     _agg = _abi.GNF_AGG_SUM          # unused by attention nets
 
     def __init__(self, kq_dim, v_dim, make_mlp_fn, num_heads=8, concat_heads_output_dim=20, concat=True,
                  residual=False, layer_norm=False, kq_dim_division=False, name="dm_self_attention"):
-        if layer_norm:
-            raise NotImplementedError("DMSelfAttentionMLP(layer_norm=True) (snt.LayerNorm, gnn.py:550-552) is not supported")
         self.kq_dim = int(kq_dim)
         self.v_dim = int(v_dim)
         self.mlp = make_mlp_fn()
@@ -287,7 +287,7 @@ class DMSelfAttentionMLP(_NodeBlock):
         self.concat_heads_output_dim = int(concat_heads_output_dim)
         self.concat = bool(concat)
         self.residual = bool(residual)
-        self.layer_norm = False
+        self.layer_norm = bool(layer_norm)
         self.kq_dim_division = bool(kq_dim_division)
         self.name = name
         self.attn_params = None     # {"wq", "wk", "wv", "wo"} fp32 tensors
@@ -298,20 +298,31 @@ class DMSelfAttentionMLP(_NodeBlock):
 
     def signature(self):
         return (type(self).__name__, self.num_heads, self.kq_dim, self.v_dim, self.concat_heads_output_dim,
-                self.concat, self.residual, self.kq_dim_division, self._mlp.act_code, self._mlp.alpha)
+                self.concat, self.residual, self.layer_norm, self.kq_dim_division, self._mlp.act_code, self._mlp.alpha)
 
     def attn_version(self):
         return self._attn_version
 
     def _shapes(self, h):
         nq = self.num_heads * self.kq_dim
-        return {"wq": (h, nq), "wk": (h, nq), "wv": (h, self.v_dim),
-                "wo": (self.num_heads * self.v_dim, self.concat_heads_output_dim)}
+        shapes = {"wq": (h, nq), "wk": (h, nq), "wv": (h, self.v_dim),
+                  "wo": (self.num_heads * self.v_dim, self.concat_heads_output_dim)}
+        if self.layer_norm:
+            w_out = self._mlp.layer_sizes[-1]
+            shapes.update(ln_gamma=(w_out,), ln_beta=(w_out,))
+        return shapes
+
+    def attn_keys(self):
+        return ("wq", "wk", "wv", "wo") + (("ln_gamma", "ln_beta") if self.layer_norm else ())
 
     def ensure_attn_built(self, h, device):
         if self.attn_params is None:
             p = {}
-            for key, (fi, fo) in self._shapes(h).items():
+            for key, shp in self._shapes(h).items():
+                if len(shp) == 1:               # snt.LayerNorm: gamma = 1, beta = 0
+                    p[key] = torch.ones(shp) if key == "ln_gamma" else torch.zeros(shp)
+                    continue
+                fi, fo = shp
                 w = torch.empty(fi, fo)
                 if key == "wo":
                     std = 1.0 / math.sqrt(fi)
@@ -333,13 +344,14 @@ class DMSelfAttentionMLP(_NodeBlock):
         return self
 
     def set_attn_params(self, attn):
-        """attn: dict with wq, wk, wv, wo (numpy or torch, [in, out]); other keys are ignored."""
+        """attn: dict with wq, wk, wv, wo (numpy or torch, [in, out]) and, for a layer_norm block, ln_gamma, ln_beta
+        [MLP output width]; other keys are ignored."""
         p = {}
-        for key in ("wq", "wk", "wv", "wo"):
+        for key in self.attn_keys():
             w = attn[key]
             w = torch.as_tensor(np.asarray(w) if not isinstance(w, torch.Tensor) else w).to(torch.float32).contiguous()
-            if w.ndim != 2:
-                raise ValueError(f"{self.name}: {key} must be 2-D [in, out]")
+            if w.ndim != (1 if key.startswith("ln_") else 2):
+                raise ValueError(f"{self.name}: {key} must be " + ("1-D [out]" if key.startswith("ln_") else "2-D [in, out]"))
             p[key] = w
         self.attn_params = p
         self._attn_version += 1
@@ -353,8 +365,10 @@ class DMSelfAttentionMLP(_NodeBlock):
         self.ensure_attn_built(h, device)
         p = self.attn_params
         return _abi.GnfAttn(self.num_heads, self.kq_dim, self.v_dim, self.concat_heads_output_dim,
-                            int(self.concat), int(self.kq_dim_division), int(self.residual), 0,
-                            p["wq"].data_ptr(), p["wk"].data_ptr(), p["wv"].data_ptr(), p["wo"].data_ptr())
+                            int(self.concat), int(self.kq_dim_division), int(self.residual), int(self.layer_norm),
+                            p["wq"].data_ptr(), p["wk"].data_ptr(), p["wv"].data_ptr(), p["wo"].data_ptr(),
+                            p["ln_gamma"].data_ptr() if self.layer_norm else 0,
+                            p["ln_beta"].data_ptr() if self.layer_norm else 0)
 
 
 def dm_self_attn_gnn(kq_dim, v_dim, make_mlp_fn, num_heads, concat_heads_output_dim, concat=True,

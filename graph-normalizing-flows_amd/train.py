@@ -123,8 +123,8 @@ class GRevNetTrainer:
         for m in mlps:
             for (w, b) in m.params:
                 sizes += [w.numel(), b.numel()]
-        for blk in attn_blocks:                       # attention front-end: wq, wk, wv, wo
-            sizes += [blk.attn_params[k].numel() for k in ("wq", "wk", "wv", "wo")]
+        for blk in attn_blocks:                       # attention front-end: wq, wk, wv, wo (+ ln_gamma, ln_beta)
+            sizes += [blk.attn_params[k].numel() for k in blk.attn_keys()]
         for b in bns:                                 # trainable: gamma, beta (the moving statistics are not)
             sizes += [b.gamma.numel(), b.beta.numel()]
         total = sum(sizes)
@@ -148,7 +148,7 @@ class GRevNetTrainer:
         self._attn_off = off
         for blk in attn_blocks:
             views = {}
-            for k in ("wq", "wk", "wv", "wo"):
+            for k in blk.attn_keys():
                 old = blk.attn_params[k]
                 view = theta[off:off + old.numel()].view_as(old)
                 view.copy_(old)
@@ -196,11 +196,14 @@ class GRevNetTrainer:
             for q, blk in enumerate(attn_blocks):     # order: s nets then t nets, like `blocks`
                 ga = gattn[q]
                 ga.num_heads, ga.kq_dim, ga.v_dim, ga.out_dim = blk.num_heads, blk.kq_dim, blk.v_dim, blk.concat_heads_output_dim
+                ga.layer_norm = int(blk.layer_norm)
                 ptrs = []
-                for k in ("wq", "wk", "wv", "wo"):
+                for k in blk.attn_keys():
                     ptrs.append(self.grad.data_ptr() + 4 * off)
                     off += blk.attn_params[k].numel()
-                ga.Wq, ga.Wk, ga.Wv, ga.Wo = ptrs
+                ga.Wq, ga.Wk, ga.Wv, ga.Wo = ptrs[:4]
+                if blk.layer_norm:
+                    ga.ln_gamma, ga.ln_beta = ptrs[4:]
                 arr = gs if q < n else gt
                 arr[q % n].attn = C.cast(C.byref(gattn, q * C.sizeof(_abi.GnfAttn)), C.POINTER(_abi.GnfAttn))
         spec = net.blocks("s")[0].spec()
@@ -243,7 +246,7 @@ class GRevNetTrainer:
             per_block = []
             for blk in self._attn_blocks:
                 d = {}
-                for k in ("wq", "wk", "wv", "wo"):
+                for k in blk.attn_keys():
                     w = blk.attn_params[k]
                     d[k] = g[off:off + w.numel()].reshape(tuple(w.shape)).copy()
                     off += w.numel()

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GNF_ABI_VERSION 6
+#define GNF_ABI_VERSION 7
 #define GNF_MAX_LAYERS 8 /* Linear layers per MLP (gnn.py:165-166 builds num_layers of them) */
 
 typedef void* gnf_stream_t; /* hipStream_t */
@@ -74,7 +74,10 @@ typedef struct GnfCsr {
  *   softmax over each receiver's incoming edges; attended[r,h] = sum_e w[e,h] v[sender e].
  * All weights device, row-major [in, out] like snt.Linear(use_bias=False) (gnn.py:509-540).
  * GnfGnnSpec.agg / combine / epsilon are ignored for such a net; activation / alpha still apply to
- * the MLP.  residual: MLP output += x (gnn.py:547-548).  layer_norm is not supported. */
+ * the MLP.  residual: MLP output += x (gnn.py:547-548).  layer_norm: snt.LayerNorm() over the feature axis of
+ * the block's output after the residual add (gnn.py:550-552): (h - mean) / sqrt(var + GNF_LN_EPS) * ln_gamma
+ * + ln_beta with the biased per-row variance; ln_gamma / ln_beta have the MLP's output width. */
+#define GNF_LN_EPS 1e-5f
 typedef struct GnfAttn {
     int32_t num_heads;       /* 1..64 */
     int32_t kq_dim;          /* 1..32 */
@@ -83,11 +86,13 @@ typedef struct GnfAttn {
     int32_t concat;          /* attn_concat */
     int32_t kq_dim_division; /* divide logits by sqrt(kq_dim) */
     int32_t residual;
-    int32_t reserved;
+    int32_t layer_norm;
     const float* Wq; /* [H, num_heads*kq_dim] */
     const float* Wk; /* [H, num_heads*kq_dim] */
     const float* Wv; /* [H, v_dim] */
     const float* Wo; /* [num_heads*v_dim, out_dim] */
+    const float* ln_gamma; /* [MLP output width], read when layer_norm != 0 (else may be NULL) */
+    const float* ln_beta;  /* [MLP output width] */
 } GnfAttn;
 
 /* One snt.nets.MLP (gnn.py:159-180): num_layers Linear layers, y = x @ W + b, W row-major [in,out];

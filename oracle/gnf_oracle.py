@@ -25,6 +25,7 @@ Upstream semantics restated (all third-party, not under /root/reference; SURVEY.
   tf.unsorted_segment_sum / _mean                         -> sum ; sum / max(count, 1)          (gnn.py:239,245,251,256)
   snt.nets.MLP(activate_final=False), snt.Linear          -> x @ W + b, W:[in,out]              (gnn.py:159-180)
   tf.nn.leaky_relu default alpha = 0.2 ; tf.nn.relu                                             (run_grevnet.py:158,179,205)
+  snt.LayerNorm() (DMSelfAttentionMLP(layer_norm=True))  -> (h - mean_f) / sqrt(var_f + 1e-5) * gamma + beta  (gnn.py:550-552)
   tfd.MultivariateNormalDiag(0,1).log_prob(z)             -> -0.5*sum(z^2) - D/2*ln(2*pi)       (run_grevnet.py:292-294)
 
 Parameter container used everywhere in tests (plain python, no framework):
@@ -38,6 +39,21 @@ import math
 import numpy as np
 
 LN_2PI = math.log(2.0 * math.pi)
+LN_EPS = 1e-5       # snt.LayerNorm default eps (Sonnet 1.x layer_norm.py; upstream-unpinned like the rest)
+
+
+def attn_weight_keys(attn):
+    """trainable tensors of one DMSelfAttentionMLP front-end (gnn.py:509-552)"""
+    return ("wq", "wk", "wv", "wo") + (("ln_gamma", "ln_beta") if attn.get("layer_norm", False) else ())
+
+
+def layer_norm_rows(h, gamma, beta):
+    """gnn.py:550-552 `snt.LayerNorm()(new_nodes)` on a [N, H] array: per-row moments over the feature axis
+    (tf.nn.moments(x, [1]): biased variance), then tf.nn.batch_normalization with eps = 1e-5, scale gamma [H],
+    offset beta [H]."""
+    mean = h.mean(axis=1, keepdims=True)
+    var = ((h - mean) ** 2).mean(axis=1, keepdims=True)
+    return (h - mean) / np.sqrt(var + LN_EPS) * gamma + beta
 
 
 # ----------------------------------------------------------------------------------------------
@@ -133,6 +149,8 @@ class Fp64Dense:
         out = self.mlp(h0, net["mlp"])
         if a.get("residual", False):
             out = out + x
+        if a.get("layer_norm", False):
+            out = layer_norm_rows(out, np.asarray(a["ln_gamma"], np.float64), np.asarray(a["ln_beta"], np.float64))
         return out
 
     def gnn(self, x, layers):
@@ -255,7 +273,7 @@ class Fp32Gather:
                 return {k: (self.to_t(v) if k != "epsilon" else v) for k, v in m.items()}
             if isinstance(m, dict) and "attn" in m:
                 a = dict(m["attn"])
-                for key in ("wq", "wk", "wv", "wo"):
+                for key in attn_weight_keys(a):
                     a[key] = self.to_t(a[key])
                 return {"attn": a, "mlp": conv(m["mlp"])}
             if isinstance(m, list) and m and isinstance(m[0], tuple):
@@ -304,6 +322,12 @@ class Fp32Gather:
         out = self.mlp(h0, net["mlp"])
         if a.get("residual", False):
             out = out + x
+        if a.get("layer_norm", False):
+            # gnn.py:550-552 snt.LayerNorm(): moments over axis 1, tf.nn.batch_normalization(eps=1e-5)
+            mean = out.mean(dim=1, keepdim=True)
+            var = ((out - mean) ** 2).mean(dim=1, keepdim=True)
+            inv = torch.rsqrt(var + LN_EPS) * a["ln_gamma"]
+            out = out * inv + (a["ln_beta"] - mean * inv)
         return out
 
     def gnn(self, x, layers):
@@ -404,7 +428,7 @@ def loss_and_grads(senders, receivers, n_total, x, params, num_timesteps, weight
     def mark(m):
         if isinstance(m, dict) and "attn" in m:           # attention net: wq, wk, wv, wo and the MLP are trainable
             a = dict(m["attn"])
-            for k in ("wq", "wk", "wv", "wo"):
+            for k in attn_weight_keys(a):
                 a[k] = a[k].clone().requires_grad_(True)
             return {"attn": a, "mlp": mark(m["mlp"])}
         if isinstance(m, dict) and "gamma" in m:          # batch-norm bijector: gamma and beta are trainable
@@ -431,7 +455,7 @@ def loss_and_grads(senders, receivers, n_total, x, params, num_timesteps, weight
 
     def grads_of(m):
         if isinstance(m, dict) and "attn" in m:
-            return {"attn": {k: m["attn"][k].grad.numpy().copy() for k in ("wq", "wk", "wv", "wo")},
+            return {"attn": {k: m["attn"][k].grad.numpy().copy() for k in attn_weight_keys(m["attn"])},
                     "mlp": grads_of(m["mlp"])}
         if isinstance(m, dict) and "gamma" in m:
             return {"gamma": m["gamma"].grad.numpy().copy(), "beta": m["beta"].grad.numpy().copy()}
@@ -518,7 +542,7 @@ def make_bn_params(seed, hdim, num_timesteps):
 
 def make_attn_net_params(rng, hdim, latent, num_layers, num_heads=8, kq_dim=10, v_dim=10, out_dim=80,
                          concat=True, kq_dim_division=False, residual=False, bias_std=0.1,
-                         final_scale=1.0, dtype=np.float32):
+                         final_scale=1.0, dtype=np.float32, layer_norm=False):
     """One DMSelfAttentionMLP net (gnn.py:480-553): Wq, Wk [H, nh*kq], Wv [H, v] xavier-uniform
     (gnn.py:504-506), Wo [nh*v, C] (snt.Linear default init ~ 1/sqrt(fan_in)), then the MLP on
     [x || new] (H + C inputs) or new (C inputs)."""
@@ -530,6 +554,10 @@ def make_attn_net_params(rng, hdim, latent, num_layers, num_heads=8, kq_dim=10, 
             "wq": xavier(hdim, num_heads * kq_dim), "wk": xavier(hdim, num_heads * kq_dim),
             "wv": xavier(hdim, v_dim),
             "wo": (rng.standard_normal((num_heads * v_dim, out_dim)) / math.sqrt(num_heads * v_dim)).astype(dtype)}
+    if layer_norm:      # snt.LayerNorm starts at gamma = 1, beta = 0; test parameters are non-trivial in both and keep
+        attn["layer_norm"] = True           # s = LayerNorm(...) small enough that exp(s) stays tame over a few steps
+        attn["ln_gamma"] = rng.uniform(0.2, 0.6, hdim).astype(dtype)
+        attn["ln_beta"] = (0.1 * rng.standard_normal(hdim)).astype(dtype)
     in_dim = hdim + out_dim if concat else out_dim
     return {"attn": attn, "mlp": make_mlp_params(rng, in_dim, latent, hdim, num_layers, bias_std, final_scale, dtype)}
 

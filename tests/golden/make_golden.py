@@ -36,7 +36,12 @@ ATTN_CASES = [
      dict(num_heads=8, kq_dim=10, v_dim=10, out_dim=80, concat=True, kq_dim_division=False, residual=False), False, 0.5),
     ("attn_small_community_noconcat_div", "community_medium", None, 12, 24, 2, 2,
      dict(num_heads=3, kq_dim=7, v_dim=5, out_dim=20, concat=False, kq_dim_division=True, residual=False), True, 0.4),
+    # --attn_layer_norm --attn_residual (run_grevnet.py:80, gnn.py:547-552): non-trivial ln_gamma / ln_beta
+    ("attn_layer_norm_residual", "grid_small", [0, 3, 9], 10, 24, 3, 2,
+     dict(num_heads=4, kq_dim=6, v_dim=5, out_dim=12, concat=True, kq_dim_division=False, residual=True,
+          layer_norm=True), False, 0.5),
 ]
+ONLY = set(sys.argv[1:])      # `make_golden.py name ...` regenerates just those fixtures
 
 CASES = [
     # name, dataset, graph ids, D, latent, K, T, agg, combine, eps, activation, weight_sharing, final_scale
@@ -49,6 +54,8 @@ CASES = [
 
 def main():
     for (name, ds, ids, d, latent, k, t, agg, combine, eps, act, ws, fscale) in CASES:
+        if ONLY and name not in ONLY:
+            continue
         n_node, n_edge, sl, rl = load(ds)
         rng = np.random.default_rng(12345)             # run_grevnet.py:108
         if ids is None:                                # config 2 draw: with replacement from the 80% train split
@@ -86,6 +93,8 @@ def main():
 
 def main_attn():
     for (name, ds, ids, d, latent, k, t, akw, ws, fscale) in ATTN_CASES:
+        if ONLY and name not in ONLY:
+            continue
         n_node, n_edge, sl, rl = load(ds)
         rng = np.random.default_rng(12345)
         if ids is None:
@@ -111,7 +120,7 @@ def main_attn():
             for half in range(2):
                 nets = [p[kind][half]] if ws else p[kind][half]
                 for i, net in enumerate(nets):
-                    for key in ("wq", "wk", "wv", "wo"):
+                    for key in O.attn_weight_keys(net["attn"]):
                         blob[f"a_{kind}_{half}_{i}_{key}"] = net["attn"][key]
                     for j, (w, b) in enumerate(net["mlp"]):
                         blob[f"w_{kind}_{half}_{i}_{j}"] = w
@@ -168,4 +177,5 @@ def main_bn():
 if __name__ == "__main__":
     main()
     main_attn()
-    main_bn()
+    if not ONLY or "bn_small_community" in ONLY:
+        main_bn()

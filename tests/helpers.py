@@ -5,7 +5,7 @@ import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDEN_CASES = ["cfg1_grid_small_d2", "cfg1_grid_small_d8", "cfg2_small_community", "sum_concat_relu_shared"]
-ATTN_GOLDEN_CASES = ["attn_cfg1_grid_small", "attn_small_community_noconcat_div"]
+ATTN_GOLDEN_CASES = ["attn_cfg1_grid_small", "attn_small_community_noconcat_div", "attn_layer_norm_residual"]
 BN_GOLDEN_CASES = ["bn_small_community"]
 ATTN_KEYS = ("num_heads", "kq_dim", "v_dim", "out_dim", "concat", "kq_dim_division", "residual")
 
@@ -26,6 +26,7 @@ def load_golden(name):
         for key in ATTN_KEYS:
             v = g["attn_" + key]
             attn[key] = bool(v) if key in ("concat", "kq_dim_division", "residual") else int(v)
+        attn["layer_norm"] = bool(g["attn_layer_norm"]) if "attn_layer_norm" in g else False
         g["attn"] = attn
     params = {}
     for kind in ("s", "t"):
@@ -38,7 +39,7 @@ def load_golden(name):
                     nets.append(mlp)
                 else:
                     a = dict(attn)
-                    for key in ("wq", "wk", "wv", "wo"):
+                    for key in ("wq", "wk", "wv", "wo") + (("ln_gamma", "ln_beta") if attn["layer_norm"] else ()):
                         a[key] = g[f"a_{kind}_{half}_{i}_{key}"]
                     nets.append({"attn": a, "mlp": mlp})
             halves.append(nets[0] if ws else nets)
@@ -64,7 +65,7 @@ def make_product_grevnet(hp, params):
         a = hp["attn"]
         mk = partial(gnn.dm_self_attn_gnn, kq_dim=a["kq_dim"], v_dim=a["v_dim"], make_mlp_fn=mk_mlp,
                      num_heads=a["num_heads"], concat_heads_output_dim=a["out_dim"], concat=a["concat"],
-                     residual=a["residual"], layer_norm=False, kq_dim_division=a["kq_dim_division"])
+                     residual=a["residual"], layer_norm=a.get("layer_norm", False), kq_dim_division=a["kq_dim_division"])
     elif hp["combine"] == "concat":
         mk = partial(gnn.sum_concat_then_mlp_gnn if hp["agg"] == "sum" else gnn.avg_concat_then_mlp_gnn, mk_mlp)
     else:

@@ -459,3 +459,87 @@ def test_gradient_oracle_attention_matches_finite_differences():
                 pp[kind][half][i]["attn"][key][idx] -= 2 * eps
                 lm = loss(pp)
                 assert abs((lp - lm) / (2 * eps) - res["grads"][kind][half][i]["attn"][key][idx]) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# DMSelfAttentionMLP(layer_norm=True): snt.LayerNorm over the block output (gnn.py:550-552)
+# ------------------------------------------------------------------------------------------------
+def test_layer_norm_known_answers():
+    """rows come out with mean beta-weighted / unit biased variance; a constant row maps to beta exactly
+    (var = 0 -> (h - mean) = 0); eps = 1e-5 sits inside the square root."""
+    h = np.array([[1.0, 2.0, 3.0, 6.0], [5.0, 5.0, 5.0, 5.0], [-1.0, 1.0, -1.0, 1.0]])
+    one, zero = np.ones(4), np.zeros(4)
+    y = O.layer_norm_rows(h, one, zero)
+    np.testing.assert_allclose(y.mean(axis=1), 0.0, atol=1e-15)
+    np.testing.assert_allclose(y[1], 0.0, atol=0)
+    np.testing.assert_allclose(y[2], np.array([-1.0, 1.0, -1.0, 1.0]) / np.sqrt(1.0 + 1e-5), rtol=1e-15)
+    var0 = ((h[0] - 3.0) ** 2).mean()                      # 3.5: biased (population) variance, tf.nn.moments
+    np.testing.assert_allclose(y[0], (h[0] - 3.0) / np.sqrt(var0 + 1e-5), rtol=1e-15)
+    g, b = np.array([2.0, 0.5, 1.0, -1.0]), np.array([0.1, 0.2, 0.3, 0.4])
+    np.testing.assert_allclose(O.layer_norm_rows(h, g, b), y * g + b, rtol=1e-15)
+
+
+def test_layer_norm_attention_dual_agreement_round_trip_and_jacobian(grid_small):
+    n_node, n_edge, sl, rl = grid_small
+    nn, ne, s, r = O.batch_graphs(n_node, n_edge, sl, rl, [6, 0, 3])
+    n = int(nn.sum())
+    rng = np.random.default_rng(11)
+    for concat, res, ws in [(True, True, False), (False, False, True)]:
+        d, t = 12, 2
+        p = O.make_attn_grevnet_params(4, d // 2, 24, 3, t, weight_sharing=ws, num_heads=4, kq_dim=5, v_dim=6, out_dim=12,
+                                       concat=concat, residual=res, layer_norm=True, final_scale=0.5)
+        assert p["s"][0]["attn"]["layer_norm"] if ws else p["s"][0][0]["attn"]["layer_norm"]
+        x = rng.standard_normal((n, d)).astype(np.float32)
+        a = O.Fp64Dense(s, r, n, activation="relu")
+        b = O.Fp32Gather(s, r, n, activation="relu")
+        ra = a.log_prob(x, p, t, ws)
+        rb = b.log_prob(b.to_t(x), b.prep_params(p), t, ws)
+        assert abs(ra["log_prob_xs_per_node"] - rb["log_prob_xs_per_node"]) < 1e-5
+        np.testing.assert_allclose(rb["z"].numpy(), ra["z"], atol=3e-5, rtol=3e-5)
+        np.testing.assert_allclose(a.g(ra["z"], p, t, ws), x, atol=1e-9)
+    # log-det = log |det J| of the flow with the normalisation inside the nets
+    s, r, n = tiny_graph()
+    d, t = 4, 2
+    p = O.make_attn_grevnet_params(5, d // 2, 8, 2, t, num_heads=2, kq_dim=3, v_dim=2, out_dim=4, layer_norm=True,
+                                   residual=True, final_scale=0.6, dtype=np.float64)
+    o = O.Fp32Gather(s, r, n, activation="relu", dtype=torch.float64)
+    pt = o.prep_params(p)
+    x = torch.as_tensor(np.random.default_rng(2).standard_normal((n, d)))
+    z, ld = o.f(x, pt, t)
+    jac = torch.autograd.functional.jacobian(lambda v: o.f(v.reshape(n, d), pt, t)[0].reshape(-1), x.reshape(-1))
+    assert abs(float(torch.linalg.slogdet(jac)[1]) - float(ld)) < 1e-9
+
+
+def test_gradient_oracle_layer_norm_matches_finite_differences():
+    """ln_gamma / ln_beta (and a weight in front of the normalisation) vs central differences of the dense restatement."""
+    import copy
+    s = np.array([0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 0, 1, 1], np.int32)
+    r = np.array([0, 1, 2, 3, 4, 1, 2, 3, 4, 0, 2, 3, 3], np.int32)
+    n, t, hd = 5, 2, 3
+    raw = O.make_attn_grevnet_params(9, hd, 6, 2, t, num_heads=3, kq_dim=4, v_dim=3, out_dim=5, final_scale=0.5,
+                                     layer_norm=True, residual=True, dtype=np.float64)
+    x = np.random.default_rng(0).standard_normal((n, 2 * hd))
+    res = O.loss_and_grads(s, r, n, x, raw, t, activation="relu")
+    dense = O.Fp64Dense(s, r, n, activation="relu")
+
+    def loss(pp):
+        return -dense.log_prob(x, pp, t)["log_prob_xs"]
+
+    assert abs(res["total_loss"] - loss(raw)) < 1e-9
+    eps = 1e-6
+    for (kind, half, i) in [("s", 1, 0), ("t", 0, 1)]:
+        for key, idxs in (("ln_gamma", [(0,), (2,)]), ("ln_beta", [(1,)]), ("wo", [(1, 2)]), ("wq", [(0, 0)])):
+            for idx in idxs:
+                pp = copy.deepcopy(raw)
+                pp[kind][half][i]["attn"][key][idx] += eps
+                lp = loss(pp)
+                pp[kind][half][i]["attn"][key][idx] -= 2 * eps
+                lm = loss(pp)
+                assert abs((lp - lm) / (2 * eps) - res["grads"][kind][half][i]["attn"][key][idx]) < 1e-6
+        w = raw[kind][half][i]["mlp"][-1][0]
+        pp = copy.deepcopy(raw)
+        pp[kind][half][i]["mlp"][-1][0][0, 1] += eps
+        lp = loss(pp)
+        pp[kind][half][i]["mlp"][-1][0][0, 1] -= 2 * eps
+        lm = loss(pp)
+        assert abs((lp - lm) / (2 * eps) - res["grads"][kind][half][i]["mlp"][-1][0][0, 1]) < 1e-6

@@ -419,6 +419,76 @@ def test_attention_gnn_vs_oracle(grid_small, community_medium, shape, fused):
     np.testing.assert_allclose(xg, o.g(zs, p, t, ws), atol=3e-4, rtol=3e-4)
 
 
+ATTN_LN_SHAPES = [
+    # D, latent, K, T, heads, kq, v, C, concat, residual, ws          (all layer_norm=True, gnn.py:550-552)
+    (64, 256, 5, 2, 8, 10, 10, 80, True, True, False),     # --attn_layer_norm --attn_residual on the reference defaults
+    (20, 48, 2, 1, 3, 7, 5, 20, False, False, True),       # no concat, no residual, shared nets
+    (2, 32, 3, 2, 8, 10, 10, 80, True, True, False),       # H = 1: one feature -> variance 0 -> s = t = ln_beta
+    (300, 64, 2, 1, 2, 4, 4, 8, True, True, False),        # H = 150 > two wave widths per row
+]
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "layered"])
+@pytest.mark.parametrize("shape", ATTN_LN_SHAPES, ids=[f"D{s[0]}_L{s[1]}_h{s[4]}_C{s[7]}" for s in ATTN_LN_SHAPES])
+def test_attention_layer_norm_vs_oracle(grid_small, community_medium, shape, fused):
+    """DMSelfAttentionMLP(layer_norm=True) (run_grevnet.py:80 --attn_layer_norm): forward, log-det and sampling
+    direction vs the fp64 oracle, through the fused MLP kernel (one net per workgroup + normalisation + coupling
+    launches) and through the layered path."""
+    d, latent, k, t, nh, kq, vd, c, concat, res, ws = shape
+    akw = dict(num_heads=nh, kq_dim=kq, v_dim=vd, out_dim=c, concat=concat, kq_dim_division=False, residual=res,
+               layer_norm=True)
+    hp = dict(D=d, latent=latent, K=k, T=t, agg="mean", combine="agg", epsilon=0.0, activation="relu",
+              weight_sharing=ws, attn=akw)
+    nn, ne, s, r = _batch(grid_small, list(range(12))) if d != 64 else _batch(community_medium, [3, 77, 150, 9])
+    n = int(nn.sum())
+    rng = np.random.default_rng(d * 100 + nh)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    p = O.make_attn_grevnet_params(d + nh, d // 2, latent, k, t, weight_sharing=ws, final_scale=0.3, **akw)
+    o = O.Fp64Dense(s, r, n, activation="relu")
+    ref = o.log_prob(x, p, t, ws)
+    net = make_product_grevnet(hp, p)
+    net.fused = fused
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    out = _run_forward(net, graph)
+    # the normalised s is O(1) per feature, so |z| grows to ~e^3 over the flow: the bound is the error the fp32 CPU
+    # restatement makes on the same inputs (x 6) next to the usual 1e-4
+    o32 = O.Fp32Gather(s, r, n, activation="relu")
+    r32 = o32.log_prob(o32.to_t(x), o32.prep_params(p), t, ws)
+    tol = 1e-4 + 6.0 * abs(r32["log_prob_xs_per_node"] - ref["log_prob_xs_per_node"])
+    assert abs(float(out["log_prob_xs_per_node"]) - ref["log_prob_xs_per_node"]) <= tol
+    np.testing.assert_allclose(out["z_graph"].nodes.cpu().numpy(), ref["z"], atol=3e-4, rtol=3e-4)
+    zs = rng.standard_normal((n, d)).astype(np.float32)
+    xg = net(graph.replace(nodes=torch.as_tensor(zs).to(DEV)), inverse=False).nodes.cpu().numpy()
+    np.testing.assert_allclose(xg, o.g(zs, p, t, ws), atol=3e-4, rtol=3e-4)
+    back = net(graph.replace(nodes=torch.as_tensor(xg).to(DEV)), inverse=True)[0].nodes.cpu().numpy()
+    np.testing.assert_allclose(back, zs, atol=3e-4, rtol=3e-4)
+
+
+def test_attention_module_with_layer_norm_called_alone():
+    """module(GraphsTuple) with layer_norm=True and a free MLP output width (7): the normalisation runs over the
+    MLP's output width, not H; first-connect initialisation is gamma = 1, beta = 0 (snt.LayerNorm)."""
+    from gnf_amd import gnn
+    s = np.array([0, 0, 2, 1], np.int32)
+    r = np.array([1, 2, 1, 1], np.int32)
+    n, h = 4, 6
+    x = np.random.default_rng(0).standard_normal((n, h)).astype(np.float32)
+    net = O.make_attn_net_params(np.random.default_rng(1), h, 16, 2, num_heads=4, kq_dim=3, v_dim=2, out_dim=5)
+    net["mlp"] = O.make_mlp_params(np.random.default_rng(2), h + 5, 16, 7, 2)
+    mod = gnn.dm_self_attn_gnn(kq_dim=3, v_dim=2, make_mlp_fn=partial(gnn.make_mlp_model, 16, 7, 2, gnn.relu),
+                               num_heads=4, concat_heads_output_dim=5, layer_norm=True)
+    graph = graph_from_arrays([4], [4], s, r, x, DEV)
+    mod(graph)                                           # first connection creates the variables
+    np.testing.assert_array_equal(mod.attn_params["ln_gamma"].cpu().numpy(), np.ones(7, np.float32))
+    np.testing.assert_array_equal(mod.attn_params["ln_beta"].cpu().numpy(), np.zeros(7, np.float32))
+    net["attn"].update(layer_norm=True, ln_gamma=np.linspace(0.5, 1.5, 7).astype(np.float32),
+                       ln_beta=np.linspace(-0.3, 0.3, 7).astype(np.float32))
+    mod.set_attn_params(net["attn"])
+    mod._mlp.set_params(net["mlp"])
+    out = mod(graph)
+    want = O.Fp64Dense(s, r, n, activation="relu").gnn(x.astype(np.float64), net)
+    np.testing.assert_allclose(out.nodes.cpu().numpy(), want, atol=1e-4, rtol=1e-4)
+
+
 def test_attention_module_call_alone_and_isolated_nodes():
     """module(GraphsTuple) -> GraphsTuple for a dm_self_attn_gnn product; a node without incoming edges
     gets attended value 0 (gnn.py:403)."""

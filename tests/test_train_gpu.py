@@ -213,8 +213,9 @@ def _flat_attn(grads, ws):
     for kind in ("s", "t"):
         nets = grads[kind] if ws else grads[kind][0] + grads[kind][1]
         for q, net in enumerate(nets):
-            for key in ("wq", "wk", "wv", "wo"):
-                yield f"{kind}[{q}].{key}", net["attn"][key]
+            for key in ("wq", "wk", "wv", "wo", "ln_gamma", "ln_beta"):
+                if key in net["attn"]:
+                    yield f"{kind}[{q}].{key}", net["attn"][key]
             for j, (w, b) in enumerate(net["mlp"]):
                 yield f"{kind}[{q}].W{j}", w
                 yield f"{kind}[{q}].b{j}", b
@@ -259,6 +260,72 @@ def test_attention_gradients_vs_oracle(community_medium, case, fused, stash):
         tol = 5e-4 * float(np.abs(b).max()) + 1e-5
         err = float(np.abs(a - b).max())
         assert err <= tol, f"{name}: max err {err:.3e} > {tol:.3e} (max|g| {np.abs(b).max():.3e})"
+
+
+ATTN_LN_TRAIN_CASES = [
+    # D, latent, K, T, heads, kq, v, C, concat, residual, weight sharing       (all with layer_norm=True, gnn.py:550-552)
+    (64, 64, 3, 2, 8, 10, 10, 80, True, True, False),     # --attn_layer_norm --attn_residual on the default head geometry
+    (8, 24, 2, 3, 3, 4, 5, 6, False, False, True),        # no concat, no residual, weight sharing (gradients accumulate)
+    (260, 32, 1, 1, 2, 4, 4, 8, True, True, False),       # H = 130 > 2 wave widths; K = 1 (normalisation right behind layer 0)
+]
+
+
+@pytest.mark.parametrize("stash", [True, False], ids=["stash", "recompute"])
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "gemm"])
+@pytest.mark.parametrize("case", ATTN_LN_TRAIN_CASES, ids=[f"D{c[0]}_h{c[4]}_C{c[7]}" for c in ATTN_LN_TRAIN_CASES])
+def test_attention_layer_norm_gradients_vs_oracle(community_medium, case, fused, stash):
+    """DMSelfAttentionMLP(layer_norm=True): gradients of ln_gamma / ln_beta and of everything in front of the
+    normalisation vs the autograd oracle (pinned by finite differences in tests/test_oracle.py)."""
+    from gnf_amd.train import GRevNetTrainer
+    d, latent, k, t, nh, kq, vd, c, concat, res, ws = case
+    attn = dict(num_heads=nh, kq_dim=kq, v_dim=vd, out_dim=c, concat=concat, kq_dim_division=False, residual=res,
+                layer_norm=True)
+    hp = dict(D=d, latent=latent, K=k, T=t, agg="mean", combine="agg", epsilon=0.0, activation="relu",
+              weight_sharing=ws, attn=attn)
+    nn, ne, s, r = _batch(community_medium, [3, 50, 77, 12, 100])
+    n = int(nn.sum())
+    rng = np.random.default_rng(d + nh)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    p = O.make_attn_grevnet_params(d + 1, d // 2, latent, k, t, weight_sharing=ws, final_scale=0.3, **attn)
+    ref = O.loss_and_grads(s, r, n, x, p, t, ws, activation="relu")
+    net = make_product_grevnet(hp, p)
+    net.fused = fused
+    tr = GRevNetTrainer(net)
+    tr.stash_attention = stash
+    out = tr.loss_and_grads(graph_from_arrays(nn, ne, s, r, x, DEV))
+    torch.cuda.synchronize()
+    # (the normalised s is O(1) per feature: |z| and the loss are large, the bound is relative to them)
+    assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n + 1e-6 * abs(ref["total_loss"])
+    np.testing.assert_allclose(out["reconstruction"].cpu().numpy(), x, atol=3e-4, rtol=3e-4)
+    names = []
+    for (name, a), (_, b) in zip(_flat_attn(tr.named_gradients(), ws), _flat_attn(ref["grads"], ws)):
+        names.append(name)
+        tol = 5e-4 * float(np.abs(b).max()) + 1e-5
+        err = float(np.abs(a - b).max())
+        assert err <= tol, f"{name}: max err {err:.3e} > {tol:.3e} (max|g| {np.abs(b).max():.3e})"
+    assert any(nm.endswith("ln_gamma") for nm in names) and any(nm.endswith("ln_beta") for nm in names)
+
+
+def test_layer_norm_parameters_train(community_medium):
+    """ln_gamma / ln_beta sit in the optimiser's arena: a few Adam steps move them and reduce the loss."""
+    from gnf_amd.train import GRevNetTrainer
+    attn = dict(num_heads=4, kq_dim=6, v_dim=5, out_dim=12, concat=True, kq_dim_division=False, residual=True,
+                layer_norm=True)
+    hp = dict(D=16, latent=48, K=3, T=2, agg="mean", combine="agg", epsilon=0.0, activation="relu",
+              weight_sharing=False, attn=attn)
+    nn, ne, s, r = _batch(community_medium, [3, 50, 77, 12, 100])
+    n = int(nn.sum())
+    x = (np.random.default_rng(0).standard_normal((n, 16)) * 2 + 1).astype(np.float32)
+    net = make_product_grevnet(hp, None)          # Sonnet-style first-connect initialisation: gamma = 1, beta = 0
+    tr = GRevNetTrainer(net, lr=2e-3, use_lr_decay=False)
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    first = float(tr.step(graph)["total_loss"])
+    blk = net.blocks("s")[0]
+    np.testing.assert_array_less(0.0, np.abs(blk.attn_params["ln_gamma"].cpu().numpy() - 1.0).max())
+    for _ in range(30):
+        last = float(tr.step(graph)["total_loss"])
+    assert last < first
+    assert np.abs(blk.attn_params["ln_beta"].cpu().numpy()).max() > 0.0
 
 
 def test_attention_gradients_high_degree_rows():
