@@ -12,279 +12,15 @@
 // The 2K "layers" (K forward rows then K backward rows) share the forward kernel's chunk loop
 // (gnf_fused_dev.h): a backward row is a layer whose packed weights are WpT_j, whose bias is zero and
 // whose activation is the mask multiply.
-#include "gnf_fused_dev.h"
+#include "gnf_fused_bwd_dev.h"
 
 #include <string.h>
 
 namespace gnf {
 
-static constexpr int kBwdThreads = 512;
-static constexpr int kBwdLdsLimit = 160 * 1024;
-static constexpr int kBwdRowptrPad = 40;
-static constexpr int kBwdColCap = 2048;
-static constexpr int kRows = 2 * GNF_MAX_LAYERS;
-
-// table row: 0 ipg, 1 ont, 2 boff, 3 true output width, 4 mode (0 recompute, 1 backward), 5 mask slot (-1: none),
-//            6 dump row stride, 7 -, 8-9 packed weights net 0, 10-11 net 1, 12-13 dump pointer net 0, 14-15 net 1
-struct BwdArgs {
-    const int32_t* rowptr;
-    const int32_t* col;
-    const float* x_cond;
-    float* y_upd;
-    float* g_upd;
-    float* h0_out;
-    const float* h0_in[2];  // attention GNNs: the layer-0 input of each net comes from the attention front-end
-    float* gst[2];
-    const float* bias[2];
-    int32_t tab[kRows][16];
-    int64_t ld, ldg;
-    int32_t n_nodes, n_tiles, H, in0, K, LS, bias_tot, bias_tot2, mld;
-    int32_t mean, concat, act;
-    int32_t residual;  // attention block with residual: s, t = MLP(h0) + x_cond (gnn.py:547-548)
-    float eps, alpha;
-};
-
-template <int MT>  // 16 * MT nodes per workgroup: MT = 2 halves the weight stream per node on batches with more than
-                    // one 16-node tile per CU (measured on the forward kernel: 64 us per 32 nodes vs 37.5 per 16)
+template <int MT>
 __global__ __launch_bounds__(kBwdThreads) void k_half_bwd_fused(const BwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TM = 16 * MT, WPN = 4;
-    const int LS = a.LS;
-    auto buf = [&](int net_, int pp_) -> float* { return smem + (2 * net_ + pp_) * TM * LS; };
-    float* bias_lds = smem + 4 * TM * LS;
-    int* tab = reinterpret_cast<int*>(bias_lds + 2 * a.bias_tot2);
-    int* s_rowptr = tab + kRows * 16;
-    int* s_col = s_rowptr + kBwdRowptrPad;
-    unsigned long long* masks = reinterpret_cast<unsigned long long*>(s_col + kBwdColCap);  // [net][K-1][MT*4][mld]
-
-    int tile;
-    {
-        const int bid = blockIdx.x, nwg = gridDim.x, xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
-        tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    }
-    const int row0 = tile * TM;
-    const int tid = threadIdx.x;
-    const int H = a.H;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int nl = wave / WPN;
-    const int wl = (wave % WPN + nl * (WPN / 2)) % WPN;  // t-net ownership rotated by half a turn (see gnf_fused.hip)
-    const int voff = lane * 16;
-    const int R = 2 * a.K;  // rows of the layer table
-
-    auto fill_chunk = [&](WChunk& c, int r, int ipg_, int ont_, int boff_, const float* wb, int nt0) {
-        c.wbase = wb;
-        c.wbytes = (unsigned)ipg_ * (unsigned)ont_ * 1024u;
-        c.ipg = ipg_;
-        c.ont = ont_;
-        c.boff = boff_;
-        c.nt0 = nt0;
-        const int nv = (ont_ - nt0 + WPN - 1) / WPN;
-        c.nv = nv > 4 ? 4 : nv;
-        c.layer = r;
-    };
-    auto ptr_of = [&](const int* row, int slot) -> unsigned long long {
-        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane(row[slot]);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane(row[slot + 1]);
-        return ((unsigned long long)hi << 32) | lo;
-    };
-    auto chunk_from_tab = [&](int r, int nt0) -> WChunk {
-        const int* row = tab + 16 * r;
-        WChunk c;
-        fill_chunk(c, r, __builtin_amdgcn_readfirstlane(row[0]), __builtin_amdgcn_readfirstlane(row[1]),
-                   __builtin_amdgcn_readfirstlane(row[2]), reinterpret_cast<const float*>(ptr_of(row, 8 + 2 * nl)), nt0);
-        return c;
-    };
-    auto next_chunk = [&](const WChunk& c) -> WChunk {
-        int r = c.layer, nt0 = c.nt0 + 4 * WPN;
-        if (nt0 < c.ont) {
-            WChunk n = c;
-            n.nt0 = nt0;
-            const int nv = (c.ont - nt0 + WPN - 1) / WPN;
-            n.nv = nv > 4 ? 4 : nv;
-            return n;
-        }
-        for (++r; r < R; ++r) {
-            const int ont_ = __builtin_amdgcn_readfirstlane(tab[16 * r + 1]);
-            if (wl < ont_) return chunk_from_tab(r, wl);
-        }
-        WChunk n = c;
-        n.layer = R;
-        return n;
-    };
-    WChunk cur;
-    {   // first chunk straight from the kernel arguments (the LDS table does not exist yet)
-        int r0 = 0;
-        while (r0 < R && wl >= a.tab[r0][1]) ++r0;
-        const int rr = r0 < R ? r0 : 0;
-        const unsigned long long wp = ((unsigned long long)(unsigned)a.tab[rr][9 + 2 * nl] << 32) |
-                                      (unsigned)a.tab[rr][8 + 2 * nl];
-        fill_chunk(cur, rr, a.tab[rr][0], a.tab[rr][1], a.tab[rr][2], reinterpret_cast<const float*>(wp),
-                   r0 < R ? wl : 0);
-        if (r0 >= R) cur.layer = R;
-    }
-    f32x4 b_pre[kPF][4];
-    prefetch_chunk(cur, WPN, voff, b_pre);
-
-    // ---- prologue loads, all issued before any is consumed ----------------------------------------
-    int rp_reg = 0;
-    if (tid <= TM) {
-        const int r = row0 + tid;
-        rp_reg = a.rowptr[r < a.n_nodes ? r : a.n_nodes];
-    }
-    constexpr int kBiasRegs = 8;
-    const int bias_all = 2 * a.bias_tot2;
-    float breg[kBiasRegs];
-#pragma unroll
-    for (int q = 0; q < kBiasRegs; ++q) {
-        const int i = tid + q * kBwdThreads;
-        const int net_ = i >= a.bias_tot2 ? 1 : 0;
-        const int k = i - net_ * a.bias_tot2;
-        const bool live = i < bias_all && k < a.bias_tot;
-        const float* src = net_ ? a.bias[1] : a.bias[0];
-        breg[q] = live ? src[k] : 0.f;  // the tail of each net's block is the zero bias of the backward rows
-    }
-    if (tid < R * 16) tab[tid] = a.tab[tid >> 4][tid & 15];
-    if (tid <= TM) s_rowptr[tid] = rp_reg;
-#pragma unroll
-    for (int q = 0; q < kBiasRegs; ++q) {
-        const int i = tid + q * kBwdThreads;
-        if (i < bias_all) bias_lds[i] = breg[q];
-    }
-    for (int i = tid + kBiasRegs * kBwdThreads; i < bias_all; i += kBwdThreads) {
-        const int net_ = i >= a.bias_tot2 ? 1 : 0;
-        const int k = i - net_ * a.bias_tot2;
-        bias_lds[i] = k < a.bias_tot ? (net_ ? a.bias[1] : a.bias[0])[k] : 0.f;
-    }
-    __syncthreads();
-    // ---- A: aggregate + combine (same arithmetic and order as the forward kernel) ----------------
-    if (a.h0_in[0] != nullptr) {
-        const int in0p = a.tab[0][0] * 16;
-        for (int idx = tid; idx < TM * in0p; idx += kBwdThreads) {
-            const int rl = idx / in0p, c = idx - rl * in0p;
-            const int r = row0 + rl;
-            const bool live = r < a.n_nodes && c < a.in0;
-            buf(0, 0)[rl * LS + c] = live ? a.h0_in[0][(int64_t)r * a.in0 + c] : 0.f;
-            buf(1, 0)[rl * LS + c] = live ? a.h0_in[1][(int64_t)r * a.in0 + c] : 0.f;
-        }
-    } else {
-        const TileAgg ta{a.col, a.x_cond, a.ld, a.n_nodes, row0, H, a.in0, a.tab[0][0] * 16, a.mean, a.concat, a.eps};
-        tile_aggregate<TM, kBwdThreads, kBwdColCap>(ta, s_rowptr, s_col, buf(0, 0), buf(1, 0), LS, a.h0_out, tid);
-    }
-    __syncthreads();
-
-    // ---- one table row = one layer of one direction --------------------------------------------
-    int pp = 0;
-    auto run_row = [&](int r) {
-        const int* row = tab + 16 * r;
-        const int mode = __builtin_amdgcn_readfirstlane(row[4]);
-        const int slot = __builtin_amdgcn_readfirstlane(row[5]);
-        const bool last_fwd = (r == a.K - 1);
-        const float* in_lds = buf(nl, pp);
-        float* out_lds = buf(nl, pp ^ 1);
-        const float act_slope = a.act == GNF_ACT_RELU ? 0.f : a.alpha;
-        const float slope = (mode == 1 || last_fwd) ? 1.f : act_slope;
-        EpiArgs ea;
-        ea.mode = mode;
-        ea.dump = nullptr;  // the layer's outputs leave through the coalesced copy below, not element by element
-        ea.dld = __builtin_amdgcn_readfirstlane(row[6]);
-        ea.width = __builtin_amdgcn_readfirstlane(row[3]);
-        ea.row0 = row0;
-        ea.n_nodes = a.n_nodes;
-        ea.mask = slot >= 0 ? masks + ((size_t)(nl * (a.K - 1) + slot)) * (MT * 4) * a.mld : nullptr;
-        ea.mld = a.mld;
-        ea.act_slope = act_slope;
-        while (cur.layer == r) {  // wave-uniform
-            const WChunk c = cur;
-            const WChunk nxt = next_chunk(c);
-            const WChunk nx = nxt.layer < R ? nxt : c;
-            const float* bl = bias_lds + nl * a.bias_tot2 + c.boff;
-            if (c.nv >= 4)
-                mlp_chunk<MT, 4, EPI_EX>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea);
-            else if (c.nv == 3)
-                mlp_chunk<MT, 3, EPI_EX>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea);
-            else if (c.nv == 2)
-                mlp_chunk<MT, 2, EPI_EX>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea);
-            else
-                mlp_chunk<MT, 1, EPI_EX>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea);
-            cur = nxt;
-        }
-        pp ^= 1;
-        __syncthreads();
-        // the row's outputs (h_{j+1} or dP_{j-1} of both nets) go to global memory for the dW GEMM: one coalesced
-        // 16-byte-per-lane copy out of the LDS buffer the next row reads (element-wise stores from the accumulator
-        // layout, 64-byte segments, made this kernel store-bound on large batches)
-        {
-            const int width = ea.width;
-            const int64_t dld = ea.dld;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                float* dump = reinterpret_cast<float*>(ptr_of(row, 12 + 2 * q));
-#ifdef GNF_ABL_NODUMP  // timing ablation only (wrong gradients): what the dW operand dumps cost
-                dump = nullptr;
-#endif
-                if (dump == nullptr) continue;
-                const float* src = buf(q, pp);
-                if (((width | (int)dld) & 3) == 0 && (reinterpret_cast<uintptr_t>(dump) & 15) == 0) {
-                    const int w4 = width >> 2;
-                    for (int i = tid; i < TM * w4; i += kBwdThreads) {
-                        const int rl = i / w4, c4 = (i - rl * w4) * 4;
-                        const int r = row0 + rl;
-                        if (r < a.n_nodes)
-                            *reinterpret_cast<f32x4*>(dump + (int64_t)r * dld + c4) =
-                                *reinterpret_cast<const f32x4*>(src + rl * LS + c4);
-                    }
-                } else {
-                    for (int i = tid; i < TM * width; i += kBwdThreads) {
-                        const int rl = i / width, c = i - rl * width;
-                        const int r = row0 + rl;
-                        if (r < a.n_nodes) dump[(int64_t)r * dld + c] = src[rl * LS + c];
-                    }
-                }
-            }
-        }
-    };
-
-    // ---- B: recompute -------------------------------------------------------------------------
-    for (int r = 0; r < a.K; ++r) run_row(r);
-
-    // ---- C': coupling, undone and differentiated --------------------------------------------------
-    {
-        const float* s_lds = buf(0, pp);
-        const float* t_lds = buf(1, pp);
-        float* gs_lds = buf(0, pp ^ 1);
-        float* gt_lds = buf(1, pp ^ 1);
-        const int hp = a.tab[a.K][0] * 16;  // padded input width of the first backward row
-        for (int idx = tid; idx < TM * hp; idx += kBwdThreads) {
-            const int rl = idx / hp, f = idx - rl * hp;
-            const int r = row0 + rl;
-            float gs = 0.f, gt = 0.f;
-            if (r < a.n_nodes && f < H) {
-                float sv = s_lds[rl * LS + f], tv = t_lds[rl * LS + f];
-                if (a.residual) {
-                    const float xr = a.x_cond[(int64_t)r * a.ld + f];
-                    sv += xr;
-                    tv += xr;
-                }
-                float* py = a.y_upd + (int64_t)r * a.ld + f;
-                float* pg = a.g_upd + (int64_t)r * a.ldg + f;
-                const float yv = *py, gv = *pg;
-                const float d = yv - tv;
-                *py = d * expf(-sv);
-                *pg = gv * expf(sv);
-                gs = gv * d - 1.f;
-                gt = gv;
-                a.gst[0][(int64_t)r * H + f] = gs;
-                a.gst[1][(int64_t)r * H + f] = gt;
-            }
-            gs_lds[rl * LS + f] = gs;
-            gt_lds[rl * LS + f] = gt;
-        }
-        pp ^= 1;
-        __syncthreads();
-    }
-
-    // ---- B': the layers backwards -----------------------------------------------------------------
-    for (int r = a.K; r < R; ++r) run_row(r);
+    half_bwd_body<MT>(a, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -329,14 +65,13 @@ void fused_bwd_launch_shape(const GnfMlp* s, int64_t n, int64_t* tiles, size_t* 
 
 // hin / dP: [net * K + j] global buffers the dW GEMM will read: hin[.][j] = input of layer j (j >= 1; h0 is
 // shared), dP[.][j] = dL/d(pre-activation of layer j) for j <= K-2; dh0: [net] = dL/dh0.
-int launch_half_bwd_fused(const int32_t* rowptr, const int32_t* col, int64_t n, const GnfGnnSpec& gnn,
-                          const GnfMlp* s, const GnfMlp* t, const float* x_cond, float* y_upd, int64_t ld,
-                          float* g_upd, int64_t ldg, int32_t H, float* h0_out, const float* const* h0_in, float* const* hin,
-                          int64_t ldh, float* const* dP, int64_t lddp, float* const* gst, float* const* dh0,
-                          hipStream_t st) {
-    if (n == 0) return GNF_OK;
+int build_bwd_args(const int32_t* rowptr, const int32_t* col, int64_t n, const GnfGnnSpec& gnn, const GnfMlp* s,
+                   const GnfMlp* t, const float* x_cond, float* y_upd, int64_t ld, float* g_upd, int64_t ldg, int32_t H,
+                   float* h0_out, const float* const* h0_in, float* const* hin, int64_t ldh, float* const* dP,
+                   int64_t lddp, float* const* gst, float* const* dh0, BwdArgs* out, int* mt, int64_t* tiles_out,
+                   size_t* lds) {
     const int K = s->num_layers;
-    BwdArgs a;
+    BwdArgs& a = *out;
     memset(&a, 0, sizeof(a));
     a.rowptr = rowptr;
     a.col = col;
@@ -416,15 +151,34 @@ int launch_half_bwd_fused(const int32_t* rowptr, const int32_t* col, int64_t n, 
     const int MT = ((n + 15) / 16 > 256 && bwd_lds_bytes(s, 2) <= (size_t)kBwdLdsLimit) ? 2 : 1;
     const int64_t tiles = (n + 16 * MT - 1) / (16 * MT);
     a.n_tiles = (int32_t)tiles;
+    *mt = MT;
+    *tiles_out = tiles;
+    *lds = bwd_lds_bytes(s, MT);
+    return GNF_OK;
+}
+
+int launch_half_bwd_fused(const int32_t* rowptr, const int32_t* col, int64_t n, const GnfGnnSpec& gnn,
+                          const GnfMlp* s, const GnfMlp* t, const float* x_cond, float* y_upd, int64_t ld,
+                          float* g_upd, int64_t ldg, int32_t H, float* h0_out, const float* const* h0_in, float* const* hin,
+                          int64_t ldh, float* const* dP, int64_t lddp, float* const* gst, float* const* dh0,
+                          hipStream_t st) {
+    if (n == 0) return GNF_OK;
+    BwdArgs a;
+    int MT;
+    int64_t tiles;
+    size_t lds;
+    const int rc = build_bwd_args(rowptr, col, n, gnn, s, t, x_cond, y_upd, ld, g_upd, ldg, H, h0_out, h0_in, hin, ldh, dP,
+                                  lddp, gst, dh0, &a, &MT, &tiles, &lds);
+    if (rc) return rc;
     GNF_ONCE_PER_DEVICE(
         GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_bwd_fused<1>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLdsLimit));
         GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_bwd_fused<2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLdsLimit)));
     if (MT == 2)
-        hipLaunchKernelGGL(k_half_bwd_fused<2>, dim3((unsigned)tiles), dim3(kBwdThreads), bwd_lds_bytes(s, 2), st, a);
+        hipLaunchKernelGGL(k_half_bwd_fused<2>, dim3((unsigned)tiles), dim3(kBwdThreads), lds, st, a);
     else
-        hipLaunchKernelGGL(k_half_bwd_fused<1>, dim3((unsigned)tiles), dim3(kBwdThreads), bwd_lds_bytes(s, 1), st, a);
+        hipLaunchKernelGGL(k_half_bwd_fused<1>, dim3((unsigned)tiles), dim3(kBwdThreads), lds, st, a);
     GNF_LAUNCH_CHECK("k_half_bwd_fused");
     return GNF_OK;
 }

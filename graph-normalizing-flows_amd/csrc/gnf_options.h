@@ -31,6 +31,7 @@ enum OptionId {
     OPT_DW_DEBUG,            // print the dW launch plan to stderr (first two launches)
     OPT_DW_LATE_FORK,        // fork the dW stream behind the dL/dx scatter
     OPT_BWD_GENERIC,         // backward pass through the generic GEMM path even where the fused kernel fits
+    OPT_DW_UNMERGED,         // small batches: dW GEMMs on the auxiliary stream (round-1 scheme) instead of inside the backward launch
     OPT_COUNT
 };
 

@@ -18,6 +18,7 @@
 // is ever made.  Also here: the multi-tensor weight re-pack after an optimiser step, Adam
 // (tf.train.AdamOptimizer, run_grevnet.py:352-356) and the two gradient clippers (run_grevnet.py:363-373).
 #include "gnf_common.h"
+#include "gnf_fused_bwd_dev.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -572,14 +573,15 @@ static constexpr size_t kWideLdsMin = (size_t)2 * kWideStage * sizeof(float);
 #endif
 static constexpr int kWideLoadPolicy = GNF_DW_LOAD_POLICY;
 
-struct WideGemm {
-    GemmJob job[kMaxGroup];  // largest first
-    int64_t lda[kMaxGroup], ldb[kMaxGroup];
-    int32_t M[kMaxGroup], N[kMaxGroup];
-    int32_t unit_base[kMaxGroup + 1];  // prefix sums of workgroups (128 x 128 tiles x node chunks) per job
-    int32_t gx[kMaxGroup];
-    int32_t chunks[kMaxGroup];         // split of the node axis, per job: light jobs are cut less often
-    int32_t kchunk[kMaxGroup];         // rows per chunk, a multiple of WGK
+template <int G>
+struct WideGemmT {
+    GemmJob job[G];  // largest first
+    int64_t lda[G], ldb[G];
+    int32_t M[G], N[G];
+    int32_t unit_base[G + 1];  // prefix sums of workgroups (128 x 128 tiles x node chunks) per job
+    int32_t gx[G];
+    int32_t chunks[G];         // split of the node axis, per job: light jobs are cut less often
+    int32_t kchunk[G];         // rows per chunk, a multiple of WGK
     int64_t K;
     int32_t njobs;
     // stream-K over the costliest jobs (sk_q > 0): their tiles x k-steps form ONE axis of sk_tiles * sk_steps steps, cut
@@ -590,6 +592,10 @@ struct WideGemm {
     int32_t sk_q, sk_steps, sk_tiles, sk_jobs;
     int32_t sk_light_base;  // first unit of the jobs cut the uniform way (they ride behind, strided)
 };
+using WideGemm = WideGemmT<kMaxGroup>;
+// message-passing nets only (no attention matrices): what fits next to the backward kernel's arguments in one launch
+static constexpr int kMergedGroup = 2 * GNF_MAX_LAYERS;
+using WideGemmS = WideGemmT<kMergedGroup>;
 
 // One BK = 32 step of a wave's MTW x NTW block of MFMA tiles.  A wave is alone on its SIMD here and issues in order,
 // so everything that is not an MFMA has to sit BETWEEN MFMAs to be free (an instruction placed behind a run of MFMAs
@@ -668,20 +674,21 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // interleaves; tiles past the chunk's end are fetched and stashed like any other (zeros, never read).  Columns past
 // M / N read whatever follows in the row; they only reach accumulators that are never stored.  The generic path
 // (any pitch / alignment) keeps the bounds-checked fetch in front of the MFMA block.
-template <bool BUF>
-__global__ __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_dw_wide(const WideGemm g) {
+// vblock / vgrid: this workgroup's index among the vgrid workgroups that share the launch's weight-gradient work
+template <bool BUF, class WG>
+__device__ __forceinline__ void dw_wide_body(const WG& g, const int vblock, const int vgrid) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
 #ifdef GNF_DW_TRACE
     unsigned long long tt0 = __builtin_amdgcn_s_memtime();
 #endif
-    // a workgroup takes unit blockIdx.x (a chunk of one of the costliest tiles; those are cut equal) and then, strided,
+    // a workgroup takes unit vblock (a chunk of one of the costliest tiles; those are cut equal) and then, strided,
     // its share of the cheap units that follow them in the list
     for (int it = 0;; ++it) {
     int j = 0, lt, chunk, zero_from = 0, zero_to = 0;
     int64_t kbeg, kend;
     if (g.sk_q > 0 && it < 2) {  // stream-K: this workgroup's run [a, b) of the costliest jobs' step axis
         const int64_t total = (int64_t)g.sk_tiles * g.sk_steps;
-        const int64_t a = (int64_t)blockIdx.x * g.sk_q, b = a + g.sk_q < total ? a + g.sk_q : total;
+        const int64_t a = (int64_t)vblock * g.sk_q, b = a + g.sk_q < total ? a + g.sk_q : total;
         if (a >= b) continue;
         const int t0 = (int)(a / g.sk_steps);
         const int64_t e0 = b < (int64_t)(t0 + 1) * g.sk_steps ? b : (int64_t)(t0 + 1) * g.sk_steps;
@@ -697,13 +704,13 @@ __global__ __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(2,
         lt = t - g.unit_base[j];
         const int first_w = (int)(((int64_t)t * g.sk_steps) / g.sk_q);
         const int last_w = (int)((((int64_t)(t + 1) * g.sk_steps) - 1) / g.sk_q);
-        chunk = (int)blockIdx.x - first_w;
+        chunk = vblock - first_w;
         kbeg = s0 * WGK;
         kend = s1 * WGK < g.K ? s1 * WGK : g.K;
         if (chunk == 0) zero_from = last_w - first_w + 1, zero_to = g.chunks[j];
     } else {
         const int first = g.sk_q > 0 ? g.sk_light_base : 0;
-        const int u = first + (int)blockIdx.x + (it - (g.sk_q > 0 ? 2 : 0)) * (int)gridDim.x;
+        const int u = first + vblock + (it - (g.sk_q > 0 ? 2 : 0)) * vgrid;
         if (u >= g.unit_base[g.njobs]) break;
         j = g.sk_q > 0 ? g.sk_jobs : 0;
         while (j + 1 < g.njobs && u >= g.unit_base[j + 1]) ++j;
@@ -822,7 +829,7 @@ __global__ __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(2,
             GNF_DWT(4, tt);
             cur ^= 1;
 #ifdef GNF_DW_TRACE
-            if (blockIdx.x == 0 && threadIdx.x == 0) g_dw_trace[7] += 1;
+            if (vblock == 0 && threadIdx.x == 0) g_dw_trace[7] += 1;
 #endif
         }
     };
@@ -896,6 +903,11 @@ __global__ __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(2,
     GNF_DWT(6, tt0);
 #endif
     }  // items of this workgroup
+}
+
+template <bool BUF>
+__global__ __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_dw_wide(const WideGemm g) {
+    dw_wide_body<BUF>(g, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Thin outputs with a long reduction (a 2048 -> 100 layer on a 440-node batch: 16 tiles, 64 k-steps each, 80 us on 16
@@ -1025,20 +1037,23 @@ struct ReduceJob {
     float* gw;
     float* gb;
 };
-struct GroupedReduce {
-    ReduceJob job[kMaxGroup];
-    int64_t nw[kMaxGroup];
-    int32_t nb[kMaxGroup];
-    int32_t chunks[kMaxGroup];
+template <int G>
+struct GroupedReduceT {
+    ReduceJob job[G];
+    int64_t nw[G];
+    int32_t nb[G];
+    int32_t chunks[G];
     int32_t accumulate;
 };
-__global__ __launch_bounds__(256) void k_reduce_grouped(const GroupedReduce g) {
-    const int j = blockIdx.y;
+using GroupedReduce = GroupedReduceT<kMaxGroup>;
+using GroupedReduceS = GroupedReduceT<kMergedGroup>;
+// element e of job j (the weight gradient first, then the bias gradient)
+template <class GR>
+__device__ __forceinline__ void reduce_element(const GR& g, const int j, const int64_t e) {
     const ReduceJob job = g.job[j];
     const int64_t nw = g.nw[j];
     const int nb = g.nb[j];
     const int nchunk = g.chunks[j];
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e < nw) {
         float s = 0.f;
         for (int c = 0; c < nchunk; ++c) s += job.wslab[(int64_t)c * nw + e];
@@ -1049,6 +1064,80 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const GroupedReduce g) {
         for (int c = 0; c < nchunk; ++c) s += job.bslab[(int64_t)c * nb + i];
         job.gb[i] = g.accumulate ? job.gb[i] + s : s;
     }
+}
+// All jobs of a reduce as ONE index space, strided over `nthr` threads (this one is thread `t`): every item (four
+// consecutive weight-gradient elements, or one element where a job cannot be read as float4) sums its slabs with up to
+// eight chunk loads in flight, and a thread's items are independent of each other.  (The first version walked job after
+// job and chunk after chunk, one dependent load at a time: 18 us for the config-2 nets on 85 workgroups against 5 us
+// for k_reduce_grouped on the whole chip.)  The sum keeps chunk order, so the gradients are bitwise the same.
+template <class T>
+__device__ __forceinline__ T sum_slabs(const float* __restrict__ slab, const int64_t stride, const int64_t e, const int nchunk) {
+    T s = T(0.f);
+    for (int c = 0; c < nchunk; c += 8) {
+        T v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {  // indices clamped, adds predicated: one round trip for up to eight chunks
+            const int cc = c + q < nchunk ? c + q : nchunk - 1;
+            v[q] = *reinterpret_cast<const T*>(slab + (int64_t)cc * stride + e);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (c + q < nchunk) s += v[q];
+    }
+    return s;
+}
+template <class GR>
+__device__ __forceinline__ void reduce_jobs_strided(const GR& g, const int nj, const int64_t t, const int64_t nthr) {
+    typedef float V4 __attribute__((ext_vector_type(4)));
+    auto vec_ok = [&](int j) {
+        return (g.nw[j] & 3) == 0 &&
+               ((reinterpret_cast<uintptr_t>(g.job[j].wslab) | reinterpret_cast<uintptr_t>(g.job[j].gw)) & 15) == 0;
+    };
+    int64_t quads = 0, singles = 0;
+    for (int j = 0; j < nj; ++j) {
+        if (vec_ok(j))
+            quads += g.nw[j] >> 2;
+        else
+            singles += g.nw[j];
+        singles += g.nb[j];
+    }
+    for (int64_t q = t; q < quads; q += nthr) {
+        int j = 0;
+        int64_t lq = q;
+        for (;; ++j) {
+            const int64_t nq = vec_ok(j) ? g.nw[j] >> 2 : 0;
+            if (lq < nq) break;
+            lq -= nq;
+        }
+        const ReduceJob job = g.job[j];
+        const V4 s = sum_slabs<V4>(job.wslab, g.nw[j], 4 * lq, g.chunks[j]);
+        V4* dst = reinterpret_cast<V4*>(job.gw + 4 * lq);
+        *dst = g.accumulate ? *dst + s : s;
+    }
+    for (int64_t q = t; q < singles; q += nthr) {
+        int j = 0;
+        int64_t lq = q;
+        bool bias = false;
+        for (;; ++j) {
+            const int64_t n1 = vec_ok(j) ? 0 : g.nw[j];
+            if (lq < n1) break;
+            lq -= n1;
+            if (lq < g.nb[j]) {
+                bias = true;
+                break;
+            }
+            lq -= g.nb[j];
+        }
+        const ReduceJob job = g.job[j];
+        const float s = bias ? sum_slabs<float>(job.bslab, g.nb[j], lq, g.chunks[j])
+                             : sum_slabs<float>(job.wslab, g.nw[j], lq, g.chunks[j]);
+        float* dst = (bias ? job.gb : job.gw) + lq;
+        *dst = g.accumulate ? *dst + s : s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_grouped(const GroupedReduce g) {
+    reduce_element(g, blockIdx.y, (int64_t)blockIdx.x * 256 + threadIdx.x);
 }
 
 // g[N, D] <- z[N, D]: dL/dz of L = 1/2 sum z^2 + const - logdet
@@ -1304,6 +1393,8 @@ struct BwdPlan {
     size_t set_stride;  // the dW operands exist n_sets times: half-step k's dW GEMMs run on the auxiliary stream while
                         // half-steps k+1, k+2 refill the other sets (with two sets the walk waited ~10 us per half-step
                         // for the dW launch of two half-steps earlier to release the set it was about to refill)
+    int slab_sets;      // 2 where the merged backward + dW launch may run (the dW GEMMs of half-step k-1 write one
+    size_t slab_stride; // set while the reduce of half-step k-2 reads the other), else 1;  floats between the sets
     size_t total;
 };
 
@@ -1315,6 +1406,7 @@ static inline size_t al64(size_t v) { return (v + 63) / 64 * 64; }  // keep ever
 // per half-step, i.e. no wait on the main stream at all, changed nothing in the step time (2.41 vs 2.38 ms), and a
 // captured-graph replay of the whole step is 2 % faster than eager launches: the gaps belong to the cross-queue
 // dependency itself, not to the host or to the wait packets.  The generic code below still takes any set count.)
+static constexpr int kMergedMaxTiles = 192;  // backward tiles of a launch that still leaves CUs for the dW GEMMs
 static constexpr int kLnBwdRows = 64;  // rows per workgroup of the layer-norm backward kernel
 static constexpr int kBwdMaxSets = 64;
 static constexpr int kBwdSetsDefault = 3;
@@ -1373,6 +1465,9 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net, int n_sets
     p.st = off, off += 2 * al64((size_t)n * p.H);
     p.wslab = off, off += al64((size_t)chunks * p.wsum);
     p.bslab = off, off += al64((size_t)chunks * p.osum);
+    p.slab_stride = off - p.wslab;
+    p.slab_sets = (!net->attn && (n + 15) / 16 <= kMergedMaxTiles) ? 2 : 1;
+    off += (size_t)(p.slab_sets - 1) * p.slab_stride;
     p.qkv = off, off += 2 * al64((size_t)n * p.P);
     p.dagg = off, off += 2 * al64((size_t)n * p.NV);
     p.stats = off, off += 2 * al64((size_t)n * 3 * p.nh);
@@ -1512,12 +1607,31 @@ static DwPolicy dw_policy(const GnfMlp* net, int64_t bwd_tiles, size_t bwd_lds) 
     return pol;
 }
 
-static int launch_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob* jobs, int nj, bool accumulate,
-                               float* ws, hipStream_t st) {
+// Everything launch_weight_grads decides, kept so that the GEMM launch and the reduce launch can be issued apart (or
+// ride in another launch: the merged backward + dW kernel below).
+struct DwLaunch {
+    bool wide, buf, direct;
+    WideGemm wg;
     GroupedGemm gg;
     GroupedReduce gr;
+    int units, nj;
+    size_t lds;
+    int64_t maxred;
+    int gx, gy, nz, groups, rpg;  // grouped kernel geometry
+    unsigned blocks;
+    bool gbuf;
+};
+
+// slab_set: which of the plan's slab sets (BwdPlan.slab_sets) the GEMM writes and the reduce reads
+static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob* jobs, int nj, bool accumulate,
+                             float* ws, int slab_set, DwLaunch* L) {
+    GroupedGemm& gg = L->gg;
+    GroupedReduce& gr = L->gr;
     memset(&gg, 0, sizeof(gg));
     memset(&gr, 0, sizeof(gr));
+    L->nj = nj;
+    L->lds = pol.lds;
+    ws += (size_t)slab_set * p.slab_stride;
     int maxM = 1, maxN = 1;
     int64_t maxred = 1;
     int64_t woff = 0, boff = 0;
@@ -1545,10 +1659,9 @@ static int launch_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJo
     gg.chunks = p.chunks;
     for (int e = 0; e < nj; ++e) gr.chunks[e] = p.chunks;
     gr.accumulate = accumulate ? 1 : 0;
-    bool direct = false;  // gradients written by the GEMM itself (single chunk): no reduce launch
     // ---- wide kernel: cut every job along the node axis so that the workgroups carry about equal MFMA work --------
     bool wide = pol.max_units > 0 && p.n > 0;
-    WideGemm wg;
+    WideGemm& wg = L->wg;
     int units = 0;
     int64_t max_kchunk = WGK;
     if (wide) {
@@ -1691,23 +1804,19 @@ static int launch_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJo
             }
         }
     }
+    L->wide = wide;
+    L->units = units;
+    L->maxred = maxred;
+    L->direct = false;
+    L->buf = false;
     if (wide) {
-        GNF_ONCE_PER_DEVICE(
-            GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_wide<true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_wide<false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
         // buffer path: byte offsets inside a chunk (+ the two tiles fetched past its end) stay below 2^31.  Rows need
         // not be 16-byte aligned: buffer_load_dwordx4 only asks for dword alignment (the attention projections have
         // 170-float rows)
         bool buf = opt(OPT_DW_NO_BUF) == 0;
         for (int e = 0; e < nj; ++e)
             buf = buf && (max_kchunk + 4 * WGK) * (jobs[e].lda > jobs[e].ldb ? jobs[e].lda : jobs[e].ldb) * 4 < ((int64_t)1 << 31);
-        if (buf)
-            hipLaunchKernelGGL(k_gemm_dw_wide<true>, dim3((unsigned)units), dim3(kWideThreads), pol.lds, st, wg);
-        else
-            hipLaunchKernelGGL(k_gemm_dw_wide<false>, dim3((unsigned)units), dim3(kWideThreads), pol.lds, st, wg);
-        GNF_LAUNCH_CHECK("k_gemm_dw_wide");
+        L->buf = buf;
     } else {
         const int gx = (maxN + TGN - 1) / TGN, gy = (maxM + TGM - 1) / TGM, nz = nj * p.chunks;
         int groups = nz >= 32 ? 1 : (32 + nz - 1) / nz;   // enough bands that every XCD gets several
@@ -1715,23 +1824,133 @@ static int launch_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJo
         const int rpg = (gy + groups - 1) / groups;
         groups = (gy + rpg - 1) / rpg;
         const int nv = nz * groups;
-        const unsigned blocks = 8u * (unsigned)((nv + 7) / 8) * (unsigned)(gx * rpg);
+        L->blocks = 8u * (unsigned)((nv + 7) / 8) * (unsigned)(gx * rpg);
+        L->gx = gx, L->gy = gy, L->nz = nz, L->groups = groups, L->rpg = rpg;
         if (p.chunks == 1 && !accumulate) {  // one chunk: its "slab" IS the gradient - written in place, no reduce pass
             for (int e = 0; e < nj; ++e) gg.job[e].C = jobs[e].gw, gg.job[e].aux_out = jobs[e].gb;
-            direct = true;
+            L->direct = true;
         }
         bool gbuf = true;
         for (int e = 0; e < nj; ++e)
             gbuf = gbuf && gemm_buf_ok(OPND_MC, OPND_MC, p.kchunk, jobs[e].lda, p.kchunk, jobs[e].ldb, p.n);
-        if (gbuf)
-            hipLaunchKernelGGL(k_gemm_dw_grouped<true>, dim3(blocks), dim3(kGemmThreads), 0, st, gg, gx, gy, nz, groups, rpg);
+        L->gbuf = gbuf;
+    }
+    return GNF_OK;
+}
+
+static int run_weight_gemms(const DwLaunch& L, hipStream_t st) {
+    if (L.wide) {
+        GNF_ONCE_PER_DEVICE(
+            GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_wide<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_dw_wide<false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+        if (L.buf)
+            hipLaunchKernelGGL(k_gemm_dw_wide<true>, dim3((unsigned)L.units), dim3(kWideThreads), L.lds, st, L.wg);
         else
-            hipLaunchKernelGGL(k_gemm_dw_grouped<false>, dim3(blocks), dim3(kGemmThreads), 0, st, gg, gx, gy, nz, groups, rpg);
+            hipLaunchKernelGGL(k_gemm_dw_wide<false>, dim3((unsigned)L.units), dim3(kWideThreads), L.lds, st, L.wg);
+        GNF_LAUNCH_CHECK("k_gemm_dw_wide");
+    } else {
+        if (L.gbuf)
+            hipLaunchKernelGGL(k_gemm_dw_grouped<true>, dim3(L.blocks), dim3(kGemmThreads), 0, st, L.gg, L.gx, L.gy, L.nz,
+                               L.groups, L.rpg);
+        else
+            hipLaunchKernelGGL(k_gemm_dw_grouped<false>, dim3(L.blocks), dim3(kGemmThreads), 0, st, L.gg, L.gx, L.gy, L.nz,
+                               L.groups, L.rpg);
         GNF_LAUNCH_CHECK("k_gemm_dw_grouped");
     }
-    if (direct) return GNF_OK;
-    hipLaunchKernelGGL(k_reduce_grouped, dim3((unsigned)((maxred + 255) / 256), (unsigned)nj), dim3(256), 0, st, gr);
+    return GNF_OK;
+}
+
+static int run_weight_reduce(const DwLaunch& L, hipStream_t st) {
+    if (L.direct) return GNF_OK;
+    hipLaunchKernelGGL(k_reduce_grouped, dim3((unsigned)((L.maxred + 255) / 256), (unsigned)L.nj), dim3(256), 0, st, L.gr);
     GNF_LAUNCH_CHECK("k_reduce_grouped");
+    return GNF_OK;
+}
+
+static int launch_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob* jobs, int nj, bool accumulate,
+                               float* ws, hipStream_t st) {
+    DwLaunch L;
+    int rc = plan_weight_grads(p, pol, jobs, nj, accumulate, ws, 0, &L);
+    if (rc) return rc;
+    rc = run_weight_gemms(L, st);
+    if (rc) return rc;
+    return run_weight_reduce(L, st);
+}
+
+// ---- one launch per half-step of the backward walk (small batches) ------------------------------------------------
+// A batch of up to kMergedMaxTiles 16-node tiles leaves CUs idle under the fused backward kernel (config-2 batch: 170
+// tiles on 256 CUs).  Until round 2 the weight-gradient GEMMs of a half-step ran on a second stream into exactly those
+// CUs; every fork / join event between the two queues cost ~6 us of command-processor latency on the critical path
+// (profiles/r2u_train_timeline.txt).  Here ONE launch carries, software-pipelined,
+//   workgroups [0, n_bwd)        the backward kernel of half-step k            (half_bwd_body, one 16-node tile each)
+//   workgroups [n_bwd, n_bwd+n_dw) the dW GEMMs of half-step k-1                 (dw_wide_body; its operands are complete)
+//   all workgroups behind n_bwd  the fixed-order slab reduce of half-step k-2  (reduce_element; slab sets alternate)
+// so the walk needs no second stream, no events, and the kernel boundary is the only synchronisation.  Every
+// workgroup asks for the backward kernel's LDS footprint (> 80 KB), i.e. one workgroup per CU.
+template <int MT>
+__global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_half_bwd_dw(const BwdArgs a, const WideGemmS g, const GroupedReduceS r, const int n_bwd, const int n_dw, const int r_nj) {
+    const int bid = (int)blockIdx.x;
+    if (bid < n_bwd) {
+        half_bwd_body<MT>(a, bid, n_bwd);
+        return;
+    }
+    const int v = bid - n_bwd;
+    if (v < n_dw) dw_wide_body<true>(g, v, n_dw);
+    if (r_nj > 0) reduce_jobs_strided(r, r_nj, (int64_t)v * kBwdThreads + threadIdx.x, (int64_t)((int)gridDim.x - n_bwd) * kBwdThreads);
+}
+static_assert(kBwdThreads == kWideThreads, "the merged launch runs both bodies with one workgroup size");
+static_assert(sizeof(BwdArgs) + sizeof(WideGemmS) + sizeof(GroupedReduceS) + 16 <= 4096, "kernel arguments exceed 4 KB");
+
+static void narrow_wide(const WideGemm& w, WideGemmS* o) {
+    memset(o, 0, sizeof(*o));
+    for (int q = 0; q < kMergedGroup && q < w.njobs; ++q) {
+        o->job[q] = w.job[q];
+        o->lda[q] = w.lda[q], o->ldb[q] = w.ldb[q];
+        o->M[q] = w.M[q], o->N[q] = w.N[q];
+        o->unit_base[q] = w.unit_base[q];
+        o->gx[q] = w.gx[q], o->chunks[q] = w.chunks[q], o->kchunk[q] = w.kchunk[q];
+    }
+    o->unit_base[w.njobs] = w.unit_base[w.njobs];
+    o->K = w.K, o->njobs = w.njobs;
+    o->sk_q = w.sk_q, o->sk_steps = w.sk_steps, o->sk_tiles = w.sk_tiles, o->sk_jobs = w.sk_jobs;
+    o->sk_light_base = w.sk_light_base;
+}
+static void narrow_reduce(const GroupedReduce& r, int nj, GroupedReduceS* o) {
+    memset(o, 0, sizeof(*o));
+    for (int q = 0; q < kMergedGroup && q < nj; ++q) {
+        o->job[q] = r.job[q];
+        o->nw[q] = r.nw[q], o->nb[q] = r.nb[q], o->chunks[q] = r.chunks[q];
+    }
+    o->accumulate = r.accumulate;
+}
+
+// bwd: the half-step to walk (NULL: none - the tail of the pipeline); dw: GEMMs to run beside it (NULL: none);
+// red: a finished GEMM launch whose slabs are due (NULL: none)
+static int launch_half_bwd_dw(const BwdArgs* bwd, int64_t bwd_tiles, size_t bwd_lds, const DwLaunch* dw, const DwLaunch* red,
+                              hipStream_t st) {
+    static const BwdArgs kNoBwd = {};
+    WideGemmS g;
+    GroupedReduceS r;
+    memset(&g, 0, sizeof(g));
+    memset(&r, 0, sizeof(r));
+    int n_dw = 0, r_nj = 0;
+    const int64_t dbg = opt(OPT_DW_DEBUG);  // TEMP ablations: 2 = reduce in its own launch, 4 = no dW GEMMs, 8 = no backward tiles
+    if (dw && !(dbg & 4)) narrow_wide(dw->wg, &g), n_dw = dw->units;
+    if (red && !red->direct && !(dbg & 2)) narrow_reduce(red->gr, red->nj, &r), r_nj = red->nj;
+    if (red && (dbg & 2)) { const int rc_ = run_weight_reduce(*red, st); if (rc_) return rc_; }
+    if (dbg & 8) bwd = nullptr;
+    const int n_bwd = bwd ? (int)bwd_tiles : 0;
+    int grid = n_bwd + n_dw;
+    if (r_nj > 0 && grid == n_bwd) grid += 64;  // reduce only: some workgroups to carry it
+    if (grid == 0) return GNF_OK;
+    GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_bwd_dw<1>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+    size_t lds = bwd_lds > kWideLdsMin ? bwd_lds : kWideLdsMin;
+    hipLaunchKernelGGL(k_half_bwd_dw<1>, dim3((unsigned)grid), dim3(kBwdThreads), lds, st, bwd ? *bwd : kNoBwd, g, r, n_bwd, n_dw, r_nj);
+    GNF_LAUNCH_CHECK("k_half_bwd_dw");
     return GNF_OK;
 }
 
@@ -2246,6 +2465,20 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     // for the last launch, as the final join.
     hipStream_t aux = (hipStream_t)aux_stream;
     if (aux == st) aux = nullptr;
+    // small message-passing batches: one launch per half-step carries the backward kernel, the previous half-step's dW
+    // GEMMs and the reduce of the one before (k_half_bwd_dw) - no second stream
+    bool merged = false;
+    int64_t m_tiles = 0;
+    size_t m_lds = 0;
+    if (!opt(OPT_DW_UNMERGED) && !opt(OPT_BWD_GENERIC) && !opt(OPT_DW_GROUPED) && !flow->s_nets[0].attn && p.slab_sets == 2) {
+        merged = true;
+        for (int q = 0; q < n_nets; ++q) merged = merged && fused_bwd_supported(&flow->s_nets[q], &flow->t_nets[q]);
+        if (merged) {
+            fused_bwd_launch_shape(&flow->s_nets[0], n, &m_tiles, &m_lds);
+            merged = m_tiles == (n + 15) / 16 && m_tiles <= kMergedMaxTiles && m_lds > 80 * 1024;
+        }
+    }
+    if (merged) aux = nullptr;
     const bool reuse_sets = 2 * T > p.n_sets;
     struct CallEvents {
         hipEvent_t ev[kBwdMaxSets + 1] = {};
@@ -2262,6 +2495,8 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     hipEvent_t ev_last = nullptr;
     int step = 0;
     bool used[2] = {false, false};  // weight sharing: the T uses of a net accumulate
+    DwLaunch pend[2];
+    bool pend_ok[2] = {false, false};
     for (int i = T - 1; i >= 0; --i)
         for (int half = 1; half >= 0; --half) {
             const GnfMlp* nets[2] = {pick_net(flow, flow->s_nets, half, i), pick_net(flow, flow->t_nets, half, i)};
@@ -2304,6 +2539,42 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 rc = launch_aggregate(csr->rowptr, csr->col, n, x_cond, ld, H, flow->gnn.agg == GNF_AGG_MEAN,
                                       flow->gnn.combine == GNF_COMBINE_CONCAT ? 1 : 0, flow->gnn.epsilon, o.h0[0], p.in0, st);
                 if (rc) return rc;
+            }
+            if (merged) {
+                BwdArgs ba;
+                int mt;
+                int64_t tiles;
+                size_t lds;
+                rc = build_bwd_args(csr->rowptr, csr->col, n, flow->gnn, nets[0], nets[1], x_cond, z + uo, ld, g + uo, D, H,
+                                    o.h0[0], nullptr, o.hin, p.lmax, o.dPs, p.lmax, o.gst, o.dh0, &ba, &mt, &tiles, &lds);
+                if (rc) return rc;
+                const int prev = (step + 1) & 1, cur = step & 1;   // pend[prev]: half-step k-1, pend[cur]: k-2
+                rc = launch_half_bwd_dw(&ba, tiles, lds, step >= 1 && pend_ok[prev] ? &pend[prev] : nullptr,
+                                        step >= 2 && pend_ok[cur] ? &pend[cur] : nullptr, st);
+                if (rc) return rc;
+                // this half-step's dW GEMMs ride in the next launch (the last one's get the whole chip)
+                WGJob jobs[kMaxGroup];
+                const int nj = weight_grad_jobs(p, o, nets, grads, jobs);
+                const bool last = step == 2 * T - 1;
+                const DwPolicy pol{last ? 256 : 256 - (int)tiles, lds, 1e30};
+                rc = plan_weight_grads(p, pol, jobs, nj, acc, wsf, cur, &pend[cur]);
+                if (rc) return rc;
+                pend_ok[cur] = pend[cur].wide && pend[cur].buf && nj <= kMergedGroup;
+                if (!pend_ok[cur]) {  // (a plan the merged launch cannot carry: run it here and now)
+                    rc = run_weight_gemms(pend[cur], st);
+                    if (rc) return rc;
+                    rc = run_weight_reduce(pend[cur], st);
+                    if (rc) return rc;
+                }
+                rc = launch_aggregate_bwd(p, csr_t, flow->gnn, wsf + p.invdeg, o.dh0[0], o.dh0[1], g + co, D, st);
+                if (rc) return rc;
+                ++step;
+                if (flow->bns) {
+                    rc = launch_bn_backward(flow, &flow->bns[half * T + i], &grad->bns[half * T + i], z + co, ld, g + co, D, n, H,
+                                            reinterpret_cast<double*>(wsf + p.bnpart), st);
+                    if (rc) return rc;
+                }
+                continue;
             }
             // ---- recompute + coupling + dP chain -------------------------------------------------------------
             if (fused) {
@@ -2378,6 +2649,16 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 if (rc) return rc;
             }
         }
+    if (merged) {  // drain the pipeline: dW of the last half-step (+ the reduce before it), then its own reduce
+        const int last = (step + 1) & 1, before = step & 1;
+        rc = launch_half_bwd_dw(nullptr, 0, m_lds, pend_ok[last] ? &pend[last] : nullptr,
+                                step >= 2 && pend_ok[before] ? &pend[before] : nullptr, st);
+        if (rc) return rc;
+        if (pend_ok[last]) {
+            rc = run_weight_reduce(pend[last], st);
+            if (rc) return rc;
+        }
+    }
     // join: the auxiliary stream runs its launches in order, so the last one's event covers them all
     if (aux && ev_last) GNF_HIP_TRY(hipStreamWaitEvent(st, ev_last, 0));
     return GNF_OK;
