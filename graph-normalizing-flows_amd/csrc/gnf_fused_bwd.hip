@@ -41,8 +41,11 @@ static size_t bwd_lds_bytes(const GnfMlp* m, int MT) {
     const int bias_tot2 = bias_tot + max_padded_width_b(m);
     size_t floats = (size_t)(4 * 16 * MT * LS + 2 * bias_tot2);
     floats = (floats + 1) & ~(size_t)1;  // the 64-bit mask words start 8-byte aligned
+    const int HP = pad16b(m->dims[K]);  // output width = H for the nets of a coupling
     return floats * sizeof(float) + (size_t)(kRows * 16 + kBwdRowptrPad + kBwdColCap) * sizeof(int) +
-           (size_t)2 * (K > 1 ? K - 1 : 0) * (MT * 4) * mld * sizeof(unsigned long long);
+           (size_t)2 * (K > 1 ? K - 1 : 0) * (MT * 4) * mld * sizeof(unsigned long long) +
+           // the folded message-passing backward of the previous half-step: transposed CSR slice + two [TM][HP] terms
+           (size_t)(kBwdRowptrPad + kBwdColCap) * sizeof(int) + (size_t)2 * 16 * MT * HP * sizeof(float);
 }
 
 bool fused_bwd_fits_lds(const GnfMlp* m) { return bwd_lds_bytes(m, 1) <= (size_t)kBwdLdsLimit; }
@@ -69,7 +72,7 @@ int build_bwd_args(const int32_t* rowptr, const int32_t* col, int64_t n, const G
                    const GnfMlp* t, const float* x_cond, float* y_upd, int64_t ld, float* g_upd, int64_t ldg, int32_t H,
                    float* h0_out, const float* const* h0_in, float* const* hin, int64_t ldh, float* const* dP,
                    int64_t lddp, float* const* gst, float* const* dh0, BwdArgs* out, int* mt, int64_t* tiles_out,
-                   size_t* lds) {
+                   size_t* lds, const BwdFold* fold) {
     const int K = s->num_layers;
     BwdArgs& a = *out;
     memset(&a, 0, sizeof(a));
@@ -86,6 +89,15 @@ int build_bwd_args(const int32_t* rowptr, const int32_t* col, int64_t n, const G
     a.gst[1] = gst[1];
     a.ld = ld;
     a.ldg = ldg;
+    if (fold) {
+        a.rowptr_t = fold->rowptr_t;
+        a.col_t = fold->col_t;
+        a.invdeg = fold->invdeg;
+        a.dh_prev[0] = fold->dh_prev[0];
+        a.dh_prev[1] = fold->dh_prev[1];
+        a.fold_concat = gnn.combine == GNF_COMBINE_CONCAT ? 1 : 0;
+        a.fold_aggcol = a.fold_concat ? H : 0;
+    }
     int bias_tot = 0, mld = 1;
     int64_t wtot = 0;
     for (int j = 0; j < K; ++j) {

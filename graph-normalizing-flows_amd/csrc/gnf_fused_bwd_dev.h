@@ -29,6 +29,22 @@ struct BwdArgs {
     int32_t mean, concat, act;
     int32_t residual;  // attention block with residual: s, t = MLP(h0) + x_cond (gnn.py:547-548)
     float eps, alpha;
+    // Message-passing backward of the PREVIOUS half-step of the walk, folded into this launch's prologue (NULL rowptr_t:
+    // not folded).  That half-step's dL/dh0 rows (both nets) scatter into the gradient of ITS conditioning half, which is
+    // this half-step's updated half: g_upd[u, f] += base * dh[u, f] + sum over edges u -> v of dh[v, aggcol + f] * w(v),
+    // dh = dh_prev[0] + dh_prev[1] ([N, in0] each), w(v) = invdeg[v] (mean aggregator) or 1 - the arithmetic of
+    // k_aggregate_bwd (gnf_train.hip), applied where the coupling stage reads g_upd instead of in a launch of its own.
+    const int32_t* rowptr_t;  // CSR by SENDER
+    const int32_t* col_t;
+    const float* invdeg;
+    const float* dh_prev[2];
+    int32_t fold_aggcol, fold_concat;
+};
+struct BwdFold {
+    const int32_t* rowptr_t;
+    const int32_t* col_t;
+    const float* invdeg;
+    const float* dh_prev[2];
 };
 
 // bid / nwg: this workgroup's index among the nwg backward workgroups of the launch (the launch may hold other work
@@ -45,6 +61,12 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
     int* s_rowptr = tab + kRows * 16;
     int* s_col = s_rowptr + kBwdRowptrPad;
     unsigned long long* masks = reinterpret_cast<unsigned long long*>(s_col + kBwdColCap);  // [net][K-1][MT*4][mld]
+    const int HP = (a.H + 15) & ~15;
+    int* f_rowptr = reinterpret_cast<int*>(masks + (size_t)2 * (a.K > 1 ? a.K - 1 : 0) * (MT * 4) * a.mld);
+    int* f_col = f_rowptr + kBwdRowptrPad;
+    float* f_own = reinterpret_cast<float*>(f_col + kBwdColCap);  // [TM][HP] base term of the folded scatter
+    float* f_acc = f_own + TM * HP;                                // [TM][HP] its neighbour sum
+    const bool fold = a.rowptr_t != nullptr;
 
     int tile;
     {
@@ -115,10 +137,11 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
     prefetch_chunk(cur, WPN, voff, b_pre);
 
     // ---- prologue loads, all issued before any is consumed ----------------------------------------
-    int rp_reg = 0;
+    int rp_reg = 0, rp2_reg = 0;
     if (tid <= TM) {
         const int r = row0 + tid;
         rp_reg = a.rowptr[r < a.n_nodes ? r : a.n_nodes];
+        if (fold) rp2_reg = a.rowptr_t[r < a.n_nodes ? r : a.n_nodes];
     }
     constexpr int kBiasRegs = 8;
     const int bias_all = 2 * a.bias_tot2;
@@ -134,6 +157,7 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
     }
     if (tid < R * 16) tab[tid] = a.tab[tid >> 4][tid & 15];
     if (tid <= TM) s_rowptr[tid] = rp_reg;
+    if (fold && tid <= TM) f_rowptr[tid] = rp2_reg;
 #pragma unroll
     for (int q = 0; q < kBiasRegs; ++q) {
         const int i = tid + q * kBwdThreads;
@@ -156,8 +180,56 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
             buf(1, 0)[rl * LS + c] = live ? a.h0_in[1][(int64_t)r * a.in0 + c] : 0.f;
         }
     } else {
+        if (fold) {  // the transposed CSR slice rides behind the same barrier as the forward one
+            const int fb = f_rowptr[0], fl = f_rowptr[TM] - fb;
+            if (fl <= kBwdColCap)
+                for (int i = tid; i < fl; i += kBwdThreads) f_col[i] = a.col_t[fb + i];
+        }
         const TileAgg ta{a.col, a.x_cond, a.ld, a.n_nodes, row0, H, a.in0, a.tab[0][0] * 16, a.mean, a.concat, a.eps};
         tile_aggregate<TM, kBwdThreads, kBwdColCap>(ta, s_rowptr, s_col, buf(0, 0), buf(1, 0), LS, a.h0_out, tid);
+    }
+    if (fold) {
+        // one (row, feature) per thread, four neighbour rows in flight, adds in edge order (k_aggregate_bwd's order)
+        const int fb = f_rowptr[0];
+        const bool staged = f_rowptr[TM] - fb <= kBwdColCap;
+        const float* __restrict__ d0 = a.dh_prev[0];
+        const float* __restrict__ d1 = a.dh_prev[1];
+        for (int idx = tid; idx < TM * H; idx += kBwdThreads) {
+            const int rl = idx / H, f = idx - rl * H;
+            const int u = row0 + rl;
+            float own = 0.f, acc = 0.f;
+            if (u < a.n_nodes) {
+                const int beg = f_rowptr[rl], end = f_rowptr[rl + 1];
+                auto colat = [&](int e) { return staged ? f_col[e - fb] : a.col_t[e]; };
+                auto ld2 = [&](int v) {
+                    const int64_t o = (int64_t)v * a.in0 + a.fold_aggcol + f;
+                    return d0[o] + d1[o];
+                };
+                int e = beg;
+                for (; e + 4 <= end; e += 4) {
+                    int vi[4];
+                    float w[4], vv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) vi[q] = colat(e + q);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        w[q] = a.invdeg ? a.invdeg[vi[q]] : 1.f;
+                        vv[q] = ld2(vi[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc += vv[q] * w[q];
+                }
+                for (; e < end; ++e) {
+                    const int v = colat(e);
+                    acc += ld2(v) * (a.invdeg ? a.invdeg[v] : 1.f);
+                }
+                const int64_t oo = (int64_t)u * a.in0 + f;
+                const float o2 = d0[oo] + d1[oo];
+                own = a.fold_concat ? o2 : o2 * a.eps;
+            }
+            f_own[rl * HP + f] = own;
+            f_acc[rl * HP + f] = acc;
+        }
     }
     __syncthreads();
 
@@ -256,7 +328,9 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
                 }
                 float* py = a.y_upd + (int64_t)r * a.ld + f;
                 float* pg = a.g_upd + (int64_t)r * a.ldg + f;
-                const float yv = *py, gv = *pg;
+                const float yv = *py;
+                float gv = *pg;
+                if (fold) gv = gv + f_own[rl * HP + f] + f_acc[rl * HP + f];
                 const float d = yv - tv;
                 *py = d * expf(-sv);
                 *pg = gv * expf(sv);
@@ -281,6 +355,7 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
 int build_bwd_args(const int32_t* rowptr, const int32_t* col, int64_t n, const GnfGnnSpec& gnn, const GnfMlp* s,
                    const GnfMlp* t, const float* x_cond, float* y_upd, int64_t ld, float* g_upd, int64_t ldg, int32_t H,
                    float* h0_out, const float* const* h0_in, float* const* hin, int64_t ldh, float* const* dP,
-                   int64_t lddp, float* const* gst, float* const* dh0, BwdArgs* out, int* mt, int64_t* tiles, size_t* lds);
+                   int64_t lddp, float* const* gst, float* const* dh0, BwdArgs* out, int* mt, int64_t* tiles, size_t* lds,
+                   const BwdFold* fold = nullptr);
 
 }  // namespace gnf

@@ -32,6 +32,7 @@ enum OptionId {
     OPT_DW_LATE_FORK,        // fork the dW stream behind the dL/dx scatter
     OPT_BWD_GENERIC,         // backward pass through the generic GEMM path even where the fused kernel fits
     OPT_DW_UNMERGED,         // small batches: dW GEMMs on the auxiliary stream (round-1 scheme) instead of inside the backward launch
+    OPT_BWD_NO_FOLD,         // ... and the message-passing backward in a launch of its own instead of the next half-step's prologue
     OPT_COUNT
 };
 

@@ -2497,6 +2497,8 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     bool used[2] = {false, false};  // weight sharing: the T uses of a net accumulate
     DwLaunch pend[2];
     bool pend_ok[2] = {false, false};
+    bool have_fold = false;  // the previous half-step left its dL/dh0 rows for this one's prologue to scatter
+    const float* fold_dh[2] = {nullptr, nullptr};
     for (int i = T - 1; i >= 0; --i)
         for (int half = 1; half >= 0; --half) {
             const GnfMlp* nets[2] = {pick_net(flow, flow->s_nets, half, i), pick_net(flow, flow->t_nets, half, i)};
@@ -2545,8 +2547,19 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 int mt;
                 int64_t tiles;
                 size_t lds;
+                // the previous half-step's message-passing backward rides in this launch's prologue: it scatters into
+                // the gradient of the half this half-step updates (with a batch-norm bijector in between, its backward
+                // needs that gradient complete first: the scatter keeps its own launch)
+                BwdFold bf;
+                const bool folded = have_fold;
+                if (folded) {
+                    bf.rowptr_t = csr_t->rowptr, bf.col_t = csr_t->col;
+                    bf.invdeg = flow->gnn.agg == GNF_AGG_MEAN ? wsf + p.invdeg : nullptr;
+                    bf.dh_prev[0] = fold_dh[0], bf.dh_prev[1] = fold_dh[1];
+                }
                 rc = build_bwd_args(csr->rowptr, csr->col, n, flow->gnn, nets[0], nets[1], x_cond, z + uo, ld, g + uo, D, H,
-                                    o.h0[0], nullptr, o.hin, p.lmax, o.dPs, p.lmax, o.gst, o.dh0, &ba, &mt, &tiles, &lds);
+                                    o.h0[0], nullptr, o.hin, p.lmax, o.dPs, p.lmax, o.gst, o.dh0, &ba, &mt, &tiles, &lds,
+                                    folded ? &bf : nullptr);
                 if (rc) return rc;
                 const int prev = (step + 1) & 1, cur = step & 1;   // pend[prev]: half-step k-1, pend[cur]: k-2
                 rc = launch_half_bwd_dw(&ba, tiles, lds, step >= 1 && pend_ok[prev] ? &pend[prev] : nullptr,
@@ -2566,8 +2579,13 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                     rc = run_weight_reduce(pend[cur], st);
                     if (rc) return rc;
                 }
-                rc = launch_aggregate_bwd(p, csr_t, flow->gnn, wsf + p.invdeg, o.dh0[0], o.dh0[1], g + co, D, st);
-                if (rc) return rc;
+                have_fold = !flow->bns && !last && !opt(OPT_BWD_NO_FOLD);
+                if (have_fold) {
+                    fold_dh[0] = o.dh0[0], fold_dh[1] = o.dh0[1];
+                } else {
+                    rc = launch_aggregate_bwd(p, csr_t, flow->gnn, wsf + p.invdeg, o.dh0[0], o.dh0[1], g + co, D, st);
+                    if (rc) return rc;
+                }
                 ++step;
                 if (flow->bns) {
                     rc = launch_bn_backward(flow, &flow->bns[half * T + i], &grad->bns[half * T + i], z + co, ld, g + co, D, n, H,
