@@ -240,6 +240,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                    help="device pre-warm in front of the W warmup steps: the same step in a loop for this long (a fresh "
+                         "process runs its first ~100 iterations up to 8 %% slower - clocks, first touches); 0 = off")
     ap.add_argument("--layered", action="store_true", help="run the generic layered kernels instead of the fused one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
@@ -350,6 +353,17 @@ def main():
             work.wait()
             host[j].copy_(t, non_blocking=True)
 
+    prewarm_steps = 0
+    if args.prewarm_ms > 0:
+        t_pre = time.perf_counter()
+        # (sharded runs: a fixed count, the same on every rank - the steps hold collectives)
+        fixed = int(args.prewarm_ms / 1.0) if world > 1 else 0
+        while (prewarm_steps < fixed) if world > 1 else (time.perf_counter() - t_pre < 1e-3 * args.prewarm_ms):
+            for _ in range(8):
+                step(0)
+            prewarm_steps += 8
+            drain(len(pending))
+            torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     drain(len(pending))
@@ -629,7 +643,7 @@ def main():
         "metric": ("node-updates/sec (fwd+logdet) on community_medium batch" if args.workload == "config2" else
                    f"node-updates/sec ({'inverse' if inverse else 'fwd+logdet'}) on {args.workload}"), "value": round(value, 1),
         "unit": "node-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "host_enqueue_ms_per_step": round(1e3 * t_enqueued / args.steps, 4),
+        "ms_per_step": round(ms_per_step, 4), "prewarm_steps": prewarm_steps, "host_enqueue_ms_per_step": round(1e3 * t_enqueued / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {WORKLOAD['desc']} batch={GRAPHS_PER_GPU}/GPU ({GRAPHS_PER_GPU * world} graphs total), "

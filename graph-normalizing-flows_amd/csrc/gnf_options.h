@@ -28,7 +28,8 @@ enum OptionId {
     OPT_DW_WIDE_LDS,         // ... and this LDS request per workgroup (bytes)
     OPT_DW_NO_STREAMK,       // ... whole chunks instead of stream-K runs
     OPT_DW_NO_BUF,           // ... bounds-checked fetch
-    OPT_DW_DEBUG,            // print the dW launch plan to stderr (first two launches)
+    OPT_DW_DEBUG,            // bit 1: print the dW launch plan to stderr (first two launches); bits 2 / 4 / 8: timing ablations
+                             // of the merged backward + dW launch (gnf_train.hip, launch_half_bwd_dw)
     OPT_DW_LATE_FORK,        // fork the dW stream behind the dL/dx scatter
     OPT_BWD_GENERIC,         // backward pass through the generic GEMM path even where the fused kernel fits
     OPT_DW_UNMERGED,         // small batches: dW GEMMs on the auxiliary stream (round-1 scheme) instead of inside the backward launch

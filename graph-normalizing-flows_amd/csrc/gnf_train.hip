@@ -1141,14 +1141,21 @@ __global__ __launch_bounds__(256) void k_reduce_grouped(const GroupedReduce g) {
 }
 
 // g[N, D] <- z[N, D]: dL/dz of L = 1/2 sum z^2 + const - logdet
+// (+ when rowptr != NULL: invdeg[i] = 1 / max(indeg(i), 1) for the mean aggregator's backward, in the same launch)
 __global__ __launch_bounds__(256) void k_copy_rows(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst,
-                                                   int64_t ldd, int64_t n, int W) {
+                                                   int64_t ldd, int64_t n, int W, const int32_t* __restrict__ rowptr,
+                                                   float* __restrict__ invdeg) {
     const int64_t total = n * W;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / W;
         const int f = (int)(i - r * W);
         dst[r * ldd + f] = src[r * lds_ + f];
     }
+    if (rowptr)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+            const int dg = rowptr[i + 1] - rowptr[i];
+            invdeg[i] = 1.f / (float)(dg > 1 ? dg : 1);
+        }
 }
 
 // coupling backward (see the file header): y, g in place; gs, gt dense [N, H]
@@ -1181,14 +1188,6 @@ __global__ __launch_bounds__(256) void k_coupling_bwd(const float* __restrict__ 
 // rowptr_t / col_t: CSR by SENDER (row u lists the receivers v of u's out-edges, in edge order).
 // Same shape as kernel A (gnf_layered.hip): a group of G lanes owns a row, VEC floats per lane, four
 // neighbour rows in flight; the adds stay in edge order.
-__global__ __launch_bounds__(256) void k_invdeg(const int32_t* __restrict__ rowptr, int64_t n, float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) {
-        const int dg = rowptr[i + 1] - rowptr[i];
-        out[i] = 1.f / (float)(dg > 1 ? dg : 1);
-    }
-}
-
 template <int VEC>
 __global__ __launch_bounds__(256) void k_aggregate_bwd(const int32_t* __restrict__ rowptr_t,
                                                        const int32_t* __restrict__ col_t,
@@ -1752,7 +1751,7 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
             }
         }
         if (grid == 0 || est_us > pol.budget_us) wide = false;
-        if (opt(OPT_DW_DEBUG)) {
+        if (opt(OPT_DW_DEBUG) & 1) {
             static std::atomic<int> shown_ctr{0};
             const int shown = shown_ctr.fetch_add(1) + 1;
             if (shown <= 2)
@@ -1937,7 +1936,9 @@ static int launch_half_bwd_dw(const BwdArgs* bwd, int64_t bwd_tiles, size_t bwd_
     memset(&g, 0, sizeof(g));
     memset(&r, 0, sizeof(r));
     int n_dw = 0, r_nj = 0;
-    const int64_t dbg = opt(OPT_DW_DEBUG);  // TEMP ablations: 2 = reduce in its own launch, 4 = no dW GEMMs, 8 = no backward tiles
+    // developer option dw_debug, bits beyond 1 (plan print): timing ablations of this launch - 2 = the reduce in a launch
+    // of its own, 4 = no dW GEMMs, 8 = no backward tiles (4 and 8 give wrong gradients; DESIGN.md section 10 has the numbers)
+    const int64_t dbg = opt(OPT_DW_DEBUG);
     if (dw && !(dbg & 4)) narrow_wide(dw->wg, &g), n_dw = dw->units;
     if (red && !red->direct && !(dbg & 2)) narrow_reduce(red->gr, red->nj, &r), r_nj = red->nj;
     if (red && (dbg & 2)) { const int rc_ = run_weight_reduce(*red, st); if (rc_) return rc_; }
@@ -1949,6 +1950,7 @@ static int launch_half_bwd_dw(const BwdArgs* bwd, int64_t bwd_tiles, size_t bwd_
     GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_bwd_dw<1>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
     size_t lds = bwd_lds > kWideLdsMin ? bwd_lds : kWideLdsMin;
+    if (lds <= 80 * 1024) lds = 80 * 1024 + 256;  // one workgroup per CU whatever the layer widths: a backward tile never shares its CU
     hipLaunchKernelGGL(k_half_bwd_dw<1>, dim3((unsigned)grid), dim3(kBwdThreads), lds, st, bwd ? *bwd : kNoBwd, g, r, n_bwd, n_dw, r_nj);
     GNF_LAUNCH_CHECK("k_half_bwd_dw");
     return GNF_OK;
@@ -2449,13 +2451,10 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     {
         int64_t blocks = (n * D + 255) / 256;
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)blocks), dim3(256), 0, st, z, ld, g, (int64_t)D, n, D);
+        const bool mean = flow->gnn.agg == GNF_AGG_MEAN;
+        hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)blocks), dim3(256), 0, st, z, ld, g, (int64_t)D, n, D,
+                           mean ? csr->rowptr : nullptr, mean ? wsf + p.invdeg : nullptr);
         GNF_LAUNCH_CHECK("k_copy_rows");
-        if (flow->gnn.agg == GNF_AGG_MEAN) {
-            hipLaunchKernelGGL(k_invdeg, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, csr->rowptr, n,
-                               wsf + p.invdeg);
-            GNF_LAUNCH_CHECK("k_invdeg");
-        }
     }
     // fork / join events of the weight-gradient stream: flag-only events owned by THIS call (created on the current
     // device, destroyed when the call returns - hipEventDestroy defers the release until the recorded work has
@@ -2475,7 +2474,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
         for (int q = 0; q < n_nets; ++q) merged = merged && fused_bwd_supported(&flow->s_nets[q], &flow->t_nets[q]);
         if (merged) {
             fused_bwd_launch_shape(&flow->s_nets[0], n, &m_tiles, &m_lds);
-            merged = m_tiles == (n + 15) / 16 && m_tiles <= kMergedMaxTiles && m_lds > 80 * 1024;
+            merged = m_tiles == (n + 15) / 16 && m_tiles <= kMergedMaxTiles;
         }
     }
     if (merged) aux = nullptr;
@@ -2535,7 +2534,8 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 }
                 int64_t blocks = (n * H + 255) / 256;
                 if (blocks > 4096) blocks = 4096;
-                hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)blocks), dim3(256), 0, st, x_cond, ld, o.xc, (int64_t)H, n, H);
+                hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)blocks), dim3(256), 0, st, x_cond, ld, o.xc, (int64_t)H, n, H,
+                                   (const int32_t*)nullptr, (float*)nullptr);
                 GNF_LAUNCH_CHECK("k_copy_rows");
             } else if (!fused) {
                 rc = launch_aggregate(csr->rowptr, csr->col, n, x_cond, ld, H, flow->gnn.agg == GNF_AGG_MEAN,
@@ -2569,7 +2569,9 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 WGJob jobs[kMaxGroup];
                 const int nj = weight_grad_jobs(p, o, nets, grads, jobs);
                 const bool last = step == 2 * T - 1;
-                const DwPolicy pol{last ? 256 : 256 - (int)tiles, lds, 1e30};
+                int room = last ? 256 : 256 - (int)tiles;   // CUs the backward tiles of the NEXT launch leave
+                if (const int64_t force = opt(OPT_DW_WIDE_UNITS)) room = force < room ? (int)force : room;  // developer A/B option
+                const DwPolicy pol{room, lds, 1e30};
                 rc = plan_weight_grads(p, pol, jobs, nj, acc, wsf, cur, &pend[cur]);
                 if (rc) return rc;
                 pend_ok[cur] = pend[cur].wide && pend[cur].buf && nj <= kMergedGroup;

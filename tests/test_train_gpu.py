@@ -502,23 +502,32 @@ def test_thin_layers_behind_wide_ones_take_the_split_k_path(grid_small):
 
 
 DW_MODES = [   # (gnf_set_option values, dw_modes_check.py flags)
-    ({}, ""),                                                     # what the library picks by itself
-    ({"dw_grouped": 1}, ""),                                      # the 128 x 64 grouped kernel
-    ({"dw_wide_units": 8}, ""),                                   # few workgroups: cheap units ride behind, strided
-    ({"dw_wide_units": 200}, "ws"),                               # many node chunks per job + accumulating reduce
-    ({"dw_wide_units": 24, "dw_no_buf": 1}, ""),                  # bounds-checked generic tile fetch
-    ({"dw_wide_units": 40}, "ws,serial"),                         # no auxiliary stream
-    ({"dw_wide_units": 24, "dw_no_streamk": 1}, ""),              # whole chunks instead of stream-K runs
-    ({"dw_wide_units": 13}, "ws"),                                # stream-K with an odd workgroup count
+    ({}, ""),                                                     # what the library picks by itself (this batch: the merged launch)
+    ({}, "ws"),                                                   # ... with weight sharing: the in-launch reduce accumulates
+    ({"bwd_no_fold": 1}, ""),                                     # merged launch, message-passing scatter in its own launch
+    ({"dw_wide_units": 8}, ""),                                   # merged launch, few dW workgroups: cheap units ride behind, strided
+    ({"dw_wide_units": 13}, "ws"),                                # ... stream-K with an odd workgroup count
+    ({"dw_no_streamk": 1}, ""),                                   # ... whole chunks instead of stream-K runs
+    ({"dw_no_buf": 1}, ""),                                       # ... a plan the merged launch cannot carry runs on its own
+    ({"dw_unmerged": 1}, ""),                                     # round-1 scheme: dW GEMMs on the auxiliary stream
+    ({"dw_unmerged": 1, "dw_grouped": 1}, ""),                    # the 128 x 64 grouped kernel
+    ({"dw_unmerged": 1, "dw_wide_units": 8}, ""),
+    ({"dw_unmerged": 1, "dw_wide_units": 200}, "ws"),             # many node chunks per job + accumulating reduce
+    ({"dw_unmerged": 1, "dw_wide_units": 24, "dw_no_buf": 1}, ""),  # bounds-checked generic tile fetch
+    ({"dw_unmerged": 1, "dw_wide_units": 40}, "ws,serial"),       # no auxiliary stream
+    ({"dw_unmerged": 1, "dw_wide_units": 24, "dw_no_streamk": 1}, ""),
+    ({"dw_unmerged": 1, "dw_wide_units": 13}, "ws"),
     ({"bwd_generic": 1}, ""),                                     # generic (GEMM) backward: buffer-descriptor tile fetch
     ({"bwd_generic": 1, "gemm_lds_direct": 1}, ""),               # ... through the LDS-direct (fragment-order) tile
     ({"bwd_generic": 1, "gemm_no_buf": 1}, "ws"),                 # ... through the bounds-checked fetch
 ]
 
 
-@pytest.mark.parametrize("env,arg", DW_MODES, ids=["auto", "grouped", "wide8", "wide200_ws", "wide24_nobuf", "wide40_serial_ws", "wide24_chunks",
-                              "wide13_streamk_ws", "generic_bwd",
-                              "generic_bwd_lds_direct", "generic_bwd_nobuf_ws"])
+def _mode_id(m):
+    return ("-".join(f"{k}{v}" for k, v in m[0].items()) or "auto") + ("_" + m[1].replace(",", "_") if m[1] else "")
+
+
+@pytest.mark.parametrize("env,arg", DW_MODES, ids=[_mode_id(m) for m in DW_MODES])
 def test_weight_gradient_kernel_launch_shapes(env, arg):
     """The dW GEMM has several launch shapes chosen per batch; each forced shape (developer
     options of the library, gnf_set_option, handed to the child through the binding's GNF_OPTIONS variable) runs
