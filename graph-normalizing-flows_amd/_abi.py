@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 GNF_MAX_LAYERS = 8
-GNF_ABI_VERSION = 7
+GNF_ABI_VERSION = 8
 
 GNF_AGG_SUM, GNF_AGG_MEAN = 0, 1
 GNF_COMBINE_EPS, GNF_COMBINE_CONCAT = 0, 1
@@ -62,7 +62,8 @@ class GnfFlow(C.Structure):
                 ("s_nets", C.POINTER(GnfMlp)), ("t_nets", C.POINTER(GnfMlp)), ("gnn", GnfGnnSpec),
                 ("bns", C.POINTER(GnfBatchNorm)),
                 ("bn_allreduce", BN_ALLREDUCE_FN), ("bn_allreduce_ctx", C.c_void_p), ("bn_sync_buf", C.c_void_p),
-                ("attn_stash", C.c_void_p), ("attn_stash_bytes", C.c_size_t)]
+                ("attn_stash", C.c_void_p), ("attn_stash_bytes", C.c_size_t),
+                ("mlp_stash", C.c_void_p), ("mlp_stash_bytes", C.c_size_t)]
 
 
 _SIGNATURES = {
@@ -70,6 +71,7 @@ _SIGNATURES = {
     "gnf_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
     "gnf_get_option": (C.c_int64, [C.c_char_p]),
     "gnf_attn_stash_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.POINTER(GnfFlow)]),
+    "gnf_mlp_stash_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.POINTER(GnfFlow)]),
     "gnf_last_error": (C.c_char_p, []),
     "gnf_packed_floats": (C.c_int64, [C.POINTER(GnfMlp)]),
     "gnf_pack_mlp": (C.c_int, [C.POINTER(GnfMlp), C.c_void_p, C.c_void_p]),

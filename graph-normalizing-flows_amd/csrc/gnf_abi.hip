@@ -17,7 +17,7 @@ static const char* const kOptionNames[OPT_COUNT] = {
     "force_shape",     "fused_variant",  "flow_no_oop",    "attn_edge_tiled",  "attn_rows",    "attn_lane_feature", "gemm_no_buf",
     "gemm_lds_direct", "gemm_no_splitk", "layered_own_gemm", "dw_grouped",   "dw_wide_units",     "dw_wide_lds",
     "dw_no_streamk",   "dw_no_buf",      "dw_debug",         "dw_late_fork", "bwd_generic",
-    "dw_unmerged",     "bwd_no_fold"};
+    "dw_unmerged",     "bwd_no_fold",    "no_mlp_stash"};
 
 static int option_index(const char* name) {
     if (!name) return -1;
@@ -223,6 +223,12 @@ int64_t gnf_get_option(const char* name) {
         return GNF_EINVAL;
     }
     return g_options[i].load(std::memory_order_relaxed);
+}
+
+size_t gnf_mlp_stash_bytes(int64_t n_nodes, int32_t D, const GnfFlow* flow) {
+    if (n_nodes <= 0 || D < 2 || (D & 1) || !flow || !flow->s_nets || !flow->t_nets || flow->num_timesteps <= 0) return 0;
+    if (!mlp_stash_supported(flow, n_nodes, D / 2)) return 0;
+    return (size_t)2 * flow->num_timesteps * mlp_stash_layout(&flow->s_nets[0], n_nodes, D / 2).slot * sizeof(float);
 }
 
 size_t gnf_attn_stash_bytes(int64_t n_nodes, int32_t D, const GnfFlow* flow) {
@@ -469,6 +475,18 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
         }
         stash = flow->attn_stash;
     }
+    // ... and, for message-passing nets on small batches, every row its MLP kernels would recompute (ABI v8)
+    float* mstash = nullptr;
+    size_t mstash_slot = 0;
+    if (direction == GNF_FORWARD && flow->mlp_stash && n > 0 && mlp_stash_supported(flow, n, H)) {
+        mstash_slot = mlp_stash_layout(&flow->s_nets[0], n, H).slot;
+        if (flow->mlp_stash_bytes < (size_t)2 * T * mstash_slot * sizeof(float)) {
+            set_error("gnf_grevnet_f32: mlp_stash %zu < %zu bytes", flow->mlp_stash_bytes,
+                      (size_t)2 * T * mstash_slot * sizeof(float));
+            return GNF_EWORKSPACE;
+        }
+        mstash = flow->mlp_stash;
+    }
 
     if (n > 0) {
         if (direction == GNF_FORWARD) {
@@ -488,6 +506,7 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
                                 stash ? stash + (size_t)(2 * i + half) * stash_slot : nullptr, csr->n_edges};
                     mark_first(hs, half);
                     mark_attn(hs, half, i);
+                    if (mstash) hs.mlp_stash = mstash + (size_t)(2 * i + half) * mstash_slot;
                     rc = run_half(hs, scratch, st);
                     if (rc) return rc;
                     used += np_;

@@ -57,7 +57,20 @@ struct HalfStep {
     float* cond_copy = nullptr;
     // attention nets: fragment-order copies of this half-step's two attention blocks (launch_attn_pack), or NULL
     const float* attn_packed[2] = {nullptr, nullptr};
+    // training forward: this half-step's slot of GnfFlow.mlp_stash (mlp_stash_layout), or NULL
+    float* mlp_stash = nullptr;
 };
+
+// MLP-row stash (GnfFlow.mlp_stash, ABI v8): the rows of a half-step the backward walk would otherwise recompute
+struct MlpStashLayout {
+    size_t h0, act, act_each, st, st_each, mask, slot;  // float offsets inside a slot / floats per slot
+    int ld_act;                                   // row pitch of the hidden activations (widest hidden layer)
+    int mld, mask_words;                          // act' ballot words: 16-column tiles per mask row, 64-bit words per 16-node tile
+};
+MlpStashLayout mlp_stash_layout(const GnfMlp* net, int64_t n, int32_t H);
+bool fused_stash_shape(const GnfMlp* s, const GnfMlp* t, int64_t n);   // forward side (gnf_fused.hip)
+// both sides: message-passing nets on the fused forward kernel's (1,2) shape AND the merged backward launch
+bool mlp_stash_supported(const GnfFlow* flow, int64_t n, int32_t H);   // gnf_train.hip
 bool fused_supports_oop(const HalfStep& hs);
 // floats of one half-step's slot in GnfFlow.attn_stash ( = attn_scratch_floats: [2][n][P] q|k|v, then [2][n][in0] h0)
 size_t attn_stash_slot_floats(const GnfFlow* flow, int64_t n_nodes);

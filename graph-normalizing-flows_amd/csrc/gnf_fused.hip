@@ -26,6 +26,7 @@
 //
 // Zero padding: every layer width is padded to a multiple of 16 in the packed weights (pad rows,
 // pad columns and pad biases are 0), so padded activations are act(0) = 0 and never contribute.
+#include <cstring>
 #include "gnf_common.h"
 
 namespace gnf {
@@ -137,6 +138,15 @@ struct FusedArgs {
     int32_t residual;  // attention block with residual: s, t += x_cond (gnn.py:547-548)
     int32_t variant;   // developer A/B bits (gnf_set_option("fused_variant", ...)); 0 = shipped behaviour
     float eps, alpha;
+    // training forward (STASH instance only): every row the backward pass would otherwise recompute goes to the
+    // half-step's slot of GnfFlow.mlp_stash - the layer-0 input, each hidden activation of both nets, s and t
+    float* stash_h0;                          // [N, in0]
+    float* stash_act[2][GNF_MAX_LAYERS];      // [net][j], j = 1 .. K-1: input of layer j, [N, stash_ld]
+    float* stash_st[2];                       // s, t [N, H]
+    int32_t stash_w[GNF_MAX_LAYERS];          // true output width of layer j
+    int32_t stash_ld;
+    unsigned long long* stash_mask;           // [tile][net][K-1][4][mld] ballot of "activation > 0" (act' for the way back)
+    int32_t stash_mld;
 };
 
 #ifdef GNF_TRACE  // developer build only: per-wave cycle stamps of workgroup 0
@@ -165,7 +175,7 @@ __device__ int g_trace_layer = 1;
 #include "gnf_fused_dev.h"
 namespace gnf {
 
-template <int MT, int NETS>
+template <int MT, int NETS, bool STASH = false>
 __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TM = 16 * MT;
@@ -277,13 +287,14 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
     GNF_STAMP(0);
     // ---- weights of the first chunk start streaming before anything else -----------------------
     f32x4 b_pre[kPF][4];
-    prefetch_chunk(cur, WPN, voff, b_pre, MT == 1 && !(a.variant & 1));
+    prefetch_chunk(cur, WPN, voff, b_pre, !STASH && MT == 1 && !(a.variant & 1));
     GNF_PSTAMP(0);
     // ---- every independent global read of the prologue is ISSUED before any is consumed: rowptr of
     // the tile, the biases (<= 8 floats per thread in registers), the layer table - one memory round
     // trip instead of three back-to-back ones ----------------------------------------------------------
     int* s_rowptr = tab + GNF_MAX_LAYERS * 8;
     int* s_col = s_rowptr + kRowptrPad;
+    [[maybe_unused]] unsigned long long* fmask = reinterpret_cast<unsigned long long*>(s_col + kColCap);  // STASH only
     int rp_reg = 0;
     if (tid <= TM) {
         const int r = row0 + tid;
@@ -341,7 +352,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
     } else {
         const TileAgg ta{a.col, a.x_cond, a.ld, a.n_nodes, row0, H, a.in0, a.ipg[0] * 16, a.mean, a.concat, a.eps, a.cond_copy};
         tile_aggregate<TM, kFusedThreads, kColCap>(ta, s_rowptr, s_col, buf(0, 0), NETS == 2 ? buf(1, 0) : nullptr, LS,
-                                                   nullptr, tid);
+                                                   STASH ? a.stash_h0 : nullptr, tid);
     }  // message-passing prologue
     GNF_STAMP(1);
     __syncthreads();
@@ -363,25 +374,48 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
             const WChunk nx = nxt.layer < a.K ? nxt : c;  // no next chunk: harmless re-load
             const float* bl = bias_lds + nl * a.bias_tot + c.boff;
             constexpr bool kThin = MT == 1;  // the thin-chunk form keeps 32 fragments in registers: one M-tile only
-            const bool thin_ok = kThin && !(a.variant & 1);
+            // (STASH: the masks come out of mlp_chunk's epilogue, and the thin form's prefetch packing must match the
+            // form that consumes it - the stash instance does without the thin form)
+            const bool thin_ok = !STASH && kThin && !(a.variant & 1);
+            // STASH: a hidden layer's epilogue also leaves the ballot of "activation > 0" (act' for the backward pass) in
+            // LDS, word [net][layer][4 m + r][column tile] - the recompute rows of the backward kernel write the same words
+            constexpr int EPI = STASH ? EPI_EX : EPI_PLAIN;
+            EpiArgs ea{};
+            if constexpr (STASH) {
+                ea.mode = 0;
+                ea.mask = j < a.K - 1 ? fmask + (size_t)(nl * (a.K - 1) + j) * (MT * 4) * a.stash_mld : nullptr;
+                ea.mld = a.stash_mld;
+            }
             if (c.nv >= 4)
-                mlp_chunk<MT, 4>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, EpiArgs{}, thin_ok);
+                mlp_chunk<MT, 4, EPI>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea, thin_ok);
             else if (c.nv == 3)
-                mlp_chunk<MT, 3>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, EpiArgs{}, thin_ok);
+                mlp_chunk<MT, 3, EPI>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea, thin_ok);
             else if (c.nv == 2)
-                mlp_chunk<MT, 2>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, EpiArgs{}, thin_ok);
+                mlp_chunk<MT, 2, EPI>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea, thin_ok);
             else if (kThin && thin_ok && chunk_is_thin(c))
                 mlp_chunk_thin(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre);
             else
-                mlp_chunk<MT, 1>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, EpiArgs{}, thin_ok);
+                mlp_chunk<MT, 1, EPI>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea, thin_ok);
             cur = nxt;
         }
         pp ^= 1;
         GNF_STAMP(3 + 2 * j);
         __syncthreads();
         GNF_STAMP(4 + 2 * j);
+        if constexpr (STASH && NETS == 2) {  // the layer's outputs of both nets, out of the buffer the next layer reads
+            const bool lastl = j == a.K - 1;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                tile_dump<TM, kFusedThreads>(buf(q, pp), LS, lastl ? a.stash_st[q] : a.stash_act[q][j + 1],
+                                             lastl ? (int64_t)H : (int64_t)a.stash_ld, a.stash_w[j], row0, a.n_nodes, tid);
+        }
     }
 
+    if constexpr (STASH) {  // (every layer's barrier has passed: the words are complete)
+        const int total_words = 2 * (a.K - 1) * (MT * 4) * a.stash_mld;
+        unsigned long long* gm = a.stash_mask + (size_t)tile * total_words;
+        for (int i = tid; i < total_words; i += kFusedThreads) gm[i] = fmask[i];
+    }
     if (NETS == 1) {
         // ---- hand the s (or t) tile to the coupling kernel through the global scratch ------------
         const float* o_lds = buf(0, pp);
@@ -505,13 +539,44 @@ static void choose_shape(const HalfStep& hs, int* mt, int* nets) {
     *nets = n;
 }
 
-template <int MT, int NETS>
+template <int MT, int NETS, bool STASH = false>
 static int launch_shape(const FusedArgs& a, unsigned grid, size_t lds, hipStream_t st) {
-    GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_fused<MT, NETS>),
+    GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_fused<MT, NETS, STASH>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit)));
-    hipLaunchKernelGGL((k_half_fused<MT, NETS>), dim3(grid), dim3(kFusedThreads), lds, st, a);
+    hipLaunchKernelGGL((k_half_fused<MT, NETS, STASH>), dim3(grid), dim3(kFusedThreads), lds, st, a);
     GNF_LAUNCH_CHECK("k_half_fused");
     return GNF_OK;
+}
+
+// One half-step's slot of GnfFlow.mlp_stash (float offsets, every region 256-byte aligned)
+MlpStashLayout mlp_stash_layout(const GnfMlp* net, int64_t n, int32_t H) {
+    auto al = [](size_t v) { return (v + 63) / 64 * 64; };
+    MlpStashLayout L;
+    const int K = net->num_layers;
+    int lmax = 1;
+    for (int j = 1; j < K; ++j) lmax = lmax > net->dims[j] ? lmax : net->dims[j];
+    L.ld_act = lmax;
+    size_t off = 0;
+    L.h0 = off, off += al((size_t)n * net->dims[0]);
+    L.act_each = al((size_t)n * lmax);
+    L.act = off, off += 2 * (size_t)(K > 1 ? K - 1 : 0) * L.act_each;
+    L.st_each = al((size_t)n * H);
+    L.st = off, off += 2 * L.st_each;
+    L.mld = 1;
+    for (int j = 1; j < K; ++j) L.mld = L.mld > pad16(net->dims[j]) / 16 ? L.mld : pad16(net->dims[j]) / 16;
+    L.mask_words = 2 * (K > 1 ? K - 1 : 0) * 4 * L.mld;
+    L.mask = off, off += al((size_t)((n + 15) / 16) * L.mask_words * 2);
+    L.slot = off;
+    return L;
+}
+
+// the forward half of mlp_stash_supported: the (1,2) shape is what the launch would pick
+bool fused_stash_shape(const GnfMlp* s, const GnfMlp* t, int64_t n) {
+    if (!s->packed || !t->packed || s->attn || s->num_layers != t->num_layers) return false;
+    for (int j = 0; j <= s->num_layers; ++j)
+        if (s->dims[j] != t->dims[j]) return false;
+    if (opt(OPT_FORCE_SHAPE)) return false;
+    return (n + 15) / 16 <= 256 && fused_lds_bytes(s, 1, 2) <= (size_t)kLdsLimit;
 }
 
 int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
@@ -534,6 +599,13 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
     a.st_out[1] = scratch + hs.n_nodes * hs.H;
     a.h0[0] = a.h0[1] = nullptr;
     a.residual = 0;
+    a.stash_h0 = nullptr;
+    memset(a.stash_act, 0, sizeof(a.stash_act));
+    a.stash_st[0] = a.stash_st[1] = nullptr;
+    memset(a.stash_w, 0, sizeof(a.stash_w));
+    a.stash_ld = 0;
+    a.stash_mask = nullptr;
+    a.stash_mld = 0;
     if (s->attn) {
         float* h0_pair[2];
         const int rc0 = launch_attn_pair(hs, scratch, h0_pair, st);
@@ -574,6 +646,26 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
     a.n_tiles = (int32_t)tiles;
     const size_t lds = fused_lds_bytes(s, MT, NETS);
     int rc;
+    if (hs.mlp_stash && !(MT == 1 && NETS == 2)) {
+        set_error("internal: MLP-row stash on a launch shape other than (1,2) (mlp_stash_supported is false there)");
+        return GNF_EINVAL;
+    }
+    if (hs.mlp_stash) {
+        const MlpStashLayout L = mlp_stash_layout(s, hs.n_nodes, hs.H);
+        a.stash_h0 = hs.mlp_stash + L.h0;
+        for (int q = 0; q < 2; ++q) {
+            for (int j = 1; j < s->num_layers; ++j) a.stash_act[q][j] = hs.mlp_stash + L.act + ((size_t)q * (s->num_layers - 1) + (j - 1)) * L.act_each;
+            a.stash_st[q] = hs.mlp_stash + L.st + (size_t)q * L.st_each;
+        }
+        for (int j = 0; j < s->num_layers; ++j) a.stash_w[j] = s->dims[j + 1];
+        a.stash_ld = L.ld_act;
+        a.stash_mask = reinterpret_cast<unsigned long long*>(hs.mlp_stash + L.mask);
+        a.stash_mld = L.mld;
+        rc = launch_shape<1, 2, true>(a, (unsigned)tiles, lds + (size_t)L.mask_words * sizeof(unsigned long long), st);
+        if (rc) return rc;
+        *hs.n_partials = (int32_t)tiles;
+        return GNF_OK;
+    }
     if (NETS == 2) {
         rc = MT == 2 ? launch_shape<2, 2>(a, (unsigned)tiles, lds, st) : launch_shape<1, 2>(a, (unsigned)tiles, lds, st);
         if (rc) return rc;

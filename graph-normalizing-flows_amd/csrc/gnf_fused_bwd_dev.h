@@ -39,6 +39,10 @@ struct BwdArgs {
     const float* invdeg;
     const float* dh_prev[2];
     int32_t fold_aggcol, fold_concat;
+    // STASHED instance (GnfFlow.mlp_stash, filled by the training forward): s, t and the hidden activations of this
+    // half-step, read instead of recomputed
+    const float* st_in[2];                     // [N, H]
+    const unsigned long long* mask_in;         // [tile][net][K-1][4][mld] act' ballot words (NULL: timing ablation)
 };
 struct BwdFold {
     const int32_t* rowptr_t;
@@ -49,7 +53,10 @@ struct BwdFold {
 
 // bid / nwg: this workgroup's index among the nwg backward workgroups of the launch (the launch may hold other work
 // behind them: gnf_train.hip puts the previous half-step's weight-gradient GEMMs on the CUs a small batch leaves idle)
-template <int MT>  // 16 * MT nodes per workgroup: MT = 2 halves the weight stream per node on batches with more than
+// STASHED: the forward pass left this half-step's rows in GnfFlow.mlp_stash - no aggregation, no recompute layers: the
+// act' masks are rebuilt from the stashed activations, the coupling stage reads the stashed s and t, then the K backward
+// layers run as usual (about half the matrix work of the recomputing form).
+template <int MT, bool STASHED = false>  // 16 * MT nodes per workgroup: MT = 2 halves the weight stream per node on batches with more than
                     // one 16-node tile per CU (measured on the forward kernel: 64 us per 32 nodes vs 37.5 per 16)
 __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, const int nwg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -124,7 +131,7 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
     };
     WChunk cur;
     {   // first chunk straight from the kernel arguments (the LDS table does not exist yet)
-        int r0 = 0;
+        int r0 = STASHED ? a.K : 0;
         while (r0 < R && wl >= a.tab[r0][1]) ++r0;
         const int rr = r0 < R ? r0 : 0;
         const unsigned long long wp = ((unsigned long long)(unsigned)a.tab[rr][9 + 2 * nl] << 32) |
@@ -140,7 +147,7 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
     int rp_reg = 0, rp2_reg = 0;
     if (tid <= TM) {
         const int r = row0 + tid;
-        rp_reg = a.rowptr[r < a.n_nodes ? r : a.n_nodes];
+        if (!STASHED) rp_reg = a.rowptr[r < a.n_nodes ? r : a.n_nodes];
         if (fold) rp2_reg = a.rowptr_t[r < a.n_nodes ? r : a.n_nodes];
     }
     constexpr int kBiasRegs = 8;
@@ -151,7 +158,7 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
         const int i = tid + q * kBwdThreads;
         const int net_ = i >= a.bias_tot2 ? 1 : 0;
         const int k = i - net_ * a.bias_tot2;
-        const bool live = i < bias_all && k < a.bias_tot;
+        const bool live = !STASHED && i < bias_all && k < a.bias_tot;  // (STASHED: only the zero bias of the backward rows is read)
         const float* src = net_ ? a.bias[1] : a.bias[0];
         breg[q] = live ? src[k] : 0.f;  // the tail of each net's block is the zero bias of the backward rows
     }
@@ -166,9 +173,26 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
     for (int i = tid + kBiasRegs * kBwdThreads; i < bias_all; i += kBwdThreads) {
         const int net_ = i >= a.bias_tot2 ? 1 : 0;
         const int k = i - net_ * a.bias_tot2;
-        bias_lds[i] = k < a.bias_tot ? (net_ ? a.bias[1] : a.bias[0])[k] : 0.f;
+        bias_lds[i] = (!STASHED && k < a.bias_tot) ? (net_ ? a.bias[1] : a.bias[0])[k] : 0.f;
     }
     __syncthreads();
+    if constexpr (STASHED) {
+        if (fold) {
+            const int fb = f_rowptr[0], fl = f_rowptr[TM] - fb;
+            if (fl <= kBwdColCap)
+                for (int i = tid; i < fl; i += kBwdThreads) f_col[i] = a.col_t[fb + i];
+        }
+        // act' masks: the training forward kernel left this tile's ballot words (the very words the recompute rows
+        // would write: [net][slot][4 m + r][column tile]) next to the activations - one coalesced 8-byte load per thread.
+        // (Rebuilding them from the stashed activations - 64 scattered row-segment loads per wave - took 33 us per tile.)
+        {
+            const int total_words = 2 * (a.K - 1) * (MT * 4) * a.mld;
+            const unsigned long long* __restrict__ gm = a.mask_in + (size_t)tile * total_words;
+            if (a.mask_in)
+                for (int i = tid; i < total_words; i += kBwdThreads) masks[i] = gm[i];
+        }
+        __syncthreads();  // the transposed CSR slice is in place (the masks are first read after the coupling stage's barrier)
+    } else
     // ---- A: aggregate + combine (same arithmetic and order as the forward kernel) ----------------
     if (a.h0_in[0] != nullptr) {
         const int in0p = a.tab[0][0] * 16;
@@ -284,29 +308,14 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
                 dump = nullptr;
 #endif
                 if (dump == nullptr) continue;
-                const float* src = buf(q, pp);
-                if (((width | (int)dld) & 3) == 0 && (reinterpret_cast<uintptr_t>(dump) & 15) == 0) {
-                    const int w4 = width >> 2;
-                    for (int i = tid; i < TM * w4; i += kBwdThreads) {
-                        const int rl = i / w4, c4 = (i - rl * w4) * 4;
-                        const int r = row0 + rl;
-                        if (r < a.n_nodes)
-                            *reinterpret_cast<f32x4*>(dump + (int64_t)r * dld + c4) =
-                                *reinterpret_cast<const f32x4*>(src + rl * LS + c4);
-                    }
-                } else {
-                    for (int i = tid; i < TM * width; i += kBwdThreads) {
-                        const int rl = i / width, c = i - rl * width;
-                        const int r = row0 + rl;
-                        if (r < a.n_nodes) dump[(int64_t)r * dld + c] = src[rl * LS + c];
-                    }
-                }
+                tile_dump<TM, kBwdThreads>(buf(q, pp), LS, dump, dld, width, row0, a.n_nodes, tid);
             }
         }
     };
 
     // ---- B: recompute -------------------------------------------------------------------------
-    for (int r = 0; r < a.K; ++r) run_row(r);
+    if constexpr (!STASHED)
+        for (int r = 0; r < a.K; ++r) run_row(r);
 
     // ---- C': coupling, undone and differentiated --------------------------------------------------
     {
@@ -320,7 +329,12 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
             const int r = row0 + rl;
             float gs = 0.f, gt = 0.f;
             if (r < a.n_nodes && f < H) {
-                float sv = s_lds[rl * LS + f], tv = t_lds[rl * LS + f];
+                float sv, tv;
+                if constexpr (STASHED) {
+                    sv = a.st_in[0][(int64_t)r * H + f], tv = a.st_in[1][(int64_t)r * H + f];
+                } else {
+                    sv = s_lds[rl * LS + f], tv = t_lds[rl * LS + f];
+                }
                 if (a.residual) {
                     const float xr = a.x_cond[(int64_t)r * a.ld + f];
                     sv += xr;

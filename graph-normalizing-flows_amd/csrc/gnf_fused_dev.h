@@ -285,6 +285,29 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
 
 
 
+// A tile's rows of one LDS activation buffer ([TM][LS], first `width` columns) to global memory [n_nodes, dld]: coalesced
+// 16-byte-per-lane copy where the widths allow (element-wise stores from the accumulator layout, 64-byte segments, made
+// the backward kernel store-bound on large batches).  All NTHR threads take part.
+template <int TM, int NTHR>
+__device__ __forceinline__ void tile_dump(const float* __restrict__ src, int LS, float* __restrict__ dump, int64_t dld,
+                                          int width, int row0, int n_nodes, int tid) {
+    if (((width | (int)dld) & 3) == 0 && (reinterpret_cast<uintptr_t>(dump) & 15) == 0) {
+        const int w4 = width >> 2;
+        for (int i = tid; i < TM * w4; i += NTHR) {
+            const int rl = i / w4, c4 = (i - rl * w4) * 4;
+            const int r = row0 + rl;
+            if (r < n_nodes)
+                *reinterpret_cast<f32x4*>(dump + (int64_t)r * dld + c4) = *reinterpret_cast<const f32x4*>(src + rl * LS + c4);
+        }
+    } else {
+        for (int i = tid; i < TM * width; i += NTHR) {
+            const int rl = i / width, c = i - rl * width;
+            const int r = row0 + rl;
+            if (r < n_nodes) dump[(int64_t)r * dld + c] = src[rl * LS + c];
+        }
+    }
+}
+
 // ---- A: aggregate + combine of one node tile into the layer-0 input (shared by the forward and backward
 // kernels; same arithmetic and order as gnn.py:103-104,117-118,123 | 108-109) ----------------------------
 // The tile's CSR slice is staged in LDS first (the caller has put rowptr[row0 .. row0+TM] into s_rowptr;

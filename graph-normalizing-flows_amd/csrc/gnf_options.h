@@ -34,6 +34,7 @@ enum OptionId {
     OPT_BWD_GENERIC,         // backward pass through the generic GEMM path even where the fused kernel fits
     OPT_DW_UNMERGED,         // small batches: dW GEMMs on the auxiliary stream (round-1 scheme) instead of inside the backward launch
     OPT_BWD_NO_FOLD,         // ... and the message-passing backward in a launch of its own instead of the next half-step's prologue
+    OPT_NO_MLP_STASH,        // ignore GnfFlow.mlp_stash (the backward walk recomputes the MLP rows)
     OPT_COUNT
 };
 

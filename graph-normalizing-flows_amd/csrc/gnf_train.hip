@@ -1888,12 +1888,12 @@ static int launch_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJo
 //   all workgroups behind n_bwd  the fixed-order slab reduce of half-step k-2  (reduce_element; slab sets alternate)
 // so the walk needs no second stream, no events, and the kernel boundary is the only synchronisation.  Every
 // workgroup asks for the backward kernel's LDS footprint (> 80 KB), i.e. one workgroup per CU.
-template <int MT>
+template <int MT, bool STASHED>
 __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_half_bwd_dw(const BwdArgs a, const WideGemmS g, const GroupedReduceS r, const int n_bwd, const int n_dw, const int r_nj) {
     const int bid = (int)blockIdx.x;
     if (bid < n_bwd) {
-        half_bwd_body<MT>(a, bid, n_bwd);
+        half_bwd_body<MT, STASHED>(a, bid, n_bwd);
         return;
     }
     const int v = bid - n_bwd;
@@ -1929,7 +1929,7 @@ static void narrow_reduce(const GroupedReduce& r, int nj, GroupedReduceS* o) {
 // bwd: the half-step to walk (NULL: none - the tail of the pipeline); dw: GEMMs to run beside it (NULL: none);
 // red: a finished GEMM launch whose slabs are due (NULL: none)
 static int launch_half_bwd_dw(const BwdArgs* bwd, int64_t bwd_tiles, size_t bwd_lds, const DwLaunch* dw, const DwLaunch* red,
-                              hipStream_t st) {
+                              bool stashed, hipStream_t st) {
     static const BwdArgs kNoBwd = {};
     WideGemmS g;
     GroupedReduceS r;
@@ -1947,13 +1947,41 @@ static int launch_half_bwd_dw(const BwdArgs* bwd, int64_t bwd_tiles, size_t bwd_
     int grid = n_bwd + n_dw;
     if (r_nj > 0 && grid == n_bwd) grid += 64;  // reduce only: some workgroups to carry it
     if (grid == 0) return GNF_OK;
-    GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_bwd_dw<1>),
+    GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_bwd_dw<1, false>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_bwd_dw<1, true>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
     size_t lds = bwd_lds > kWideLdsMin ? bwd_lds : kWideLdsMin;
     if (lds <= 80 * 1024) lds = 80 * 1024 + 256;  // one workgroup per CU whatever the layer widths: a backward tile never shares its CU
-    hipLaunchKernelGGL(k_half_bwd_dw<1>, dim3((unsigned)grid), dim3(kBwdThreads), lds, st, bwd ? *bwd : kNoBwd, g, r, n_bwd, n_dw, r_nj);
+    if (stashed)
+        hipLaunchKernelGGL((k_half_bwd_dw<1, true>), dim3((unsigned)grid), dim3(kBwdThreads), lds, st, bwd ? *bwd : kNoBwd, g, r, n_bwd, n_dw, r_nj);
+    else
+        hipLaunchKernelGGL((k_half_bwd_dw<1, false>), dim3((unsigned)grid), dim3(kBwdThreads), lds, st, bwd ? *bwd : kNoBwd, g, r, n_bwd, n_dw, r_nj);
     GNF_LAUNCH_CHECK("k_half_bwd_dw");
     return GNF_OK;
+}
+
+// the backward half of the merged-launch / stash conditions (the forward half: fused_stash_shape)
+static bool merged_walk_ok(const GnfFlow* flow, int64_t n, int64_t* tiles_out, size_t* lds_out) {
+    if (opt(OPT_DW_UNMERGED) || opt(OPT_BWD_GENERIC) || opt(OPT_DW_GROUPED) || flow->s_nets[0].attn) return false;
+    const int n_nets = flow->weight_sharing ? 2 : 2 * flow->num_timesteps;
+    for (int q = 0; q < n_nets; ++q)
+        if (!fused_bwd_supported(&flow->s_nets[q], &flow->t_nets[q])) return false;
+    int64_t tiles;
+    size_t lds;
+    fused_bwd_launch_shape(&flow->s_nets[0], n, &tiles, &lds);
+    if (tiles_out) *tiles_out = tiles;
+    if (lds_out) *lds_out = lds;
+    return tiles == (n + 15) / 16 && tiles <= kMergedMaxTiles;
+}
+
+bool mlp_stash_supported(const GnfFlow* flow, int64_t n, int32_t H) {
+    (void)H;
+    if (opt(OPT_NO_MLP_STASH) || n <= 0 || !flow->s_nets || !flow->t_nets) return false;
+    const int n_nets = flow->weight_sharing ? 2 : 2 * flow->num_timesteps;
+    for (int q = 0; q < n_nets; ++q)
+        if (!fused_stash_shape(&flow->s_nets[q], &flow->t_nets[q], n)) return false;
+    return merged_walk_ok(flow, n, nullptr, nullptr);
 }
 
 // job list of one half-step: the K layers of both nets, then the four attention matrices of both nets
@@ -2469,13 +2497,14 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     bool merged = false;
     int64_t m_tiles = 0;
     size_t m_lds = 0;
-    if (!opt(OPT_DW_UNMERGED) && !opt(OPT_BWD_GENERIC) && !opt(OPT_DW_GROUPED) && !flow->s_nets[0].attn && p.slab_sets == 2) {
-        merged = true;
-        for (int q = 0; q < n_nets; ++q) merged = merged && fused_bwd_supported(&flow->s_nets[q], &flow->t_nets[q]);
-        if (merged) {
-            fused_bwd_launch_shape(&flow->s_nets[0], n, &m_tiles, &m_lds);
-            merged = m_tiles == (n + 15) / 16 && m_tiles <= kMergedMaxTiles;
-        }
+    if (p.slab_sets == 2) merged = merged_walk_ok(flow, n, &m_tiles, &m_lds);
+    // the training forward left every half-step's MLP rows in GnfFlow.mlp_stash: no recompute (ABI v8)
+    const bool mstashed = merged && flow->mlp_stash != nullptr && mlp_stash_supported(flow, n, D / 2);
+    const MlpStashLayout msl = mstashed ? mlp_stash_layout(&flow->s_nets[0], n, D / 2) : MlpStashLayout{};
+    if (mstashed && flow->mlp_stash_bytes < (size_t)2 * T * msl.slot * sizeof(float)) {
+        set_error("gnf_grevnet_backward_f32: mlp_stash %zu < %zu bytes", flow->mlp_stash_bytes,
+                  (size_t)2 * T * msl.slot * sizeof(float));
+        return GNF_EWORKSPACE;
     }
     if (merged) aux = nullptr;
     const bool reuse_sets = 2 * T > p.n_sets;
@@ -2550,6 +2579,14 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 // the previous half-step's message-passing backward rides in this launch's prologue: it scatters into
                 // the gradient of the half this half-step updates (with a batch-norm bijector in between, its backward
                 // needs that gradient complete first: the scatter keeps its own launch)
+                if (mstashed) {  // layer inputs of both nets come from the half-step's slot of the stash
+                    float* slot = flow->mlp_stash + (size_t)(2 * i + half) * msl.slot;
+                    for (int q = 0; q < 2; ++q) {
+                        o.h0[q] = slot + msl.h0;
+                        o.hin[q * p.K] = o.h0[q];
+                        for (int j = 1; j < p.K; ++j) o.hin[q * p.K + j] = slot + msl.act + ((size_t)q * (p.K - 1) + (j - 1)) * msl.act_each;
+                    }
+                }
                 BwdFold bf;
                 const bool folded = have_fold;
                 if (folded) {
@@ -2561,9 +2598,15 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                                     o.h0[0], nullptr, o.hin, p.lmax, o.dPs, p.lmax, o.gst, o.dh0, &ba, &mt, &tiles, &lds,
                                     folded ? &bf : nullptr);
                 if (rc) return rc;
+                if (mstashed) {
+                    const float* slot = flow->mlp_stash + (size_t)(2 * i + half) * msl.slot;
+                    for (int q = 0; q < 2; ++q) ba.st_in[q] = slot + msl.st + (size_t)q * msl.st_each;
+                    // dw_debug bit 16: no act' masks (timing ablation, wrong gradients)
+                    ba.mask_in = (opt(OPT_DW_DEBUG) & 16) ? nullptr : reinterpret_cast<const unsigned long long*>(slot + msl.mask);
+                }
                 const int prev = (step + 1) & 1, cur = step & 1;   // pend[prev]: half-step k-1, pend[cur]: k-2
                 rc = launch_half_bwd_dw(&ba, tiles, lds, step >= 1 && pend_ok[prev] ? &pend[prev] : nullptr,
-                                        step >= 2 && pend_ok[cur] ? &pend[cur] : nullptr, st);
+                                        step >= 2 && pend_ok[cur] ? &pend[cur] : nullptr, mstashed, st);
                 if (rc) return rc;
                 // this half-step's dW GEMMs ride in the next launch (the last one's get the whole chip)
                 WGJob jobs[kMaxGroup];
@@ -2672,7 +2715,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     if (merged) {  // drain the pipeline: dW of the last half-step (+ the reduce before it), then its own reduce
         const int last = (step + 1) & 1, before = step & 1;
         rc = launch_half_bwd_dw(nullptr, 0, m_lds, pend_ok[last] ? &pend[last] : nullptr,
-                                step >= 2 && pend_ok[before] ? &pend[before] : nullptr, st);
+                                step >= 2 && pend_ok[before] ? &pend[before] : nullptr, false, st);
         if (rc) return rc;
         if (pend_ok[last]) {
             rc = run_weight_reduce(pend[last], st);

@@ -91,6 +91,8 @@ class GRevNetTrainer:
         self._clip_ws = None     # scratch of the two-pass clip_by_norm
         self._stash = None       # attention front-end stash (uint8 device buffer), see loss_and_grads
         self.stash_attention = True          # False: recompute the attention front-end in the backward walk
+        self.stash_mlp_rows = True           # False: recompute the MLP rows too (the fully reversible walk)
+        self._mlp_stash = None
         self._arena_versions = None   # version counters of every parameter container when the arena was (re)built
         self._arena_epoch = -1
         self._aux = None         # second HIP stream: the weight-gradient GEMMs overlap the backward walk
@@ -287,10 +289,19 @@ class GRevNetTrainer:
             if self._stash is None or self._stash.numel() < stash_bytes or self._stash.device != dev:
                 self._stash = torch.empty(stash_bytes, dtype=torch.uint8, device=dev)
             fwd_flow.attn_stash, fwd_flow.attn_stash_bytes = self._stash.data_ptr(), stash_bytes
+        # message-passing nets on small batches: the same trade for the MLP rows (layer-0 inputs, hidden activations,
+        # s and t of every half-step - what TensorFlow keeps for tf.gradients anyway): the backward kernels skip their
+        # recompute half.  gnf_mlp_stash_bytes is 0 where the library would not use a stash.
+        mlp_bytes = lib.gnf_mlp_stash_bytes(n, d, C.byref(fwd_flow)) if self.stash_mlp_rows else 0
+        if mlp_bytes:
+            if self._mlp_stash is None or self._mlp_stash.numel() < mlp_bytes or self._mlp_stash.device != dev:
+                self._mlp_stash = torch.empty(mlp_bytes, dtype=torch.uint8, device=dev)
+            fwd_flow.mlp_stash, fwd_flow.mlp_stash_bytes = self._mlp_stash.data_ptr(), mlp_bytes
         try:
             return self._loss_and_grads(graph, n, d, dev)
-        finally:   # plain forward calls of the same net must not write into (or rely on) the stash
+        finally:   # plain forward calls of the same net must not write into (or rely on) the stashes
             fwd_flow.attn_stash, fwd_flow.attn_stash_bytes = None, 0
+            fwd_flow.mlp_stash, fwd_flow.mlp_stash_bytes = None, 0
 
     def _loss_and_grads(self, graph, n, d, dev):
         lib = _abi.lib()

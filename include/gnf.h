@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GNF_ABI_VERSION 7
+#define GNF_ABI_VERSION 8
 #define GNF_MAX_LAYERS 8 /* Linear layers per MLP (gnn.py:165-166 builds num_layers of them) */
 
 typedef void* gnf_stream_t; /* hipStream_t */
@@ -168,6 +168,15 @@ typedef struct GnfFlow {
      * forward produced - reads them instead of recomputing.  gnf_attn_stash_bytes() sizes it (2T slots). */
     float* attn_stash;
     size_t attn_stash_bytes;
+    /* ABI v8: optional stash of the MLP rows (message-passing nets on small batches; NULL = none).  Same trade for the
+     * MLPs: gnf_grevnet_f32 / gnf_grevnet_from_f32(GNF_FORWARD) then leaves every half-step's layer-0 input, hidden
+     * activations and s, t of both nets in mlp_stash (what TensorFlow keeps for tf.gradients anyway), and
+     * gnf_grevnet_backward_f32 - called next with the SAME flow, graph and the z that forward produced - skips the
+     * recompute half of its fused kernel and feeds the weight-gradient GEMMs from the stash.  gnf_mlp_stash_bytes()
+     * sizes it and returns 0 where the library would not use one (attention nets, batches of more than 192 16-node
+     * tiles, layers too wide for the fused kernels): pass NULL then. */
+    float* mlp_stash;
+    size_t mlp_stash_bytes;
 } GnfFlow;
 
 int gnf_abi_version(void);
@@ -181,6 +190,8 @@ int gnf_set_option(const char* name, int64_t value);
 int64_t gnf_get_option(const char* name);
 /* Bytes of GnfFlow.attn_stash for n_nodes nodes of width D (0 when the flow's nets have no attention front-end). */
 size_t gnf_attn_stash_bytes(int64_t n_nodes, int32_t D, const GnfFlow* flow);
+/* ABI v8: bytes of GnfFlow.mlp_stash for n_nodes nodes of width D (2T slots), or 0 where it would not be used. */
+size_t gnf_mlp_stash_bytes(int64_t n_nodes, int32_t D, const GnfFlow* flow);
 const char* gnf_last_error(void); /* thread-local, valid until the next failing call on this thread */
 
 /* Number of floats gnf_pack_mlp writes for this MLP (host computation, no device access). */
