@@ -1573,6 +1573,7 @@ struct DwPolicy {
     int max_units;
     size_t lds;
     double budget_us;
+    bool whole_chunks = false;  // no stream-K runs
 };
 
 // The fused backward kernel of the NEXT half-step runs beside this half-step's dW GEMMs (one 16-node tile per
@@ -1721,7 +1722,7 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
         // ---- stream-K for the costliest jobs: equal runs of k-steps across tile boundaries instead of whole chunks ----
         // (24 tiles on 64 workgroups is 2.67 workgroups per tile: cut in whole chunks that is 2 per tile = 48 busy
         // workgroups with 43 steps each; as one axis of 24 x 85 steps it is 64 workgroups with 32 steps each)
-        const bool no_sk = opt(OPT_DW_NO_STREAMK) != 0;  // developer A/B option
+        const bool no_sk = opt(OPT_DW_NO_STREAMK) != 0 || pol.whole_chunks;  // (developer A/B option)
         const int sk_steps = (int)((p.n + WGK - 1) / WGK);
         int sk_q = 0, sk_grid = 0, sk_cmax = 0;
         if (!no_sk && c_heavy > 0 && heavy_tiles > 0 && heavy_tiles <= pol.max_units && sk_steps >= 8) {
@@ -1894,11 +1895,17 @@ void k_half_bwd_dw(const BwdArgs a, const WideGemmS g, const GroupedReduceS r, c
     const int bid = (int)blockIdx.x;
     if (bid < n_bwd) {
         half_bwd_body<MT, STASHED>(a, bid, n_bwd);
+        // the tiles finish before the dW workgroups do (with the MLP-row stash after about 60 % of their time): the slab
+        // reduce is theirs
+        // (recomputing tiles are the longer side: there the reduce stays with the dW workgroups - 2.18 vs 2.29 ms per step)
+        if (STASHED && r_nj > 0)
+            reduce_jobs_strided(r, r_nj, (int64_t)bid * kBwdThreads + threadIdx.x, (int64_t)n_bwd * kBwdThreads);
         return;
     }
     const int v = bid - n_bwd;
     if (v < n_dw) dw_wide_body<true>(g, v, n_dw);
-    if (r_nj > 0) reduce_jobs_strided(r, r_nj, (int64_t)v * kBwdThreads + threadIdx.x, (int64_t)((int)gridDim.x - n_bwd) * kBwdThreads);
+    if (r_nj > 0 && (!STASHED || n_bwd == 0))
+        reduce_jobs_strided(r, r_nj, (int64_t)v * kBwdThreads + threadIdx.x, (int64_t)((int)gridDim.x - n_bwd) * kBwdThreads);
 }
 static_assert(kBwdThreads == kWideThreads, "the merged launch runs both bodies with one workgroup size");
 static_assert(sizeof(BwdArgs) + sizeof(WideGemmS) + sizeof(GroupedReduceS) + 16 <= 4096, "kernel arguments exceed 4 KB");
@@ -2614,7 +2621,10 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 const bool last = step == 2 * T - 1;
                 int room = last ? 256 : 256 - (int)tiles;   // CUs the backward tiles of the NEXT launch leave
                 if (const int64_t force = opt(OPT_DW_WIDE_UNITS)) room = force < room ? (int)force : room;  // developer A/B option
-                const DwPolicy pol{room, lds, 1e30};
+                // whole chunks, not stream-K runs: inside the merged launch 24 tiles x 3 chunks + 8 light units on 80
+                // workgroups measured 25 us per step faster than 85 equal stream-K runs (three slabs per tile to write
+                // and reduce instead of five) although the plan's estimate says the opposite (dw_merged_streamk=1: runs)
+                DwPolicy pol{room, lds, 1e30, opt(OPT_DW_MERGED_STREAMK) == 0};
                 rc = plan_weight_grads(p, pol, jobs, nj, acc, wsf, cur, &pend[cur]);
                 if (rc) return rc;
                 pend_ok[cur] = pend[cur].wide && pend[cur].buf && nj <= kMergedGroup;
