@@ -398,17 +398,22 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
                 mlp_chunk<MT, 1, EPI>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea, thin_ok);
             cur = nxt;
         }
+        if constexpr (STASH && NETS == 2) {
+            // this layer's INPUT rows of both nets (the previous layer's outputs) go to the stash here, behind the
+            // wave's own MFMA work and in front of the layer barrier: the buffer is read-only until the layer after
+            // this one writes it, and a wave's copy overlaps the MFMAs of the wave it shares its SIMD with (all waves
+            // copying right behind the barrier cost 8 us per launch).  s and t leave through the coupling epilogue.
+            if (j >= 1) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    tile_dump<TM, kFusedThreads>(buf(q, pp), LS, a.stash_act[q][j], (int64_t)a.stash_ld, a.stash_w[j - 1], row0,
+                                                 a.n_nodes, tid);
+            }
+        }
         pp ^= 1;
         GNF_STAMP(3 + 2 * j);
         __syncthreads();
         GNF_STAMP(4 + 2 * j);
-        if constexpr (STASH && NETS == 2) {  // the layer's outputs of both nets, out of the buffer the next layer reads
-            const bool lastl = j == a.K - 1;
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                tile_dump<TM, kFusedThreads>(buf(q, pp), LS, lastl ? a.stash_st[q] : a.stash_act[q][j + 1],
-                                             lastl ? (int64_t)H : (int64_t)a.stash_ld, a.stash_w[j], row0, a.n_nodes, tid);
-        }
     }
 
     if constexpr (STASH) {  // (every layer's barrier has passed: the words are complete)
@@ -444,6 +449,10 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
                 const float xv = a.x_upd_src[(int64_t)r * a.ld + f];
                 a.x_upd[(int64_t)r * a.ld + f] = a.inverse ? (xv - tv) * expf(-sv) : xv * expf(sv) + tv;
                 local += (double)sv;
+                if constexpr (STASH) {  // (message-passing nets: no residual, sv / tv are the MLP outputs)
+                    a.stash_st[0][(int64_t)r * H + f] = sv;
+                    a.stash_st[1][(int64_t)r * H + f] = tv;
+                }
             }
         }
         for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
