@@ -406,8 +406,8 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
             if (j >= 1) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
-                    tile_dump<TM, kFusedThreads>(buf(q, pp), LS, a.stash_act[q][j], (int64_t)a.stash_ld, a.stash_w[j - 1], row0,
-                                                 a.n_nodes, tid);
+                    tile_dump<TM, kFusedThreads, true>(buf(q, pp), LS, a.stash_act[q][j], (int64_t)a.stash_ld, a.stash_w[j - 1], row0,
+                                                       a.n_nodes, tid);
             }
         }
         pp ^= 1;

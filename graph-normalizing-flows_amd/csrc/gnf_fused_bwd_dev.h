@@ -308,7 +308,7 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
                 dump = nullptr;
 #endif
                 if (dump == nullptr) continue;
-                tile_dump<TM, kBwdThreads>(buf(q, pp), LS, dump, dld, width, row0, a.n_nodes, tid);
+                tile_dump<TM, kBwdThreads, true>(buf(q, pp), LS, dump, dld, width, row0, a.n_nodes, tid);
             }
         }
     };

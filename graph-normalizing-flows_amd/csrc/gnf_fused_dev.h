@@ -288,7 +288,10 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
 // A tile's rows of one LDS activation buffer ([TM][LS], first `width` columns) to global memory [n_nodes, dld]: coalesced
 // 16-byte-per-lane copy where the widths allow (element-wise stores from the accumulator layout, 64-byte segments, made
 // the backward kernel store-bound on large batches).  All NTHR threads take part.
-template <int TM, int NTHR>
+// NT: non-temporal stores - rows nobody reads before the launch ends (dW operands, the stash): left as ordinary dirty
+// lines they sit in the XCD L2s until the kernel-end write-back and the launch ends that much later (23 MB per
+// launch: 6 us of the training forward).
+template <int TM, int NTHR, bool NT = false>
 __device__ __forceinline__ void tile_dump(const float* __restrict__ src, int LS, float* __restrict__ dump, int64_t dld,
                                           int width, int row0, int n_nodes, int tid) {
     if (((width | (int)dld) & 3) == 0 && (reinterpret_cast<uintptr_t>(dump) & 15) == 0) {
@@ -296,14 +299,25 @@ __device__ __forceinline__ void tile_dump(const float* __restrict__ src, int LS,
         for (int i = tid; i < TM * w4; i += NTHR) {
             const int rl = i / w4, c4 = (i - rl * w4) * 4;
             const int r = row0 + rl;
-            if (r < n_nodes)
-                *reinterpret_cast<f32x4*>(dump + (int64_t)r * dld + c4) = *reinterpret_cast<const f32x4*>(src + rl * LS + c4);
+            if (r < n_nodes) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + rl * LS + c4);
+                f32x4* d = reinterpret_cast<f32x4*>(dump + (int64_t)r * dld + c4);
+                if (NT)
+                    __builtin_nontemporal_store(v, d);
+                else
+                    *d = v;
+            }
         }
     } else {
         for (int i = tid; i < TM * width; i += NTHR) {
             const int rl = i / width, c = i - rl * width;
             const int r = row0 + rl;
-            if (r < n_nodes) dump[(int64_t)r * dld + c] = src[rl * LS + c];
+            if (r < n_nodes) {
+                if (NT)
+                    __builtin_nontemporal_store(src[rl * LS + c], dump + (int64_t)r * dld + c);
+                else
+                    dump[(int64_t)r * dld + c] = src[rl * LS + c];
+            }
         }
     }
 }
