@@ -115,6 +115,64 @@ def test_gradients_config2_batch(community_medium):
     assert np.mean(np.array(rel) <= 1e-3) >= 0.9, sorted(rel)[-40:]
 
 
+@pytest.mark.parametrize("flavour", ["plain", "batch_norm", "weight_sharing_concat"])
+def test_mlp_row_stash_matches_the_recomputing_walk(community_medium, flavour):
+    """GnfFlow.mlp_stash (ABI v8): the training forward leaves the rows the backward walk would recompute; the gradients,
+    the loss and the reconstructed input agree with the fully reversible walk (stash_mlp_rows=False) to rounding, and
+    with the oracle.  The stash is only offered where the library uses it (gnf_mlp_stash_bytes)."""
+    import ctypes as C
+    from gnf_amd import _abi
+    from gnf_amd.train import GRevNetTrainer
+    combine = "concat" if flavour == "weight_sharing_concat" else "agg"
+    ws = flavour == "weight_sharing_concat"
+    hp = dict(D=24, latent=96, K=4, T=3, agg="mean", combine=combine, epsilon=1.0, activation="leaky_relu", weight_sharing=ws)
+    nn, ne, s, r = _batch(community_medium, [3, 50, 77, 12, 100, 5, 9, 130])
+    n = int(nn.sum())
+    x = np.random.default_rng(4).standard_normal((n, hp["D"])).astype(np.float32)
+    p = O.make_grevnet_params(31, hp["D"] // 2, hp["latent"], hp["K"], hp["T"], combine=combine, weight_sharing=ws, final_scale=0.3)
+    if flavour == "batch_norm":
+        p["bn"] = O.make_bn_params(32, hp["D"] // 2, hp["T"])
+    ref = O.loss_and_grads(s, r, n, x, p, hp["T"], ws, agg="mean", combine=combine, epsilon=1.0, activation="leaky_relu")
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    res = {}
+    for stash in (True, False):
+        net = make_product_grevnet(hp, p)
+        tr = GRevNetTrainer(net)
+        tr.stash_mlp_rows = stash
+        out = tr.loss_and_grads(graph)
+        torch.cuda.synchronize()
+        assert (tr._mlp_stash is not None) == stash
+        if stash:
+            flow = net._flow(hp["D"] // 2, torch.device(DEV))
+            assert tr._mlp_stash.numel() == _abi.lib().gnf_mlp_stash_bytes(n, hp["D"], C.byref(flow)) > 0
+        assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
+        np.testing.assert_allclose(out["reconstruction"].cpu().numpy(), x, atol=2e-4, rtol=2e-4)
+        _check_grads(tr.named_gradients(), ref["grads"], ws)
+        res[stash] = (tr.grad.detach().cpu().numpy().copy(), float(out["total_loss"]))
+    scale = float(np.abs(res[False][0]).max())
+    assert float(np.abs(res[True][0] - res[False][0]).max()) <= 2e-5 * scale
+    assert abs(res[True][1] - res[False][1]) <= 1e-9 * abs(res[False][1])      # the same forward arithmetic
+
+
+def test_mlp_row_stash_is_not_offered_where_it_would_not_be_used(community_medium, grid_small):
+    """gnf_mlp_stash_bytes: 0 for attention nets and for batches of more than 192 16-node tiles."""
+    import ctypes as C
+    from gnf_amd import _abi
+    lib = _abi.lib()
+    attn = dict(num_heads=2, kq_dim=3, v_dim=4, out_dim=6, concat=True, kq_dim_division=True, residual=False)
+    hp_a = dict(D=8, latent=32, K=2, T=1, agg="mean", combine="agg", epsilon=0.0, activation="relu", weight_sharing=False, attn=attn)
+    net_a = make_product_grevnet(hp_a, O.make_attn_grevnet_params(5, 4, 32, 2, 1, **attn))
+    nn, ne, s, r = _batch(grid_small, [0, 1])
+    net_a(graph_from_arrays(nn, ne, s, r, np.zeros((int(nn.sum()), 8), np.float32), DEV))
+    assert lib.gnf_mlp_stash_bytes(500, 8, C.byref(net_a._flow(4, torch.device(DEV)))) == 0
+    hp = dict(D=16, latent=64, K=3, T=2, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu", weight_sharing=False)
+    net = make_product_grevnet(hp, O.make_grevnet_params(6, 8, 64, 3, 2))
+    net(graph_from_arrays(nn, ne, s, r, np.zeros((int(nn.sum()), 16), np.float32), DEV))
+    flow = net._flow(8, torch.device(DEV))
+    assert lib.gnf_mlp_stash_bytes(192 * 16, 16, C.byref(flow)) > 0
+    assert lib.gnf_mlp_stash_bytes(192 * 16 + 1, 16, C.byref(flow)) == 0
+
+
 def test_isolated_nodes_and_directed_edges():
     """A directed, asymmetric edge list with isolated nodes: the backward aggregation runs over the by-sender
     CSR, which is NOT the receiver CSR here."""
