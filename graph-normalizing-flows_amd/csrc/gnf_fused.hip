@@ -449,7 +449,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
                 const float xv = a.x_upd_src[(int64_t)r * a.ld + f];
                 a.x_upd[(int64_t)r * a.ld + f] = a.inverse ? (xv - tv) * expf(-sv) : xv * expf(sv) + tv;
                 local += (double)sv;
-                if constexpr (STASH) {  // (message-passing nets: no residual, sv / tv are the MLP outputs)
+                if constexpr (STASH) {  // (what the coupling used: a residual block's x_cond is already in)
                     a.stash_st[0][(int64_t)r * H + f] = sv;
                     a.stash_st[1][(int64_t)r * H + f] = tv;
                 }
@@ -581,7 +581,8 @@ MlpStashLayout mlp_stash_layout(const GnfMlp* net, int64_t n, int32_t H) {
 
 // the forward half of mlp_stash_supported: the (1,2) shape is what the launch would pick
 bool fused_stash_shape(const GnfMlp* s, const GnfMlp* t, int64_t n) {
-    if (!s->packed || !t->packed || s->attn || s->num_layers != t->num_layers) return false;
+    if (!s->packed || !t->packed || s->num_layers != t->num_layers) return false;
+    if (s->attn && s->attn->layer_norm) return false;  // (one net per workgroup there: s, t leave through the global scratch)
     for (int j = 0; j <= s->num_layers; ++j)
         if (s->dims[j] != t->dims[j]) return false;
     if (opt(OPT_FORCE_SHAPE)) return false;

@@ -18,9 +18,9 @@
 
 namespace gnf {
 
-template <int MT>
+template <int MT, bool STASHED = false>
 __global__ __launch_bounds__(kBwdThreads) void k_half_bwd_fused(const BwdArgs a) {
-    half_bwd_body<MT>(a, blockIdx.x, gridDim.x);
+    half_bwd_body<MT, STASHED>(a, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -192,6 +192,19 @@ int launch_half_bwd_fused(const int32_t* rowptr, const int32_t* col, int64_t n, 
     else
         hipLaunchKernelGGL(k_half_bwd_fused<1>, dim3((unsigned)tiles), dim3(kBwdThreads), lds, st, a);
     GNF_LAUNCH_CHECK("k_half_bwd_fused");
+    return GNF_OK;
+}
+
+// the same launch for arguments that carry a half-step's stash rows (st_in, mask_in set by the caller): 16-node tiles only
+int launch_half_bwd_fused_stashed(const BwdArgs& a, int mt, int64_t tiles, size_t lds, hipStream_t st) {
+    if (mt != 1) {
+        set_error("internal: MLP-row stash with 32-node backward tiles (mlp_stash_supported is false there)");
+        return GNF_EINVAL;
+    }
+    GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_bwd_fused<1, true>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLdsLimit)));
+    hipLaunchKernelGGL((k_half_bwd_fused<1, true>), dim3((unsigned)tiles), dim3(kBwdThreads), lds, st, a);
+    GNF_LAUNCH_CHECK("k_half_bwd_fused (stash)");
     return GNF_OK;
 }
 

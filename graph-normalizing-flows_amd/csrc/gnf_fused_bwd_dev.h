@@ -44,6 +44,10 @@ struct BwdArgs {
     const float* st_in[2];                     // [N, H]
     const unsigned long long* mask_in;         // [tile][net][K-1][4][mld] act' ballot words (NULL: timing ablation)
 };
+struct BwdStash {   // one half-step's rows of GnfFlow.mlp_stash as the backward kernel reads them
+    const float* st_in[2];
+    const unsigned long long* mask_in;
+};
 struct BwdFold {
     const int32_t* rowptr_t;
     const int32_t* col_t;
@@ -335,7 +339,7 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
                 } else {
                     sv = s_lds[rl * LS + f], tv = t_lds[rl * LS + f];
                 }
-                if (a.residual) {
+                if (!STASHED && a.residual) {  // (the stashed s, t are what the coupling used: the residual is in)
                     const float xr = a.x_cond[(int64_t)r * a.ld + f];
                     sv += xr;
                     tv += xr;
@@ -371,5 +375,6 @@ int build_bwd_args(const int32_t* rowptr, const int32_t* col, int64_t n, const G
                    float* h0_out, const float* const* h0_in, float* const* hin, int64_t ldh, float* const* dP,
                    int64_t lddp, float* const* gst, float* const* dh0, BwdArgs* out, int* mt, int64_t* tiles, size_t* lds,
                    const BwdFold* fold = nullptr);
+int launch_half_bwd_fused_stashed(const BwdArgs& a, int mt, int64_t tiles, size_t lds, hipStream_t st);
 
 }  // namespace gnf

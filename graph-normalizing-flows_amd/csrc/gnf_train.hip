@@ -1984,11 +1984,15 @@ static bool merged_walk_ok(const GnfFlow* flow, int64_t n, int64_t* tiles_out, s
 
 bool mlp_stash_supported(const GnfFlow* flow, int64_t n, int32_t H) {
     (void)H;
-    if (opt(OPT_NO_MLP_STASH) || n <= 0 || !flow->s_nets || !flow->t_nets) return false;
+    if (opt(OPT_NO_MLP_STASH) || opt(OPT_BWD_GENERIC) || n <= 0 || !flow->s_nets || !flow->t_nets) return false;
     const int n_nets = flow->weight_sharing ? 2 : 2 * flow->num_timesteps;
     for (int q = 0; q < n_nets; ++q)
-        if (!fused_stash_shape(&flow->s_nets[q], &flow->t_nets[q], n)) return false;
-    return merged_walk_ok(flow, n, nullptr, nullptr);
+        if (!fused_stash_shape(&flow->s_nets[q], &flow->t_nets[q], n) || !fused_bwd_supported(&flow->s_nets[q], &flow->t_nets[q]))
+            return false;
+    int64_t tiles;
+    size_t lds;
+    fused_bwd_launch_shape(&flow->s_nets[0], n, &tiles, &lds);
+    return tiles == (n + 15) / 16 && tiles <= kMergedMaxTiles;  // 16-node backward tiles (message-passing nets: the merged launch)
 }
 
 // job list of one half-step: the K layers of both nets, then the four attention matrices of both nets
@@ -2506,7 +2510,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     size_t m_lds = 0;
     if (p.slab_sets == 2) merged = merged_walk_ok(flow, n, &m_tiles, &m_lds);
     // the training forward left every half-step's MLP rows in GnfFlow.mlp_stash: no recompute (ABI v8)
-    const bool mstashed = merged && flow->mlp_stash != nullptr && mlp_stash_supported(flow, n, D / 2);
+    const bool mstashed = flow->mlp_stash != nullptr && mlp_stash_supported(flow, n, D / 2);
     const MlpStashLayout msl = mstashed ? mlp_stash_layout(&flow->s_nets[0], n, D / 2) : MlpStashLayout{};
     if (mstashed && flow->mlp_stash_bytes < (size_t)2 * T * msl.slot * sizeof(float)) {
         set_error("gnf_grevnet_backward_f32: mlp_stash %zu < %zu bytes", flow->mlp_stash_bytes,
@@ -2650,7 +2654,23 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 continue;
             }
             // ---- recompute + coupling + dP chain -------------------------------------------------------------
-            if (fused) {
+            if (fused && mstashed) {  // (attention nets, or the auxiliary-stream scheme by option: the stash without the merged launch)
+                float* slot = flow->mlp_stash + (size_t)(2 * i + half) * msl.slot;
+                for (int q = 0; q < 2; ++q)
+                    for (int j = 1; j < p.K; ++j) o.hin[q * p.K + j] = slot + msl.act + ((size_t)q * (p.K - 1) + (j - 1)) * msl.act_each;
+                if (!attn) o.h0[0] = o.h0[1] = o.hin[0] = o.hin[p.K] = slot + msl.h0;
+                const float* h0c[2] = {o.h0[0], o.h0[1]};
+                BwdArgs ba;
+                int mt;
+                int64_t tiles;
+                size_t lds;
+                rc = build_bwd_args(csr->rowptr, csr->col, n, flow->gnn, nets[0], nets[1], x_cond, z + uo, ld, g + uo, D, H,
+                                    o.h0[0], attn ? h0c : nullptr, o.hin, p.lmax, o.dPs, p.lmax, o.gst, o.dh0, &ba, &mt, &tiles, &lds);
+                if (rc) return rc;
+                for (int q = 0; q < 2; ++q) ba.st_in[q] = slot + msl.st + (size_t)q * msl.st_each;
+                ba.mask_in = reinterpret_cast<const unsigned long long*>(slot + msl.mask);
+                rc = launch_half_bwd_fused_stashed(ba, mt, tiles, lds, st);
+            } else if (fused) {
                 const float* h0c[2] = {o.h0[0], o.h0[1]};
                 rc = launch_half_bwd_fused(csr->rowptr, csr->col, n, flow->gnn, nets[0], nets[1], x_cond, z + uo, ld,
                                            g + uo, D, H, o.h0[0], attn ? h0c : nullptr, o.hin, p.lmax, o.dPs, p.lmax,

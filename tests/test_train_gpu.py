@@ -155,16 +155,18 @@ def test_mlp_row_stash_matches_the_recomputing_walk(community_medium, flavour):
 
 
 def test_mlp_row_stash_is_not_offered_where_it_would_not_be_used(community_medium, grid_small):
-    """gnf_mlp_stash_bytes: 0 for attention nets and for batches of more than 192 16-node tiles."""
+    """gnf_mlp_stash_bytes: 0 for batches of more than 192 16-node tiles and for blocks that end in snt.LayerNorm (their
+    half-steps run one net per workgroup); attention nets without it do get one."""
     import ctypes as C
     from gnf_amd import _abi
     lib = _abi.lib()
-    attn = dict(num_heads=2, kq_dim=3, v_dim=4, out_dim=6, concat=True, kq_dim_division=True, residual=False)
-    hp_a = dict(D=8, latent=32, K=2, T=1, agg="mean", combine="agg", epsilon=0.0, activation="relu", weight_sharing=False, attn=attn)
-    net_a = make_product_grevnet(hp_a, O.make_attn_grevnet_params(5, 4, 32, 2, 1, **attn))
     nn, ne, s, r = _batch(grid_small, [0, 1])
-    net_a(graph_from_arrays(nn, ne, s, r, np.zeros((int(nn.sum()), 8), np.float32), DEV))
-    assert lib.gnf_mlp_stash_bytes(500, 8, C.byref(net_a._flow(4, torch.device(DEV)))) == 0
+    for ln, want in ((False, True), (True, False)):
+        attn = dict(num_heads=2, kq_dim=3, v_dim=4, out_dim=6, concat=True, kq_dim_division=True, residual=False, layer_norm=ln)
+        hp_a = dict(D=8, latent=32, K=2, T=1, agg="mean", combine="agg", epsilon=0.0, activation="relu", weight_sharing=False, attn=attn)
+        net_a = make_product_grevnet(hp_a, O.make_attn_grevnet_params(5, 4, 32, 2, 1, **attn))
+        net_a(graph_from_arrays(nn, ne, s, r, np.zeros((int(nn.sum()), 8), np.float32), DEV))
+        assert (lib.gnf_mlp_stash_bytes(500, 8, C.byref(net_a._flow(4, torch.device(DEV)))) > 0) == want
     hp = dict(D=16, latent=64, K=3, T=2, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu", weight_sharing=False)
     net = make_product_grevnet(hp, O.make_grevnet_params(6, 8, 64, 3, 2))
     net(graph_from_arrays(nn, ne, s, r, np.zeros((int(nn.sum()), 16), np.float32), DEV))
@@ -309,6 +311,7 @@ def test_attention_gradients_vs_oracle(community_medium, case, fused, stash):
     net.fused = fused
     tr = GRevNetTrainer(net)
     tr.stash_attention = stash
+    tr.stash_mlp_rows = stash          # "recompute": the fully reversible walk (neither stash)
     out = tr.loss_and_grads(graph_from_arrays(nn, ne, s, r, x, DEV))
     torch.cuda.synchronize()
     assert (tr._stash is not None) == stash
@@ -350,6 +353,7 @@ def test_attention_layer_norm_gradients_vs_oracle(community_medium, case, fused,
     net.fused = fused
     tr = GRevNetTrainer(net)
     tr.stash_attention = stash
+    tr.stash_mlp_rows = stash          # "recompute": the fully reversible walk (neither stash)
     out = tr.loss_and_grads(graph_from_arrays(nn, ne, s, r, x, DEV))
     torch.cuda.synchronize()
     # (the normalised s is O(1) per feature: |z| and the loss are large, the bound is relative to them)
