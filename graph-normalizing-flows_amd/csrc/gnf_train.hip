@@ -593,8 +593,8 @@ struct WideGemmT {
     int32_t sk_light_base;  // first unit of the jobs cut the uniform way (they ride behind, strided)
 };
 using WideGemm = WideGemmT<kMaxGroup>;
-// message-passing nets only (no attention matrices): what fits next to the backward kernel's arguments in one launch
-static constexpr int kMergedGroup = 2 * GNF_MAX_LAYERS;
+// what fits next to the backward kernel's arguments in one launch (4 KB of kernel arguments)
+static constexpr int kMergedGroup = 20;  // message-passing nets of up to 8 layers (16 jobs), attention nets of up to 6 (2 x (6 + 4))
 using WideGemmS = WideGemmT<kMergedGroup>;
 
 // One BK = 32 step of a wave's MTW x NTW block of MFMA tiles.  A wave is alone on its SIMD here and issues in order,
@@ -1465,7 +1465,7 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net, int n_sets
     p.wslab = off, off += al64((size_t)chunks * p.wsum);
     p.bslab = off, off += al64((size_t)chunks * p.osum);
     p.slab_stride = off - p.wslab;
-    p.slab_sets = (!net->attn && (n + 15) / 16 <= kMergedMaxTiles) ? 2 : 1;
+    p.slab_sets = (n + 15) / 16 <= kMergedMaxTiles ? 2 : 1;
     off += (size_t)(p.slab_sets - 1) * p.slab_stride;
     p.qkv = off, off += 2 * al64((size_t)n * p.P);
     p.dagg = off, off += 2 * al64((size_t)n * p.NV);
@@ -1573,7 +1573,6 @@ struct DwPolicy {
     int max_units;
     size_t lds;
     double budget_us;
-    bool whole_chunks = false;  // no stream-K runs
 };
 
 // The fused backward kernel of the NEXT half-step runs beside this half-step's dW GEMMs (one 16-node tile per
@@ -1722,7 +1721,7 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
         // ---- stream-K for the costliest jobs: equal runs of k-steps across tile boundaries instead of whole chunks ----
         // (24 tiles on 64 workgroups is 2.67 workgroups per tile: cut in whole chunks that is 2 per tile = 48 busy
         // workgroups with 43 steps each; as one axis of 24 x 85 steps it is 64 workgroups with 32 steps each)
-        const bool no_sk = opt(OPT_DW_NO_STREAMK) != 0 || pol.whole_chunks;  // (developer A/B option)
+        const bool no_sk = opt(OPT_DW_NO_STREAMK) != 0;  // developer A/B option
         const int sk_steps = (int)((p.n + WGK - 1) / WGK);
         int sk_q = 0, sk_grid = 0, sk_cmax = 0;
         if (!no_sk && c_heavy > 0 && heavy_tiles > 0 && heavy_tiles <= pol.max_units && sk_steps >= 8) {
@@ -1970,7 +1969,8 @@ static int launch_half_bwd_dw(const BwdArgs* bwd, int64_t bwd_tiles, size_t bwd_
 
 // the backward half of the merged-launch / stash conditions (the forward half: fused_stash_shape)
 static bool merged_walk_ok(const GnfFlow* flow, int64_t n, int64_t* tiles_out, size_t* lds_out) {
-    if (opt(OPT_DW_UNMERGED) || opt(OPT_BWD_GENERIC) || opt(OPT_DW_GROUPED) || flow->s_nets[0].attn) return false;
+    if (opt(OPT_DW_UNMERGED) || opt(OPT_BWD_GENERIC) || opt(OPT_DW_GROUPED)) return false;
+    if (flow->s_nets[0].attn && 2 * (flow->s_nets[0].num_layers + 4) > kMergedGroup) return false;
     const int n_nets = flow->weight_sharing ? 2 : 2 * flow->num_timesteps;
     for (int q = 0; q < n_nets; ++q)
         if (!fused_bwd_supported(&flow->s_nets[q], &flow->t_nets[q])) return false;
@@ -2534,6 +2534,22 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     hipEvent_t ev_last = nullptr;
     int step = 0;
     bool used[2] = {false, false};  // weight sharing: the T uses of a net accumulate
+    // the attention front-end backwards: dagg = dnew Wo^T ([nodes, C] x [C, heads*v]; Wo is [heads*v, C]: rows = output
+    // columns), then the edge kernels; dL/dx_cond accumulates into g_cond
+    auto attention_backward = [&](const GnfMlp* const* nets_, const BwdOperands& o_, float* g_cond) -> int {
+        const GnfAttn* at[2] = {nets_[0]->attn, nets_[1]->attn};
+        const int off = at[0]->concat ? D / 2 : 0;
+        GemmJob jobs[2];
+        for (int q = 0; q < 2; ++q) jobs[q] = GemmJob{o_.dh0[q] + off, at[q]->Wo, o_.dagg[q], nullptr, nullptr};
+        GemmShape sh;
+        memset(&sh, 0, sizeof(sh));
+        sh.lda = p.in0, sh.ldb = p.C, sh.ldc = p.NV;
+        sh.M = n, sh.K = p.C, sh.N = p.NV, sh.chunks = 1, sh.kchunk = TGK;
+        int rc_ = launch_gemm<OPND_KC, OPND_KC, EPI_MASK>(jobs, 2, sh, st);
+        if (rc_) return rc_;
+        return launch_attn_backward(at, n, D / 2, p.in0, csr->rowptr, csr->col, csr_t->rowptr, csr_t->col, o_.qkv, o_.dh0, o_.gst,
+                                    o_.dqkv, o_.agg, o_.dagg, o_.stats, g_cond, D, st);
+    };
     DwLaunch pend[2];
     bool pend_ok[2] = {false, false};
     bool have_fold = false;  // the previous half-step left its dL/dh0 rows for this one's prologue to scatter
@@ -2593,11 +2609,14 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 if (mstashed) {  // layer inputs of both nets come from the half-step's slot of the stash
                     float* slot = flow->mlp_stash + (size_t)(2 * i + half) * msl.slot;
                     for (int q = 0; q < 2; ++q) {
-                        o.h0[q] = slot + msl.h0;
-                        o.hin[q * p.K] = o.h0[q];
+                        if (!attn) {  // (attention nets: the layer-0 inputs are the front-end's, stashed or recomputed above)
+                            o.h0[q] = slot + msl.h0;
+                            o.hin[q * p.K] = o.h0[q];
+                        }
                         for (int j = 1; j < p.K; ++j) o.hin[q * p.K + j] = slot + msl.act + ((size_t)q * (p.K - 1) + (j - 1)) * msl.act_each;
                     }
                 }
+                const float* h0c[2] = {o.h0[0], o.h0[1]};
                 BwdFold bf;
                 const bool folded = have_fold;
                 if (folded) {
@@ -2606,7 +2625,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                     bf.dh_prev[0] = fold_dh[0], bf.dh_prev[1] = fold_dh[1];
                 }
                 rc = build_bwd_args(csr->rowptr, csr->col, n, flow->gnn, nets[0], nets[1], x_cond, z + uo, ld, g + uo, D, H,
-                                    o.h0[0], nullptr, o.hin, p.lmax, o.dPs, p.lmax, o.gst, o.dh0, &ba, &mt, &tiles, &lds,
+                                    o.h0[0], attn ? h0c : nullptr, o.hin, p.lmax, o.dPs, p.lmax, o.gst, o.dh0, &ba, &mt, &tiles, &lds,
                                     folded ? &bf : nullptr);
                 if (rc) return rc;
                 if (mstashed) {
@@ -2625,10 +2644,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 const bool last = step == 2 * T - 1;
                 int room = last ? 256 : 256 - (int)tiles;   // CUs the backward tiles of the NEXT launch leave
                 if (const int64_t force = opt(OPT_DW_WIDE_UNITS)) room = force < room ? (int)force : room;  // developer A/B option
-                // whole chunks, not stream-K runs: inside the merged launch 24 tiles x 3 chunks + 8 light units on 80
-                // workgroups measured 25 us per step faster than 85 equal stream-K runs (three slabs per tile to write
-                // and reduce instead of five) although the plan's estimate says the opposite (dw_merged_streamk=1: runs)
-                DwPolicy pol{room, lds, 1e30, opt(OPT_DW_MERGED_STREAMK) == 0};
+                const DwPolicy pol{room, lds, 1e30};
                 rc = plan_weight_grads(p, pol, jobs, nj, acc, wsf, cur, &pend[cur]);
                 if (rc) return rc;
                 pend_ok[cur] = pend[cur].wide && pend[cur].buf && nj <= kMergedGroup;
@@ -2638,8 +2654,11 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                     rc = run_weight_reduce(pend[cur], st);
                     if (rc) return rc;
                 }
-                have_fold = !flow->bns && !last && !opt(OPT_BWD_NO_FOLD);
-                if (have_fold) {
+                have_fold = !attn && !flow->bns && !last && !opt(OPT_BWD_NO_FOLD);
+                if (attn) {
+                    rc = attention_backward(nets, o, g + co);
+                    if (rc) return rc;
+                } else if (have_fold) {
                     fold_dh[0] = o.dh0[0], fold_dh[1] = o.dh0[1];
                 } else {
                     rc = launch_aggregate_bwd(p, csr_t, flow->gnn, wsf + p.invdeg, o.dh0[0], o.dh0[1], g + co, D, st);
@@ -2690,20 +2709,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             }
             // ---- dL/dx_cond: on the critical path (the next half-step's coupling reads g), so it goes first -----
             if (attn) {
-                const GnfAttn* at[2] = {nets[0]->attn, nets[1]->attn};
-                {   // dagg = dnew Wo^T   [nodes, C] x [C, heads*v]  (Wo is [heads*v, C]: rows = output columns)
-                    const int off = at[0]->concat ? H : 0;
-                    GemmJob jobs[2];
-                    for (int q = 0; q < 2; ++q) jobs[q] = GemmJob{o.dh0[q] + off, at[q]->Wo, o.dagg[q], nullptr, nullptr};
-                    GemmShape sh;
-                    memset(&sh, 0, sizeof(sh));
-                    sh.lda = p.in0, sh.ldb = p.C, sh.ldc = p.NV;
-                    sh.M = n, sh.K = p.C, sh.N = p.NV, sh.chunks = 1, sh.kchunk = TGK;
-                    rc = launch_gemm<OPND_KC, OPND_KC, EPI_MASK>(jobs, 2, sh, st);
-                    if (rc) return rc;
-                }
-                rc = launch_attn_backward(at, n, H, p.in0, csr->rowptr, csr->col, csr_t->rowptr, csr_t->col, o.qkv, o.dh0,
-                                          o.gst, o.dqkv, o.agg, o.dagg, o.stats, g + co, D, st);
+                rc = attention_backward(nets, o, g + co);
             } else {
                 rc = launch_aggregate_bwd(p, csr_t, flow->gnn, wsf + p.invdeg, o.dh0[0], o.dh0[1], g + co, D, st);
             }

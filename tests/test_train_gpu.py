@@ -568,8 +568,8 @@ DW_MODES = [   # (gnf_set_option values, dw_modes_check.py flags)
     ({}, "ws"),                                                   # ... with weight sharing: the in-launch reduce accumulates
     ({"bwd_no_fold": 1}, ""),                                     # merged launch, message-passing scatter in its own launch
     ({"dw_wide_units": 8}, ""),                                   # merged launch, few dW workgroups: cheap units ride behind, strided
-    ({"dw_merged_streamk": 1}, ""),                               # ... stream-K runs instead of whole chunks
-    ({"dw_merged_streamk": 1, "dw_wide_units": 13}, "ws"),        # ... with an odd workgroup count
+    ({"dw_no_streamk": 1}, ""),                                   # ... whole chunks instead of stream-K runs
+    ({"dw_wide_units": 13}, "ws"),                                # ... stream-K with an odd workgroup count
     ({"no_mlp_stash": 1}, "ws"),                                  # merged launch recomputing the MLP rows (no stash)
     ({"no_mlp_stash": 1, "bwd_no_fold": 1}, ""),
     ({"dw_no_buf": 1}, ""),                                       # ... a plan the merged launch cannot carry runs on its own
