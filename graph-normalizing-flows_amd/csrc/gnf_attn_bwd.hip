@@ -17,6 +17,7 @@
 #include "gnf_attn_dev.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 namespace gnf {
 
@@ -504,35 +505,38 @@ __device__ __forceinline__ void attn_recv_thread(const AttnBwdArgs& a, int net, 
         if (j < vd) a.agg[net][(int64_t)r * NV + h * vd + j] = ag[j];
 }
 
-template <int KQM, int VDM>
+// ROWS: receiver rows per workgroup (lanes ROWS .. 63 of every head's wave idle).  64 suits the complete graphs these
+// kernels were built for (the window IS the graph); on sparse batches 64-row tiles are 43 workgroups per net for 256
+// CUs and every thread's serial walk over its edges is the whole kernel: 32-row tiles put twice as many CUs to work.
+template <int KQM, int VDM, int ROWS = 64>
 __global__ __launch_bounds__(512) void k_attn_bwd_recv_rows(const AttnBwdArgs a, int win_cap) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int net = blockIdx.y;
     const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * kRowsTile;
+    const int row0 = blockIdx.x * ROWS;
     int* s_rp = reinterpret_cast<int*>(sm);
-    int* s_hdr = s_rp + kRowsTile + 1;
+    int* s_hdr = s_rp + ROWS + 1;
     int* s_col = s_hdr + 3;
     float* win = reinterpret_cast<float*>(s_col + kRowsColCap);
     const int WS = (nq + vd + 2) & ~1;  // even: rows stay 8-byte aligned
-    if (tid <= kRowsTile) {
+    if (tid <= ROWS) {
         const int r = row0 + tid;
         s_rp[tid] = a.rowptr[r < a.n ? r : a.n];
     }
     __syncthreads();
     const float* qkv = a.qkv[net];
-    const int lo = stage_window(a.col, s_rp, kRowsTile, s_hdr, win_cap, tid, 512, [&](int lo_, int cnt) {
+    const int lo = stage_window(a.col, s_rp, ROWS, s_hdr, win_cap, tid, 512, [&](int lo_, int cnt) {
         window_copy(win, WS, cnt, nq + vd, tid, 512, [&](int rr, int c) {
             return qkv[(int64_t)(lo_ + rr) * P + (c < nq ? c : nq + c)];
         });
     });
-    const bool cols_in_lds = stage_cols(a.col, s_rp, kRowsTile, s_col, kRowsColCap, tid, 512);
+    const bool cols_in_lds = stage_cols(a.col, s_rp, ROWS, s_col, kRowsColCap, tid, 512);
     __syncthreads();
     const int* cols = cols_in_lds ? s_col : a.col;
     const int col_base = cols_in_lds ? s_rp[0] : 0;
     const int r = row0 + lane;
-    if (wave < nh && r < a.n) {
+    if (wave < nh && lane < ROWS && r < a.n) {
         const bool even = ((kq | vd | nq) & 1) == 0;
         if (lo >= 0)
             attn_recv_thread<KQM, VDM, true>(a, net, r, wave, win, lo, WS, cols, col_base,
@@ -617,31 +621,31 @@ __device__ __forceinline__ void attn_send_thread(const AttnBwdArgs& a, int net, 
     for (int j = 0; j < VDM; ++j) dvp_out[j] = dvp[j];
 }
 
-template <int KQM, int VDM>
+template <int KQM, int VDM, int ROWS = 64>
 __global__ __launch_bounds__(512) void k_attn_bwd_send_rows(const AttnBwdArgs a, int win_cap) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int net = blockIdx.y;
     const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * kRowsTile;
+    const int row0 = blockIdx.x * ROWS;
     int* s_rp = reinterpret_cast<int*>(sm);
-    int* s_hdr = s_rp + kRowsTile + 1;
+    int* s_hdr = s_rp + ROWS + 1;
     int* s_col = s_hdr + 3;
     float* win = reinterpret_cast<float*>(s_col + kRowsColCap);
     const int WS = (nq + NV + 2) & ~1;  // even: rows stay 8-byte aligned
-    if (tid <= kRowsTile) {
+    if (tid <= ROWS) {
         const int r = row0 + tid;
         s_rp[tid] = a.rowptr_t[r < a.n ? r : a.n];
     }
     __syncthreads();
     const float* qkv = a.qkv[net];
     const float* dagg = a.dagg[net];
-    const int lo = stage_window(a.col_t, s_rp, kRowsTile, s_hdr, win_cap, tid, 512, [&](int lo_, int cnt) {
+    const int lo = stage_window(a.col_t, s_rp, ROWS, s_hdr, win_cap, tid, 512, [&](int lo_, int cnt) {
         window_copy(win, WS, cnt, nq + NV, tid, 512, [&](int rr, int c) {
             return c < nq ? qkv[(int64_t)(lo_ + rr) * P + nq + c] : dagg[(int64_t)(lo_ + rr) * NV + (c - nq)];
         });
     });
-    const bool cols_in_lds = stage_cols(a.col_t, s_rp, kRowsTile, s_col, kRowsColCap, tid, 512);
+    const bool cols_in_lds = stage_cols(a.col_t, s_rp, ROWS, s_col, kRowsColCap, tid, 512);
     __syncthreads();
     const int* cols = cols_in_lds ? s_col : a.col_t;
     const int col_base = cols_in_lds ? s_rp[0] : 0;
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_send_rows(const AttnBwdArgs a,
     float dvp[VDM];
 #pragma unroll
     for (int j = 0; j < VDM; ++j) dvp[j] = 0.f;
-    if (wave < nh && u_ < a.n) {
+    if (wave < nh && lane < ROWS && u_ < a.n) {
         const bool even = ((kq | vd | nq | NV) & 1) == 0;
         if (lo >= 0)
             attn_send_thread<KQM, VDM, true>(a, net, u_, wave, win, lo, WS, cols, col_base,
@@ -664,7 +668,7 @@ __global__ __launch_bounds__(512) void k_attn_bwd_send_rows(const AttnBwdArgs a,
 #pragma unroll
     for (int j = 0; j < VDM; ++j) red[(wave * 64 + lane) * VDM + j] = dvp[j];
     __syncthreads();
-    if (u_ < a.n)
+    if (lane < ROWS && u_ < a.n)
         for (int j = wave; j < vd; j += 8) {
             float s = 0.f;
             for (int h = 0; h < nh; ++h) s += red[(h * 64 + lane) * VDM + j];
@@ -741,7 +745,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dx(const AttnDxArgs a) {
 int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t in0, const int32_t* rowptr,
                          const int32_t* col, const int32_t* rowptr_t, const int32_t* col_t, const float* const* qkv,
                          const float* const* dh0, const float* const* gst, float* const* dqkv, float* const* agg,
-                         float* const* dagg, float* const* stats, float* g_cond, int64_t ldg, hipStream_t st) {
+                         float* const* dagg, float* const* stats, float* g_cond, int64_t ldg, hipStream_t st, int64_t n_edges) {
     if (n == 0) return GNF_OK;
     const GnfAttn* a0 = at[0];
     AttnBwdArgs a;
@@ -796,19 +800,36 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
         // the sender pass re-uses the window region for its head reduction: 8 x 64 x VDM floats must fit
         if (capr >= 64 && (size_t)caps * (nq + NV) >= (size_t)8 * 64 * 32) {
             GNF_ONCE_PER_DEVICE(
-                const void* ks[4] = {reinterpret_cast<const void*>(k_attn_bwd_recv_rows<10, 10>),
-                                     reinterpret_cast<const void*>(k_attn_bwd_recv_rows<32, 32>),
-                                     reinterpret_cast<const void*>(k_attn_bwd_send_rows<10, 10>),
-                                     reinterpret_cast<const void*>(k_attn_bwd_send_rows<32, 32>)};
+                const void* ks[12] = {
+                    reinterpret_cast<const void*>(k_attn_bwd_recv_rows<10, 10, 64>), reinterpret_cast<const void*>(k_attn_bwd_recv_rows<32, 32, 64>),
+                    reinterpret_cast<const void*>(k_attn_bwd_send_rows<10, 10, 64>), reinterpret_cast<const void*>(k_attn_bwd_send_rows<32, 32, 64>),
+                    reinterpret_cast<const void*>(k_attn_bwd_recv_rows<10, 10, 32>), reinterpret_cast<const void*>(k_attn_bwd_recv_rows<32, 32, 32>),
+                    reinterpret_cast<const void*>(k_attn_bwd_send_rows<10, 10, 32>), reinterpret_cast<const void*>(k_attn_bwd_send_rows<32, 32, 32>),
+                    reinterpret_cast<const void*>(k_attn_bwd_recv_rows<10, 10, 16>), reinterpret_cast<const void*>(k_attn_bwd_recv_rows<32, 32, 16>),
+                    reinterpret_cast<const void*>(k_attn_bwd_send_rows<10, 10, 16>), reinterpret_cast<const void*>(k_attn_bwd_send_rows<32, 32, 16>)};
                 for (const void* k : ks) GNF_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
-            const dim3 rgrid((unsigned)((n + kRowsTile - 1) / kRowsTile), 2);
-            if (a.kq <= 10 && a.v <= 10) {
-                hipLaunchKernelGGL((k_attn_bwd_recv_rows<10, 10>), rgrid, dim3(512), (size_t)kRowsLdsBudget, st, a, capr);
-                hipLaunchKernelGGL((k_attn_bwd_send_rows<10, 10>), rgrid, dim3(512), (size_t)kRowsLdsBudget, st, a, caps);
-            } else {
-                hipLaunchKernelGGL((k_attn_bwd_recv_rows<32, 32>), rgrid, dim3(512), (size_t)kRowsLdsBudget, st, a, capr);
-                hipLaunchKernelGGL((k_attn_bwd_send_rows<32, 32>), rgrid, dim3(512), (size_t)kRowsLdsBudget, st, a, caps);
-            }
+            // sparse batches (mean degree below 24): 32-row tiles - default-flags training step on the config-2 batch 4.44
+            // (64) / 4.24 (32) / 4.74 ms (16: the window staging per workgroup takes over); option attn_bwd_rows forces one
+            int rows = (n_edges > 0 && n_edges < 24 * n) ? 32 : 64;
+            if (const int64_t force = opt(OPT_ATTN_BWD_ROWS); force == 64 || force == 32 || force == 16) rows = (int)force;
+            const dim3 rgrid((unsigned)((n + rows - 1) / rows), 2);
+            const bool small = a.kq <= 10 && a.v <= 10;
+            auto go = [&](auto rows_c) {
+                constexpr int R = decltype(rows_c)::value;
+                if (small) {
+                    hipLaunchKernelGGL((k_attn_bwd_recv_rows<10, 10, R>), rgrid, dim3(512), (size_t)kRowsLdsBudget, st, a, capr);
+                    hipLaunchKernelGGL((k_attn_bwd_send_rows<10, 10, R>), rgrid, dim3(512), (size_t)kRowsLdsBudget, st, a, caps);
+                } else {
+                    hipLaunchKernelGGL((k_attn_bwd_recv_rows<32, 32, R>), rgrid, dim3(512), (size_t)kRowsLdsBudget, st, a, capr);
+                    hipLaunchKernelGGL((k_attn_bwd_send_rows<32, 32, R>), rgrid, dim3(512), (size_t)kRowsLdsBudget, st, a, caps);
+                }
+            };
+            if (rows == 16)
+                go(std::integral_constant<int, 16>{});
+            else if (rows == 32)
+                go(std::integral_constant<int, 32>{});
+            else
+                go(std::integral_constant<int, 64>{});
             GNF_LAUNCH_CHECK("k_attn_bwd_recv_rows / k_attn_bwd_send_rows");
             goto dx_pass;
         }

@@ -138,7 +138,8 @@ int launch_half_bwd_fused(const int32_t* rowptr, const int32_t* col, int64_t n, 
 int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t in0, const int32_t* rowptr,
                          const int32_t* col, const int32_t* rowptr_t, const int32_t* col_t, const float* const* qkv,
                          const float* const* dh0, const float* const* gst, float* const* dqkv, float* const* agg,
-                         float* const* dagg, float* const* stats, float* g_cond, int64_t ldg, hipStream_t st);
+                         float* const* dagg, float* const* stats, float* g_cond, int64_t ldg, hipStream_t st,
+                         int64_t n_edges = 0);  // n_edges: 0 = unknown (picks between tile sizes by mean degree)
 
 // thin y = act(x W + b) through the split-K generic GEMM (gnf_train.hip); 1 = not thin, the caller runs its own kernel
 int launch_linear_splitk(const float* const* x, int64_t ldx, const float* const* W, const float* const* b, float* const* y,

@@ -2548,7 +2548,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
         int rc_ = launch_gemm<OPND_KC, OPND_KC, EPI_MASK>(jobs, 2, sh, st);
         if (rc_) return rc_;
         return launch_attn_backward(at, n, D / 2, p.in0, csr->rowptr, csr->col, csr_t->rowptr, csr_t->col, o_.qkv, o_.dh0, o_.gst,
-                                    o_.dqkv, o_.agg, o_.dagg, o_.stats, g_cond, D, st);
+                                    o_.dqkv, o_.agg, o_.dagg, o_.stats, g_cond, D, st, csr->n_edges);
     };
     DwLaunch pend[2];
     bool pend_ok[2] = {false, false};
