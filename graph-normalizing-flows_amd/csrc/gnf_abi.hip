@@ -489,6 +489,12 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
         mstash = flow->mlp_stash;
     }
 
+    // sum(z^2): per-workgroup partials out of the coupling epilogues of the last two half-steps instead of a k_gauss
+    // launch over z (without batch norm - a bijector in front of the very last half-step still changes the other half -
+    // and while two launches' partials fit the slots; paths that do not write them leave nsq at 0)
+    double* const gpart = partials + 2 * (int64_t)(T > 0 ? T : 1) * p.partial_stride;
+    int32_t nsq[2] = {0, 0};
+    const bool sq_ok = direction == GNF_FORWARD && !flow->bns && T > 0 && 2 * ((n + 15) / 16) <= kMaxGaussBlocks;
     if (n > 0) {
         if (direction == GNF_FORWARD) {
             for (int i = 0; i < T; ++i) {  // gnn.py:309-338
@@ -508,6 +514,10 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
                     mark_first(hs, half);
                     mark_attn(hs, half, i);
                     if (mstash) hs.mlp_stash = mstash + (size_t)(2 * i + half) * mstash_slot;
+                    if (sq_ok && i == T - 1) {  // the outputs of the flow's last two half-steps are z: sum(z^2) rides along
+                        hs.sq_partials = gpart + (half == 0 ? 0 : nsq[0]);
+                        hs.n_sq = &nsq[half];
+                    }
                     rc = run_half(hs, scratch, st);
                     if (rc) return rc;
                     used += np_;
@@ -535,12 +545,13 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
         }
     }
     if (direction == GNF_FORWARD) {
-        double* gpart = partials + 2 * (int64_t)(T > 0 ? T : 1) * p.partial_stride;
         // (measured and dropped, tools/ab_options.py: k_gauss + k_finalize merged into one launch whose last-arriving
         // workgroup runs the final reduction - the release / ticket / acquire hand-off costs 1 us more than the launch
         // boundary it removes)
         int32_t ng = 0;
-        if (n > 0) {
+        if (nsq[0] > 0 && nsq[1] > 0) {
+            ng = nsq[0] + nsq[1];
+        } else if (n > 0) {
             rc = launch_gauss_partials(x, n, D, ld, gpart, &ng, st);
             if (rc) return rc;
         }

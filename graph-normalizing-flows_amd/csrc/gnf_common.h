@@ -59,6 +59,10 @@ struct HalfStep {
     const float* attn_packed[2] = {nullptr, nullptr};
     // training forward: this half-step's slot of GnfFlow.mlp_stash (mlp_stash_layout), or NULL
     float* mlp_stash = nullptr;
+    // forward, the flow's last two half-steps (their outputs are z): room for one fp64 partial of sum(x_upd_new^2) per
+    // workgroup; *n_sq = how many the launch wrote (0: this path does not - the caller runs k_gauss over z instead)
+    double* sq_partials = nullptr;
+    int32_t* n_sq = nullptr;
 };
 
 // MLP-row stash (GnfFlow.mlp_stash, ABI v8): the rows of a half-step the backward walk would otherwise recompute

@@ -119,6 +119,8 @@ struct FusedArgs {
     const float* x_upd_src;              // old value of the updated half (= x_upd, or the source buffer of an out-of-place first step)
     float* cond_copy;                    // NULL, or where this tile's rows of the conditioning half are copied to (out-of-place first step)
     double* partials;
+    double* sq_partials;                 // NETS = 2, forward: also sum(x_upd_new^2) per workgroup (the Gaussian term of the
+                                         // flow's last two half-steps, whose outputs are z), or NULL
     float* st_out[2];                    // NETS = 1: global [N, H] scratch for s (0) and t (1)
     const float* h0[2];                  // precomputed layer-0 input per net ([N, in0], attention GNNs) or NULL
     const float* wp[2][GNF_MAX_LAYERS];  // [net][layer] packed weights
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
         // ---- C: coupling update + block-reduced sum(s) -----------------------------------------
         const float* s_lds = buf(0, pp);
         const float* t_lds = buf(1, pp);
-        double local = 0.0;
+        double local = 0.0, local2 = 0.0;
         for (int idx = tid; idx < TM * H; idx += kFusedThreads) {
             const int rl = idx / H, f = idx - rl * H;
             const int r = row0 + rl;
@@ -447,8 +449,10 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
                     tv += xr;
                 }
                 const float xv = a.x_upd_src[(int64_t)r * a.ld + f];
-                a.x_upd[(int64_t)r * a.ld + f] = a.inverse ? (xv - tv) * expf(-sv) : xv * expf(sv) + tv;
+                const float xn = a.inverse ? (xv - tv) * expf(-sv) : xv * expf(sv) + tv;
+                a.x_upd[(int64_t)r * a.ld + f] = xn;
                 local += (double)sv;
+                local2 += (double)xn * (double)xn;
                 if constexpr (STASH) {  // (what the coupling used: a residual block's x_cond is already in)
                     a.stash_st[0][(int64_t)r * H + f] = sv;
                     a.stash_st[1][(int64_t)r * H + f] = tv;
@@ -462,6 +466,17 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
             double tot = 0.0;
             for (int w = 0; w < kFusedThreads / 64; ++w) tot += red[w];
             a.partials[tile] = tot;
+        }
+        if (a.sq_partials) {  // (workgroup-uniform) the same fixed-order reduction for sum(x_new^2)
+            for (int off = 32; off > 0; off >>= 1) local2 += __shfl_down(local2, off, 64);
+            __syncthreads();
+            if (lane == 0) red[wave] = local2;
+            __syncthreads();
+            if (tid == 0) {
+                double tot = 0.0;
+                for (int w = 0; w < kFusedThreads / 64; ++w) tot += red[w];
+                a.sq_partials[tile] = tot;
+            }
         }
     }
     GNF_STAMP(15);
@@ -604,6 +619,7 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
     a.x_upd_src = hs.x_upd_src ? hs.x_upd_src : hs.x_upd;
     a.cond_copy = hs.cond_copy;
     a.partials = hs.partials;
+    a.sq_partials = NETS == 2 ? hs.sq_partials : nullptr;
     // NETS = 1 scratch: s [N,H] | t [N,H] at the head of the float scratch
     a.st_out[0] = scratch;
     a.st_out[1] = scratch + hs.n_nodes * hs.H;
@@ -674,12 +690,14 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
         rc = launch_shape<1, 2, true>(a, (unsigned)tiles, lds + (size_t)L.mask_words * sizeof(unsigned long long), st);
         if (rc) return rc;
         *hs.n_partials = (int32_t)tiles;
+        if (hs.n_sq) *hs.n_sq = a.sq_partials ? (int32_t)tiles : 0;
         return GNF_OK;
     }
     if (NETS == 2) {
         rc = MT == 2 ? launch_shape<2, 2>(a, (unsigned)tiles, lds, st) : launch_shape<1, 2>(a, (unsigned)tiles, lds, st);
         if (rc) return rc;
         *hs.n_partials = (int32_t)tiles;
+        if (hs.n_sq) *hs.n_sq = a.sq_partials ? (int32_t)tiles : 0;
         return GNF_OK;
     }
     if (hs.x_upd_src || hs.cond_copy) {
