@@ -344,6 +344,21 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
     if (a.h0[0] != nullptr) {
         // attention GNNs: the layer-0 input of each net was produced by the attention front-end
         const int in0p = a.ipg[0] * 16;
+        const bool v4 = (a.in0 & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.h0[net0]) | reinterpret_cast<uintptr_t>(a.h0[NETS == 2 ? 1 : net0])) & 15) == 0;
+        if (v4) {  // 16 bytes per lane, both nets' rows requested together (LS and in0p are multiples of 4)
+            const int q4 = in0p >> 2;
+            for (int idx = tid; idx < TM * q4; idx += kFusedThreads) {
+                const int rl = idx / q4, c = (idx - rl * q4) * 4;
+                const int r = row0 + rl;
+                const bool live = r < a.n_nodes && c < a.in0;
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 v0 = live ? *reinterpret_cast<const f32x4*>(a.h0[net0] + (int64_t)r * a.in0 + c) : z4;
+                f32x4 v1 = z4;
+                if (NETS == 2 && live) v1 = *reinterpret_cast<const f32x4*>(a.h0[1] + (int64_t)r * a.in0 + c);
+                *reinterpret_cast<f32x4*>(buf(0, 0) + rl * LS + c) = v0;
+                if (NETS == 2) *reinterpret_cast<f32x4*>(buf(1, 0) + rl * LS + c) = v1;
+            }
+        } else
         for (int idx = tid; idx < TM * in0p; idx += kFusedThreads) {
             const int rl = idx / in0p, c = idx - rl * in0p;
             const int r = row0 + rl;

@@ -200,6 +200,19 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
     // ---- A: aggregate + combine (same arithmetic and order as the forward kernel) ----------------
     if (a.h0_in[0] != nullptr) {
         const int in0p = a.tab[0][0] * 16;
+        if ((a.in0 & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.h0_in[0]) | reinterpret_cast<uintptr_t>(a.h0_in[1])) & 15) == 0) {
+            const int q4 = in0p >> 2;  // 16 bytes per lane, both nets' rows requested together
+            for (int idx = tid; idx < TM * q4; idx += kBwdThreads) {
+                const int rl = idx / q4, c = (idx - rl * q4) * 4;
+                const int r = row0 + rl;
+                const bool live = r < a.n_nodes && c < a.in0;
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 v0 = live ? *reinterpret_cast<const f32x4*>(a.h0_in[0] + (int64_t)r * a.in0 + c) : z4;
+                const f32x4 v1 = live ? *reinterpret_cast<const f32x4*>(a.h0_in[1] + (int64_t)r * a.in0 + c) : z4;
+                *reinterpret_cast<f32x4*>(buf(0, 0) + rl * LS + c) = v0;
+                *reinterpret_cast<f32x4*>(buf(1, 0) + rl * LS + c) = v1;
+            }
+        } else
         for (int idx = tid; idx < TM * in0p; idx += kBwdThreads) {
             const int rl = idx / in0p, c = idx - rl * in0p;
             const int r = row0 + rl;
