@@ -494,6 +494,7 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
     // and while two launches' partials fit the slots; paths that do not write them leave nsq at 0)
     double* const gpart = partials + 2 * (int64_t)(T > 0 ? T : 1) * p.partial_stride;
     int32_t nsq[2] = {0, 0};
+    int32_t bn_pre = 0;  // partial rows the previous half-step's kernel left for the next bijector's moments (0: none)
     const bool sq_ok = direction == GNF_FORWARD && !flow->bns && T > 0 && 2 * ((n + 15) / 16) <= kMaxGaussBlocks;
     if (n > 0) {
         if (direction == GNF_FORWARD) {
@@ -501,9 +502,10 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
                 for (int half = 0; half < 2; ++half) {
                     if (flow->bns) {  // gnn.py:310-313, 325-328: normalise the conditioning half first
                         rc = launch_bn_normalize(flow, &flow->bns[half * T + i], half == 0 ? half0 : half1, ld, n, H,
-                                                 partials + p.bn_offset, partials + used, st);
+                                                 partials + p.bn_offset, partials + used, st, bn_pre);
                         if (rc) return rc;
                         used += 1;
+                        bn_pre = 0;
                     }
                     int32_t np_ = 0;
                     HalfStep hs{csr->rowptr, csr->col, n, half == 0 ? half0 : half1,
@@ -514,6 +516,11 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
                     mark_first(hs, half);
                     mark_attn(hs, half, i);
                     if (mstash) hs.mlp_stash = mstash + (size_t)(2 * i + half) * mstash_slot;
+                    // the half this half-step updates is what the NEXT bijector normalises: its column sums ride along
+                    if (flow->bns && !(i == T - 1 && half == 1) && (n + 15) / 16 <= kBnBlocksMax) {
+                        hs.bn_part = partials + p.bn_offset;
+                        hs.n_bn = &bn_pre;
+                    }
                     if (sq_ok && i == T - 1) {  // the outputs of the flow's last two half-steps are z: sum(z^2) rides along
                         hs.sq_partials = gpart + (half == 0 ? 0 : nsq[0]);
                         hs.n_sq = &nsq[half];

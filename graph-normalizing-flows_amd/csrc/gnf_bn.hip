@@ -95,12 +95,43 @@ __global__ __launch_bounds__(256) void k_bn_apply(float* __restrict__ x, int64_t
                                                   const double* __restrict__ n_moments) {
     extern __shared__ float ss[];  // scale[H] | shift[H]
     __shared__ double red[256];
+    __shared__ double gsum[512];   // [G][H][2] group sums of the partials (G * H <= 256)
     float* scale = ss;
     float* shift = ss + H;
     const int tid = threadIdx.x;
     double ld_local = 0.0;
+    // column sums of the partials.  Few partials (k_bn_stats' ~16 row chunks): one thread per column walks them.  Many
+    // (one per 16-node tile when the previous half-step's kernel left them): all 256 threads share the walk - thread
+    // (g, c) sums partials g, g + G, ..; the G group sums are then added in order.  Fixed order either way.
+    const int G = (nparts > 32 && H <= 128) ? 256 / H : 1;
+    if (G > 1) {
+        const int c = tid % H, g = tid / H;
+        double s = 0.0, q = 0.0;
+        if (g < G)
+            for (int b0 = g; b0 < nparts; b0 += 8 * G) {
+                double ps[8], pq_[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int b = b0 + k * G < nparts ? b0 + k * G : g;
+                    ps[k] = part[((int64_t)b * H + c) * 2 + 0];
+                    pq_[k] = part[((int64_t)b * H + c) * 2 + 1];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (b0 + k * G < nparts) {
+                        s += ps[k];
+                        q += pq_[k];
+                    }
+            }
+        __syncthreads();
+        if (g < G) gsum[(g * H + c) * 2 + 0] = s, gsum[(g * H + c) * 2 + 1] = q;
+        __syncthreads();
+    }
     for (int c = tid; c < H; c += 256) {
         double s = 0.0, q = 0.0;
+        if (G > 1) {
+            for (int g = 0; g < G; ++g) s += gsum[(g * H + c) * 2 + 0], q += gsum[(g * H + c) * 2 + 1];
+        } else
         for (int b0 = 0; b0 < nparts; b0 += 8) {  // eight partial pairs in flight, summed in order
             double ps[8], pq_[8];
 #pragma unroll
@@ -183,13 +214,17 @@ int bn_blocks(int64_t n, int64_t* rows_per_block) {
     return (int)blocks;
 }
 
+// pre_parts > 0: `part` already holds that many [H][2] partial rows of sum / sum of squares over x's rows (left by the
+// fused kernel of the half-step that produced x): no moment pass
 int launch_bn_normalize(const GnfFlow* flow, const GnfBatchNorm* bn, float* x, int64_t ld, int64_t n, int32_t H,
-                        double* part, double* logdet_slot, hipStream_t st) {
+                        double* part, double* logdet_slot, hipStream_t st, int pre_parts) {
     if (n == 0) return GNF_OK;
     int64_t rpb;
-    int blocks = bn_blocks(n, &rpb);
-    hipLaunchKernelGGL(k_bn_stats, dim3(blocks), dim3(256), 0, st, x, ld, n, H, rpb, part);
-    GNF_LAUNCH_CHECK("k_bn_stats");
+    int blocks = pre_parts > 0 ? pre_parts : bn_blocks(n, &rpb);
+    if (pre_parts <= 0) {
+        hipLaunchKernelGGL(k_bn_stats, dim3(blocks), dim3(256), 0, st, x, ld, n, H, rpb, part);
+        GNF_LAUNCH_CHECK("k_bn_stats");
+    }
     const double* n_moments = nullptr;
     if (flow->bn_allreduce) {  // the moments of the whole batch, not of this rank's shard
         const int rc = bn_sync_exchange(flow, part, blocks, n, H, nullptr, st);

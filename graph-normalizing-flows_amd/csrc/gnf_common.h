@@ -63,6 +63,10 @@ struct HalfStep {
     // workgroup; *n_sq = how many the launch wrote (0: this path does not - the caller runs k_gauss over z instead)
     double* sq_partials = nullptr;
     int32_t* n_sq = nullptr;
+    // forward with a batch-norm bijector in front of the NEXT half-step: room for one [H][2] fp64 row of column sums /
+    // sums of squares of the updated half per workgroup (that bijector's batch moments); *n_bn = rows written (0: none)
+    double* bn_part = nullptr;
+    int32_t* n_bn = nullptr;
 };
 
 // MLP-row stash (GnfFlow.mlp_stash, ABI v8): the rows of a half-step the backward walk would otherwise recompute
@@ -157,7 +161,7 @@ int validate_bn(const GnfBatchNorm* bn, int direction, const char* what, int q);
 int bn_sync_exchange(const GnfFlow* flow, const double* part, int nparts, int64_t n, int32_t H, double* local_copy,
                      hipStream_t st);
 int launch_bn_normalize(const GnfFlow* flow, const GnfBatchNorm* bn, float* x, int64_t ld, int64_t n, int32_t H,
-                        double* part, double* logdet_slot, hipStream_t st);
+                        double* part, double* logdet_slot, hipStream_t st, int pre_parts = 0);
 int launch_bn_denormalize(const GnfBatchNorm* bn, float* z, int64_t ld, int64_t n, int32_t H, hipStream_t st);
 
 int validate_mlp(const GnfMlp* m, const char* what);

@@ -121,6 +121,8 @@ struct FusedArgs {
     double* partials;
     double* sq_partials;                 // NETS = 2, forward: also sum(x_upd_new^2) per workgroup (the Gaussian term of the
                                          // flow's last two half-steps, whose outputs are z), or NULL
+    double* bn_part;                     // NETS = 2, forward: [tile][H][2] column sums / sums of squares of the updated rows
+                                         // (batch moments of the bijector in front of the next half-step), or NULL
     float* st_out[2];                    // NETS = 1: global [N, H] scratch for s (0) and t (1)
     const float* h0[2];                  // precomputed layer-0 input per net ([N, in0], attention GNNs) or NULL
     const float* wp[2][GNF_MAX_LAYERS];  // [net][layer] packed weights
@@ -453,9 +455,11 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
         const float* s_lds = buf(0, pp);
         const float* t_lds = buf(1, pp);
         double local = 0.0, local2 = 0.0;
+        float* xn_lds = buf(0, pp ^ 1);  // (free by now) the updated rows, for the column sums below
         for (int idx = tid; idx < TM * H; idx += kFusedThreads) {
             const int rl = idx / H, f = idx - rl * H;
             const int r = row0 + rl;
+            if (a.bn_part) xn_lds[rl * LS + f] = 0.f;
             if (r < a.n_nodes) {
                 float sv = s_lds[rl * LS + f], tv = t_lds[rl * LS + f];
                 if (a.residual) {
@@ -468,6 +472,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
                 a.x_upd[(int64_t)r * a.ld + f] = xn;
                 local += (double)sv;
                 local2 += (double)xn * (double)xn;
+                if (a.bn_part) xn_lds[rl * LS + f] = xn;
                 if constexpr (STASH) {  // (what the coupling used: a residual block's x_cond is already in)
                     a.stash_st[0][(int64_t)r * H + f] = sv;
                     a.stash_st[1][(int64_t)r * H + f] = tv;
@@ -481,6 +486,18 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
             double tot = 0.0;
             for (int w = 0; w < kFusedThreads / 64; ++w) tot += red[w];
             a.partials[tile] = tot;
+        }
+        if (a.bn_part) {  // (workgroup-uniform) column sums over the tile's rows, fixed order
+            __syncthreads();
+            for (int i = tid; i < 2 * H; i += kFusedThreads) {
+                const int f = i >> 1, which = i & 1;
+                double acc = 0.0;
+                for (int rl = 0; rl < TM; ++rl) {
+                    const double v = (double)xn_lds[rl * LS + f];
+                    acc += which ? v * v : v;
+                }
+                a.bn_part[((int64_t)tile * H + f) * 2 + which] = acc;
+            }
         }
         if (a.sq_partials) {  // (workgroup-uniform) the same fixed-order reduction for sum(x_new^2)
             for (int off = 32; off > 0; off >>= 1) local2 += __shfl_down(local2, off, 64);
@@ -635,6 +652,7 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
     a.cond_copy = hs.cond_copy;
     a.partials = hs.partials;
     a.sq_partials = NETS == 2 ? hs.sq_partials : nullptr;
+    a.bn_part = NETS == 2 ? hs.bn_part : nullptr;
     // NETS = 1 scratch: s [N,H] | t [N,H] at the head of the float scratch
     a.st_out[0] = scratch;
     a.st_out[1] = scratch + hs.n_nodes * hs.H;
@@ -706,6 +724,7 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
         if (rc) return rc;
         *hs.n_partials = (int32_t)tiles;
         if (hs.n_sq) *hs.n_sq = a.sq_partials ? (int32_t)tiles : 0;
+        if (hs.n_bn) *hs.n_bn = a.bn_part ? (int32_t)tiles : 0;
         return GNF_OK;
     }
     if (NETS == 2) {
@@ -713,6 +732,7 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
         if (rc) return rc;
         *hs.n_partials = (int32_t)tiles;
         if (hs.n_sq) *hs.n_sq = a.sq_partials ? (int32_t)tiles : 0;
+        if (hs.n_bn) *hs.n_bn = a.bn_part ? (int32_t)tiles : 0;
         return GNF_OK;
     }
     if (hs.x_upd_src || hs.cond_copy) {
