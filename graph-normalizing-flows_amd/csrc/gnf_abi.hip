@@ -138,7 +138,7 @@ WorkspacePlan plan_workspace(int64_t n_nodes, int32_t H, const GnfMlp* net, int3
     p.partial_stride = partials_per_halfstep(n_nodes);
     p.n_halfsteps = n_halfsteps;
     p.bn_offset = (size_t)(n_halfsteps * p.partial_stride + kMaxGaussBlocks);
-    size_t pb = (p.bn_offset + (size_t)kBnBlocksMax * (size_t)H * 2) * sizeof(double);
+    size_t pb = (p.bn_offset + (size_t)kBnPartRowsMax * (size_t)H * 2) * sizeof(double);
     p.partial_bytes = (pb + 255) / 256 * 256;
     int lmax = 1;
     if (net)
@@ -517,7 +517,7 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
                     mark_attn(hs, half, i);
                     if (mstash) hs.mlp_stash = mstash + (size_t)(2 * i + half) * mstash_slot;
                     // the half this half-step updates is what the NEXT bijector normalises: its column sums ride along
-                    if (flow->bns && !(i == T - 1 && half == 1) && (n + 15) / 16 <= kBnBlocksMax) {
+                    if (flow->bns && !(i == T - 1 && half == 1) && (n + 15) / 16 <= kBnPartRowsMax) {
                         hs.bn_part = partials + p.bn_offset;
                         hs.n_bn = &bn_pre;
                     }

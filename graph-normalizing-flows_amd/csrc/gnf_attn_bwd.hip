@@ -688,6 +688,13 @@ struct AttnDxArgs {
     float* g;
     int64_t ldg;
     int32_t n, H, nq, v, in0, concat;
+    // batch-norm bijector in front of the half-step (NULL bn_part: none): this kernel's rows of g are final, so it also
+    // leaves sum G and sum G x^ (x^ = (y - beta) / gamma) over its rows, one [H][2] fp64 row per workgroup
+    const float* bn_y;
+    int64_t bn_ld;
+    const float* bn_gamma;
+    const float* bn_beta;
+    double* bn_part;
 };
 
 static constexpr int kDxRows = 8;  // rows per workgroup
@@ -737,6 +744,29 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dx(const AttnDxArgs a) {
             a.g[r * a.ldg + f] += s;
         }
     }
+    if (a.bn_part) {  // (the same thread wrote g[r, f] in both passes: it re-reads its own final value)
+        float* bg = dl + kDxRows * P;   // [kDxRows][H] G | [kDxRows][H] G x^
+        float* bx = bg + kDxRows * H;
+        for (int i = tid; i < kDxRows * H; i += 256) {
+            const int rl = i / H, f = i - rl * H;
+            float gv = 0.f, gx = 0.f;
+            if (rl < rows) {
+                const int64_t r = row0 + rl;
+                gv = a.g[r * a.ldg + f];
+                gx = gv * ((a.bn_y[r * a.bn_ld + f] - a.bn_beta[f]) / a.bn_gamma[f]);
+            }
+            bg[i] = gv;
+            bx[i] = gx;
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * H; i += 256) {
+            const int f = i >> 1, which = i & 1;
+            const float* src = which ? bx : bg;
+            double acc = 0.0;
+            for (int rl = 0; rl < kDxRows; ++rl) acc += (double)src[rl * H + f];
+            a.bn_part[((int64_t)blockIdx.x * H + f) * 2 + which] = acc;
+        }
+    }
 }
 
 // at[2]: the two attention blocks; qkv: [2][N, P] forward projections (launch_attn_front's scratch);
@@ -745,7 +775,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dx(const AttnDxArgs a) {
 int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t in0, const int32_t* rowptr,
                          const int32_t* col, const int32_t* rowptr_t, const int32_t* col_t, const float* const* qkv,
                          const float* const* dh0, const float* const* gst, float* const* dqkv, float* const* agg,
-                         float* const* dagg, float* const* stats, float* g_cond, int64_t ldg, hipStream_t st, int64_t n_edges) {
+                         float* const* dagg, float* const* stats, float* g_cond, int64_t ldg, hipStream_t st, int64_t n_edges,
+                         const AttnBnFold* bn) {
     if (n == 0) return GNF_OK;
     const GnfAttn* a0 = at[0];
     AttnBwdArgs a;
@@ -780,7 +811,7 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
     const size_t fixed = attn_bwd_fixed_bytes(nq, NV, a.nh);
     const int cap_r = (int)((kWinBudget - fixed) / ((size_t)(nq + a.v + 1) * sizeof(float)));   // window rows, receiver pass
     const int cap_s = (int)((kWinBudget - fixed) / ((size_t)(nq + NV + 1) * sizeof(float)));    // window rows, sender pass
-    const size_t lds_x = ((size_t)H * (P + 1) + (size_t)kDxRows * P) * sizeof(float);
+    const size_t lds_x = ((size_t)H * (P + 1) + (size_t)kDxRows * P + (size_t)2 * kDxRows * H) * sizeof(float);
     if (lds_x > 160 * 1024 || cap_s < 1) {
         set_error("attention backward: head geometry needs more LDS than a CU has");
         return GNF_EUNSUPPORTED;
@@ -868,7 +899,14 @@ dx_pass:
     d.v = a.v;
     d.in0 = in0;
     d.concat = a.concat;
-    hipLaunchKernelGGL(k_attn_bwd_dx, dim3((unsigned)((n + kDxRows - 1) / kDxRows)), dim3(256), lds_x, st, d);
+    const int64_t dx_blocks = (n + kDxRows - 1) / kDxRows;
+    d.bn_y = nullptr, d.bn_ld = 0, d.bn_gamma = d.bn_beta = nullptr, d.bn_part = nullptr;
+    if (bn && bn->n_parts) *bn->n_parts = 0;
+    if (bn && bn->part && dx_blocks <= kBnPartRowsMax) {
+        d.bn_y = bn->y, d.bn_ld = bn->ld, d.bn_gamma = bn->gamma, d.bn_beta = bn->beta, d.bn_part = bn->part;
+        if (bn->n_parts) *bn->n_parts = (int32_t)dx_blocks;
+    }
+    hipLaunchKernelGGL(k_attn_bwd_dx, dim3((unsigned)dx_blocks), dim3(256), lds_x, st, d);
     GNF_LAUNCH_CHECK("k_attn_bwd_dx");
     return GNF_OK;
 }

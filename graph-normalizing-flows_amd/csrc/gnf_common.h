@@ -88,6 +88,7 @@ size_t attn_stash_slot_floats(const GnfFlow* flow, int64_t n_nodes);
 static constexpr int kFinalizeBlock = 256;
 static constexpr int kMaxGaussBlocks = 1024;
 static constexpr int kBnBlocksMax = 256;  // workgroups of the batch-norm moment pass
+static constexpr int kBnPartRowsMax = 1024;  // [H][2] fp64 partial rows the moment buffers hold (a producer kernel may leave one per workgroup)
 
 inline int64_t coupling_blocks_max(int64_t n_nodes) { return (n_nodes + 15) / 16 + 1; }
 // per half-step: the coupling partials + one slot for the batch-norm log-det term
@@ -142,12 +143,25 @@ int launch_half_bwd_fused(const int32_t* rowptr, const int32_t* col, int64_t n, 
                           float* g_upd, int64_t ldg, int32_t H, float* h0_out, const float* const* h0_in, float* const* hin,
                           int64_t ldh, float* const* dP, int64_t lddp, float* const* gst, float* const* dh0,
                           hipStream_t st);
+// a batch-norm bijector sits in front of this half-step: the last kernel of the attention backward writes the final
+// dL/dy rows of the conditioning half, so it also leaves the bijector's backward moments (sum G, sum G x^ per column)
+// as one [H][2] fp64 row per workgroup in `part`; *n_parts = rows written
+struct AttnBnFold {
+    const float* y;      // the normalised conditioning half [n, H], leading dimension ld
+    int64_t ld;
+    const float* gamma;
+    const float* beta;
+    double* part;
+    int32_t* n_parts;
+};
 // attention front-end, backwards (gnf_attn_bwd.hip)
 int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t in0, const int32_t* rowptr,
                          const int32_t* col, const int32_t* rowptr_t, const int32_t* col_t, const float* const* qkv,
                          const float* const* dh0, const float* const* gst, float* const* dqkv, float* const* agg,
                          float* const* dagg, float* const* stats, float* g_cond, int64_t ldg, hipStream_t st,
-                         int64_t n_edges = 0);  // n_edges: 0 = unknown (picks between tile sizes by mean degree)
+                         int64_t n_edges = 0,   // 0 = unknown (picks between tile sizes by mean degree)
+                         const AttnBnFold* bn = nullptr);
+
 
 // thin y = act(x W + b) through the split-K generic GEMM (gnf_train.hip); 1 = not thin, the caller runs its own kernel
 int launch_linear_splitk(const float* const* x, int64_t ldx, const float* const* W, const float* const* b, float* const* y,

@@ -1295,8 +1295,37 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(float* __restrict__ y, int
     float* ssig = ss + 4 * H;
     float* smu = ss + 5 * H;
     const int tid = threadIdx.x;
+    // many partial rows (one per workgroup of the kernel that left them): the 256 threads share the walk, thread (g, c)
+    // sums rows g, g + G, ..; the G group sums are then added in order (as k_bn_apply does, gnf_bn.hip)
+    __shared__ double gsum2[512];
+    const int G = (nparts > 32 && H <= 128) ? 256 / H : 1;
+    if (G > 1) {
+        const int c = tid % H, g = tid / H;
+        double s = 0.0, q = 0.0;
+        if (g < G)
+            for (int b0 = g; b0 < nparts; b0 += 8 * G) {
+                double ps[8], pq_[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int b = b0 + k * G < nparts ? b0 + k * G : g;
+                    ps[k] = part[((int64_t)b * H + c) * 2 + 0];
+                    pq_[k] = part[((int64_t)b * H + c) * 2 + 1];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (b0 + k * G < nparts) {
+                        s += ps[k];
+                        q += pq_[k];
+                    }
+            }
+        if (g < G) gsum2[(g * H + c) * 2 + 0] = s, gsum2[(g * H + c) * 2 + 1] = q;
+        __syncthreads();
+    }
     for (int c = tid; c < H; c += 256) {
         double s = 0.0, q = 0.0;
+        if (G > 1) {
+            for (int g = 0; g < G; ++g) s += gsum2[(g * H + c) * 2 + 0], q += gsum2[(g * H + c) * 2 + 1];
+        } else
         for (int b0 = 0; b0 < nparts; b0 += 8) {  // eight partial pairs in flight, summed in order
             double ps[8], pq_[8];
 #pragma unroll
@@ -1346,8 +1375,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(float* __restrict__ y, int
     }
 }
 
+// pre_parts > 0: `part` already holds that many [H][2] partial rows (sum G, sum G x^) left by the kernel that wrote the
+// final gy rows (k_attn_bwd_dx): no moment pass
 static int launch_bn_backward(const GnfFlow* flow, const GnfBatchNorm* bn, const GnfBatchNorm* gbn, float* y, int64_t ld,
-                              float* gy, int64_t ldg, int64_t n, int32_t H, double* part, hipStream_t st) {
+                              float* gy, int64_t ldg, int64_t n, int32_t H, double* part, hipStream_t st, int pre_parts = 0) {
     int64_t rpb = (n + 15) / 16;  // about sixteen chunks of at least 32 rows (see bn_blocks in gnf_bn.hip)
     if (rpb < 32) rpb = 32;
     int64_t blocks = (n + rpb - 1) / rpb;
@@ -1355,12 +1386,16 @@ static int launch_bn_backward(const GnfFlow* flow, const GnfBatchNorm* bn, const
         rpb = (n + kBnBlocksMax - 1) / kBnBlocksMax;
         blocks = (n + rpb - 1) / rpb;
     }
-    hipLaunchKernelGGL(k_bn_bwd_stats, dim3((unsigned)blocks), dim3(256), 0, st, y, ld, gy, ldg, n, H, rpb, bn->gamma,
-                       bn->beta, part);
-    GNF_LAUNCH_CHECK("k_bn_bwd_stats");
+    if (pre_parts > 0) {
+        blocks = pre_parts;
+    } else {
+        hipLaunchKernelGGL(k_bn_bwd_stats, dim3((unsigned)blocks), dim3(256), 0, st, y, ld, gy, ldg, n, H, rpb, bn->gamma,
+                           bn->beta, part);
+        GNF_LAUNCH_CHECK("k_bn_bwd_stats");
+    }
     const double *gsum = nullptr, *n_moments = nullptr;
     if (flow->bn_allreduce) {  // sum G, sum G x^ over the whole batch; this rank's own sums stay behind the partials
-        double* local = part + (size_t)kBnBlocksMax * H * 2;
+        double* local = part + (size_t)kBnPartRowsMax * H * 2;
         const int rc = bn_sync_exchange(flow, part, (int)blocks, n, H, local, st);
         if (rc) return rc;
         part = local;
@@ -1460,7 +1495,7 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net, int n_sets
     size_t off = 0;
     p.g = off, off += al64((size_t)n * D);
     p.invdeg = off, off += al64((size_t)n);
-    p.bnpart = off, off += al64(((size_t)kBnBlocksMax + 1) * (size_t)p.H * 4);  // fp64 pairs of the batch-norm backward (+ one row: this rank's sums under cross-rank moments)
+    p.bnpart = off, off += al64(((size_t)kBnPartRowsMax + 1) * (size_t)p.H * 4);  // fp64 pairs of the batch-norm backward (+ one row: this rank's sums under cross-rank moments)
     p.st = off, off += 2 * al64((size_t)n * p.H);
     p.wslab = off, off += al64((size_t)chunks * p.wsum);
     p.bslab = off, off += al64((size_t)chunks * p.osum);
@@ -2536,7 +2571,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     bool used[2] = {false, false};  // weight sharing: the T uses of a net accumulate
     // the attention front-end backwards: dagg = dnew Wo^T ([nodes, C] x [C, heads*v]; Wo is [heads*v, C]: rows = output
     // columns), then the edge kernels; dL/dx_cond accumulates into g_cond
-    auto attention_backward = [&](const GnfMlp* const* nets_, const BwdOperands& o_, float* g_cond) -> int {
+    auto attention_backward = [&](const GnfMlp* const* nets_, const BwdOperands& o_, float* g_cond, const AttnBnFold* bnf = nullptr) -> int {
         const GnfAttn* at[2] = {nets_[0]->attn, nets_[1]->attn};
         const int off = at[0]->concat ? D / 2 : 0;
         GemmJob jobs[2];
@@ -2548,8 +2583,9 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
         int rc_ = launch_gemm<OPND_KC, OPND_KC, EPI_MASK>(jobs, 2, sh, st);
         if (rc_) return rc_;
         return launch_attn_backward(at, n, D / 2, p.in0, csr->rowptr, csr->col, csr_t->rowptr, csr_t->col, o_.qkv, o_.dh0, o_.gst,
-                                    o_.dqkv, o_.agg, o_.dagg, o_.stats, g_cond, D, st, csr->n_edges);
+                                    o_.dqkv, o_.agg, o_.dagg, o_.stats, g_cond, D, st, csr->n_edges, bnf);
     };
+    int32_t bn_pre = 0;  // batch-norm backward moments left by the attention backward's last kernel (partial rows)
     DwLaunch pend[2];
     bool pend_ok[2] = {false, false};
     bool have_fold = false;  // the previous half-step left its dL/dh0 rows for this one's prologue to scatter
@@ -2656,7 +2692,11 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 }
                 have_fold = !attn && !flow->bns && !last && !opt(OPT_BWD_NO_FOLD);
                 if (attn) {
-                    rc = attention_backward(nets, o, g + co);
+                    const GnfBatchNorm* bq = flow->bns ? &flow->bns[half * T + i] : nullptr;
+                    const AttnBnFold bnf{z + co, ld, bq ? bq->gamma : nullptr, bq ? bq->beta : nullptr,
+                                         reinterpret_cast<double*>(wsf + p.bnpart), &bn_pre};
+                    bn_pre = 0;
+                    rc = attention_backward(nets, o, g + co, bq ? &bnf : nullptr);
                     if (rc) return rc;
                 } else if (have_fold) {
                     fold_dh[0] = o.dh0[0], fold_dh[1] = o.dh0[1];
@@ -2667,7 +2707,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 ++step;
                 if (flow->bns) {
                     rc = launch_bn_backward(flow, &flow->bns[half * T + i], &grad->bns[half * T + i], z + co, ld, g + co, D, n, H,
-                                            reinterpret_cast<double*>(wsf + p.bnpart), st);
+                                            reinterpret_cast<double*>(wsf + p.bnpart), st, attn ? bn_pre : 0);
                     if (rc) return rc;
                 }
                 continue;
@@ -2709,7 +2749,11 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             }
             // ---- dL/dx_cond: on the critical path (the next half-step's coupling reads g), so it goes first -----
             if (attn) {
-                rc = attention_backward(nets, o, g + co);
+                const GnfBatchNorm* bq = flow->bns ? &flow->bns[half * T + i] : nullptr;
+                const AttnBnFold bnf{z + co, ld, bq ? bq->gamma : nullptr, bq ? bq->beta : nullptr,
+                                     reinterpret_cast<double*>(wsf + p.bnpart), &bn_pre};
+                bn_pre = 0;
+                rc = attention_backward(nets, o, g + co, bq ? &bnf : nullptr);
             } else {
                 rc = launch_aggregate_bwd(p, csr_t, flow->gnn, wsf + p.invdeg, o.dh0[0], o.dh0[1], g + co, D, st);
             }
@@ -2744,7 +2788,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             if (rc) return rc;
             if (flow->bns) {  // the bijector sat in front of this half-step (gnn.py:310-313, 325-328)
                 rc = launch_bn_backward(flow, &flow->bns[half * T + i], &grad->bns[half * T + i], z + co, ld, g + co, D, n, H,
-                                        reinterpret_cast<double*>(wsf + p.bnpart), st);
+                                        reinterpret_cast<double*>(wsf + p.bnpart), st, attn ? bn_pre : 0);
                 if (rc) return rc;
             }
         }
