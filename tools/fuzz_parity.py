@@ -54,6 +54,8 @@ def random_case(rng):
         attn = dict(num_heads=int(rng.integers(1, 5)), kq_dim=int(rng.integers(1, 8)), v_dim=int(rng.integers(1, 8)),
                     out_dim=int(rng.integers(1, 12)), concat=bool(rng.integers(0, 2)),
                     kq_dim_division=bool(rng.integers(0, 2)), residual=False)
+        if rng.random() < 0.3:          # --attn_layer_norm (gnn.py:550-552), with or without the residual
+            attn.update(layer_norm=True, residual=bool(rng.integers(0, 2)))
         hp.update(attn=attn, activation="relu", agg="mean", combine="agg", epsilon=0.0)
     return hp, attn, rng.random() < 0.4
 
