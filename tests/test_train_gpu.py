@@ -390,6 +390,32 @@ def test_layer_norm_parameters_train(community_medium):
     assert np.abs(blk.attn_params["ln_beta"].cpu().numpy()).max() > 0.0
 
 
+@pytest.mark.parametrize("rows", [16, 32, 64])
+def test_attention_backward_row_tile_sizes(community_medium, rows):
+    """k_attn_bwd_recv_rows / _send_rows exist for 64-, 32- and 16-row tiles (the library picks by mean degree; the
+    developer option attn_bwd_rows forces one): the same gradients through each."""
+    from gnf_amd import _abi
+    from gnf_amd.train import GRevNetTrainer
+    attn = dict(num_heads=4, kq_dim=6, v_dim=5, out_dim=12, concat=True, kq_dim_division=True, residual=False)
+    hp = dict(D=12, latent=32, K=2, T=2, agg="mean", combine="agg", epsilon=0.0, activation="relu",
+              weight_sharing=False, attn=attn)
+    nn, ne, s, r = _batch(community_medium, [3, 50, 77, 12, 100])
+    n = int(nn.sum())
+    x = np.random.default_rng(8).standard_normal((n, 12)).astype(np.float32)
+    p = O.make_attn_grevnet_params(13, 6, 32, 2, 2, final_scale=0.3, **attn)
+    ref = O.loss_and_grads(s, r, n, x, p, 2, activation="relu")
+    _abi.set_option("attn_bwd_rows", rows)
+    try:
+        tr = GRevNetTrainer(make_product_grevnet(hp, p))
+        out = tr.loss_and_grads(graph_from_arrays(nn, ne, s, r, x, DEV))
+        torch.cuda.synchronize()
+    finally:
+        _abi.set_option("attn_bwd_rows", 0)
+    assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
+    for (name, a), (_, b) in zip(_flat_attn(tr.named_gradients(), False), _flat_attn(ref["grads"], False)):
+        assert np.abs(a - b).max() <= 5e-4 * np.abs(b).max() + 1e-5, name
+
+
 def test_attention_gradients_high_degree_rows():
     """Complete topology with a 70-node graph: rows with more than 64 in / out edges take the kernels' general
     (edge-tiled) path, the 9-node graph next to it the LDS-resident one."""
