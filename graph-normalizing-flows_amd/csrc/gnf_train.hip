@@ -2027,7 +2027,7 @@ bool mlp_stash_supported(const GnfFlow* flow, int64_t n, int32_t H) {
     int64_t tiles;
     size_t lds;
     fused_bwd_launch_shape(&flow->s_nets[0], n, &tiles, &lds);
-    return tiles == (n + 15) / 16 && tiles <= kMergedMaxTiles;  // 16-node backward tiles (message-passing nets: the merged launch)
+    return tiles == (n + 15) / 16 && tiles <= 256;  // 16-node tiles in both directions (one per CU at most)
 }
 
 // job list of one half-step: the K layers of both nets, then the four attention matrices of both nets

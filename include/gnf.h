@@ -168,12 +168,12 @@ typedef struct GnfFlow {
      * forward produced - reads them instead of recomputing.  gnf_attn_stash_bytes() sizes it (2T slots). */
     float* attn_stash;
     size_t attn_stash_bytes;
-    /* ABI v8: optional stash of the MLP rows (batches of up to 192 16-node tiles; NULL = none).  Same trade for the
+    /* ABI v8: optional stash of the MLP rows (batches of up to 256 16-node tiles; NULL = none).  Same trade for the
      * MLPs: gnf_grevnet_f32 / gnf_grevnet_from_f32(GNF_FORWARD) then leaves every half-step's layer-0 input, hidden
      * activations, their sign bits and s, t of both nets in mlp_stash (what TensorFlow keeps for tf.gradients anyway), and
      * gnf_grevnet_backward_f32 - called next with the SAME flow, graph and the z that forward produced - skips the
      * recompute half of its fused kernel and feeds the weight-gradient GEMMs from the stash.  gnf_mlp_stash_bytes()
-     * sizes it and returns 0 where the library would not use one (batches of more than 192 16-node tiles, layers too
+     * sizes it and returns 0 where the library would not use one (batches of more than 256 16-node tiles, layers too
      * wide for the fused kernels, attention blocks that end in LayerNorm): pass NULL then. */
     float* mlp_stash;
     size_t mlp_stash_bytes;

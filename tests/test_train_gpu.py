@@ -155,7 +155,7 @@ def test_mlp_row_stash_matches_the_recomputing_walk(community_medium, flavour):
 
 
 def test_mlp_row_stash_is_not_offered_where_it_would_not_be_used(community_medium, grid_small):
-    """gnf_mlp_stash_bytes: 0 for batches of more than 192 16-node tiles and for blocks that end in snt.LayerNorm (their
+    """gnf_mlp_stash_bytes: 0 for batches of more than 256 16-node tiles and for blocks that end in snt.LayerNorm (their
     half-steps run one net per workgroup); attention nets without it do get one."""
     import ctypes as C
     from gnf_amd import _abi
@@ -171,8 +171,8 @@ def test_mlp_row_stash_is_not_offered_where_it_would_not_be_used(community_mediu
     net = make_product_grevnet(hp, O.make_grevnet_params(6, 8, 64, 3, 2))
     net(graph_from_arrays(nn, ne, s, r, np.zeros((int(nn.sum()), 16), np.float32), DEV))
     flow = net._flow(8, torch.device(DEV))
-    assert lib.gnf_mlp_stash_bytes(192 * 16, 16, C.byref(flow)) > 0
-    assert lib.gnf_mlp_stash_bytes(192 * 16 + 1, 16, C.byref(flow)) == 0
+    assert lib.gnf_mlp_stash_bytes(256 * 16, 16, C.byref(flow)) > 0
+    assert lib.gnf_mlp_stash_bytes(256 * 16 + 1, 16, C.byref(flow)) == 0
 
 
 def test_isolated_nodes_and_directed_edges():
