@@ -431,22 +431,24 @@ extern "C" int gnf_debug_read_attn_trace(unsigned long long* out) {
 #define GNF_ATRACE(i)
 #endif
 
-template <int KQM, int VDM>
+// ROWS: receiver rows per workgroup (lanes ROWS .. 63 of every head's wave idle): 64, or 32 while 64-row tiles would be
+// fewer workgroups than the chip has CUs (the drivers' default batch: 3200 nodes = 50 tiles per net)
+template <int KQM, int VDM, int ROWS = 64>
 __global__ __launch_bounds__(512) void k_attn_fwd_rows(const AttnArgs a, int win_cap) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     GNF_ATRACE(0);
     const int net = blockIdx.y;
     const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd, C = a.C, H = a.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * kRowsTile;
+    const int row0 = blockIdx.x * ROWS;
     int* s_rp = reinterpret_cast<int*>(sm);
-    int* s_hdr = s_rp + kRowsTile + 1;
+    int* s_hdr = s_rp + ROWS + 1;
     float* wo = reinterpret_cast<float*>(s_hdr + 3);        // [NV][C]
     float* agg_s = wo + NV * C;                            // [64][NV + 1]
-    int* s_col = reinterpret_cast<int*>(agg_s + kRowsTile * (NV + 1));  // [kRowsColCap]
+    int* s_col = reinterpret_cast<int*>(agg_s + ROWS * (NV + 1));  // [kRowsColCap]
     float* win = reinterpret_cast<float*>(s_col + kRowsColCap);          // [cap][WS]
     const int WS = (nq + vd + 2) & ~1;  // even: rows stay 8-byte aligned
-    if (tid <= kRowsTile) {
+    if (tid <= ROWS) {
         const int r = row0 + tid;
         s_rp[tid] = a.rowptr[r < a.n_nodes ? r : a.n_nodes];
     }
@@ -469,19 +471,19 @@ __global__ __launch_bounds__(512) void k_attn_fwd_rows(const AttnArgs a, int win
     __syncthreads();
     GNF_ATRACE(1);
     const float* qkv = a.qkv[net];
-    const int lo = stage_window(a.col, s_rp, kRowsTile, s_hdr, win_cap, tid, 512, [&](int lo_, int cnt) {
+    const int lo = stage_window(a.col, s_rp, ROWS, s_hdr, win_cap, tid, 512, [&](int lo_, int cnt) {
         window_copy(win, WS, cnt, nq + vd, tid, 512, [&](int rr, int c) {
             return qkv[(int64_t)(lo_ + rr) * P + (c < nq ? c : nq + c)];   // q at [0, nq), v at [2 nq, 2 nq + vd)
         });
     });
     GNF_ATRACE(2);
-    const bool cols_in_lds = stage_cols(a.col, s_rp, kRowsTile, s_col, kRowsColCap, tid, 512);
+    const bool cols_in_lds = stage_cols(a.col, s_rp, ROWS, s_col, kRowsColCap, tid, 512);
     __syncthreads();
     GNF_ATRACE(3);
     const int* cols = cols_in_lds ? s_col : a.col;
     const int col_base = cols_in_lds ? s_rp[0] : 0;
     const int r = row0 + lane;
-    if (wave < nh && r < a.n_nodes) {
+    if (wave < nh && lane < ROWS && r < a.n_nodes) {
         // 8-byte reads when every row segment is even-sized and 8-byte aligned (window base / qkv base and row stride)
         const bool even = ((kq | vd | nq) & 1) == 0;
         if (lo >= 0)
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(512) void k_attn_fwd_rows(const AttnArgs a, int win
     // output projection new = agg Wo (Wo broadcast from LDS, agg row per lane) and h0 = [x || new] | new
     float* h0 = a.h0[net];
     const int off = a.concat ? H : 0;
-    if (r < a.n_nodes) {
+    if (lane < ROWS && r < a.n_nodes) {
         // wave w takes the contiguous columns [w * cw, (w + 1) * cw): per agg element one LDS read of it and a run of
         // consecutive Wo values (broadcast), instead of two LDS reads per multiply-add
         const float* ar = agg_s + lane * (NV + 1);
@@ -608,15 +610,27 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
         if (fixed + 64 * (size_t)(nq + a.v + 2) * sizeof(float) <= (size_t)kRowsLdsBudget) {
             const int cap = (int)((kRowsLdsBudget - fixed) / ((size_t)(nq + a.v + 2) * sizeof(float)));
             GNF_ONCE_PER_DEVICE(
-                GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_fwd_rows<10, 10>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_fwd_rows<32, 32>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
-            const dim3 rgrid((unsigned)((n + kRowsTile - 1) / kRowsTile), nets);
-            if (a.kq <= 10 && a.v <= 10)
-                hipLaunchKernelGGL((k_attn_fwd_rows<10, 10>), rgrid, dim3(512), (size_t)kRowsLdsBudget, st, a, cap);
-            else
-                hipLaunchKernelGGL((k_attn_fwd_rows<32, 32>), rgrid, dim3(512), (size_t)kRowsLdsBudget, st, a, cap);
+                const void* ks[4] = {reinterpret_cast<const void*>(k_attn_fwd_rows<10, 10, 64>),
+                                     reinterpret_cast<const void*>(k_attn_fwd_rows<32, 32, 64>),
+                                     reinterpret_cast<const void*>(k_attn_fwd_rows<10, 10, 32>),
+                                     reinterpret_cast<const void*>(k_attn_fwd_rows<32, 32, 32>)};
+                for (const void* k : ks) GNF_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+            // (the LDS plan above is the 64-row one: a 32-row tile needs less)
+            const bool half_tiles = (int64_t)nets * ((n + 63) / 64) < 256;
+            const int rows = half_tiles ? 32 : 64;
+            const dim3 rgrid((unsigned)((n + rows - 1) / rows), nets);
+            const bool small = a.kq <= 10 && a.v <= 10;
+            if (half_tiles) {
+                if (small)
+                    hipLaunchKernelGGL((k_attn_fwd_rows<10, 10, 32>), rgrid, dim3(512), (size_t)kRowsLdsBudget, st, a, cap);
+                else
+                    hipLaunchKernelGGL((k_attn_fwd_rows<32, 32, 32>), rgrid, dim3(512), (size_t)kRowsLdsBudget, st, a, cap);
+            } else {
+                if (small)
+                    hipLaunchKernelGGL((k_attn_fwd_rows<10, 10, 64>), rgrid, dim3(512), (size_t)kRowsLdsBudget, st, a, cap);
+                else
+                    hipLaunchKernelGGL((k_attn_fwd_rows<32, 32, 64>), rgrid, dim3(512), (size_t)kRowsLdsBudget, st, a, cap);
+            }
             GNF_LAUNCH_CHECK("k_attn_fwd_rows");
             return GNF_OK;
         }

@@ -841,7 +841,9 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
                 for (const void* k : ks) GNF_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
             // sparse batches (mean degree below 24): 32-row tiles - default-flags training step on the config-2 batch 4.44
             // (64) / 4.24 (32) / 4.74 ms (16: the window staging per workgroup takes over); option attn_bwd_rows forces one
-            int rows = (n_edges > 0 && n_edges < 24 * n) ? 32 : 64;
+            // ... and on any batch whose 64-row tiles would be fewer workgroups than the chip has CUs (the drivers'
+            // default batch, 32 complete 100-node graphs: 10.25 -> 9.9 ms per iteration of examples/run_grevnet.py)
+            int rows = ((n_edges > 0 && n_edges < 24 * n) || 2 * ((n + 63) / 64) < 256) ? 32 : 64;
             if (const int64_t force = opt(OPT_ATTN_BWD_ROWS); force == 64 || force == 32 || force == 16) rows = (int)force;
             const dim3 rgrid((unsigned)((n + rows - 1) / rows), 2);
             const bool small = a.kq <= 10 && a.v <= 10;
