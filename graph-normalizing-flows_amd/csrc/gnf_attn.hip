@@ -361,10 +361,12 @@ int validate_attn(const GnfAttn* at, const GnfMlp* mlp, int32_t H, const char* w
 // The edge-tiled kernel above re-staged every sender row once per 16 receivers and took 290 us on 32 complete
 // 100-node graphs; this one is the default whenever heads <= 8 and kq, v <= KQM, VDM.
 // ------------------------------------------------------------------------------------------------
-template <int KQM, int VDM, bool WIN>
+// PAR = 2: two lanes (lane, lane ^ 32) share a receiver row, each walks one half of its edges with its own running
+// (max, Z, weighted values); the two states are merged by the online-softmax rule and lane parity 0 writes.
+template <int KQM, int VDM, bool WIN, int PAR = 1>
 __device__ __forceinline__ void attn_fwd_thread(const AttnArgs& a, const float* __restrict__ qkv, int r, int h,
                                                 const float* win, int win_lo, int WS, const int* cols, int col_base,
-                                                bool v2, float* agg_row) {
+                                                bool v2, float* agg_row, int par = 0) {
     const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd;
     float kreg[KQM], ag[VDM];
 #pragma unroll
@@ -372,7 +374,12 @@ __device__ __forceinline__ void attn_fwd_thread(const AttnArgs& a, const float* 
 #pragma unroll
     for (int j = 0; j < VDM; ++j) ag[j] = 0.f;
     float m = -INFINITY, z = 0.f;
-    const int beg = a.rowptr[r], end = a.rowptr[r + 1];
+    int beg = a.rowptr[r], end = a.rowptr[r + 1];
+    const bool any_edge = end > beg;
+    if (PAR == 2) {
+        const int mid = beg + (end - beg + 1) / 2;
+        if (par == 0) end = mid; else beg = mid;
+    }
     // edges four at a time: the four column indices, then the four rows, are independent loads issued together;
     // only the softmax recurrence is sequential (a thread walking its row one edge at a time waits for
     // col -> row -> arithmetic on every edge)
@@ -415,7 +422,16 @@ __device__ __forceinline__ void attn_fwd_thread(const AttnArgs& a, const float* 
         fetch(cols[e - col_base], qq, vv);
         update(qq, vv);
     }
-    const float inv = end > beg ? 1.f / z : 0.f;
+    if (PAR == 2) {
+        const float m2 = __shfl_xor(m, 32, 64), z2 = __shfl_xor(z, 32, 64);
+        const float mn = fmaxf(m, m2);
+        const float c1 = m == -INFINITY ? 0.f : __expf(m - mn), c2 = m2 == -INFINITY ? 0.f : __expf(m2 - mn);
+        z = z * c1 + z2 * c2;
+#pragma unroll
+        for (int j = 0; j < VDM; ++j) ag[j] = ag[j] * c1 + __shfl_xor(ag[j], 32, 64) * c2;
+        if (par != 0) return;
+    }
+    const float inv = any_edge ? 1.f / z : 0.f;
 #pragma unroll
     for (int j = 0; j < VDM; ++j)
         if (j < vd) agg_row[h * vd + j] = ag[j] * inv;
@@ -482,16 +498,18 @@ __global__ __launch_bounds__(512) void k_attn_fwd_rows(const AttnArgs a, int win
     GNF_ATRACE(3);
     const int* cols = cols_in_lds ? s_col : a.col;
     const int col_base = cols_in_lds ? s_rp[0] : 0;
-    const int r = row0 + lane;
-    if (wave < nh && lane < ROWS && r < a.n_nodes) {
+    constexpr int PAR = ROWS == 32 ? 2 : 1;  // 32-row tiles: the wave's other 32 lanes take half of every row's edges
+    const int row_l = PAR == 2 ? (lane & 31) : lane, par = PAR == 2 ? (lane >> 5) : 0;
+    const int r = row0 + row_l;
+    if (wave < nh && row_l < ROWS && r < a.n_nodes) {
         // 8-byte reads when every row segment is even-sized and 8-byte aligned (window base / qkv base and row stride)
         const bool even = ((kq | vd | nq) & 1) == 0;
         if (lo >= 0)
-            attn_fwd_thread<KQM, VDM, true>(a, qkv, r, wave, win, lo, WS, cols, col_base,
-                                            even && (reinterpret_cast<uintptr_t>(win) & 7) == 0, agg_s + lane * (NV + 1));
+            attn_fwd_thread<KQM, VDM, true, PAR>(a, qkv, r, wave, win, lo, WS, cols, col_base,
+                                                 even && (reinterpret_cast<uintptr_t>(win) & 7) == 0, agg_s + row_l * (NV + 1), par);
         else
-            attn_fwd_thread<KQM, VDM, false>(a, qkv, r, wave, win, 0, WS, cols, col_base,
-                                             even && (reinterpret_cast<uintptr_t>(qkv) & 7) == 0, agg_s + lane * (NV + 1));
+            attn_fwd_thread<KQM, VDM, false, PAR>(a, qkv, r, wave, win, 0, WS, cols, col_base,
+                                                  even && (reinterpret_cast<uintptr_t>(qkv) & 7) == 0, agg_s + row_l * (NV + 1), par);
     }
     GNF_ATRACE(4);
     __syncthreads();
@@ -499,7 +517,7 @@ __global__ __launch_bounds__(512) void k_attn_fwd_rows(const AttnArgs a, int win
     // output projection new = agg Wo (Wo broadcast from LDS, agg row per lane) and h0 = [x || new] | new
     float* h0 = a.h0[net];
     const int off = a.concat ? H : 0;
-    if (lane < ROWS && r < a.n_nodes) {
+    if (lane < ROWS && r < a.n_nodes) {  // (32-row tiles: lanes 0 .. 31, for which row_l = lane)
         // wave w takes the contiguous columns [w * cw, (w + 1) * cw): per agg element one LDS read of it and a run of
         // consecutive Wo values (broadcast), instead of two LDS reads per multiply-add
         const float* ar = agg_s + lane * (NV + 1);

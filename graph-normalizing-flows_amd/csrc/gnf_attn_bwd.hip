@@ -393,9 +393,11 @@ __global__ __launch_bounds__(512) void k_attn_bwd_send(const AttnBwdArgs a, int 
 // heads <= 8 and kq, v <= 32; the lane-per-feature kernels above remain for wider heads.  On the drivers' default
 // dataset (complete 100-node graphs) the receiver pass went from 438 to ... us, the sender pass from 288 to ... us.
 // ------------------------------------------------------------------------------------------------
-template <int KQM, int VDM, bool WIN>
+// PAR = 2: two lanes (lane, lane ^ 32) share a receiver row, each walks one half of its edges; the softmax statistics
+// are merged between the sweeps (online-softmax merge), the sums after the second one, and lane parity 0 writes.
+template <int KQM, int VDM, bool WIN, int PAR = 1>
 __device__ __forceinline__ void attn_recv_thread(const AttnBwdArgs& a, int net, int r, int h, const float* win,
-                                                 int win_lo, int WS, const int* cols, int col_base, bool v2) {
+                                                 int win_lo, int WS, const int* cols, int col_base, bool v2, int par = 0) {
     const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
     const float* qkv = a.qkv[net];
     float kreg[KQM], dreg[VDM];
@@ -403,7 +405,12 @@ __device__ __forceinline__ void attn_recv_thread(const AttnBwdArgs& a, int net, 
     for (int j = 0; j < KQM; ++j) kreg[j] = j < kq ? qkv[(int64_t)r * P + nq + h * kq + j] : 0.f;
 #pragma unroll
     for (int j = 0; j < VDM; ++j) dreg[j] = j < vd ? a.dagg[net][(int64_t)r * NV + h * vd + j] : 0.f;
-    const int beg = a.rowptr[r], end = a.rowptr[r + 1];
+    int beg = a.rowptr[r], end = a.rowptr[r + 1];
+    const bool any_edge = end > beg;
+    if (PAR == 2) {  // this lane's half of the row's edges
+        const int mid = beg + (end - beg + 1) / 2;
+        if (par == 0) end = mid; else beg = mid;
+    }
     auto row_of = [&](int s_, const float*& qrow, const float*& vrow) {
         if (WIN) {
             qrow = win + (s_ - win_lo) * WS + h * kq;
@@ -453,9 +460,17 @@ __device__ __forceinline__ void attn_recv_thread(const AttnBwdArgs& a, int net, 
             stat(qv, vv);
         }
     }
-    const float sumw = end > beg ? s1 / z : 0.f;
-    const float zz = end > beg ? z : 1.f;
-    {
+    if (PAR == 2) {
+        const float m2 = __shfl_xor(m, 32, 64), z2 = __shfl_xor(z, 32, 64), t2 = __shfl_xor(s1, 32, 64);
+        const float mn = fmaxf(m, m2);
+        const float c1 = m == -INFINITY ? 0.f : __expf(m - mn), c2 = m2 == -INFINITY ? 0.f : __expf(m2 - mn);
+        z = z * c1 + z2 * c2;
+        s1 = s1 * c1 + t2 * c2;
+        m = mn;
+    }
+    const float sumw = any_edge ? s1 / z : 0.f;
+    const float zz = any_edge ? z : 1.f;
+    if (par == 0) {
         float* st = a.stats[net] + (int64_t)r * 3 * nh;
         st[h] = m;
         st[nh + h] = zz;
@@ -497,6 +512,13 @@ __device__ __forceinline__ void attn_recv_thread(const AttnBwdArgs& a, int net, 
             accum(qv, vv);
         }
     }
+    if (PAR == 2) {
+#pragma unroll
+        for (int j = 0; j < KQM; ++j) dk[j] += __shfl_xor(dk[j], 32, 64);
+#pragma unroll
+        for (int j = 0; j < VDM; ++j) ag[j] += __shfl_xor(ag[j], 32, 64);
+        if (par != 0) return;
+    }
 #pragma unroll
     for (int j = 0; j < KQM; ++j)
         if (j < kq) a.dqkv[net][(int64_t)r * P + nq + h * kq + j] = dk[j] * a.scale;
@@ -535,22 +557,25 @@ __global__ __launch_bounds__(512) void k_attn_bwd_recv_rows(const AttnBwdArgs a,
     __syncthreads();
     const int* cols = cols_in_lds ? s_col : a.col;
     const int col_base = cols_in_lds ? s_rp[0] : 0;
-    const int r = row0 + lane;
-    if (wave < nh && lane < ROWS && r < a.n) {
+    constexpr int PAR = ROWS == 32 ? 2 : 1;  // 32-row tiles: the wave's other 32 lanes take half of every row's edges
+    const int row_l = PAR == 2 ? (lane & 31) : lane, par = PAR == 2 ? (lane >> 5) : 0;
+    const int r = row0 + row_l;
+    if (wave < nh && row_l < ROWS && r < a.n) {
         const bool even = ((kq | vd | nq) & 1) == 0;
         if (lo >= 0)
-            attn_recv_thread<KQM, VDM, true>(a, net, r, wave, win, lo, WS, cols, col_base,
-                                             even && (reinterpret_cast<uintptr_t>(win) & 7) == 0);
+            attn_recv_thread<KQM, VDM, true, PAR>(a, net, r, wave, win, lo, WS, cols, col_base,
+                                                  even && (reinterpret_cast<uintptr_t>(win) & 7) == 0, par);
         else
-            attn_recv_thread<KQM, VDM, false>(a, net, r, wave, win, 0, WS, cols, col_base,
-                                              even && (reinterpret_cast<uintptr_t>(qkv) & 7) == 0);
+            attn_recv_thread<KQM, VDM, false, PAR>(a, net, r, wave, win, 0, WS, cols, col_base,
+                                                   even && (reinterpret_cast<uintptr_t>(qkv) & 7) == 0, par);
     }
 }
 
 // sender side: window rows = the receivers' k | dagg (row stride WS); their softmax statistics from global memory
-template <int KQM, int VDM, bool WIN>
+template <int KQM, int VDM, bool WIN, int PAR = 1>   // PAR = 2: lanes (lane, lane ^ 32) share a sender row (see attn_recv_thread)
 __device__ __forceinline__ void attn_send_thread(const AttnBwdArgs& a, int net, int u_, int h, const float* win,
-                                                 int win_lo, int WS, const int* cols, int col_base, bool v2, float* dvp_out) {
+                                                 int win_lo, int WS, const int* cols, int col_base, bool v2, float* dvp_out,
+                                                 int par = 0) {
     const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
     const float* qkv = a.qkv[net];
     const float* dagg = a.dagg[net];
@@ -566,7 +591,11 @@ __device__ __forceinline__ void attn_send_thread(const AttnBwdArgs& a, int net, 
         vreg[j] = j < vd ? qkv[(int64_t)u_ * P + 2 * nq + j] : 0.f;
         dvp[j] = 0.f;
     }
-    const int beg = a.rowptr_t[u_], end = a.rowptr_t[u_ + 1];
+    int beg = a.rowptr_t[u_], end = a.rowptr_t[u_ + 1];
+    if (PAR == 2) {
+        const int mid = beg + (end - beg + 1) / 2;
+        if (par == 0) end = mid; else beg = mid;
+    }
     auto fetch = [&](int r, float (&kv)[KQM], float (&dv_)[VDM], float (&st3)[3]) {
         const float *krow, *drow;
         if (WIN) {
@@ -614,11 +643,18 @@ __device__ __forceinline__ void attn_send_thread(const AttnBwdArgs& a, int net, 
             accum(kv, dv_, st3);
         }
     }
+    if (PAR == 2) {
+#pragma unroll
+        for (int j = 0; j < KQM; ++j) dq[j] += __shfl_xor(dq[j], 32, 64);
+#pragma unroll
+        for (int j = 0; j < VDM; ++j) dvp[j] += __shfl_xor(dvp[j], 32, 64);
+    }
+#pragma unroll
+    for (int j = 0; j < VDM; ++j) dvp_out[j] = dvp[j];
+    if (par != 0) return;
 #pragma unroll
     for (int j = 0; j < KQM; ++j)
         if (j < kq) a.dqkv[net][(int64_t)u_ * P + h * kq + j] = dq[j] * a.scale;
-#pragma unroll
-    for (int j = 0; j < VDM; ++j) dvp_out[j] = dvp[j];
 }
 
 template <int KQM, int VDM, int ROWS = 64>
@@ -649,18 +685,20 @@ __global__ __launch_bounds__(512) void k_attn_bwd_send_rows(const AttnBwdArgs a,
     __syncthreads();
     const int* cols = cols_in_lds ? s_col : a.col_t;
     const int col_base = cols_in_lds ? s_rp[0] : 0;
-    const int u_ = row0 + lane;
+    constexpr int PAR = ROWS == 32 ? 2 : 1;
+    const int row_l = PAR == 2 ? (lane & 31) : lane, par = PAR == 2 ? (lane >> 5) : 0;
+    const int u_ = row0 + row_l;
     float dvp[VDM];
 #pragma unroll
     for (int j = 0; j < VDM; ++j) dvp[j] = 0.f;
-    if (wave < nh && lane < ROWS && u_ < a.n) {
+    if (wave < nh && row_l < ROWS && u_ < a.n) {
         const bool even = ((kq | vd | nq | NV) & 1) == 0;
         if (lo >= 0)
-            attn_send_thread<KQM, VDM, true>(a, net, u_, wave, win, lo, WS, cols, col_base,
-                                             even && (reinterpret_cast<uintptr_t>(win) & 7) == 0, dvp);
+            attn_send_thread<KQM, VDM, true, PAR>(a, net, u_, wave, win, lo, WS, cols, col_base,
+                                                  even && (reinterpret_cast<uintptr_t>(win) & 7) == 0, dvp, par);
         else
-            attn_send_thread<KQM, VDM, false>(a, net, u_, wave, win, 0, WS, cols, col_base,
-                                              even && ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(dagg)) & 7) == 0, dvp);
+            attn_send_thread<KQM, VDM, false, PAR>(a, net, u_, wave, win, 0, WS, cols, col_base,
+                                                   even && ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(dagg)) & 7) == 0, dvp, par);
     }
     // v is shared by the heads: dv[u, :] = sum over the head waves (through the LDS region the window occupied)
     __syncthreads();
