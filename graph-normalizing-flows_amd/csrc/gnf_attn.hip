@@ -634,7 +634,8 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
                                      reinterpret_cast<const void*>(k_attn_fwd_rows<32, 32, 32>)};
                 for (const void* k : ks) GNF_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
             // (the LDS plan above is the 64-row one: a 32-row tile needs less)
-            const bool half_tiles = (int64_t)nets * ((n + 63) / 64) < 256;
+            bool half_tiles = (int64_t)nets * ((n + 63) / 64) < 256;
+            if (const int64_t force = opt(OPT_ATTN_BWD_ROWS); force == 64 || force == 32) half_tiles = force == 32;  // developer option
             const int rows = half_tiles ? 32 : 64;
             const dim3 rgrid((unsigned)((n + rows - 1) / rows), nets);
             const bool small = a.kq <= 10 && a.v <= 10;

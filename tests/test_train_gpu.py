@@ -392,8 +392,10 @@ def test_layer_norm_parameters_train(community_medium):
 
 @pytest.mark.parametrize("rows", [16, 32, 64])
 def test_attention_backward_row_tile_sizes(community_medium, rows):
-    """k_attn_bwd_recv_rows / _send_rows exist for 64-, 32- and 16-row tiles (the library picks by mean degree; the
-    developer option attn_bwd_rows forces one): the same gradients through each."""
+    """k_attn_bwd_recv_rows / _send_rows exist for 64-, 32- and 16-row tiles, k_attn_fwd_rows for 64 and 32 (the library
+    picks by batch size and mean degree; the developer option attn_bwd_rows forces one; 32-row tiles split every row's
+    edges over two lanes): the same loss and gradients through each.  attn_rows=1 keeps the sparse batch on the rows
+    kernels in the forward pass too."""
     from gnf_amd import _abi
     from gnf_amd.train import GRevNetTrainer
     attn = dict(num_heads=4, kq_dim=6, v_dim=5, out_dim=12, concat=True, kq_dim_division=True, residual=False)
@@ -405,12 +407,14 @@ def test_attention_backward_row_tile_sizes(community_medium, rows):
     p = O.make_attn_grevnet_params(13, 6, 32, 2, 2, final_scale=0.3, **attn)
     ref = O.loss_and_grads(s, r, n, x, p, 2, activation="relu")
     _abi.set_option("attn_bwd_rows", rows)
+    _abi.set_option("attn_rows", 1)
     try:
         tr = GRevNetTrainer(make_product_grevnet(hp, p))
         out = tr.loss_and_grads(graph_from_arrays(nn, ne, s, r, x, DEV))
         torch.cuda.synchronize()
     finally:
         _abi.set_option("attn_bwd_rows", 0)
+        _abi.set_option("attn_rows", 0)
     assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
     for (name, a), (_, b) in zip(_flat_attn(tr.named_gradients(), False), _flat_attn(ref["grads"], False)):
         assert np.abs(a - b).max() <= 5e-4 * np.abs(b).max() + 1e-5, name
