@@ -18,7 +18,7 @@ static const char* const kOptionNames[OPT_COUNT] = {
     "gemm_lds_direct", "gemm_no_splitk", "layered_own_gemm", "dw_grouped",   "dw_wide_units",     "dw_wide_lds",
     "dw_no_streamk",   "dw_no_buf",      "dw_debug",         "dw_late_fork", "bwd_generic",
     "dw_unmerged",     "bwd_no_fold",    "no_mlp_stash",
-    "attn_bwd_rows"};
+    "attn_bwd_rows",   "attn_bwd_split"};
 
 static int option_index(const char* name) {
     if (!name) return -1;

@@ -28,6 +28,8 @@ struct AttnArgs {
     const float* Wo[2];
     float* qkv[2];  // [N, 2*nh*kq + v] scratch per net
     float* h0[2];   // [N, in0] output per net
+    float* agg_out[2];  // NULL, or [N, nh*v]: the attended values (training: the backward pass reads them back)
+    float* mz_out[2];   // NULL, or [N, 3*nh]: softmax running max at [h], denominator at [nh + h] (third block: backward scratch)
     const int32_t* rowptr;
     const int32_t* col;
     const float* x;
@@ -273,6 +275,7 @@ __global__ __launch_bounds__(512) void k_attn_agg(const AttnArgs a, int RB) {
                     if (el == 0) mx_lds[grp] = fmaxf(mx_lds[grp], mx);
                 } else {
                     if (ntiles > 1) mx = mx_lds[grp];  // global max of the row from pass 0
+                    else if (el == 0) mx_lds[grp] = mx;  // (kept for mz_out)
                     float den = 0.f;
                     for (int e = beg + el; e < end; e += kEL) {
                         const float w = expf(w_lds[(e - t0) * nh + g_h] - mx);
@@ -305,6 +308,19 @@ __global__ __launch_bounds__(512) void k_attn_agg(const AttnArgs a, int RB) {
         agg_lds[i] = den > 0.f ? agg_lds[i] / den : 0.f;  // no incoming edge -> 0 (gnn.py:403)
     }
     __syncthreads();
+    if (a.agg_out[net])
+        for (int i = tid; i < RB * NV; i += nthr) {
+            const int rl = i / NV;
+            if (row0 + rl < a.n_nodes) a.agg_out[net][(int64_t)(row0 + rl) * NV + (i - rl * NV)] = agg_lds[i];
+        }
+    if (a.mz_out[net])
+        for (int i = tid; i < RB * nh; i += nthr) {
+            const int rl = i / nh, h = i - rl * nh;
+            if (row0 + rl >= a.n_nodes) continue;
+            float* mz = a.mz_out[net] + (int64_t)(row0 + rl) * 3 * nh;
+            mz[h] = mx_lds[i];
+            mz[nh + h] = den_lds[i] > 0.f ? den_lds[i] : 1.f;
+        }
     float* h0 = a.h0[net];
     const int off = a.concat ? a.H : 0;
     for (int i = tid; i < RB * OCr; i += nthr) {
@@ -366,7 +382,7 @@ int validate_attn(const GnfAttn* at, const GnfMlp* mlp, int32_t H, const char* w
 template <int KQM, int VDM, bool WIN, int PAR = 1>
 __device__ __forceinline__ void attn_fwd_thread(const AttnArgs& a, const float* __restrict__ qkv, int r, int h,
                                                 const float* win, int win_lo, int WS, const int* cols, int col_base,
-                                                bool v2, float* agg_row, int par = 0) {
+                                                bool v2, float* agg_row, int par = 0, float* mz = nullptr) {
     const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd;
     float kreg[KQM], ag[VDM];
 #pragma unroll
@@ -429,12 +445,17 @@ __device__ __forceinline__ void attn_fwd_thread(const AttnArgs& a, const float* 
         z = z * c1 + z2 * c2;
 #pragma unroll
         for (int j = 0; j < VDM; ++j) ag[j] = ag[j] * c1 + __shfl_xor(ag[j], 32, 64) * c2;
+        m = mn;
         if (par != 0) return;
     }
     const float inv = any_edge ? 1.f / z : 0.f;
 #pragma unroll
     for (int j = 0; j < VDM; ++j)
         if (j < vd) agg_row[h * vd + j] = ag[j] * inv;
+    if (mz) {
+        mz[(int64_t)r * 3 * nh + h] = m;
+        mz[(int64_t)r * 3 * nh + nh + h] = any_edge ? z : 1.f;
+    }
 }
 
 #ifdef GNF_ATTN_TRACE  // developer build: cycle stamps of workgroup 0 / thread 0 at the phase boundaries
@@ -506,14 +527,21 @@ __global__ __launch_bounds__(512) void k_attn_fwd_rows(const AttnArgs a, int win
         const bool even = ((kq | vd | nq) & 1) == 0;
         if (lo >= 0)
             attn_fwd_thread<KQM, VDM, true, PAR>(a, qkv, r, wave, win, lo, WS, cols, col_base,
-                                                 even && (reinterpret_cast<uintptr_t>(win) & 7) == 0, agg_s + row_l * (NV + 1), par);
+                                                 even && (reinterpret_cast<uintptr_t>(win) & 7) == 0, agg_s + row_l * (NV + 1), par,
+                                                 a.mz_out[net]);
         else
             attn_fwd_thread<KQM, VDM, false, PAR>(a, qkv, r, wave, win, 0, WS, cols, col_base,
-                                                  even && (reinterpret_cast<uintptr_t>(qkv) & 7) == 0, agg_s + row_l * (NV + 1), par);
+                                                  even && (reinterpret_cast<uintptr_t>(qkv) & 7) == 0, agg_s + row_l * (NV + 1), par,
+                                                  a.mz_out[net]);
     }
     GNF_ATRACE(4);
     __syncthreads();
     GNF_ATRACE(5);
+    if (a.agg_out[net])  // the attended values stay for the backward pass (coalesced rows)
+        for (int i = tid; i < ROWS * NV; i += 512) {
+            const int rl = i / NV, c = i - rl * NV;
+            if (row0 + rl < a.n_nodes) a.agg_out[net][(int64_t)(row0 + rl) * NV + c] = agg_s[rl * (NV + 1) + c];
+        }
     // output projection new = agg Wo (Wo broadcast from LDS, agg row per lane) and h0 = [x || new] | new
     float* h0 = a.h0[net];
     const int off = a.concat ? H : 0;
@@ -546,7 +574,8 @@ __global__ __launch_bounds__(512) void k_attn_fwd_rows(const AttnArgs a, int win
 size_t attn_scratch_floats(const GnfAttn* at, int64_t n_nodes, int32_t in0) {
     if (!at) return 0;
     const size_t P = 2 * (size_t)at->num_heads * at->kq_dim + at->v_dim;
-    return 2 * (size_t)n_nodes * (P + (size_t)in0);
+    // [2][n][P] q|k|v, [2][n][in0] h0, [2][n][heads*v] attended values, [2][n][3*heads] softmax statistics
+    return 2 * (size_t)n_nodes * (P + (size_t)in0 + (size_t)at->num_heads * at->v_dim + 3 * (size_t)at->num_heads);
 }
 
 size_t attn_stash_slot_floats(const GnfFlow* flow, int64_t n_nodes) {
@@ -558,7 +587,8 @@ size_t attn_stash_slot_floats(const GnfFlow* flow, int64_t n_nodes) {
 // nets: 1 or 2 attention blocks sharing x / topology; writes h0[q] ([N, in0]) for each.
 int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, const float* x, int64_t ldx,
                       int32_t H, const GnfAttn* const* at, int nets, int32_t in0, float* scratch,
-                      float* const* h0_out, hipStream_t st, int64_t n_edges, bool need_qkv, const float* const* packed) {
+                      float* const* h0_out, hipStream_t st, int64_t n_edges, bool need_qkv, const float* const* packed,
+                      float* const* agg_out, float* const* mz_out) {
     if (n == 0) return GNF_OK;
     const GnfAttn* a0 = at[0];
     for (int q = 1; q < nets; ++q)
@@ -575,7 +605,7 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
     if (packed && packed[0] && n_edges > 0 && n_edges < 24 * n && attn_front_fused_ok(a0, H)) {
         float* qkv_ptr[2] = {scratch, scratch + (size_t)(nets > 1 ? 1 : 0) * n * P};
         return launch_attn_front_fused(rowptr, col, n, x, ldx, H, at, nets, in0, packed, need_qkv ? qkv_ptr : nullptr,
-                                       h0_out, st);
+                                       h0_out, st, agg_out, mz_out);
     }
     for (int q = 0; q < 2; ++q) {
         const GnfAttn* t = at[q < nets ? q : 0];
@@ -585,6 +615,8 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
         a.Wo[q] = t->Wo;
         a.qkv[q] = scratch + (size_t)q * n * P;
         a.h0[q] = h0_out[q < nets ? q : 0];
+        a.agg_out[q] = agg_out ? agg_out[q < nets ? q : 0] : nullptr;
+        a.mz_out[q] = mz_out ? mz_out[q < nets ? q : 0] : nullptr;
     }
     a.rowptr = rowptr;
     a.col = col;

@@ -393,8 +393,15 @@ __global__ __launch_bounds__(512) void k_attn_bwd_send(const AttnBwdArgs a, int 
 // heads <= 8 and kq, v <= 32; the lane-per-feature kernels above remain for wider heads.  On the drivers' default
 // dataset (complete 100-node graphs) the receiver pass went from 438 to ... us, the sender pass from 288 to ... us.
 // ------------------------------------------------------------------------------------------------
-// PAR = 2: two lanes (lane, lane ^ 32) share a receiver row, each walks one half of its edges; the softmax statistics
-// are merged between the sweeps (online-softmax merge), the sums after the second one, and lane parity 0 writes.
+// The forward pass leaves, per (row, head), the softmax statistics (running max m, denominator Z) and the attended values
+// O = sum_e w_e v_e (AttnArgs.agg_out / mz_out): the backward pass never rebuilds them.  With
+//   delta[r, h] = sum_e w_e <dO[r,h,:], v_e> = <dO[r,h,:], O[r,h,:]>
+// the receiver side is ONE sweep over a row's edges (it used to be two: statistics, then gradients) and the sender side
+// depends on nothing the receiver side computes, so on sparse batches both run in one launch (k_attn_bwd_edges: a sender
+// tile forms the delta of its window rows while staging them); as two launches the receiver pass leaves delta in the
+// statistics' third block for the sender pass.
+// PAR = 2: two lanes (lane, lane ^ 32) share a receiver row, each walks one half of its edges; the sums are added at the
+// end and lane parity 0 writes.
 template <int KQM, int VDM, bool WIN, int PAR = 1>
 __device__ __forceinline__ void attn_recv_thread(const AttnBwdArgs& a, int net, int r, int h, const float* win,
                                                  int win_lo, int WS, const int* cols, int col_base, bool v2, int par = 0) {
@@ -403,15 +410,22 @@ __device__ __forceinline__ void attn_recv_thread(const AttnBwdArgs& a, int net, 
     float kreg[KQM], dreg[VDM];
 #pragma unroll
     for (int j = 0; j < KQM; ++j) kreg[j] = j < kq ? qkv[(int64_t)r * P + nq + h * kq + j] : 0.f;
+    float delta = 0.f;
 #pragma unroll
-    for (int j = 0; j < VDM; ++j) dreg[j] = j < vd ? a.dagg[net][(int64_t)r * NV + h * vd + j] : 0.f;
+    for (int j = 0; j < VDM; ++j) {
+        dreg[j] = j < vd ? a.dagg[net][(int64_t)r * NV + h * vd + j] : 0.f;
+        delta += dreg[j] * (j < vd ? a.agg[net][(int64_t)r * NV + h * vd + j] : 0.f);
+    }
+    float* st = a.stats[net] + (int64_t)r * 3 * nh;
+    const float m = st[h], rz = 1.f / st[nh + h];
+    if (par == 0) st[2 * nh + h] = delta;  // (what a sender pass in a launch of its own reads)
     int beg = a.rowptr[r], end = a.rowptr[r + 1];
-    const bool any_edge = end > beg;
     if (PAR == 2) {  // this lane's half of the row's edges
         const int mid = beg + (end - beg + 1) / 2;
         if (par == 0) end = mid; else beg = mid;
     }
-    auto row_of = [&](int s_, const float*& qrow, const float*& vrow) {
+    auto fetch = [&](int s_, float (&qv)[KQM], float (&vv)[VDM]) {
+        const float *qrow, *vrow;
         if (WIN) {
             qrow = win + (s_ - win_lo) * WS + h * kq;
             vrow = win + (s_ - win_lo) * WS + nq;
@@ -419,82 +433,23 @@ __device__ __forceinline__ void attn_recv_thread(const AttnBwdArgs& a, int net, 
             qrow = qkv + (int64_t)s_ * P + h * kq;
             vrow = qkv + (int64_t)s_ * P + 2 * nq;
         }
-    };
-    float m = -INFINITY, z = 0.f, s1 = 0.f;
-    // edges four at a time: column indices and rows of a chunk are independent loads issued together; only the
-    // recurrences are sequential
-    auto fetch = [&](int s_, float (&qv)[KQM], float (&vv)[VDM]) {
-        const float *qrow, *vrow;
-        row_of(s_, qrow, vrow);
         load_row<KQM>(qrow, kq, v2, qv);
         load_row<VDM>(vrow, vd, v2, vv);
     };
-    auto stat = [&](const float (&qv)[KQM], const float (&vv)[VDM]) {
-        float lg = 0.f, dw = 0.f;
-#pragma unroll
-        for (int j = 0; j < KQM; ++j) lg += qv[j] * kreg[j];
-#pragma unroll
-        for (int j = 0; j < VDM; ++j) dw += vv[j] * dreg[j];
-        lg *= a.scale;
-        const float mn = fmaxf(m, lg);
-        const float sc = __expf(m - mn), pe = __expf(lg - mn);
-        z = z * sc + pe;
-        s1 = s1 * sc + pe * dw;
-        m = mn;
-    };
-    {
-        int e = beg;
-        for (; e + 4 <= end; e += 4) {
-            int s4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) s4[u] = cols[e + u - col_base];
-            float qv[4][KQM], vv[4][VDM];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) fetch(s4[u], qv[u], vv[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) stat(qv[u], vv[u]);
-        }
-        for (; e < end; ++e) {
-            float qv[KQM], vv[VDM];
-            fetch(cols[e - col_base], qv, vv);
-            stat(qv, vv);
-        }
-    }
-    if (PAR == 2) {
-        const float m2 = __shfl_xor(m, 32, 64), z2 = __shfl_xor(z, 32, 64), t2 = __shfl_xor(s1, 32, 64);
-        const float mn = fmaxf(m, m2);
-        const float c1 = m == -INFINITY ? 0.f : __expf(m - mn), c2 = m2 == -INFINITY ? 0.f : __expf(m2 - mn);
-        z = z * c1 + z2 * c2;
-        s1 = s1 * c1 + t2 * c2;
-        m = mn;
-    }
-    const float sumw = any_edge ? s1 / z : 0.f;
-    const float zz = any_edge ? z : 1.f;
-    if (par == 0) {
-        float* st = a.stats[net] + (int64_t)r * 3 * nh;
-        st[h] = m;
-        st[nh + h] = zz;
-        st[2 * nh + h] = sumw;
-    }
-    float dk[KQM], ag[VDM];
+    float dk[KQM];
 #pragma unroll
     for (int j = 0; j < KQM; ++j) dk[j] = 0.f;
-#pragma unroll
-    for (int j = 0; j < VDM; ++j) ag[j] = 0.f;
     auto accum = [&](const float (&qv)[KQM], const float (&vv)[VDM]) {
         float lg = 0.f, dw = 0.f;
 #pragma unroll
         for (int j = 0; j < KQM; ++j) lg += qv[j] * kreg[j];
 #pragma unroll
         for (int j = 0; j < VDM; ++j) dw += vv[j] * dreg[j];
-        const float w = __expf(lg * a.scale - m) / zz;
-        const float dl = w * (dw - sumw);
+        const float dl = __expf(lg * a.scale - m) * rz * (dw - delta);
 #pragma unroll
         for (int j = 0; j < KQM; ++j) dk[j] += dl * qv[j];
-#pragma unroll
-        for (int j = 0; j < VDM; ++j) ag[j] += w * vv[j];
     };
-    {
+    {   // edges four at a time: column indices and rows of a chunk are independent loads issued together
         int e = beg;
         for (; e + 4 <= end; e += 4) {
             int s4[4];
@@ -515,28 +470,20 @@ __device__ __forceinline__ void attn_recv_thread(const AttnBwdArgs& a, int net, 
     if (PAR == 2) {
 #pragma unroll
         for (int j = 0; j < KQM; ++j) dk[j] += __shfl_xor(dk[j], 32, 64);
-#pragma unroll
-        for (int j = 0; j < VDM; ++j) ag[j] += __shfl_xor(ag[j], 32, 64);
         if (par != 0) return;
     }
 #pragma unroll
     for (int j = 0; j < KQM; ++j)
         if (j < kq) a.dqkv[net][(int64_t)r * P + nq + h * kq + j] = dk[j] * a.scale;
-#pragma unroll
-    for (int j = 0; j < VDM; ++j)
-        if (j < vd) a.agg[net][(int64_t)r * NV + h * vd + j] = ag[j];
 }
 
-// ROWS: receiver rows per workgroup (lanes ROWS .. 63 of every head's wave idle).  64 suits the complete graphs these
-// kernels were built for (the window IS the graph); on sparse batches 64-row tiles are 43 workgroups per net for 256
-// CUs and every thread's serial walk over its edges is the whole kernel: 32-row tiles put twice as many CUs to work.
-template <int KQM, int VDM, int ROWS = 64>
-__global__ __launch_bounds__(512) void k_attn_bwd_recv_rows(const AttnBwdArgs a, int win_cap) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int net = blockIdx.y;
+// ROWS: receiver rows per workgroup (lanes ROWS .. 63 of every head's wave idle).  64 suits large batches of complete
+// graphs (the window IS the graph); 32-row tiles put twice as many CUs to work and split every row's edges over two lanes.
+template <int KQM, int VDM, int ROWS>
+__device__ __forceinline__ void attn_recv_tile(const AttnBwdArgs& a, int net, int tile, int win_cap, float* sm) {
     const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * ROWS;
+    const int row0 = tile * ROWS;
     int* s_rp = reinterpret_cast<int*>(sm);
     int* s_hdr = s_rp + ROWS + 1;
     int* s_col = s_hdr + 3;
@@ -571,8 +518,17 @@ __global__ __launch_bounds__(512) void k_attn_bwd_recv_rows(const AttnBwdArgs a,
     }
 }
 
-// sender side: window rows = the receivers' k | dagg (row stride WS); their softmax statistics from global memory
-template <int KQM, int VDM, bool WIN, int PAR = 1>   // PAR = 2: lanes (lane, lane ^ 32) share a sender row (see attn_recv_thread)
+template <int KQM, int VDM, int ROWS = 64>
+__global__ __launch_bounds__(512) void k_attn_bwd_recv_rows(const AttnBwdArgs a, int win_cap) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    attn_recv_tile<KQM, VDM, ROWS>(a, blockIdx.y, blockIdx.x, win_cap, sm);
+}
+
+// sender side: window rows = the receivers' k | dagg (row stride WS), and with SW their m | Z | delta too (else those
+// come from global memory)
+// DG (one launch, window too wide for the LDS): delta formed per edge from global memory - nothing may be read that the
+// receiver tiles of the same launch write
+template <int KQM, int VDM, bool WIN, bool SW, bool DG, int PAR = 1>   // PAR = 2: lanes (lane, lane ^ 32) share a sender row
 __device__ __forceinline__ void attn_send_thread(const AttnBwdArgs& a, int net, int u_, int h, const float* win,
                                                  int win_lo, int WS, const int* cols, int col_base, bool v2, float* dvp_out,
                                                  int par = 0) {
@@ -605,12 +561,25 @@ __device__ __forceinline__ void attn_send_thread(const AttnBwdArgs& a, int net, 
             krow = qkv + (int64_t)r * P + nq + h * kq;
             drow = dagg + (int64_t)r * NV + h * vd;
         }
-        const float* st = stats + (int64_t)r * 3 * nh;
-        st3[0] = st[h];
-        st3[1] = st[nh + h];
-        st3[2] = st[2 * nh + h];
+        if (WIN && SW) {
+            const float* st = win + (r - win_lo) * WS + nq + NV;
+            st3[0] = st[h];
+            st3[1] = st[nh + h];
+            st3[2] = st[2 * nh + h];
+        } else {
+            const float* st = stats + (int64_t)r * 3 * nh;
+            st3[0] = st[h];
+            st3[1] = st[nh + h];
+            st3[2] = DG ? 0.f : st[2 * nh + h];
+        }
         load_row<KQM>(krow, kq, v2, kv);
         load_row<VDM>(drow, vd, v2, dv_);
+        if (DG) {
+            float ag[VDM];
+            load_row<VDM>(a.agg[net] + (int64_t)r * NV + h * vd, vd, false, ag);
+#pragma unroll
+            for (int j = 0; j < VDM; ++j) st3[2] += dv_[j] * ag[j];
+        }
     };
     auto accum = [&](const float (&kv)[KQM], const float (&dv_)[VDM], const float (&st3)[3]) {
         float lg = 0.f, dw = 0.f;
@@ -657,18 +626,19 @@ __device__ __forceinline__ void attn_send_thread(const AttnBwdArgs& a, int net, 
         if (j < kq) a.dqkv[net][(int64_t)u_ * P + h * kq + j] = dq[j] * a.scale;
 }
 
-template <int KQM, int VDM, int ROWS = 64>
-__global__ __launch_bounds__(512) void k_attn_bwd_send_rows(const AttnBwdArgs a, int win_cap) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int net = blockIdx.y;
+// SW (the one-launch form): the window rows also carry the receivers' m | Z | delta, delta formed here from the staged dagg
+// rows and the forward pass's attended values - nothing the receiver tiles write is read.  (On the complete 100-node
+// graphs of the drivers' datasets the window of a tile that straddles two graphs has no room for them: two launches.)
+template <int KQM, int VDM, int ROWS, bool SW>
+__device__ __forceinline__ void attn_send_tile(const AttnBwdArgs& a, int net, int tile, int win_cap, float* sm) {
     const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * ROWS;
+    const int row0 = tile * ROWS;
     int* s_rp = reinterpret_cast<int*>(sm);
     int* s_hdr = s_rp + ROWS + 1;
     int* s_col = s_hdr + 3;
     float* win = reinterpret_cast<float*>(s_col + kRowsColCap);
-    const int WS = (nq + NV + 2) & ~1;  // even: rows stay 8-byte aligned
+    const int WS = (nq + NV + (SW ? 3 * nh : 0) + 2) & ~1;  // even: rows stay 8-byte aligned
     if (tid <= ROWS) {
         const int r = row0 + tid;
         s_rp[tid] = a.rowptr_t[r < a.n ? r : a.n];
@@ -676,11 +646,27 @@ __global__ __launch_bounds__(512) void k_attn_bwd_send_rows(const AttnBwdArgs a,
     __syncthreads();
     const float* qkv = a.qkv[net];
     const float* dagg = a.dagg[net];
+    const float* stats = a.stats[net];
     const int lo = stage_window(a.col_t, s_rp, ROWS, s_hdr, win_cap, tid, 512, [&](int lo_, int cnt) {
-        window_copy(win, WS, cnt, nq + NV, tid, 512, [&](int rr, int c) {
-            return c < nq ? qkv[(int64_t)(lo_ + rr) * P + nq + c] : dagg[(int64_t)(lo_ + rr) * NV + (c - nq)];
+        window_copy(win, WS, cnt, nq + NV + (SW ? 2 * nh : 0), tid, 512, [&](int rr, int c) {
+            const int64_t r = lo_ + rr;
+            if (c < nq) return qkv[r * P + nq + c];
+            if (c < nq + NV) return dagg[r * NV + (c - nq)];
+            return stats[r * 3 * nh + (c - nq - NV)];
         });
     });
+    if (SW && lo >= 0) {  // delta of the window rows: <dagg (staged), agg> per head
+        const float* agg = a.agg[net];
+        const int cells = (s_hdr[1] - lo + 1) * nh;
+        for (int i = tid; i < cells; i += 512) {
+            const int rr = i / nh, h = i - rr * nh;
+            const float* ap = agg + (int64_t)(lo + rr) * NV + h * vd;
+            const float* dp = win + rr * WS + nq + h * vd;
+            float d = 0.f;
+            for (int j = 0; j < vd; ++j) d += dp[j] * ap[j];
+            win[rr * WS + nq + NV + 2 * nh + h] = d;
+        }
+    }
     const bool cols_in_lds = stage_cols(a.col_t, s_rp, ROWS, s_col, kRowsColCap, tid, 512);
     __syncthreads();
     const int* cols = cols_in_lds ? s_col : a.col_t;
@@ -694,11 +680,11 @@ __global__ __launch_bounds__(512) void k_attn_bwd_send_rows(const AttnBwdArgs a,
     if (wave < nh && row_l < ROWS && u_ < a.n) {
         const bool even = ((kq | vd | nq | NV) & 1) == 0;
         if (lo >= 0)
-            attn_send_thread<KQM, VDM, true, PAR>(a, net, u_, wave, win, lo, WS, cols, col_base,
-                                                  even && (reinterpret_cast<uintptr_t>(win) & 7) == 0, dvp, par);
+            attn_send_thread<KQM, VDM, true, SW, false, PAR>(a, net, u_, wave, win, lo, WS, cols, col_base,
+                                                             even && (reinterpret_cast<uintptr_t>(win) & 7) == 0, dvp, par);
         else
-            attn_send_thread<KQM, VDM, false, PAR>(a, net, u_, wave, win, 0, WS, cols, col_base,
-                                                   even && ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(dagg)) & 7) == 0, dvp, par);
+            attn_send_thread<KQM, VDM, false, false, SW, PAR>(a, net, u_, wave, win, 0, WS, cols, col_base,
+                                                              even && ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(dagg)) & 7) == 0, dvp, par);
     }
     // v is shared by the heads: dv[u, :] = sum over the head waves (through the LDS region the window occupied)
     __syncthreads();
@@ -712,6 +698,26 @@ __global__ __launch_bounds__(512) void k_attn_bwd_send_rows(const AttnBwdArgs a,
             for (int h = 0; h < nh; ++h) s += red[(h * 64 + lane) * VDM + j];
             a.dqkv[net][(int64_t)u_ * P + 2 * nq + j] = s;
         }
+}
+
+template <int KQM, int VDM, int ROWS = 64>
+__global__ __launch_bounds__(512) void k_attn_bwd_send_rows(const AttnBwdArgs a, int win_cap) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    attn_send_tile<KQM, VDM, ROWS, false>(a, blockIdx.y, blockIdx.x, win_cap, sm);
+}
+
+// both passes of both nets in ONE launch: workgroups [0, 2 ts) are the sender tiles (RS rows each; the longer ones, first
+// in dispatch order), [2 ts, 2 ts + 2 tr) the receiver tiles (RR rows each).  One workgroup per CU (the LDS window), so
+// the launcher picks the tile sizes that make the launch one round of the chip where it can: the config-2 batch (2718
+// nodes) is 170 sender tiles of 32 rows + 86 receiver tiles of 64 rows = 256 workgroups.
+template <int KQM, int VDM, int RS, int RR>
+__global__ __launch_bounds__(512) void k_attn_bwd_edges(const AttnBwdArgs a, int cap_recv, int cap_send, int ts) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x;
+    if (b < 2 * ts)
+        attn_send_tile<KQM, VDM, RS, true>(a, b & 1, b >> 1, cap_send, sm);
+    else
+        attn_recv_tile<KQM, VDM, RR>(a, (b - 2 * ts) & 1, (b - 2 * ts) >> 1, cap_recv, sm);
 }
 
 // g[r, f] += sum over nets of ( dq Wq^T + dk Wk^T + dv Wv^T )[r, f]  (+ dh0[r, f] when concatenated)
@@ -808,8 +814,9 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dx(const AttnDxArgs a) {
 }
 
 // at[2]: the two attention blocks; qkv: [2][N, P] forward projections (launch_attn_front's scratch);
-// dh0 / gst: per net;  dqkv / agg: per net outputs kept for the dW GEMMs;  dagg = dnew Wo^T [N, heads*v]
-// (computed by the caller with the matrix-core GEMM);  stats: scratch.
+// dh0 / gst: per net;  dqkv: per net outputs kept for the dW GEMMs;  dagg = dnew Wo^T [N, heads*v] (computed by the
+// caller with the matrix-core GEMM);  agg / stats: the forward pass's attended values and softmax statistics
+// (launch_attn_front's agg_out / mz_out; the lane-per-feature kernels for wide heads rebuild both in place).
 int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t in0, const int32_t* rowptr,
                          const int32_t* col, const int32_t* rowptr_t, const int32_t* col_t, const float* const* qkv,
                          const float* const* dh0, const float* const* gst, float* const* dqkv, float* const* agg,
@@ -866,25 +873,62 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
         const size_t fixed_r = (size_t)(kRowsTile + 1 + 3 + kRowsColCap) * sizeof(int);
         const int capr = (int)((kRowsLdsBudget - fixed_r) / ((size_t)(nq + a.v + 2) * sizeof(float)));
         const int caps = (int)((kRowsLdsBudget - fixed_r) / ((size_t)(nq + NV + 2) * sizeof(float)));
+        const int capw = (int)((kRowsLdsBudget - fixed_r) / ((size_t)(nq + NV + 3 * a.nh + 2) * sizeof(float)));  // with statistics
         // the sender pass re-uses the window region for its head reduction: 8 x 64 x VDM floats must fit
-        if (capr >= 64 && (size_t)caps * (nq + NV) >= (size_t)8 * 64 * 32) {
+        if (capr >= 64 && (size_t)capw * (nq + NV) >= (size_t)8 * 64 * 32) {
             GNF_ONCE_PER_DEVICE(
-                const void* ks[12] = {
+                const void* ks[18] = {
                     reinterpret_cast<const void*>(k_attn_bwd_recv_rows<10, 10, 64>), reinterpret_cast<const void*>(k_attn_bwd_recv_rows<32, 32, 64>),
                     reinterpret_cast<const void*>(k_attn_bwd_send_rows<10, 10, 64>), reinterpret_cast<const void*>(k_attn_bwd_send_rows<32, 32, 64>),
                     reinterpret_cast<const void*>(k_attn_bwd_recv_rows<10, 10, 32>), reinterpret_cast<const void*>(k_attn_bwd_recv_rows<32, 32, 32>),
                     reinterpret_cast<const void*>(k_attn_bwd_send_rows<10, 10, 32>), reinterpret_cast<const void*>(k_attn_bwd_send_rows<32, 32, 32>),
                     reinterpret_cast<const void*>(k_attn_bwd_recv_rows<10, 10, 16>), reinterpret_cast<const void*>(k_attn_bwd_recv_rows<32, 32, 16>),
-                    reinterpret_cast<const void*>(k_attn_bwd_send_rows<10, 10, 16>), reinterpret_cast<const void*>(k_attn_bwd_send_rows<32, 32, 16>)};
+                    reinterpret_cast<const void*>(k_attn_bwd_send_rows<10, 10, 16>), reinterpret_cast<const void*>(k_attn_bwd_send_rows<32, 32, 16>),
+                    reinterpret_cast<const void*>(k_attn_bwd_edges<10, 10, 64, 64>), reinterpret_cast<const void*>(k_attn_bwd_edges<32, 32, 64, 64>),
+                    reinterpret_cast<const void*>(k_attn_bwd_edges<10, 10, 32, 32>), reinterpret_cast<const void*>(k_attn_bwd_edges<32, 32, 32, 32>),
+                    reinterpret_cast<const void*>(k_attn_bwd_edges<10, 10, 32, 64>), reinterpret_cast<const void*>(k_attn_bwd_edges<32, 32, 32, 64>)};
                 for (const void* k : ks) GNF_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
-            // sparse batches (mean degree below 24): 32-row tiles - default-flags training step on the config-2 batch 4.44
-            // (64) / 4.24 (32) / 4.74 ms (16: the window staging per workgroup takes over); option attn_bwd_rows forces one
-            // ... and on any batch whose 64-row tiles would be fewer workgroups than the chip has CUs (the drivers'
-            // default batch, 32 complete 100-node graphs: 10.25 -> 9.9 ms per iteration of examples/run_grevnet.py)
-            int rows = ((n_edges > 0 && n_edges < 24 * n) || 2 * ((n + 63) / 64) < 256) ? 32 : 64;
-            if (const int64_t force = opt(OPT_ATTN_BWD_ROWS); force == 64 || force == 32 || force == 16) rows = (int)force;
-            const dim3 rgrid((unsigned)((n + rows - 1) / rows), 2);
+            // Tile sizes.  Two launches (dense batches; option attn_bwd_split): 32-row tiles on sparse batches (default-flags
+            // training step on the config-2 batch: 4.44 (64) / 4.24 (32) / 4.74 ms (16: the window staging per workgroup
+            // takes over)) and on any batch whose 64-row tiles would be fewer workgroups than the chip has CUs (the drivers'
+            // default batch, 32 complete 100-node graphs: 10.25 -> 9.9 ms per iteration of examples/run_grevnet.py).
+            // One launch (sparse batches): the first of (32, 32), (32 sender / 64 receiver), (64, 64) that is at most one
+            // workgroup per CU; beyond that 32-row tiles.  Option attn_bwd_rows forces a size (16: two launches).
+            const bool sparse = n_edges > 0 && n_edges < 24 * n;
+            int rows = (sparse || 2 * ((n + 63) / 64) < 256) ? 32 : 64;
+            const int64_t force = opt(OPT_ATTN_BWD_ROWS);
+            if (force == 64 || force == 32 || force == 16) rows = (int)force;
+            const bool one_launch = sparse && !opt(OPT_ATTN_BWD_SPLIT) && rows != 16;
             const bool small = a.kq <= 10 && a.v <= 10;
+            if (one_launch) {
+                const int64_t t32 = (n + 31) / 32, t64 = (n + 63) / 64;
+                int rs = rows, rr = rows;
+                if (!force) {
+                    if (4 * t32 <= 256) rs = rr = 32;
+                    else if (2 * t32 + 2 * t64 <= 256) rs = 32, rr = 64;
+                    else if (4 * t64 <= 256) rs = rr = 64;
+                } else if (force == 3264) {
+                    rs = 32, rr = 64;
+                }
+                const int ts = (int)((n + rs - 1) / rs), tr = (int)((n + rr - 1) / rr);
+                const dim3 egrid((unsigned)(2 * ts + 2 * tr));
+                auto go1 = [&](auto rs_c, auto rr_c) {
+                    constexpr int RS = decltype(rs_c)::value, RR = decltype(rr_c)::value;
+                    if (small)
+                        hipLaunchKernelGGL((k_attn_bwd_edges<10, 10, RS, RR>), egrid, dim3(512), (size_t)kRowsLdsBudget, st, a, capr, capw, ts);
+                    else
+                        hipLaunchKernelGGL((k_attn_bwd_edges<32, 32, RS, RR>), egrid, dim3(512), (size_t)kRowsLdsBudget, st, a, capr, capw, ts);
+                };
+                if (rs == 32 && rr == 64)
+                    go1(std::integral_constant<int, 32>{}, std::integral_constant<int, 64>{});
+                else if (rs == 32)
+                    go1(std::integral_constant<int, 32>{}, std::integral_constant<int, 32>{});
+                else
+                    go1(std::integral_constant<int, 64>{}, std::integral_constant<int, 64>{});
+                GNF_LAUNCH_CHECK("k_attn_bwd_edges");
+                goto dx_pass;
+            }
+            const dim3 rgrid((unsigned)((n + rows - 1) / rows), 2);
             auto go = [&](auto rows_c) {
                 constexpr int R = decltype(rows_c)::value;
                 if (small) {

@@ -127,6 +127,8 @@ struct FrontArgs {
     const float* packed[2];  // per net: Wqv | Wk | Wo fragments
     float* qkv[2];           // NULL, or [N, 2*nq + v] per net (q | k | v of every node)
     float* h0[2];            // [N, in0] per net
+    float* agg_out[2];       // NULL, or [N, heads*v] per net: the attended values (kept for the backward pass)
+    float* mz_out[2];        // NULL, or [N, 3*heads] per net: softmax running max at [h], denominator at [heads + h]
     const int32_t* rowptr;
     const int32_t* col;
     const float* x;
@@ -545,6 +547,7 @@ __global__ __launch_bounds__(kFrThreads) void k_attn_front(const FrontArgs a) {
             const float a_o = __shfl_xor(ag[j], 1, 64);
             ag[j] = ag[j] * s_me + a_o * s_o;
         }
+        m_run = mn;
     }
     // Wo fragments of this wave's output column tiles {wn, wn + 4}: requested before the normalisation and its barrier
     constexpr int kOutNT = 2, kOutKG = 8;  // register form when C <= 128 and heads * v <= 128 (else read in the loop below)
@@ -562,6 +565,11 @@ __global__ __launch_bounds__(kFrThreads) void k_attn_front(const FrontArgs a) {
 #pragma unroll
         for (int j = 0; j < VDM; ++j)
             if (EXACT || j < vd) agg[t_rl * L.ldagg + t_h * vd + j] = ag[j] * inv;
+        if (a.mz_out[net] && row0 + t_rl < a.n_nodes) {
+            float* mz = a.mz_out[net] + (int64_t)(row0 + t_rl) * 3 * nh;
+            mz[t_h] = m_run;
+            mz[nh + t_h] = t_end > t_beg ? z_run : 1.f;
+        }
     }
     if (NVp > NV)
         for (int i = tn; i < kFrRows * (NVp - NV); i += 256) {  // zero the pad columns the k-groups of P9 run over
@@ -570,6 +578,11 @@ __global__ __launch_bounds__(kFrThreads) void k_attn_front(const FrontArgs a) {
         }
     __syncthreads();
     FR_STAMP(28);
+    if (a.agg_out[net])
+        for (int i = tn; i < kFrRows * NV; i += 256) {
+            const int rl = i / NV, c = i - rl * NV;
+            if (row0 + rl < a.n_nodes) a.agg_out[net][(int64_t)(row0 + rl) * NV + c] = agg[rl * L.ldagg + c];
+        }
     // ---- P9: new = agg Wo on the matrix cores, then h0 = [x || new] ------------------------------------------------
     {
         const int off = a.concat ? H : 0;
@@ -627,7 +640,8 @@ bool attn_front_fused_ok(const GnfAttn* at, int32_t H) {
 // packed[q]: the net's fragments (launch_attn_pack).  qkv_out may be NULL.
 int launch_attn_front_fused(const int32_t* rowptr, const int32_t* col, int64_t n, const float* x, int64_t ldx, int32_t H,
                             const GnfAttn* const* at, int nets, int32_t in0, const float* const* packed,
-                            float* const* qkv_out, float* const* h0_out, hipStream_t st) {
+                            float* const* qkv_out, float* const* h0_out, hipStream_t st, float* const* agg_out,
+                            float* const* mz_out) {
     const GnfAttn* a0 = at[0];
     FrontArgs a;
     a.d = front_dims(H, a0->num_heads, a0->kq_dim, a0->v_dim, a0->out_dim);
@@ -638,6 +652,8 @@ int launch_attn_front_fused(const int32_t* rowptr, const int32_t* col, int64_t n
         a.packed[q] = packed[s];
         a.qkv[q] = qkv_out ? qkv_out[s] : nullptr;
         a.h0[q] = h0_out[s];
+        a.agg_out[q] = agg_out ? agg_out[s] : nullptr;
+        a.mz_out[q] = mz_out ? mz_out[s] : nullptr;
     }
     a.rowptr = rowptr, a.col = col, a.x = x, a.ldx = ldx;
     a.n_nodes = (int32_t)n;

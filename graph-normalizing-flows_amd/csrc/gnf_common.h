@@ -80,7 +80,8 @@ bool fused_stash_shape(const GnfMlp* s, const GnfMlp* t, int64_t n);   // forwar
 // both sides: message-passing nets on the fused forward kernel's (1,2) shape AND the merged backward launch
 bool mlp_stash_supported(const GnfFlow* flow, int64_t n, int32_t H);   // gnf_train.hip
 bool fused_supports_oop(const HalfStep& hs);
-// floats of one half-step's slot in GnfFlow.attn_stash ( = attn_scratch_floats: [2][n][P] q|k|v, then [2][n][in0] h0)
+// floats of one half-step's slot in GnfFlow.attn_stash ( = attn_scratch_floats: [2][n][P] q|k|v, [2][n][in0] h0,
+// [2][n][heads*v] attended values, [2][n][3*heads] softmax statistics)
 size_t attn_stash_slot_floats(const GnfFlow* flow, int64_t n_nodes);
 
 // ---- layout of the caller-provided workspace --------------------------------------------------
@@ -187,14 +188,17 @@ size_t attn_scratch_floats(const GnfAttn* at, int64_t n_nodes, int32_t in0);
 int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, const float* x, int64_t ldx,
                       int32_t H, const GnfAttn* const* at, int nets, int32_t in0, float* scratch,
                       float* const* h0_out, hipStream_t st, int64_t n_edges = 0, bool need_qkv = true,
-                      const float* const* packed = nullptr);
+                      const float* const* packed = nullptr, float* const* agg_out = nullptr, float* const* mz_out = nullptr);
+// agg_out / mz_out (training): per net [N, heads*v] attended values and [N, 3*heads] softmax statistics (running max at [h],
+// denominator at [heads + h]; the third block is scratch of the backward pass), kept for launch_attn_backward
 // one-launch front-end for sparse batches (gnf_attn_front.hip), weights pre-packed into fragment order once per flow call
 bool attn_front_fused_ok(const GnfAttn* at, int32_t H);
 size_t attn_pack_floats(const GnfAttn* at, int32_t H);
 int launch_attn_pack(const GnfAttn* const* at, int count, int32_t H, float* out, hipStream_t st);
 int launch_attn_front_fused(const int32_t* rowptr, const int32_t* col, int64_t n, const float* x, int64_t ldx, int32_t H,
                             const GnfAttn* const* at, int nets, int32_t in0, const float* const* packed,
-                            float* const* qkv_out, float* const* h0_out, hipStream_t st);
+                            float* const* qkv_out, float* const* h0_out, hipStream_t st, float* const* agg_out = nullptr,
+                            float* const* mz_out = nullptr);
 // snt.LayerNorm over the feature axis of a block's output (gnn.py:550-552), one or two [N, W] blocks per launch:
 //   u = in (+ xres);  y = (u - mean_f u) / sqrt(var_f u + GNF_LN_EPS) * gamma + beta   (biased variance)
 // y may alias in.  u (may be NULL, may alias in; leading dimension ldin) keeps the un-normalised rows for the backward pass.

@@ -687,8 +687,15 @@ int launch_attn_pair(const HalfStep& hs, float* scratch, float** h0_pair, hipStr
     h0_pair[0] = region + 2 * (size_t)n * P;
     h0_pair[1] = h0_pair[0] + (size_t)n * in0;
     const GnfAttn* at[2] = {hs.s_net->attn, hs.t_net->attn};
+    // a stash slot also keeps the attended values and the softmax statistics (attn_scratch_floats' layout)
+    const size_t NV = (size_t)a0->num_heads * a0->v_dim;
+    float* agg0 = h0_pair[1] + (size_t)n * in0;
+    float* mz0 = agg0 + 2 * (size_t)n * NV;
+    float* agg_out[2] = {agg0, agg0 + (size_t)n * NV};
+    float* mz_out[2] = {mz0, mz0 + (size_t)n * 3 * a0->num_heads};
+    const bool keep = hs.attn_region != nullptr;
     return launch_attn_front(hs.rowptr, hs.col, n, hs.x_cond, hs.ld, hs.H, at, 2, in0, region, h0_pair, st, hs.n_edges,
-                             /*need_qkv=*/hs.attn_region != nullptr, hs.attn_packed);
+                             /*need_qkv=*/keep, hs.attn_packed, keep ? agg_out : nullptr, keep ? mz_out : nullptr);
 }
 
 int launch_coupling(const float* sbuf, const float* tbuf, const HalfStep& hs, const float* xres, hipStream_t st) {

@@ -36,6 +36,7 @@ enum OptionId {
     OPT_BWD_NO_FOLD,         // ... and the message-passing backward in a launch of its own instead of the next half-step's prologue
     OPT_NO_MLP_STASH,        // ignore GnfFlow.mlp_stash (the backward walk recomputes the MLP rows)
     OPT_ATTN_BWD_ROWS,       // attention rows kernels: 64 / 32 (backward also 16) rows per workgroup (0 = by batch size / mean degree)
+    OPT_ATTN_BWD_SPLIT,      // attention backward on sparse batches: receiver and sender pass as two launches (A/B)
     OPT_COUNT
 };
 

@@ -2611,6 +2611,9 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                     o.qkv[q] = slot + (size_t)q * n * p.P;
                     o.h0[q] = slot + 2 * (size_t)n * p.P + (size_t)q * n * p.in0;
                     o.hin[q * p.K] = o.h0[q];
+                    // attended values (A operand of dWo) and softmax statistics of the forward pass
+                    o.agg[q] = slot + 2 * (size_t)n * (p.P + p.in0) + (size_t)q * n * p.NV;
+                    o.stats[q] = slot + 2 * (size_t)n * (p.P + p.in0 + p.NV) + (size_t)q * n * 3 * p.nh;
                 }
             }
             float* x_cond = z + co;
@@ -2621,7 +2624,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 const GnfAttn* at[2] = {nets[0]->attn, nets[1]->attn};
                 if (!stashed) {
                     rc = launch_attn_front(csr->rowptr, csr->col, n, x_cond, ld, H, at, 2, p.in0, o.qkv[0], o.h0, st,
-                                           csr->n_edges);
+                                           csr->n_edges, true, nullptr, o.agg, o.stats);
                     if (rc) return rc;
                 }
                 int64_t blocks = (n * H + 255) / 256;

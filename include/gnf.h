@@ -184,7 +184,7 @@ int gnf_abi_version(void);
  * use to reach every code path).  value 0 = automatic.  Names: force_shape (<MT><NETS>, e.g. 21), flow_no_oop,
  * (out-of-place flows copy first instead of running the first half-step out of place), attn_edge_tiled, attn_rows,
  * attn_lane_feature, gemm_no_buf, gemm_lds_direct, gemm_no_splitk, layered_own_gemm, dw_grouped, dw_wide_units,
- * dw_wide_lds, dw_no_streamk, dw_no_buf, dw_debug, dw_late_fork, bwd_generic, dw_unmerged, bwd_no_fold, no_mlp_stash, attn_bwd_rows
+ * dw_wide_lds, dw_no_streamk, dw_no_buf, dw_debug, dw_late_fork, bwd_generic, dw_unmerged, bwd_no_fold, no_mlp_stash, attn_bwd_rows, attn_bwd_split
  * (the training walk's merged backward + dW launch and the MLP-row stash).  Process-wide, relaxed atomics: takes effect
  * for calls made after it returns.  Unknown name: GNF_EINVAL.  Nothing in the reference corresponds to these. */
 int gnf_set_option(const char* name, int64_t value);
