@@ -739,6 +739,11 @@ struct AttnDxArgs {
     const float* bn_gamma;
     const float* bn_beta;
     double* bn_part;
+    // the conditioning half as the attention dW GEMMs will read it (it changes under the bijector's backward pass and the
+    // next half-step before they run): copied here, by the last kernel of the half-step that sees it intact (NULL: no copy)
+    const float* xc_src;
+    int64_t xc_ld;
+    float* xc_dst;  // [n][H]
 };
 
 static constexpr int kDxRows = 8;  // rows per workgroup
@@ -751,6 +756,11 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dx(const AttnDxArgs a) {
     const int tid = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * kDxRows;
     const int rows = (int)((a.n - row0) < kDxRows ? (a.n - row0) : kDxRows);
+    if (a.xc_dst)
+        for (int i = tid; i < rows * H; i += 256) {
+            const int rl = i / H, f = i - rl * H;
+            a.xc_dst[(row0 + rl) * H + f] = a.xc_src[(row0 + rl) * a.xc_ld + f];
+        }
     for (int net = 0; net < 2; ++net) {
         __syncthreads();
         for (int base = 0; base < H * P; base += 256 * 8) {  // loads first, stores after
@@ -821,7 +831,7 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
                          const int32_t* col, const int32_t* rowptr_t, const int32_t* col_t, const float* const* qkv,
                          const float* const* dh0, const float* const* gst, float* const* dqkv, float* const* agg,
                          float* const* dagg, float* const* stats, float* g_cond, int64_t ldg, hipStream_t st, int64_t n_edges,
-                         const AttnBnFold* bn) {
+                         const AttnBnFold* bn, const float* xc_src, int64_t xc_ld, float* xc_dst) {
     if (n == 0) return GNF_OK;
     const GnfAttn* a0 = at[0];
     AttnBwdArgs a;
@@ -983,6 +993,7 @@ dx_pass:
     d.v = a.v;
     d.in0 = in0;
     d.concat = a.concat;
+    d.xc_src = xc_src, d.xc_ld = xc_ld, d.xc_dst = xc_dst;
     const int64_t dx_blocks = (n + kDxRows - 1) / kDxRows;
     d.bn_y = nullptr, d.bn_ld = 0, d.bn_gamma = d.bn_beta = nullptr, d.bn_part = nullptr;
     if (bn && bn->n_parts) *bn->n_parts = 0;

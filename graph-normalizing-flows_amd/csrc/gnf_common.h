@@ -161,7 +161,10 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
                          const float* const* dh0, const float* const* gst, float* const* dqkv, float* const* agg,
                          float* const* dagg, float* const* stats, float* g_cond, int64_t ldg, hipStream_t st,
                          int64_t n_edges = 0,   // 0 = unknown (picks between tile sizes by mean degree)
-                         const AttnBnFold* bn = nullptr);
+                         const AttnBnFold* bn = nullptr,
+                         // xc_dst != NULL: the last kernel also copies the conditioning half [n, H] (leading dimension xc_ld)
+                         // into xc_dst [n][H] for the dW GEMMs that run after it has changed
+                         const float* xc_src = nullptr, int64_t xc_ld = 0, float* xc_dst = nullptr);
 
 
 // thin y = act(x W + b) through the split-K generic GEMM (gnf_train.hip); 1 = not thin, the caller runs its own kernel

@@ -2571,7 +2571,8 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     bool used[2] = {false, false};  // weight sharing: the T uses of a net accumulate
     // the attention front-end backwards: dagg = dnew Wo^T ([nodes, C] x [C, heads*v]; Wo is [heads*v, C]: rows = output
     // columns), then the edge kernels; dL/dx_cond accumulates into g_cond
-    auto attention_backward = [&](const GnfMlp* const* nets_, const BwdOperands& o_, float* g_cond, const AttnBnFold* bnf = nullptr) -> int {
+    auto attention_backward = [&](const GnfMlp* const* nets_, const BwdOperands& o_, float* g_cond, const AttnBnFold* bnf,
+                                  const float* x_cond_) -> int {
         const GnfAttn* at[2] = {nets_[0]->attn, nets_[1]->attn};
         const int off = at[0]->concat ? D / 2 : 0;
         GemmJob jobs[2];
@@ -2583,7 +2584,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
         int rc_ = launch_gemm<OPND_KC, OPND_KC, EPI_MASK>(jobs, 2, sh, st);
         if (rc_) return rc_;
         return launch_attn_backward(at, n, D / 2, p.in0, csr->rowptr, csr->col, csr_t->rowptr, csr_t->col, o_.qkv, o_.dh0, o_.gst,
-                                    o_.dqkv, o_.agg, o_.dagg, o_.stats, g_cond, D, st, csr->n_edges, bnf);
+                                    o_.dqkv, o_.agg, o_.dagg, o_.stats, g_cond, D, st, csr->n_edges, bnf, x_cond_, ld, o_.xc);
     };
     int32_t bn_pre = 0;  // batch-norm backward moments left by the attention backward's last kernel (partial rows)
     DwLaunch pend[2];
@@ -2627,11 +2628,8 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                                            csr->n_edges, true, nullptr, o.agg, o.stats);
                     if (rc) return rc;
                 }
-                int64_t blocks = (n * H + 255) / 256;
-                if (blocks > 4096) blocks = 4096;
-                hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)blocks), dim3(256), 0, st, x_cond, ld, o.xc, (int64_t)H, n, H,
-                                   (const int32_t*)nullptr, (float*)nullptr);
-                GNF_LAUNCH_CHECK("k_copy_rows");
+                // (the conditioning half as the dW GEMMs of Wq / Wk / Wv read it, o.xc, is copied by the attention
+                // backward's last kernel: launch_attn_backward)
             } else if (!fused) {
                 rc = launch_aggregate(csr->rowptr, csr->col, n, x_cond, ld, H, flow->gnn.agg == GNF_AGG_MEAN,
                                       flow->gnn.combine == GNF_COMBINE_CONCAT ? 1 : 0, flow->gnn.epsilon, o.h0[0], p.in0, st);
@@ -2699,7 +2697,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                     const AttnBnFold bnf{z + co, ld, bq ? bq->gamma : nullptr, bq ? bq->beta : nullptr,
                                          reinterpret_cast<double*>(wsf + p.bnpart), &bn_pre};
                     bn_pre = 0;
-                    rc = attention_backward(nets, o, g + co, bq ? &bnf : nullptr);
+                    rc = attention_backward(nets, o, g + co, bq ? &bnf : nullptr, x_cond);
                     if (rc) return rc;
                 } else if (have_fold) {
                     fold_dh[0] = o.dh0[0], fold_dh[1] = o.dh0[1];
@@ -2756,7 +2754,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 const AttnBnFold bnf{z + co, ld, bq ? bq->gamma : nullptr, bq ? bq->beta : nullptr,
                                      reinterpret_cast<double*>(wsf + p.bnpart), &bn_pre};
                 bn_pre = 0;
-                rc = attention_backward(nets, o, g + co, bq ? &bnf : nullptr);
+                rc = attention_backward(nets, o, g + co, bq ? &bnf : nullptr, x_cond);
             } else {
                 rc = launch_aggregate_bwd(p, csr_t, flow->gnn, wsf + p.invdeg, o.dh0[0], o.dh0[1], g + co, D, st);
             }
