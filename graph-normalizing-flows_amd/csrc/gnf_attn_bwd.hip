@@ -823,6 +823,103 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dx(const AttnDxArgs a) {
     }
 }
 
+// The same with BOTH nets' operands in LDS at once: every global load of the workgroup (2 x Wcat, 2 x kDxRows dqkv rows,
+// g, dh0, gst) is in flight before the first LDS store, then one barrier, one pass over 2 P products per thread and one
+// store of g - two round trips to memory instead of ten.  NQ / VD: compile-time heads*kq and v (0 = run-time values; the
+// reference's geometry gets an instance whose index arithmetic has no divisions).  Needs kDxRows * H <= 256.
+static constexpr int kDx2Loads = 24;  // W elements per thread per net held in registers (256 x 24 >= H * P)
+template <int NQ, int VD>
+__global__ __launch_bounds__(256) void k_attn_bwd_dx2(const AttnDxArgs a) {
+    extern __shared__ float sm[];  // [2] Wcat [H][P + 1] | [2] dqkv rows [kDxRows][P] | bn scratch [2][kDxRows][H]
+    const int nq = NQ ? NQ : a.nq, vd = VD ? VD : a.v;
+    const int P = 2 * nq + vd, P1 = P + 1, H = a.H;
+    float* wl = sm;
+    float* dl = wl + 2 * H * P1;
+    const int tid = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * kDxRows;
+    const int rows = (int)((a.n - row0) < kDxRows ? (a.n - row0) : kDxRows);
+    float wreg[2][kDx2Loads], dreg[2][6];
+#pragma unroll
+    for (int net = 0; net < 2; ++net) {
+        const float *Wq = a.Wq[net], *Wk = a.Wk[net], *Wv = a.Wv[net];
+#pragma unroll
+        for (int q = 0; q < kDx2Loads; ++q) {
+            const int i0 = tid + q * 256;
+            const int i = i0 < H * P ? i0 : 0;
+            const int f = i / P, c = i - f * P;
+            wreg[net][q] = c < nq ? Wq[f * nq + c] : (c < 2 * nq ? Wk[f * nq + (c - nq)] : Wv[f * vd + (c - 2 * nq)]);
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int i = tid + q * 256;
+            dreg[net][q] = a.dqkv[net][row0 * P + (i < rows * P ? i : 0)];
+        }
+    }
+    const int rl0 = tid / H, f0 = tid - rl0 * H;
+    const bool live = tid < rows * H;
+    float s0 = 0.f, xc = 0.f;
+    if (live) {
+        const int64_t r = row0 + rl0;
+        s0 = a.g[r * a.ldg + f0];
+#pragma unroll
+        for (int net = 0; net < 2; ++net) {
+            if (a.concat) s0 += a.dh0[net][r * a.in0 + f0];
+            if (a.gst[net]) s0 += a.gst[net][r * H + f0];
+        }
+        if (a.xc_dst) xc = a.xc_src[r * a.xc_ld + f0];
+    }
+#pragma unroll
+    for (int net = 0; net < 2; ++net) {
+#pragma unroll
+        for (int q = 0; q < kDx2Loads; ++q) {
+            const int i = tid + q * 256;
+            if (i < H * P) wl[net * H * P1 + (i / P) * P1 + (i % P)] = wreg[net][q];
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int i = tid + q * 256;
+            if (i < rows * P) dl[net * kDxRows * P + i] = dreg[net][q];
+        }
+    }
+    for (int i = tid + 6 * 256; i < rows * P; i += 256)  // (P > 192: the rest of the rows, plainly)
+        for (int net = 0; net < 2; ++net) dl[net * kDxRows * P + i] = a.dqkv[net][row0 * P + i];
+    __syncthreads();
+    float gv = 0.f;
+    if (live) {
+        float s = 0.f;
+#pragma unroll
+        for (int net = 0; net < 2; ++net) {
+            const float* d = dl + net * kDxRows * P + rl0 * P;
+            const float* w = wl + net * H * P1 + f0 * P1;
+            float sn = 0.f;
+#pragma unroll 10
+            for (int c = 0; c < P; ++c) sn += d[c] * w[c];
+            s += sn;
+        }
+        gv = s0 + s;
+        a.g[(row0 + rl0) * a.ldg + f0] = gv;
+        if (a.xc_dst) a.xc_dst[(row0 + rl0) * H + f0] = xc;
+    }
+    if (a.bn_part) {
+        float* bg = dl + 2 * kDxRows * P;   // [kDxRows][H] G | [kDxRows][H] G x^
+        float* bx = bg + kDxRows * H;
+        if (tid < kDxRows * H) {
+            float gx = 0.f;
+            if (live) gx = gv * ((a.bn_y[(row0 + rl0) * a.bn_ld + f0] - a.bn_beta[f0]) / a.bn_gamma[f0]);
+            bg[tid] = live ? gv : 0.f;
+            bx[tid] = gx;
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * H; i += 256) {
+            const int f = i >> 1, which = i & 1;
+            const float* src = which ? bx : bg;
+            double acc = 0.0;
+            for (int rl = 0; rl < kDxRows; ++rl) acc += (double)src[rl * H + f];
+            a.bn_part[((int64_t)blockIdx.x * H + f) * 2 + which] = acc;
+        }
+    }
+}
+
 // at[2]: the two attention blocks; qkv: [2][N, P] forward projections (launch_attn_front's scratch);
 // dh0 / gst: per net;  dqkv: per net outputs kept for the dW GEMMs;  dagg = dnew Wo^T [N, heads*v] (computed by the
 // caller with the matrix-core GEMM);  agg / stats: the forward pass's attended values and softmax statistics
@@ -1001,7 +1098,15 @@ dx_pass:
         d.bn_y = bn->y, d.bn_ld = bn->ld, d.bn_gamma = bn->gamma, d.bn_beta = bn->beta, d.bn_part = bn->part;
         if (bn->n_parts) *bn->n_parts = (int32_t)dx_blocks;
     }
-    hipLaunchKernelGGL(k_attn_bwd_dx, dim3((unsigned)dx_blocks), dim3(256), lds_x, st, d);
+    const size_t lds_x2 = (2 * ((size_t)H * (P + 1) + (size_t)kDxRows * P) + (size_t)2 * kDxRows * H) * sizeof(float);
+    if (kDxRows * H <= 256 && H * P <= 256 * kDx2Loads && lds_x2 <= 64 * 1024 && !opt(OPT_ATTN_BWD_SPLIT)) {
+        if (d.nq == 80 && d.v == 10)  // the reference's head geometry (run_grevnet.py:74-76)
+            hipLaunchKernelGGL((k_attn_bwd_dx2<80, 10>), dim3((unsigned)dx_blocks), dim3(256), lds_x2, st, d);
+        else
+            hipLaunchKernelGGL((k_attn_bwd_dx2<0, 0>), dim3((unsigned)dx_blocks), dim3(256), lds_x2, st, d);
+    } else {
+        hipLaunchKernelGGL(k_attn_bwd_dx, dim3((unsigned)dx_blocks), dim3(256), lds_x, st, d);
+    }
     GNF_LAUNCH_CHECK("k_attn_bwd_dx");
     return GNF_OK;
 }

@@ -390,12 +390,16 @@ def test_layer_norm_parameters_train(community_medium):
     assert np.abs(blk.attn_params["ln_beta"].cpu().numpy()).max() > 0.0
 
 
-@pytest.mark.parametrize("rows", [16, 32, 64])
-def test_attention_backward_row_tile_sizes(community_medium, rows):
-    """k_attn_bwd_recv_rows / _send_rows exist for 64-, 32- and 16-row tiles, k_attn_fwd_rows for 64 and 32 (the library
+@pytest.mark.parametrize("rows,split", [(16, 0), (32, 0), (64, 0), (3264, 0), (32, 1), (64, 1)],
+                         ids=["16", "32", "64", "32s64r", "32-two-launches", "64-two-launches"])
+def test_attention_backward_row_tile_sizes(community_medium, rows, split):
+    """The attention backward's edge passes exist for 64-, 32- and 16-row tiles, k_attn_fwd_rows for 64 and 32 (the library
     picks by batch size and mean degree; the developer option attn_bwd_rows forces one; 32-row tiles split every row's
-    edges over two lanes): the same loss and gradients through each.  attn_rows=1 keeps the sparse batch on the rows
-    kernels in the forward pass too."""
+    edges over two lanes), and on sparse batches as ONE launch (k_attn_bwd_edges: sender tiles, which then carry the
+    receivers' softmax statistics and delta in their LDS window, and receiver tiles; 3264 = 32-row sender / 64-row
+    receiver tiles) or as two (attn_bwd_split=1, what dense batches take; 16-row tiles always; also the older
+    k_attn_bwd_dx): the same loss and gradients through each.  attn_rows=1 keeps the sparse batch on the rows kernels in
+    the forward pass too."""
     from gnf_amd import _abi
     from gnf_amd.train import GRevNetTrainer
     attn = dict(num_heads=4, kq_dim=6, v_dim=5, out_dim=12, concat=True, kq_dim_division=True, residual=False)
@@ -407,6 +411,7 @@ def test_attention_backward_row_tile_sizes(community_medium, rows):
     p = O.make_attn_grevnet_params(13, 6, 32, 2, 2, final_scale=0.3, **attn)
     ref = O.loss_and_grads(s, r, n, x, p, 2, activation="relu")
     _abi.set_option("attn_bwd_rows", rows)
+    _abi.set_option("attn_bwd_split", split)
     _abi.set_option("attn_rows", 1)
     try:
         tr = GRevNetTrainer(make_product_grevnet(hp, p))
@@ -414,10 +419,56 @@ def test_attention_backward_row_tile_sizes(community_medium, rows):
         torch.cuda.synchronize()
     finally:
         _abi.set_option("attn_bwd_rows", 0)
+        _abi.set_option("attn_bwd_split", 0)
         _abi.set_option("attn_rows", 0)
     assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
     for (name, a), (_, b) in zip(_flat_attn(tr.named_gradients(), False), _flat_attn(ref["grads"], False)):
         assert np.abs(a - b).max() <= 5e-4 * np.abs(b).max() + 1e-5, name
+
+
+def test_attention_backward_window_wider_than_lds():
+    """A sparse batch whose graphs are too large for the edge passes' LDS row window (one 1500-node graph with random
+    long-range edges next to a small one): the tiles read their rows from global memory instead, and in the one-launch
+    form the sender tiles then form delta = <dagg, attended> per edge themselves (nothing a receiver tile of the same
+    launch writes may be read) - same gradients, both forms."""
+    from gnf_amd import _abi
+    from gnf_amd.train import GRevNetTrainer
+    attn = dict(num_heads=4, kq_dim=6, v_dim=5, out_dim=12, concat=True, kq_dim_division=True, residual=False)
+    hp = dict(D=8, latent=16, K=2, T=1, agg="mean", combine="agg", epsilon=0.0, activation="relu",
+              weight_sharing=False, attn=attn)
+    rng = np.random.default_rng(77)
+    sizes = [1500, 9]
+    s_l, r_l, ne, off = [], [], [], 0
+    for m in sizes:
+        a = rng.integers(0, m, size=3 * m)
+        b = rng.integers(0, m, size=3 * m)
+        pairs = {(int(i), int(i)) for i in range(m)}
+        for u, v in zip(a, b):
+            pairs.add((int(u), int(v)))
+            pairs.add((int(v), int(u)))
+        pairs = sorted(pairs)
+        s_l.append(np.array([u for u, _ in pairs], np.int32) + off)
+        r_l.append(np.array([v for _, v in pairs], np.int32) + off)
+        ne.append(len(pairs))
+        off += m
+    nn, ne = np.array(sizes, np.int32), np.array(ne, np.int32)
+    s, r = np.concatenate(s_l), np.concatenate(r_l)
+    n = int(nn.sum())
+    assert len(s) < 24 * n     # sparse: the one-launch form
+    x = rng.standard_normal((n, 8)).astype(np.float32)
+    p = O.make_attn_grevnet_params(5, 4, 16, 2, 1, final_scale=0.3, **attn)
+    ref = O.loss_and_grads(s, r, n, x, p, 1, activation="relu")
+    for split in (0, 1):
+        _abi.set_option("attn_bwd_split", split)
+        try:
+            tr = GRevNetTrainer(make_product_grevnet(hp, p))
+            out = tr.loss_and_grads(graph_from_arrays(nn, ne, s, r, x, DEV))
+            torch.cuda.synchronize()
+        finally:
+            _abi.set_option("attn_bwd_split", 0)
+        assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
+        for (name, a), (_, b) in zip(_flat_attn(tr.named_gradients(), False), _flat_attn(ref["grads"], False)):
+            assert np.abs(a - b).max() <= 5e-4 * np.abs(b).max() + 1e-5, (split, name)
 
 
 def test_attention_gradients_high_degree_rows():
