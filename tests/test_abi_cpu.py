@@ -139,7 +139,8 @@ def test_missing_library_raises(monkeypatch, tmp_path):
 
 def test_abi_v5_size_helpers_are_host_computations():
     """gnf_clip_workspace_bytes / gnf_attn_stash_bytes touch no device: 64 fp64 partials per tensor; the stash is
-    zero without an attention front-end and 2T slots of 2 n (P + in0) floats with one."""
+    zero without an attention front-end and 2T slots of 2 n (P + in0 + heads v + 3 heads) floats with one (q | k | v,
+    layer-0 inputs, attended values, softmax statistics of both nets)."""
     lib = _abi.lib()
     assert lib.gnf_clip_workspace_bytes(0) == 0
     assert lib.gnf_clip_workspace_bytes(7) == 7 * 64 * 8
@@ -155,5 +156,5 @@ def test_abi_v5_size_helpers_are_host_computations():
     fa = _abi.GnfFlow(3, 1, C.cast(sa, C.POINTER(_abi.GnfMlp)), C.cast(sa, C.POINTER(_abi.GnfMlp)),
                       _abi.GnfGnnSpec(1, 0, 1.0, 1, 0.2))
     p = 2 * 4 * 5 + 6
-    assert lib.gnf_attn_stash_bytes(100, 16, C.byref(fa)) == 2 * 3 * (2 * 100 * (p + 20)) * 4
+    assert lib.gnf_attn_stash_bytes(100, 16, C.byref(fa)) == 2 * 3 * (2 * 100 * (p + 20 + 4 * 6 + 3 * 4)) * 4
     assert lib.gnf_attn_stash_bytes(0, 16, C.byref(fa)) == 0
