@@ -291,7 +291,11 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
     GNF_STAMP(0);
     // ---- weights of the first chunk start streaming before anything else -----------------------
     f32x4 b_pre[kPF][4];
-    prefetch_chunk(cur, WPN, voff, b_pre, !STASH && MT == 1 && !(a.variant & 1));
+    // thin-chunk form (gnf_fused_dev.h) of a one-tile chunk: everywhere in the inference instances; the stash instance
+    // only in the LAST layer (a hidden layer's epilogue there also leaves the act' ballots, which the thin form does not do).
+    // The prefetch of a chunk packs its registers for the form that will consume it: both sides ask thin_for(layer).
+    auto thin_for = [&](int layer) { return MT == 1 && !(a.variant & 1) && (!STASH || layer == a.K - 1); };
+    prefetch_chunk(cur, WPN, voff, b_pre, thin_for(cur.layer));
     GNF_PSTAMP(0);
     // ---- every independent global read of the prologue is ISSUED before any is consumed: rowptr of
     // the tile, the biases (<= 8 floats per thread in registers), the layer table - one memory round
@@ -393,9 +397,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
             const WChunk nx = nxt.layer < a.K ? nxt : c;  // no next chunk: harmless re-load
             const float* bl = bias_lds + nl * a.bias_tot + c.boff;
             constexpr bool kThin = MT == 1;  // the thin-chunk form keeps 32 fragments in registers: one M-tile only
-            // (STASH: the masks come out of mlp_chunk's epilogue, and the thin form's prefetch packing must match the
-            // form that consumes it - the stash instance does without the thin form)
-            const bool thin_ok = !STASH && kThin && !(a.variant & 1);
+            const bool thin_ok = kThin && thin_for(j), thin_nx = kThin && thin_for(nx.layer);
             // STASH: a hidden layer's epilogue also leaves the ballot of "activation > 0" (act' for the backward pass) in
             // LDS, word [net][layer][4 m + r][column tile] - the recompute rows of the backward kernel write the same words
             constexpr int EPI = STASH ? EPI_EX : EPI_PLAIN;
@@ -406,15 +408,15 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
                 ea.mld = a.stash_mld;
             }
             if (c.nv >= 4)
-                mlp_chunk<MT, 4, EPI>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea, thin_ok);
+                mlp_chunk<MT, 4, EPI>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea, thin_nx);
             else if (c.nv == 3)
-                mlp_chunk<MT, 3, EPI>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea, thin_ok);
+                mlp_chunk<MT, 3, EPI>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea, thin_nx);
             else if (c.nv == 2)
-                mlp_chunk<MT, 2, EPI>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea, thin_ok);
+                mlp_chunk<MT, 2, EPI>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea, thin_nx);
             else if (kThin && thin_ok && chunk_is_thin(c))
                 mlp_chunk_thin(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre);
             else
-                mlp_chunk<MT, 1, EPI>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea, thin_ok);
+                mlp_chunk<MT, 1, EPI>(in_lds, LS, c, nx, WPN, bl, out_lds, slope, lane, b_pre, ea, thin_nx);
             cur = nxt;
         }
         if constexpr (STASH && NETS == 2) {
