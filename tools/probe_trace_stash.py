@@ -38,6 +38,13 @@ def read(label):
     for sl in range(16):
         if names[sl] != "-":
             print(f"{names[sl]:14s} " + " ".join(f"{int(t[w, sl] - t0):8d}" for w in range(8)))
+    st = (C.c_ulonglong * 320)()
+    if hasattr(raw, "gnf_debug_read_stages") and raw.gnf_debug_read_stages(st) == 0:
+        g = np.array(list(st), dtype=np.int64).reshape(8, 40)
+        base = t[:, 4]  # barrier before layer 1
+        print("layer-1 stage stamps relative to the layer's opening barrier (0 = chunk entry, 2+kg = after stage kg, 38 = MFMAs done)")
+        for sl in [0] + list(range(2, 18)) + [38]:
+            print(f"{sl:3d} " + " ".join(f"{int(g[w, sl] - base[w]):8d}" for w in range(8)))
 
 
 for stash in (False, True):
