@@ -163,8 +163,8 @@ typedef struct GnfFlow {
     /* ABI v5: optional stash of the attention front-end (attention GNNs only; NULL = none).  The reversible backward
      * pass recomputes every half-step's activations from the reconstructed inputs; for the attention front-end
      * (q | k | v projections, edge softmax, attended values: the costliest part of such a half-step) that recompute
-     * can be traded for memory: gnf_grevnet_f32(GNF_FORWARD) then leaves each half-step's q | k | v and layer-0 inputs
-     * of both nets in attn_stash, and gnf_grevnet_backward_f32 - called next with the SAME flow, graph and the z that
+     * can be traded for memory: gnf_grevnet_f32(GNF_FORWARD) then leaves each half-step's q | k | v, layer-0 inputs,
+     * attended values and softmax statistics of both nets in attn_stash, and gnf_grevnet_backward_f32 - called next with the SAME flow, graph and the z that
      * forward produced - reads them instead of recomputing.  gnf_attn_stash_bytes() sizes it (2T slots). */
     float* attn_stash;
     size_t attn_stash_bytes;
