@@ -471,6 +471,45 @@ def test_attention_backward_window_wider_than_lds():
             assert np.abs(a - b).max() <= 5e-4 * np.abs(b).max() + 1e-5, (split, name)
 
 
+def test_attention_backward_statistics_from_the_edge_tiled_forward():
+    """The backward walk that RECOMPUTES the attention front-end (no stash) runs the two-launch forward kernels; on a
+    sparse batch that is k_attn_agg, which takes a workgroup's edges 256 at a time - here 64 receiver rows of mean degree
+    ~20 per workgroup, several edge tiles each (max pass first) - and leaves the softmax statistics and attended values
+    the single-sweep backward kernels read."""
+    from gnf_amd.train import GRevNetTrainer
+    attn = dict(num_heads=2, kq_dim=5, v_dim=3, out_dim=7, concat=True, kq_dim_division=False, residual=False)
+    hp = dict(D=6, latent=16, K=2, T=1, agg="mean", combine="agg", epsilon=0.0, activation="relu",
+              weight_sharing=False, attn=attn)
+    rng = np.random.default_rng(31)
+    sizes = [260, 40]
+    s_l, r_l, ne, off = [], [], [], 0
+    for m in sizes:
+        pairs = {(i, i) for i in range(m)}
+        for u, v in zip(rng.integers(0, m, size=9 * m), rng.integers(0, m, size=9 * m)):
+            pairs.add((int(u), int(v)))
+            pairs.add((int(v), int(u)))
+        pairs = sorted(pairs)
+        s_l.append(np.array([u for u, _ in pairs], np.int32) + off)
+        r_l.append(np.array([v for _, v in pairs], np.int32) + off)
+        ne.append(len(pairs))
+        off += m
+    nn, ne = np.array(sizes, np.int32), np.array(ne, np.int32)
+    s, r = np.concatenate(s_l), np.concatenate(r_l)
+    n = int(nn.sum())
+    assert 12 * n < len(s) < 24 * n     # sparse by the library's rule, yet > 256 edges per 64 rows
+    x = rng.standard_normal((n, 6)).astype(np.float32)
+    p = O.make_attn_grevnet_params(9, 3, 16, 2, 1, final_scale=0.3, **attn)
+    ref = O.loss_and_grads(s, r, n, x, p, 1, activation="relu")
+    tr = GRevNetTrainer(make_product_grevnet(hp, p))
+    tr.stash_attention = False
+    tr.stash_mlp_rows = False
+    out = tr.loss_and_grads(graph_from_arrays(nn, ne, s, r, x, DEV))
+    torch.cuda.synchronize()
+    assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
+    for (name, a), (_, b) in zip(_flat_attn(tr.named_gradients(), False), _flat_attn(ref["grads"], False)):
+        assert np.abs(a - b).max() <= 5e-4 * np.abs(b).max() + 1e-5, name
+
+
 def test_attention_gradients_high_degree_rows():
     """Complete topology with a 70-node graph: rows with more than 64 in / out edges take the kernels' general
     (edge-tiled) path, the 9-node graph next to it the LDS-resident one."""
