@@ -508,13 +508,13 @@ __global__ __launch_bounds__(512) void k_attn_fwd_rows(const AttnArgs a, int win
     __syncthreads();
     GNF_ATRACE(1);
     const float* qkv = a.qkv[net];
+    bool cols_in_lds = false;
     const int lo = stage_window(a.col, s_rp, ROWS, s_hdr, win_cap, tid, 512, [&](int lo_, int cnt) {
         window_copy(win, WS, cnt, nq + vd, tid, 512, [&](int rr, int c) {
             return qkv[(int64_t)(lo_ + rr) * P + (c < nq ? c : nq + c)];   // q at [0, nq), v at [2 nq, 2 nq + vd)
         });
-    });
+    }, s_col, kRowsColCap, &cols_in_lds);
     GNF_ATRACE(2);
-    const bool cols_in_lds = stage_cols(a.col, s_rp, ROWS, s_col, kRowsColCap, tid, 512);
     __syncthreads();
     GNF_ATRACE(3);
     const int* cols = cols_in_lds ? s_col : a.col;

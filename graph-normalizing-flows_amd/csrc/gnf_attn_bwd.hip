@@ -495,12 +495,12 @@ __device__ __forceinline__ void attn_recv_tile(const AttnBwdArgs& a, int net, in
     }
     __syncthreads();
     const float* qkv = a.qkv[net];
+    bool cols_in_lds = false;
     const int lo = stage_window(a.col, s_rp, ROWS, s_hdr, win_cap, tid, 512, [&](int lo_, int cnt) {
         window_copy(win, WS, cnt, nq + vd, tid, 512, [&](int rr, int c) {
             return qkv[(int64_t)(lo_ + rr) * P + (c < nq ? c : nq + c)];
         });
-    });
-    const bool cols_in_lds = stage_cols(a.col, s_rp, ROWS, s_col, kRowsColCap, tid, 512);
+    }, s_col, kRowsColCap, &cols_in_lds);
     __syncthreads();
     const int* cols = cols_in_lds ? s_col : a.col;
     const int col_base = cols_in_lds ? s_rp[0] : 0;
@@ -647,6 +647,7 @@ __device__ __forceinline__ void attn_send_tile(const AttnBwdArgs& a, int net, in
     const float* qkv = a.qkv[net];
     const float* dagg = a.dagg[net];
     const float* stats = a.stats[net];
+    bool cols_in_lds = false;
     const int lo = stage_window(a.col_t, s_rp, ROWS, s_hdr, win_cap, tid, 512, [&](int lo_, int cnt) {
         window_copy(win, WS, cnt, nq + NV + (SW ? 2 * nh : 0), tid, 512, [&](int rr, int c) {
             const int64_t r = lo_ + rr;
@@ -654,7 +655,7 @@ __device__ __forceinline__ void attn_send_tile(const AttnBwdArgs& a, int net, in
             if (c < nq + NV) return dagg[r * NV + (c - nq)];
             return stats[r * 3 * nh + (c - nq - NV)];
         });
-    });
+    }, s_col, kRowsColCap, &cols_in_lds);
     if (SW && lo >= 0) {  // delta of the window rows: <dagg (staged), agg> per head
         const float* agg = a.agg[net];
         const int cells = (s_hdr[1] - lo + 1) * nh;
@@ -667,7 +668,6 @@ __device__ __forceinline__ void attn_send_tile(const AttnBwdArgs& a, int net, in
             win[rr * WS + nq + NV + 2 * nh + h] = d;
         }
     }
-    const bool cols_in_lds = stage_cols(a.col_t, s_rp, ROWS, s_col, kRowsColCap, tid, 512);
     __syncthreads();
     const int* cols = cols_in_lds ? s_col : a.col_t;
     const int col_base = cols_in_lds ? s_rp[0] : 0;
