@@ -510,9 +510,16 @@ __global__ __launch_bounds__(512) void k_attn_fwd_rows(const AttnArgs a, int win
     const float* qkv = a.qkv[net];
     bool cols_in_lds = false;
     const int lo = stage_window(a.col, s_rp, ROWS, s_hdr, win_cap, tid, 512, [&](int lo_, int cnt) {
-        window_copy(win, WS, cnt, nq + vd, tid, 512, [&](int rr, int c) {
-            return qkv[(int64_t)(lo_ + rr) * P + (c < nq ? c : nq + c)];   // q at [0, nq), v at [2 nq, 2 nq + vd)
-        });
+        // q at [0, nq), v at [2 nq, 2 nq + vd) of a row; in 8-byte units when every segment starts on an even column
+        if (((nq | vd) & 1) == 0 && (reinterpret_cast<uintptr_t>(qkv) & 7) == 0 && (reinterpret_cast<uintptr_t>(win) & 7) == 0)
+            window_copy2(win, WS, cnt, (nq + vd) >> 1, tid, 512, [&](int rr, int c2) {
+                const int c = 2 * c2;
+                return *reinterpret_cast<const f32x2_win*>(qkv + (int64_t)(lo_ + rr) * P + (c < nq ? c : nq + c));
+            });
+        else
+            window_copy(win, WS, cnt, nq + vd, tid, 512, [&](int rr, int c) {
+                return qkv[(int64_t)(lo_ + rr) * P + (c < nq ? c : nq + c)];
+            });
     }, s_col, kRowsColCap, &cols_in_lds);
     GNF_ATRACE(2);
     __syncthreads();

@@ -497,9 +497,16 @@ __device__ __forceinline__ void attn_recv_tile(const AttnBwdArgs& a, int net, in
     const float* qkv = a.qkv[net];
     bool cols_in_lds = false;
     const int lo = stage_window(a.col, s_rp, ROWS, s_hdr, win_cap, tid, 512, [&](int lo_, int cnt) {
-        window_copy(win, WS, cnt, nq + vd, tid, 512, [&](int rr, int c) {
-            return qkv[(int64_t)(lo_ + rr) * P + (c < nq ? c : nq + c)];
-        });
+        // q at [0, nq), v at [2 nq, 2 nq + vd) of a row; in 8-byte units when every segment starts on an even column
+        if (((nq | vd) & 1) == 0 && (reinterpret_cast<uintptr_t>(qkv) & 7) == 0 && (reinterpret_cast<uintptr_t>(win) & 7) == 0)
+            window_copy2(win, WS, cnt, (nq + vd) >> 1, tid, 512, [&](int rr, int c2) {
+                const int c = 2 * c2;
+                return *reinterpret_cast<const f32x2_win*>(qkv + (int64_t)(lo_ + rr) * P + (c < nq ? c : nq + c));
+            });
+        else
+            window_copy(win, WS, cnt, nq + vd, tid, 512, [&](int rr, int c) {
+                return qkv[(int64_t)(lo_ + rr) * P + (c < nq ? c : nq + c)];
+            });
     }, s_col, kRowsColCap, &cols_in_lds);
     __syncthreads();
     const int* cols = cols_in_lds ? s_col : a.col;
@@ -649,12 +656,24 @@ __device__ __forceinline__ void attn_send_tile(const AttnBwdArgs& a, int net, in
     const float* stats = a.stats[net];
     bool cols_in_lds = false;
     const int lo = stage_window(a.col_t, s_rp, ROWS, s_hdr, win_cap, tid, 512, [&](int lo_, int cnt) {
-        window_copy(win, WS, cnt, nq + NV + (SW ? 2 * nh : 0), tid, 512, [&](int rr, int c) {
-            const int64_t r = lo_ + rr;
-            if (c < nq) return qkv[r * P + nq + c];
-            if (c < nq + NV) return dagg[r * NV + (c - nq)];
-            return stats[r * 3 * nh + (c - nq - NV)];
-        });
+        // k | dagg (| m | Z) of a row; in 8-byte units when every segment starts on an even column (then P, NV and 3 nh
+        // are even too: every row of the three arrays is 8-byte aligned)
+        const bool pairs = ((nq | vd | NV | nh) & 1) == 0 && (reinterpret_cast<uintptr_t>(win) & 7) == 0 &&
+                           ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(dagg) | reinterpret_cast<uintptr_t>(stats)) & 7) == 0;
+        if (pairs)
+            window_copy2(win, WS, cnt, (nq + NV + (SW ? 2 * nh : 0)) >> 1, tid, 512, [&](int rr, int c2) {
+                const int64_t r = lo_ + rr;
+                const int c = 2 * c2;
+                const float* src = c < nq ? qkv + r * P + nq + c : (c < nq + NV ? dagg + r * NV + (c - nq) : stats + r * 3 * nh + (c - nq - NV));
+                return *reinterpret_cast<const f32x2_win*>(src);
+            });
+        else
+            window_copy(win, WS, cnt, nq + NV + (SW ? 2 * nh : 0), tid, 512, [&](int rr, int c) {
+                const int64_t r = lo_ + rr;
+                if (c < nq) return qkv[r * P + nq + c];
+                if (c < nq + NV) return dagg[r * NV + (c - nq)];
+                return stats[r * 3 * nh + (c - nq - NV)];
+            });
     }, s_col, kRowsColCap, &cols_in_lds);
     if (SW && lo >= 0) {  // delta of the window rows: <dagg (staged), agg> per head
         const float* agg = a.agg[net];

@@ -84,6 +84,31 @@ __device__ __forceinline__ void window_copy(float* __restrict__ win, int WS, int
     }
 }
 
+// the same in 8-byte units (W2 float pairs per row; src(row, c2) returns the pair at float column 2 c2): for rows whose
+// segments all start on even columns of 8-byte aligned arrays - half the loads and half the index arithmetic
+typedef float f32x2_win __attribute__((ext_vector_type(2)));
+template <typename Src>
+__device__ __forceinline__ void window_copy2(float* __restrict__ win, int WS, int cnt, int W2, int tid, int nthr, Src src) {
+    const int total = cnt * W2;
+    int r = tid / W2, c = tid - r * W2;
+    const int dr = nthr / W2, dc = nthr - dr * W2;
+    for (int base = 0; base < total; base += nthr * 8) {
+        f32x2_win reg[8];
+        int at[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool in = base + tid + q * nthr < total;
+            at[q] = in ? r * WS + 2 * c : -1;
+            reg[q] = src(in ? r : 0, in ? c : 0);
+            r += dr, c += dc;
+            if (c >= W2) c -= W2, ++r;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (at[q] >= 0) *reinterpret_cast<f32x2_win*>(win + at[q]) = reg[q];
+    }
+}
+
 // the tile's slice of the CSR column array, staged coalesced (a thread walking its own row would otherwise wait one
 // memory round trip per edge); returns false when it does not fit (the caller then reads col from global memory)
 __device__ __forceinline__ bool stage_cols(const int32_t* __restrict__ col, const int* s_rp, int nrows, int* s_col,
