@@ -1303,16 +1303,16 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(float* __restrict__ y, int
         const int c = tid % H, g = tid / H;
         double s = 0.0, q = 0.0;
         if (g < G)
-            for (int b0 = g; b0 < nparts; b0 += 8 * G) {
-                double ps[8], pq_[8];
+            for (int b0 = g; b0 < nparts; b0 += 16 * G) {
+                double ps[16], pq_[16];  // sixteen partial pairs in flight per thread (eight: six dependent round trips for 340 partial rows)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < 16; ++k) {
                     const int b = b0 + k * G < nparts ? b0 + k * G : g;
                     ps[k] = part[((int64_t)b * H + c) * 2 + 0];
                     pq_[k] = part[((int64_t)b * H + c) * 2 + 1];
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
+                for (int k = 0; k < 16; ++k)
                     if (b0 + k * G < nparts) {
                         s += ps[k];
                         q += pq_[k];
