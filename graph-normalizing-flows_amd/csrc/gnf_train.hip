@@ -2266,24 +2266,48 @@ struct PackBatch {
 __global__ __launch_bounds__(256) void k_pack_multi(const PackBatch pb) {
     const PackDesc& d = pb.d[blockIdx.y];
     const int64_t nw = (int64_t)d.Ip * d.Op;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // a thread = the four k-consecutive elements of one lane's fragment (i = 4 t .. 4 t + 3): one 16-byte store per copy, and
+    // for the transposed copy - whose four elements are consecutive in a row of W - one 16-byte load where rows are aligned
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = 4 * t;
     if (i < nw) {  // same fragment order as k_pack_layer (gnf_fused.hip)
-        const int q = (int)(i & 3);
-        const int lane = (int)((i >> 2) & 63);
-        const int64_t blk = i >> 8;
+        const int lane = (int)(t & 63);
+        const int64_t blk = t >> 6;
         const int nts = d.Op >> 4;
         const int kg = (int)(blk / nts), nt = (int)(blk % nts);
-        const int k = 16 * kg + 4 * (lane >> 4) + q;
+        const int k = 16 * kg + 4 * (lane >> 4);
         const int c = 16 * nt + (lane & 15);
-        d.wout[i] = (k < d.I && c < d.O) ? d.W[(int64_t)k * d.O + c] : 0.f;
+        float w4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w4[q] = (k + q < d.I && c < d.O) ? d.W[(int64_t)(k + q) * d.O + c] : 0.f;
         const int nts_t = d.Ip >> 4;
         const int kg_t = (int)(blk / nts_t), nt_t = (int)(blk % nts_t);
-        const int ko = 16 * kg_t + 4 * (lane >> 4) + q;
+        const int ko = 16 * kg_t + 4 * (lane >> 4);
         const int ci = 16 * nt_t + (lane & 15);
-        d.wtout[i] = (ci < d.I && ko < d.O) ? d.W[(int64_t)ci * d.O + ko] : 0.f;
-    } else if (i < nw + d.Op) {
-        const int c = (int)(i - nw);
-        d.bout[c] = c < d.O ? d.b[c] : 0.f;
+        float t4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ci < d.I) {
+            const float* row = d.W + (int64_t)ci * d.O + ko;
+            if (ko + 3 < d.O && (d.O & 3) == 0 && (reinterpret_cast<uintptr_t>(d.W) & 15) == 0) {
+                const float4 v = *reinterpret_cast<const float4*>(row);
+                t4[0] = v.x, t4[1] = v.y, t4[2] = v.z, t4[3] = v.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (ko + q < d.O) t4[q] = row[q];
+            }
+        }
+        if (((reinterpret_cast<uintptr_t>(d.wout) | reinterpret_cast<uintptr_t>(d.wtout)) & 15) == 0) {
+            *reinterpret_cast<float4*>(d.wout + i) = make_float4(w4[0], w4[1], w4[2], w4[3]);
+            *reinterpret_cast<float4*>(d.wtout + i) = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d.wout[i + q] = w4[q], d.wtout[i + q] = t4[q];
+        }
+    } else if (i < nw + 4 * ((d.Op + 3) / 4)) {
+        for (int q = 0; q < 4; ++q) {
+            const int c = (int)(i - nw) + q;
+            if (c < d.Op) d.bout[c] = c < d.O ? d.b[c] : 0.f;
+        }
     }
 }
 
@@ -2296,7 +2320,7 @@ static int pack_flow(const GnfFlow* flow, hipStream_t st) {
     int64_t maxtot = 0;
     auto flush = [&]() -> int {
         if (!cnt) return GNF_OK;
-        hipLaunchKernelGGL(k_pack_multi, dim3((unsigned)((maxtot + 255) / 256), cnt), dim3(256), 0, st, pb);
+        hipLaunchKernelGGL(k_pack_multi, dim3((unsigned)((maxtot / 4 + 255) / 256), cnt), dim3(256), 0, st, pb);  // 4 elements per thread
         GNF_LAUNCH_CHECK("k_pack_multi");
         cnt = 0;
         maxtot = 0;
