@@ -117,6 +117,13 @@ bool fused_supported(const HalfStep& hs);
 bool fused_fits_lds(const GnfMlp* m);      // forward kernel, smallest shape
 bool fused_bwd_fits_lds(const GnfMlp* m);  // backward kernel
 int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st);
+// large-batch form of the fused kernel (gnf_fused_big.hip): workgroups of up to `cap` (<= 4) row tiles of 16 nodes, dealt
+// out evenly over rounds x 2 x CUs workgroups (big_plan); *n_wg_out = workgroups launched (= fp64 partials written)
+struct FusedArgs;
+bool big_supported(const GnfMlp* s, int32_t H);
+int big_cu_count();
+int big_plan(int64_t n_nodes, int cus, int cap, int32_t* seg_n, int32_t* seg_sz);  // -> workgroups; runs of (count, row tiles)
+int launch_half_big(FusedArgs& a, int64_t n_nodes, int cap, hipStream_t st, int* n_wg_out);
 // coupling epilogue from global s / t [N, H] buffers (writes hs.partials, *hs.n_partials)
 int launch_coupling(const float* s, const float* t, const HalfStep& hs, const float* xres, hipStream_t st);
 int launch_half_layered(const HalfStep& hs, float* scratch, hipStream_t st);

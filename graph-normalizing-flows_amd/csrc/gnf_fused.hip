@@ -110,49 +110,6 @@ int launch_pack_mlp(const GnfMlp* m, float* packed, hipStream_t st) {
     return GNF_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-struct FusedArgs {
-    const int32_t* rowptr;
-    const int32_t* col;
-    const float* x_cond;
-    float* x_upd;
-    const float* x_upd_src;              // old value of the updated half (= x_upd, or the source buffer of an out-of-place first step)
-    float* cond_copy;                    // NULL, or where this tile's rows of the conditioning half are copied to (out-of-place first step)
-    double* partials;
-    double* sq_partials;                 // NETS = 2, forward: also sum(x_upd_new^2) per workgroup (the Gaussian term of the
-                                         // flow's last two half-steps, whose outputs are z), or NULL
-    double* bn_part;                     // NETS = 2, forward: [tile][H][2] column sums / sums of squares of the updated rows
-                                         // (batch moments of the bijector in front of the next half-step), or NULL
-    float* st_out[2];                    // NETS = 1: global [N, H] scratch for s (0) and t (1)
-    const float* h0[2];                  // precomputed layer-0 input per net ([N, in0], attention GNNs) or NULL
-    const float* wp[2][GNF_MAX_LAYERS];  // [net][layer] packed weights
-    const float* bias[2];                // [net] contiguous padded bias block (bias_tot floats)
-    int32_t ipg[GNF_MAX_LAYERS];         // padded input width / 16 of layer j
-    int32_t ont[GNF_MAX_LAYERS];         // padded output width / 16 of layer j
-    int32_t boff[GNF_MAX_LAYERS];        // offset of layer j's bias in the LDS bias block
-    int64_t ld;
-    int32_t n_nodes;
-    int32_t n_tiles;
-    int32_t H;
-    int32_t in0;       // true layer-0 input width (H or 2H)
-    int32_t K;
-    int32_t LS;        // LDS row stride (floats)
-    int32_t bias_tot;  // floats of bias per net in LDS
-    int32_t mean, concat, act, inverse;
-    int32_t residual;  // attention block with residual: s, t += x_cond (gnn.py:547-548)
-    int32_t variant;   // developer A/B bits (gnf_set_option("fused_variant", ...)); 0 = shipped behaviour
-    float eps, alpha;
-    // training forward (STASH instance only): every row the backward pass would otherwise recompute goes to the
-    // half-step's slot of GnfFlow.mlp_stash - the layer-0 input, each hidden activation of both nets, s and t
-    float* stash_h0;                          // [N, in0]
-    float* stash_act[2][GNF_MAX_LAYERS];      // [net][j], j = 1 .. K-1: input of layer j, [N, stash_ld]
-    float* stash_st[2];                       // s, t [N, H]
-    int32_t stash_w[GNF_MAX_LAYERS];          // true output width of layer j
-    int32_t stash_ld;
-    unsigned long long* stash_mask;           // [tile][net][K-1][4][mld] ballot of "activation > 0" (act' for the way back)
-    int32_t stash_mld;
-};
-
 #ifdef GNF_TRACE  // developer build only: per-wave cycle stamps of workgroup 0
 #define GNF_TRACE_GLOBALS 1
 __device__ unsigned long long g_trace[8][16];
@@ -548,6 +505,7 @@ static size_t fused_lds_bytes(const GnfMlp* m, int MT, int NETS) {
 bool fused_fits_lds(const GnfMlp* m) { return fused_lds_bytes(m, 1, 1) <= (size_t)kLdsLimit; }
 
 static void choose_shape(const HalfStep& hs, int* mt, int* nets);
+static int choose_big(const HalfStep& hs);
 
 bool fused_supported(const HalfStep& hs) {
     const GnfMlp *s = hs.s_net, *t = hs.t_net;
@@ -562,6 +520,7 @@ bool fused_supported(const HalfStep& hs) {
 // gathers, copies and updates in one launch; attention nets take their layer-0 input from the front-end kernels.
 bool fused_supports_oop(const HalfStep& hs) {
     if (!fused_supported(hs) || hs.s_net->attn) return false;
+    if (choose_big(hs)) return true;
     int mt, nets;
     choose_shape(hs, &mt, &nets);
     return nets == 2;
@@ -595,6 +554,29 @@ static void choose_shape(const HalfStep& hs, int* mt, int* nets) {
     if (s->attn && s->attn->layer_norm) n = 1;
     *mt = m;
     *nets = n;
+}
+
+// The large-batch form (gnf_fused_big.hip: 4-wave workgroups of up to 4 row tiles, the two nets one after the other,
+// activations in place, two workgroups per CU): 0 = not this launch, else the row-tile cap.
+// A launch's time moves in quanta - one 32-row tile per CU for the both-nets shape, two 4-tile workgroups per CU here -
+// so the choice is by the quanta each needs, in units of the (2,2) shape's pass over 256 tiles (59 us at L = 256, K = 5):
+//   (2,2):  ceil(g / (2 C))                                       g = 16-row granules, C = CUs
+//   here :  g <= 8 C (even deal, one pass):  1.22 + 0.525 g / (2 C)
+//           else                          :  1.81 ceil(g / (4 C)) + 0.29      (+ the aggregation launch, in the 0.29)
+// fitted to tools/ab_shapes.sh on config-4 batches of 3.5 k .. 78 k nodes: e.g. 8.2 k nodes 101 vs 117 us,
+// 13 k 127 vs 119, 20 k 149 vs 177, 30 k 221 vs 237, 40 k 338 vs 295, 59 k 426 vs 471, 78 k 549 vs 588.
+// gnf_set_option("force_shape", 40 | 30 | 20 | 10) forces it with that cap, any other forced shape keeps it off.
+static int choose_big(const HalfStep& hs) {
+    const GnfMlp* s = hs.s_net;
+    if (!big_supported(s, hs.H) || hs.mlp_stash) return 0;
+    if (hs.n_nodes * hs.ld >= (int64_t(1) << 31)) return 0;  // (its coupling loop indexes the rows with 32-bit offsets)
+    if (s->attn && s->attn->layer_norm) return 0;  // (whole rows of s and t before the coupling: one-net-per-workgroup shape)
+    if (const int64_t force = opt(OPT_FORCE_SHAPE)) return (force % 10 == 0 && force >= 10 && force <= 40) ? (int)(force / 10) : 0;
+    const int64_t g = (hs.n_nodes + 15) / 16, c = big_cu_count();
+    if (g <= 2 * c) return 0;  // one tile per CU or less: the 16- / 32-row both-nets shapes
+    const double old_q = (double)((g + 2 * c - 1) / (2 * c));
+    const double big_q = g <= 8 * c ? 1.22 + 0.525 * (double)g / (double)(2 * c) : 1.81 * (double)((g + 4 * c - 1) / (4 * c)) + 0.29;
+    return big_q < old_q ? 4 : 0;
 }
 
 template <int MT, int NETS, bool STASH = false>
@@ -650,6 +632,8 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
     a.x_cond = hs.x_cond;
     a.x_upd = hs.x_upd;
     a.variant = (int32_t)opt(OPT_FUSED_VARIANT);
+    memset(a.big_seg_n, 0, sizeof(a.big_seg_n));
+    memset(a.big_seg_sz, 0, sizeof(a.big_seg_sz));
     a.x_upd_src = hs.x_upd_src ? hs.x_upd_src : hs.x_upd;
     a.cond_copy = hs.cond_copy;
     a.partials = hs.partials;
@@ -703,10 +687,31 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
     a.eps = hs.gnn.epsilon;
     a.alpha = hs.gnn.alpha;
 
+    int rc;
+    if (const int big = choose_big(hs)) {
+        // bn_part stays unwritten (*n_bn = 0: the bijector in front of the next half-step runs its own moment pass)
+        a.sq_partials = hs.sq_partials;
+        a.bn_part = nullptr;
+        if (!s->attn) {
+            // message-passing GNNs: the layer-0 input rows of both nets (eps * x + agg | [x || agg], gnn.py:108-109,123)
+            // from the standalone aggregation kernel - same edge order, same fma as the fused kernels' gather - into the
+            // head of the scratch; the large-batch kernel reads them like an attention front-end's output
+            rc = launch_aggregate(hs.rowptr, hs.col, hs.n_nodes, hs.x_cond, hs.ld, hs.H, a.mean, a.concat ? 1 : 0, a.eps, scratch,
+                                  a.in0, st);
+            if (rc) return rc;
+            a.h0[0] = a.h0[1] = scratch;
+        }
+        int n_wg = 0;
+        rc = launch_half_big(a, hs.n_nodes, big, st, &n_wg);
+        if (rc) return rc;
+        *hs.n_partials = (int32_t)n_wg;
+        if (hs.n_sq) *hs.n_sq = a.sq_partials ? (int32_t)n_wg : 0;
+        if (hs.n_bn) *hs.n_bn = 0;
+        return GNF_OK;
+    }
     const int64_t tiles = (hs.n_nodes + 16 * MT - 1) / (16 * MT);
     a.n_tiles = (int32_t)tiles;
     const size_t lds = fused_lds_bytes(s, MT, NETS);
-    int rc;
     if (hs.mlp_stash && !(MT == 1 && NETS == 2)) {
         set_error("internal: MLP-row stash on a launch shape other than (1,2) (mlp_stash_supported is false there)");
         return GNF_EINVAL;

@@ -1,0 +1,697 @@
+// Fused coupling half-step, large-batch form (gfx950 / MI355X): the kernel for batches with several node tiles per CU.
+//
+// Same arithmetic as k_half_fused (gnf_fused.hip; gnn.py:103-126, 159-180, 320-338 | 356-372): same packed weights, same
+// MFMA fragment mapping and k order, so s, t and the updated rows are BITWISE what the 16- / 32-row shapes produce.  What
+// changes is how the work is laid out, to answer what bounds those shapes once the chip is full (every
+// workgroup re-streams both nets' packed weights from L2 for its own 16 or 32 rows; one 133 KB workgroup per CU leaves
+// nothing to run in the shadow of its prologue, layer barriers, thin layers and epilogue; and a launch's time moves in
+// quanta of "one tile per CU"):
+//
+//   * a workgroup is 4 waves (one per SIMD) and owns 1 .. 4 row tiles of 16 nodes; it runs the s-net, then the t-net,
+//     over them.  In a 256-wide layer a wave owns column tiles {w, w+4, w+8, w+12} x every row tile: 16 accumulators,
+//     4 weight loads + 4 LDS reads per 64 MFMAs - the weight stream per row is half the 32-row both-nets shape's;
+//   * activations live in ONE [64][260] LDS buffer, updated in place: a wave's column tiles of a layer fit its
+//     accumulators, so a layer is "all waves read - barrier - all waves write - barrier" (layers wider than 256 would
+//     need a second pass per wave: such nets stay on k_half_fused).  66.7 KB per workgroup = TWO workgroups per CU, each
+//     filling the other's barriers / prologue / thin layers / epilogue with its MFMAs; 2 waves per SIMD = 256 VGPRs each,
+//     no spills (a first 8-wave / 128-register form spilled 70-90 registers per layer: 880 MB of scratch traffic per launch);
+//   * how many row tiles a workgroup gets is a RUN-TIME value (big_plan): a batch of up to one pass of the chip is dealt
+//     out evenly over 2 x CUs workgroups so that the launch ends everywhere at once instead of rounding up to whole
+//     64-row tiles per CU; larger batches run whole 4-tile workgroups.  The MFMAs of a k-group run row tile by row
+//     tile; absent row tiles are skipped behind wave-uniform branches at the row-tile boundaries, and workgroups of 1 or
+//     2 row tiles take an instance with a twice-as-deep weight ring in the same registers;
+//   * s stays in the accumulator registers while the t-net runs; then s | t go side by side into the (now free)
+//     activation buffer and ONE compact loop does the coupling update x*exp(s)+t | (x-t)*exp(-s) with 16-byte row
+//     accesses and the fp64 partials of sum(s), sum(x_new^2);
+//   * the layer-0 input rows (eps*x + agg | [x || agg]) come from the standalone aggregation kernel (k_aggregate,
+//     launched in front by launch_half_fused): thousands of light waves hide the neighbour-row latency there, two
+//     256-register waves per SIMD cannot (an in-kernel gather cost a 64-row workgroup 20 k cycles at H = 32 and
+//     70-170 k at H = 128).  Attention GNNs hand their per-net layer-0 rows over the same way;
+//   * thin layers (1 or 2 column tiles: the 256 -> 32 output layer) split the ROW tiles over the waves so that all four
+//     SIMDs work on them, with every k-group's weights requested up front;
+//   * the kernel's code is kept small on purpose (loops that run once per tile are NOT unrolled, one copy of expf):
+//     two CUs share one 64 KB instruction cache, and a 33 KB unrolled gather once made everything 2x slower.
+#include "gnf_common.h"
+#include "gnf_fused_dev.h"
+
+namespace gnf {
+
+static constexpr int kBigThreads = 256;  // 4 waves: one per SIMD and workgroup, two workgroups per CU
+static constexpr int kBigWaves = 4;
+static constexpr int kBigMT = 4;         // row tiles (of 16 nodes) a workgroup holds at most
+static constexpr int kBigTM = 16 * kBigMT;
+static constexpr int kBigLS = 260;       // LDS row stride (floats): 256 + 4, rows 16-byte aligned and spread over banks
+static constexpr int kBigMaxW = 256;     // widest padded layer input / hidden width
+static constexpr int kBigMaxH = 128;     // widest padded output (s stays in 8 * 4 accumulator registers of its wave)
+#ifndef GNF_BIG_RBW
+#define GNF_BIG_RBW 2  // weight k-groups in the register ring of the widest shapes (one less in flight; 3 measured equal)
+#endif
+
+static inline int pad16(int v) { return (v + 15) & ~15; }
+
+#ifdef GNF_BIG_TRACE  // developer build only (tools/probe_big_trace.py): s_memtime stamps of every wave of two workgroups
+__device__ unsigned long long g_big_trace[2][8][64];
+__device__ unsigned int g_big_hwid[2][8];
+__device__ int g_big_trace_blocks[2] = {0, 256};
+__device__ unsigned long long g_big_span[8192][3];  // per block: start, end, HW_ID | XCC_ID << 16 (wave 0)
+#define GNF_BSTAMP(slot)                                                                              \
+    do {                                                                                              \
+        if (trace_slot >= 0 && (threadIdx.x & 63) == 0) g_big_trace[trace_slot][threadIdx.x >> 6][slot] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define GNF_BSTAMP(slot)
+#endif
+
+// a wave's share of one layer (all wave-uniform)
+struct BChunk {
+    const float* wbase;  // packed weights of the layer
+    const float* bias;   // this layer's padded bias row
+    unsigned wbytes;
+    int ipg;   // k-groups
+    int ont;   // column tiles of the layer
+    int col0;  // first column tile (the others: col0 + 4, + 8, + 12)
+    int nv;    // column tiles of this wave: 0 .. 4
+    int m0;    // first row tile
+    int mw;    // row tiles of this wave: 0 .. 4
+    int thin;  // the layer has 1 or 2 column tiles: the row tiles are split over the waves (big_chunk_thin)
+    int active;
+};
+
+#define GNF_BIG_LOAD_B(RSRC, VOFF, SOFF) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RSRC, VOFF, SOFF, 0))
+
+// stage 0 of a chunk's weight stream + its bias values: requested while the previous layer is still multiplying
+__device__ __forceinline__ void big_prefetch(const BChunk& c, int lane, f32x4 (&b_nx)[4], float (&bias_nx)[4]) {
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.wbase), 0, (int)c.wbytes, 0x00020000);
+    const int voff = lane * 16;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int ct = c.col0 + (b < c.nv ? kBigWaves * b : 0);
+        b_nx[b] = GNF_BIG_LOAD_B(rsrc, voff, ct * 1024);
+        bias_nx[b] = c.bias[16 * ct + (lane & 15)];
+    }
+}
+
+// What happens to a chunk's accumulators (row tiles m < c.mw): a hidden layer ends with "barrier (every wave has read the
+// layer's input) - activation, write in place - barrier"; the s-net's last layer leaves s in registers; the t-net's last
+// layer puts s (columns [0, hp)) and t (columns [hp, 2 hp)) of the tile's rows into the activation buffer, behind a
+// barrier (every wave has read the last hidden rows) - the kernel's coupling loop takes them from there.
+template <int NV, int MW>
+__device__ __forceinline__ void big_layer_end(float* __restrict__ act, const BChunk& c, int lane, const f32x4 (&acc)[MW][NV],
+                                              bool last, float slope, f32x4 (&s_keep)[kBigMT][2], bool couple, int hp) {
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    if (!last) {
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+            if (m < c.mw) {  // wave-uniform
+#pragma unroll
+                for (int b = 0; b < NV; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[m][b][r];
+                        act[(16 * (c.m0 + m) + 4 * lgrp + r) * kBigLS + 16 * (c.col0 + kBigWaves * b) + lrow] = fmaxf(v, slope * v);
+                    }
+            }
+        __syncthreads();
+    } else if constexpr (NV <= 2) {  // (the coupling half has at most 8 column tiles: two per wave)
+        if (!couple) {
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int b = 0; b < NV; ++b) s_keep[m][b] = acc[m][b];
+        } else {
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+                if (m < c.mw) {
+#pragma unroll
+                    for (int b = 0; b < NV; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float* p = act + (16 * (c.m0 + m) + 4 * lgrp + r) * kBigLS + 16 * (c.col0 + kBigWaves * b) + lrow;
+                            p[0] = s_keep[m][b][r];
+                            p[hp] = acc[m][b][r];
+                        }
+                }
+        }
+    }
+}
+
+// One layer's share of a wave in a layer with 3 or more column tiles:
+//     acc[m][b] = bias + sum_k act[16 m .. +16][k] * W[k][16 (col0 + 4 b) .. +16],   m < c.mw (run time), b < NV.
+// B ring: RB slots (RB - 1 k-groups in flight).  A fragments: ONE slot per row tile, refilled in place - the MFMAs of a
+// k-group run row tile by row tile and a[m]'s next k-group is requested right behind the last MFMA that reads the current
+// one, most of a stage before it is needed.  An accumulator sees its k-groups and the four MFMAs inside a k-group in
+// k_half_fused's order: bitwise the same sums.  The issue order is pinned the same way (sched_group_barrier): loads sit
+// behind MFMAs, never bunched in front of them.  Row tiles >= c.mw are skipped (wave-uniform branches between the row
+// tiles' MFMA blocks).
+// MW = 4 | 2: the row tiles the instance holds accumulators for.  A workgroup of 1 or 2 row tiles takes the MW = 2 instance,
+// whose B ring is twice as deep in the same registers: its k-groups are half as long, and the weight fragments have to be
+// requested the same TIME ahead (a lone 1-tile workgroup with one k-group in flight ran 925 cycles per 512-cycle k-group:
+// the L2 round trip; a 2-tile workgroup beside a 4-tile one took as long as its partner).
+template <int NV, int RB, int MW>
+__device__ __forceinline__ void big_chunk(float* __restrict__ act, const BChunk& c, const BChunk& nx, bool have_nx,
+                                          int lane, f32x4 (&b_nx)[4], float (&bias_nx)[4], bool last, float slope,
+                                          f32x4 (&s_keep)[kBigMT][2], bool couple, int hp) {
+    constexpr int PF = RB - 1;
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    const int ipg = c.ipg, mw = c.mw;
+    f32x4 acc[MW][NV];
+#pragma unroll
+    for (int b = 0; b < NV; ++b)
+#pragma unroll
+        for (int m = 0; m < MW; ++m) acc[m][b] = f32x4{bias_nx[b], bias_nx[b], bias_nx[b], bias_nx[b]};
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.wbase), 0, (int)c.wbytes, 0x00020000);
+    const int voff = lane * 16;
+    int wtile[NV];
+#pragma unroll
+    for (int b = 0; b < NV; ++b) wtile[b] = (c.col0 + kBigWaves * b) * 1024;
+    const int kstride = c.ont * 1024;
+    const float* arow = act + lrow * kBigLS + 4 * lgrp;  // (m0 = 0: every row tile of the workgroup)
+
+    f32x4 a_frag[MW], b_ring[RB][NV];
+#pragma unroll
+    for (int b = 0; b < NV; ++b) b_ring[0][b] = b_nx[b];
+#pragma unroll
+    for (int u = 1; u < RB - 1; ++u) {  // (slot RB - 1 is requested by the first stage below)
+        const int kn = u < ipg ? u : ipg - 1;
+#pragma unroll
+        for (int b = 0; b < NV; ++b) b_ring[u][b] = GNF_BIG_LOAD_B(rsrc, voff, wtile[b] + kn * kstride);
+    }
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+        if (m < mw) a_frag[m] = *reinterpret_cast<const f32x4*>(arow + 16 * m * kBigLS);
+
+    // the MFMAs of one row tile with B slot SB, then the refill of its A fragment with k-group KA
+#define GNF_BIG_MBLOCK(M, SB, KA)                                                                       \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int b = 0; b < NV; ++b)        \
+        acc[M][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_frag[M][q], b_ring[SB][b][q], acc[M][b], 0, 0, 0); \
+    a_frag[M] = *reinterpret_cast<const f32x4*>(arow + 16 * (M) * kBigLS + 16 * (KA));
+    // stage kg: B slot kg % RB; the k-group RB - 1 ahead goes into the slot stage kg - 1 just left (LOADS: not in the tail)
+#define GNF_BIG_STAGE(SB, KA, KB, LOADS)                                                                \
+    if (LOADS) {                                                                                        \
+        _Pragma("unroll") for (int b = 0; b < NV; ++b) b_ring[((SB) + PF) % RB][b] =                    \
+            GNF_BIG_LOAD_B(rsrc, voff, wtile[b] + (KB) * kstride);                                      \
+    }                                                                                                   \
+    GNF_BIG_MBLOCK(0, SB, KA)                                                                           \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                  \
+    if (LOADS) __builtin_amdgcn_sched_group_barrier(0x020, NV, 0);                                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NV - 1, 0);                                         \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    _Pragma("unroll") for (int m_ = 1; m_ < MW; ++m_) {                                                 \
+        if (m_ < mw) { /* wave-uniform */                                                               \
+            GNF_BIG_MBLOCK(m_, SB, KA)                                                                  \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NV, 0);                                     \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                          \
+        }                                                                                               \
+    }
+#define GNF_BIG_ROUND(KG0)                                                                              \
+    _Pragma("unroll") for (int u = 0; u < RB; ++u) {                                                    \
+        const int kg = (KG0) + u;                                                                       \
+        const int ka = kg + 1 < ipg ? kg + 1 : ipg - 1;                                                 \
+        const int kb = kg + PF < ipg ? kg + PF : ipg - 1;                                               \
+        GNF_BIG_STAGE(u, ka, kb, true)                                                                  \
+    }
+    // Wave priority.  The SIMD's arbiter serves the older wave first and a wave that streams MFMAs always has one ready:
+    // everything runs at priority 3 except the MFMA stream of a wide chunk, so that the co-resident workgroup's
+    // latency-bound phases take the few issue slots they need at once and the stream fills the rest.
+    __builtin_amdgcn_s_setprio(0);
+    // (one copy of the round: the next layer's first k-group is requested in front of the LAST round - it lands while
+    // that round's MFMAs, the write-back and the layer barriers are in progress - behind a scalar branch at the round
+    // boundary, where the issue order is pinned anyway)
+    int kg0 = 0;
+    bool pre_done = false;
+    for (; kg0 + RB <= ipg; kg0 += RB) {
+        if (kg0 + 2 * RB > ipg) {
+            if (have_nx) big_prefetch(nx, lane, b_nx, bias_nx);  // (b_nx was consumed above)
+            pre_done = true;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        GNF_BIG_ROUND(kg0)
+    }
+    if (!pre_done) {
+        if (have_nx) big_prefetch(nx, lane, b_nx, bias_nx);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // tail: stages kg0 .. ipg-1 sit in B slots 0 .. rem-1 (requested by the last round, or by the chunk's entry when
+    // there was no round)
+    const int rem = ipg - kg0;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        if (u < rem) {  // wave-uniform
+            const int ka = kg0 + u + 1 < ipg ? kg0 + u + 1 : ipg - 1;
+            GNF_BIG_STAGE(u, ka, 0, false)
+        }
+    }
+#undef GNF_BIG_ROUND
+#undef GNF_BIG_STAGE
+#undef GNF_BIG_MBLOCK
+    __builtin_amdgcn_s_setprio(3);
+    big_layer_end<NV, MW>(act, c, lane, acc, last, slope, s_keep, couple, hp);
+}
+
+// Thin layers (1 or 2 column tiles: 4 or 8 MFMAs per k-group cannot hide a weight load): the row tiles are split over
+// the waves (<= 2 each), every k-group's fragment is requested before the first MFMA (<= 16 k-groups = 64 registers),
+// the A fragments alternate between two slots.  Same k order as big_chunk: bitwise the same sums.
+__device__ __forceinline__ void big_chunk_thin(float* __restrict__ act, const BChunk& c, const BChunk& nx, bool have_nx,
+                                               int lane, f32x4 (&b_nx)[4], float (&bias_nx)[4], bool last, float slope,
+                                               f32x4 (&s_keep)[kBigMT][2], bool couple, int hp) {
+    constexpr int NS = kBigMaxW / 16, MW = 2;
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    const int ipg = c.ipg, mw = c.mw;
+    f32x4 acc[MW][1];
+#pragma unroll
+    for (int m = 0; m < MW; ++m) acc[m][0] = f32x4{bias_nx[0], bias_nx[0], bias_nx[0], bias_nx[0]};
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.wbase), 0, (int)c.wbytes, 0x00020000);
+    const int voff = lane * 16, wtile = c.col0 * 1024, kstride = c.ont * 1024;
+    const float* arow = act + (16 * c.m0 + lrow) * kBigLS + 4 * lgrp;
+    const int m1 = mw > 1 ? 1 : 0;  // (a wave with one row tile reads it twice and drops the second result)
+    f32x4 bst[NS], a_ring[2][MW];
+    bst[0] = b_nx[0];
+#pragma unroll
+    for (int u = 1; u < NS; ++u) bst[u] = GNF_BIG_LOAD_B(rsrc, voff, wtile + (u < ipg ? u : ipg - 1) * kstride);
+    a_ring[0][0] = *reinterpret_cast<const f32x4*>(arow);
+    a_ring[0][1] = *reinterpret_cast<const f32x4*>(arow + 16 * m1 * kBigLS);
+    if (have_nx) big_prefetch(nx, lane, b_nx, bias_nx);
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        if (u < ipg) {  // wave-uniform
+            const int ka = u + 1 < ipg ? u + 1 : ipg - 1;
+            a_ring[(u + 1) % 2][0] = *reinterpret_cast<const f32x4*>(arow + 16 * ka);
+            a_ring[(u + 1) % 2][1] = *reinterpret_cast<const f32x4*>(arow + 16 * m1 * kBigLS + 16 * ka);
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ring[u % 2][m][q], bst[u][q], acc[m][0], 0, 0, 0);
+        }
+    }
+    big_layer_end<1, MW>(act, c, lane, acc, last, slope, s_keep, couple, hp);
+}
+
+__global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_half_big(const FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* act = smem;
+    double* red = reinterpret_cast<double*>(act + kBigTM * kBigLS);  // [4] sum(s) | [4] sum(x_new^2)
+    int* tab = reinterpret_cast<int*>(red + 16);                     // [K][8]: ipg, ont, boff, -, wp[0] lo/hi, wp[1] lo/hi
+
+    // workgroup = block (dispatch order = row order: nothing here gathers, so which XCD a row tile lands on does not
+    // matter); its row tiles from the launch's run table (big_plan)
+    const int wg = blockIdx.x;
+    int mt = 1, row0 = 0;
+    {
+        int w = wg, g0 = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int nk = a.big_seg_n[k], sk = a.big_seg_sz[k];
+            if (w >= 0 && w < nk) {
+                mt = sk;
+                g0 += w * sk;
+                w = -1;
+            } else if (w >= 0) {
+                w -= nk;
+                g0 += nk * sk;
+            }
+        }
+        row0 = 16 * g0;
+    }
+    const int rows = a.n_nodes - row0 < 16 * mt ? a.n_nodes - row0 : 16 * mt;   // live rows (> 0)
+    const int tid = threadIdx.x;
+    const int H = a.H, K = a.K;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+#ifdef GNF_BIG_TRACE
+    const int trace_slot = (int)blockIdx.x == g_big_trace_blocks[0] ? 0 : ((int)blockIdx.x == g_big_trace_blocks[1] ? 1 : -1);
+    if (trace_slot >= 0 && lane == 0) g_big_hwid[trace_slot][wave] = (__builtin_amdgcn_s_getreg(4 | (15 << 11)) & 0xffffu) | (__builtin_amdgcn_s_getreg(20 | (3 << 11)) << 16);  // HW_ID[15:0] | XCC_ID << 16
+    if (tid == 0 && blockIdx.x < 8192) {
+        g_big_span[blockIdx.x][0] = __builtin_amdgcn_s_memtime();
+        g_big_span[blockIdx.x][2] = (__builtin_amdgcn_s_getreg(4 | (15 << 11)) & 0xffffu) | (__builtin_amdgcn_s_getreg(20 | (3 << 11)) << 16);
+    }
+#endif
+    GNF_BSTAMP(0);
+    __builtin_amdgcn_s_setprio(3);  // (see big_chunk)
+
+    // this wave's share of a layer: column tiles {w, w+4, w+8, w+12} x every row tile when the layer has at least 3 column
+    // tiles; a thinner layer spreads its column tiles over the first cg = ont waves of each group and the row tiles over
+    // the 4 / cg groups (the 256 -> 32 output layer: 2 column tiles x 2 halves of the rows)
+    auto assign = [&](BChunk& c) {
+        const int ont = c.ont;
+        const int cg = ont >= 3 ? 4 : (ont <= 1 ? 1 : 2);
+        const int groups = kBigWaves / cg;           // 1, 2, 4
+        const int per = (mt + groups - 1) / groups;  // row tiles per wave group: <= 2 when groups >= 2
+        const int g = wave / cg;
+        c.col0 = wave % cg;
+        c.nv = c.col0 < ont ? (ont - c.col0 + kBigWaves - 1) / kBigWaves : 0;
+        c.m0 = g * per;
+        const int left = mt - c.m0;
+        c.mw = left < 0 ? 0 : (left < per ? left : per);
+        c.thin = cg < 4;
+        c.active = (c.nv > 0 && c.mw > 0) ? 1 : 0;
+    };
+    auto chunk_from_args = [&](int j, int net) -> BChunk {
+        BChunk c;
+        c.ipg = a.ipg[j];
+        c.ont = a.ont[j];
+        c.wbase = a.wp[net][j];
+        c.wbytes = (unsigned)c.ipg * (unsigned)c.ont * 1024u;
+        c.bias = a.bias[net] + a.boff[j];
+        assign(c);
+        return c;
+    };
+    auto chunk_from_tab = [&](int j, int net) -> BChunk {
+        const int* row = tab + 8 * j;
+        BChunk c;
+        c.ipg = __builtin_amdgcn_readfirstlane(row[0]);
+        c.ont = __builtin_amdgcn_readfirstlane(row[1]);
+        const int boff = __builtin_amdgcn_readfirstlane(row[2]);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane(row[4 + 2 * net]);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane(row[5 + 2 * net]);
+        c.wbase = reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+        c.wbytes = (unsigned)c.ipg * (unsigned)c.ont * 1024u;
+        c.bias = a.bias[net] + boff;
+        assign(c);
+        return c;
+    };
+
+    // ---- the first chunk's weights start streaming before anything else --------------------------------
+    f32x4 b_nx[4];
+    float bias_nx[4];
+    BChunk cur = chunk_from_args(0, 0);
+    bool have_pre = cur.active;
+    if (have_pre) big_prefetch(cur, lane, b_nx, bias_nx);
+
+    if (tid < 8 * K) {  // layer table (one thread per word)
+        const int j = tid >> 3, w = tid & 7;
+        const unsigned long long p0 = reinterpret_cast<unsigned long long>(a.wp[0][j]);
+        const unsigned long long p1 = reinterpret_cast<unsigned long long>(a.wp[1][j]);
+        int v = 0;
+        switch (w) {
+            case 0: v = a.ipg[j]; break;
+            case 1: v = a.ont[j]; break;
+            case 2: v = a.boff[j]; break;
+            case 4: v = (int)(unsigned)p0; break;
+            case 5: v = (int)(unsigned)(p0 >> 32); break;
+            case 6: v = (int)(unsigned)p1; break;
+            case 7: v = (int)(unsigned)(p1 >> 32); break;
+            default: break;
+        }
+        tab[tid] = v;
+    }
+
+    // layer-0 input of one net from global rows [n, in0] (the aggregation kernel's or the attention front-end's output):
+    // eight 16-byte reads per thread requested before the first is stored (a 64 x 128 tile is exactly eight per thread)
+    auto load_h0 = [&](const float* __restrict__ src) {
+        const int in0p = a.ipg[0] * 16;
+        if ((a.in0 & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+            const int q4 = in0p >> 2, total = 16 * mt * q4;
+#pragma unroll 1
+            for (int base = tid; base < total; base += 8 * kBigThreads) {
+                f32x4 v[8];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const int idx = base + g * kBigThreads;
+                    const int rl = idx / q4, c = (idx - rl * q4) * 4;
+                    const bool live = idx < total && rl < rows && c < a.in0;
+                    v[g] = live ? *reinterpret_cast<const f32x4*>(src + (int64_t)(row0 + rl) * a.in0 + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const int idx = base + g * kBigThreads;
+                    const int rl = idx / q4, c = (idx - rl * q4) * 4;
+                    if (idx < total) *reinterpret_cast<f32x4*>(act + rl * kBigLS + c) = v[g];
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int idx = tid; idx < 16 * mt * in0p; idx += kBigThreads) {
+                const int rl = idx / in0p, c = idx - rl * in0p;
+                act[rl * kBigLS + c] = (rl < rows && c < a.in0) ? src[(int64_t)(row0 + rl) * a.in0 + c] : 0.f;
+            }
+        }
+    };
+
+    // ---- A: the s-net's layer-0 input (see the header); an out-of-place first half-step also copies its conditioning
+    // rows on the way ------------------------------------------------------------------------------------------
+    load_h0(a.h0[0]);
+    if (a.cond_copy) {
+#pragma unroll 1
+        for (int i = tid; i < rows * H; i += kBigThreads) {
+            const int rl = i / H, f = i - rl * H;
+            a.cond_copy[(int64_t)(row0 + rl) * a.ld + f] = a.x_cond[(int64_t)(row0 + rl) * a.ld + f];
+        }
+    }
+    GNF_BSTAMP(2);
+    __syncthreads();
+    GNF_BSTAMP(3);
+
+    // ---- B: s-net, then t-net ------------------------------------------------------------------------------
+    f32x4 s_keep[kBigMT][2];
+    const int hp = a.ont[K - 1] * 16;  // padded coupling half: t sits at this column offset beside s
+    const float slope_hidden = a.act == GNF_ACT_RELU ? 0.f : a.alpha;
+    for (int net = 0; net < 2; ++net) {
+        for (int j = 0; j < K; ++j) {
+            // the layer after this one in the wave's sequence (the t-net's first layer follows the s-net's last)
+            const bool last = j == K - 1;
+            const bool has_next = !(last && net == 1);
+            BChunk nx = cur;
+            if (has_next) nx = last ? chunk_from_tab(0, 1) : chunk_from_tab(j + 1, net);
+            const bool pre_next = has_next && nx.active;
+            GNF_BSTAMP(4 + 6 * (net * K + j) + 0);
+            if (cur.active) {
+                if (!have_pre) big_prefetch(cur, lane, b_nx, bias_nx);
+#define GNF_BIG_RUN(NV_, RB_, MW_) \
+    big_chunk<NV_, RB_, MW_>(act, cur, nx, pre_next, lane, b_nx, bias_nx, last, slope_hidden, s_keep, net == 1, hp)
+                if (cur.thin)
+                    big_chunk_thin(act, cur, nx, pre_next, lane, b_nx, bias_nx, last, slope_hidden, s_keep, net == 1, hp);
+                else if (cur.nv == 4) {
+                    if (cur.mw > 2)
+                        GNF_BIG_RUN(4, GNF_BIG_RBW, kBigMT);
+                    else
+                        GNF_BIG_RUN(4, 2 * GNF_BIG_RBW, 2);
+                } else if (cur.nv == 3) {
+                    if (cur.mw > 2)
+                        GNF_BIG_RUN(3, GNF_BIG_RBW, kBigMT);
+                    else
+                        GNF_BIG_RUN(3, 2 * GNF_BIG_RBW, 2);
+                } else if (cur.nv == 2) {
+                    if (cur.mw > 2)
+                        GNF_BIG_RUN(2, 3, kBigMT);
+                    else
+                        GNF_BIG_RUN(2, 6, 2);
+                } else {
+                    GNF_BIG_RUN(1, 4, kBigMT);
+                }
+#undef GNF_BIG_RUN
+            } else {
+                if (pre_next) big_prefetch(nx, lane, b_nx, bias_nx);
+                if (!last) {  // (the two barriers of an in-place layer)
+                    __syncthreads();
+                    __syncthreads();
+                } else if (net == 1) {
+                    __syncthreads();  // (the barrier in front of the s | t rows, big_layer_end)
+                }
+            }
+            GNF_BSTAMP(4 + 6 * (net * K + j) + 5);
+            if (last && net == 0) {
+                __syncthreads();  // every wave is done with the s-net's last hidden rows
+                GNF_BSTAMP(4 + 6 * (net * K + j) + 2);
+                load_h0(a.h0[1]);
+                GNF_BSTAMP(4 + 6 * (net * K + j) + 3);
+                __syncthreads();
+                GNF_BSTAMP(4 + 6 * (net * K + j) + 4);
+            }
+            if (has_next) {
+                have_pre = pre_next;
+                cur = nx;
+            }
+        }
+    }
+
+    // ---- C: coupling update from the s | t rows in LDS, rows of x coalesced (16 bytes per lane where the widths allow,
+    // four requests per thread before the first use); this lane's fp64 shares of sum(s) and sum(x_new^2) ----
+    __syncthreads();
+    double local = 0.0, local2 = 0.0;
+    {
+        auto one = [&](float xv, float xr, float sv, float tv, float& xn) {
+            const float s_ = sv + xr, t_ = tv + xr;
+            xn = a.inverse ? (xv - t_) * expf(-s_) : xv * expf(s_) + t_;
+            local += (double)s_;
+            local2 += (double)xn * (double)xn;
+        };
+        const bool v4 = (H & 3) == 0 && (a.ld & 3) == 0 &&
+                        ((reinterpret_cast<uintptr_t>(a.x_upd_src) | reinterpret_cast<uintptr_t>(a.x_upd) |
+                          reinterpret_cast<uintptr_t>(a.x_cond)) & 15) == 0;
+        if (v4) {
+            const int q4 = H >> 2, total = rows * q4;
+#pragma unroll 1
+            for (int base = tid; base < total; base += 4 * kBigThreads) {
+                f32x4 xv[4], xr[4];
+                int off[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int idx = base + g * kBigThreads;
+                    const int i = idx < total ? idx : total - 1;
+                    const int rl = i / q4, f = (i - rl * q4) * 4;
+                    off[g] = (int)((row0 + rl) * a.ld) + f;  // < 2^31: choose_big checked n_nodes * ld
+                    xv[g] = *reinterpret_cast<const f32x4*>(a.x_upd_src + off[g]);
+                    xr[g] = a.residual ? *reinterpret_cast<const f32x4*>(a.x_cond + off[g]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int idx = base + g * kBigThreads;
+                    if (idx < total) {
+                        const int rl = idx / q4, f = (idx - rl * q4) * 4;
+                        const f32x4 sv = *reinterpret_cast<const f32x4*>(act + rl * kBigLS + f);
+                        const f32x4 tv = *reinterpret_cast<const f32x4*>(act + rl * kBigLS + hp + f);
+                        f32x4 xn;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float o;
+                            one(xv[g][k], xr[g][k], sv[k], tv[k], o);
+                            xn[k] = o;
+                        }
+                        *reinterpret_cast<f32x4*>(a.x_upd + off[g]) = xn;
+                    }
+                }
+            }
+        } else {
+            const int total = rows * H;
+#pragma unroll 1
+            for (int base = tid; base < total; base += 4 * kBigThreads) {  // four independent elements in flight
+                float xv[4], xr[4];
+                int off[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int idx = base + g * kBigThreads;
+                    const int i = idx < total ? idx : total - 1;
+                    const int rl = i / H, f = i - rl * H;
+                    off[g] = (int)((row0 + rl) * a.ld) + f;
+                    xv[g] = a.x_upd_src[off[g]];
+                    xr[g] = a.residual ? a.x_cond[off[g]] : 0.f;
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int idx = base + g * kBigThreads;
+                    if (idx < total) {
+                        const int rl = idx / H, f = idx - rl * H;
+                        float xn;
+                        one(xv[g], xr[g], act[rl * kBigLS + f], act[rl * kBigLS + hp + f], xn);
+                        a.x_upd[off[g]] = xn;
+                    }
+                }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        local += __shfl_down(local, off, 64);
+        local2 += __shfl_down(local2, off, 64);
+    }
+    if (lane == 0) {
+        red[wave] = local;
+        red[kBigWaves + wave] = local2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0.0, tot2 = 0.0;
+        for (int w = 0; w < kBigWaves; ++w) {
+            tot += red[w];
+            tot2 += red[kBigWaves + w];
+        }
+        a.partials[wg] = tot;
+        if (a.sq_partials) a.sq_partials[wg] = tot2;
+    }
+    GNF_BSTAMP(63);
+#ifdef GNF_BIG_TRACE
+    if (tid == 0 && blockIdx.x < 8192) g_big_span[blockIdx.x][1] = __builtin_amdgcn_s_memtime();
+#endif
+}
+
+#ifdef GNF_BIG_TRACE
+extern "C" int gnf_debug_big_trace(unsigned long long* out, unsigned int* hwid, int b0, int b1) {
+    if (b0 >= 0) {  // set the two traced blocks for the next launches
+        int v[2] = {b0, b1};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_big_trace_blocks), v, sizeof(v));
+    }
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_trace), sizeof(unsigned long long) * 2 * 8 * 64);
+    if (rc) return rc;
+    return (int)hipMemcpyFromSymbol(hwid, HIP_SYMBOL(g_big_hwid), sizeof(unsigned int) * 2 * 8);
+}
+extern "C" int gnf_debug_big_spans(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_span), sizeof(unsigned long long) * 8192 * 3);
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------
+static size_t big_lds_bytes() {
+    return (size_t)kBigTM * kBigLS * sizeof(float) + 16 * sizeof(double) + (size_t)(GNF_MAX_LAYERS * 8) * sizeof(int);
+}
+
+// layer widths the in-place form holds: every layer input <= 256 (one LDS row), every hidden width <= 256 (a wave's
+// four column tiles), the coupling half <= 128 (s stays in two column tiles' accumulators per wave)
+bool big_supported(const GnfMlp* s, int32_t H) {
+    if (!s->packed) return false;
+    const int K = s->num_layers;
+    for (int j = 0; j < K; ++j)
+        if (pad16(s->dims[j]) > kBigMaxW) return false;
+    if (pad16(s->dims[K]) > kBigMaxH || pad16(H) > kBigMaxH) return false;
+    return true;
+}
+
+// How the batch's 16-row granules are dealt out (cus = CUs of the device, cap = row tiles per workgroup at most: 4,
+// developer override 1 .. 4), as runs of (count, row tiles) in dispatch order:
+//   * up to one pass of the chip (g <= cap * 2 * cus granules): an even deal over 2 * cus workgroups, sizes differing by
+//     one row tile, the larger ones first - every CU slot gets one workgroup and the launch ends everywhere at once
+//     (20 k nodes at the config-4 widths: 149 us against 177 for the 32-row both-nets shape, 214 for whole 64-row tiles);
+//   * more than that: whole cap-tile workgroups (the last one's rows clamped).  The dispatcher hands a new workgroup to
+//     whichever slot frees first, and the SIMD arbiter serves the OLDER of a CU's two workgroups first: the older one runs
+//     at its own pace, the younger fills its gaps and becomes the older one in turn - pairs drift out of phase by
+//     themselves.  Measured and dropped (tools/ab_shapes.sh): an even deal over whole rounds (642 vs 555 us
+//     on config 4: more, smaller workgroups pay the per-workgroup weight stream and prologue more often than the even
+//     finish gives back) and an opening of cap-tile + half-tile workgroups (the half-size one, served second, takes as
+//     long as its partner).
+int big_plan(int64_t n_nodes, int cus, int cap, int32_t* seg_n, int32_t* seg_sz) {
+    for (int k = 0; k < 6; ++k) seg_n[k] = 0, seg_sz[k] = 1;
+    const int64_t g = (n_nodes + 15) / 16;
+    if (g <= (int64_t)cap * 2 * cus) {
+        const int64_t w = g < 2 * (int64_t)cus ? g : 2 * (int64_t)cus;
+        const int base = (int)(g / w);
+        const int64_t rem = g % w;
+        int k = 0;
+        if (rem) seg_n[k] = (int32_t)rem, seg_sz[k] = base + 1, ++k;
+        seg_n[k] = (int32_t)(w - rem), seg_sz[k] = base;
+        return (int)w;
+    }
+    seg_n[0] = (int32_t)((g + cap - 1) / cap);
+    seg_sz[0] = cap;
+    return seg_n[0];
+}
+
+int big_cu_count() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static std::atomic<int> cu_cache[64];  // multiProcessorCount per device (0 = not asked yet)
+    int c = cu_cache[dev & 63].load(std::memory_order_relaxed);
+    if (c == 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+        cu_cache[dev & 63].store(c, std::memory_order_relaxed);
+    }
+    return c;
+}
+
+int launch_half_big(FusedArgs& a, int64_t n_nodes, int cap, hipStream_t st, int* n_wg_out) {
+    const int n_wg = big_plan(n_nodes, big_cu_count(), cap, a.big_seg_n, a.big_seg_sz);
+    a.n_tiles = n_wg;
+    const size_t lds = big_lds_bytes();
+    GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_big),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
+    hipLaunchKernelGGL(k_half_big, dim3((unsigned)n_wg), dim3(kBigThreads), lds, st, a);
+    GNF_LAUNCH_CHECK("k_half_big");
+    *n_wg_out = n_wg;
+    return GNF_OK;
+}
+
+}  // namespace gnf

@@ -20,6 +20,52 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// ---- kernel arguments of the fused forward half-step kernels (gnf_fused.hip, gnf_fused_big.hip) ----
+struct FusedArgs {
+    const int32_t* rowptr;
+    const int32_t* col;
+    const float* x_cond;
+    float* x_upd;
+    const float* x_upd_src;              // old value of the updated half (= x_upd, or the source buffer of an out-of-place first step)
+    float* cond_copy;                    // NULL, or where this tile's rows of the conditioning half are copied to (out-of-place first step)
+    double* partials;
+    double* sq_partials;                 // NETS = 2, forward: also sum(x_upd_new^2) per workgroup (the Gaussian term of the
+                                         // flow's last two half-steps, whose outputs are z), or NULL
+    double* bn_part;                     // NETS = 2, forward: [tile][H][2] column sums / sums of squares of the updated rows
+                                         // (batch moments of the bijector in front of the next half-step), or NULL
+    float* st_out[2];                    // NETS = 1: global [N, H] scratch for s (0) and t (1)
+    const float* h0[2];                  // precomputed layer-0 input per net ([N, in0], attention GNNs) or NULL
+    const float* wp[2][GNF_MAX_LAYERS];  // [net][layer] packed weights
+    const float* bias[2];                // [net] contiguous padded bias block (bias_tot floats)
+    int32_t ipg[GNF_MAX_LAYERS];         // padded input width / 16 of layer j
+    int32_t ont[GNF_MAX_LAYERS];         // padded output width / 16 of layer j
+    int32_t boff[GNF_MAX_LAYERS];        // offset of layer j's bias in the LDS bias block
+    int64_t ld;
+    int32_t n_nodes;
+    int32_t n_tiles;
+    int32_t H;
+    int32_t in0;       // true layer-0 input width (H or 2H)
+    int32_t K;
+    int32_t LS;        // LDS row stride (floats)
+    int32_t bias_tot;  // floats of bias per net in LDS
+    int32_t mean, concat, act, inverse;
+    int32_t residual;  // attention block with residual: s, t += x_cond (gnn.py:547-548)
+    int32_t variant;   // developer A/B bits (gnf_set_option("fused_variant", ...)); 0 = shipped behaviour
+    // k_half_big: the launch is a sequence of runs of big_seg_n[k] workgroups that own big_seg_sz[k] row tiles of 16 nodes each
+    int32_t big_seg_n[6], big_seg_sz[6];
+    float eps, alpha;
+    // training forward (STASH instance only): every row the backward pass would otherwise recompute goes to the
+    // half-step's slot of GnfFlow.mlp_stash - the layer-0 input, each hidden activation of both nets, s and t
+    float* stash_h0;                          // [N, in0]
+    float* stash_act[2][GNF_MAX_LAYERS];      // [net][j], j = 1 .. K-1: input of layer j, [N, stash_ld]
+    float* stash_st[2];                       // s, t [N, H]
+    int32_t stash_w[GNF_MAX_LAYERS];          // true output width of layer j
+    int32_t stash_ld;
+    unsigned long long* stash_mask;           // [tile][net][K-1][4][mld] ballot of "activation > 0" (act' for the way back)
+    int32_t stash_mld;
+};
+
+
 // B fragments come through a buffer descriptor: base = this (net, layer)'s packed weights (SGPRs),
 // soffset = wave-uniform byte offset of the 1 KiB fragment block, voffset = lane * 16.  No per-load
 // 64-bit VALU address arithmetic and a single constant address VGPR.

@@ -1,0 +1,33 @@
+#!/bin/bash
+# PMC passes for one bench workload under one GNF_OPTIONS setting (run on the GPU box):
+#   tools/pmc_shape.sh <tag> <workload> [GNF_OPTIONS]
+# -> gpurun_out/pmc_<tag>/{kernel_stats.txt, pmc_means.txt}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+tag=$1; wl=$2; export GNF_OPTIONS=$3
+out=$R/gpurun_out/pmc_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py --workload $wl --no-cpu-baseline --no-secondary --latency-steps 0 --prewarm-ms 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o kt -- $B --steps 20 --warmup 5 > $out/bench_under_rocprof.log 2>&1
+python $R/tools/kstats.py $out/trace 6 > $out/kernel_stats.txt
+i=0
+for p in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT" \
+         "GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVES SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CU_CYCLES" \
+         "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum"; do
+  i=$((i+1))
+  rocprofv3 --pmc $p --kernel-trace --output-format csv -d $out/p$i -o pmc -- $B --steps 3 --warmup 1 --kernel-timing-steps 1 > $out/p$i.log 2>&1
+done
+python - <<PY > $out/pmc_means.txt
+import csv, glob, collections
+rows = list(csv.DictReader(open(glob.glob("$out/trace/**/*kernel_stats.csv", recursive=True)[0])))
+dom = max(rows, key=lambda r: float(r["TotalDurationNs"]))["Name"]
+print("# workload $wl  GNF_OPTIONS=$3  dominant kernel:", dom[:100])
+for f in sorted(glob.glob("$out/p*/**/*counter_collection.csv", recursive=True)):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Kernel_Name"] == dom:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        print(f"{sum(v)/len(v):18.1f}  n={len(v):4d}  {k}")
+PY
+cat $out/kernel_stats.txt $out/pmc_means.txt
