@@ -65,7 +65,7 @@ __device__ unsigned long long g_big_span[8192][3];  // per block: start, end, HW
 // a wave's share of one layer (all wave-uniform)
 struct BChunk {
     const float* wbase;  // packed weights of the layer
-    const float* bias;   // this layer's padded bias row
+    const float* bias;   // this layer's padded bias row (LDS)
     unsigned wbytes;
     int ipg;   // k-groups
     int ont;   // column tiles of the layer
@@ -79,8 +79,8 @@ struct BChunk {
 
 #define GNF_BIG_LOAD_B(RSRC, VOFF, SOFF) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RSRC, VOFF, SOFF, 0))
 
-// stage 0 of a chunk's weight stream + its bias values: requested while the previous layer is still multiplying
-__device__ __forceinline__ void big_prefetch(const BChunk& c, int lane, f32x4 (&b_nx)[4], float (&bias_nx)[4]) {
+// stage 0 of a chunk's weight stream: requested while the previous layer is still multiplying
+__device__ __forceinline__ void big_prefetch(const BChunk& c, int lane, f32x4 (&b_nx)[4]) {
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.wbase), 0, (int)c.wbytes, 0x00020000);
     const int voff = lane * 16;
@@ -88,10 +88,15 @@ __device__ __forceinline__ void big_prefetch(const BChunk& c, int lane, f32x4 (&
     for (int b = 0; b < 4; ++b) {
         const int ct = c.col0 + (b < c.nv ? kBigWaves * b : 0);
         b_nx[b] = GNF_BIG_LOAD_B(rsrc, voff, ct * 1024);
-        bias_nx[b] = c.bias[16 * ct + (lane & 15)];
     }
 }
 
+// Accumulator layout.  The MFMAs take the WEIGHT fragment as their first operand and the activation fragment as the
+// second (k_half_fused has them the other way round): the product is the transposed tile, lane l holds
+// out[row = l & 15][16 ct + 4 (l >> 4) + r], r = 0 .. 3 - four consecutive COLUMNS of one row, so a layer's write-back is
+// one 16-byte LDS store per (row tile, column tile) instead of four 4-byte ones.  Same registers, same four products per
+// MFMA in the same k order: bitwise the same sums (tests/test_big_shape_gpu.py compares with the 16-row shape).
+//
 // What happens to a chunk's accumulators (row tiles m < c.mw): a hidden layer ends with "barrier (every wave has read the
 // layer's input) - activation, write in place - barrier"; the s-net's last layer leaves s in registers; the t-net's last
 // layer puts s (columns [0, hp)) and t (columns [hp, 2 hp)) of the tile's rows into the activation buffer, behind a
@@ -100,18 +105,19 @@ template <int NV, int MW>
 __device__ __forceinline__ void big_layer_end(float* __restrict__ act, const BChunk& c, int lane, const f32x4 (&acc)[MW][NV],
                                               bool last, float slope, f32x4 (&s_keep)[kBigMT][2], bool couple, int hp) {
     const int lrow = lane & 15, lgrp = lane >> 4;
+    float* const base = act + (16 * c.m0 + lrow) * kBigLS + 16 * c.col0 + 4 * lgrp;
     if (!last) {
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < MW; ++m)
             if (m < c.mw) {  // wave-uniform
 #pragma unroll
-                for (int b = 0; b < NV; ++b)
+                for (int b = 0; b < NV; ++b) {
+                    f32x4 o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = acc[m][b][r];
-                        act[(16 * (c.m0 + m) + 4 * lgrp + r) * kBigLS + 16 * (c.col0 + kBigWaves * b) + lrow] = fmaxf(v, slope * v);
-                    }
+                    for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[m][b][r], slope * acc[m][b][r]);
+                    *reinterpret_cast<f32x4*>(base + 16 * m * kBigLS + 16 * kBigWaves * b) = o;
+                }
             }
         __syncthreads();
     } else if constexpr (NV <= 2) {  // (the coupling half has at most 8 column tiles: two per wave)
@@ -126,13 +132,11 @@ __device__ __forceinline__ void big_layer_end(float* __restrict__ act, const BCh
             for (int m = 0; m < MW; ++m)
                 if (m < c.mw) {
 #pragma unroll
-                    for (int b = 0; b < NV; ++b)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float* p = act + (16 * (c.m0 + m) + 4 * lgrp + r) * kBigLS + 16 * (c.col0 + kBigWaves * b) + lrow;
-                            p[0] = s_keep[m][b][r];
-                            p[hp] = acc[m][b][r];
-                        }
+                    for (int b = 0; b < NV; ++b) {
+                        float* p = base + 16 * m * kBigLS + 16 * kBigWaves * b;
+                        *reinterpret_cast<f32x4*>(p) = s_keep[m][b];
+                        *reinterpret_cast<f32x4*>(p + hp) = acc[m][b];
+                    }
                 }
         }
     }
@@ -150,18 +154,19 @@ __device__ __forceinline__ void big_layer_end(float* __restrict__ act, const BCh
 // whose B ring is twice as deep in the same registers: its k-groups are half as long, and the weight fragments have to be
 // requested the same TIME ahead (a lone 1-tile workgroup with one k-group in flight ran 925 cycles per 512-cycle k-group:
 // the L2 round trip; a 2-tile workgroup beside a 4-tile one took as long as its partner).
-template <int NV, int RB, int MW>
+// FULL: every row tile of the instance is live (c.mw == MW) - no branches between the row tiles' MFMA blocks.
+template <int NV, int RB, int MW, bool FULL>
 __device__ __forceinline__ void big_chunk(float* __restrict__ act, const BChunk& c, const BChunk& nx, bool have_nx,
-                                          int lane, f32x4 (&b_nx)[4], float (&bias_nx)[4], bool last, float slope,
+                                          int lane, f32x4 (&b_nx)[4], bool last, float slope,
                                           f32x4 (&s_keep)[kBigMT][2], bool couple, int hp) {
     constexpr int PF = RB - 1;
     const int lrow = lane & 15, lgrp = lane >> 4;
-    const int ipg = c.ipg, mw = c.mw;
+    const int ipg = c.ipg, mw = FULL ? MW : c.mw;
     f32x4 acc[MW][NV];
 #pragma unroll
     for (int b = 0; b < NV; ++b)
 #pragma unroll
-        for (int m = 0; m < MW; ++m) acc[m][b] = f32x4{bias_nx[b], bias_nx[b], bias_nx[b], bias_nx[b]};
+        for (int m = 0; m < MW; ++m) acc[m][b] = *reinterpret_cast<const f32x4*>(c.bias + 16 * (c.col0 + kBigWaves * b) + 4 * lgrp);
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.wbase), 0, (int)c.wbytes, 0x00020000);
     const int voff = lane * 16;
@@ -182,12 +187,12 @@ __device__ __forceinline__ void big_chunk(float* __restrict__ act, const BChunk&
     }
 #pragma unroll
     for (int m = 0; m < MW; ++m)
-        if (m < mw) a_frag[m] = *reinterpret_cast<const f32x4*>(arow + 16 * m * kBigLS);
+        if (FULL || m < mw) a_frag[m] = *reinterpret_cast<const f32x4*>(arow + 16 * m * kBigLS);
 
     // the MFMAs of one row tile with B slot SB, then the refill of its A fragment with k-group KA
 #define GNF_BIG_MBLOCK(M, SB, KA)                                                                       \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int b = 0; b < NV; ++b)        \
-        acc[M][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_frag[M][q], b_ring[SB][b][q], acc[M][b], 0, 0, 0); \
+        acc[M][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_ring[SB][b][q], a_frag[M][q], acc[M][b], 0, 0, 0); \
     a_frag[M] = *reinterpret_cast<const f32x4*>(arow + 16 * (M) * kBigLS + 16 * (KA));
     // stage kg: B slot kg % RB; the k-group RB - 1 ahead goes into the slot stage kg - 1 just left (LOADS: not in the tail)
 #define GNF_BIG_STAGE(SB, KA, KB, LOADS)                                                                \
@@ -200,15 +205,16 @@ __device__ __forceinline__ void big_chunk(float* __restrict__ act, const BChunk&
     if (LOADS) __builtin_amdgcn_sched_group_barrier(0x020, NV, 0);                                      \
     __builtin_amdgcn_sched_group_barrier(0x008, 4 * NV - 1, 0);                                         \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if (!FULL) __builtin_amdgcn_sched_barrier(0);                                                       \
     _Pragma("unroll") for (int m_ = 1; m_ < MW; ++m_) {                                                 \
-        if (m_ < mw) { /* wave-uniform */                                                               \
+        if (FULL || m_ < mw) { /* wave-uniform */                                                       \
             GNF_BIG_MBLOCK(m_, SB, KA)                                                                  \
             __builtin_amdgcn_sched_group_barrier(0x008, 4 * NV, 0);                                     \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                          \
-            __builtin_amdgcn_sched_barrier(0);                                                          \
+            if (!FULL) __builtin_amdgcn_sched_barrier(0);                                               \
         }                                                                                               \
-    }
+    }                                                                                                   \
+    if (FULL) __builtin_amdgcn_sched_barrier(0);
 #define GNF_BIG_ROUND(KG0)                                                                              \
     _Pragma("unroll") for (int u = 0; u < RB; ++u) {                                                    \
         const int kg = (KG0) + u;                                                                       \
@@ -227,14 +233,14 @@ __device__ __forceinline__ void big_chunk(float* __restrict__ act, const BChunk&
     bool pre_done = false;
     for (; kg0 + RB <= ipg; kg0 += RB) {
         if (kg0 + 2 * RB > ipg) {
-            if (have_nx) big_prefetch(nx, lane, b_nx, bias_nx);  // (b_nx was consumed above)
+            if (have_nx) big_prefetch(nx, lane, b_nx);  // (b_nx was consumed above)
             pre_done = true;
             __builtin_amdgcn_sched_barrier(0);
         }
         GNF_BIG_ROUND(kg0)
     }
     if (!pre_done) {
-        if (have_nx) big_prefetch(nx, lane, b_nx, bias_nx);
+        if (have_nx) big_prefetch(nx, lane, b_nx);
         __builtin_amdgcn_sched_barrier(0);
     }
     // tail: stages kg0 .. ipg-1 sit in B slots 0 .. rem-1 (requested by the last round, or by the chunk's entry when
@@ -258,14 +264,14 @@ __device__ __forceinline__ void big_chunk(float* __restrict__ act, const BChunk&
 // the waves (<= 2 each), every k-group's fragment is requested before the first MFMA (<= 16 k-groups = 64 registers),
 // the A fragments alternate between two slots.  Same k order as big_chunk: bitwise the same sums.
 __device__ __forceinline__ void big_chunk_thin(float* __restrict__ act, const BChunk& c, const BChunk& nx, bool have_nx,
-                                               int lane, f32x4 (&b_nx)[4], float (&bias_nx)[4], bool last, float slope,
+                                               int lane, f32x4 (&b_nx)[4], bool last, float slope,
                                                f32x4 (&s_keep)[kBigMT][2], bool couple, int hp) {
     constexpr int NS = kBigMaxW / 16, MW = 2;
     const int lrow = lane & 15, lgrp = lane >> 4;
     const int ipg = c.ipg, mw = c.mw;
     f32x4 acc[MW][1];
 #pragma unroll
-    for (int m = 0; m < MW; ++m) acc[m][0] = f32x4{bias_nx[0], bias_nx[0], bias_nx[0], bias_nx[0]};
+    for (int m = 0; m < MW; ++m) acc[m][0] = *reinterpret_cast<const f32x4*>(c.bias + 16 * c.col0 + 4 * lgrp);
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.wbase), 0, (int)c.wbytes, 0x00020000);
     const int voff = lane * 16, wtile = c.col0 * 1024, kstride = c.ont * 1024;
@@ -277,7 +283,7 @@ __device__ __forceinline__ void big_chunk_thin(float* __restrict__ act, const BC
     for (int u = 1; u < NS; ++u) bst[u] = GNF_BIG_LOAD_B(rsrc, voff, wtile + (u < ipg ? u : ipg - 1) * kstride);
     a_ring[0][0] = *reinterpret_cast<const f32x4*>(arow);
     a_ring[0][1] = *reinterpret_cast<const f32x4*>(arow + 16 * m1 * kBigLS);
-    if (have_nx) big_prefetch(nx, lane, b_nx, bias_nx);
+    if (have_nx) big_prefetch(nx, lane, b_nx);
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
         if (u < ipg) {  // wave-uniform
@@ -288,7 +294,7 @@ __device__ __forceinline__ void big_chunk_thin(float* __restrict__ act, const BC
             for (int m = 0; m < MW; ++m)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ring[u % 2][m][q], bst[u][q], acc[m][0], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bst[u][q], a_ring[u % 2][m][q], acc[m][0], 0, 0, 0);
         }
     }
     big_layer_end<1, MW>(act, c, lane, acc, last, slope, s_keep, couple, hp);
@@ -299,6 +305,7 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
     float* act = smem;
     double* red = reinterpret_cast<double*>(act + kBigTM * kBigLS);  // [4] sum(s) | [4] sum(x_new^2)
     int* tab = reinterpret_cast<int*>(red + 16);                     // [K][8]: ipg, ont, boff, -, wp[0] lo/hi, wp[1] lo/hi
+    float* bias_lds = reinterpret_cast<float*>(tab + GNF_MAX_LAYERS * 8);  // [2][bias_tot]: every layer's padded bias row, both nets
 
     // workgroup = block (dispatch order = row order: nothing here gathers, so which XCD a row tile lands on does not
     // matter); its row tiles from the launch's run table (big_plan)
@@ -338,18 +345,18 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
     // this wave's share of a layer: column tiles {w, w+4, w+8, w+12} x every row tile when the layer has at least 3 column
     // tiles; a thinner layer spreads its column tiles over the first cg = ont waves of each group and the row tiles over
     // the 4 / cg groups (the 256 -> 32 output layer: 2 column tiles x 2 halves of the rows)
-    auto assign = [&](BChunk& c) {
+    auto assign = [&](BChunk& c) {  // (shifts and masks only: this runs on the scalar unit in front of every layer)
         const int ont = c.ont;
-        const int cg = ont >= 3 ? 4 : (ont <= 1 ? 1 : 2);
-        const int groups = kBigWaves / cg;           // 1, 2, 4
-        const int per = (mt + groups - 1) / groups;  // row tiles per wave group: <= 2 when groups >= 2
-        const int g = wave / cg;
-        c.col0 = wave % cg;
-        c.nv = c.col0 < ont ? (ont - c.col0 + kBigWaves - 1) / kBigWaves : 0;
+        const int cgl = ont >= 3 ? 2 : (ont <= 1 ? 0 : 1);  // log2 of the waves a group has: 4, 1, 2
+        const int gl = 2 - cgl;                             // log2 of the groups: 1, 4, 2
+        const int per = (mt + (1 << gl) - 1) >> gl;         // row tiles per wave group: <= 2 when there are 2 or 4 groups
+        const int g = wave >> cgl;
+        c.col0 = wave & ((1 << cgl) - 1);
+        c.nv = c.col0 < ont ? (ont - c.col0 + kBigWaves - 1) >> 2 : 0;
         c.m0 = g * per;
         const int left = mt - c.m0;
         c.mw = left < 0 ? 0 : (left < per ? left : per);
-        c.thin = cg < 4;
+        c.thin = cgl < 2;
         c.active = (c.nv > 0 && c.mw > 0) ? 1 : 0;
     };
     auto chunk_from_args = [&](int j, int net) -> BChunk {
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
         c.ont = a.ont[j];
         c.wbase = a.wp[net][j];
         c.wbytes = (unsigned)c.ipg * (unsigned)c.ont * 1024u;
-        c.bias = a.bias[net] + a.boff[j];
+        c.bias = bias_lds + net * a.bias_tot + a.boff[j];
         assign(c);
         return c;
     };
@@ -372,18 +379,19 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
         const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane(row[5 + 2 * net]);
         c.wbase = reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
         c.wbytes = (unsigned)c.ipg * (unsigned)c.ont * 1024u;
-        c.bias = a.bias[net] + boff;
+        c.bias = bias_lds + net * a.bias_tot + boff;
         assign(c);
         return c;
     };
 
     // ---- the first chunk's weights start streaming before anything else --------------------------------
     f32x4 b_nx[4];
-    float bias_nx[4];
     BChunk cur = chunk_from_args(0, 0);
     bool have_pre = cur.active;
-    if (have_pre) big_prefetch(cur, lane, b_nx, bias_nx);
+    if (have_pre) big_prefetch(cur, lane, b_nx);
 
+    for (int i = tid; i < 2 * a.bias_tot; i += kBigThreads)  // (one coalesced copy per net: the bias block is contiguous)
+        bias_lds[i] = i < a.bias_tot ? a.bias[0][i] : a.bias[1][i - a.bias_tot];
     if (tid < 8 * K) {  // layer table (one thread per word)
         const int j = tid >> 3, w = tid & 7;
         const unsigned long long p0 = reinterpret_cast<unsigned long long>(a.wp[0][j]);
@@ -462,32 +470,29 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
             const bool pre_next = has_next && nx.active;
             GNF_BSTAMP(4 + 6 * (net * K + j) + 0);
             if (cur.active) {
-                if (!have_pre) big_prefetch(cur, lane, b_nx, bias_nx);
+                if (!have_pre) big_prefetch(cur, lane, b_nx);
 #define GNF_BIG_RUN(NV_, RB_, MW_) \
-    big_chunk<NV_, RB_, MW_>(act, cur, nx, pre_next, lane, b_nx, bias_nx, last, slope_hidden, s_keep, net == 1, hp)
+    big_chunk<NV_, RB_, MW_, false>(act, cur, nx, pre_next, lane, b_nx, last, slope_hidden, s_keep, net == 1, hp)
                 if (cur.thin)
-                    big_chunk_thin(act, cur, nx, pre_next, lane, b_nx, bias_nx, last, slope_hidden, s_keep, net == 1, hp);
+                    big_chunk_thin(act, cur, nx, pre_next, lane, b_nx, last, slope_hidden, s_keep, net == 1, hp);
                 else if (cur.nv == 4) {
-                    if (cur.mw > 2)
+                    if (cur.mw == kBigMT)  // (the shape almost all of a large batch's work runs in: no row-tile branches)
+                        big_chunk<4, GNF_BIG_RBW, kBigMT, true>(act, cur, nx, pre_next, lane, b_nx, last, slope_hidden, s_keep,
+                                                                net == 1, hp);
+                    else if (cur.mw > 2)
                         GNF_BIG_RUN(4, GNF_BIG_RBW, kBigMT);
                     else
                         GNF_BIG_RUN(4, 2 * GNF_BIG_RBW, 2);
-                } else if (cur.nv == 3) {
-                    if (cur.mw > 2)
-                        GNF_BIG_RUN(3, GNF_BIG_RBW, kBigMT);
-                    else
-                        GNF_BIG_RUN(3, 2 * GNF_BIG_RBW, 2);
+                } else if (cur.nv == 3) {  // (the less common widths: one instance each, to keep the code small)
+                    GNF_BIG_RUN(3, GNF_BIG_RBW, kBigMT);
                 } else if (cur.nv == 2) {
-                    if (cur.mw > 2)
-                        GNF_BIG_RUN(2, 3, kBigMT);
-                    else
-                        GNF_BIG_RUN(2, 6, 2);
+                    GNF_BIG_RUN(2, 3, kBigMT);
                 } else {
                     GNF_BIG_RUN(1, 4, kBigMT);
                 }
 #undef GNF_BIG_RUN
             } else {
-                if (pre_next) big_prefetch(nx, lane, b_nx, bias_nx);
+                if (pre_next) big_prefetch(nx, lane, b_nx);
                 if (!last) {  // (the two barriers of an in-place layer)
                     __syncthreads();
                     __syncthreads();
@@ -626,8 +631,9 @@ extern "C" int gnf_debug_big_spans(unsigned long long* out) {
 #endif
 
 // ------------------------------------------------------------------------------------------------
-static size_t big_lds_bytes() {
-    return (size_t)kBigTM * kBigLS * sizeof(float) + 16 * sizeof(double) + (size_t)(GNF_MAX_LAYERS * 8) * sizeof(int);
+static size_t big_lds_bytes(int bias_tot) {
+    return (size_t)kBigTM * kBigLS * sizeof(float) + 16 * sizeof(double) + (size_t)(GNF_MAX_LAYERS * 8) * sizeof(int) +
+           (size_t)2 * bias_tot * sizeof(float);
 }
 
 // layer widths the in-place form holds: every layer input <= 256 (one LDS row), every hidden width <= 256 (a wave's
@@ -685,9 +691,9 @@ int big_cu_count() {
 int launch_half_big(FusedArgs& a, int64_t n_nodes, int cap, hipStream_t st, int* n_wg_out) {
     const int n_wg = big_plan(n_nodes, big_cu_count(), cap, a.big_seg_n, a.big_seg_sz);
     a.n_tiles = n_wg;
-    const size_t lds = big_lds_bytes();
+    const size_t lds = big_lds_bytes(a.bias_tot);  // <= 66.7 KB + 2 * 8 * 256 * 4: two workgroups per CU
     GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_big),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024)));  // (K = 8 layers of 256: 83.3 KB)
     hipLaunchKernelGGL(k_half_big, dim3((unsigned)n_wg), dim3(kBigThreads), lds, st, a);
     GNF_LAUNCH_CHECK("k_half_big");
     *n_wg_out = n_wg;

@@ -49,3 +49,30 @@ def test_workload_table():
     assert set(bench.WORKLOADS) == {"config2", "config2_fc", "config2_attn", "config4", "config5", "wide_fc", "config2_train", "default_flags_train"}
     assert bench.WORKLOADS["config5"]["hp"] == dict(D=256, T=16)
     assert bench.WORKLOADS["config4"]["inverse"] is True
+
+
+def test_line_consistency_checks():
+    """kernel_us x launches_per_step <= ms_per_step (round 2's attention line had 78.8 us x 16 = 1.26 ms against a 0.866 ms
+    step: its kernel-timing leg ran a path the step does not), on synthetic lines and on every round-3 line committed
+    under profiles/."""
+    import glob
+    import json
+    import os
+    good = {"ms_per_step": 0.566, "config": {"workload": "config2: ..."},
+            "spread": {"ms_per_step_min": 0.56, "ms_per_step_max": 0.57},
+            "roofline": {"kernel_us": 35.2, "launches_per_step": 16, "frac": 0.4184, "achieved": 65.82, "peak": 157.3}}
+    assert bench.line_consistency_errors(good) == []
+    bad = json.loads(json.dumps(good))
+    bad["ms_per_step"] = 0.866
+    bad["spread"] = {"ms_per_step_min": 0.86, "ms_per_step_max": 0.87}
+    bad["roofline"]["kernel_us"] = 78.81
+    assert any("kernel_us" in e for e in bench.line_consistency_errors(bad))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = 0
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "r3*"))):
+        for line in open(f, errors="replace"):
+            if line.startswith('{"metric"'):
+                d = json.loads(line)
+                assert bench.line_consistency_errors(d) == [], (f, bench.line_consistency_errors(d))
+                seen += 1
+    assert seen >= 1

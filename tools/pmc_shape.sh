@@ -9,6 +9,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --workload $wl --no-cpu-baseline --no-secondary --latency-steps 0 --prewarm-ms 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o kt -- $B --steps 20 --warmup 5 > $out/bench_under_rocprof.log 2>&1
+python -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.kernel_source_stamp())" > $out/source_stamp.txt
 python $R/tools/kstats.py $out/trace 6 > $out/kernel_stats.txt
 i=0
 for p in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT" \
@@ -21,7 +22,9 @@ python - <<PY > $out/pmc_means.txt
 import csv, glob, collections
 rows = list(csv.DictReader(open(glob.glob("$out/trace/**/*kernel_stats.csv", recursive=True)[0])))
 dom = max(rows, key=lambda r: float(r["TotalDurationNs"]))["Name"]
-print("# workload $wl  GNF_OPTIONS=$3  dominant kernel:", dom[:100])
+print("# workload $wl  GNF_OPTIONS=$3  kernel sources stamp (bench.kernel_source_stamp):", open("$out/source_stamp.txt").read().strip())
+print("# dominant kernel:", dom[:100])
+print("# PMC passes (separate runs, --pmc only with --kernel-trace): mean per dispatch of the dominant kernel")
 for f in sorted(glob.glob("$out/p*/**/*counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
@@ -30,4 +33,5 @@ for f in sorted(glob.glob("$out/p*/**/*counter_collection.csv", recursive=True))
     for k, v in agg.items():
         print(f"{sum(v)/len(v):18.1f}  n={len(v):4d}  {k}")
 PY
-cat $out/kernel_stats.txt $out/pmc_means.txt
+$B --steps 50 --warmup 10 > $out/bench.json 2> $out/bench.err
+cat $out/kernel_stats.txt $out/pmc_means.txt; tail -1 $out/bench.json

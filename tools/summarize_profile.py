@@ -12,6 +12,45 @@ import os
 import sys
 
 
+TRAFFIC_NOTE = ("HBM-side bytes per launch of each workload's dominant kernel: rocprofv3 --pmc FETCH_SIZE x 1024 x 2 (gfx950 "
+                "correction, MI355X_MICROARCH.md) + WRITE_SIZE x 1024, separate passes (tools/profile.sh, tools/pmc_shape.sh); "
+                "bench.py quotes an entry only when source_stamp is the build's")
+
+
+def merge_traffic(path, stamp, workload, entry):
+    """profiles/pmc_traffic.json = {source_stamp, workloads: {name: entry}}; entries taken on other kernel sources go."""
+    try:
+        cur = json.load(open(path))
+    except (OSError, ValueError):
+        cur = {}
+    if cur.get("source_stamp") != stamp:
+        cur = {"source_stamp": stamp, "note": TRAFFIC_NOTE, "workloads": {}}
+    cur.setdefault("workloads", {})[workload] = entry
+    json.dump(cur, open(path, "w"), indent=1)
+
+
+def merge_pmc_shape(src, workload, dst):
+    """A tools/pmc_shape.sh output directory (gpurun_out/pmc_<tag>) -> profiles/<tag>_rocprof_summary.txt + its entry."""
+    import re
+    tag = os.path.basename(os.path.normpath(src))[len("pmc_"):]
+    txt = open(os.path.join(src, "pmc_means.txt")).read()
+    stamp = re.search(r"stamp \(bench.kernel_source_stamp\): (\w+)", txt).group(1)
+    vals = {m.group(2): float(m.group(1)) for m in re.finditer(r"^\s*([\d.]+)\s+n=\s*\d+\s+(\w+)$", txt, re.M)}
+    kern = re.search(r"# dominant kernel: (.*)", txt).group(1).strip()
+    f, w = vals["FETCH_SIZE"] * 1024 * 2, vals["WRITE_SIZE"] * 1024
+    merge_traffic(os.path.join(dst, "pmc_traffic.json"), stamp, workload,
+                  {"tag": tag, "kernel": kern, "fetch_bytes_per_launch": f, "write_bytes_per_launch": w,
+                   "traffic_bytes_per_launch": f + w, "l2_hit_rate": vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]),
+                   "mfma_busy_cycles_per_launch": vals["SQ_VALU_MFMA_BUSY_CYCLES"],
+                   "grbm_gui_active_sum_over_8_xcds": vals["GRBM_GUI_ACTIVE"]})
+    lines = [f"# tools/pmc_shape.sh {tag} {workload}: rocprofv3 --kernel-trace --stats of bench.py --workload {workload} --steps 20 "
+             "--warmup 5 --no-cpu-baseline --no-secondary --latency-steps 0 --prewarm-ms 0, then one --pmc pass per counter group",
+             open(os.path.join(src, "kernel_stats.txt")).read(), txt,
+             f"# bench.py --workload {workload} --steps 50 --warmup 10 on the same box, un-profiled:",
+             open(os.path.join(src, "bench.json")).read().strip().split("\n")[-1]]
+    open(os.path.join(dst, f"{tag}_rocprof_summary.txt"), "w").write("\n".join(lines) + "\n")
+
+
 def main(src, tag, dst):
     os.makedirs(dst, exist_ok=True)
     lines = []
@@ -56,7 +95,7 @@ def main(src, tag, dst):
                      f"SQ_WAIT_INST_ANY/SQ_WAVE_CYCLES = {pmc['SQ_WAIT_INST_ANY']/pmc['SQ_WAVE_CYCLES']:.3f}, "
                      f"SQ_ACTIVE_INST_ANY/SQ_WAVE_CYCLES = {pmc['SQ_ACTIVE_INST_ANY']/pmc['SQ_WAVE_CYCLES']:.3f}")
     open(os.path.join(dst, f"{tag}_rocprof_summary.txt"), "w").write("\n".join(lines) + "\n")
-    json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+    merge_traffic(os.path.join(dst, "pmc_traffic.json"), out.pop("source_stamp"), "config2", out)
     bj = os.path.join(src, "bench.json")
     if os.path.exists(bj):
         txt = [l for l in open(bj) if l.startswith("{")]
@@ -65,5 +104,8 @@ def main(src, tag, dst):
     print("\n".join(lines))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--pmc-shape":
+    # summarize_profile.py --pmc-shape gpurun_out/pmc_<tag> <workload> [profiles]
+    merge_pmc_shape(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "profiles")
+elif __name__ == "__main__":
     main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "profiles")
