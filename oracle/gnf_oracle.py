@@ -419,9 +419,12 @@ def loss_and_grads(senders, receivers, n_total, x, params, num_timesteps, weight
     returns.  The reference differentiates its TF graph with tf.gradients; here torch autograd
     differentiates the float64 edition of the `Fp32Gather` restatement above (same op graph), which
     tests/test_oracle.py pins against central finite differences of `Fp64Dense`.
-    Returns {"total_loss", "log_det_jacobian", "log_prob_zs", "z", "grads"}; grads has the layout of params."""
+    Returns {"total_loss", "log_det_jacobian", "log_prob_zs", "z", "grads"}; grads has the layout of params.
+    dtype=torch.float32 (keyword) runs the same autograd in single precision: what float32 arithmetic costs on the given
+    inputs - the full-batch GPU tests derive their gradient tolerances from it."""
     import torch
-    o = Fp32Gather(senders, receivers, n_total, dtype=torch.float64, **gnn_kw)
+    dtype = gnn_kw.pop("dtype", torch.float64)
+    o = Fp32Gather(senders, receivers, n_total, dtype=dtype, **gnn_kw)
     pt = o.prep_params(params)
     leaves = []
 

@@ -1,6 +1,10 @@
 """BASELINE configs at their STATED batch sizes on one MI355X, against the float64 oracle.
 
-  config 2  community_medium, 64 graphs (the benchmarked launch: 170 node tiles, XCD remap) - whole batch vs the oracle
+  config 2  community_medium, 64 graphs (the benchmarked launch: 170 node tiles, XCD remap) - whole batch vs the oracle;
+            the same batch with the drivers' DEFAULT flags (dm_self_attn GNN + use_batch_norm=True): forward, inverse,
+            gradients with and without the stashes; and on the fully connected topology of train_grevnet_with_data.py
+  config 4  protein stand-in, 256 graphs (~78 k nodes, the large-batch kernel): inverse pass, round trip, and the
+            graphs with the worst round-trip error (+ two arbitrary ones) re-run through the oracle's g
   config 3  community_medium, 512 graphs "sharded 8 ways": whole batch vs the oracle, and the 8 shards of
             shard_graph_ids (what 8 ranks would run) add up to the batch sums
   config 5  ego stand-in, D = 256, T = 16: (i) the hyper-parameters vs the oracle on 8 graphs, forward and
@@ -62,13 +66,23 @@ def _graph_rows(nn):
     return off
 
 
-def _bench_batch():
-    """Exactly bench.py's config-2 batch, weights and features (N = 2718, E = 32202)."""
+def _bench_batch(workload="config2"):
+    """Exactly bench.py's batch, weights and features of a workload (config 2: N = 2718, E = 32202)."""
     import bench
-    dicts, n, e = bench.make_batch(1, 0)
-    params = bench.make_params(bench.WEIGHT_SEED, dict(bench.HP), bench.FINAL_SCALE)
+    saved = (bench.WORKLOAD, bench.GRAPHS_PER_GPU, dict(bench.HP))
+    try:
+        bench.WORKLOAD = bench.WORKLOADS[workload]
+        bench.GRAPHS_PER_GPU = bench.WORKLOAD["graphs"]
+        bench.HP.update(bench.WORKLOAD["hp"])
+        dicts, n, e = bench.make_batch(1, 0)
+        hp = dict(bench.HP)
+        params = bench.make_params(bench.WEIGHT_SEED, hp, bench.FINAL_SCALE)
+    finally:
+        bench.WORKLOAD, bench.GRAPHS_PER_GPU = saved[0], saved[1]
+        bench.HP.clear()
+        bench.HP.update(saved[2])
     from gnf_amd.graphs import data_dicts_to_graphs_tuple
-    return data_dicts_to_graphs_tuple(dicts), params, dict(bench.HP)
+    return data_dicts_to_graphs_tuple(dicts), params, hp
 
 
 # ------------------------------------------------------------------------------------------------
@@ -227,3 +241,155 @@ def test_config5_1024_graphs_properties_and_worst_graphs_vs_oracle():
         z_err = float((zc[off[gi]:off[gi + 1]].double() - c["ref"]["z"]).abs().max())
         assert z_err <= SLACK * c["z_err32"] + FLOOR, (gi, z_err, c["z_err32"])
     assert per_graph.max() == per_graph[worst[0]]
+
+
+# ------------------------------------------------------------------------------------------------
+# the drivers' DEFAULT flags at the bench batch (run_grevnet.py:56,90: --make_gnn_fn dm_self_attn, use_batch_norm=True):
+# what `bench.py --workload default_flags_train` times.  No forced options: the launch choices that depend on the batch
+# size (32- vs 64-row attention tiles, one- vs two-launch edge passes, packed front-end, stash limits) are the bench's.
+# ------------------------------------------------------------------------------------------------
+def test_default_flags_full_batch_forward_and_inverse_vs_fp64_oracle():
+    g_cpu, p, hp = _bench_batch("default_flags_train")
+    assert g_cpu.nodes.shape[0] == 2718 and hp.get("attn") and hp.get("use_batch_norm")
+    x, s, r = g_cpu.nodes.numpy(), g_cpu.senders.numpy(), g_cpu.receivers.numpy()
+    n = x.shape[0]
+    c = _conditioning(hp, s, r, n, x, p)
+    ref = c["ref"]
+    net = make_product_grevnet(hp, p)
+    from gnf_amd.flow import log_prob_terms
+    graph = graph_from_arrays(g_cpu.n_node.numpy(), g_cpu.n_edge.numpy(), s, r, x, DEV)
+    out = log_prob_terms(net, graph)
+    torch.cuda.synchronize()
+    for key in ("log_prob_xs_per_node", "log_prob_zs_per_node", "log_det_jacobian_per_node"):
+        assert abs(float(out[key]) - ref[key]) <= 1e-4, (key, float(out[key]), ref[key])
+    z_err = float((out["z_graph"].nodes.cpu().double() - ref["z"]).abs().max())
+    assert z_err <= SLACK * c["z_err32"] + FLOOR, (z_err, c["z_err32"])
+    # inverse (gnn.py:343-373 with bn.forward on the moving statistics) on the oracle's latent vs the oracle's g
+    zin = torch.as_tensor(ref["z"].numpy().astype(np.float32))
+    xg = net(graph.replace(nodes=zin.to(DEV)), inverse=False).nodes.cpu().double()
+    want = c["o64"].g(zin.double(), c["p64"], hp["T"])
+    o32 = _oracles(hp, s, r, n)[1]
+    g_err32 = float((o32.g(zin, o32.prep_params(p), hp["T"]).double() - want).abs().max())
+    assert float((xg - want).abs().max()) <= SLACK * g_err32 + FLOOR, (float((xg - want).abs().max()), g_err32)
+
+
+def _grad_tensors(grads, hp):
+    """(name, array) of every trainable tensor of an attention + batch-norm flow, in a fixed order."""
+    for kind in ("s", "t"):
+        for half in range(2):
+            for i in range(hp["T"]):
+                net = grads[kind][half][i]
+                for k_ in ("wq", "wk", "wv", "wo"):
+                    yield f"{kind}[{half}][{i}].{k_}", net["attn"][k_]
+                for j in range(hp["K"]):
+                    yield f"{kind}[{half}][{i}].W{j}", net["mlp"][j][0]
+                    yield f"{kind}[{half}][{i}].b{j}", net["mlp"][j][1]
+    for half in range(2):
+        for i in range(hp["T"]):
+            for key in ("gamma", "beta"):
+                yield f"bn[{half}][{i}].{key}", grads["bn"][half][i][key]
+
+
+def _grad_errors(got, ref, hp):
+    """Per tensor: max |a - b| / max |b| and ||a - b||_2 / ||b||_2, tensors whose gradient is zero by cancellation
+    (the last bias of a t-net in front of a batch-norm bijector) judged against the flow's overall gradient scale."""
+    gmax = max(float(np.abs(b).max()) for _, b in _grad_tensors(ref, hp))
+    out = []
+    for (name, a), (_, b) in zip(_grad_tensors(got, hp), _grad_tensors(ref, hp)):
+        scale = max(float(np.abs(b).max()), 1e-3 * gmax)
+        l2 = max(float(np.linalg.norm(b)), 1e-3 * gmax * np.sqrt(b.size))
+        out.append((name, float(np.abs(a - b).max()) / scale, float(np.linalg.norm(a - b)) / l2))
+    return out
+
+
+@pytest.mark.parametrize("stash", [True, False], ids=["stash", "recompute"])
+def test_default_flags_full_batch_gradients_vs_fp64_autograd(stash):
+    """One training iteration's gradients (run_grevnet.py:340-377) on the bench batch with the default flags: every
+    attention, MLP and batch-norm parameter vs float64 autograd of the oracle (itself pinned by finite differences,
+    tests/test_oracle.py), with the forward pass's stashes (the default) and with the fully reversible walk.
+    The tolerance is derived like the forward ones: the SAME autograd in float32 on the CPU shows what single precision
+    costs on these inputs (a pre-activation within rounding of a relu's kink flips a whole column of a gradient: its
+    worst tensor is 1e-2 off in the maximum norm, 1e-3 in the 2-norm) and the HIP path has to stay within SLACK of the
+    worst tensor of that run, in both norms."""
+    from gnf_amd.train import GRevNetTrainer
+    g_cpu, p, hp = _bench_batch("default_flags_train")
+    x, s, r = g_cpu.nodes.numpy(), g_cpu.senders.numpy(), g_cpu.receivers.numpy()
+    n, t = x.shape[0], hp["T"]
+    ref = O.loss_and_grads(s, r, n, x, p, t, activation="relu")
+    r32 = O.loss_and_grads(s, r, n, x, p, t, activation="relu", dtype=torch.float32)
+    e32 = _grad_errors(r32["grads"], ref["grads"], hp)
+    max32, l232 = max(e[1] for e in e32), max(e[2] for e in e32)
+    net = make_product_grevnet(hp, p)
+    tr = GRevNetTrainer(net)
+    tr.stash_attention = stash
+    tr.stash_mlp_rows = stash
+    out = tr.loss_and_grads(graph_from_arrays(g_cpu.n_node.numpy(), g_cpu.n_edge.numpy(), s, r, x, DEV))
+    torch.cuda.synchronize()
+    assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
+    np.testing.assert_allclose(out["reconstruction"].cpu().numpy(), x, atol=5e-4, rtol=5e-4)
+    errs = _grad_errors(tr.named_gradients(), ref["grads"], hp)
+    worst_max = max(errs, key=lambda e: e[1])
+    worst_l2 = max(errs, key=lambda e: e[2])
+    assert worst_max[1] <= SLACK * max32 + 1e-4, (worst_max, max32)
+    assert worst_l2[2] <= SLACK * l232 + 1e-5, (worst_l2, l232)
+    # and the bulk, not only the worst tensor: the median tensor's 2-norm error within SLACK of the CPU run's median
+    med32 = float(np.median([e[2] for e in e32]))
+    assert float(np.median([e[2] for e in errs])) <= SLACK * med32 + 1e-5, (float(np.median([e[2] for e in errs])), med32)
+
+
+def test_config2_fully_connected_topology_full_batch_vs_fp64_oracle():
+    """train_grevnet_with_data.py's topology (every ordered pair of a graph incl. self, utils.py:164-183) on the bench
+    batch: 122 916 edges, mean in-degree 45 - the gathers' long-row path at the benchmarked batch size."""
+    g_cpu, p, hp = _bench_batch("config2_fc")
+    assert g_cpu.senders.shape[0] == 122916
+    x, s, r = g_cpu.nodes.numpy(), g_cpu.senders.numpy(), g_cpu.receivers.numpy()
+    n = x.shape[0]
+    c = _conditioning(hp, s, r, n, x, p)
+    net = make_product_grevnet(hp, p)
+    from gnf_amd.flow import log_prob_terms
+    graph = graph_from_arrays(g_cpu.n_node.numpy(), g_cpu.n_edge.numpy(), s, r, x, DEV)
+    out = log_prob_terms(net, graph)
+    torch.cuda.synchronize()
+    for key in ("log_prob_xs_per_node", "log_prob_zs_per_node", "log_det_jacobian_per_node"):
+        assert abs(float(out[key]) - c["ref"][key]) <= 1e-4, key
+    z_err = float((out["z_graph"].nodes.cpu().double() - c["ref"]["z"]).abs().max())
+    assert z_err <= SLACK * c["z_err32"] + FLOOR, (z_err, c["z_err32"])
+    back = net(out["z_graph"], inverse=False).nodes
+    assert float((back - graph.nodes).abs().max()) <= SLACK * c["rt_err32"] + FLOOR
+
+
+def test_config4_256_graphs_inverse_worst_graphs_vs_oracle():
+    """BASELINE config 4 at its stated batch (protein stand-in, 256 graphs, ~78 k nodes: the large-batch kernel, picked
+    by the automatic rule): the inverse (sampling) pass on z ~ N(0, I), the round trip f(g(z)) = z, and the graphs with
+    the worst round-trip error + two arbitrary ones re-run through the float64 oracle's g and f."""
+    g_cpu, p, hp = _bench_batch("config4")
+    nn = g_cpu.n_node.numpy()
+    b, n = len(nn), int(nn.sum())
+    assert b == 256 and n > 70_000
+    net = make_product_grevnet(hp, p)
+    z_all = g_cpu.nodes.numpy()                               # the bench's N(0, 1) features are the latent sample
+    graph = graph_from_arrays(nn, g_cpu.n_edge.numpy(), g_cpu.senders.numpy(), g_cpu.receivers.numpy(), z_all, DEV)
+    xg = net(graph, inverse=False)                            # g: latent -> data (gnn.py:343-373)
+    zb, _ = net(xg, inverse=True)                             # f back
+    xg2 = net(graph, inverse=False)
+    torch.cuda.synchronize()
+    assert torch.equal(xg2.nodes, xg.nodes)                   # bitwise re-run
+    off = _graph_rows(nn)
+    err = (zb.nodes - graph.nodes).abs().max(dim=1).values.cpu().numpy()
+    per_graph = np.array([err[off[i]:off[i + 1]].max() for i in range(b)])
+    xg_c, s_all, r_all, ne = xg.nodes.cpu(), g_cpu.senders.numpy(), g_cpu.receivers.numpy(), g_cpu.n_edge.numpy()
+    eoff = np.concatenate([[0], np.cumsum(ne)])
+    for gi in list(np.argsort(-per_graph)[:4]) + [0, b // 2]:
+        sl, rl = s_all[eoff[gi]:eoff[gi + 1]] - off[gi], r_all[eoff[gi]:eoff[gi + 1]] - off[gi]
+        nloc = int(nn[gi])
+        zs = z_all[off[gi]:off[gi + 1]]
+        o64, o32 = _oracles(hp, sl, rl, nloc)
+        p64, p32 = o64.prep_params(p), o32.prep_params(p)
+        want = o64.g(o64.to_t(zs), p64, hp["T"])
+        x32 = o32.g(o32.to_t(zs), p32, hp["T"])
+        g_err32 = float((x32.double() - want).abs().max())
+        got = xg_c[off[gi]:off[gi + 1]].double()
+        assert float((got - want).abs().max()) <= SLACK * g_err32 + FLOOR, (gi, float((got - want).abs().max()), g_err32)
+        rt32 = float((o32.f(x32, p32, hp["T"])[0] - o32.to_t(zs)).abs().max())
+        assert per_graph[gi] <= SLACK * rt32 + FLOOR, (gi, per_graph[gi], rt32)
+    assert per_graph.max() <= 5e-5

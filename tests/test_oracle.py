@@ -543,3 +543,117 @@ def test_gradient_oracle_layer_norm_matches_finite_differences():
         pp[kind][half][i]["mlp"][-1][0][0, 1] -= 2 * eps
         lm = loss(pp)
         assert abs((lp - lm) / (2 * eps) - res["grads"][kind][half][i]["mlp"][-1][0][0, 1]) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# Independent checks of the restated third-party semantics against implementations that ARE installed
+# (torch's own layer_norm / batch_norm / softmax / leaky_relu / Normal).  The reference's TensorFlow stack is
+# absent, so parity stays "unpinned"; these shrink the risk that the oracle, the fixtures generated from it
+# and the kernels all share one misreading of the formula (DESIGN.md section 12 names the upstream files).
+# ------------------------------------------------------------------------------------------------
+def test_layer_norm_rows_vs_torch_layer_norm():
+    """snt.LayerNorm (gnn.py:550-552): per-row moments over features, biased variance, eps 1e-5, gamma / beta."""
+    rng = np.random.default_rng(3)
+    for n, h in ((7, 5), (3, 1), (12, 150)):
+        x = rng.standard_normal((n, h)) * 3.0 + 1.5
+        gamma, beta = rng.standard_normal(h) + 1.0, rng.standard_normal(h)
+        want = torch.nn.functional.layer_norm(torch.as_tensor(x), (h,), torch.as_tensor(gamma), torch.as_tensor(beta), eps=1e-5)
+        np.testing.assert_allclose(O.layer_norm_rows(x, gamma, beta), want.numpy(), rtol=1e-12, atol=1e-12)
+    # H = 1: variance 0 -> output is beta (the kernels' H = 1 test relies on it)
+    np.testing.assert_allclose(O.layer_norm_rows(np.array([[4.2]]), np.array([2.0]), np.array([-0.3])), [[-0.3]], atol=1e-12)
+
+
+def test_batch_norm_bijector_vs_torch_batch_norm_training_mode():
+    """tfb.BatchNormalization.inverse in training mode (gnn.py:260-263, 310-313): batch moments over the node axis with
+    the BIASED variance, eps 1e-3 (tf.layers.BatchNormalization default), scale gamma / offset beta - what
+    torch.nn.functional.batch_norm(training=True) computes; the moments it reports; and the log-det term
+    N * sum_f(log gamma_f - 0.5 log(var_f + eps)) against the Jacobian of torch's own function."""
+    rng = np.random.default_rng(4)
+    n, h = 11, 6
+    x = rng.standard_normal((n, h)) * 2.0 + 0.7
+    bn = dict(gamma=np.abs(rng.standard_normal(h)) + 0.5, beta=rng.standard_normal(h), epsilon=1e-3,
+              moving_mean=np.zeros(h), moving_variance=np.ones(h))
+    y, ildj, mean, var = O.Fp64Dense.bn_inverse(x, bn)
+    rm, rv = torch.zeros(h, dtype=torch.float64), torch.ones(h, dtype=torch.float64)
+    want = torch.nn.functional.batch_norm(torch.as_tensor(x), rm, rv, torch.as_tensor(bn["gamma"]), torch.as_tensor(bn["beta"]),
+                                          training=True, momentum=1.0, eps=1e-3)
+    np.testing.assert_allclose(y, want.numpy(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(mean, rm.numpy(), rtol=1e-12, atol=1e-12)            # momentum 1: running mean = batch mean
+    np.testing.assert_allclose(var * n / (n - 1), rv.numpy(), rtol=1e-12)           # torch's running var is the UNBIASED one
+    # log |det d y / d x| of the per-element affine map with the batch statistics held fixed (what TFP's
+    # inverse_log_det_jacobian reports: the statistics are not differentiated), summed over all N * H elements
+    scale = torch.as_tensor(bn["gamma"]) / torch.sqrt(torch.as_tensor(var) + 1e-3)
+    assert abs(ildj - n * float(torch.log(scale).sum())) < 1e-10
+    # fp32 restatement in TF op order agrees
+    f32 = O.Fp32Gather(np.zeros(1, np.int32), np.zeros(1, np.int32), 1)
+    bn_t = {k: torch.as_tensor(np.asarray(v, np.float32)) if k != "epsilon" else v for k, v in bn.items()}
+    y32, ildj32 = f32.bn_inverse(torch.as_tensor(x.astype(np.float32)), bn_t)
+    np.testing.assert_allclose(y32.numpy(), y, rtol=2e-5, atol=2e-5)
+    assert abs(float(ildj32) - ildj) < 1e-3
+    # bn.forward is the inverse map with the moving statistics in place of the batch's
+    bn2 = dict(bn, moving_mean=mean, moving_variance=var)
+    np.testing.assert_allclose(O.Fp64Dense.bn_forward(y, bn2), x, rtol=1e-10, atol=1e-10)
+
+
+def test_segment_softmax_vs_per_receiver_torch_softmax():
+    """graph_nets _unsorted_segment_softmax (gnn.py:413, 462-464): per head, softmax over the incoming edges of each
+    receiver; duplicate edges count twice; a receiver without incoming edges contributes nothing.  Checked edge by edge
+    against torch.softmax over each receiver's own logits, through both restatements' attention blocks."""
+    rng = np.random.default_rng(5)
+    n = 6
+    s = np.array([0, 1, 2, 2, 3, 0, 1, 1, 4, 2], np.int32)      # duplicate edge 1 -> 3; node 5 has no incoming edge
+    r = np.array([0, 0, 0, 1, 1, 2, 3, 3, 4, 4], np.int32)
+    nh, kq, vd, c, hd = 2, 3, 2, 4, 3
+    a = dict(num_heads=nh, kq_dim=kq, v_dim=vd, out_dim=c, concat=False, kq_dim_division=True, residual=False,
+             wq=rng.standard_normal((hd, nh * kq)), wk=rng.standard_normal((hd, nh * kq)), wv=rng.standard_normal((hd, vd)),
+             wo=np.eye(nh * vd, c))                               # identity-like output projection: agg readable in `new`
+    net = {"attn": a, "mlp": [(np.eye(c), np.zeros(c))]}          # identity MLP: the block returns `new`
+    x = rng.standard_normal((n, hd))
+    q = (x @ a["wq"]).reshape(n, nh, kq)
+    k = (x @ a["wk"]).reshape(n, nh, kq)
+    v = x @ a["wv"]
+    want = np.zeros((n, nh, vd))
+    for recv in range(n):
+        es = np.nonzero(r == recv)[0]
+        if es.size == 0:
+            continue
+        logits = torch.as_tensor(np.einsum("ehd,hd->eh", q[s[es]], k[recv]) / math.sqrt(kq))   # <xWq[sender], xWk[receiver]>
+        w = torch.softmax(logits, dim=0).numpy()                                              # over this receiver's edges
+        want[recv] = np.einsum("eh,ej->hj", w, v[s[es]])
+    want = want.reshape(n, nh * vd) @ a["wo"]
+    got64 = O.Fp64Dense(s, r, n, activation="relu").attn_gnn(x, net)
+    np.testing.assert_allclose(got64, want, rtol=1e-12, atol=1e-12)
+    f32 = O.Fp32Gather(s, r, n, activation="relu")
+    net32 = {"attn": {kk: (torch.as_tensor(np.asarray(vv, np.float32)) if isinstance(vv, np.ndarray) else vv) for kk, vv in a.items()},
+             "mlp": [(torch.eye(c), torch.zeros(c))]}
+    got32 = f32.attn_gnn(torch.as_tensor(x.astype(np.float32)), net32).numpy()
+    # (the edge-list form divides 0 / 0 for the isolated receiver like the TF graph would; everything else agrees)
+    np.testing.assert_allclose(got32[:5], want[:5], rtol=2e-5, atol=2e-5)
+    assert np.all(got64[5] == 0.0)
+
+
+def test_activations_and_gaussian_vs_torch():
+    """tf.nn.leaky_relu default alpha 0.2, tf.nn.relu; MultivariateNormalDiag(0, 1).log_prob summed over nodes."""
+    x = np.linspace(-3, 3, 13)
+    d = O.Fp64Dense(np.zeros(1, np.int32), np.zeros(1, np.int32), 1, activation="leaky_relu")
+    np.testing.assert_allclose(d.act(x), torch.nn.functional.leaky_relu(torch.as_tensor(x), 0.2).numpy(), rtol=0, atol=0)
+    d = O.Fp64Dense(np.zeros(1, np.int32), np.zeros(1, np.int32), 1, activation="relu")
+    np.testing.assert_allclose(d.act(x), torch.relu(torch.as_tensor(x)).numpy(), rtol=0, atol=0)
+    z = np.random.default_rng(6).standard_normal((9, 4))
+    want = torch.distributions.Normal(0.0, 1.0).log_prob(torch.as_tensor(z)).sum()
+    assert abs(O.gaussian_log_prob_sum(z) - float(want)) < 1e-10
+
+
+def test_unsorted_segment_mean_vs_torch_scatter():
+    """tf.unsorted_segment_mean = segment_sum / max(count, 1) (empty segment -> 0), against torch's scatter_reduce("mean")."""
+    rng = np.random.default_rng(7)
+    n = 5
+    s = np.array([0, 1, 2, 3, 3, 1], np.int32)
+    r = np.array([1, 1, 2, 0, 0, 0], np.int32)                    # nodes 3 and 4 receive nothing
+    x = rng.standard_normal((n, 3))
+    o = O.Fp64Dense(s, r, n, agg="mean", combine="concat")
+    agg = (o.adj @ x) / o.deg
+    want = torch.zeros(n, 3, dtype=torch.float64).scatter_reduce(0, torch.as_tensor(r.astype(np.int64)).unsqueeze(1).expand(-1, 3),
+                                                                  torch.as_tensor(x[s]), "mean", include_self=False)
+    np.testing.assert_allclose(agg, want.numpy(), rtol=1e-12, atol=1e-12)
+    assert np.all(agg[3:] == 0.0)
