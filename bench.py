@@ -274,6 +274,8 @@ def main():
     ap.add_argument("--graphs-per-gpu", type=int, default=0,
                     help="override the workload's graphs per rank (tests: one rank over the batch that N ranks shard)")
     ap.add_argument("--latency-steps", type=int, default=200, help="iterations of the p50/p95 leg (0: skip)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N > 1 code path (process group + collectives) even with one rank")
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed regions of --steps steps each, back to back: the line reports the median one (+ spread)")
     ap.add_argument("--all-workloads", action="store_true",
@@ -301,7 +303,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # --force-dist: ONE rank through every branch of the N > 1 path (process group, asynchronous all-reduce of the
+    # shard sums, drain, barrier, MAX over ranks, shard-balance gather) - on a 1-GPU box the RCCL side of bench.py's
+    # sharded protocol would otherwise first run on the driver's 8-GPU node
+    multi = world > 1 or args.force_dist
+    if args.force_dist and world == 1:
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.dist_backend == "nccl":
@@ -324,7 +334,7 @@ def main():
     net.fused = not args.layered
     # batch-norm workloads under sharding: the bijectors take their moments over the whole (global) batch like the
     # single-device reference does (one small all-reduce per bijector call)
-    net.sync_batch_norm = bool(HP.get("use_batch_norm")) and world > 1
+    net.sync_batch_norm = bool(HP.get("use_batch_norm")) and multi
 
     from gnf_amd.graphs import build_csr_device
     build_csr_device(graph)                  # warm (first-call kernel load), then time one build
@@ -348,18 +358,18 @@ def main():
 
     def step(i):
         if trainer is not None:   # gradient all-reduce (one flat RCCL all-reduce) when sharded
-            trainer.step(graph, all_reduce=world > 1)
+            trainer.step(graph, all_reduce=multi)
             return
         if inverse:   # config 4: sampling direction g (gnn.py:343-373); no scalar comes back
             net(graph, inverse=False)
             return
-        if world > 1:
+        if multi:
             # two alternating sum buffers: batch i's 3-scalar all-reduce runs on RCCL's stream while batch i + 1 is
             # already computing; its result is read (stream-ordered wait, pinned-host copy) one step later
             buf = sums_pair[i & 1]
             _, s3 = forward_shard_sums(net, graph, buf)
             s3[2] = float(n_local)           # all-reduce sums in place: restore this rank's count first
-            pending.append((all_reduce_shard_sums_async(s3), s3, i))
+            pending.append((all_reduce_shard_sums_async(s3, force=args.force_dist), s3, i))
             if len(pending) > 1 or args.sync_each_step:
                 drain(1 if not args.sync_each_step else len(pending))
         else:
@@ -382,8 +392,8 @@ def main():
     if args.prewarm_ms > 0:
         t_pre = time.perf_counter()
         # (sharded runs: a fixed count, the same on every rank - the steps hold collectives)
-        fixed = int(args.prewarm_ms / 1.0) if world > 1 else 0
-        while (prewarm_steps < fixed) if world > 1 else (time.perf_counter() - t_pre < 1e-3 * args.prewarm_ms):
+        fixed = int(args.prewarm_ms / 1.0) if multi else 0
+        while (prewarm_steps < fixed) if multi else (time.perf_counter() - t_pre < 1e-3 * args.prewarm_ms):
             for _ in range(8):
                 step(0)
             prewarm_steps += 8
@@ -397,7 +407,7 @@ def main():
     def timed_region():
         """EXACTLY args.steps steps between barrier + synchronize on both sides; MAX over ranks.  Every step of a region
         writes the same host rows (args.warmup + i): the rows are results, not a log."""
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -407,11 +417,11 @@ def main():
                                               # loop is bound by the device or by the host's launch rate)
         drain(len(pending))                   # inside the timed region: every batch's log-prob has reached the host buffer
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([el], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t[0])
@@ -438,7 +448,7 @@ def main():
     # ---- secondary figure: the same step when the batch's topology is new every step (training loop
     # of run_grevnet.py:440-447 draws a fresh batch per step): CSR rebuilt on device inside the step
     rebuild = None
-    if not inverse and world == 1 and trainer is None and not args.no_secondary:
+    if not inverse and not multi and trainer is None and not args.no_secondary:
         from gnf_amd.graphs import clear_csr_cache
         nreb = max(10, min(50, args.steps))
         torch.cuda.synchronize()
@@ -456,7 +466,7 @@ def main():
     # nodes / senders / receivers / n_node / n_edge start in pinned host memory every step, are uploaded, the CSR
     # is rebuilt on device, then the same forward runs.  Never the headline value.
     host_fed = None
-    if not inverse and world == 1 and trainer is None and not args.no_secondary:
+    if not inverse and not multi and trainer is None and not args.no_secondary:
         from gnf_amd.graphs import clear_csr_cache
         fields = ("nodes", "senders", "receivers", "n_node", "n_edge")
         # ONE packed pinned staging buffer and ONE device landing buffer, both allocated once: a batch is one
@@ -501,7 +511,7 @@ def main():
     # other) can use the idle third of the chip by keeping two batches in flight.  Not the headline protocol
     # (one batch at a time); reported next to it.
     two_streams = None
-    if not inverse and world == 1 and trainer is None and not args.no_secondary:
+    if not inverse and not multi and trainer is None and not args.no_secondary:
         streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         bufs = [torch.zeros(3, dtype=torch.float64, device=dev) for _ in streams]
         host2 = torch.zeros(args.steps, 3, dtype=torch.float64).pin_memory()
@@ -532,7 +542,7 @@ def main():
     # ---- steady-state p50 / p95 per step, "inputs in memory -> scalar log-prob on the host":
     # every iteration is closed by a stream synchronise (latency mode), >= 10 warm-ups, args.latency_steps iterations
     latency = None
-    if not inverse and world == 1 and trainer is None and args.latency_steps > 0:
+    if not inverse and not multi and trainer is None and args.latency_steps > 0:
         cur = torch.cuda.current_stream()
         for i in range(10):
             step(args.warmup)
@@ -548,7 +558,7 @@ def main():
     # ---- the same step replayed from a captured HIP graph (one hipGraphLaunch per step instead of ~20 launches):
     # removes the host's launch work from the loop; the device-side kernel boundaries stay
     graph_replay = None
-    if not inverse and world == 1 and trainer is None and not args.no_secondary:
+    if not inverse and not multi and trainer is None and not args.no_secondary:
         gs3 = torch.zeros(3, dtype=torch.float64, device=dev)
         gs3[2] = float(n_local)
         ghost = torch.zeros(1, 3, dtype=torch.float64).pin_memory()
@@ -574,7 +584,7 @@ def main():
     # ---- BASELINE.md section 4, config 2 secondary: the same batch topology at D = 100 (run_gnn.py:111; H = 50 is not
     # a multiple of 16: padded fragments)
     d100 = None
-    if args.workload == "config2" and world == 1 and not args.no_secondary and not args.layered:
+    if args.workload == "config2" and not multi and not args.no_secondary and not args.layered:
         hp100 = dict(HP, D=100)
         rng100 = np.random.default_rng(77)
         g100 = graph.replace(nodes=torch.as_tensor(rng100.standard_normal((n_local, 100)).astype(np.float32)).to(dev))
@@ -693,7 +703,7 @@ def main():
                                + (", fully connected topology" if WORKLOAD["fc"] else ", sparse topology+self loops"),
                    "nodes_total": n_global, "edges_total": e_global, "nodes_rank0": n_local, "edges_rank0": e_local,
                    "weights": f"N(0,2/(fan_in+fan_out)), seed {WEIGHT_SEED}, last layer x{FINAL_SCALE}",
-                   "parallelism": f"graph-shard dp{world}, 1 all-reduce of 3xfp64 per step (async: overlapped with the next batch's forward)" if world > 1 else "single GPU",
+                   "parallelism": f"graph-shard dp{world}, 1 all-reduce of 3xfp64 per step (async: overlapped with the next batch's forward)" if multi else "single GPU",
                    "path": "fused MFMA half-step kernel" if net.fused else "layered kernels",
                    "csr": f"built on device once per batch before the timed region (gnf_build_csr: {csr_ms:.3f} ms wall incl. host launch), cached",
                    "host_sync": "every step" if args.sync_each_step else "results copied to pinned host memory each step; one sync at end"},
@@ -715,12 +725,12 @@ def main():
         torch.cuda.synchronize()
         out["round_trip_max_abs_err"] = float((back.nodes - graph.nodes).abs().max())
         out["log_prob_xs_per_node"] = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not inverse and trainer is None:
+    if rank == 0 and not multi and not args.no_cpu_baseline and not inverse and trainer is None:
         cb, ref = cpu_baseline(dicts, params)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_baseline"] = round(value / cb["value"], 2)
         out["log_prob_delta_vs_cpu_fp32"] = abs(last["log_prob_xs_per_node"] - ref["log_prob_xs_per_node"])
-    if world > 1:   # how evenly the shards came out (whole graphs per rank, greedy balance): every rank's nodes / edges
+    if multi:   # how evenly the shards came out (whole graphs per rank, greedy balance): every rank's nodes / edges
         shard = torch.tensor([n_local, e_local], dtype=torch.int64, device=dev if args.dist_backend == "nccl" else "cpu")
         allsh = [torch.zeros_like(shard) for _ in range(world)]
         dist.all_gather(allsh, shard)
@@ -729,7 +739,7 @@ def main():
         out["config"]["edges_per_rank"] = edges_r
         out["config"]["shard_imbalance_max_over_mean"] = {"nodes": round(max(nodes_r) * world / max(1, sum(nodes_r)), 4),
                                                            "edges": round(max(edges_r) * world / max(1, sum(edges_r)), 4)}
-    if rank == 0 and world == 1 and args.all_workloads:
+    if rank == 0 and not multi and args.all_workloads:
         import subprocess
         sec = {}
         for wl in ("config4", "config5", "config2_attn"):
@@ -752,7 +762,7 @@ def main():
     out["consistency"] = line_consistency_errors(out)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

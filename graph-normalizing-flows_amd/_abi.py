@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 GNF_MAX_LAYERS = 8
-GNF_ABI_VERSION = 8
+GNF_ABI_VERSION = 9
 
 GNF_AGG_SUM, GNF_AGG_MEAN = 0, 1
 GNF_COMBINE_EPS, GNF_COMBINE_CONCAT = 0, 1
@@ -102,6 +102,10 @@ _SIGNATURES = {
                                            C.c_size_t, C.c_void_p, C.c_void_p]),
     "gnf_pack_flow": (C.c_int, [C.POINTER(GnfFlow), C.c_void_p]),
     "gnf_bn_post_step_f32": (C.c_int, [C.POINTER(GnfFlow), C.c_int32, C.c_float, C.c_void_p]),
+    "gnf_rccl_unique_id": (C.c_int, [C.c_char_p]),
+    "gnf_rccl_comm_create": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "gnf_rccl_comm_destroy": (C.c_int, [C.c_void_p]),
+    "gnf_rccl_allreduce_sum_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gnf_adam_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_void_p]),
     "gnf_clip_by_value_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p]),

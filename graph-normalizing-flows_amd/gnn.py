@@ -515,6 +515,9 @@ class GRevNet:
         # whole batch (gnn.py:310-313).  False: per-shard moments, no extra collective.
         self.sync_batch_norm = bool(sync_batch_norm)
         self.bn_process_group = None   # torch.distributed group of the cross-rank moments (None: the default group)
+        # an RCCL communicator of the library's own (sharding.RcclComm): the moments are then all-reduced by
+        # gnf_rccl_allreduce_sum_f64 straight from the C launch path (no Python callback, no torch.distributed)
+        self.bn_rccl_comm = None
         self.num_timesteps = int(num_timesteps)
         self.weight_sharing = bool(weight_sharing)
         self.node_embedding_dim = node_embedding_dim  # accepted and unused, as in gnn.py:277
@@ -644,7 +647,14 @@ class GRevNet:
                             C.cast(s_arr, C.POINTER(_abi.GnfMlp)), C.cast(t_arr, C.POINTER(_abi.GnfMlp)),
                             b0.spec(), C.cast(bn_arr, C.POINTER(_abi.GnfBatchNorm)) if bn_arr is not None else None)
         hook_keep = None
-        if sync > 1:   # cross-rank batch moments: the library fills sync_buf, calls back, reads the reduced sums
+        if self.use_batch_norm and self.sync_batch_norm and self.bn_rccl_comm is not None:
+            # the library's own hook on a native communicator (ABI v9)
+            sync_buf = torch.zeros(2 * hdim + 1, dtype=torch.float64, device=device)
+            flow.bn_allreduce = C.cast(lib.gnf_rccl_allreduce_sum_f64, _abi.BN_ALLREDUCE_FN)
+            flow.bn_allreduce_ctx = self.bn_rccl_comm.handle
+            flow.bn_sync_buf = sync_buf.data_ptr()
+            hook_keep = (self.bn_rccl_comm, sync_buf)
+        elif sync > 1:   # cross-rank batch moments: the library fills sync_buf, calls back, reads the reduced sums
             import torch.distributed as dist
             sync_buf = torch.zeros(2 * hdim + 1, dtype=torch.float64, device=device)
             group = self.bn_process_group
@@ -668,6 +678,8 @@ class GRevNet:
         """World size the batch-norm moments are taken over (1: this process only)."""
         if not (self.use_batch_norm and self.sync_batch_norm):
             return 1
+        if self.bn_rccl_comm is not None:
+            return self.bn_rccl_comm.n_ranks + 1000   # (cache key only: distinct from any torch.distributed world size)
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
             return 1

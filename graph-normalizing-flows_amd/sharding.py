@@ -53,13 +53,14 @@ class _Reduced:
         return True
 
 
-def all_reduce_shard_sums_async(shard_sums, group=None):
+def all_reduce_shard_sums_async(shard_sums, group=None, force=False):
     """The same collective, not waited for: returns a handle whose .wait() orders the CURRENT stream behind the
     reduction (torch.distributed Work semantics; no host blocking with RCCL).  A throughput loop over independent
     batches calls it right after batch i's forward, launches batch i + 1 on the compute stream, and only then waits
     and reads batch i's sums - the few tens of microseconds a 24-byte all-reduce over 8 GPUs takes are hidden behind
-    the next batch instead of sitting between two of them.  `shard_sums` must stay untouched until .wait()."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    the next batch instead of sitting between two of them.  `shard_sums` must stay untouched until .wait().
+    force: issue the collective even in a one-rank group (bench.py --force-dist: the RCCL call on a 1-GPU box)."""
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
         if shard_sums.is_cuda and dist.get_backend(group) == "gloo":
             all_reduce_shard_sums(shard_sums, group)      # debugging path: staged through the host, synchronous
             return _Reduced()
@@ -77,3 +78,48 @@ def assemble_from_sums(sums):
         "log_prob_xs_per_node": log_prob_xs / n, "log_prob_zs_per_node": log_prob_zs / n,
         "log_det_jacobian_per_node": logdet / n,
     }
+
+
+class RcclComm:
+    """An RCCL communicator created by the library itself (gnf_rccl_comm_create, ABI v9) on the CURRENT device: what a
+    non-Python host would hand to GnfFlow.bn_allreduce_ctx with bn_allreduce = gnf_rccl_allreduce_sum_f64.
+    `unique_id`: the 128 bytes of rank 0's RcclComm.unique_id(), carried to the other ranks by any means
+    (RcclComm.from_process_group uses torch.distributed for exactly that and nothing else)."""
+
+    def __init__(self, unique_id, n_ranks, rank):
+        import ctypes as C
+        from . import _abi
+        self.n_ranks, self.rank = int(n_ranks), int(rank)
+        h = C.c_void_p()
+        _abi.check(_abi.lib().gnf_rccl_comm_create(bytes(unique_id), self.n_ranks, self.rank, C.byref(h)), "gnf_rccl_comm_create")
+        self.handle = h.value
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _abi
+        buf = C.create_string_buffer(128)
+        _abi.check(_abi.lib().gnf_rccl_unique_id(buf), "gnf_rccl_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls, group=None):
+        """One communicator over the ranks of a torch.distributed group (the id travels by broadcast_object_list)."""
+        n, r = dist.get_world_size(group), dist.get_rank(group)
+        box = [cls.unique_id() if r == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(box[0], n, r)
+
+    def all_reduce_sum_f64(self, t):
+        """In-place SUM all-reduce of a float64 device tensor on the current stream (the hook's own entry point)."""
+        from . import _abi
+        assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+        _abi.check(_abi.lib().gnf_rccl_allreduce_sum_f64(self.handle, t.data_ptr(), t.numel(), _abi.stream_ptr(t.device)),
+                   "gnf_rccl_allreduce_sum_f64")
+        return t
+
+    def destroy(self):
+        from . import _abi
+        if self.handle:
+            _abi.check(_abi.lib().gnf_rccl_comm_destroy(self.handle), "gnf_rccl_comm_destroy")
+            self.handle = None

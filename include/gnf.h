@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GNF_ABI_VERSION 8
+#define GNF_ABI_VERSION 9
 #define GNF_MAX_LAYERS 8 /* Linear layers per MLP (gnn.py:165-166 builds num_layers of them) */
 
 typedef void* gnf_stream_t; /* hipStream_t */
@@ -311,6 +311,22 @@ int gnf_pack_flow(const GnfFlow* flow, gnf_stream_t stream);
  * (run_grevnet.py:360): moving <- moving * momentum + batch * (1 - momentum), with the batch moments the last
  * gnf_grevnet_f32(GNF_FORWARD) left in batch_mean / batch_variance.  H = D/2.  No-op without bijectors. */
 int gnf_bn_post_step_f32(const GnfFlow* flow, int32_t H, float momentum, gnf_stream_t stream);
+
+/* ABI v9: the path's collective without a host language in the launch path.  The reference is single-device (no
+ * counterpart); under graph sharding the only exchange INSIDE the flow's launch sequence is the batch-norm
+ * bijector's cross-rank moments (GnfFlow.bn_allreduce above, 2 D/2 + 1 doubles per bijector call).
+ * gnf_rccl_allreduce_sum_f64 has exactly that hook's signature with an RCCL communicator as its context:
+ *     flow.bn_allreduce = gnf_rccl_allreduce_sum_f64;  flow.bn_allreduce_ctx = comm;
+ * enqueues ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, stream) on the caller's stream.  `comm` is an
+ * ncclComm_t: the caller's own, or one made here - rank 0 calls gnf_rccl_unique_id, hands the 128 bytes to the other
+ * ranks by whatever means it has (MPI, a file, torch.distributed), every rank calls gnf_rccl_comm_create on its device.
+ * librccl.so is resolved with dlopen at the first of these calls (no link-time dependency: GNF_EINVAL + gnf_last_error
+ * when it cannot be found); a process that already holds RCCL (PyTorch bundles its own copy) gets that copy. */
+#define GNF_RCCL_UNIQUE_ID_BYTES 128
+int gnf_rccl_unique_id(char* id_out /* GNF_RCCL_UNIQUE_ID_BYTES */);
+int gnf_rccl_comm_create(const char* id, int32_t n_ranks, int32_t rank, void** comm_out);
+int gnf_rccl_comm_destroy(void* comm);
+int gnf_rccl_allreduce_sum_f64(void* comm, double* device_buf, int64_t count, gnf_stream_t stream);
 
 /* tf.train.AdamOptimizer.apply_gradients on one flat fp32 parameter vector (run_grevnet.py:352-356, 375):
  *   m <- b1 m + (1-b1) g;  v <- b2 v + (1-b2) g^2;  w <- w - lr_t m / (sqrt(v) + epsilon)

@@ -61,3 +61,68 @@ def test_trainer_step_all_reduce_two_ranks_match_one_process():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_train_check.py")], capture_output=True, text=True,
                        timeout=800, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0 and "dp-train-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.timeout(900)
+def test_bench_one_rank_through_the_rccl_branch_of_the_sharded_path():
+    """`bench.py --force-dist --dist-backend nccl`: ONE rank through every branch of the N > 1 protocol over RCCL itself
+    (init_process_group("nccl", device_id=...), the asynchronous 3 x fp64 all-reduce of the shard sums and its
+    stream-ordered wait, the drain into the pinned host rows, barrier, the MAX all-reduce of the elapsed time, the
+    shard-balance all-gather) - so that the first multi-GPU contact is not the first time those lines run.  The
+    reduced log-prob must equal the plain single-GPU run's."""
+    plain = _bench(1, 64)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--dist-backend", "nccl", "--steps", "6",
+           "--warmup", "2", "--no-cpu-baseline", "--no-secondary", "--latency-steps", "0", "--kernel-timing-steps", "1", "--repeats", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and "graph-shard dp1" in d["config"]["parallelism"]
+    assert d["config"]["nodes_per_rank"] == [d["config"]["nodes_total"]]
+    assert d["config"]["shard_imbalance_max_over_mean"] == {"nodes": 1.0, "edges": 1.0}
+    assert d["steps_landed_on_host"] == 6
+    assert abs(d["log_prob_xs_per_node"] - plain["log_prob_xs_per_node"]) <= 1e-12
+    assert d["consistency"] == []
+
+
+def test_native_rccl_communicator_and_batch_norm_hook_one_rank(grid_small):
+    """ABI v9: a communicator made by the library itself (gnf_rccl_unique_id / gnf_rccl_comm_create: ncclCommInitRank
+    through dlopen'ed librccl.so) and gnf_rccl_allreduce_sum_f64 as GnfFlow.bn_allreduce - no Python callback and no
+    torch.distributed anywhere in the launch path.  One rank: the all-reduce is the identity, so a batch-norm flow with
+    sync_batch_norm over the native communicator must reproduce the unsynchronised flow bit for bit."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import graph_from_arrays, make_product_grevnet
+    from gnf_amd.flow import log_prob_terms
+    from gnf_amd.sharding import RcclComm
+    from oracle import gnf_oracle as O
+    comm = RcclComm(RcclComm.unique_id(), 1, 0)
+    try:
+        t = torch.arange(7, dtype=torch.float64, device="cuda:0") * 1.5
+        want = t.clone()
+        comm.all_reduce_sum_f64(t)
+        torch.cuda.synchronize()
+        assert torch.equal(t, want)
+        n_node, n_edge, sl, rl = grid_small
+        nn, ne, s, r = O.batch_graphs(n_node, n_edge, sl, rl, list(range(12)))
+        n = int(nn.sum())
+        hp = dict(D=8, latent=32, K=3, T=2, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu", weight_sharing=False)
+        p = O.make_grevnet_params(8, 4, 32, 3, 2, final_scale=0.3)
+        p["bn"] = O.make_bn_params(9, 4, 2)
+        x = (np.random.default_rng(31).standard_normal((n, 8)) * 1.5 + 0.5).astype(np.float32)
+        graph = graph_from_arrays(nn, ne, s, r, x, "cuda:0")
+        plain = log_prob_terms(make_product_grevnet(hp, p), graph)
+        net = make_product_grevnet(hp, p)
+        net.sync_batch_norm = True
+        net.bn_rccl_comm = comm
+        synced = log_prob_terms(net, graph)
+        torch.cuda.synchronize()
+        assert torch.equal(synced["z_graph"].nodes, plain["z_graph"].nodes)
+        assert float(synced["log_prob_xs_per_node"]) == float(plain["log_prob_xs_per_node"])
+        ref = O.Fp64Dense(s, r, n).log_prob(x, p, 2)
+        assert abs(float(synced["log_prob_xs_per_node"]) - ref["log_prob_xs_per_node"]) <= 1e-4
+    finally:
+        comm.destroy()
