@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gnf_amd import gnn                                              # noqa: E402
 from gnf_amd.flow import sample                                      # noqa: E402
+from gnf_amd.train import get_learning_rate                          # noqa: E402
 from gnf_amd.grevnet_synthetic_data import DATASETS_MAP              # noqa: E402
 from gnf_amd.train import GRevNetTrainer                             # noqa: E402
 
@@ -93,9 +94,8 @@ def main():
     for iteration in range(F.num_train_iters + 1):
         graph = dataset.get_next_batch(F.train_batch_size, dev)
         lr = None
-        if F.use_lr_schedule:   # --use_lr_schedule (utils.py:93-105): warm-up to --lr, plateau, then --lr / sqrt(steps past it)
-            past = iteration - F.lr_schedule_hold
-            lr = F.lr * (min(1.0, iteration / F.lr_schedule_ramp_up) if past <= 0 else past ** -0.5)
+        if F.use_lr_schedule:   # --use_lr_schedule (utils.py:93-105 through run_grevnet.py:444)
+            lr = get_learning_rate(iteration, F.lr, F.lr_schedule_ramp_up, F.lr_schedule_hold)
         v = trainer.step(graph, learning_rate=lr)
         if iteration % F.log_every_n_steps == 0:
             z = v["z_graph"].nodes

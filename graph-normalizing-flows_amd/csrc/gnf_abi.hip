@@ -14,11 +14,9 @@ static thread_local char g_err[512] = "";
 std::atomic<int64_t> g_options[OPT_COUNT];  // zero-initialised: every option "auto"
 
 static const char* const kOptionNames[OPT_COUNT] = {
-    "force_shape",     "fused_variant",  "flow_no_oop",    "attn_edge_tiled",  "attn_rows",    "attn_lane_feature", "gemm_no_buf",
-    "gemm_lds_direct", "gemm_no_splitk", "layered_own_gemm", "dw_grouped",   "dw_wide_units",     "dw_wide_lds",
-    "dw_no_streamk",   "dw_no_buf",      "dw_debug",         "dw_late_fork", "bwd_generic",
-    "dw_unmerged",     "bwd_no_fold",    "no_mlp_stash",
-    "attn_bwd_rows",   "attn_bwd_split"};
+    "force_shape",   "fused_variant", "flow_no_oop",   "attn_edge_tiled", "attn_rows",    "gemm_no_buf",  "gemm_no_splitk",
+    "dw_grouped",    "dw_wide_units", "dw_wide_lds",   "dw_no_streamk",   "dw_no_buf",    "dw_debug",     "bwd_generic",
+    "dw_unmerged",   "no_mlp_stash",  "attn_bwd_rows", "attn_bwd_split"};
 
 static int option_index(const char* name) {
     if (!name) return -1;

@@ -994,8 +994,7 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
                              reinterpret_cast<const void*>(k_attn_bwd_recv<4>), reinterpret_cast<const void*>(k_attn_bwd_send<1>),
                              reinterpret_cast<const void*>(k_attn_bwd_send<2>), reinterpret_cast<const void*>(k_attn_bwd_send<4>)};
         for (const void* k : ks) GNF_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
-    const bool lane_feature = opt(OPT_ATTN_LANE_FEATURE) != 0;  // developer A/B switch (gnf_set_option)
-    if (!lane_feature && a.nh <= kRowsMaxHeads && a.kq <= 32 && a.v <= 32) {
+    if (a.nh <= kRowsMaxHeads && a.kq <= 32 && a.v <= 32) {
         const size_t fixed_r = (size_t)(kRowsTile + 1 + 3 + kRowsColCap) * sizeof(int);
         const int capr = (int)((kRowsLdsBudget - fixed_r) / ((size_t)(nq + a.v + 2) * sizeof(float)));
         const int caps = (int)((kRowsLdsBudget - fixed_r) / ((size_t)(nq + NV + 2) * sizeof(float)));

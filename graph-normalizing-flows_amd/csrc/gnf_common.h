@@ -121,7 +121,7 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st);
 // out evenly over rounds x 2 x CUs workgroups (big_plan); *n_wg_out = workgroups launched (= fp64 partials written)
 struct FusedArgs;
 bool big_supported(const GnfMlp* s, int32_t H);
-int big_cu_count();
+int big_cu_count();  // multiProcessorCount of the current device (cached per device)
 int big_plan(int64_t n_nodes, int cus, int cap, int32_t* seg_n, int32_t* seg_sz);  // -> workgroups; runs of (count, row tiles)
 int launch_half_big(FusedArgs& a, int64_t n_nodes, int cap, hipStream_t st, int* n_wg_out);
 // coupling epilogue from global s / t [N, H] buffers (writes hs.partials, *hs.n_partials)
@@ -188,6 +188,10 @@ int bn_sync_exchange(const GnfFlow* flow, const double* part, int nparts, int64_
 int launch_bn_normalize(const GnfFlow* flow, const GnfBatchNorm* bn, float* x, int64_t ld, int64_t n, int32_t H,
                         double* part, double* logdet_slot, hipStream_t st, int pre_parts = 0);
 int launch_bn_denormalize(const GnfBatchNorm* bn, float* z, int64_t ld, int64_t n, int32_t H, hipStream_t st);
+
+// batch-norm bijector, backwards (gnf_bn_bwd.hip).  pre_parts > 0: `part` already holds that many [H][2] partial rows
+int launch_bn_backward(const GnfFlow* flow, const GnfBatchNorm* bn, const GnfBatchNorm* gbn, float* y, int64_t ld,
+                       float* gy, int64_t ldg, int64_t n, int32_t H, double* part, hipStream_t st, int pre_parts = 0);
 
 int validate_mlp(const GnfMlp* m, const char* what);
 int validate_flow_call(const GnfCsr* csr, const GnfFlow* flow, int64_t ld, int32_t D, const char* what);

@@ -538,11 +538,12 @@ static void choose_shape(const HalfStep& hs, int* mt, int* nets) {
     const int64_t tiles16 = (hs.n_nodes + 15) / 16;
     auto fits = [&](int m, int n) { return fused_lds_bytes(s, m, n) <= (size_t)kLdsLimit; };
     int m = 1, n = 1;
-    if (tiles16 > 256 && fits(2, 2)) {
+    const int64_t cus = big_cu_count();
+    if (tiles16 > cus && fits(2, 2)) {
         m = 2, n = 2;
     } else if (fits(1, 2)) {
         m = 1, n = 2;
-    } else if (tiles16 > 256 && fits(2, 1)) {
+    } else if (tiles16 > cus && fits(2, 1)) {
         m = 2, n = 1;
     }
     if (const int64_t force = opt(OPT_FORCE_SHAPE)) {
@@ -617,7 +618,7 @@ bool fused_stash_shape(const GnfMlp* s, const GnfMlp* t, int64_t n) {
     for (int j = 0; j <= s->num_layers; ++j)
         if (s->dims[j] != t->dims[j]) return false;
     if (opt(OPT_FORCE_SHAPE)) return false;
-    return (n + 15) / 16 <= 256 && fused_lds_bytes(s, 1, 2) <= (size_t)kLdsLimit;
+    return (n + 15) / 16 <= big_cu_count() && fused_lds_bytes(s, 1, 2) <= (size_t)kLdsLimit;
 }
 
 int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {

@@ -170,148 +170,6 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same linear layer on the fp32 matrix cores, for layers too wide for the LDS-resident fused
-// kernel (e.g. the 2048-wide MLPs of train_grevnet_with_data.py:111-112).  128x64 output tile, BK = 32,
-// 8 waves: wave w owns node tile (w & 3) * 32 .. +32 (two 16-row M-tiles) x column half (w >> 2) * 32
-// (two 16-column N-tiles).  X and W tiles are staged in LDS (X row-major, W row-major); A fragments
-// are ds_read_b128 with the same k permutation as the fused kernel (k = 16*kg + 4*(lane>>4) + q),
-// B fragments four ds_read_b32 rows.  Exact fp32 (v_mfma_f32_16x16x4_f32 = fmaf chain).
-// ------------------------------------------------------------------------------------------------
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-static constexpr int GM = 128, GN = 64, GK = 32;
-
-// One GEMM of a grouped launch (blockIdx.z picks the job: the s- and the t-net of a half-step have the
-// same layer shapes, gnf_abi.hip validate_pair, so their layers run side by side in one grid).
-struct LinJob {
-    const float* X;
-    const float* W;
-    const float* b;
-    float* Y;
-};
-
-// VEC: X rows, W rows and both base pointers are 16-byte aligned and I, O are multiples of 4, so tiles
-// are fetched with dwordx4 loads; otherwise dword loads with per-element bounds.
-template <bool VEC>
-__global__ __launch_bounds__(512) void k_linear_mfma(LinJob j0, LinJob j1, int64_t ldx, int64_t ldy,
-                                                     int64_t n_rows, int I, int O, int act, float alpha,
-                                                     int apply_act) {
-    __shared__ __attribute__((aligned(16))) float Xs[GM][GK + 4];  // +4: rows stay 16-B aligned, banks spread
-    __shared__ __attribute__((aligned(16))) float Ws[GK][GN + 4];
-    const LinJob job = blockIdx.z ? j1 : j0;
-    const float* __restrict__ X = job.X;
-    const float* __restrict__ W = job.W;
-    const int64_t row0 = (int64_t)blockIdx.y * GM;
-    const int col0 = blockIdx.x * GN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lrow = lane & 15, lgrp = lane >> 4;
-    const int wm = (wave & 3) * 32, wn = (wave >> 2) * 32;
-    f32x4_t acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int gc = col0 + wn + 16 * b + lrow;
-            const float bv = gc < O ? job.b[gc] : 0.f;
-            acc[m][b] = f32x4_t{bv, bv, bv, bv};
-        }
-    // register stage of the NEXT k-tile: fetched while the matrix cores work on the current one
-    f32x4_t xv[2], wv;
-    float xr[8], wr[4];
-    auto fetch = [&](int k0) {
-        if (VEC) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int i = tid + q * 512, r = i >> 3, k = (i & 7) * 4;
-                const int64_t gr = row0 + r;
-                xv[q] = (gr < n_rows && k0 + k < I)
-                            ? *reinterpret_cast<const f32x4_t*>(X + gr * ldx + k0 + k)
-                            : f32x4_t{0.f, 0.f, 0.f, 0.f};
-            }
-            const int k = tid >> 4, c = (tid & 15) * 4;
-            wv = (k0 + k < I && col0 + c < O)
-                     ? *reinterpret_cast<const f32x4_t*>(W + (int64_t)(k0 + k) * O + col0 + c)
-                     : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int i = tid + q * 512, r = i >> 5, k = i & 31;
-                const int64_t gr = row0 + r;
-                xr[q] = (gr < n_rows && k0 + k < I) ? X[gr * ldx + k0 + k] : 0.f;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = tid + q * 512, k = i >> 6, c = i & 63;
-                wr[q] = (k0 + k < I && col0 + c < O) ? W[(int64_t)(k0 + k) * O + col0 + c] : 0.f;
-            }
-        }
-    };
-    auto stash = [&]() {
-        if (VEC) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int i = tid + q * 512;
-                *reinterpret_cast<f32x4_t*>(&Xs[i >> 3][(i & 7) * 4]) = xv[q];
-            }
-            *reinterpret_cast<f32x4_t*>(&Ws[tid >> 4][(tid & 15) * 4]) = wv;
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int i = tid + q * 512;
-                Xs[i >> 5][i & 31] = xr[q];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = tid + q * 512;
-                Ws[i >> 6][i & 63] = wr[q];
-            }
-        }
-    };
-    fetch(0);
-    for (int k0 = 0; k0 < I; k0 += GK) {
-        __syncthreads();  // previous tile fully consumed
-        stash();
-        __syncthreads();
-        if (k0 + GK < I) fetch(k0 + GK);
-#pragma unroll
-        for (int kg = 0; kg < GK / 16; ++kg) {
-            f32x4_t a[2];
-            float bq[2][4];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-                a[m] = *reinterpret_cast<const f32x4_t*>(&Xs[wm + 16 * m + lrow][16 * kg + 4 * lgrp]);
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bq[b][q] = Ws[16 * kg + 4 * lgrp + q][wn + 16 * b + lrow];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][q], bq[b][q], acc[m][b], 0, 0, 0);
-        }
-    }
-    // accumulator layout: col = lane & 15, row = 4 * (lane >> 4) + r
-    float* __restrict__ Y = job.Y;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int gc = col0 + wn + 16 * b + lrow;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t gr = row0 + wm + 16 * m + 4 * lgrp + r;
-                if (gr < n_rows && gc < O) {
-                    float v = acc[m][b][r];
-                    if (apply_act) v = (act == GNF_ACT_RELU) ? fmaxf(v, 0.f) : fmaxf(v, alpha * v);
-                    Y[gr * ldy + gc] = v;
-                }
-            }
-        }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Coupling epilogue: x_upd <- x_upd*exp(s)+t  or  (x_upd-t)*exp(-s); one fp64 partial of sum(s)
 // per workgroup (fixed in-block order -> bitwise reproducible).
 // ------------------------------------------------------------------------------------------------
@@ -487,31 +345,13 @@ static int run_mlps(const GnfMlp* const* nets, int nj, const float* const* h0, i
             }
             const int rc = launch_linear_splitk(xin, ldin, wq, bq, yq, lddst, nj, n, I, O, g.activation, g.alpha,
                                                 last ? 0 : 1, sk, (size_t)n * (size_t)ldbuf, st);
-            if (rc < 0) return rc;
-            if (rc == 0) {
-                in[0] = dst[0];
-                in[1] = dst[1];
-                ldin = lddst;
-                continue;
-            }
+            if (rc) return rc;
+            in[0] = dst[0];
+            in[1] = dst[1];
+            ldin = lddst;
+            continue;
         }
-        if (I >= 32 && O >= 32) {  // (A/B switch) gnf_layered.hip's own matrix-core kernel
-            LinJob jobs[2];
-            bool vec = (I % 4 == 0) && (O % 4 == 0) && (ldin % 4 == 0);
-            for (int q = 0; q < 2; ++q) {
-                const GnfMlp* mq = nets[q < nj ? q : nj - 1];
-                jobs[q] = LinJob{in[q], mq->W[j], mq->b[j], dst[q]};
-                vec = vec && ((uintptr_t)in[q] % 16 == 0) && ((uintptr_t)mq->W[j] % 16 == 0);
-            }
-            dim3 grid((O + GN - 1) / GN, (unsigned)((n + GM - 1) / GM), nj);
-            if (vec)
-                hipLaunchKernelGGL(k_linear_mfma<true>, grid, dim3(512), 0, st, jobs[0], jobs[1], ldin, lddst, n, I,
-                                   O, g.activation, g.alpha, last ? 0 : 1);
-            else
-                hipLaunchKernelGGL(k_linear_mfma<false>, grid, dim3(512), 0, st, jobs[0], jobs[1], ldin, lddst, n,
-                                   I, O, g.activation, g.alpha, last ? 0 : 1);
-            GNF_LAUNCH_CHECK("k_linear_mfma");
-        } else {
+        {
             dim3 grid((O + LT - 1) / LT, (unsigned)((n + LT - 1) / LT));
             for (int q = 0; q < nj; ++q) {
                 hipLaunchKernelGGL(k_linear, grid, dim3(256), 0, st, in[q], ldin, nets[q]->W[j], nets[q]->b[j],

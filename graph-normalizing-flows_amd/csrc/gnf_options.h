@@ -18,11 +18,8 @@ enum OptionId {
     OPT_FLOW_NO_OOP,         // out-of-place flows: always copy first, then walk in place (A/B of the fused first step)
     OPT_ATTN_EDGE_TILED,     // attention forward: always the edge-tiled kernel
     OPT_ATTN_ROWS,           // attention forward: always the rows kernel
-    OPT_ATTN_LANE_FEATURE,   // attention backward: lane-per-feature kernels instead of the rows kernels
     OPT_GEMM_NO_BUF,         // generic GEMM: bounds-checked fetch instead of buffer descriptors
-    OPT_GEMM_LDS_DIRECT,     // generic GEMM: LDS-direct tile (measured slower; parity-tested)
     OPT_GEMM_NO_SPLITK,      // generic GEMM: never split thin launches over the reduction
-    OPT_LAYERED_OWN_GEMM,    // layered forward: k_linear_mfma instead of the shared GEMM tile
     OPT_DW_GROUPED,          // weight gradients: always the grouped kernel
     OPT_DW_WIDE_UNITS,       // weight gradients: wide kernel with this many workgroups
     OPT_DW_WIDE_LDS,         // ... and this LDS request per workgroup (bytes)
@@ -30,10 +27,8 @@ enum OptionId {
     OPT_DW_NO_BUF,           // ... bounds-checked fetch
     OPT_DW_DEBUG,            // bit 1: print the dW launch plan to stderr (first two launches); bits 2 / 4 / 8: timing ablations
                              // of the merged backward + dW launch (gnf_train.hip, launch_half_bwd_dw)
-    OPT_DW_LATE_FORK,        // fork the dW stream behind the dL/dx scatter
     OPT_BWD_GENERIC,         // backward pass through the generic GEMM path even where the fused kernel fits
     OPT_DW_UNMERGED,         // small batches: dW GEMMs on the auxiliary stream (round-1 scheme) instead of inside the backward launch
-    OPT_BWD_NO_FOLD,         // ... and the message-passing backward in a launch of its own instead of the next half-step's prologue
     OPT_NO_MLP_STASH,        // ignore GnfFlow.mlp_stash (the backward walk recomputes the MLP rows)
     OPT_ATTN_BWD_ROWS,       // attention rows kernels: 64 / 32 (backward also 16) rows per workgroup (0 = by batch size / mean degree)
     OPT_ATTN_BWD_SPLIT,      // attention backward on sparse batches: receiver and sender pass as two launches (A/B)

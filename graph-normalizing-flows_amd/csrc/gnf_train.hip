@@ -291,214 +291,10 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
         job.aux_out[(int64_t)chunk * sh.N + n0 + tid] = colsum;
 }
 
-// ---- the same tile with LDS-direct loads ------------------------------------------------------------------------
-// `buffer_load_dword[x4] ... lds` writes a wave's 64 elements straight into LDS (lane l -> M0 base + l * size): no
-// register staging, no ds_write, and a load can stay in flight for as many k-steps as there are LDS stages.  The
-// tiles are kept in LDS in MFMA FRAGMENT ORDER - one 1 KB block per (16-row tile, 16-k group): for a KC operand
-// ([row][k]) lane (r = l & 15, g = l >> 4) fetches the float4 X[row0 + 16 i + r][k0 + 16 kg + 4 g ..] with ONE dwordx4
-// load and later reads exactly that float4 back as its fragment of four k-slices (ds_read_b128, conflict-free by
-// construction); for an MC operand ([k][col]) the four k-slices sit in four rows, so block (i, kg) is four 256-byte
-// sub-blocks filled by dword loads.  Three stages: at step t the loads of tile t + 2 are issued right after the one
-// barrier of the step (which also says: everybody is done with the stage they overwrite), a wave waits for its OWN
-// loads of tile t with s_waitcnt vmcnt(L) - L loads per wave and tile, the loads of tile t + 1 stay in flight.
-// The loads are inline asm: through the builtin the compiler's wait-count pass makes every LDS read wait for ALL
-// LDS-direct loads in flight (it cannot tell the stages apart), which serialises exactly what this is for.  Loads are
-// issued unconditionally (tiles past the reduction are out of the descriptor's range: zeros) so that L is a constant.
-__device__ __forceinline__ void lds_load_x4(__amdgpu_buffer_rsrc_t r, int voff, unsigned lds_byte_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(r), "s"(lds_byte_addr) : "memory");
-}
-__device__ __forceinline__ void lds_load_x1(__amdgpu_buffer_rsrc_t r, int voff, unsigned lds_byte_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dword %0, %1, 0 offen lds" ::"v"(voff), "s"(r), "s"(lds_byte_addr) : "memory");
-}
-
-static constexpr int kLdStages = 3;
-static constexpr int kLdStageFloats = (TGM + TGN) * TGK;  // 4096 (A) + 2048 (B)
-static constexpr size_t kLdLdsBytes = (size_t)kLdStages * kLdStageFloats * sizeof(float);
-
-template <int AK, int BK, int EPI>
-__device__ __forceinline__ void gemm_tile_ld(const GemmJob& job, const GemmShape& sh, const int bx, const int by,
-                                             const int chunk) {
-    extern __shared__ __attribute__((aligned(16))) float ld_lds[];
-    const int64_t m0 = (int64_t)by * TGM;
-    const int n0 = bx * TGN;
-    const int64_t kbeg = (int64_t)chunk * sh.kchunk;
-    const int64_t kend = (EPI == EPI_SLAB) ? (kbeg + sh.kchunk < sh.K ? kbeg + sh.kchunk : sh.K) : sh.K;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lrow = lane & 15, lgrp = lane >> 4;
-    const int wm = (wave & 3) * 32, wn = (wave >> 2) * 32;
-    constexpr int kOut = 0x7fffffff;
-    // loads per wave and tile: KC operand = one dwordx4 per block, MC operand = four dwords per block;
-    // A has 16 blocks (2 per wave), B has 8 (1 per wave)
-    constexpr int L = (AK == OPND_KC ? 2 : 8) + (BK == OPND_KC ? 1 : 4);
-
-    f32x4_t acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            float bv = 0.f;
-            if (EPI == EPI_BIAS_ACT) {
-                const int gc = n0 + wn + 16 * b + lrow;
-                bv = gc < sh.N ? job.aux[gc] : 0.f;
-            }
-            acc[m][b] = f32x4_t{bv, bv, bv, bv};
-        }
-    float cs[2] = {0.f, 0.f};  // EPI_SLAB: this lane's share of the column sums of B (columns wn + 16 n + lrow)
-
-    const int64_t a_rows = AK == OPND_KC ? sh.M - m0 : kend - kbeg, b_rows = BK == OPND_KC ? (int64_t)sh.N - n0 : kend - kbeg;
-    const float* a_base = AK == OPND_KC ? job.A + m0 * sh.lda : job.A + kbeg * sh.lda + m0;
-    const float* b_base = BK == OPND_KC ? job.B + (int64_t)n0 * sh.ldb : job.B + kbeg * sh.ldb + n0;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a_base), 0, a_rows > 0 ? (int)((a_rows * sh.lda - (AK == OPND_KC ? 0 : m0)) * 4) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(b_base), 0, b_rows > 0 ? (int)((b_rows * sh.ldb - (BK == OPND_KC ? 0 : n0)) * 4) : 0, 0x00020000);
-    const int lda = (int)sh.lda, ldb = (int)sh.ldb;
-    // lane part of the byte offsets:  KC: row lrow, k 4 lgrp;   MC: k row 4 lgrp, column lrow
-    const int va = AK == OPND_KC ? (lrow * lda + 4 * lgrp) * 4 : (4 * lgrp * lda + lrow) * 4;
-    const int vb = BK == OPND_KC ? (lrow * ldb + 4 * lgrp) * 4 : (4 * lgrp * ldb + lrow) * 4;
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ld_lds;
-
-    // issue this wave's share of tile `t` (k0 = kbeg + 32 t) into stage `stage`
-    auto issue = [&](int64_t k0, int stage) {
-        const unsigned sa = lds0 + (unsigned)(stage * kLdStageFloats) * 4, sb = sa + TGM * TGK * 4;
-        {   // A: blocks (i = wave, kg = 0, 1)
-            const int i = wave;
-#pragma unroll
-            for (int kg = 0; kg < 2; ++kg) {
-                const unsigned blk = sa + (unsigned)((i * 2 + kg) * 1024);
-                if (AK == OPND_KC) {
-                    const bool in = k0 + 16 * kg + 4 * lgrp < kend;
-                    lds_load_x4(ra, in ? va + (16 * i * lda + 16 * kg) * 4 + (int)k0 * 4 : kOut, blk);
-                } else {
-                    const int kr = (int)(k0 - kbeg) + 16 * kg;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) lds_load_x1(ra, va + ((kr + q) * lda + 16 * i) * 4, blk + q * 256);
-                }
-            }
-        }
-        {   // B: block (j = wave >> 1, kg = wave & 1)
-            const int j = wave >> 1, kg = wave & 1;
-            const unsigned blk = sb + (unsigned)((j * 2 + kg) * 1024);
-            if (BK == OPND_KC) {
-                const bool in = k0 + 16 * kg + 4 * lgrp < kend;
-                lds_load_x4(rb, in ? vb + (16 * j * ldb + 16 * kg) * 4 + (int)k0 * 4 : kOut, blk);
-            } else {
-                const int kr = (int)(k0 - kbeg) + 16 * kg;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) lds_load_x1(rb, vb + ((kr + q) * ldb + 16 * j) * 4, blk + q * 256);
-            }
-        }
-    };
-    auto compute = [&](int stage) {
-        const float* As = ld_lds + stage * kLdStageFloats;
-        const float* Bs = As + TGM * TGK;
-#pragma unroll
-        for (int kg = 0; kg < 2; ++kg) {
-            float a[2][4], b[2][4];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const float* blk = As + (((wm >> 4) + m) * 2 + kg) * 256;
-                if (AK == OPND_KC) {
-                    const f32x4_t t = *reinterpret_cast<const f32x4_t*>(blk + lane * 4);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) a[m][q] = t[q];
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) a[m][q] = blk[q * 64 + lane];
-                }
-            }
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const float* blk = Bs + (((wn >> 4) + n) * 2 + kg) * 256;
-                if (BK == OPND_KC) {
-                    const f32x4_t t = *reinterpret_cast<const f32x4_t*>(blk + lane * 4);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) b[n][q] = t[q];
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) b[n][q] = blk[q * 64 + lane];
-                }
-                if (EPI == EPI_SLAB) cs[n] += (b[n][0] + b[n][1]) + (b[n][2] + b[n][3]);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][q], b[n][q], acc[m][n], 0, 0, 0);
-        }
-    };
-
-    issue(kbeg, 0);
-    issue(kbeg + TGK, 1);
-    int st_cur = 0, st_nxt = 2;
-    for (int64_t k0 = kbeg; k0 < kend; k0 += TGK) {
-        // tile k0 (this wave's loads: all but the L newest) has landed; the barrier extends that to every wave's loads
-        // and tells us that everybody has finished reading the stage about to be refilled
-#ifdef GNF_DW_TRACE
-        unsigned long long tt = __builtin_amdgcn_s_memtime();
-#endif
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-        GNF_DWT(3, tt);
-        asm volatile("s_barrier" ::: "memory");
-        GNF_DWT(4, tt);
-        issue(k0 + 2 * TGK, st_nxt);
-        GNF_DWT(0, tt);
-        compute(st_cur);
-        GNF_DWT(2, tt);
-#ifdef GNF_DW_TRACE
-        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_dw_trace[7] += 1;
-#endif
-        st_cur = st_cur == kLdStages - 1 ? 0 : st_cur + 1;
-        st_nxt = st_nxt == kLdStages - 1 ? 0 : st_nxt + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still be writing LDS when the workgroup retires
-
-    // accumulator layout: col = lane & 15, row = 4 * (lane >> 4) + r
-    float* __restrict__ Cp = job.C;
-    if (EPI == EPI_SLAB) Cp += (int64_t)chunk * sh.M * sh.N;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int gc = n0 + wn + 16 * b + lrow;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t gr = m0 + wm + 16 * m + 4 * lgrp + r;
-                if (gr < sh.M && gc < sh.N) {
-                    float v = acc[m][b][r];
-                    if (EPI == EPI_BIAS_ACT) {
-                        if (sh.apply_act) v = (sh.act == GNF_ACT_RELU) ? fmaxf(v, 0.f) : fmaxf(v, sh.alpha * v);
-                    } else if (EPI == EPI_MASK) {
-                        if (job.aux) {  // act'(pre) read off the stored activation: h > 0 <=> pre > 0
-                            const float h = job.aux[gr * sh.ldaux + gc];
-                            const float slope = (sh.act == GNF_ACT_RELU) ? 0.f : sh.alpha;
-                            v = h > 0.f ? v : v * slope;
-                        }
-                    }
-                    Cp[gr * sh.ldc + gc] = v;
-                }
-            }
-        }
-    if (EPI == EPI_SLAB && BK == OPND_MC && job.aux_out && by == 0 && wm == 0) {
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {  // the four lane groups hold the four k-residues of every column
-            float v = cs[n];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            const int gc = n0 + wn + 16 * n + lrow;
-            if (lgrp == 0 && gc < sh.N) job.aux_out[(int64_t)chunk * sh.N + gc] = v;
-        }
-    }
-}
-
-template <int AK, int BK, int EPI>
-__global__ __launch_bounds__(kGemmThreads) void k_gemm_ld(GemmJob j0, GemmJob j1, GemmShape sh) {
-    const int jz = blockIdx.z / sh.chunks, chunk = blockIdx.z - jz * sh.chunks;
-    const GemmJob job = jz ? j1 : j0;
-    gemm_tile_ld<AK, BK, EPI>(job, sh, blockIdx.x, blockIdx.y, chunk);
-}
+// (An LDS-direct edition of this tile - `buffer_load ... lds` into fragment-order blocks, three stages - was built and
+// measured in round 1: the wait for a tile's loads dropped from ~1050 to ~100 cycles per k-step, but ISSUING them took
+// 1600 cycles per step; wide_fc 10.4 -> 10.8 ms, the 2048-wide trainer 12.0 -> 13.0 ms per iteration.  Removed in round 3
+// with its developer option; DESIGN.md's changelog has the numbers.)
 
 template <int AK, int BK, int EPI, bool BUF>
 __global__ __launch_bounds__(kGemmThreads) void k_gemm(GemmJob j0, GemmJob j1, GemmShape sh) {
@@ -938,25 +734,6 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(GemmJob j0, GemmJob j1,
     job.C[m * sh.ldc + n] = v;
 }
 
-template <int AK, int BK, int EPI>
-static int launch_k_gemm_ld(dim3 grid, hipStream_t st, const GemmJob& j0, const GemmJob& j1, const GemmShape& sh) {
-    GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_ld<AK, BK, EPI>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdLdsBytes)));
-    hipLaunchKernelGGL((k_gemm_ld<AK, BK, EPI>), grid, dim3(kGemmThreads), kLdLdsBytes, st, j0, j1, sh);
-    GNF_LAUNCH_CHECK("k_gemm_ld");
-    return GNF_OK;
-}
-// Measured (MI355X, end of round 1) and therefore OFF unless gnf_set_option("gemm_lds_direct", 1): the LDS-direct tile does what it
-// was built for - the wait for a tile's loads drops from ~1050 to ~100 cycles per k-step - but ISSUING the loads then
-// takes 1600 cycles per step: the texture-address unit is the bottleneck either way (720 cycles for three dwordx4
-// loads on the register path), and an MC operand needs four dword loads per block (a fragment's four k-slices sit in
-// four rows), twice the instructions.  wide_fc 10.4 -> 10.8 ms, the 2048-wide trainer 12.0 -> 13.0 ms per iteration;
-// KC x KC alone (the dX GEMM, all dwordx4) is a wash (47 vs 50 us).  Next: a swizzled dwordx4 layout for MC operands.
-static bool gemm_ld_on(int ak, int bk) {
-    (void)ak, (void)bk;
-    return opt(OPT_GEMM_LDS_DIRECT) != 0;  // developer A/B option
-}
-
 // sk[q] (nullable): scratch of sk_floats floats for job q's slabs when the launch is thin enough to be split
 template <int AK, int BK, int EPI>
 static int launch_gemm(const GemmJob* jobs, int nj, const GemmShape& sh, hipStream_t st, float* const* sk = nullptr,
@@ -980,10 +757,7 @@ static int launch_gemm(const GemmJob* jobs, int nj, const GemmShape& sh, hipStre
                 dim3 grid((unsigned)((sh.N + TGN - 1) / TGN), (unsigned)((sh.M + TGM - 1) / TGM), (unsigned)(nj * s2.chunks));
                 const bool buf = gemm_buf_ok(AK, BK, AK == OPND_KC ? sh.M : sh.K, sh.lda, BK == OPND_KC ? (int64_t)sh.N : sh.K, sh.ldb, sh.K) &&
                                  (AK != OPND_KC && BK != OPND_KC ? true : s2.kchunk % 4 == 0);
-                if (buf && gemm_ld_on(AK, BK)) {
-                    const int rc = launch_k_gemm_ld<AK, BK, EPI_SLAB>(grid, st, sj[0], sj[nj - 1], s2);
-                    if (rc) return rc;
-                } else if (buf)
+                if (buf)
                     hipLaunchKernelGGL((k_gemm<AK, BK, EPI_SLAB, true>), grid, dim3(kGemmThreads), 0, st, sj[0], sj[nj - 1], s2);
                 else
                     hipLaunchKernelGGL((k_gemm<AK, BK, EPI_SLAB, false>), grid, dim3(kGemmThreads), 0, st, sj[0], sj[nj - 1], s2);
@@ -998,7 +772,6 @@ static int launch_gemm(const GemmJob* jobs, int nj, const GemmShape& sh, hipStre
     }
     dim3 grid((unsigned)((sh.N + TGN - 1) / TGN), (unsigned)((sh.M + TGM - 1) / TGM), (unsigned)(nj * sh.chunks));
     const bool buf = gemm_buf_ok(AK, BK, AK == OPND_KC ? sh.M : sh.K, sh.lda, BK == OPND_KC ? (int64_t)sh.N : sh.K, sh.ldb, sh.K);
-    if (buf && gemm_ld_on(AK, BK)) return launch_k_gemm_ld<AK, BK, EPI>(grid, st, jobs[0], jobs[nj - 1], sh);
     if (buf)
         hipLaunchKernelGGL((k_gemm<AK, BK, EPI, true>), grid, dim3(kGemmThreads), 0, st, jobs[0], jobs[nj - 1], sh);
     else
@@ -1009,17 +782,11 @@ static int launch_gemm(const GemmJob* jobs, int nj, const GemmShape& sh, hipStre
 
 // y = act(x W + b) for up to two nets sharing shapes: the layered forward path's matrix-core layers run through the
 // same GEMM tile as the generic backward (split over the reduction when the layer is thin and the caller has a free
-// ping-pong activation buffer to lend as slab scratch; sk may be NULL).  Returns 1 only under the A/B switch that
-// sends ordinary layers back to gnf_layered.hip's own kernel.
+// ping-pong activation buffer to lend as slab scratch; sk may be NULL).
 int launch_linear_splitk(const float* const* x, int64_t ldx, const float* const* W, const float* const* b, float* const* y,
                          int64_t ldy, int nj, int64_t n, int32_t I, int32_t O, int act, float alpha, int apply_act,
                          float* const* sk, size_t sk_floats, hipStream_t st) {
     if (n == 0) return GNF_OK;
-    const bool own_kernel = opt(OPT_LAYERED_OWN_GEMM) != 0;  // developer A/B option: k_linear_mfma
-    if (own_kernel) {
-        const int64_t tiles = (int64_t)((O + TGN - 1) / TGN) * ((n + TGM - 1) / TGM) * nj;
-        if (tiles >= 96 || I < 512 || !sk || (size_t)2 * n * O > sk_floats) return 1;
-    }
     GemmJob jobs[2];
     for (int q = 0; q < nj; ++q) jobs[q] = GemmJob{x[q], W[q], y[q], b[q], nullptr};
     GemmShape sh;
@@ -1232,184 +999,6 @@ __global__ __launch_bounds__(256) void k_aggregate_bwd(const int32_t* __restrict
         V* pg = reinterpret_cast<V*>(g + u * ldg + f);
         *pg = *pg + (concat ? own : own * eps) + acc;
     }
-}
-
-// ---- batch-norm bijector, backwards (forward: gnf_bn.hip) ------------------------------------------------
-// y = (x - mu) / sigma * gamma + beta with the batch moments mu, var (sigma = sqrt(var + eps)) and the
-// log-det term N * sum_f(log gamma_f - 0.5 log(var_f + eps)) inside L = -(log_prob_zs + logdet).  tf.gradients
-// differentiates THROUGH the moments (they are functions of x).  With xh = (y - beta) / gamma, Gy = dL/dy:
-//   dbeta = sum_n Gy          dgamma = sum_n Gy xh - N / gamma
-//   dx    = [ gamma Gy - mean_n(gamma Gy) - xh mean_n(gamma Gy xh) + xh ] / sigma        (+xh: from 0.5 N log(var + eps))
-//   x     = xh sigma + mu                                                              (the state, rebuilt)
-__global__ __launch_bounds__(256) void k_bn_bwd_stats(const float* __restrict__ y, int64_t ld,
-                                                      const float* __restrict__ gy, int64_t ldg, int64_t n, int H,
-                                                      int64_t rows_per_block, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, double* __restrict__ part) {
-    __shared__ double sh[2][256];
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
-    const int tid = threadIdx.x;
-    for (int c0 = 0; c0 < H; c0 += 256) {
-        const int w = H - c0 < 256 ? H - c0 : 256;
-        const int lanes = 256 / w;
-        const int c = tid % w, rs = tid / w;
-        double s = 0.0, q = 0.0;
-        if (rs < lanes) {
-            const float ig = 1.f / gamma[c0 + c], b = beta[c0 + c];
-            for (int64_t r = r0 + rs; r < r1; r += lanes) {
-                const double gv = (double)gy[r * ldg + c0 + c];
-                const double xh = (double)((y[r * ld + c0 + c] - b) * ig);
-                s += gv;
-                q += gv * xh;
-            }
-        }
-        sh[0][tid] = s;
-        sh[1][tid] = q;
-        __syncthreads();
-        if (tid < w) {
-            double ts = 0.0, tq = 0.0;
-            for (int k = 0; k < lanes; ++k) {
-                ts += sh[0][k * w + tid];
-                tq += sh[1][k * w + tid];
-            }
-            part[((int64_t)blockIdx.x * H + c0 + tid) * 2 + 0] = ts;
-            part[((int64_t)blockIdx.x * H + c0 + tid) * 2 + 1] = tq;
-        }
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(256) void k_bn_bwd_apply(float* __restrict__ y, int64_t ld, float* __restrict__ gy,
-                                                      int64_t ldg, int64_t n, int H, int64_t rows_per_block,
-                                                      const double* __restrict__ part, int nparts,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      const float* __restrict__ bmean, const float* __restrict__ bvar,
-                                                      float eps, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                      int accumulate, const double* __restrict__ gsum,
-                                                      const double* __restrict__ n_moments) {
-    extern __shared__ float ss[];  // per column: m1 = mean(gamma Gy), m2 = mean(gamma Gy xh), gamma, beta, sigma, mu
-    float* m1 = ss;
-    float* m2 = ss + H;
-    float* sg = ss + 2 * H;
-    float* sb = ss + 3 * H;
-    float* ssig = ss + 4 * H;
-    float* smu = ss + 5 * H;
-    const int tid = threadIdx.x;
-    // many partial rows (one per workgroup of the kernel that left them): the 256 threads share the walk, thread (g, c)
-    // sums rows g, g + G, ..; the G group sums are then added in order (as k_bn_apply does, gnf_bn.hip)
-    __shared__ double gsum2[512];
-    const int G = (nparts > 32 && H <= 128) ? 256 / H : 1;
-    if (G > 1) {
-        const int c = tid % H, g = tid / H;
-        double s = 0.0, q = 0.0;
-        if (g < G)
-            for (int b0 = g; b0 < nparts; b0 += 16 * G) {
-                double ps[16], pq_[16];  // sixteen partial pairs in flight per thread (eight: six dependent round trips for 340 partial rows)
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int b = b0 + k * G < nparts ? b0 + k * G : g;
-                    ps[k] = part[((int64_t)b * H + c) * 2 + 0];
-                    pq_[k] = part[((int64_t)b * H + c) * 2 + 1];
-                }
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (b0 + k * G < nparts) {
-                        s += ps[k];
-                        q += pq_[k];
-                    }
-            }
-        if (g < G) gsum2[(g * H + c) * 2 + 0] = s, gsum2[(g * H + c) * 2 + 1] = q;
-        __syncthreads();
-    }
-    for (int c = tid; c < H; c += 256) {
-        double s = 0.0, q = 0.0;
-        if (G > 1) {
-            for (int g = 0; g < G; ++g) s += gsum2[(g * H + c) * 2 + 0], q += gsum2[(g * H + c) * 2 + 1];
-        } else
-        for (int b0 = 0; b0 < nparts; b0 += 8) {  // eight partial pairs in flight, summed in order
-            double ps[8], pq_[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int b = b0 + k < nparts ? b0 + k : nparts - 1;
-                ps[k] = part[((int64_t)b * H + c) * 2 + 0];
-                pq_[k] = part[((int64_t)b * H + c) * 2 + 1];
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (b0 + k < nparts) {
-                    s += ps[k];
-                    q += pq_[k];
-                }
-        }
-        const float g = gamma[c];
-        // the means in dx are over the whole batch (cross-rank sums when gsum != NULL); d gamma / d beta below are
-        // THIS rank's share - the gradient all-reduce adds the shares up
-        const double nm = n_moments ? *n_moments : (double)n;
-        const double sg_ = gsum ? gsum[2 * c + 0] : s, qg_ = gsum ? gsum[2 * c + 1] : q;
-        m1[c] = (float)(sg_ / nm) * g;
-        m2[c] = (float)(qg_ / nm) * g;
-        sg[c] = g;
-        sb[c] = beta[c];
-        ssig[c] = sqrtf(bvar[c] + eps);
-        smu[c] = bmean[c];
-        if (blockIdx.x == 0) {
-            const float db = (float)s;
-            const float dg = (float)(q - (double)n / (double)g);
-            dbeta[c] = accumulate ? dbeta[c] + db : db;
-            dgamma[c] = accumulate ? dgamma[c] + dg : dg;
-        }
-    }
-    __syncthreads();
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
-    const int64_t tot = (r1 - r0) * H;
-    for (int64_t i = tid; i < tot; i += 256) {
-        const int64_t r = r0 + i / H;
-        const int c = (int)(i % H);
-        float* py = y + r * ld + c;
-        float* pg = gy + r * ldg + c;
-        const float xh = (*py - sb[c]) / sg[c];
-        const float sig = ssig[c];
-        *pg = (sg[c] * *pg - m1[c] - xh * m2[c] + xh) / sig;
-        *py = xh * sig + smu[c];
-    }
-}
-
-// pre_parts > 0: `part` already holds that many [H][2] partial rows (sum G, sum G x^) left by the kernel that wrote the
-// final gy rows (k_attn_bwd_dx): no moment pass
-static int launch_bn_backward(const GnfFlow* flow, const GnfBatchNorm* bn, const GnfBatchNorm* gbn, float* y, int64_t ld,
-                              float* gy, int64_t ldg, int64_t n, int32_t H, double* part, hipStream_t st, int pre_parts = 0) {
-    int64_t rpb = (n + 15) / 16;  // about sixteen chunks of at least 32 rows (see bn_blocks in gnf_bn.hip)
-    if (rpb < 32) rpb = 32;
-    int64_t blocks = (n + rpb - 1) / rpb;
-    if (blocks > kBnBlocksMax) {
-        rpb = (n + kBnBlocksMax - 1) / kBnBlocksMax;
-        blocks = (n + rpb - 1) / rpb;
-    }
-    if (pre_parts > 0) {
-        blocks = pre_parts;
-    } else {
-        hipLaunchKernelGGL(k_bn_bwd_stats, dim3((unsigned)blocks), dim3(256), 0, st, y, ld, gy, ldg, n, H, rpb, bn->gamma,
-                           bn->beta, part);
-        GNF_LAUNCH_CHECK("k_bn_bwd_stats");
-    }
-    const double *gsum = nullptr, *n_moments = nullptr;
-    if (flow->bn_allreduce) {  // sum G, sum G x^ over the whole batch; this rank's own sums stay behind the partials
-        double* local = part + (size_t)kBnPartRowsMax * H * 2;
-        const int rc = bn_sync_exchange(flow, part, (int)blocks, n, H, local, st);
-        if (rc) return rc;
-        part = local;
-        blocks = 1;
-        gsum = flow->bn_sync_buf;
-        n_moments = flow->bn_sync_buf + 2 * (int64_t)H;
-    }
-    const int64_t arows = 16;
-    const int64_t ablocks = (n + arows - 1) / arows;
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)ablocks), dim3(256), 6 * H * sizeof(float), st, y, ld, gy, ldg, n,
-                       H, arows, part, (int)blocks, bn->gamma, bn->beta, bn->batch_mean, bn->batch_variance, bn->epsilon,
-                       const_cast<float*>(gbn->gamma), const_cast<float*>(gbn->beta), 0, gsum, n_moments);
-    GNF_LAUNCH_CHECK("k_bn_bwd_apply");
-    return GNF_OK;
 }
 
 // ---- workspace ---------------------------------------------------------------------------------
@@ -2027,7 +1616,7 @@ bool mlp_stash_supported(const GnfFlow* flow, int64_t n, int32_t H) {
     int64_t tiles;
     size_t lds;
     fused_bwd_launch_shape(&flow->s_nets[0], n, &tiles, &lds);
-    return tiles == (n + 15) / 16 && tiles <= 256;  // 16-node tiles in both directions (one per CU at most)
+    return tiles == (n + 15) / 16 && tiles <= big_cu_count();  // 16-node tiles in both directions (one per CU at most)
 }
 
 // job list of one half-step: the K layers of both nets, then the four attention matrices of both nets
@@ -2249,189 +1838,6 @@ static int mlp_backward_generic(const BwdPlan& p, const BwdOperands& o, const Gn
     return GNF_OK;
 }
 
-// ---- multi-tensor re-pack (after an optimiser step every net's MFMA fragment copy is stale) ----------
-struct PackDesc {
-    const float* W;
-    const float* b;
-    float* wout;
-    float* bout;
-    float* wtout;
-    int32_t I, O, Ip, Op;
-};
-static constexpr int kPackBatch = 56;
-struct PackBatch {
-    PackDesc d[kPackBatch];
-};
-
-__global__ __launch_bounds__(256) void k_pack_multi(const PackBatch pb) {
-    const PackDesc& d = pb.d[blockIdx.y];
-    const int64_t nw = (int64_t)d.Ip * d.Op;
-    // a thread = the four k-consecutive elements of one lane's fragment (i = 4 t .. 4 t + 3): one 16-byte store per copy, and
-    // for the transposed copy - whose four elements are consecutive in a row of W - one 16-byte load where rows are aligned
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t i = 4 * t;
-    if (i < nw) {  // same fragment order as k_pack_layer (gnf_fused.hip)
-        const int lane = (int)(t & 63);
-        const int64_t blk = t >> 6;
-        const int nts = d.Op >> 4;
-        const int kg = (int)(blk / nts), nt = (int)(blk % nts);
-        const int k = 16 * kg + 4 * (lane >> 4);
-        const int c = 16 * nt + (lane & 15);
-        float w4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w4[q] = (k + q < d.I && c < d.O) ? d.W[(int64_t)(k + q) * d.O + c] : 0.f;
-        const int nts_t = d.Ip >> 4;
-        const int kg_t = (int)(blk / nts_t), nt_t = (int)(blk % nts_t);
-        const int ko = 16 * kg_t + 4 * (lane >> 4);
-        const int ci = 16 * nt_t + (lane & 15);
-        float t4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (ci < d.I) {
-            const float* row = d.W + (int64_t)ci * d.O + ko;
-            if (ko + 3 < d.O && (d.O & 3) == 0 && (reinterpret_cast<uintptr_t>(d.W) & 15) == 0) {
-                const float4 v = *reinterpret_cast<const float4*>(row);
-                t4[0] = v.x, t4[1] = v.y, t4[2] = v.z, t4[3] = v.w;
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (ko + q < d.O) t4[q] = row[q];
-            }
-        }
-        if (((reinterpret_cast<uintptr_t>(d.wout) | reinterpret_cast<uintptr_t>(d.wtout)) & 15) == 0) {
-            *reinterpret_cast<float4*>(d.wout + i) = make_float4(w4[0], w4[1], w4[2], w4[3]);
-            *reinterpret_cast<float4*>(d.wtout + i) = make_float4(t4[0], t4[1], t4[2], t4[3]);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) d.wout[i + q] = w4[q], d.wtout[i + q] = t4[q];
-        }
-    } else if (i < nw + 4 * ((d.Op + 3) / 4)) {
-        for (int q = 0; q < 4; ++q) {
-            const int c = (int)(i - nw) + q;
-            if (c < d.Op) d.bout[c] = c < d.O ? d.b[c] : 0.f;
-        }
-    }
-}
-
-static inline int pad16i(int v) { return (v + 15) & ~15; }
-
-static int pack_flow(const GnfFlow* flow, hipStream_t st) {
-    const int n_nets = flow->weight_sharing ? 2 : 2 * flow->num_timesteps;
-    PackBatch pb;
-    int cnt = 0;
-    int64_t maxtot = 0;
-    auto flush = [&]() -> int {
-        if (!cnt) return GNF_OK;
-        hipLaunchKernelGGL(k_pack_multi, dim3((unsigned)((maxtot / 4 + 255) / 256), cnt), dim3(256), 0, st, pb);  // 4 elements per thread
-        GNF_LAUNCH_CHECK("k_pack_multi");
-        cnt = 0;
-        maxtot = 0;
-        return GNF_OK;
-    };
-    for (int kind = 0; kind < 2; ++kind)
-        for (int q = 0; q < n_nets; ++q) {
-            const GnfMlp* m = kind ? &flow->t_nets[q] : &flow->s_nets[q];
-            if (!m->packed) continue;
-            // layers too wide for LDS never run the fused kernels: nothing reads their fragment-order copy (at the
-            // data-backed trainer's 2048-wide layers the re-pack was 1.1 ms per step and 1.5 GB)
-            if (!fused_fits_lds(m) && !fused_bwd_fits_lds(m)) continue;
-            int64_t woff = 0, boff = 0;
-            for (int j = 0; j < m->num_layers; ++j) boff += (int64_t)pad16i(m->dims[j]) * pad16i(m->dims[j + 1]);
-            int64_t toff = boff;
-            for (int j = 0; j < m->num_layers; ++j) toff += pad16i(m->dims[j + 1]);
-            for (int j = 0; j < m->num_layers; ++j) {
-                const int I = m->dims[j], O = m->dims[j + 1], Ip = pad16i(I), Op = pad16i(O);
-                float* pk = const_cast<float*>(m->packed);
-                pb.d[cnt++] = PackDesc{m->W[j], m->b[j], pk + woff, pk + boff, pk + toff + woff, I, O, Ip, Op};
-                const int64_t tot = (int64_t)Ip * Op + Op;
-                maxtot = maxtot > tot ? maxtot : tot;
-                woff += (int64_t)Ip * Op;
-                boff += Op;
-                if (cnt == kPackBatch) {
-                    const int rc = flush();
-                    if (rc) return rc;
-                }
-            }
-        }
-    return flush();
-}
-
-// ---- optimiser ---------------------------------------------------------------------------------
-// tf.train.AdamOptimizer (run_grevnet.py:352-356): lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) is computed by the
-// caller (fp64 on the host, like TF's python side);  m <- b1 m + (1-b1) g;  v <- b2 v + (1-b2) g^2;
-// w <- w - lr_t m / (sqrt(v) + eps)
-__global__ __launch_bounds__(256) void k_adam(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
-                                              float* __restrict__ v, int64_t n, float lr_t, float b1, float b2,
-                                              float eps) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float gv = g[i];
-        const float mv = b1 * m[i] + (1.f - b1) * gv;
-        const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
-        m[i] = mv;
-        v[i] = vv;
-        w[i] = w[i] - lr_t * mv / (sqrtf(vv) + eps);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_clip_value(float* __restrict__ g, int64_t n, float lo, float hi) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        g[i] = fminf(fmaxf(g[i], lo), hi);
-}
-
-// tf.clip_by_norm per gradient tensor (run_grevnet.py:369-372): t * clip / max(||t||_2, clip).
-// One workgroup per tensor; offsets[i] .. offsets[i+1] delimit tensor i inside the flat gradient.
-__global__ __launch_bounds__(256) void k_clip_norm(float* __restrict__ g, const int64_t* __restrict__ offsets,
-                                                   float clip) {
-    __shared__ double red[256];
-    const int64_t beg = offsets[blockIdx.x], end = offsets[blockIdx.x + 1];
-    double s = 0.0;
-    for (int64_t i = beg + threadIdx.x; i < end; i += 256) s += (double)g[i] * (double)g[i];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    const float nrm = (float)sqrt(red[0]);
-    const float scale = clip / fmaxf(nrm, clip);
-    for (int64_t i = beg + threadIdx.x; i < end; i += 256) g[i] *= scale;
-}
-
-// The same in two passes with kClipSlices workgroups per tensor (a 2048 x 2048 gradient in ONE workgroup took 10 ms):
-// pass 1: fp64 sum of squares of slice s of tensor t -> part[t][s];  pass 2: every slice's workgroup adds the
-// tensor's partials in slice order (the same number in every workgroup) and scales its slice.
-static constexpr int kClipSlices = 64;
-__device__ __forceinline__ void clip_slice(const int64_t* __restrict__ offsets, int64_t& lo, int64_t& hi) {
-    const int64_t beg = offsets[blockIdx.y], len = offsets[blockIdx.y + 1] - beg;
-    const int64_t per = (len + kClipSlices - 1) / kClipSlices;
-    lo = beg + (int64_t)blockIdx.x * per;
-    hi = lo + per < beg + len ? lo + per : beg + len;
-}
-__global__ __launch_bounds__(256) void k_clip_norm_part(const float* __restrict__ g, const int64_t* __restrict__ offsets,
-                                                        double* __restrict__ part) {
-    __shared__ double red[256];
-    int64_t lo, hi;
-    clip_slice(offsets, lo, hi);
-    double s = 0.0;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) s += (double)g[i] * (double)g[i];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) part[(int64_t)blockIdx.y * kClipSlices + blockIdx.x] = red[0];
-}
-__global__ __launch_bounds__(256) void k_clip_norm_scale(float* __restrict__ g, const int64_t* __restrict__ offsets,
-                                                         const double* __restrict__ part, float clip) {
-    int64_t lo, hi;
-    clip_slice(offsets, lo, hi);
-    if (lo >= hi) return;
-    double tot = 0.0;
-    for (int q = 0; q < kClipSlices; ++q) tot += part[(int64_t)blockIdx.y * kClipSlices + q];
-    const float nrm = (float)sqrt(tot);
-    const float scale = clip / fmaxf(nrm, clip);
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) g[i] *= scale;
-}
-
 }  // namespace gnf
 
 using namespace gnf;
@@ -2578,17 +1984,35 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     }
     if (merged) aux = nullptr;
     const bool reuse_sets = 2 * T > p.n_sets;
-    struct CallEvents {
-        hipEvent_t ev[kBwdMaxSets + 1] = {};
-        ~CallEvents() {
-            for (hipEvent_t e : ev)
-                if (e) (void)hipEventDestroy(e);
+    // The events live in a per-host-thread, per-device cache (created at a thread's first call on a device, released
+    // when the thread ends): no create / destroy per training step, nothing shared between threads or devices, and no
+    // event destroyed while work recorded on it is still pending or being captured.
+    struct EventCache {
+        hipEvent_t ev[64][kBwdMaxSets + 2] = {};
+        ~EventCache() {
+            for (auto& dev_ev : ev)
+                for (hipEvent_t e : dev_ev)
+                    if (e) (void)hipEventDestroy(e);
         }
-    } call_events;
+    };
+    static thread_local EventCache tl_events;
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    hipEvent_t* const call_ev = tl_events.ev[cur_dev & 63];
     if (aux)
-        for (int q = 0; q < (reuse_sets ? p.n_sets + 1 : 2); ++q)
-            GNF_HIP_TRY(hipEventCreateWithFlags(&call_events.ev[q], hipEventDisableTiming));
-    const hipEvent_t ev_ready = call_events.ev[0];
+        for (int q = 0; q < kBwdMaxSets + 2; ++q)
+            if (!call_ev[q]) GNF_HIP_TRY(hipEventCreateWithFlags(&call_ev[q], hipEventDisableTiming));
+    // whatever path leaves this function after the auxiliary stream was given work, the caller's stream is ordered
+    // behind it (an early error return used to leave the fork unjoined: fatal inside a stream capture)
+    struct AuxJoin {
+        hipStream_t aux, st;
+        hipEvent_t ev;
+        bool armed = false;
+        ~AuxJoin() {
+            if (armed && aux && ev && hipEventRecord(ev, aux) == hipSuccess) (void)hipStreamWaitEvent(st, ev, 0);
+        }
+    } aux_join{aux, st, aux ? call_ev[kBwdMaxSets + 1] : nullptr};
+    const hipEvent_t ev_ready = call_ev[0];
     hipEvent_t ev_done[kBwdMaxSets] = {};
     hipEvent_t ev_last = nullptr;
     int step = 0;
@@ -2703,7 +2127,8 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 WGJob jobs[kMaxGroup];
                 const int nj = weight_grad_jobs(p, o, nets, grads, jobs);
                 const bool last = step == 2 * T - 1;
-                int room = last ? 256 : 256 - (int)tiles;   // CUs the backward tiles of the NEXT launch leave
+                const int cus = big_cu_count();
+                int room = last ? cus : cus - (int)tiles;   // CUs the backward tiles of the NEXT launch leave
                 if (const int64_t force = opt(OPT_DW_WIDE_UNITS)) room = force < room ? (int)force : room;  // developer A/B option
                 const DwPolicy pol{room, lds, 1e30};
                 rc = plan_weight_grads(p, pol, jobs, nj, acc, wsf, cur, &pend[cur]);
@@ -2715,7 +2140,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                     rc = run_weight_reduce(pend[cur], st);
                     if (rc) return rc;
                 }
-                have_fold = !attn && !flow->bns && !last && !opt(OPT_BWD_NO_FOLD);
+                have_fold = !attn && !flow->bns && !last;
                 if (attn) {
                     const GnfBatchNorm* bq = flow->bns ? &flow->bns[half * T + i] : nullptr;
                     const AttnBnFold bnf{z + co, ld, bq ? bq->gamma : nullptr, bq ? bq->beta : nullptr,
@@ -2766,8 +2191,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             // message passing: the weight gradients only read what the fused kernel has just written, so their stream
             // forks HERE, before the scatter of dL/dx_cond (with an attention front-end they also read its backward
             // pass and fork after it)
-            const bool late_fork = opt(OPT_DW_LATE_FORK) != 0;  // developer A/B option
-            const bool early_fork = aux && !attn && !late_fork;
+            const bool early_fork = aux && !attn;
             if (early_fork) {
                 GNF_HIP_TRY(hipEventRecord(ev_ready, st));
                 GNF_HIP_TRY(hipStreamWaitEvent(aux, ev_ready, 0));
@@ -2803,7 +2227,8 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 rc = launch_weight_grads(p, dw_policy(nets[0], bwd_tiles, bwd_lds), jobs, nj, acc, wsf, wst);
                 if (rc) return rc;
                 if (aux && (reuse_sets || step == 2 * T - 1)) {
-                    hipEvent_t e = call_events.ev[1 + (reuse_sets ? set : 0)];
+                    hipEvent_t e = call_ev[1 + (reuse_sets ? set : 0)];
+                    aux_join.armed = true;
                     GNF_HIP_TRY(hipEventRecord(e, aux));
                     ev_done[set] = e;
                     ev_last = e;
@@ -2829,123 +2254,6 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     }
     // join: the auxiliary stream runs its launches in order, so the last one's event covers them all
     if (aux && ev_last) GNF_HIP_TRY(hipStreamWaitEvent(st, ev_last, 0));
-    return GNF_OK;
-}
-
-// After an optimiser step, for every batch-norm bijector of the flow in ONE launch (was 4 torch elementwise launches
-// per bijector): the gamma_constraint projection relu(gamma) + 1e-6 (gnn.py:261-262) and tf.layers' UPDATE_OPS
-// moving <- moving * momentum + batch * (1 - momentum) (run_grevnet.py:360).
-struct BnPostBatch {
-    GnfBatchNorm bn[48];
-    int32_t H;
-    float momentum;
-};
-__global__ __launch_bounds__(256) void k_bn_post_step(const BnPostBatch b) {
-    const GnfBatchNorm bn = b.bn[blockIdx.x];
-    float* gamma = const_cast<float*>(bn.gamma);
-    float* mm = const_cast<float*>(bn.moving_mean);
-    float* mv = const_cast<float*>(bn.moving_variance);
-    for (int f = threadIdx.x; f < b.H; f += 256) {
-        gamma[f] = fmaxf(gamma[f], 0.f) + 1e-6f;
-        mm[f] = mm[f] * b.momentum + bn.batch_mean[f] * (1.f - b.momentum);
-        mv[f] = mv[f] * b.momentum + bn.batch_variance[f] * (1.f - b.momentum);
-    }
-}
-
-int gnf_bn_post_step_f32(const GnfFlow* flow, int32_t H, float momentum, gnf_stream_t stream) {
-    if (!flow || H < 1 || !(momentum >= 0.f && momentum <= 1.f)) {
-        set_error("gnf_bn_post_step_f32: bad arguments");
-        return GNF_EINVAL;
-    }
-    if (!flow->bns) return GNF_OK;
-    const int total = 2 * flow->num_timesteps;
-    for (int q = 0; q < total; ++q) {
-        const GnfBatchNorm& bn = flow->bns[q];
-        if (!bn.gamma || !bn.moving_mean || !bn.moving_variance || !bn.batch_mean || !bn.batch_variance) {
-            set_error("gnf_bn_post_step_f32: bijector %d has a null pointer", q);
-            return GNF_EINVAL;
-        }
-    }
-    for (int base = 0; base < total; base += 48) {
-        BnPostBatch b;
-        const int nb = total - base < 48 ? total - base : 48;
-        for (int q = 0; q < nb; ++q) b.bn[q] = flow->bns[base + q];
-        b.H = H;
-        b.momentum = momentum;
-        hipLaunchKernelGGL(k_bn_post_step, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, b);
-        GNF_LAUNCH_CHECK("k_bn_post_step");
-    }
-    return GNF_OK;
-}
-
-int gnf_pack_flow(const GnfFlow* flow, gnf_stream_t stream) {
-    if (!flow || !flow->s_nets || !flow->t_nets || flow->num_timesteps < 0) {
-        set_error("gnf_pack_flow: null flow / nets");
-        return GNF_EINVAL;
-    }
-    const int n_nets = flow->weight_sharing ? 2 : 2 * flow->num_timesteps;
-    for (int q = 0; q < n_nets; ++q) {
-        int rc = validate_mlp(&flow->s_nets[q], "gnf_pack_flow s_net");
-        if (rc) return rc;
-        rc = validate_mlp(&flow->t_nets[q], "gnf_pack_flow t_net");
-        if (rc) return rc;
-    }
-    return pack_flow(flow, (hipStream_t)stream);
-}
-
-int gnf_adam_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
-                 float epsilon, gnf_stream_t stream) {
-    if (n < 0 || (n > 0 && (!w || !g || !m || !v))) {
-        set_error("gnf_adam_f32: null buffer or n=%lld", (long long)n);
-        return GNF_EINVAL;
-    }
-    if (n == 0) return GNF_OK;
-    int64_t blocks = (n + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n, lr_t, beta1,
-                       beta2, epsilon);
-    GNF_LAUNCH_CHECK("k_adam");
-    return GNF_OK;
-}
-
-int gnf_clip_by_value_f32(float* g, int64_t n, float lo, float hi, gnf_stream_t stream) {
-    if (n < 0 || (n > 0 && !g) || !(lo <= hi)) {
-        set_error("gnf_clip_by_value_f32: bad arguments");
-        return GNF_EINVAL;
-    }
-    if (n == 0) return GNF_OK;
-    int64_t blocks = (n + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_clip_value, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, lo, hi);
-    GNF_LAUNCH_CHECK("k_clip_value");
-    return GNF_OK;
-}
-
-size_t gnf_clip_workspace_bytes(int32_t n_tensors) {
-    return n_tensors > 0 ? (size_t)n_tensors * kClipSlices * sizeof(double) : 0;
-}
-
-int gnf_clip_by_norm_f32(float* g, const int64_t* offsets, int32_t n_tensors, float clip_norm, void* ws, size_t ws_bytes,
-                         gnf_stream_t stream) {
-    if (n_tensors < 0 || (n_tensors > 0 && (!g || !offsets)) || !(clip_norm > 0.f)) {
-        set_error("gnf_clip_by_norm_f32: bad arguments");
-        return GNF_EINVAL;
-    }
-    if (n_tensors == 0) return GNF_OK;
-    if (!ws) {  // no scratch: one workgroup per tensor (fine for small tensors)
-        hipLaunchKernelGGL(k_clip_norm, dim3((unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, g, offsets, clip_norm);
-        GNF_LAUNCH_CHECK("k_clip_norm");
-        return GNF_OK;
-    }
-    if (ws_bytes < gnf_clip_workspace_bytes(n_tensors)) {
-        set_error("gnf_clip_by_norm_f32: workspace %zu < %zu bytes", ws_bytes, gnf_clip_workspace_bytes(n_tensors));
-        return GNF_EWORKSPACE;
-    }
-    const dim3 grid(kClipSlices, (unsigned)n_tensors);
-    hipLaunchKernelGGL(k_clip_norm_part, grid, dim3(256), 0, (hipStream_t)stream, g, offsets, (double*)ws);
-    GNF_LAUNCH_CHECK("k_clip_norm_part");
-    hipLaunchKernelGGL(k_clip_norm_scale, grid, dim3(256), 0, (hipStream_t)stream, g, offsets, (const double*)ws, clip_norm);
-    GNF_LAUNCH_CHECK("k_clip_norm_scale");
     return GNF_OK;
 }
 

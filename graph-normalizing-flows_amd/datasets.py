@@ -260,20 +260,35 @@ def plan_variable_batches(n_node, max_nodes):
 class _ChunkBatches:
     """Batches out of a directory of embedding chunks: the files are visited once in order, each chunk is cut by
     `plan` into graph ranges, a batch is (node_embeddings[rows of the range], n_node[range]).  Running past the
-    last file raises IndexError, like the reference's `self.files[self.file_ind]`."""
+    last file raises IndexError, like the reference's `self.files[self.file_ind]`.
+    The first chunk is opened (and cut) by the constructor, as the reference's readers do in theirs
+    (train_grevnet_with_data.py:150-157, 188-195): an empty or unreadable directory, or a graph that can never fit under
+    max_nodes, fails there and not in the middle of an epoch; `file_ind` exists from the start.
+    One deliberate difference: the short LAST batch of the LAST file is handed out (the variable-size reader of the
+    reference loses it - it raises IndexError while opening the file after the last one, before returning the batch)."""
 
     def __init__(self, directory, files, plan):
         import os
         self._paths = [os.path.join(directory, f) for f in files]
         self.files = list(files)
         self._plan = plan
+        self.file_ind = 0
+        if not self._paths:
+            raise IndexError(f"{type(self).__name__}: no training files in {directory!r}")
+        self._first = self._cut(self._paths[0])
         self._batches = self._generate()
 
+    def _cut(self, path):
+        emb, n_node = _read_embedding_chunk(path)
+        row_end = np.concatenate([[0], np.cumsum(n_node)])
+        return emb, n_node, row_end, self._plan(n_node)
+
     def _generate(self):
-        for self.file_ind, path in enumerate(self._paths):
-            emb, n_node = _read_embedding_chunk(path)
-            row_end = np.concatenate([[0], np.cumsum(n_node)])
-            for lo, hi in self._plan(n_node):
+        for ind, path in enumerate(self._paths):
+            self.file_ind = ind
+            emb, n_node, row_end, ranges = self._first if ind == 0 else self._cut(path)
+            self._first = None
+            for lo, hi in ranges:
                 yield emb[row_end[lo]:row_end[hi]], n_node[lo:hi]
 
     def train_batch(self):

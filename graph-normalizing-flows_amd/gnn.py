@@ -697,7 +697,7 @@ class GRevNet:
         # TF ops are functional: the result goes to a NEW buffer; the library reads `src` and writes `out`
         # (gnf_grevnet_from_f32: no separate copy pass where the fused kernel runs the first half-step)
         src = x.to(torch.float32)
-        if src.stride(1) != 1 and n > 0:
+        if n > 0 and (src.stride(1) != 1 or src.stride(0) < d):   # (expand()ed / as_strided views: rows must not overlap)
             src = src.contiguous()
         out = torch.empty((n, d), dtype=torch.float32, device=dev)
         flow = self._flow(d // 2, dev)
@@ -714,7 +714,7 @@ class GRevNet:
         with torch.cuda.device(dev):
             _abi.check(lib.gnf_grevnet_from_f32(C.byref(csr.desc), C.byref(flow), _abi.ptr(src), src.stride(0) if n else d,
                                                 _abi.ptr(out), d, d, direction, _abi.ptr(sums), _abi.ptr(ws), ws_bytes,
-                                                _abi.stream_ptr(dev)), "gnf_grevnet_f32")
+                                                _abi.stream_ptr(dev)), "gnf_grevnet_from_f32")
         return out, sums
 
     # ---- the reference's methods --------------------------------------------------------------

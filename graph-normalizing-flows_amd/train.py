@@ -32,6 +32,19 @@ def exponential_decay(learning_rate, global_step, decay_steps, decay_rate, stair
     return learning_rate * decay_rate ** p
 
 
+def get_learning_rate(timestep, max_lr, ramp_up=1000, hold_steady=2000, const_multiple=3):
+    """The drivers' --use_lr_schedule (utils.py:93-105, called at run_grevnet.py:444): linear warm-up to max_lr over
+    `ramp_up` steps, max_lr up to and including step `hold_steady`, then max_lr * min(1, const_multiple) /
+    sqrt(steps past hold_steady).  The warm-up test comes first, so with ramp_up > hold_steady the ramp runs to its end
+    and the decay starts from there."""
+    if timestep < ramp_up:
+        return max_lr * timestep / ramp_up
+    if timestep <= hold_steady:
+        return max_lr
+    inv = 1.0 / math.sqrt(timestep - hold_steady)
+    return max_lr * min(inv, const_multiple * inv)
+
+
 class _StepTerms(dict):
     """values_map of a training iteration (run_grevnet.py:290-302).  The two batch sums come out of the flow as device
     fp64 scalars; every derived scalar (log_prob_zs, total_loss, the *_per_node values ...) is a few 0-d torch

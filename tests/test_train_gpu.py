@@ -686,12 +686,10 @@ def test_thin_layers_behind_wide_ones_take_the_split_k_path(grid_small):
 DW_MODES = [   # (gnf_set_option values, dw_modes_check.py flags)
     ({}, ""),                                                     # what the library picks by itself (this batch: the merged launch)
     ({}, "ws"),                                                   # ... with weight sharing: the in-launch reduce accumulates
-    ({"bwd_no_fold": 1}, ""),                                     # merged launch, message-passing scatter in its own launch
     ({"dw_wide_units": 8}, ""),                                   # merged launch, few dW workgroups: cheap units ride behind, strided
     ({"dw_no_streamk": 1}, ""),                                   # ... whole chunks instead of stream-K runs
     ({"dw_wide_units": 13}, "ws"),                                # ... stream-K with an odd workgroup count
     ({"no_mlp_stash": 1}, "ws"),                                  # merged launch recomputing the MLP rows (no stash)
-    ({"no_mlp_stash": 1, "bwd_no_fold": 1}, ""),
     ({"dw_no_buf": 1}, ""),                                       # ... a plan the merged launch cannot carry runs on its own
     ({"dw_unmerged": 1}, ""),                                     # round-1 scheme: dW GEMMs on the auxiliary stream
     ({"dw_unmerged": 1, "dw_grouped": 1}, ""),                    # the 128 x 64 grouped kernel
@@ -702,7 +700,6 @@ DW_MODES = [   # (gnf_set_option values, dw_modes_check.py flags)
     ({"dw_unmerged": 1, "dw_wide_units": 24, "dw_no_streamk": 1}, ""),
     ({"dw_unmerged": 1, "dw_wide_units": 13}, "ws"),
     ({"bwd_generic": 1}, ""),                                     # generic (GEMM) backward: buffer-descriptor tile fetch
-    ({"bwd_generic": 1, "gemm_lds_direct": 1}, ""),               # ... through the LDS-direct (fragment-order) tile
     ({"bwd_generic": 1, "gemm_no_buf": 1}, "ws"),                 # ... through the bounds-checked fetch
 ]
 
