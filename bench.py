@@ -507,7 +507,7 @@ def main():
                     "note": "GraphsTuple fields packed in ONE pinned host buffer each step: one upload + gnf_build_csr + forward"}
 
     # ---- secondary figure: independent forwards on TWO HIP streams.  A 64-graph batch fills 170 of the 256 CUs
-    # (one 16-node tile per CU, DESIGN.md 4.2); evaluation of many batches (the steps here are independent of each
+    # (one 16-node tile per CU, DESIGN.md 4.1); evaluation of many batches (the steps here are independent of each
     # other) can use the idle third of the chip by keeping two batches in flight.  Not the headline protocol
     # (one batch at a time); reported next to it.
     two_streams = None

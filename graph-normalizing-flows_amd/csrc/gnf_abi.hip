@@ -552,7 +552,7 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
     if (direction == GNF_FORWARD) {
         // (measured and dropped, tools/ab_options.py: k_gauss + k_finalize merged into one launch whose last-arriving
         // workgroup runs the final reduction - the release / ticket / acquire hand-off costs 1 us more than the launch
-        // boundary it removes)
+        // boundary it removes, CHANGELOG.md section 4.4)
         int32_t ng = 0;
         if (nsq[0] > 0 && nsq[1] > 0) {
             ng = nsq[0] + nsq[1];

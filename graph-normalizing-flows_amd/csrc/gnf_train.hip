@@ -1567,7 +1567,7 @@ static int launch_half_bwd_dw(const BwdArgs* bwd, int64_t bwd_tiles, size_t bwd_
     memset(&r, 0, sizeof(r));
     int n_dw = 0, r_nj = 0;
     // developer option dw_debug, bits beyond 1 (plan print): timing ablations of this launch - 2 = the reduce in a launch
-    // of its own, 4 = no dW GEMMs, 8 = no backward tiles (4 and 8 give wrong gradients; DESIGN.md section 10 has the numbers)
+    // of its own, 4 = no dW GEMMs, 8 = no backward tiles (4 and 8 give wrong gradients; CHANGELOG.md section 10 has the numbers)
     const int64_t dbg = opt(OPT_DW_DEBUG);
     if (dw && !(dbg & 4)) narrow_wide(dw->wg, &g), n_dw = dw->units;
     if (red && !red->direct && !(dbg & 2)) narrow_reduce(red->gr, red->nj, &r), r_nj = red->nj;
