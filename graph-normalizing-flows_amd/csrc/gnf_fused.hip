@@ -563,9 +563,11 @@ static void choose_shape(const HalfStep& hs, int* mt, int* nets) {
 // so the choice is by the quanta each needs, in units of the (2,2) shape's pass over 256 tiles (59 us at L = 256, K = 5):
 //   (2,2):  ceil(g / (2 C))                                       g = 16-row granules, C = CUs
 //   here :  g <= 8 C (even deal, one pass):  1.22 + 0.525 g / (2 C)
-//           else                          :  1.81 ceil(g / (4 C)) + 0.29      (+ the aggregation launch, in the 0.29)
-// fitted to tools/ab_shapes.sh on config-4 batches of 3.5 k .. 78 k nodes: e.g. 8.2 k nodes 101 vs 117 us,
-// 13 k 127 vs 119, 20 k 149 vs 177, 30 k 221 vs 237, 40 k 338 vs 295, 59 k 426 vs 471, 78 k 549 vs 588.
+//           else: 3.36 per whole double round (8 C granules) + 0.15 (the aggregation launch) + the closing round
+//                 (big_plan) by the row tiles left per CU:  <= 1: 0.8 | <= 2: 1.25 | <= 3: 1.7 | <= 4: 2.18 | <= 5: 2.4 |
+//                 <= 6: 2.6 | more: another double round
+// fitted to tools/ab_shapes.sh / tools/ab_tail.sh on config-4 batches of 3.5 k .. 78 k nodes: e.g. 8.2 k
+// nodes 101 vs 117 us, 13 k 127 vs 119, 20 k 149 vs 177, 30 k 221 vs 237, 49 k 326 vs 352, 59 k 422 vs 471, 78 k 520 vs 588.
 // gnf_set_option("force_shape", 40 | 30 | 20 | 10) forces it with that cap, any other forced shape keeps it off.
 static int choose_big(const HalfStep& hs) {
     const GnfMlp* s = hs.s_net;
@@ -576,7 +578,14 @@ static int choose_big(const HalfStep& hs) {
     const int64_t g = (hs.n_nodes + 15) / 16, c = big_cu_count();
     if (g <= 2 * c) return 0;  // one tile per CU or less: the 16- / 32-row both-nets shapes
     const double old_q = (double)((g + 2 * c - 1) / (2 * c));
-    const double big_q = g <= 8 * c ? 1.22 + 0.525 * (double)g / (double)(2 * c) : 1.81 * (double)((g + 4 * c - 1) / (4 * c)) + 0.29;
+    double big_q;
+    if (g <= 8 * c) {
+        big_q = 1.22 + 0.525 * (double)g / (double)(2 * c);
+    } else {
+        static const double closing[7] = {0.0, 0.8, 1.25, 1.7, 2.18, 2.4, 2.6};
+        const int64_t full = g / (8 * c), left = g - full * 8 * c, t = (left + c - 1) / c;  // row tiles left per CU, rounded up
+        big_q = 3.36 * (double)full + 0.15 + (t <= 6 ? closing[t] : 3.36);
+    }
     return big_q < old_q ? 4 : 0;
 }
 

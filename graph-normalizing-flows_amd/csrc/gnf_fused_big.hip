@@ -46,6 +46,9 @@ static constexpr int kBigMaxH = 128;     // widest padded output (s stays in 8 *
 #ifndef GNF_BIG_RBW
 #define GNF_BIG_RBW 2  // weight k-groups in the register ring of the widest shapes (one less in flight; 3 measured equal)
 #endif
+#ifndef GNF_BIG_RB2
+#define GNF_BIG_RB2 (2 * GNF_BIG_RBW)  // the same for workgroups of 1 or 2 row tiles (their k-groups are half as long)
+#endif
 
 static inline int pad16(int v) { return (v + 15) & ~15; }
 
@@ -53,7 +56,8 @@ static inline int pad16(int v) { return (v + 15) & ~15; }
 __device__ unsigned long long g_big_trace[2][8][64];
 __device__ unsigned int g_big_hwid[2][8];
 __device__ int g_big_trace_blocks[2] = {0, 256};
-__device__ unsigned long long g_big_span[8192][3];  // per block: start, end, HW_ID | XCC_ID << 16 (wave 0)
+__device__ unsigned long long g_big_span[8192][5];  // per block: start, end (s_memtime: a per-CU clock), HW_ID | XCC_ID << 16 (wave 0),
+                                                    // start, end in s_memrealtime ticks (100 MHz, one clock for the chip)
 #define GNF_BSTAMP(slot)                                                                              \
     do {                                                                                              \
         if (trace_slot >= 0 && (threadIdx.x & 63) == 0) g_big_trace[trace_slot][threadIdx.x >> 6][slot] = __builtin_amdgcn_s_memtime(); \
@@ -336,6 +340,7 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
     if (trace_slot >= 0 && lane == 0) g_big_hwid[trace_slot][wave] = (__builtin_amdgcn_s_getreg(4 | (15 << 11)) & 0xffffu) | (__builtin_amdgcn_s_getreg(20 | (3 << 11)) << 16);  // HW_ID[15:0] | XCC_ID << 16
     if (tid == 0 && blockIdx.x < 8192) {
         g_big_span[blockIdx.x][0] = __builtin_amdgcn_s_memtime();
+        g_big_span[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();
         g_big_span[blockIdx.x][2] = (__builtin_amdgcn_s_getreg(4 | (15 << 11)) & 0xffffu) | (__builtin_amdgcn_s_getreg(20 | (3 << 11)) << 16);
     }
 #endif
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
                     else if (cur.mw > 2)
                         GNF_BIG_RUN(4, GNF_BIG_RBW, kBigMT);
                     else
-                        GNF_BIG_RUN(4, 2 * GNF_BIG_RBW, 2);
+                        GNF_BIG_RUN(4, GNF_BIG_RB2, 2);
                 } else if (cur.nv == 3) {  // (the less common widths: one instance each, to keep the code small)
                     GNF_BIG_RUN(3, GNF_BIG_RBW, kBigMT);
                 } else if (cur.nv == 2) {
@@ -611,7 +616,10 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
     }
     GNF_BSTAMP(63);
 #ifdef GNF_BIG_TRACE
-    if (tid == 0 && blockIdx.x < 8192) g_big_span[blockIdx.x][1] = __builtin_amdgcn_s_memtime();
+    if (tid == 0 && blockIdx.x < 8192) {
+        g_big_span[blockIdx.x][1] = __builtin_amdgcn_s_memtime();
+        g_big_span[blockIdx.x][4] = __builtin_amdgcn_s_memrealtime();
+    }
 #endif
 }
 
@@ -626,7 +634,7 @@ extern "C" int gnf_debug_big_trace(unsigned long long* out, unsigned int* hwid, 
     return (int)hipMemcpyFromSymbol(hwid, HIP_SYMBOL(g_big_hwid), sizeof(unsigned int) * 2 * 8);
 }
 extern "C" int gnf_debug_big_spans(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_span), sizeof(unsigned long long) * 8192 * 3);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_span), sizeof(unsigned long long) * 8192 * 5);
 }
 #endif
 
@@ -659,7 +667,7 @@ bool big_supported(const GnfMlp* s, int32_t H) {
 //     on config 4: more, smaller workgroups pay the per-workgroup weight stream and prologue more often than the even
 //     finish gives back) and an opening of cap-tile + half-tile workgroups (the half-size one, served second, takes as
 //     long as its partner).
-int big_plan(int64_t n_nodes, int cus, int cap, int32_t* seg_n, int32_t* seg_sz) {
+int big_plan(int64_t n_nodes, int cus, int cap, bool no_tail, int32_t* seg_n, int32_t* seg_sz) {
     for (int k = 0; k < 6; ++k) seg_n[k] = 0, seg_sz[k] = 1;
     const int64_t g = (n_nodes + 15) / 16;
     if (g <= (int64_t)cap * 2 * cus) {
@@ -670,6 +678,34 @@ int big_plan(int64_t n_nodes, int cus, int cap, int32_t* seg_n, int32_t* seg_sz)
         if (rem) seg_n[k] = (int32_t)rem, seg_sz[k] = base + 1, ++k;
         seg_n[k] = (int32_t)(w - rem), seg_sz[k] = base;
         return (int)w;
+    }
+    // Larger batches: whole double rounds of cap-tile workgroups (a pair per CU each), then ONE closing round laid out by
+    // what is left per CU (t = left / cus row tiles; workgroups in dispatch order, the larger ones first - a CU's two
+    // slots free half a period apart, so every CU gets one of each run):
+    //     t <= 2        : 1-tile workgroups                        (one or two per CU)
+    //     t <= 3        : 2 cus workgroups of 2 and 1 row tiles
+    //     t <= 4        : cap-tile workgroups, one per CU          (pairs of 2-tile ones measured 3 % slower)
+    //     t <= 6        : cus cap-tile workgroups, then cus of 2 and 1 row tiles beside them
+    //     else          : cap-tile workgroups again (a 3-tile workgroup runs the 4-tile instance)
+    // A closing round of whole cap-tile workgroups handed out one by one would run on a part of the CUs only - for
+    // as long as a full pair where two of them share a CU (config 4, 19 row tiles per CU: 23 % of the CUs idle for the
+    // last quarter of the launch; 520 us with the closing round of 2 + 1 row tiles against 531).  The small workgroups
+    // are not efficient themselves (a 1-tile workgroup streams the same 1.7 MB of weights as a 4-tile one: 115 k
+    // cycles alone, 180 k beside another, against 315 k / 475 k for 4-tile ones) - they only keep every CU busy to the end.
+    const int64_t per_round = (int64_t)cap * 2 * cus;
+    const int64_t full = cap == kBigMT && !no_tail ? g / per_round : 0, left = g - full * per_round;
+    if (full > 0 && left > 0 && (left <= 3 * (int64_t)cus || (left > 4 * (int64_t)cus && left <= 6 * (int64_t)cus))) {
+        int k = 0;
+        int64_t n_wg = full * 2 * cus, rest = left;
+        if (left > 4 * (int64_t)cus) n_wg += cus, rest -= 4 * (int64_t)cus;   // one more cap-tile workgroup per CU
+        seg_n[k] = (int32_t)n_wg, seg_sz[k] = cap, ++k;
+        const int64_t slots = left > 4 * (int64_t)cus ? cus : 2 * (int64_t)cus;
+        const int64_t w = rest < slots ? rest : slots;
+        const int base = (int)(rest / w);
+        const int64_t rem = rest % w;
+        if (rem) seg_n[k] = (int32_t)rem, seg_sz[k] = base + 1, ++k;
+        seg_n[k] = (int32_t)(w - rem), seg_sz[k] = base;
+        return (int)(n_wg + w);
     }
     seg_n[0] = (int32_t)((g + cap - 1) / cap);
     seg_sz[0] = cap;
@@ -689,7 +725,7 @@ int big_cu_count() {
 }
 
 int launch_half_big(FusedArgs& a, int64_t n_nodes, int cap, hipStream_t st, int* n_wg_out) {
-    const int n_wg = big_plan(n_nodes, big_cu_count(), cap, a.big_seg_n, a.big_seg_sz);
+    const int n_wg = big_plan(n_nodes, big_cu_count(), cap, (a.variant & 64) != 0, a.big_seg_n, a.big_seg_sz);
     a.n_tiles = n_wg;
     const size_t lds = big_lds_bytes(a.bias_tot);  // <= 66.7 KB + 2 * 8 * 256 * 4: two workgroups per CU
     GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_big),

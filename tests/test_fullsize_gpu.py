@@ -66,13 +66,14 @@ def _graph_rows(nn):
     return off
 
 
-def _bench_batch(workload="config2"):
-    """Exactly bench.py's batch, weights and features of a workload (config 2: N = 2718, E = 32202)."""
+def _bench_batch(workload="config2", graphs=0):
+    """Exactly bench.py's batch, weights and features of a workload (config 2: N = 2718, E = 32202); `graphs` overrides
+    the workload's graphs per GPU (bench.py --graphs-per-gpu)."""
     import bench
     saved = (bench.WORKLOAD, bench.GRAPHS_PER_GPU, dict(bench.HP))
     try:
         bench.WORKLOAD = bench.WORKLOADS[workload]
-        bench.GRAPHS_PER_GPU = bench.WORKLOAD["graphs"]
+        bench.GRAPHS_PER_GPU = graphs or bench.WORKLOAD["graphs"]
         bench.HP.update(bench.WORKLOAD["hp"])
         dicts, n, e = bench.make_batch(1, 0)
         hp = dict(bench.HP)
@@ -393,3 +394,35 @@ def test_config4_256_graphs_inverse_worst_graphs_vs_oracle():
         rt32 = float((o32.f(x32, p32, hp["T"])[0] - o32.to_t(zs)).abs().max())
         assert per_graph[gi] <= SLACK * rt32 + FLOOR, (gi, per_graph[gi], rt32)
     assert per_graph.max() <= 5e-5
+
+
+@pytest.mark.parametrize("graphs,closing", [(112, "1-tile workgroups"), (144, "2 + 1 row tiles"), (160, "one 4-tile workgroup per CU"),
+                                            (176, "4-tile + 2 / 1 row tiles"), (224, "two double rounds + 1-tile workgroups")])
+def test_config4_closing_rounds_of_the_large_batch_kernel_bitwise_vs_32_row_shape(graphs, closing):
+    """The large-batch kernel's launch plan (gnf_fused_big.hip, big_plan): whole double rounds of 4-tile workgroups, then a
+    closing round whose layout depends on the row tiles left per CU.  Config-4 batches that land in each layout: the
+    forward pass and the inverse pass must equal the 32-row both-nets shape BITWISE (every row tile handled exactly once,
+    by the instance its workgroup's size selects), the log-det sums up to their summation order, and the round trip closes."""
+    from gnf_amd import _abi
+    g_cpu, p, hp = _bench_batch("config4", graphs)
+    nn = g_cpu.n_node.numpy()
+    n = int(nn.sum())
+    tiles, cus = (n + 15) // 16, torch.cuda.get_device_properties(0).multi_processor_count
+    assert tiles > 8 * cus, "these batches are meant to need more than one double round"
+    net = make_product_grevnet(hp, p)
+    graph = graph_from_arrays(nn, g_cpu.n_edge.numpy(), g_cpu.senders.numpy(), g_cpu.receivers.numpy(), g_cpu.nodes.numpy(), DEV)
+    try:
+        _abi.set_option("force_shape", 22)
+        z_ref, ld_ref = net(graph, inverse=True)
+        x_ref = net(graph, inverse=False)
+        _abi.set_option("force_shape", 40)
+        z, ld = net(graph, inverse=True)
+        x = net(graph, inverse=False)
+        back = net(z, inverse=False)
+    finally:
+        _abi.set_option("force_shape", 0)
+    torch.cuda.synchronize()
+    assert torch.equal(z.nodes, z_ref.nodes), closing
+    assert torch.equal(x.nodes, x_ref.nodes), closing
+    assert abs(float(ld) - float(ld_ref)) <= 1e-9 * max(1.0, abs(float(ld_ref)))
+    assert float((back.nodes - graph.nodes).abs().max()) <= 5e-5

@@ -80,48 +80,41 @@ for sl in sorted(names):
     nw = int((t[0, :, 0] > 0).sum())
     print(f"{names[sl]:14s} " + " ".join(f"{int(t[0, w, sl] - t0):7d}" for w in range(nw)) + "  |  " + " ".join(f"{int(t[1, w, sl] - t0):7d}" for w in range(nw)))
 
-# ---- every workgroup's span: durations by dispatch round, concurrency per CU ----
-sp = (C.c_ulonglong * (8192 * 3))()
+# ---- every workgroup's span.  s_memtime is a PER-CU clock (offsets between CUs are arbitrary): durations and per-CU
+# timelines come from it; the launch's ramp and drain across CUs from s_memrealtime (100 MHz, one clock for the chip) ----
+sp = (C.c_ulonglong * (8192 * 5))()
 if hasattr(raw, "gnf_debug_big_spans") and raw.gnf_debug_big_spans(sp) == 0:
-    a = np.array(list(sp), dtype=np.int64).reshape(8192, 3)
+    a = np.array(list(sp), dtype=np.int64).reshape(8192, 5)
     nblk = int((a[:, 1] > 0).sum())          # (the array is zero before the first launch of this process)
     a = a[:nblk]
-    # s_memtime is per XCC: align each XCC to its own first start
-    xcc = a[:, 2] >> 16
-    cu = ((a[:, 2] >> 8) & 15) | (((a[:, 2] >> 13) & 7) << 4) | (xcc << 8)
-    st_ = a[:, 0].copy()
-    en = a[:, 1].copy()
-    for x in np.unique(xcc):
-        m = xcc == x
-        base = st_[m].min()
-        st_[m] -= base
-        en[m] -= base
-    dur = en - st_
+    if os.environ.get("GNF_SPANS_OUT"):
+        np.save(os.environ["GNF_SPANS_OUT"], a)
+    hw = a[:, 2] & 0xffff
+    cu = (hw >> 8) & 15 | (((hw >> 13) & 7) << 4) | ((a[:, 2] >> 16) << 8)
+    dur = a[:, 1] - a[:, 0]
+    r0 = a[:, 3].min()
+    rs, re = (a[:, 3] - r0) * 10, (a[:, 4] - r0) * 10   # ns since the first workgroup's start
+    print(f"# {nblk} workgroups on {len(np.unique(cu))} CUs; launch span {re.max() / 1e3:.1f} us (first start to last end, s_memrealtime)")
+    first = np.argsort(rs)[:min(nblk, 2 * len(np.unique(cu)))]
+    print(f"#   ramp: the first {len(first)} workgroups start within {rs[first].max() / 1e3:.2f} us (median {np.median(rs[first]) / 1e3:.2f}); "
+          f"last end per CU: min {min(re[cu == c].max() for c in np.unique(cu)) / 1e3:.1f} us, median {np.median([re[cu == c].max() for c in np.unique(cu)]) / 1e3:.1f}, max {re.max() / 1e3:.1f}")
     for lo in range(0, nblk, 256):
         part = slice(lo, min(nblk, lo + 256))
-        print(f"#   blocks {lo:5d}..{min(nblk, lo + 256) - 1:5d}: start mean {st_[part].mean():9.0f}  duration mean {dur[part].mean():9.0f} min {dur[part].min():8d} max {dur[part].max():8d}")
-    print(f"# {nblk} workgroups on {len(np.unique(cu))} CUs; kernel span (max end over XCCs) {en.max()} cycles; workgroup duration mean {dur.mean():.0f} min {dur.min()} max {dur.max()}")
-    order = np.argsort(st_)
-    q = np.array_split(order, 10)
-    print("# by start time decile: start range, mean duration")
-    for part in q:
-        print(f"   start {st_[part].min():8d} .. {st_[part].max():8d}   dur mean {dur[part].mean():9.0f}  min {dur[part].min():8d} max {dur[part].max():8d}")
-    # per-CU: busy time with 1 and 2 resident workgroups
-    tot1 = tot2 = 0
-    ends = []
+        print(f"#   blocks {lo:5d}..{min(nblk, lo + 256) - 1:5d}: start {rs[part].mean() / 1e3:7.1f} us (min {rs[part].min() / 1e3:7.1f} max {rs[part].max() / 1e3:7.1f})  "
+              f"duration mean {dur[part].mean():9.0f} cycles (min {dur[part].min()} max {dur[part].max()}) = {(re[part] - rs[part]).mean() / 1e3:.1f} us")
+    one = two = 0
     for c in np.unique(cu):
         m = cu == c
-        ev = sorted([(t_, 1) for t_ in st_[m]] + [(t_, -1) for t_ in en[m]])
+        ev = sorted([(t_, 1) for t_ in a[m, 0]] + [(t_, -1) for t_ in a[m, 1]])
         lvl, last = 0, 0
         for t_, d in ev:
             if lvl == 1:
-                tot1 += t_ - last
+                one += t_ - last
             elif lvl >= 2:
-                tot2 += t_ - last
+                two += t_ - last
             lvl += d
             last = t_
-        ends.append(en[m].max())
-    ends = np.array(ends)
-    print(f"# per CU: cycles with one resident workgroup {tot1 / len(ends):.0f}, with two {tot2 / len(ends):.0f}; last end per CU min {ends.min()} mean {ends.mean():.0f} max {ends.max()}")
+    ncu = len(np.unique(cu))
     cnt = np.bincount(np.unique(cu, return_inverse=True)[1])
-    print(f"# workgroups per CU: min {cnt.min()} max {cnt.max()}")
+    print(f"# per CU: cycles with one resident workgroup {one / ncu:.0f}, with two {two / ncu:.0f}; workgroups per CU min {cnt.min()} max {cnt.max()}")
+    print(f"# clock: {dur.sum() / ((re - rs).sum() / 1e3):.0f} cycles per us")
