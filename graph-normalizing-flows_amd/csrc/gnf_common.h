@@ -122,7 +122,7 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st);
 struct FusedArgs;
 bool big_supported(const GnfMlp* s, int32_t H);
 int big_cu_count();  // multiProcessorCount of the current device (cached per device)
-int big_plan(int64_t n_nodes, int cus, int cap, bool no_tail, int32_t* seg_n, int32_t* seg_sz);  // -> workgroups; runs of (count, row tiles)
+int big_plan(int64_t n_nodes, int cus, int cap, int variant, int32_t* seg_n, int32_t* seg_sz);  // -> workgroups; runs of (count, row tiles)
 int launch_half_big(FusedArgs& a, int64_t n_nodes, int cap, hipStream_t st, int* n_wg_out);
 // coupling epilogue from global s / t [N, H] buffers (writes hs.partials, *hs.n_partials)
 int launch_coupling(const float* s, const float* t, const HalfStep& hs, const float* xres, hipStream_t st);

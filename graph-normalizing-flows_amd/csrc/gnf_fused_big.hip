@@ -17,9 +17,10 @@
 //     no spills (a first 8-wave / 128-register form spilled 70-90 registers per layer: 880 MB of scratch traffic per launch);
 //   * how many row tiles a workgroup gets is a RUN-TIME value (big_plan): a batch of up to one pass of the chip is dealt
 //     out evenly over 2 x CUs workgroups so that the launch ends everywhere at once instead of rounding up to whole
-//     64-row tiles per CU; larger batches run whole 4-tile workgroups.  The MFMAs of a k-group run row tile by row
-//     tile; absent row tiles are skipped behind wave-uniform branches at the row-tile boundaries, and workgroups of 1 or
-//     2 row tiles take an instance with a twice-as-deep weight ring in the same registers;
+//     64-row tiles per CU; larger batches run whole double rounds of 4-tile workgroups and a closing round dealt out the
+//     same way.  The MFMAs of a k-group run row tile by row
+//     tile; 4- and 3-tile workgroups have an instance each without row-tile branches, workgroups of 1 or 2 row tiles
+//     take one with a twice-as-deep weight ring in the same registers;
 //   * s stays in the accumulator registers while the t-net runs; then s | t go side by side into the (now free)
 //     activation buffer and ONE compact loop does the coupling update x*exp(s)+t | (x-t)*exp(-s) with 16-byte row
 //     accesses and the fp64 partials of sum(s), sum(x_new^2);
@@ -154,7 +155,7 @@ __device__ __forceinline__ void big_layer_end(float* __restrict__ act, const BCh
 // k_half_fused's order: bitwise the same sums.  The issue order is pinned the same way (sched_group_barrier): loads sit
 // behind MFMAs, never bunched in front of them.  Row tiles >= c.mw are skipped (wave-uniform branches between the row
 // tiles' MFMA blocks).
-// MW = 4 | 2: the row tiles the instance holds accumulators for.  A workgroup of 1 or 2 row tiles takes the MW = 2 instance,
+// MW = 4 | 3 | 2: the row tiles the instance holds accumulators for.  A workgroup of 1 or 2 row tiles takes the MW = 2 instance,
 // whose B ring is twice as deep in the same registers: its k-groups are half as long, and the weight fragments have to be
 // requested the same TIME ahead (a lone 1-tile workgroup with one k-group in flight ran 925 cycles per 512-cycle k-group:
 // the L2 round trip; a 2-tile workgroup beside a 4-tile one took as long as its partner).
@@ -484,8 +485,9 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
                     if (cur.mw == kBigMT)  // (the shape almost all of a large batch's work runs in: no row-tile branches)
                         big_chunk<4, GNF_BIG_RBW, kBigMT, true>(act, cur, nx, pre_next, lane, b_nx, last, slope_hidden, s_keep,
                                                                 net == 1, hp);
-                    else if (cur.mw > 2)
-                        GNF_BIG_RUN(4, GNF_BIG_RBW, kBigMT);
+                    else if (cur.mw == 3)  // (its own instance: a 3-tile workgroup in the 4-tile one took a 4-tile workgroup's time)
+                        big_chunk<4, GNF_BIG_RBW, 3, true>(act, cur, nx, pre_next, lane, b_nx, last, slope_hidden, s_keep,
+                                                           net == 1, hp);
                     else
                         GNF_BIG_RUN(4, GNF_BIG_RB2, 2);
                 } else if (cur.nv == 3) {  // (the less common widths: one instance each, to keep the code small)
@@ -524,6 +526,7 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
     // ---- C: coupling update from the s | t rows in LDS, rows of x coalesced (16 bytes per lane where the widths allow,
     // four requests per thread before the first use); this lane's fp64 shares of sum(s) and sum(x_new^2) ----
     __syncthreads();
+    GNF_BSTAMP(60);
     double local = 0.0, local2 = 0.0;
     {
         auto one = [&](float xv, float xr, float sv, float tv, float& xn) {
@@ -596,6 +599,7 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
             }
         }
     }
+    GNF_BSTAMP(61);
     for (int off = 32; off > 0; off >>= 1) {
         local += __shfl_down(local, off, 64);
         local2 += __shfl_down(local2, off, 64);
@@ -660,14 +664,13 @@ bool big_supported(const GnfMlp* s, int32_t H) {
 //   * up to one pass of the chip (g <= cap * 2 * cus granules): an even deal over 2 * cus workgroups, sizes differing by
 //     one row tile, the larger ones first - every CU slot gets one workgroup and the launch ends everywhere at once
 //     (20 k nodes at the config-4 widths: 149 us against 177 for the 32-row both-nets shape, 214 for whole 64-row tiles);
-//   * more than that: whole cap-tile workgroups (the last one's rows clamped).  The dispatcher hands a new workgroup to
-//     whichever slot frees first, and the SIMD arbiter serves the OLDER of a CU's two workgroups first: the older one runs
-//     at its own pace, the younger fills its gaps and becomes the older one in turn - pairs drift out of phase by
-//     themselves.  Measured and dropped (tools/ab_shapes.sh): an even deal over whole rounds (642 vs 555 us
-//     on config 4: more, smaller workgroups pay the per-workgroup weight stream and prologue more often than the even
-//     finish gives back) and an opening of cap-tile + half-tile workgroups (the half-size one, served second, takes as
-//     long as its partner).
-int big_plan(int64_t n_nodes, int cus, int cap, bool no_tail, int32_t* seg_n, int32_t* seg_sz) {
+//   * more than that: whole double rounds of cap-tile workgroups and a closing round (below).  The dispatcher hands a
+//     new workgroup to whichever slot frees first, and the SIMD arbiter serves the OLDER of a CU's two workgroups first:
+//     the older one runs at its own pace, the younger fills its gaps and becomes the older one in turn - pairs drift out
+//     of phase by themselves.  Measured and dropped (tools/ab_shapes.sh, CHANGELOG.md): an even deal over ALL rounds
+//     (642 vs 555 us on config 4 while 3-tile workgroups still ran the 4-tile instance) and an opening of cap-tile +
+//     half-tile workgroups (the half-size one, served second, takes as long as its partner).
+int big_plan(int64_t n_nodes, int cus, int cap, int variant, int32_t* seg_n, int32_t* seg_sz) {
     for (int k = 0; k < 6; ++k) seg_n[k] = 0, seg_sz[k] = 1;
     const int64_t g = (n_nodes + 15) / 16;
     if (g <= (int64_t)cap * 2 * cus) {
@@ -680,32 +683,28 @@ int big_plan(int64_t n_nodes, int cus, int cap, bool no_tail, int32_t* seg_n, in
         return (int)w;
     }
     // Larger batches: whole double rounds of cap-tile workgroups (a pair per CU each), then ONE closing round laid out by
-    // what is left per CU (t = left / cus row tiles; workgroups in dispatch order, the larger ones first - a CU's two
-    // slots free half a period apart, so every CU gets one of each run):
-    //     t <= 2        : 1-tile workgroups                        (one or two per CU)
-    //     t <= 3        : 2 cus workgroups of 2 and 1 row tiles
+    // what is left per CU (t = left / cus row tiles; the larger workgroups first in dispatch order - a CU's two slots
+    // free half a period apart, so every CU gets one of each size):
+    //     t <= 3        : an even deal over 2 cus workgroups (1-tile workgroups only when t <= 2, else 2 and 1 row tiles)
     //     t <= 4        : cap-tile workgroups, one per CU          (pairs of 2-tile ones measured 3 % slower)
-    //     t <= 6        : cus cap-tile workgroups, then cus of 2 and 1 row tiles beside them
-    //     else          : cap-tile workgroups again (a 3-tile workgroup runs the 4-tile instance)
+    //     else          : an even deal over 2 cus workgroups: 3 + 2, 3 + 3, 4 + 3 row tiles per CU
     // A closing round of whole cap-tile workgroups handed out one by one would run on a part of the CUs only - for
     // as long as a full pair where two of them share a CU (config 4, 19 row tiles per CU: 23 % of the CUs idle for the
-    // last quarter of the launch; 520 us with the closing round of 2 + 1 row tiles against 531).  The small workgroups
-    // are not efficient themselves (a 1-tile workgroup streams the same 1.7 MB of weights as a 4-tile one: 115 k
-    // cycles alone, 180 k beside another, against 315 k / 475 k for 4-tile ones) - they only keep every CU busy to the end.
+    // last quarter of the launch; 520 us with the closing round of 2 + 1 row tiles against 531; 34 k nodes 259 us
+    // against 326).  The small workgroups are not efficient themselves (a 1-tile workgroup streams the same 1.7 MB of
+    // weights as a 4-tile one, and a CU takes them at 15 - 20 bytes per clock whatever the depth of the register ring:
+    // 115 k cycles alone, 180 k beside another, against 315 k / 475 k for 4-tile ones) - they keep every CU busy to the end.
     const int64_t per_round = (int64_t)cap * 2 * cus;
-    const int64_t full = cap == kBigMT && !no_tail ? g / per_round : 0, left = g - full * per_round;
-    if (full > 0 && left > 0 && (left <= 3 * (int64_t)cus || (left > 4 * (int64_t)cus && left <= 6 * (int64_t)cus))) {
+    const int64_t full = cap == kBigMT && !(variant & 64) ? g / per_round : 0, left = g - full * per_round;
+    if (full > 0 && left > 0 && (left <= 3 * (int64_t)cus || left > 4 * (int64_t)cus)) {
         int k = 0;
-        int64_t n_wg = full * 2 * cus, rest = left;
-        if (left > 4 * (int64_t)cus) n_wg += cus, rest -= 4 * (int64_t)cus;   // one more cap-tile workgroup per CU
-        seg_n[k] = (int32_t)n_wg, seg_sz[k] = cap, ++k;
-        const int64_t slots = left > 4 * (int64_t)cus ? cus : 2 * (int64_t)cus;
-        const int64_t w = rest < slots ? rest : slots;
-        const int base = (int)(rest / w);
-        const int64_t rem = rest % w;
+        seg_n[k] = (int32_t)(full * 2 * cus), seg_sz[k] = cap, ++k;
+        const int64_t w = left < 2 * (int64_t)cus ? left : 2 * (int64_t)cus;
+        const int base = (int)(left / w);
+        const int64_t rem = left % w;
         if (rem) seg_n[k] = (int32_t)rem, seg_sz[k] = base + 1, ++k;
         seg_n[k] = (int32_t)(w - rem), seg_sz[k] = base;
-        return (int)(n_wg + w);
+        return (int)(full * 2 * cus + w);
     }
     seg_n[0] = (int32_t)((g + cap - 1) / cap);
     seg_sz[0] = cap;
@@ -725,7 +724,7 @@ int big_cu_count() {
 }
 
 int launch_half_big(FusedArgs& a, int64_t n_nodes, int cap, hipStream_t st, int* n_wg_out) {
-    const int n_wg = big_plan(n_nodes, big_cu_count(), cap, (a.variant & 64) != 0, a.big_seg_n, a.big_seg_sz);
+    const int n_wg = big_plan(n_nodes, big_cu_count(), cap, a.variant, a.big_seg_n, a.big_seg_sz);
     a.n_tiles = n_wg;
     const size_t lds = big_lds_bytes(a.bias_tot);  // <= 66.7 KB + 2 * 8 * 256 * 4: two workgroups per CU
     GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_big),

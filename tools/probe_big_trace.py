@@ -72,6 +72,8 @@ for net_ in range(2):
         names[base + 3] = tag + " wr issued"
         names[base + 4] = tag + " drained"
         names[base + 5] = tag + " bar B"
+names[60] = "coupling top"
+names[61] = "coupling done"
 names[63] = "end"
 print("s_memtime ticks (100 MHz: 10 ns per tick) relative to the first traced wave's start; columns = waves 0..7 of block slot 0, then slot 1")
 for sl in sorted(names):
