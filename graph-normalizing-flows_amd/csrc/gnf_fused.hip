@@ -134,17 +134,28 @@ __device__ int g_trace_layer = 1;
 
 }  // namespace gnf
 #include "gnf_fused_dev.h"
+#include "gnf_attn_front_dev.h"
 namespace gnf {
 
-template <int MT, int NETS, bool STASH = false>
-__global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a) {
+// FRONT (MT = 1, NETS = 2, attention GNNs on sparse batches): the attention front-end (gnf_attn_front_dev.h) runs as this
+// kernel's prologue and leaves the layer-0 input rows of both nets in the activation buffers - no launch boundary, no
+// trip of those rows through global memory.  Its staging area (x rows, q | v of the sender window: 149 KB at the
+// reference's head geometry) ALIASES the activation buffers; bias / reduction scratch / layer table sit behind it.
+template <int MT, int NETS, bool STASH = false, bool FRONT = false>
+__global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a, const FrontArgs fa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    static_assert(!FRONT || (MT == 1 && NETS == 2 && !STASH), "the attention prologue exists for the 16-row both-nets shape");
     constexpr int TM = 16 * MT;
     constexpr int WPN = 8 / NETS;  // waves per net
     const int LS = a.LS;
     // [net][pingpong][TM][LS] | bias [NETS][bias_tot] | reduction scratch
     auto buf = [&](int net_, int pp_) -> float* { return smem + (2 * net_ + pp_) * TM * LS; };
-    float* bias_lds = smem + 2 * NETS * TM * LS;
+    int base_floats = 2 * NETS * TM * LS;
+    if constexpr (FRONT) {
+        const int ft = front_lds(fa.d).total;
+        base_floats = ft > base_floats ? ft : base_floats;
+    }
+    float* bias_lds = smem + base_floats;
     double* red = reinterpret_cast<double*>(bias_lds + NETS * a.bias_tot + ((NETS * a.bias_tot) & 1));
 
     // blockIdx -> (tile, net).  Block b is dispatched to XCD b % 8.
@@ -252,14 +263,54 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
     // only in the LAST layer (a hidden layer's epilogue there also leaves the act' ballots, which the thin form does not do).
     // The prefetch of a chunk packs its registers for the form that will consume it: both sides ask thin_for(layer).
     auto thin_for = [&](int layer) { return MT == 1 && !(a.variant & 1) && (!STASH || layer == a.K - 1); };
+    int* s_rowptr = tab + GNF_MAX_LAYERS * 8;
+    int* s_col = s_rowptr + kRowptrPad;
+    [[maybe_unused]] unsigned long long* fmask = reinterpret_cast<unsigned long long*>(s_col + kColCap);  // STASH only
+    if constexpr (FRONT) {
+        // ---- attention prologue: the layer table first (its words sit behind the front-end's staging area), then the
+        // front-end over this tile's 16 receiver rows; the first chunk's weights and the biases are requested between its
+        // last barrier and its output projection, and the biases reach LDS behind it ------------------------------------
+        for (int j = 0; j < a.K; ++j) {
+            if (tid == 0) {
+                const unsigned long long p0 = reinterpret_cast<unsigned long long>(a.wp[0][j]);
+                const unsigned long long p1 = reinterpret_cast<unsigned long long>(a.wp[1][j]);
+                int* row = tab + 8 * j;
+                row[0] = a.ipg[j];
+                row[1] = a.ont[j];
+                row[2] = a.boff[j];
+                row[3] = 0;
+                row[4] = (int)(unsigned)p0;
+                row[5] = (int)(unsigned)(p0 >> 32);
+                row[6] = (int)(unsigned)p1;
+                row[7] = (int)(unsigned)(p1 >> 32);
+            }
+        }
+        constexpr int kBiasRegsF = 8;
+        const int bias_all_f = NETS * a.bias_tot;
+        float breg_f[kBiasRegsF];
+        attn_front_tile<true, 10, 10, 4, true, true>(fa, smem, row0, buf(0, 0), buf(1, 0), LS, [&] {
+            prefetch_chunk(cur, WPN, voff, b_pre, thin_for(cur.layer));
+#pragma unroll
+            for (int q = 0; q < kBiasRegsF; ++q) {
+                const int i = tid + q * kFusedThreads;
+                const int ic = i < bias_all_f ? i : 0;
+                breg_f[q] = ic < a.bias_tot ? a.bias[0][ic] : a.bias[1][ic - a.bias_tot];
+            }
+        });
+#pragma unroll
+        for (int q = 0; q < kBiasRegsF; ++q) {
+            const int i = tid + q * kFusedThreads;
+            if (i < bias_all_f) bias_lds[i] = breg_f[q];
+        }
+        for (int i = tid + kBiasRegsF * kFusedThreads; i < bias_all_f; i += kFusedThreads)
+            bias_lds[i] = i < a.bias_tot ? a.bias[0][i] : a.bias[1][i - a.bias_tot];
+        __syncthreads();
+    } else {
     prefetch_chunk(cur, WPN, voff, b_pre, thin_for(cur.layer));
     GNF_PSTAMP(0);
     // ---- every independent global read of the prologue is ISSUED before any is consumed: rowptr of
     // the tile, the biases (<= 8 floats per thread in registers), the layer table - one memory round
     // trip instead of three back-to-back ones ----------------------------------------------------------
-    int* s_rowptr = tab + GNF_MAX_LAYERS * 8;
-    int* s_col = s_rowptr + kRowptrPad;
-    [[maybe_unused]] unsigned long long* fmask = reinterpret_cast<unsigned long long*>(s_col + kColCap);  // STASH only
     int rp_reg = 0;
     if (tid <= TM) {
         const int r = row0 + tid;
@@ -337,6 +388,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a)
     GNF_STAMP(1);
     __syncthreads();
     GNF_STAMP(2);
+    }  // !FRONT
 
     // ---- B: K layers ------------------------------------------------------------------------------
     int pp = 0;
@@ -589,13 +641,58 @@ static int choose_big(const HalfStep& hs) {
     return big_q < old_q ? 4 : 0;
 }
 
-template <int MT, int NETS, bool STASH = false>
-static int launch_shape(const FusedArgs& a, unsigned grid, size_t lds, hipStream_t st) {
-    GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_fused<MT, NETS, STASH>),
+template <int MT, int NETS, bool STASH = false, bool FRONT = false>
+static int launch_shape(const FusedArgs& a, unsigned grid, size_t lds, hipStream_t st, const FrontArgs* fa = nullptr) {
+    GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_fused<MT, NETS, STASH, FRONT>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit)));
-    hipLaunchKernelGGL((k_half_fused<MT, NETS, STASH>), dim3(grid), dim3(kFusedThreads), lds, st, a);
+    FrontArgs none;
+    memset(&none, 0, sizeof(none));
+    hipLaunchKernelGGL((k_half_fused<MT, NETS, STASH, FRONT>), dim3(grid), dim3(kFusedThreads), lds, st, a, fa ? *fa : none);
     GNF_LAUNCH_CHECK("k_half_fused");
     return GNF_OK;
+}
+
+// LDS of the attention instance: the front-end's staging area (or the activation buffers, whichever is larger), then
+// bias | reduction scratch | layer table (no rowptr / col slices of its own: the front-end has them in its area)
+static size_t fused_front_lds_bytes(const GnfMlp* m, const FrontDims& d) {
+    const int LS = max_padded_width(m) + 4;
+    const size_t act = (size_t)2 * 2 * 16 * LS, fr = (size_t)front_lds(d).total;
+    return ((act > fr ? act : fr) + 2 * (size_t)bias_total(m) + 2) * sizeof(float) + 8 * sizeof(double) + (GNF_MAX_LAYERS * 8) * sizeof(int);
+}
+
+// May the attention front-end run as the fused kernel's prologue (k_half_fused<1, 2, false, true>)?  The sparse-batch
+// front-end with the reference's head geometry (its register-resident instance), inference only (the training forward
+// keeps q | k | v, the attended values and h0 in the stash), widths that need no zero padding in the layer-0 rows, and
+// the two areas in 160 KB.  gnf_set_option("fused_variant", 4) keeps the two launches (A/B).
+static bool front_fold_ok(const HalfStep& hs, FrontArgs* fa) {
+    const GnfMlp *s = hs.s_net, *t = hs.t_net;
+    const GnfAttn *a0 = s->attn, *a1 = t->attn;
+    if (!a0 || !a1 || hs.attn_region || hs.mlp_stash || (opt(OPT_FUSED_VARIANT) & 4)) return false;
+    if (!hs.attn_packed[0] || !hs.attn_packed[1]) return false;
+    if (!(hs.n_edges > 0 && hs.n_edges < 24 * hs.n_nodes) || !attn_front_fused_ok(a0, hs.H)) return false;
+    if (a1->num_heads != a0->num_heads || a1->kq_dim != a0->kq_dim || a1->v_dim != a0->v_dim || a1->out_dim != a0->out_dim ||
+        a1->concat != a0->concat || a1->kq_dim_division != a0->kq_dim_division)
+        return false;  // (launch_attn_front reports it)
+    if (a0->layer_norm || opt(OPT_ATTN_EDGE_TILED) || opt(OPT_ATTN_ROWS)) return false;
+    const FrontDims d = front_dims(hs.H, a0->num_heads, a0->kq_dim, a0->v_dim, a0->out_dim);
+    if (!((d.PW >> 4) <= 6 && (d.Hp >> 4) <= 2 && d.kq == 10 && d.vd == 10)) return false;
+    const int in0 = s->dims[0];
+    if ((d.C & 15) || (a0->concat && (hs.H & 15)) || (in0 & 15) || in0 != (a0->concat ? hs.H : 0) + d.C) return false;
+    if (fused_front_lds_bytes(s, d) > (size_t)kLdsLimit) return false;
+    for (int q = 0; q < 2; ++q) {
+        fa->packed[q] = hs.attn_packed[q];
+        fa->qkv[q] = nullptr;
+        fa->h0[q] = nullptr;
+        fa->agg_out[q] = nullptr;
+        fa->mz_out[q] = nullptr;
+    }
+    fa->rowptr = hs.rowptr, fa->col = hs.col, fa->x = hs.x_cond, fa->ldx = hs.ld;
+    fa->n_nodes = (int32_t)hs.n_nodes;
+    fa->concat = a0->concat ? 1 : 0;
+    fa->in0 = in0;
+    fa->d = d;
+    fa->scale = a0->kq_dim_division ? 1.f / sqrtf((float)a0->kq_dim) : 1.f;
+    return true;
 }
 
 // One half-step's slot of GnfFlow.mlp_stash (float offsets, every region 256-byte aligned)
@@ -661,12 +758,17 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
     a.stash_ld = 0;
     a.stash_mask = nullptr;
     a.stash_mld = 0;
+    FrontArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    const bool fold = s->attn && MT == 1 && NETS == 2 && !choose_big(hs) && front_fold_ok(hs, &fa);
     if (s->attn) {
-        float* h0_pair[2];
-        const int rc0 = launch_attn_pair(hs, scratch, h0_pair, st);
-        if (rc0) return rc0;
-        a.h0[0] = h0_pair[0];
-        a.h0[1] = h0_pair[1];
+        if (!fold) {
+            float* h0_pair[2];
+            const int rc0 = launch_attn_pair(hs, scratch, h0_pair, st);
+            if (rc0) return rc0;
+            a.h0[0] = h0_pair[0];
+            a.h0[1] = h0_pair[1];
+        }
         a.residual = s->attn->residual ? 1 : 0;
     }
     int64_t off = 0;
@@ -745,7 +847,10 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
         return GNF_OK;
     }
     if (NETS == 2) {
-        rc = MT == 2 ? launch_shape<2, 2>(a, (unsigned)tiles, lds, st) : launch_shape<1, 2>(a, (unsigned)tiles, lds, st);
+        if (fold)
+            rc = launch_shape<1, 2, false, true>(a, (unsigned)tiles, fused_front_lds_bytes(s, fa.d), st, &fa);
+        else
+            rc = MT == 2 ? launch_shape<2, 2>(a, (unsigned)tiles, lds, st) : launch_shape<1, 2>(a, (unsigned)tiles, lds, st);
         if (rc) return rc;
         *hs.n_partials = (int32_t)tiles;
         if (hs.n_sq) *hs.n_sq = a.sq_partials ? (int32_t)tiles : 0;
