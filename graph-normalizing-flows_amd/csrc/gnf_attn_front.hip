@@ -99,11 +99,13 @@ int launch_attn_pack(const GnfAttn* const* at, int count, int32_t H, float* out,
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-template <bool HOIST, int KQM, int VDM, int EU, bool EXACT>
+template <bool HOIST, int KQM, int VDM, int EU, bool EXACT, bool FIXED = false>
 __global__ __launch_bounds__(kFrThreads) void k_attn_front(const FrontArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    attn_front_tile<HOIST, KQM, VDM, EU, EXACT, false>(a, lds, (int)blockIdx.x * kFrRows, nullptr, nullptr, 0, [] {});
+    attn_front_tile<HOIST, KQM, VDM, EU, EXACT, false, FIXED>(a, lds, (int)blockIdx.x * kFrRows, nullptr, nullptr, 0, [] {});
 }
+
+bool attn_front_fixed_geometry(const FrontDims& d) { return d.H == 32 && d.nh == 8 && d.kq == 10 && d.vd == 10 && d.C == 80; }
 
 // does the one-launch front-end handle this head geometry? (else: the two-launch kernels)
 bool attn_front_fused_ok(const GnfAttn* at, int32_t H) {
@@ -138,7 +140,11 @@ int launch_attn_front_fused(const int32_t* rowptr, const int32_t* col, int64_t n
     a.scale = a0->kq_dim_division ? 1.f / sqrtf((float)a0->kq_dim) : 1.f;
     const dim3 grid((unsigned)((n + kFrRows - 1) / kFrRows));
     const bool hoist = (a.d.PW >> 4) <= 6 && (a.d.Hp >> 4) <= 2;
-    if (hoist && a.d.kq == 10 && a.d.vd == 10) {  // the reference's head geometry (run_grevnet.py:74-76) at H <= 32
+    if (attn_front_fixed_geometry(a.d)) {  // the drivers' defaults at D = 64: every width a compile-time constant
+        GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_front<true, 10, 10, 4, true, true>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+        hipLaunchKernelGGL((k_attn_front<true, 10, 10, 4, true, true>), grid, dim3(kFrThreads), lds_bytes, st, a);
+    } else if (hoist && a.d.kq == 10 && a.d.vd == 10) {  // the reference's head geometry (run_grevnet.py:74-76) at H <= 32
         GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_front<true, 10, 10, 4, true>),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
         hipLaunchKernelGGL((k_attn_front<true, 10, 10, 4, true>), grid, dim3(kFrThreads), lds_bytes, st, a);

@@ -28,6 +28,7 @@ static __host__ __device__ inline FrontDims front_dims(int H, int nh, int kq, in
     d.PW = d.nqp + d.vdp;
     return d;
 }
+bool attn_front_fixed_geometry(const FrontDims& d);  // gnf_attn_front.hip: is this the geometry the FIXED instances are compiled for?
 static __host__ __device__ inline size_t front_pack_floats(const FrontDims& d) {
     return (size_t)d.Hp * d.PW + (size_t)d.Hp * d.nqp + (size_t)d.NVp * d.Cp;
 }
@@ -78,6 +79,11 @@ __device__ unsigned long long g_front_trace[32];
 extern "C" int gnf_debug_read_front_trace(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_front_trace), sizeof(unsigned long long) * 32);
 }
+#elif defined(GNF_FOLD_TRACE) && !defined(GNF_ATTN_FRONT_TU)  // developer build of gnf_fused.hip: the same stamps inside k_half_fused's attention instance
+#define FR_STAMP(i)                                                                                           \
+    do {                                                                                                      \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 32) g_fold_trace[i] = __builtin_amdgcn_s_memtime();  \
+    } while (0)
 #else
 #define FR_STAMP(i)
 #endif
@@ -91,14 +97,17 @@ extern "C" int gnf_debug_read_front_trace(unsigned long long* out) {
 // h0_lds0 / h0_lds1 (LDS rows of stride h0_ls floats: the MLP's layer-0 input buffers, which may ALIAS this function's own
 // x / q|v staging area - everything they overlap is dead behind the barrier in front of the output projection) instead
 // of a.h0; `before_out()` runs between that barrier and the output projection (the caller's own prefetches).
-template <bool HOIST, int KQM, int VDM, int EU, bool EXACT, bool TO_LDS, class Hook>
+// FIXED: the head geometry is the drivers' default at D = 64 (H = 32, 8 heads, kq = v = 10, C = 80: run_grevnet.py:59-80) -
+// every width below is a compile-time constant and the loops over k-groups / column tiles lose their run-time predicates
+// (a branch around every group of four MFMAs otherwise).
+template <bool HOIST, int KQM, int VDM, int EU, bool EXACT, bool TO_LDS, bool FIXED, class Hook>
 __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __restrict__ lds, const int row0, float* h0_lds0,
                                                 float* h0_lds1, const int h0_ls, Hook&& before_out) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int net = wave >> 2, wn = wave & 3;  // waves 0-3: s-net, 4-7: t-net
     const int lrow = lane & 15, lgrp = lane >> 4;
-    const FrontDims d = a.d;
+    const FrontDims d = FIXED ? front_dims(32, 8, 10, 10, 80) : a.d;
     const int H = d.H, nh = d.nh, kq = d.kq, vd = d.vd, nq = d.nq, NV = d.NV, P = 2 * nq + vd;
     const int Hp = d.Hp, nqp = d.nqp, NVp = d.NVp, Cp = d.Cp, PW = d.PW;
     const FrontLds L = front_lds(d);
@@ -501,6 +510,7 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
     __syncthreads();
     FR_STAMP(28);
     before_out();
+    FR_STAMP(30);
     if (a.agg_out[net])
         for (int i = tn; i < kFrRows * NV; i += 256) {
             const int rl = i / NV, c = i - rl * NV;
@@ -549,6 +559,7 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
                 }
             }
         }
+        FR_STAMP(31);
         if (a.concat) {
             if constexpr (TO_LDS) {
                 float* hl = net == 0 ? h0_lds0 : h0_lds1;

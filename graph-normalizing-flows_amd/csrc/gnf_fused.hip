@@ -134,6 +134,20 @@ __device__ int g_trace_layer = 1;
 
 }  // namespace gnf
 #include "gnf_fused_dev.h"
+#ifdef GNF_FOLD_TRACE  // developer build (tools/probe_fold_trace.py): cycle stamps of workgroup 0 / thread 0 of the attention instance
+namespace gnf {
+__device__ unsigned long long g_fold_trace[64];
+}
+extern "C" int gnf_debug_read_fold_trace(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gnf::g_fold_trace), sizeof(unsigned long long) * 64);
+}
+#define GNF_FOLD_STAMP(i)                                                                                  \
+    do {                                                                                                   \
+        if (FRONT && blockIdx.x == 0 && threadIdx.x == 0) g_fold_trace[i] = __builtin_amdgcn_s_memtime();  \
+    } while (0)
+#else
+#define GNF_FOLD_STAMP(i)
+#endif
 #include "gnf_attn_front_dev.h"
 namespace gnf {
 
@@ -141,7 +155,7 @@ namespace gnf {
 // kernel's prologue and leaves the layer-0 input rows of both nets in the activation buffers - no launch boundary, no
 // trip of those rows through global memory.  Its staging area (x rows, q | v of the sender window: 149 KB at the
 // reference's head geometry) ALIASES the activation buffers; bias / reduction scratch / layer table sit behind it.
-template <int MT, int NETS, bool STASH = false, bool FRONT = false>
+template <int MT, int NETS, bool STASH = false, bool FRONT = false, bool FIXED = false>
 __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a, const FrontArgs fa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     static_assert(!FRONT || (MT == 1 && NETS == 2 && !STASH), "the attention prologue exists for the 16-row both-nets shape");
@@ -152,7 +166,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
     auto buf = [&](int net_, int pp_) -> float* { return smem + (2 * net_ + pp_) * TM * LS; };
     int base_floats = 2 * NETS * TM * LS;
     if constexpr (FRONT) {
-        const int ft = front_lds(fa.d).total;
+        const int ft = front_lds(FIXED ? front_dims(32, 8, 10, 10, 80) : fa.d).total;
         base_floats = ft > base_floats ? ft : base_floats;
     }
     float* bias_lds = smem + base_floats;
@@ -288,7 +302,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
         constexpr int kBiasRegsF = 8;
         const int bias_all_f = NETS * a.bias_tot;
         float breg_f[kBiasRegsF];
-        attn_front_tile<true, 10, 10, 4, true, true>(fa, smem, row0, buf(0, 0), buf(1, 0), LS, [&] {
+        attn_front_tile<true, 10, 10, 4, true, true, FIXED>(fa, smem, row0, buf(0, 0), buf(1, 0), LS, [&] {
             prefetch_chunk(cur, WPN, voff, b_pre, thin_for(cur.layer));
 #pragma unroll
             for (int q = 0; q < kBiasRegsF; ++q) {
@@ -304,7 +318,9 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
         }
         for (int i = tid + kBiasRegsF * kFusedThreads; i < bias_all_f; i += kFusedThreads)
             bias_lds[i] = i < a.bias_tot ? a.bias[0][i] : a.bias[1][i - a.bias_tot];
+        GNF_FOLD_STAMP(32);
         __syncthreads();
+        GNF_FOLD_STAMP(33);
     } else {
     prefetch_chunk(cur, WPN, voff, b_pre, thin_for(cur.layer));
     GNF_PSTAMP(0);
@@ -444,6 +460,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
         GNF_STAMP(3 + 2 * j);
         __syncthreads();
         GNF_STAMP(4 + 2 * j);
+        GNF_FOLD_STAMP(34 + j);
     }
 
     if constexpr (STASH) {  // (every layer's barrier has passed: the words are complete)
@@ -523,6 +540,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
         }
     }
     GNF_STAMP(15);
+    GNF_FOLD_STAMP(48);
 }
 
 #ifdef GNF_TRACE
@@ -641,13 +659,13 @@ static int choose_big(const HalfStep& hs) {
     return big_q < old_q ? 4 : 0;
 }
 
-template <int MT, int NETS, bool STASH = false, bool FRONT = false>
+template <int MT, int NETS, bool STASH = false, bool FRONT = false, bool FIXED = false>
 static int launch_shape(const FusedArgs& a, unsigned grid, size_t lds, hipStream_t st, const FrontArgs* fa = nullptr) {
-    GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_fused<MT, NETS, STASH, FRONT>),
+    GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_fused<MT, NETS, STASH, FRONT, FIXED>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit)));
     FrontArgs none;
     memset(&none, 0, sizeof(none));
-    hipLaunchKernelGGL((k_half_fused<MT, NETS, STASH, FRONT>), dim3(grid), dim3(kFusedThreads), lds, st, a, fa ? *fa : none);
+    hipLaunchKernelGGL((k_half_fused<MT, NETS, STASH, FRONT, FIXED>), dim3(grid), dim3(kFusedThreads), lds, st, a, fa ? *fa : none);
     GNF_LAUNCH_CHECK("k_half_fused");
     return GNF_OK;
 }
@@ -847,7 +865,9 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
         return GNF_OK;
     }
     if (NETS == 2) {
-        if (fold)
+        if (fold && attn_front_fixed_geometry(fa.d))
+            rc = launch_shape<1, 2, false, true, true>(a, (unsigned)tiles, fused_front_lds_bytes(s, fa.d), st, &fa);
+        else if (fold)
             rc = launch_shape<1, 2, false, true>(a, (unsigned)tiles, fused_front_lds_bytes(s, fa.d), st, &fa);
         else
             rc = MT == 2 ? launch_shape<2, 2>(a, (unsigned)tiles, lds, st) : launch_shape<1, 2>(a, (unsigned)tiles, lds, st);
