@@ -95,8 +95,8 @@ extern "C" int gnf_debug_read_front_trace(unsigned long long* out) {
 // LDS read of the edge loop into its own basic block behind a scalar branch and waits for each one separately).
 // TO_LDS (the fused half-step kernel's attention instance, k_half_fused<1, 2, false, true>): h0 of the two nets goes to
 // h0_lds0 / h0_lds1 (LDS rows of stride h0_ls floats: the MLP's layer-0 input buffers, which may ALIAS this function's own
-// x / q|v staging area - everything they overlap is dead behind the barrier in front of the output projection) instead
-// of a.h0; `before_out()` runs between that barrier and the output projection (the caller's own prefetches).
+// x / q|v staging area - everything they overlap is dead behind the barrier in front of the output projection), and to
+// a.h0 as well when that is not NULL (training forward); `before_out()` runs between that barrier and the output projection (the caller's own prefetches).
 // FIXED: the head geometry is the drivers' default at D = 64 (H = 32, 8 heads, kq = v = 10, C = 80: run_grevnet.py:59-80) -
 // every width below is a compile-time constant and the loops over k-groups / column tiles lose their run-time predicates
 // (a branch around every group of four MFMAs otherwise).
@@ -550,7 +550,11 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
             if constexpr (TO_LDS) {  // (columns [C, Cp) come out as zeros: Wo's pad columns are zero)
                 float* hl = net == 0 ? h0_lds0 : h0_lds1;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hl[(4 * lgrp + r) * h0_ls + off + c] = row0 + 4 * lgrp + r < a.n_nodes ? acc[r] : 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = row0 + 4 * lgrp + r;
+                    hl[(4 * lgrp + r) * h0_ls + off + c] = rr < a.n_nodes ? acc[r] : 0.f;
+                    if (h0 && rr < a.n_nodes && c < d.C) h0[(int64_t)rr * a.in0 + off + c] = acc[r];  // (training forward: the stash keeps h0)
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -566,7 +570,11 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int i = tn + 256 * u;
-                    if (i < kFrRows * H) hl[(i / H) * h0_ls + (i - (i / H) * H)] = xkeep[u];
+                    if (i < kFrRows * H) {
+                        const int rl = i / H, f = i - rl * H;
+                        hl[rl * h0_ls + f] = xkeep[u];
+                        if (h0 && row0 + rl < a.n_nodes) h0[(int64_t)(row0 + rl) * a.in0 + f] = xkeep[u];
+                    }
                 }
             } else {
                 for (int i = tn; i < kFrRows * H; i += 256) {

@@ -158,7 +158,7 @@ namespace gnf {
 template <int MT, int NETS, bool STASH = false, bool FRONT = false, bool FIXED = false>
 __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a, const FrontArgs fa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    static_assert(!FRONT || (MT == 1 && NETS == 2 && !STASH), "the attention prologue exists for the 16-row both-nets shape");
+    static_assert(!FRONT || (MT == 1 && NETS == 2), "the attention prologue exists for the 16-row both-nets shape");
     constexpr int TM = 16 * MT;
     constexpr int WPN = 8 / NETS;  // waves per net
     const int LS = a.LS;
@@ -279,7 +279,10 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
     auto thin_for = [&](int layer) { return MT == 1 && !(a.variant & 1) && (!STASH || layer == a.K - 1); };
     int* s_rowptr = tab + GNF_MAX_LAYERS * 8;
     int* s_col = s_rowptr + kRowptrPad;
-    [[maybe_unused]] unsigned long long* fmask = reinterpret_cast<unsigned long long*>(s_col + kColCap);  // STASH only
+    // STASH only: the act' ballots.  With the attention prologue they sit right behind the activation buffers, inside the
+    // front-end's staging area (dead by the time the first layer's epilogue writes them)
+    [[maybe_unused]] unsigned long long* fmask =
+        FRONT ? reinterpret_cast<unsigned long long*>(smem + 2 * NETS * TM * LS) : reinterpret_cast<unsigned long long*>(s_col + kColCap);
     if constexpr (FRONT) {
         // ---- attention prologue: the layer table first (its words sit behind the front-end's staging area), then the
         // front-end over this tile's 16 receiver rows; the first chunk's weights and the biases are requested between its
@@ -679,13 +682,13 @@ static size_t fused_front_lds_bytes(const GnfMlp* m, const FrontDims& d) {
 }
 
 // May the attention front-end run as the fused kernel's prologue (k_half_fused<1, 2, false, true>)?  The sparse-batch
-// front-end with the reference's head geometry (its register-resident instance), inference only (the training forward
-// keeps q | k | v, the attended values and h0 in the stash), widths that need no zero padding in the layer-0 rows, and
-// the two areas in 160 KB.  gnf_set_option("fused_variant", 4) keeps the two launches (A/B).
+// front-end with the reference's head geometry (its register-resident instance), widths that need no zero padding in
+// the layer-0 rows, and the two areas in 160 KB; the training forward (q | k | v, the attended values and h0 also go to the
+// stash) with the drivers' default geometry only.  gnf_set_option("fused_variant", 4) keeps the two launches (A/B).
 static bool front_fold_ok(const HalfStep& hs, FrontArgs* fa) {
     const GnfMlp *s = hs.s_net, *t = hs.t_net;
     const GnfAttn *a0 = s->attn, *a1 = t->attn;
-    if (!a0 || !a1 || hs.attn_region || hs.mlp_stash || (opt(OPT_FUSED_VARIANT) & 4)) return false;
+    if (!a0 || !a1 || (opt(OPT_FUSED_VARIANT) & 4)) return false;
     if (!hs.attn_packed[0] || !hs.attn_packed[1]) return false;
     if (!(hs.n_edges > 0 && hs.n_edges < 24 * hs.n_nodes) || !attn_front_fused_ok(a0, hs.H)) return false;
     if (a1->num_heads != a0->num_heads || a1->kq_dim != a0->kq_dim || a1->v_dim != a0->v_dim || a1->out_dim != a0->out_dim ||
@@ -697,12 +700,26 @@ static bool front_fold_ok(const HalfStep& hs, FrontArgs* fa) {
     const int in0 = s->dims[0];
     if ((d.C & 15) || (a0->concat && (hs.H & 15)) || (in0 & 15) || in0 != (a0->concat ? hs.H : 0) + d.C) return false;
     if (fused_front_lds_bytes(s, d) > (size_t)kLdsLimit) return false;
+    if (hs.mlp_stash) {  // (the stash instance exists for the default geometry only; its act' ballots sit behind the activation buffers)
+        const MlpStashLayout SL = mlp_stash_layout(s, hs.n_nodes, hs.H);
+        const size_t act_bytes = (size_t)2 * 2 * 16 * (max_padded_width(s) + 4) * sizeof(float);
+        if (!attn_front_fixed_geometry(d) || act_bytes + (size_t)SL.mask_words * 8 > (size_t)front_lds(d).total * sizeof(float)) return false;
+    }
     for (int q = 0; q < 2; ++q) {
         fa->packed[q] = hs.attn_packed[q];
         fa->qkv[q] = nullptr;
         fa->h0[q] = nullptr;
         fa->agg_out[q] = nullptr;
         fa->mz_out[q] = nullptr;
+    }
+    if (hs.attn_region) {  // training forward: q | k | v, h0, the attended values and the softmax statistics stay in the
+                           // half-step's slot of GnfFlow.attn_stash (attn_scratch_floats' layout, as launch_attn_pair)
+        const size_t n = (size_t)hs.n_nodes, P = 2 * (size_t)a0->num_heads * a0->kq_dim + a0->v_dim, NV = (size_t)a0->num_heads * a0->v_dim;
+        float* r = hs.attn_region;
+        fa->qkv[0] = r, fa->qkv[1] = r + n * P;
+        fa->h0[0] = r + 2 * n * P, fa->h0[1] = fa->h0[0] + n * in0;
+        fa->agg_out[0] = fa->h0[1] + n * in0, fa->agg_out[1] = fa->agg_out[0] + n * NV;
+        fa->mz_out[0] = fa->agg_out[1] + n * NV, fa->mz_out[1] = fa->mz_out[0] + n * 3 * a0->num_heads;
     }
     fa->rowptr = hs.rowptr, fa->col = hs.col, fa->x = hs.x_cond, fa->ldx = hs.ld;
     fa->n_nodes = (int32_t)hs.n_nodes;
@@ -857,7 +874,10 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
         a.stash_ld = L.ld_act;
         a.stash_mask = reinterpret_cast<unsigned long long*>(hs.mlp_stash + L.mask);
         a.stash_mld = L.mld;
-        rc = launch_shape<1, 2, true>(a, (unsigned)tiles, lds + (size_t)L.mask_words * sizeof(unsigned long long), st);
+        if (fold)
+            rc = launch_shape<1, 2, true, true, true>(a, (unsigned)tiles, fused_front_lds_bytes(s, fa.d), st, &fa);
+        else
+            rc = launch_shape<1, 2, true>(a, (unsigned)tiles, lds + (size_t)L.mask_words * sizeof(unsigned long long), st);
         if (rc) return rc;
         *hs.n_partials = (int32_t)tiles;
         if (hs.n_sq) *hs.n_sq = a.sq_partials ? (int32_t)tiles : 0;
