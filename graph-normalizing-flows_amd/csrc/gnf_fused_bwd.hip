@@ -153,6 +153,7 @@ int build_bwd_args(const int32_t* rowptr, const int32_t* col, int64_t n, const G
     a.H = H;
     a.in0 = s->dims[0];
     a.K = K;
+    a.n_rows = 2 * K;
     a.LS = max_padded_width_b(s) + 4;
     a.mean = gnn.agg == GNF_AGG_MEAN;
     a.concat = gnn.combine == GNF_COMBINE_CONCAT;
@@ -193,6 +194,28 @@ int launch_half_bwd_fused(const int32_t* rowptr, const int32_t* col, int64_t n, 
         hipLaunchKernelGGL(k_half_bwd_fused<1>, dim3((unsigned)tiles), dim3(kBwdThreads), lds, st, a);
     GNF_LAUNCH_CHECK("k_half_bwd_fused");
     return GNF_OK;
+}
+
+bool bwd_args_add_dagg_row(BwdArgs* a, const float* const* wot, float* const* dagg, int C, int NV, int off) {
+    const int r = 2 * a->K;
+    const int Cp = pad16b(C), NVp = pad16b(NV);
+    if (a->n_rows != r || r + 1 > kRows || (off & 3) || off + Cp > a->LS - 4 || NVp > a->LS - 4 || NVp > a->bias_tot2 - a->bias_tot) return false;
+    int* row = a->tab[r];
+    row[0] = Cp / 16;
+    row[1] = NVp / 16;
+    row[2] = a->bias_tot;  // zero bias
+    row[3] = NV;
+    row[4] = 1;
+    row[5] = -1;
+    row[6] = NV;
+    row[7] = off;
+    for (int q = 0; q < 2; ++q) {
+        const unsigned long long w = reinterpret_cast<unsigned long long>(wot[q]), d = reinterpret_cast<unsigned long long>(dagg[q]);
+        row[8 + 2 * q] = (int)(unsigned)w, row[9 + 2 * q] = (int)(unsigned)(w >> 32);
+        row[12 + 2 * q] = (int)(unsigned)d, row[13 + 2 * q] = (int)(unsigned)(d >> 32);
+    }
+    a->n_rows = r + 1;
+    return true;
 }
 
 // the same launch for arguments that carry a half-step's stash rows (st_in, mask_in set by the caller): 16-node tiles only

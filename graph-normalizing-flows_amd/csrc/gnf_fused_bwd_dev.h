@@ -12,7 +12,11 @@ static constexpr int kBwdColCap = 2048;
 static constexpr int kRows = 2 * GNF_MAX_LAYERS;
 
 // table row: 0 ipg, 1 ont, 2 boff, 3 true output width, 4 mode (0 recompute, 1 backward), 5 mask slot (-1: none),
-//            6 dump row stride, 7 -, 8-9 packed weights net 0, 10-11 net 1, 12-13 dump pointer net 0, 14-15 net 1
+//            6 dump row stride, 7 first input column (floats, a multiple of 4), 8-9 packed weights net 0, 10-11 net 1,
+//            12-13 dump pointer net 0, 14-15 net 1
+// Rows 0 .. K-1: the layers forwards (recompute), K .. 2K-1: backwards; attention GNNs may add row 2K (bwd_args_add_dagg_row):
+// dagg = dnew Wo^T, dnew = columns [off, off + C) of dL/dh0 - the first product of the attention backward pass, which
+// used to be a GEMM launch of its own between this kernel and the edge kernels.
 struct BwdArgs {
     const int32_t* rowptr;
     const int32_t* col;
@@ -26,6 +30,7 @@ struct BwdArgs {
     int32_t tab[kRows][16];
     int64_t ld, ldg;
     int32_t n_nodes, n_tiles, H, in0, K, LS, bias_tot, bias_tot2, mld;
+    int32_t n_rows;  // rows of the table: 2 K, or 2 K + 1
     int32_t mean, concat, act;
     int32_t residual;  // attention block with residual: s, t = MLP(h0) + x_cond (gnn.py:547-548)
     float eps, alpha;
@@ -91,7 +96,7 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
     const int nl = wave / WPN;
     const int wl = (wave % WPN + nl * (WPN / 2)) % WPN;  // t-net ownership rotated by half a turn (see gnf_fused.hip)
     const int voff = lane * 16;
-    const int R = 2 * a.K;  // rows of the layer table
+    const int R = a.n_rows;  // rows of the layer table
 
     auto fill_chunk = [&](WChunk& c, int r, int ipg_, int ont_, int boff_, const float* wb, int nt0) {
         c.wbase = wb;
@@ -281,7 +286,7 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
         const int mode = __builtin_amdgcn_readfirstlane(row[4]);
         const int slot = __builtin_amdgcn_readfirstlane(row[5]);
         const bool last_fwd = (r == a.K - 1);
-        const float* in_lds = buf(nl, pp);
+        const float* in_lds = buf(nl, pp) + __builtin_amdgcn_readfirstlane(row[7]);
         float* out_lds = buf(nl, pp ^ 1);
         const float act_slope = a.act == GNF_ACT_RELU ? 0.f : a.alpha;
         const float slope = (mode == 1 || last_fwd) ? 1.f : act_slope;
@@ -389,5 +394,9 @@ int build_bwd_args(const int32_t* rowptr, const int32_t* col, int64_t n, const G
                    int64_t lddp, float* const* gst, float* const* dh0, BwdArgs* out, int* mt, int64_t* tiles, size_t* lds,
                    const BwdFold* fold = nullptr);
 int launch_half_bwd_fused_stashed(const BwdArgs& a, int mt, int64_t tiles, size_t lds, hipStream_t st);
+// appends the row dagg[q] = dL/dh0[q][:, off : off + C] Wo_q^T ([n, NV], row stride NV); wot[q]: Wo_q ([NV, C]) as packed
+// transposed fragments (k-groups over C, column tiles over NV: k_pack_layer's wtout layout).  false: no room / widths
+// the tile does not hold - the caller keeps its GEMM launch.
+bool bwd_args_add_dagg_row(BwdArgs* a, const float* const* wot, float* const* dagg, int C, int NV, int off);
 
 }  // namespace gnf

@@ -1010,6 +1010,7 @@ struct BwdPlan {
     int nh, kq, vd, C, P, NV;
     // float offsets.  single: g, invdeg, bnpart, st, wslab, bslab, qkv, dagg, stats;  per set: the rest
     size_t g, invdeg, bnpart, st, wslab, bslab, qkv, dagg, stats, splitk, lny, lnpart;
+    size_t wot, wot_each;  // attention nets: Wo of every net of the flow as packed transposed fragments (k_pack_wot), floats per net
     size_t splitk_each;  // floats of split-K scratch per net
     size_t h0, h0b, acts, gst, dpb, dh0, xc, dqkv, agg;
     int n_sets;
@@ -1035,7 +1036,7 @@ static constexpr int kBwdMaxSets = 64;
 static constexpr int kBwdSetsDefault = 3;
 
 // n_sets: operand sets (one per half-step of the walk, capped: see kBwdMaxSets)
-static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net, int n_sets) {
+static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net, int n_sets, int n_nets_each = 0) {
     BwdPlan p;
     memset(&p, 0, sizeof(p));
     p.n = n;
@@ -1094,6 +1095,10 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net, int n_sets
     p.qkv = off, off += 2 * al64((size_t)n * p.P);
     p.dagg = off, off += 2 * al64((size_t)n * p.NV);
     p.stats = off, off += 2 * al64((size_t)n * 3 * p.nh);
+    if (net->attn) {  // (s-nets first, then t-nets: n_nets_each of either)
+        p.wot_each = al64((size_t)((p.C + 15) & ~15) * (size_t)((p.NV + 15) & ~15));
+        p.wot = off, off += 2 * (size_t)n_nets_each * p.wot_each;
+    }
     // slabs of the split-K path of thin generic-path GEMMs (launch_gemm): only launches with < 96 tiles take it, i.e.
     // fewer than 48 row tiles per net and one or two column tiles; 16 chunks at most
     p.splitk_each = al64((size_t)16 * (size_t)(n < 48 * TGM ? n : 48 * TGM) * (size_t)(2 * TGN));
@@ -1120,6 +1125,24 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net, int n_sets
     off += (size_t)(p.n_sets - 1) * p.set_stride;             // the other sets
     p.total = off;
     return p;
+}
+
+// Wo ([NV, C], row major) of up to 64 attention blocks as packed TRANSPOSED fragments - k_pack_layer's wtout layout: k-groups
+// over the C axis, column tiles over the NV axis - for the dagg row of the backward tile kernel (bwd_args_add_dagg_row)
+struct PackWot {
+    const float* wo[64];
+    float* out[64];
+    int NV, C, NVp, Cp;
+};
+__global__ __launch_bounds__(256) void k_pack_wot(const PackWot b) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= b.NVp * b.Cp) return;
+    const int q = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
+    const int nts = b.NVp >> 4;
+    const int kg = blk / nts, nt = blk - kg * nts;
+    const int ko = 16 * kg + 4 * (lane >> 4) + q;  // along C
+    const int ci = 16 * nt + (lane & 15);           // along NV
+    b.out[blockIdx.y][i] = (ci < b.NV && ko < b.C) ? b.wo[blockIdx.y][(int64_t)ci * b.C + ko] : 0.f;
 }
 
 static const GnfMlp* pick_net(const GnfFlow* f, const GnfMlp* nets, int half, int i) {
@@ -1846,7 +1869,7 @@ extern "C" {
 
 size_t gnf_backward_workspace_bytes(int64_t n_nodes, int32_t D, const GnfFlow* flow) {
     if (n_nodes < 0 || D < 2 || (D & 1) || !flow || !flow->s_nets) return 0;
-    return plan_backward(n_nodes, D, &flow->s_nets[0], kBwdSetsDefault).total * sizeof(float);
+    return plan_backward(n_nodes, D, &flow->s_nets[0], kBwdSetsDefault, flow->weight_sharing ? 2 : 2 * flow->num_timesteps).total * sizeof(float);
 }
 
 int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFlow* flow, const GnfFlow* grad,
@@ -1908,7 +1931,8 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     const int64_t n = csr->n_nodes;
     hipStream_t st = (hipStream_t)stream;
     if (n_nets == 0) return GNF_OK;
-    const BwdPlan p = plan_backward(n, D, &flow->s_nets[0], kBwdSetsDefault);
+    const int n_nets_each = flow->weight_sharing ? 2 : 2 * flow->num_timesteps;
+    const BwdPlan p = plan_backward(n, D, &flow->s_nets[0], kBwdSetsDefault, n_nets_each);
     if (n > 0 && (!z || !ws || ws_bytes < p.total * sizeof(float))) {
         set_error("gnf_grevnet_backward_f32: workspace %zu < %zu bytes (or null z/ws)", ws_bytes,
                   p.total * sizeof(float));
@@ -1983,6 +2007,22 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
         return GNF_EWORKSPACE;
     }
     if (merged) aux = nullptr;
+    // attention nets on the merged walk: Wo of every net as transposed fragments, once per call (k_pack_wot) - the tile
+    // kernel then forms dagg = dnew Wo^T itself (its last table row) and the GEMM launch in front of the edge kernels
+    // goes (7.7 us per half-step on the config-2 batch).  dw_debug bit 32 keeps the GEMM (A/B).
+    bool wot_packed = false;
+    if (merged && flow->s_nets[0].attn && n_nets_each <= 32 && !(opt(OPT_DW_DEBUG) & 32)) {
+        PackWot pw;
+        memset(&pw, 0, sizeof(pw));
+        for (int k = 0; k < n_nets_each; ++k) {
+            pw.wo[k] = flow->s_nets[k].attn->Wo, pw.wo[n_nets_each + k] = flow->t_nets[k].attn->Wo;
+            pw.out[k] = wsf + p.wot + (size_t)k * p.wot_each, pw.out[n_nets_each + k] = wsf + p.wot + (size_t)(n_nets_each + k) * p.wot_each;
+        }
+        pw.NV = p.NV, pw.C = p.C, pw.NVp = (p.NV + 15) & ~15, pw.Cp = (p.C + 15) & ~15;
+        hipLaunchKernelGGL(k_pack_wot, dim3((unsigned)((pw.NVp * pw.Cp + 255) / 256), (unsigned)(2 * n_nets_each)), dim3(256), 0, st, pw);
+        GNF_LAUNCH_CHECK("k_pack_wot");
+        wot_packed = true;
+    }
     const bool reuse_sets = 2 * T > p.n_sets;
     // The events live in a per-host-thread, per-device cache (created at a thread's first call on a device, released
     // when the thread ends): no create / destroy per training step, nothing shared between threads or devices, and no
@@ -2020,17 +2060,19 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     // the attention front-end backwards: dagg = dnew Wo^T ([nodes, C] x [C, heads*v]; Wo is [heads*v, C]: rows = output
     // columns), then the edge kernels; dL/dx_cond accumulates into g_cond
     auto attention_backward = [&](const GnfMlp* const* nets_, const BwdOperands& o_, float* g_cond, const AttnBnFold* bnf,
-                                  const float* x_cond_) -> int {
+                                  const float* x_cond_, bool have_dagg = false) -> int {
         const GnfAttn* at[2] = {nets_[0]->attn, nets_[1]->attn};
         const int off = at[0]->concat ? D / 2 : 0;
-        GemmJob jobs[2];
-        for (int q = 0; q < 2; ++q) jobs[q] = GemmJob{o_.dh0[q] + off, at[q]->Wo, o_.dagg[q], nullptr, nullptr};
-        GemmShape sh;
-        memset(&sh, 0, sizeof(sh));
-        sh.lda = p.in0, sh.ldb = p.C, sh.ldc = p.NV;
-        sh.M = n, sh.K = p.C, sh.N = p.NV, sh.chunks = 1, sh.kchunk = TGK;
-        int rc_ = launch_gemm<OPND_KC, OPND_KC, EPI_MASK>(jobs, 2, sh, st);
-        if (rc_) return rc_;
+        if (!have_dagg) {  // (else: the backward tile kernel's last table row has written it)
+            GemmJob jobs[2];
+            for (int q = 0; q < 2; ++q) jobs[q] = GemmJob{o_.dh0[q] + off, at[q]->Wo, o_.dagg[q], nullptr, nullptr};
+            GemmShape sh;
+            memset(&sh, 0, sizeof(sh));
+            sh.lda = p.in0, sh.ldb = p.C, sh.ldc = p.NV;
+            sh.M = n, sh.K = p.C, sh.N = p.NV, sh.chunks = 1, sh.kchunk = TGK;
+            const int rc_ = launch_gemm<OPND_KC, OPND_KC, EPI_MASK>(jobs, 2, sh, st);
+            if (rc_) return rc_;
+        }
         return launch_attn_backward(at, n, D / 2, p.in0, csr->rowptr, csr->col, csr_t->rowptr, csr_t->col, o_.qkv, o_.dh0, o_.gst,
                                     o_.dqkv, o_.agg, o_.dagg, o_.stats, g_cond, D, st, csr->n_edges, bnf, x_cond_, ld, o_.xc);
     };
@@ -2113,6 +2155,12 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                                     o.h0[0], attn ? h0c : nullptr, o.hin, p.lmax, o.dPs, p.lmax, o.gst, o.dh0, &ba, &mt, &tiles, &lds,
                                     folded ? &bf : nullptr);
                 if (rc) return rc;
+                bool have_dagg = false;
+                if (attn && wot_packed) {  // dagg = dnew Wo^T as the tile kernel's last row instead of a GEMM launch
+                    const int ni = flow->weight_sharing ? half : half * T + i;
+                    const float* wot[2] = {wsf + p.wot + (size_t)ni * p.wot_each, wsf + p.wot + (size_t)(n_nets_each + ni) * p.wot_each};
+                    have_dagg = bwd_args_add_dagg_row(&ba, wot, o.dagg, p.C, p.NV, nets[0]->attn->concat ? H : 0);
+                }
                 if (mstashed) {
                     const float* slot = flow->mlp_stash + (size_t)(2 * i + half) * msl.slot;
                     for (int q = 0; q < 2; ++q) ba.st_in[q] = slot + msl.st + (size_t)q * msl.st_each;
@@ -2146,7 +2194,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                     const AttnBnFold bnf{z + co, ld, bq ? bq->gamma : nullptr, bq ? bq->beta : nullptr,
                                          reinterpret_cast<double*>(wsf + p.bnpart), &bn_pre};
                     bn_pre = 0;
-                    rc = attention_backward(nets, o, g + co, bq ? &bnf : nullptr, x_cond);
+                    rc = attention_backward(nets, o, g + co, bq ? &bnf : nullptr, x_cond, have_dagg);
                     if (rc) return rc;
                 } else if (have_fold) {
                     fold_dh[0] = o.dh0[0], fold_dh[1] = o.dh0[1];
