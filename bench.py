@@ -72,13 +72,14 @@ PEAK_HBM_GBS = 8000.0
 
 
 def kernel_source_stamp():
-    """sha256 over the sources of the dominant kernels (k_half_fused / k_half_big: gnf_fused.hip + gnf_fused_dev.h +
-    gnf_fused_big.hip): what the PMC passes under profiles/ were taken on.  (There is no .git on the GPU box, so the
+    """sha256 over the sources of the dominant kernels (k_half_fused, with the attention front-end as its prologue, and
+    k_half_big: gnf_fused.hip + gnf_fused_dev.h + gnf_attn_front_dev.h + gnf_fused_big.hip): what the PMC passes under
+    profiles/ were taken on.  (There is no .git on the GPU box, so the
     stamp is content-based.)"""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "graph-normalizing-flows_amd", "csrc")
-    for name in ("gnf_fused.hip", "gnf_fused_dev.h", "gnf_fused_big.hip"):
+    for name in ("gnf_fused.hip", "gnf_fused_dev.h", "gnf_attn_front_dev.h", "gnf_fused_big.hip"):
         h.update(name.encode())
         h.update(open(os.path.join(csrc, name), "rb").read())
     return h.hexdigest()[:16]
