@@ -763,6 +763,7 @@ struct AttnDxArgs {
     const float* xc_src;
     int64_t xc_ld;
     float* xc_dst;  // [n][H]
+    const float* wct[2];  // k_attn_bwd_dx_mfma: [Wq | Wk | Wv]^T as packed fragments (attn_wct_floats), else unused
 };
 
 static constexpr int kDxRows = 8;  // rows per workgroup
@@ -939,6 +940,119 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dx2(const AttnDxArgs a) {
     }
 }
 
+// The same product on the matrix cores: a workgroup = 16 rows, wave = (net, column tile of H): out = dqkv rows [16 x P] x
+// Wcat^T [P x H] with the weights as pre-packed fragments (one 16-byte load per lane and k-group, all requested before the
+// first MFMA), the dqkv rows staged in LDS with coalesced loads; then the same epilogue as k_attn_bwd_dx2 (g, the copy of
+// the conditioning half, the batch-norm partial sums - one [H][2] fp64 row per workgroup of SIXTEEN rows here).
+// 14.7 -> ~6 us per half-step on the config-2 batch: k_attn_bwd_dx2 re-reads both nets' 43 KB of weights element by
+// element in every 8-row workgroup and walks 2 x 170 LDS products per thread.
+static constexpr int kDxmRows = 16;
+static constexpr int kDxmMaxKG = 12;  // k-groups of fragments a wave holds in registers at a time
+typedef float f32x4_dx __attribute__((ext_vector_type(4)));
+size_t attn_wct_floats(const GnfAttn* at, int32_t H) {
+    if (!at) return 0;
+    const size_t P = 2 * (size_t)at->num_heads * at->kq_dim + at->v_dim;
+    return ((P + 15) & ~(size_t)15) * (((size_t)H + 15) & ~(size_t)15);
+}
+__global__ __launch_bounds__(256) void k_attn_bwd_dx_mfma(const AttnDxArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int P = 2 * a.nq + a.v, H = a.H;
+    const int Pp = (P + 15) & ~15, Hp = (H + 15) & ~15, kgs = Pp >> 4, nts = Hp >> 4;
+    const int lda = Pp + 4, ldo = Hp + 4;
+    float* A = sm;                              // [2][16][lda]
+    float* out = A + 2 * kDxmRows * lda;        // [2][16][ldo]
+    float* bg = out + 2 * kDxmRows * ldo;       // [16][H] G | [16][H] G x^
+    float* bx = bg + kDxmRows * H;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lrow = lane & 15, lgrp = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * kDxmRows;
+    const int rows = (int)((a.n - row0) < kDxmRows ? (a.n - row0) : kDxmRows);
+    // ---- dqkv rows of both nets -> LDS (zero padded), eight loads in flight per thread
+    {
+        const int per_net = kDxmRows * Pp, total = 2 * per_net;
+        for (int base = tid; base < total; base += 8 * 256) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256;
+                const int net = i >= per_net ? 1 : 0, j = i - net * per_net;
+                const int rl = j / Pp, c = j - rl * Pp;
+                const bool live = i < total && rl < rows && c < P;
+                const float* src = net ? a.dqkv[1] : a.dqkv[0];
+                v[u] = live ? src[(row0 + rl) * P + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256;
+                if (i < total) {
+                    const int net = i >= per_net ? 1 : 0, j = i - net * per_net;
+                    const int rl = j / Pp, c = j - rl * Pp;
+                    A[(net * kDxmRows + rl) * lda + c] = v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- wave = (net, column tile): 4 MFMAs per k-group on one accumulator
+    for (int idx = wave; idx < 2 * nts; idx += 4) {
+        const int net = idx / nts, nt = idx - net * nts;
+        const float* wp = (net ? a.wct[1] : a.wct[0]) + (size_t)nt * 256 + lane * 4;
+        const float* ab = A + (net * kDxmRows + lrow) * lda + 4 * lgrp;
+        f32x4_dx acc = {0.f, 0.f, 0.f, 0.f};
+        for (int kg0 = 0; kg0 < kgs; kg0 += kDxmMaxKG) {
+            f32x4_dx b[kDxmMaxKG];
+#pragma unroll
+            for (int u = 0; u < kDxmMaxKG; ++u) {
+                const int kg = kg0 + u < kgs ? kg0 + u : kgs - 1;
+                b[u] = *reinterpret_cast<const f32x4_dx*>(wp + (size_t)kg * nts * 256);
+            }
+#pragma unroll
+            for (int u = 0; u < kDxmMaxKG; ++u) {
+                if (kg0 + u < kgs) {  // wave-uniform
+                    const f32x4_dx av = *reinterpret_cast<const f32x4_dx*>(ab + 16 * (kg0 + u));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], b[u][q], acc, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(net * kDxmRows + 4 * lgrp + r) * ldo + 16 * nt + lrow] = acc[r];
+    }
+    __syncthreads();
+    // ---- epilogue: g += both nets' products (+ the direct terms), copy of the conditioning half, batch-norm partials
+    for (int i = tid; i < kDxmRows * H; i += 256) {
+        const int rl = i / H, f = i - rl * H;
+        const bool live = rl < rows;
+        float gv = 0.f;
+        if (live) {
+            const int64_t r = row0 + rl;
+            float s0 = a.g[r * a.ldg + f];
+#pragma unroll
+            for (int net = 0; net < 2; ++net) {
+                if (a.concat) s0 += a.dh0[net][r * a.in0 + f];
+                if (a.gst[net]) s0 += a.gst[net][r * H + f];
+            }
+            gv = s0 + (out[rl * ldo + f] + out[(kDxmRows + rl) * ldo + f]);
+            a.g[r * a.ldg + f] = gv;
+            if (a.xc_dst) a.xc_dst[r * H + f] = a.xc_src[r * a.xc_ld + f];
+        }
+        if (a.bn_part) {
+            bg[i] = gv;
+            bx[i] = live ? gv * ((a.bn_y[(row0 + rl) * a.bn_ld + f] - a.bn_beta[f]) / a.bn_gamma[f]) : 0.f;
+        }
+    }
+    if (a.bn_part) {
+        __syncthreads();
+        for (int i = tid; i < 2 * H; i += 256) {
+            const int f = i >> 1, which = i & 1;
+            const float* src = which ? bx : bg;
+            double acc = 0.0;
+            for (int rl = 0; rl < kDxmRows; ++rl) acc += (double)src[rl * H + f];
+            a.bn_part[((int64_t)blockIdx.x * H + f) * 2 + which] = acc;
+        }
+    }
+}
+
 // at[2]: the two attention blocks; qkv: [2][N, P] forward projections (launch_attn_front's scratch);
 // dh0 / gst: per net;  dqkv: per net outputs kept for the dW GEMMs;  dagg = dnew Wo^T [N, heads*v] (computed by the
 // caller with the matrix-core GEMM);  agg / stats: the forward pass's attended values and softmax statistics
@@ -947,7 +1061,7 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
                          const int32_t* col, const int32_t* rowptr_t, const int32_t* col_t, const float* const* qkv,
                          const float* const* dh0, const float* const* gst, float* const* dqkv, float* const* agg,
                          float* const* dagg, float* const* stats, float* g_cond, int64_t ldg, hipStream_t st, int64_t n_edges,
-                         const AttnBnFold* bn, const float* xc_src, int64_t xc_ld, float* xc_dst) {
+                         const AttnBnFold* bn, const float* xc_src, int64_t xc_ld, float* xc_dst, const float* const* wct) {
     if (n == 0) return GNF_OK;
     const GnfAttn* a0 = at[0];
     AttnBwdArgs a;
@@ -1109,6 +1223,23 @@ dx_pass:
     d.in0 = in0;
     d.concat = a.concat;
     d.xc_src = xc_src, d.xc_ld = xc_ld, d.xc_dst = xc_dst;
+    d.wct[0] = wct ? wct[0] : nullptr, d.wct[1] = wct ? wct[1] : nullptr;
+    {   // the matrix-core form when the caller has the packed weights
+        const int Pp = (P + 15) & ~15, Hp = (H + 15) & ~15;
+        const size_t lds_m = ((size_t)2 * kDxmRows * (Pp + 4) + (size_t)2 * kDxmRows * (Hp + 4) + (size_t)2 * kDxmRows * H) * sizeof(float);
+        const int64_t blocks_m = (n + kDxmRows - 1) / kDxmRows;
+        if (d.wct[0] && d.wct[1] && lds_m <= 64 * 1024 && !opt(OPT_ATTN_BWD_SPLIT)) {
+            d.bn_y = nullptr, d.bn_ld = 0, d.bn_gamma = d.bn_beta = nullptr, d.bn_part = nullptr;
+            if (bn && bn->n_parts) *bn->n_parts = 0;
+            if (bn && bn->part && blocks_m <= kBnPartRowsMax) {
+                d.bn_y = bn->y, d.bn_ld = bn->ld, d.bn_gamma = bn->gamma, d.bn_beta = bn->beta, d.bn_part = bn->part;
+                if (bn->n_parts) *bn->n_parts = (int32_t)blocks_m;
+            }
+            hipLaunchKernelGGL(k_attn_bwd_dx_mfma, dim3((unsigned)blocks_m), dim3(256), lds_m, st, d);
+            GNF_LAUNCH_CHECK("k_attn_bwd_dx_mfma");
+            return GNF_OK;
+        }
+    }
     const int64_t dx_blocks = (n + kDxRows - 1) / kDxRows;
     d.bn_y = nullptr, d.bn_ld = 0, d.bn_gamma = d.bn_beta = nullptr, d.bn_part = nullptr;
     if (bn && bn->n_parts) *bn->n_parts = 0;

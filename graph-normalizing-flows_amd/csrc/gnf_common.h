@@ -171,7 +171,12 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
                          const AttnBnFold* bn = nullptr,
                          // xc_dst != NULL: the last kernel also copies the conditioning half [n, H] (leading dimension xc_ld)
                          // into xc_dst [n][H] for the dW GEMMs that run after it has changed
-                         const float* xc_src = nullptr, int64_t xc_ld = 0, float* xc_dst = nullptr);
+                         const float* xc_src = nullptr, int64_t xc_ld = 0, float* xc_dst = nullptr,
+                         // wct != NULL: [Wq | Wk | Wv]^T of the two blocks as packed MFMA fragments (attn_wct_floats each,
+                         // k_pack_wot): dL/dx_cond += dqkv Wcat^T runs on the matrix cores (k_attn_bwd_dx_mfma)
+                         const float* const* wct = nullptr);
+// [Wq | Wk | Wv]^T ([P, H], P = 2 heads kq + v) as fragments: Bp[kg][nt][lane][q] = Wcat[16 nt + (lane & 15)][16 kg + 4 (lane >> 4) + q]
+size_t attn_wct_floats(const GnfAttn* at, int32_t H);
 
 
 // thin y = act(x W + b) through the split-K generic GEMM (gnf_train.hip); 1 = not thin, the caller runs its own kernel

@@ -1011,6 +1011,7 @@ struct BwdPlan {
     // float offsets.  single: g, invdeg, bnpart, st, wslab, bslab, qkv, dagg, stats;  per set: the rest
     size_t g, invdeg, bnpart, st, wslab, bslab, qkv, dagg, stats, splitk, lny, lnpart;
     size_t wot, wot_each;  // attention nets: Wo of every net of the flow as packed transposed fragments (k_pack_wot), floats per net
+    size_t wct, wct_each;  // ... and [Wq | Wk | Wv]^T (attn_wct_floats) for the matrix-core form of dL/dx_cond
     size_t splitk_each;  // floats of split-K scratch per net
     size_t h0, h0b, acts, gst, dpb, dh0, xc, dqkv, agg;
     int n_sets;
@@ -1098,6 +1099,8 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net, int n_sets
     if (net->attn) {  // (s-nets first, then t-nets: n_nets_each of either)
         p.wot_each = al64((size_t)((p.C + 15) & ~15) * (size_t)((p.NV + 15) & ~15));
         p.wot = off, off += 2 * (size_t)n_nets_each * p.wot_each;
+        p.wct_each = al64(attn_wct_floats(net->attn, p.H));
+        p.wct = off, off += 2 * (size_t)n_nets_each * p.wct_each;
     }
     // slabs of the split-K path of thin generic-path GEMMs (launch_gemm): only launches with < 96 tiles take it, i.e.
     // fewer than 48 row tiles per net and one or two column tiles; 16 chunks at most
@@ -1131,18 +1134,40 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net, int n_sets
 // over the C axis, column tiles over the NV axis - for the dagg row of the backward tile kernel (bwd_args_add_dagg_row)
 struct PackWot {
     const float* wo[64];
+    const float* wq[64];
+    const float* wk[64];
+    const float* wv[64];
     float* out[64];
+    float* out_ct[64];  // [Wq | Wk | Wv]^T fragments: Bp[kg][nt][lane][q] = Wcat[16 nt + (lane & 15)][16 kg + 4 (lane >> 4) + q]
     int NV, C, NVp, Cp;
+    int H, nq, vd, Pp, Hp;
 };
 __global__ __launch_bounds__(256) void k_pack_wot(const PackWot b) {
     const int i = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (i >= b.NVp * b.Cp) return;
     const int q = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
-    const int nts = b.NVp >> 4;
-    const int kg = blk / nts, nt = blk - kg * nts;
-    const int ko = 16 * kg + 4 * (lane >> 4) + q;  // along C
-    const int ci = 16 * nt + (lane & 15);           // along NV
-    b.out[blockIdx.y][i] = (ci < b.NV && ko < b.C) ? b.wo[blockIdx.y][(int64_t)ci * b.C + ko] : 0.f;
+    if (i < b.NVp * b.Cp) {
+        const int nts = b.NVp >> 4;
+        const int kg = blk / nts, nt = blk - kg * nts;
+        const int ko = 16 * kg + 4 * (lane >> 4) + q;  // along C
+        const int ci = 16 * nt + (lane & 15);           // along NV
+        b.out[blockIdx.y][i] = (ci < b.NV && ko < b.C) ? b.wo[blockIdx.y][(int64_t)ci * b.C + ko] : 0.f;
+    }
+    if (i < b.Pp * b.Hp) {
+        const int nts = b.Hp >> 4;
+        const int kg = blk / nts, nt = blk - kg * nts;
+        const int c = 16 * kg + 4 * (lane >> 4) + q;   // along P: q columns, k columns, v columns
+        const int f = 16 * nt + (lane & 15);            // along H
+        float v = 0.f;
+        if (f < b.H) {
+            if (c < b.nq)
+                v = b.wq[blockIdx.y][f * b.nq + c];
+            else if (c < 2 * b.nq)
+                v = b.wk[blockIdx.y][f * b.nq + (c - b.nq)];
+            else if (c < 2 * b.nq + b.vd)
+                v = b.wv[blockIdx.y][f * b.vd + (c - 2 * b.nq)];
+        }
+        b.out_ct[blockIdx.y][i] = v;
+    }
 }
 
 static const GnfMlp* pick_net(const GnfFlow* f, const GnfMlp* nets, int half, int i) {
@@ -2015,11 +2040,18 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
         PackWot pw;
         memset(&pw, 0, sizeof(pw));
         for (int k = 0; k < n_nets_each; ++k) {
-            pw.wo[k] = flow->s_nets[k].attn->Wo, pw.wo[n_nets_each + k] = flow->t_nets[k].attn->Wo;
-            pw.out[k] = wsf + p.wot + (size_t)k * p.wot_each, pw.out[n_nets_each + k] = wsf + p.wot + (size_t)(n_nets_each + k) * p.wot_each;
+            for (int q = 0; q < 2; ++q) {
+                const GnfAttn* at = q ? flow->t_nets[k].attn : flow->s_nets[k].attn;
+                const int ix = q * n_nets_each + k;
+                pw.wo[ix] = at->Wo, pw.wq[ix] = at->Wq, pw.wk[ix] = at->Wk, pw.wv[ix] = at->Wv;
+                pw.out[ix] = wsf + p.wot + (size_t)ix * p.wot_each;
+                pw.out_ct[ix] = wsf + p.wct + (size_t)ix * p.wct_each;
+            }
         }
         pw.NV = p.NV, pw.C = p.C, pw.NVp = (p.NV + 15) & ~15, pw.Cp = (p.C + 15) & ~15;
-        hipLaunchKernelGGL(k_pack_wot, dim3((unsigned)((pw.NVp * pw.Cp + 255) / 256), (unsigned)(2 * n_nets_each)), dim3(256), 0, st, pw);
+        pw.H = p.H, pw.nq = p.nh * p.kq, pw.vd = p.vd, pw.Pp = (p.P + 15) & ~15, pw.Hp = (p.H + 15) & ~15;
+        const int pack_elems = pw.NVp * pw.Cp > pw.Pp * pw.Hp ? pw.NVp * pw.Cp : pw.Pp * pw.Hp;
+        hipLaunchKernelGGL(k_pack_wot, dim3((unsigned)((pack_elems + 255) / 256), (unsigned)(2 * n_nets_each)), dim3(256), 0, st, pw);
         GNF_LAUNCH_CHECK("k_pack_wot");
         wot_packed = true;
     }
@@ -2060,7 +2092,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     // the attention front-end backwards: dagg = dnew Wo^T ([nodes, C] x [C, heads*v]; Wo is [heads*v, C]: rows = output
     // columns), then the edge kernels; dL/dx_cond accumulates into g_cond
     auto attention_backward = [&](const GnfMlp* const* nets_, const BwdOperands& o_, float* g_cond, const AttnBnFold* bnf,
-                                  const float* x_cond_, bool have_dagg = false) -> int {
+                                  const float* x_cond_, bool have_dagg = false, const float* const* wct_ = nullptr) -> int {
         const GnfAttn* at[2] = {nets_[0]->attn, nets_[1]->attn};
         const int off = at[0]->concat ? D / 2 : 0;
         if (!have_dagg) {  // (else: the backward tile kernel's last table row has written it)
@@ -2074,7 +2106,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             if (rc_) return rc_;
         }
         return launch_attn_backward(at, n, D / 2, p.in0, csr->rowptr, csr->col, csr_t->rowptr, csr_t->col, o_.qkv, o_.dh0, o_.gst,
-                                    o_.dqkv, o_.agg, o_.dagg, o_.stats, g_cond, D, st, csr->n_edges, bnf, x_cond_, ld, o_.xc);
+                                    o_.dqkv, o_.agg, o_.dagg, o_.stats, g_cond, D, st, csr->n_edges, bnf, x_cond_, ld, o_.xc, wct_);
     };
     int32_t bn_pre = 0;  // batch-norm backward moments left by the attention backward's last kernel (partial rows)
     DwLaunch pend[2];
@@ -2156,10 +2188,15 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                                     folded ? &bf : nullptr);
                 if (rc) return rc;
                 bool have_dagg = false;
+                const float* wct[2] = {nullptr, nullptr};
                 if (attn && wot_packed) {  // dagg = dnew Wo^T as the tile kernel's last row instead of a GEMM launch
                     const int ni = flow->weight_sharing ? half : half * T + i;
                     const float* wot[2] = {wsf + p.wot + (size_t)ni * p.wot_each, wsf + p.wot + (size_t)(n_nets_each + ni) * p.wot_each};
                     have_dagg = bwd_args_add_dagg_row(&ba, wot, o.dagg, p.C, p.NV, nets[0]->attn->concat ? H : 0);
+                    if (!(opt(OPT_DW_DEBUG) & 64)) {  // (dw_debug bit 64: the scalar form of dL/dx_cond, A/B)
+                        wct[0] = wsf + p.wct + (size_t)ni * p.wct_each;
+                        wct[1] = wsf + p.wct + (size_t)(n_nets_each + ni) * p.wct_each;
+                    }
                 }
                 if (mstashed) {
                     const float* slot = flow->mlp_stash + (size_t)(2 * i + half) * msl.slot;
@@ -2194,7 +2231,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                     const AttnBnFold bnf{z + co, ld, bq ? bq->gamma : nullptr, bq ? bq->beta : nullptr,
                                          reinterpret_cast<double*>(wsf + p.bnpart), &bn_pre};
                     bn_pre = 0;
-                    rc = attention_backward(nets, o, g + co, bq ? &bnf : nullptr, x_cond, have_dagg);
+                    rc = attention_backward(nets, o, g + co, bq ? &bnf : nullptr, x_cond, have_dagg, wct[0] ? wct : nullptr);
                     if (rc) return rc;
                 } else if (have_fold) {
                     fold_dh[0] = o.dh0[0], fold_dh[1] = o.dh0[1];
