@@ -402,10 +402,10 @@ __global__ __launch_bounds__(512) void k_attn_bwd_send(const AttnBwdArgs a, int 
 // statistics' third block for the sender pass.
 // PAR = 2: two lanes (lane, lane ^ 32) share a receiver row, each walks one half of its edges; the sums are added at the
 // end and lane parity 0 writes.
-template <int KQM, int VDM, bool WIN, int PAR = 1>
+template <int KQM, int VDM, bool WIN, int PAR = 1, bool FX = false>
 __device__ __forceinline__ void attn_recv_thread(const AttnBwdArgs& a, int net, int r, int h, const float* win,
                                                  int win_lo, int WS, const int* cols, int col_base, bool v2, int par = 0) {
-    const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
+    const int nh = FX ? 8 : a.nh, kq = FX ? KQM : a.kq, vd = FX ? VDM : a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
     const float* qkv = a.qkv[net];
     float kreg[KQM], dreg[VDM];
 #pragma unroll
@@ -479,9 +479,9 @@ __device__ __forceinline__ void attn_recv_thread(const AttnBwdArgs& a, int net, 
 
 // ROWS: receiver rows per workgroup (lanes ROWS .. 63 of every head's wave idle).  64 suits large batches of complete
 // graphs (the window IS the graph); 32-row tiles put twice as many CUs to work and split every row's edges over two lanes.
-template <int KQM, int VDM, int ROWS>
+template <int KQM, int VDM, int ROWS, bool FX = false>
 __device__ __forceinline__ void attn_recv_tile(const AttnBwdArgs& a, int net, int tile, int win_cap, float* sm) {
-    const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd;
+    const int nh = FX ? 8 : a.nh, kq = FX ? KQM : a.kq, vd = FX ? VDM : a.v, nq = nh * kq, P = 2 * nq + vd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = tile * ROWS;
     int* s_rp = reinterpret_cast<int*>(sm);
@@ -517,10 +517,10 @@ __device__ __forceinline__ void attn_recv_tile(const AttnBwdArgs& a, int net, in
     if (wave < nh && row_l < ROWS && r < a.n) {
         const bool even = ((kq | vd | nq) & 1) == 0;
         if (lo >= 0)
-            attn_recv_thread<KQM, VDM, true, PAR>(a, net, r, wave, win, lo, WS, cols, col_base,
+            attn_recv_thread<KQM, VDM, true, PAR, FX>(a, net, r, wave, win, lo, WS, cols, col_base,
                                                   even && (reinterpret_cast<uintptr_t>(win) & 7) == 0, par);
         else
-            attn_recv_thread<KQM, VDM, false, PAR>(a, net, r, wave, win, 0, WS, cols, col_base,
+            attn_recv_thread<KQM, VDM, false, PAR, FX>(a, net, r, wave, win, 0, WS, cols, col_base,
                                                    even && (reinterpret_cast<uintptr_t>(qkv) & 7) == 0, par);
     }
 }
@@ -535,11 +535,11 @@ __global__ __launch_bounds__(512) void k_attn_bwd_recv_rows(const AttnBwdArgs a,
 // come from global memory)
 // DG (one launch, window too wide for the LDS): delta formed per edge from global memory - nothing may be read that the
 // receiver tiles of the same launch write
-template <int KQM, int VDM, bool WIN, bool SW, bool DG, int PAR = 1>   // PAR = 2: lanes (lane, lane ^ 32) share a sender row
+template <int KQM, int VDM, bool WIN, bool SW, bool DG, int PAR = 1, bool FX = false>   // PAR = 2: lanes (lane, lane ^ 32) share a sender row
 __device__ __forceinline__ void attn_send_thread(const AttnBwdArgs& a, int net, int u_, int h, const float* win,
                                                  int win_lo, int WS, const int* cols, int col_base, bool v2, float* dvp_out,
                                                  int par = 0) {
-    const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
+    const int nh = FX ? 8 : a.nh, kq = FX ? KQM : a.kq, vd = FX ? VDM : a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
     const float* qkv = a.qkv[net];
     const float* dagg = a.dagg[net];
     const float* stats = a.stats[net];
@@ -636,9 +636,9 @@ __device__ __forceinline__ void attn_send_thread(const AttnBwdArgs& a, int net, 
 // SW (the one-launch form): the window rows also carry the receivers' m | Z | delta, delta formed here from the staged dagg
 // rows and the forward pass's attended values - nothing the receiver tiles write is read.  (On the complete 100-node
 // graphs of the drivers' datasets the window of a tile that straddles two graphs has no room for them: two launches.)
-template <int KQM, int VDM, int ROWS, bool SW>
+template <int KQM, int VDM, int ROWS, bool SW, bool FX = false>
 __device__ __forceinline__ void attn_send_tile(const AttnBwdArgs& a, int net, int tile, int win_cap, float* sm) {
-    const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
+    const int nh = FX ? 8 : a.nh, kq = FX ? KQM : a.kq, vd = FX ? VDM : a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = tile * ROWS;
     int* s_rp = reinterpret_cast<int*>(sm);
@@ -699,10 +699,10 @@ __device__ __forceinline__ void attn_send_tile(const AttnBwdArgs& a, int net, in
     if (wave < nh && row_l < ROWS && u_ < a.n) {
         const bool even = ((kq | vd | nq | NV) & 1) == 0;
         if (lo >= 0)
-            attn_send_thread<KQM, VDM, true, SW, false, PAR>(a, net, u_, wave, win, lo, WS, cols, col_base,
+            attn_send_thread<KQM, VDM, true, SW, false, PAR, FX>(a, net, u_, wave, win, lo, WS, cols, col_base,
                                                              even && (reinterpret_cast<uintptr_t>(win) & 7) == 0, dvp, par);
         else
-            attn_send_thread<KQM, VDM, false, false, SW, PAR>(a, net, u_, wave, win, 0, WS, cols, col_base,
+            attn_send_thread<KQM, VDM, false, false, SW, PAR, FX>(a, net, u_, wave, win, 0, WS, cols, col_base,
                                                               even && ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(dagg)) & 7) == 0, dvp, par);
     }
     // v is shared by the heads: dv[u, :] = sum over the head waves (through the LDS region the window occupied)
@@ -729,14 +729,15 @@ __global__ __launch_bounds__(512) void k_attn_bwd_send_rows(const AttnBwdArgs a,
 // in dispatch order), [2 ts, 2 ts + 2 tr) the receiver tiles (RR rows each).  One workgroup per CU (the LDS window), so
 // the launcher picks the tile sizes that make the launch one round of the chip where it can: the config-2 batch (2718
 // nodes) is 170 sender tiles of 32 rows + 86 receiver tiles of 64 rows = 256 workgroups.
-template <int KQM, int VDM, int RS, int RR>
+// FX: 8 heads of kq = KQM, v = VDM (the drivers' defaults, run_grevnet.py:74-76) as compile-time constants
+template <int KQM, int VDM, int RS, int RR, bool FX = false>
 __global__ __launch_bounds__(512) void k_attn_bwd_edges(const AttnBwdArgs a, int cap_recv, int cap_send, int ts) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x;
     if (b < 2 * ts)
-        attn_send_tile<KQM, VDM, RS, true>(a, b & 1, b >> 1, cap_send, sm);
+        attn_send_tile<KQM, VDM, RS, true, FX>(a, b & 1, b >> 1, cap_send, sm);
     else
-        attn_recv_tile<KQM, VDM, RR>(a, (b - 2 * ts) & 1, (b - 2 * ts) >> 1, cap_recv, sm);
+        attn_recv_tile<KQM, VDM, RR, FX>(a, (b - 2 * ts) & 1, (b - 2 * ts) >> 1, cap_recv, sm);
 }
 
 // g[r, f] += sum over nets of ( dq Wq^T + dk Wk^T + dv Wv^T )[r, f]  (+ dh0[r, f] when concatenated)
@@ -1153,7 +1154,9 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
                 const dim3 egrid((unsigned)(2 * ts + 2 * tr));
                 auto go1 = [&](auto rs_c, auto rr_c) {
                     constexpr int RS = decltype(rs_c)::value, RR = decltype(rr_c)::value;
-                    if (small)
+                    if (a.nh == 8 && a.kq == 10 && a.v == 10 && RS == 32 && RR == 64 && !(opt(OPT_DW_DEBUG) & 128))  // (dw_debug bit 128: the run-time geometry instance, A/B)
+                        hipLaunchKernelGGL((k_attn_bwd_edges<10, 10, RS, RR, true>), egrid, dim3(512), (size_t)kRowsLdsBudget, st, a, capr, capw, ts);
+                    else if (small)
                         hipLaunchKernelGGL((k_attn_bwd_edges<10, 10, RS, RR>), egrid, dim3(512), (size_t)kRowsLdsBudget, st, a, capr, capw, ts);
                     else
                         hipLaunchKernelGGL((k_attn_bwd_edges<32, 32, RS, RR>), egrid, dim3(512), (size_t)kRowsLdsBudget, st, a, capr, capw, ts);
