@@ -968,44 +968,81 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dx_mfma(const AttnDxArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lrow = lane & 15, lgrp = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * kDxmRows;
     const int rows = (int)((a.n - row0) < kDxmRows ? (a.n - row0) : kDxmRows);
-    // ---- dqkv rows of both nets -> LDS (zero padded), eight loads in flight per thread
+    // Every global read of the workgroup is requested before the first one is consumed (one round trip to memory instead
+    // of five): the weight fragments of this wave's first tile, the dqkv rows, and the epilogue's operands of the
+    // thread's first two elements (all of them when H <= 32).
+    // (buffer loads: one descriptor per array, a 32-bit VGPR offset per load - with 64-bit address arithmetic per load
+    // the ISSUE of these ~50 loads alone took 7 k cycles; rows past the batch / columns past P come back as zeros by the
+    // descriptor's range check)
+    f32x4_dx b0[kDxmMaxKG];
+    const int net0 = wave / nts, nt0 = wave - net0 * nts;  // (idx = wave: the first (net, column tile) of this wave)
+    if (wave < 2 * nts) {
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(net0 ? a.wct[1] : a.wct[0]), 0,
+                                                                             Pp * Hp * 4, 0x00020000);
+        const int vo = (nt0 * 256 + lane * 4) * 4, kstride = nts * 1024;
+#pragma unroll
+        for (int u = 0; u < kDxmMaxKG; ++u)
+            b0[u] = __builtin_bit_cast(f32x4_dx, __builtin_amdgcn_raw_buffer_load_b128(wr, vo + (u < kgs ? u : kgs - 1) * kstride, 0, 0));
+    }
+    // (thread = column, a loop over the 2 x 16 rows: no integer divisions in the index arithmetic - with i / Pp per element
+    // this phase took 19 k cycles of the kernel's 26 k)
+    float av_[2 * kDxmRows];
     {
-        const int per_net = kDxmRows * Pp, total = 2 * per_net;
-        for (int base = tid; base < total; base += 8 * 256) {
-            float v[8];
+        const int live_bytes = rows * P * 4;
+        const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dqkv[0] + row0 * P), 0, live_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dqkv[1] + row0 * P), 0, live_bytes, 0x00020000);
+        const int vcol = tid < P ? tid * 4 : 0x7ffffff0;  // (out of range: zero)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + u * 256;
-                const int net = i >= per_net ? 1 : 0, j = i - net * per_net;
-                const int rl = j / Pp, c = j - rl * Pp;
-                const bool live = i < total && rl < rows && c < P;
-                const float* src = net ? a.dqkv[1] : a.dqkv[0];
-                v[u] = live ? src[(row0 + rl) * P + c] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + u * 256;
-                if (i < total) {
-                    const int net = i >= per_net ? 1 : 0, j = i - net * per_net;
-                    const int rl = j / Pp, c = j - rl * Pp;
-                    A[(net * kDxmRows + rl) * lda + c] = v[u];
-                }
-            }
+        for (int rl = 0; rl < kDxmRows; ++rl) {
+            const int vo = tid < P ? vcol + rl * P * 4 : vcol;
+            av_[rl] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0, vo, 0, 0));
+            av_[kDxmRows + rl] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, vo, 0, 0));
         }
     }
+    float e_s0[2] = {0.f, 0.f}, e_y[2] = {0.f, 0.f}, e_xc[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + u * 256;
+        const int rl = i / H, f = i - rl * H;
+        if (i < kDxmRows * H && rl < rows) {
+            const int64_t r = row0 + rl;
+            float s0 = a.g[r * a.ldg + f];
+#pragma unroll
+            for (int net = 0; net < 2; ++net) {
+                if (a.concat) s0 += a.dh0[net][r * a.in0 + f];
+                if (a.gst[net]) s0 += a.gst[net][r * H + f];
+            }
+            e_s0[u] = s0;
+            if (a.bn_part) e_y[u] = a.bn_y[r * a.bn_ld + f];
+            if (a.xc_dst) e_xc[u] = a.xc_src[r * a.xc_ld + f];
+        }
+    }
+    if (tid < Pp) {
+#pragma unroll
+        for (int rr = 0; rr < 2 * kDxmRows; ++rr) A[rr * lda + tid] = av_[rr];
+    }
+    for (int c = tid + 256; c < Pp; c += 256)  // (more than 256 columns: the rest, plainly)
+        for (int rr = 0; rr < 2 * kDxmRows; ++rr) {
+            const int rl = rr & (kDxmRows - 1);
+            A[rr * lda + c] = (c < P && rl < rows) ? (rr >= kDxmRows ? a.dqkv[1] : a.dqkv[0])[(row0 + rl) * P + c] : 0.f;
+        }
     __syncthreads();
     // ---- wave = (net, column tile): 4 MFMAs per k-group on one accumulator
     for (int idx = wave; idx < 2 * nts; idx += 4) {
         const int net = idx / nts, nt = idx - net * nts;
         const float* wp = (net ? a.wct[1] : a.wct[0]) + (size_t)nt * 256 + lane * 4;
         const float* ab = A + (net * kDxmRows + lrow) * lda + 4 * lgrp;
-        f32x4_dx acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4_dx acc = {0.f, 0.f, 0.f, 0.f};  // (one chain: two interleaved ones measured no faster)
         for (int kg0 = 0; kg0 < kgs; kg0 += kDxmMaxKG) {
             f32x4_dx b[kDxmMaxKG];
 #pragma unroll
             for (int u = 0; u < kDxmMaxKG; ++u) {
-                const int kg = kg0 + u < kgs ? kg0 + u : kgs - 1;
-                b[u] = *reinterpret_cast<const f32x4_dx*>(wp + (size_t)kg * nts * 256);
+                if (idx == wave && kg0 == 0) {
+                    b[u] = b0[u];
+                } else {
+                    const int kg = kg0 + u < kgs ? kg0 + u : kgs - 1;
+                    b[u] = *reinterpret_cast<const f32x4_dx*>(wp + (size_t)kg * nts * 256);
+                }
             }
 #pragma unroll
             for (int u = 0; u < kDxmMaxKG; ++u) {
@@ -1021,25 +1058,32 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dx_mfma(const AttnDxArgs a) {
     }
     __syncthreads();
     // ---- epilogue: g += both nets' products (+ the direct terms), copy of the conditioning half, batch-norm partials
-    for (int i = tid; i < kDxmRows * H; i += 256) {
+    for (int i = tid, u = 0; i < kDxmRows * H; i += 256, ++u) {
         const int rl = i / H, f = i - rl * H;
         const bool live = rl < rows;
-        float gv = 0.f;
+        float gv = 0.f, yv = 0.f;
         if (live) {
             const int64_t r = row0 + rl;
-            float s0 = a.g[r * a.ldg + f];
+            float s0, xc;
+            if (u < 2) {
+                s0 = e_s0[u & 1], yv = e_y[u & 1], xc = e_xc[u & 1];
+            } else {
+                s0 = a.g[r * a.ldg + f];
 #pragma unroll
-            for (int net = 0; net < 2; ++net) {
-                if (a.concat) s0 += a.dh0[net][r * a.in0 + f];
-                if (a.gst[net]) s0 += a.gst[net][r * H + f];
+                for (int net = 0; net < 2; ++net) {
+                    if (a.concat) s0 += a.dh0[net][r * a.in0 + f];
+                    if (a.gst[net]) s0 += a.gst[net][r * H + f];
+                }
+                yv = a.bn_part ? a.bn_y[r * a.bn_ld + f] : 0.f;
+                xc = a.xc_dst ? a.xc_src[r * a.xc_ld + f] : 0.f;
             }
             gv = s0 + (out[rl * ldo + f] + out[(kDxmRows + rl) * ldo + f]);
             a.g[r * a.ldg + f] = gv;
-            if (a.xc_dst) a.xc_dst[r * H + f] = a.xc_src[r * a.xc_ld + f];
+            if (a.xc_dst) a.xc_dst[r * H + f] = xc;
         }
         if (a.bn_part) {
             bg[i] = gv;
-            bx[i] = live ? gv * ((a.bn_y[(row0 + rl) * a.bn_ld + f] - a.bn_beta[f]) / a.bn_gamma[f]) : 0.f;
+            bx[i] = live ? gv * ((yv - a.bn_beta[f]) / a.bn_gamma[f]) : 0.f;
         }
     }
     if (a.bn_part) {
