@@ -341,13 +341,19 @@ template <int TM, int NTHR, bool NT = false>
 __device__ __forceinline__ void tile_dump(const float* __restrict__ src, int LS, float* __restrict__ dump, int64_t dld,
                                           int width, int row0, int n_nodes, int tid) {
     if (((width | (int)dld) & 3) == 0 && (reinterpret_cast<uintptr_t>(dump) & 15) == 0) {
+        // thread = (row, lane of the row): NTHR / TM lanes walk a row 16 bytes each - no division by the run-time width and
+        // ONE 64-bit row address per thread (a flat index i -> (i / w4, i % w4) per element cost ~40 instructions each)
+        static_assert(NTHR % TM == 0, "whole threads per row");
+        constexpr int TPR = NTHR / TM;
         const int w4 = width >> 2;
-        for (int i = tid; i < TM * w4; i += NTHR) {
-            const int rl = i / w4, c4 = (i - rl * w4) * 4;
-            const int r = row0 + rl;
-            if (r < n_nodes) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(src + rl * LS + c4);
-                f32x4* d = reinterpret_cast<f32x4*>(dump + (int64_t)r * dld + c4);
+        const int rl = tid / TPR, c0 = tid - rl * TPR;
+        const int r = row0 + rl;
+        if (r < n_nodes) {
+            const float* sp = src + rl * LS;
+            float* dp = dump + (int64_t)r * dld;
+            for (int c4 = c0; c4 < w4; c4 += TPR) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(sp + 4 * c4);
+                f32x4* d = reinterpret_cast<f32x4*>(dp + 4 * c4);
                 if (NT)
                     __builtin_nontemporal_store(v, d);
                 else
