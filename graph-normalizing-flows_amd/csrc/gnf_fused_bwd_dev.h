@@ -48,6 +48,19 @@ struct BwdArgs {
     // half-step, read instead of recomputed
     const float* st_in[2];                     // [N, H]
     const unsigned long long* mask_in;         // [tile][net][K-1][4][mld] act' ballot words (NULL: timing ablation)
+    // Batch-norm bijector of the PREVIOUS half-step of the walk, undone and differentiated where the coupling stage
+    // reads y_upd / g_upd (NULL bn_part: not folded; the arithmetic of k_bn_bwd_apply, gnf_bn_bwd.hip): every workgroup
+    // adds up the bn_nparts partial rows (sum G, sum G x^ per feature, fp64) the kernel that finished g left, workgroup 0
+    // also writes d gamma / d beta.  Saves that kernel's launch (5.3 us per half-step on the config-2 batch).
+    const double* bn_part;
+    const float* bn_gamma;
+    const float* bn_beta;
+    const float* bn_mean;
+    const float* bn_var;
+    float* bn_dgamma;
+    float* bn_dbeta;
+    int32_t bn_nparts;
+    float bn_eps;
 };
 struct BwdStash {   // one half-step's rows of GnfFlow.mlp_stash as the backward kernel reads them
     const float* st_in[2];
@@ -339,6 +352,51 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
     if constexpr (!STASHED)
         for (int r = 0; r < a.K; ++r) run_row(r);
 
+    // ---- the previous half-step's batch-norm bijector: per-feature constants (see BwdArgs.bn_part) -------------------
+    float* bnc = f_own;  // [6][H]: m1 = mean(gamma Gy), m2 = mean(gamma Gy xh), gamma, beta, sigma, mu (the folded scatter is off)
+    const bool bnf = a.bn_part != nullptr;
+    if (bnf) {
+        double* red = reinterpret_cast<double*>(buf(0, pp ^ 1));  // [G][H][2] (free until the coupling stage writes g_s there)
+        int G = kBwdThreads / H;                                  // (H <= 128: the host checks)
+        if (G > TM * LS / (4 * H)) G = TM * LS / (4 * H);         // ... and as many groups as the buffer holds fp64 pairs for (>= 4)
+        const int c = tid % H, g = tid / H;
+        if (g < G) {
+            double s = 0.0, q = 0.0;
+            for (int b0 = g; b0 < a.bn_nparts; b0 += 8 * G) {  // eight partial pairs in flight per thread
+                double ps[8], pq[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int b = b0 + k * G < a.bn_nparts ? b0 + k * G : g;
+                    ps[k] = a.bn_part[((int64_t)b * H + c) * 2 + 0];
+                    pq[k] = a.bn_part[((int64_t)b * H + c) * 2 + 1];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (b0 + k * G < a.bn_nparts) s += ps[k], q += pq[k];
+            }
+            red[(g * H + c) * 2 + 0] = s;
+            red[(g * H + c) * 2 + 1] = q;
+        }
+        __syncthreads();
+        if (tid < H) {
+            double s = 0.0, q = 0.0;
+            for (int g2 = 0; g2 < G; ++g2) s += red[(g2 * H + tid) * 2 + 0], q += red[(g2 * H + tid) * 2 + 1];
+            const float gm = a.bn_gamma[tid];
+            const double nm = (double)a.n_nodes;
+            bnc[0 * H + tid] = (float)(s / nm) * gm;
+            bnc[1 * H + tid] = (float)(q / nm) * gm;
+            bnc[2 * H + tid] = gm;
+            bnc[3 * H + tid] = a.bn_beta[tid];
+            bnc[4 * H + tid] = sqrtf(a.bn_var[tid] + a.bn_eps);
+            bnc[5 * H + tid] = a.bn_mean[tid];
+            if (bid == 0) {
+                a.bn_dbeta[tid] = (float)s;
+                a.bn_dgamma[tid] = (float)(q - nm / (double)gm);
+            }
+        }
+        __syncthreads();
+    }
+
     // ---- C': coupling, undone and differentiated --------------------------------------------------
     {
         const float* s_lds = buf(0, pp);
@@ -364,8 +422,13 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
                 }
                 float* py = a.y_upd + (int64_t)r * a.ld + f;
                 float* pg = a.g_upd + (int64_t)r * a.ldg + f;
-                const float yv = *py;
+                float yv = *py;
                 float gv = *pg;
+                if (bnf) {  // k_bn_bwd_apply's arithmetic: the gradient through the bijector and its batch moments, the state rebuilt
+                    const float xh = (yv - bnc[3 * H + f]) / bnc[2 * H + f], sig = bnc[4 * H + f];
+                    gv = (bnc[2 * H + f] * gv - bnc[0 * H + f] - xh * bnc[1 * H + f] + xh) / sig;
+                    yv = xh * sig + bnc[5 * H + f];
+                }
                 if (fold) gv = gv + f_own[rl * HP + f] + f_acc[rl * HP + f];
                 const float d = yv - tv;
                 *py = d * expf(-sv);

@@ -2112,6 +2112,22 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     DwLaunch pend[2];
     bool pend_ok[2] = {false, false};
     bool have_fold = false;  // the previous half-step left its dL/dh0 rows for this one's prologue to scatter
+    // the previous half-step's batch-norm bijector, left for this half-step's tile kernel to undo where it reads the
+    // half it updates (BwdArgs.bn_part): merged walk, partial sums left by the attention backward's last kernel, no
+    // cross-rank moments; dw_debug bit 256 keeps k_bn_bwd_apply's own launch (A/B)
+    struct PendingBn {
+        const GnfBatchNorm* bn = nullptr;
+        const GnfBatchNorm* gbn = nullptr;
+        int nparts = 0;
+        int co = 0;
+    } pend_bn;
+    auto flush_bn = [&]() -> int {
+        if (!pend_bn.bn) return GNF_OK;
+        const int rc_ = launch_bn_backward(flow, pend_bn.bn, pend_bn.gbn, z + pend_bn.co, ld, g + pend_bn.co, D, n, H,
+                                           reinterpret_cast<double*>(wsf + p.bnpart), st, pend_bn.nparts);
+        pend_bn.bn = nullptr;
+        return rc_;
+    };
     const float* fold_dh[2] = {nullptr, nullptr};
     for (int i = T - 1; i >= 0; --i)
         for (int half = 1; half >= 0; --half) {
@@ -2187,6 +2203,15 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                                     o.h0[0], attn ? h0c : nullptr, o.hin, p.lmax, o.dPs, p.lmax, o.gst, o.dh0, &ba, &mt, &tiles, &lds,
                                     folded ? &bf : nullptr);
                 if (rc) return rc;
+                if (pend_bn.bn) {  // (pend_bn.co is this half-step's updated half by construction)
+                    ba.bn_part = reinterpret_cast<const double*>(wsf + p.bnpart);
+                    ba.bn_nparts = pend_bn.nparts;
+                    ba.bn_gamma = pend_bn.bn->gamma, ba.bn_beta = pend_bn.bn->beta;
+                    ba.bn_mean = pend_bn.bn->batch_mean, ba.bn_var = pend_bn.bn->batch_variance;
+                    ba.bn_eps = pend_bn.bn->epsilon;
+                    ba.bn_dgamma = const_cast<float*>(pend_bn.gbn->gamma), ba.bn_dbeta = const_cast<float*>(pend_bn.gbn->beta);
+                    pend_bn.bn = nullptr;
+                }
                 bool have_dagg = false;
                 const float* wct[2] = {nullptr, nullptr};
                 if (attn && wot_packed) {  // dagg = dnew Wo^T as the tile kernel's last row instead of a GEMM launch
@@ -2241,9 +2266,15 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 }
                 ++step;
                 if (flow->bns) {
-                    rc = launch_bn_backward(flow, &flow->bns[half * T + i], &grad->bns[half * T + i], z + co, ld, g + co, D, n, H,
-                                            reinterpret_cast<double*>(wsf + p.bnpart), st, attn ? bn_pre : 0);
-                    if (rc) return rc;
+                    const bool more = !(i == 0 && half == 0);
+                    if (more && attn && bn_pre > 0 && !flow->bn_allreduce && H <= 128 && !folded && !(opt(OPT_DW_DEBUG) & 256)) {
+                        pend_bn.bn = &flow->bns[half * T + i], pend_bn.gbn = &grad->bns[half * T + i];
+                        pend_bn.nparts = bn_pre, pend_bn.co = co;
+                    } else {
+                        rc = launch_bn_backward(flow, &flow->bns[half * T + i], &grad->bns[half * T + i], z + co, ld, g + co, D, n, H,
+                                                reinterpret_cast<double*>(wsf + p.bnpart), st, attn ? bn_pre : 0);
+                        if (rc) return rc;
+                    }
                 }
                 continue;
             }
@@ -2327,6 +2358,8 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 if (rc) return rc;
             }
         }
+    rc = flush_bn();  // (never pending here: the last half-step of the walk runs its bijector's own launch)
+    if (rc) return rc;
     if (merged) {  // drain the pipeline: dW of the last half-step (+ the reduce before it), then its own reduce
         const int last = (step + 1) & 1, before = step & 1;
         rc = launch_half_bwd_dw(nullptr, 0, m_lds, pend_ok[last] ? &pend[last] : nullptr,

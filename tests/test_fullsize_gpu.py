@@ -435,7 +435,8 @@ def test_default_flags_alternative_launch_sequences_agree():
         (fused_variant bit 4) - same arithmetic in the same order: z bitwise;
       * training walk: dagg = dnew Wo^T as the last row of the backward tile kernel vs the GEMM launch in front of the
         edge kernels (dw_debug bit 32), and dL/dx_cond += dqkv [Wq | Wk | Wv]^T on the matrix cores vs the scalar kernel
-        (dw_debug bit 64) - different summation trees: every gradient tensor to 5e-4 of its scale (the float32 CPU autograd of the oracle is 1e-2 off on its worst tensor)."""
+        (dw_debug bit 64), and the batch-norm bijector's backward pass folded into the next tile kernel vs its own launch
+        (dw_debug bit 256) - different summation trees: every gradient tensor to 5e-4 of its scale (the float32 CPU autograd of the oracle is 1e-2 off on its worst tensor)."""
     from gnf_amd import _abi
     from gnf_amd.train import GRevNetTrainer
     g_cpu, p, hp = _bench_batch("default_flags_train")
@@ -467,9 +468,12 @@ def test_default_flags_alternative_launch_sequences_agree():
     assert torch.equal(z0, z2) and loss0 == loss2
     z3, ld3, loss3, g3 = run(dw_debug=64)   # dL/dx_cond += dqkv Wcat^T: the scalar kernel instead of the matrix-core one
     assert torch.equal(z0, z3) and loss0 == loss3
+    z4, ld4, loss4, g4 = run(dw_debug=256)  # the batch-norm bijector's backward pass: its own launch instead of the tile kernel's prologue
+    assert torch.equal(z0, z4) and loss0 == loss4
     gmax = max(float(np.abs(v).max()) for v in g0.values())
     for name in g0:
         scale = max(float(np.abs(g0[name]).max()), 1e-3 * gmax)
         assert float(np.abs(g0[name] - g2[name]).max()) <= 5e-4 * scale, name
         assert float(np.abs(g0[name] - g1[name]).max()) <= 5e-4 * scale, name
         assert float(np.abs(g0[name] - g3[name]).max()) <= 5e-4 * scale, name
+        assert float(np.abs(g0[name] - g4[name]).max()) <= 5e-4 * scale, name
