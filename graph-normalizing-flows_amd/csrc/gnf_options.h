@@ -14,7 +14,8 @@ namespace gnf {
 
 enum OptionId {
     OPT_FORCE_SHAPE = 0,     // fused forward workgroup shape <MT><NETS>, e.g. 21; 0 = by batch size
-    OPT_FUSED_VARIANT,       // fused forward kernel: A/B bits of in-kernel experiments (0 = shipped behaviour)
+    OPT_FUSED_VARIANT,       // fused forward kernel: A/B bits (0 = shipped behaviour): 1 no thin-chunk form, 4 attention front-end as
+                             // its own launch, 64 no closing round of small workgroups in the large-batch kernel
     OPT_FLOW_NO_OOP,         // out-of-place flows: always copy first, then walk in place (A/B of the fused first step)
     OPT_ATTN_EDGE_TILED,     // attention forward: always the edge-tiled kernel
     OPT_ATTN_ROWS,           // attention forward: always the rows kernel
@@ -25,8 +26,10 @@ enum OptionId {
     OPT_DW_WIDE_LDS,         // ... and this LDS request per workgroup (bytes)
     OPT_DW_NO_STREAMK,       // ... whole chunks instead of stream-K runs
     OPT_DW_NO_BUF,           // ... bounds-checked fetch
-    OPT_DW_DEBUG,            // bit 1: print the dW launch plan to stderr (first two launches); bits 2 / 4 / 8: timing ablations
-                             // of the merged backward + dW launch (gnf_train.hip, launch_half_bwd_dw)
+    OPT_DW_DEBUG,            // bit 1: print the dW launch plan to stderr (first two launches); bits 2 / 4 / 8 / 16: timing ablations
+                             // of the merged backward + dW launch (gnf_train.hip, launch_half_bwd_dw); A/B of round 3: 32 dagg
+                             // through a GEMM launch, 64 scalar dL/dx_cond kernel, 128 run-time head geometry in the attention
+                             // backward edge kernels, 256 the batch-norm bijector's backward pass as its own launch
     OPT_BWD_GENERIC,         // backward pass through the generic GEMM path even where the fused kernel fits
     OPT_DW_UNMERGED,         // small batches: dW GEMMs on the auxiliary stream (round-1 scheme) instead of inside the backward launch
     OPT_NO_MLP_STASH,        // ignore GnfFlow.mlp_stash (the backward walk recomputes the MLP rows)
