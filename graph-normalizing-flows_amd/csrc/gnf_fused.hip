@@ -302,18 +302,20 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
                 row[7] = (int)(unsigned)(p1 >> 32);
             }
         }
+        // (the biases are requested before the front-end starts - eight registers per thread through it - so that the slot
+        // between its last barrier and its output projection only issues the weight prefetch: with the sixteen 64-bit
+        // bias addresses formed there the slot took 1.5 k cycles)
         constexpr int kBiasRegsF = 8;
         const int bias_all_f = NETS * a.bias_tot;
         float breg_f[kBiasRegsF];
-        attn_front_tile<true, 10, 10, 4, true, true, FIXED>(fa, smem, row0, buf(0, 0), buf(1, 0), LS, [&] {
-            prefetch_chunk(cur, WPN, voff, b_pre, thin_for(cur.layer));
 #pragma unroll
-            for (int q = 0; q < kBiasRegsF; ++q) {
-                const int i = tid + q * kFusedThreads;
-                const int ic = i < bias_all_f ? i : 0;
-                breg_f[q] = ic < a.bias_tot ? a.bias[0][ic] : a.bias[1][ic - a.bias_tot];
-            }
-        });
+        for (int q = 0; q < kBiasRegsF; ++q) {
+            const int i = tid + q * kFusedThreads;
+            const int ic = i < bias_all_f ? i : 0;
+            breg_f[q] = ic < a.bias_tot ? a.bias[0][ic] : a.bias[1][ic - a.bias_tot];
+        }
+        attn_front_tile<true, 10, 10, 4, true, true, FIXED>(fa, smem, row0, buf(0, 0), buf(1, 0), LS,
+                                                            [&] { prefetch_chunk(cur, WPN, voff, b_pre, thin_for(cur.layer)); });
 #pragma unroll
         for (int q = 0; q < kBiasRegsF; ++q) {
             const int i = tid + q * kFusedThreads;
