@@ -945,8 +945,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dx2(const AttnDxArgs a) {
 // Wcat^T [P x H] with the weights as pre-packed fragments (one 16-byte load per lane and k-group, all requested before the
 // first MFMA), the dqkv rows staged in LDS with coalesced loads; then the same epilogue as k_attn_bwd_dx2 (g, the copy of
 // the conditioning half, the batch-norm partial sums - one [H][2] fp64 row per workgroup of SIXTEEN rows here).
-// 14.7 -> ~6 us per half-step on the config-2 batch: k_attn_bwd_dx2 re-reads both nets' 43 KB of weights element by
-// element in every 8-row workgroup and walks 2 x 170 LDS products per thread.
+// 14.7 -> 9 us per launch on the config-2 batch (4.5 of them the launch itself): k_attn_bwd_dx2 re-reads both nets' 43 KB
+// of weights element by element in every 8-row workgroup and walks 2 x 170 LDS products per thread.
 static constexpr int kDxmRows = 16;
 static constexpr int kDxmMaxKG = 12;  // k-groups of fragments a wave holds in registers at a time
 typedef float f32x4_dx __attribute__((ext_vector_type(4)));
