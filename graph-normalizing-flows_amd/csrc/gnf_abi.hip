@@ -136,7 +136,9 @@ WorkspacePlan plan_workspace(int64_t n_nodes, int32_t H, const GnfMlp* net, int3
     p.partial_stride = partials_per_halfstep(n_nodes);
     p.n_halfsteps = n_halfsteps;
     p.bn_offset = (size_t)(n_halfsteps * p.partial_stride + kMaxGaussBlocks);
-    size_t pb = (p.bn_offset + (size_t)kBnPartRowsMax * (size_t)H * 2) * sizeof(double);
+    p.bn_offset2 = p.bn_offset + (size_t)kBnPartRowsMax * (size_t)H * 2;
+    p.bn_const_offset = p.bn_offset2 + (size_t)kBnPartRowsMax * (size_t)H * 2;
+    size_t pb = (p.bn_const_offset + ((size_t)(n_halfsteps > 0 ? n_halfsteps : 1) * 2 * (size_t)H + 1) / 2) * sizeof(double);
     p.partial_bytes = (pb + 255) / 256 * 256;
     int lmax = 1;
     if (net)
@@ -493,18 +495,17 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
     double* const gpart = partials + 2 * (int64_t)(T > 0 ? T : 1) * p.partial_stride;
     int32_t nsq[2] = {0, 0};
     int32_t bn_pre = 0;  // partial rows the previous half-step's kernel left for the next bijector's moments (0: none)
+    bool bn_on_load = false;  // forward: the bijectors are applied by the half-step kernels themselves (decided at the first half-step)
     const bool sq_ok = direction == GNF_FORWARD && !flow->bns && T > 0 && 2 * ((n + 15) / 16) <= kMaxGaussBlocks;
     if (n > 0) {
         if (direction == GNF_FORWARD) {
             for (int i = 0; i < T; ++i) {  // gnn.py:309-338
                 for (int half = 0; half < 2; ++half) {
-                    if (flow->bns) {  // gnn.py:310-313, 325-328: normalise the conditioning half first
-                        rc = launch_bn_normalize(flow, &flow->bns[half * T + i], half == 0 ? half0 : half1, ld, n, H,
-                                                 partials + p.bn_offset, partials + used, st, bn_pre);
-                        if (rc) return rc;
-                        used += 1;
-                        bn_pre = 0;
-                    }
+                    // gnn.py:310-313, 325-328: the bijector normalises the conditioning half first - as a pass of its own, or
+                    // (attention nets through the fused kernel's attention instance, fused_bn_on_load_ok) where that kernel
+                    // reads the rows, the rows in memory staying raw until the NEXT half-step's kernel rewrites them
+                    double* bn_slot = nullptr;
+                    if (flow->bns) bn_slot = partials + used, used += 1;
                     int32_t np_ = 0;
                     HalfStep hs{csr->rowptr, csr->col, n, half == 0 ? half0 : half1,
                                 half == 0 ? half1 : half0, ld, H, GNF_FORWARD, flow->gnn,
@@ -514,9 +515,32 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
                     mark_first(hs, half);
                     mark_attn(hs, half, i);
                     if (mstash) hs.mlp_stash = mstash + (size_t)(2 * i + half) * mstash_slot;
+                    const int idx = 2 * i + half;
+                    if (flow->bns && idx == 0) bn_on_load = !flow->bn_allreduce && fused_bn_on_load_ok(hs);
+                    double* const bn_rows_in = partials + ((idx & 1) && bn_on_load ? p.bn_offset2 : p.bn_offset);
+                    double* const bn_rows_out = partials + (!(idx & 1) && bn_on_load ? p.bn_offset2 : p.bn_offset);
+                    if (flow->bns && !bn_on_load) {
+                        rc = launch_bn_normalize(flow, &flow->bns[half * T + i], half == 0 ? half0 : half1, ld, n, H,
+                                                 partials + p.bn_offset, bn_slot, st, bn_pre);
+                        if (rc) return rc;
+                        bn_pre = 0;
+                    } else if (flow->bns) {
+                        int rows = bn_pre;
+                        if (rows == 0) {  // (the first bijector, or a predecessor that left no column sums)
+                            rc = launch_bn_stats(half == 0 ? half0 : half1, ld, n, H, bn_rows_in, st, &rows);
+                            if (rc) return rc;
+                        }
+                        float* consts = reinterpret_cast<float*>(partials + p.bn_const_offset);
+                        hs.bnc = &flow->bns[half * T + i];
+                        hs.bnc_part = bn_rows_in, hs.bnc_nparts = rows;
+                        hs.bnc_logdet = bn_slot;
+                        hs.bnc_const = consts + (size_t)idx * 2 * H;
+                        hs.bnu_const = idx > 0 ? consts + (size_t)(idx - 1) * 2 * H : nullptr;
+                        bn_pre = 0;
+                    }
                     // the half this half-step updates is what the NEXT bijector normalises: its column sums ride along
                     if (flow->bns && !(i == T - 1 && half == 1) && (n + 15) / 16 <= kBnPartRowsMax) {
-                        hs.bn_part = partials + p.bn_offset;
+                        hs.bn_part = bn_rows_out;
                         hs.n_bn = &bn_pre;
                     }
                     if (sq_ok && i == T - 1) {  // the outputs of the flow's last two half-steps are z: sum(z^2) rides along
@@ -527,6 +551,10 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
                     if (rc) return rc;
                     used += np_;
                 }
+            }
+            if (bn_on_load && T > 0) {  // the last bijector's conditioning half (columns [H, D)) is still raw in memory
+                rc = launch_bn_affine(half1, ld, n, H, reinterpret_cast<const float*>(partials + p.bn_const_offset) + (size_t)(2 * T - 1) * 2 * H, st);
+                if (rc) return rc;
             }
         } else {
             for (int i = T - 1; i >= 0; --i) {  // gnn.py:347-372

@@ -46,6 +46,21 @@ struct FrontArgs {
     int32_t n_nodes, concat, in0;
     FrontDims d;
     float scale;
+    // Batch-norm bijector in front of the half-step, applied where the conditioning rows are read (the fused kernel's
+    // attention prologue only; NULL bn_part: none - the rows are normalised already).  Every workgroup adds up the
+    // bn_nparts partial rows (sum x, sum x^2 per feature, fp64) of the conditioning half - the arithmetic of k_bn_apply
+    // (gnf_bn.hip) - and normalises its own rows and its window's rows as it stages them; the rows in global memory stay
+    // RAW (the next half-step's kernel, which rewrites that half, applies bn_const_out first); workgroup 0 also leaves
+    // the batch moments, the log-det term and the (scale, shift) pairs.
+    const double* bn_part;
+    const float* bn_gamma;
+    const float* bn_beta;
+    float* bn_mean_out;
+    float* bn_var_out;
+    double* bn_logdet_out;
+    float* bn_const_out;  // [2][H]: scale | shift
+    int32_t bn_nparts;
+    float bn_eps;
 };
 
 // LDS carve (floats); strides + 4 keep rows 16-byte aligned and spread rows over banks
@@ -102,7 +117,7 @@ extern "C" int gnf_debug_read_front_trace(unsigned long long* out) {
 // (a branch around every group of four MFMAs otherwise).
 template <bool HOIST, int KQM, int VDM, int EU, bool EXACT, bool TO_LDS, bool FIXED, class Hook>
 __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __restrict__ lds, const int row0, float* h0_lds0,
-                                                float* h0_lds1, const int h0_ls, Hook&& before_out) {
+                                                float* h0_lds1, const int h0_ls, Hook&& before_out, float* bn_lds = nullptr) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int net = wave >> 2, wn = wave & 3;  // waves 0-3: s-net, 4-7: t-net
@@ -158,12 +173,71 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
             const bool ok = i < kFrRows * Hp && row0 + rl < a.n_nodes && f < H;
             reg[u] = a.x[ok ? (int64_t)(row0 + rl) * a.ldx + f : 0];  // unconditional load from a clamped address
         }
+        // the bijector's per-feature (scale, shift) from the partial sums (see FrontArgs.bn_part), bn_lds = [2][Hp]
+        const bool bnf = TO_LDS && bn_lds != nullptr && a.bn_part != nullptr;  // (workgroup-uniform)
+        if (bnf) {
+            double* red = reinterpret_cast<double*>(lds + L.nets + L.qv_e);  // [G][H][2] (free until the first projection)
+            const int G = kFrThreads / H;
+            const int c = tid % H, g = tid / H;
+            if (g < G) {
+                double s_ = 0.0, q_ = 0.0;
+                for (int b0 = g; b0 < a.bn_nparts; b0 += 8 * G) {  // eight partial pairs in flight per thread
+                    double ps[8], pq[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int b = b0 + k * G < a.bn_nparts ? b0 + k * G : g;
+                        ps[k] = a.bn_part[((int64_t)b * H + c) * 2 + 0];
+                        pq[k] = a.bn_part[((int64_t)b * H + c) * 2 + 1];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (b0 + k * G < a.bn_nparts) s_ += ps[k], q_ += pq[k];
+                }
+                red[(g * H + c) * 2 + 0] = s_;
+                red[(g * H + c) * 2 + 1] = q_;
+            }
+            __syncthreads();
+            double ld_c = 0.0;
+            if (tid < H) {
+                double s_ = 0.0, q_ = 0.0;
+                for (int g2 = 0; g2 < G; ++g2) s_ += red[(g2 * H + tid) * 2 + 0], q_ += red[(g2 * H + tid) * 2 + 1];
+                const double nm = (double)a.n_nodes;
+                const double mean = s_ / nm;
+                double var = q_ / nm - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const float gm = a.bn_gamma[tid];
+                const float sc = gm / sqrtf((float)var + a.bn_eps);
+                const float sh = a.bn_beta[tid] - (float)mean * sc;
+                bn_lds[tid] = sc;
+                bn_lds[Hp + tid] = sh;
+                ld_c = log((double)gm) - 0.5 * log(var + (double)a.bn_eps);
+                if (row0 == 0) {
+                    if (a.bn_mean_out) a.bn_mean_out[tid] = (float)mean;
+                    if (a.bn_var_out) a.bn_var_out[tid] = (float)var;
+                    a.bn_const_out[tid] = sc;
+                    a.bn_const_out[H + tid] = sh;
+                }
+            }
+            if (row0 == 0) {  // log-det term: N * sum_f (log gamma_f - 0.5 log(var_f + eps)), summed in feature order
+                __syncthreads();
+                if (tid < H) red[tid] = ld_c;
+                __syncthreads();
+                if (tid == 0) {
+                    double tot = 0.0;
+                    for (int f = 0; f < H; ++f) tot += red[f];
+                    *a.bn_logdet_out = (double)a.n_nodes * tot;
+                }
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int u = 0; u < kB; ++u) {
             const int i = tid + u * kFrThreads;
             const int rl = i / Hp, f = i - rl * Hp;
             const bool ok = row0 + rl < a.n_nodes && f < H;
-            if (i < kFrRows * Hp) xs_r[rl * L.ldx + f] = ok ? reg[u] : 0.f;
+            float v = reg[u];
+            if (bnf && ok) v = v * bn_lds[f] + bn_lds[Hp + f];
+            if (i < kFrRows * Hp) xs_r[rl * L.ldx + f] = ok ? v : 0.f;
         }
     }
     if (tid <= kFrRows) rp_l[tid] = rp_reg;
@@ -325,6 +399,11 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
                     const int i = base + tid + u * kFrThreads;
                     const int e = i / f4n, f = (i - e * f4n) * 4;
                     if (e >= kFrWin) continue;
+                    if (TO_LDS && bn_lds != nullptr && a.bn_part != nullptr) {  // (the bijector, as for the own rows)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (f + q < H) v4[u][q] = v4[u][q] * bn_lds[f + q] + bn_lds[Hp + f + q];
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (!(e < nw && f + q < H)) v4[u][q] = 0.f;

@@ -242,6 +242,35 @@ int launch_bn_normalize(const GnfFlow* flow, const GnfBatchNorm* bn, float* x, i
     return GNF_OK;
 }
 
+// x[:, :H] = x * scale + shift (scale_shift = [2][H] as the fused kernel's attention instance leaves them): the one
+// bijector of a flow with batch norm on load whose conditioning half no later half-step rewrites
+__global__ __launch_bounds__(256) void k_bn_affine(float* __restrict__ x, int64_t ld, int64_t n, int H,
+                                                   const float* __restrict__ ss) {
+    const int64_t total = n * H;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / H;
+        const int c = (int)(i - r * H);
+        float* p = x + r * ld + c;
+        *p = *p * ss[c] + ss[H + c];
+    }
+}
+int launch_bn_affine(float* x, int64_t ld, int64_t n, int32_t H, const float* scale_shift, hipStream_t st) {
+    if (n == 0) return GNF_OK;
+    int64_t blocks = (n * H + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_bn_affine, dim3((unsigned)blocks), dim3(256), 0, st, x, ld, n, H, scale_shift);
+    GNF_LAUNCH_CHECK("k_bn_affine");
+    return GNF_OK;
+}
+int launch_bn_stats(const float* x, int64_t ld, int64_t n, int32_t H, double* part, hipStream_t st, int* rows_out) {
+    int64_t rpb;
+    const int blocks = bn_blocks(n, &rpb);
+    hipLaunchKernelGGL(k_bn_stats, dim3(blocks), dim3(256), 0, st, x, ld, n, H, rpb, part);
+    GNF_LAUNCH_CHECK("k_bn_stats");
+    *rows_out = blocks;
+    return GNF_OK;
+}
+
 int launch_bn_denormalize(const GnfBatchNorm* bn, float* z, int64_t ld, int64_t n, int32_t H, hipStream_t st) {
     if (n == 0) return GNF_OK;
     int64_t blocks = (n * H + 255) / 256;

@@ -67,7 +67,24 @@ struct HalfStep {
     // sums of squares of the updated half per workgroup (that bijector's batch moments); *n_bn = rows written (0: none)
     double* bn_part = nullptr;
     int32_t* n_bn = nullptr;
+    // forward with the batch-norm bijectors applied where the rows are read (the fused kernel's attention instance only:
+    // fused_bn_on_load_ok): bnc = the bijector in front of THIS half-step - bnc_nparts partial rows (sum x, sum x^2) of
+    // the conditioning half in bnc_part, its batch moments / log-det term / (scale, shift) pairs go to bnc->batch_mean /
+    // batch_variance, bnc_logdet, bnc_const ([2][H]); bnu_const = the previous half-step's pairs (its conditioning half
+    // is the half this one rewrites), or NULL
+    const GnfBatchNorm* bnc = nullptr;
+    const double* bnc_part = nullptr;
+    int32_t bnc_nparts = 0;
+    double* bnc_logdet = nullptr;
+    float* bnc_const = nullptr;
+    const float* bnu_const = nullptr;
 };
+// may a forward flow with batch-norm bijectors hand them to the half-step kernels this way? (the first half-step decides)
+bool fused_bn_on_load_ok(const HalfStep& hs);
+// the pass bn_on_load leaves for the end of the flow: x[:, :H] = x * scale + shift with the last bijector's pairs
+int launch_bn_affine(float* x, int64_t ld, int64_t n, int32_t H, const float* scale_shift, hipStream_t st);
+// partial rows (sum x, sum x^2 per feature, fp64) of x[:, :H] - the first bijector's moments; returns the row count
+int launch_bn_stats(const float* x, int64_t ld, int64_t n, int32_t H, double* part, hipStream_t st, int* rows_out);
 
 // MLP-row stash (GnfFlow.mlp_stash, ABI v8): the rows of a half-step the backward walk would otherwise recompute
 struct MlpStashLayout {
@@ -103,6 +120,8 @@ struct WorkspacePlan {
     int64_t n_halfsteps;
     size_t partial_bytes;    // (n_halfsteps * stride + kMaxGaussBlocks + batch-norm moment partials) * 8, 256-aligned
     size_t bn_offset;        // doubles: start of the batch-norm moment partials inside the fp64 region
+    size_t bn_offset2;       // ... a second set of partial rows (batch norm on load: a kernel reads one set while its epilogue fills the other)
+    size_t bn_const_offset;  // ... and the (scale, shift) pairs of every bijector of the call: n_halfsteps x [2][H] floats
     size_t attn_pack_offset; // floats: fragment-order attention weights of every net of the call, behind the attention region
     size_t attn_pack_per_net;
     size_t scratch_floats;   // layered path activations (+ attention front-end region at its end)

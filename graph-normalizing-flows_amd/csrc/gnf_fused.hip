@@ -283,6 +283,9 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
     // front-end's staging area (dead by the time the first layer's epilogue writes them)
     [[maybe_unused]] unsigned long long* fmask =
         FRONT ? reinterpret_cast<unsigned long long*>(smem + 2 * NETS * TM * LS) : reinterpret_cast<unsigned long long*>(s_col + kColCap);
+    // FRONT: (scale, shift) of the bijector in front of this half-step [2][Hp], then of the previous one [2][Hp] (where the
+    // message-passing prologue has its rowptr / col slices)
+    [[maybe_unused]] float* bn_lds = reinterpret_cast<float*>(s_rowptr);
     if constexpr (FRONT) {
         // ---- attention prologue: the layer table first (its words sit behind the front-end's staging area), then the
         // front-end over this tile's 16 receiver rows; the first chunk's weights and the biases are requested between its
@@ -315,7 +318,12 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
             breg_f[q] = ic < a.bias_tot ? a.bias[0][ic] : a.bias[1][ic - a.bias_tot];
         }
         attn_front_tile<true, 10, 10, 4, true, true, FIXED>(fa, smem, row0, buf(0, 0), buf(1, 0), LS,
-                                                            [&] { prefetch_chunk(cur, WPN, voff, b_pre, thin_for(cur.layer)); });
+                                                            [&] { prefetch_chunk(cur, WPN, voff, b_pre, thin_for(cur.layer)); },
+                                                            bn_lds);
+        if (a.bnu_const) {  // the previous bijector's (scale, shift), for the coupling stage below
+            const int HPb = (H + 15) & ~15;
+            for (int i = tid; i < 2 * H; i += kFusedThreads) bn_lds[2 * HPb + (i < H ? i : HPb + (i - H))] = a.bnu_const[i];
+        }
 #pragma unroll
         for (int q = 0; q < kBiasRegsF; ++q) {
             const int i = tid + q * kFusedThreads;
@@ -495,12 +503,19 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
             if (a.bn_part) xn_lds[rl * LS + f] = 0.f;
             if (r < a.n_nodes) {
                 float sv = s_lds[rl * LS + f], tv = t_lds[rl * LS + f];
+                [[maybe_unused]] const int HPb = (H + 15) & ~15;
                 if (a.residual) {
-                    const float xr = a.x_cond[(int64_t)r * a.ld + f];
+                    float xr = a.x_cond[(int64_t)r * a.ld + f];
+                    if constexpr (FRONT) {
+                        if (fa.bn_part) xr = xr * bn_lds[f] + bn_lds[HPb + f];  // (the conditioning rows in memory are raw)
+                    }
                     sv += xr;
                     tv += xr;
                 }
-                const float xv = a.x_upd_src[(int64_t)r * a.ld + f];
+                float xv = a.x_upd_src[(int64_t)r * a.ld + f];
+                if constexpr (FRONT) {
+                    if (a.bnu_const) xv = xv * bn_lds[2 * HPb + f] + bn_lds[3 * HPb + f];  // the previous half-step's bijector, deferred
+                }
                 const float xn = a.inverse ? (xv - tv) * expf(-sv) : xv * expf(sv) + tv;
                 a.x_upd[(int64_t)r * a.ld + f] = xn;
                 local += (double)sv;
@@ -675,12 +690,24 @@ static int launch_shape(const FusedArgs& a, unsigned grid, size_t lds, hipStream
     return GNF_OK;
 }
 
+static bool front_fold_ok(const HalfStep& hs, FrontArgs* fa);
+bool fused_bn_on_load_ok(const HalfStep& hs) {
+    if (!hs.s_net->attn || hs.direction != GNF_FORWARD || hs.H > 128 || !fused_supported(hs)) return false;
+    if (opt(OPT_FUSED_VARIANT) & 8) return false;  // (A/B: k_bn_apply's own launch per half-step)
+    int MT, NETS;
+    choose_shape(hs, &MT, &NETS);
+    FrontArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    return MT == 1 && NETS == 2 && !choose_big(hs) && front_fold_ok(hs, &fa);
+}
+
 // LDS of the attention instance: the front-end's staging area (or the activation buffers, whichever is larger), then
 // bias | reduction scratch | layer table (no rowptr / col slices of its own: the front-end has them in its area)
 static size_t fused_front_lds_bytes(const GnfMlp* m, const FrontDims& d) {
     const int LS = max_padded_width(m) + 4;
     const size_t act = (size_t)2 * 2 * 16 * LS, fr = (size_t)front_lds(d).total;
-    return ((act > fr ? act : fr) + 2 * (size_t)bias_total(m) + 2) * sizeof(float) + 8 * sizeof(double) + (GNF_MAX_LAYERS * 8) * sizeof(int);
+    return ((act > fr ? act : fr) + 2 * (size_t)bias_total(m) + 2) * sizeof(float) + 8 * sizeof(double) + (GNF_MAX_LAYERS * 8) * sizeof(int) +
+           (size_t)4 * d.Hp * sizeof(float);  // (scale, shift) of two batch-norm bijectors
 }
 
 // May the attention front-end run as the fused kernel's prologue (k_half_fused<1, 2, false, true>)?  The sparse-batch
@@ -795,9 +822,21 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
     a.stash_ld = 0;
     a.stash_mask = nullptr;
     a.stash_mld = 0;
+    a.bnu_const = nullptr;
     FrontArgs fa;
     memset(&fa, 0, sizeof(fa));
     const bool fold = s->attn && MT == 1 && NETS == 2 && !choose_big(hs) && front_fold_ok(hs, &fa);
+    if (hs.bnc) {  // the bijector on load (the caller asked fused_bn_on_load_ok first)
+        if (!fold || hs.direction != GNF_FORWARD) {
+            set_error("internal: batch norm on load handed to a half-step that does not run the fused attention instance");
+            return GNF_EINVAL;
+        }
+        fa.bn_part = hs.bnc_part, fa.bn_nparts = hs.bnc_nparts;
+        fa.bn_gamma = hs.bnc->gamma, fa.bn_beta = hs.bnc->beta, fa.bn_eps = hs.bnc->epsilon;
+        fa.bn_mean_out = hs.bnc->batch_mean, fa.bn_var_out = hs.bnc->batch_variance;
+        fa.bn_logdet_out = hs.bnc_logdet, fa.bn_const_out = hs.bnc_const;
+        a.bnu_const = hs.bnu_const;
+    }
     if (s->attn) {
         if (!fold) {
             float* h0_pair[2];

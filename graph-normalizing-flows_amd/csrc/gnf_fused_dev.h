@@ -63,6 +63,10 @@ struct FusedArgs {
     int32_t stash_ld;
     unsigned long long* stash_mask;           // [tile][net][K-1][4][mld] ballot of "activation > 0" (act' for the way back)
     int32_t stash_mld;
+    // attention instance with the batch-norm bijectors applied on load (FrontArgs.bn_part): (scale, shift) [2][H] of the
+    // bijector in front of the PREVIOUS half-step - that half-step read its conditioning rows raw and normalised them on
+    // the fly; they are the half THIS half-step rewrites, so the coupling applies the pair to the old value first (NULL: none)
+    const float* bnu_const;
 };
 
 

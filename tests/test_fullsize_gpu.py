@@ -433,6 +433,8 @@ def test_default_flags_alternative_launch_sequences_agree():
     give the same numbers on the bench batch with the drivers' default flags:
       * inference / training forward: the attention front-end as the fused kernel's prologue vs its own launch
         (fused_variant bit 4) - same arithmetic in the same order: z bitwise;
+      * forward: the batch-norm bijectors applied where the fused kernel reads the rows vs k_bn_apply's own pass per
+        half-step (fused_variant bit 8): z to 2e-5, log-det and loss to 1e-6;
       * training walk: dagg = dnew Wo^T as the last row of the backward tile kernel vs the GEMM launch in front of the
         edge kernels (dw_debug bit 32), and dL/dx_cond += dqkv [Wq | Wk | Wv]^T on the matrix cores vs the scalar kernel
         (dw_debug bit 64), and the batch-norm bijector's backward pass folded into the next tile kernel vs its own launch
@@ -468,6 +470,9 @@ def test_default_flags_alternative_launch_sequences_agree():
     assert torch.equal(z0, z2) and loss0 == loss2
     z3, ld3, loss3, g3 = run(dw_debug=64)   # dL/dx_cond += dqkv Wcat^T: the scalar kernel instead of the matrix-core one
     assert torch.equal(z0, z3) and loss0 == loss3
+    z5, ld5, loss5, g5 = run(fused_variant=8)  # the bijector's forward pass: k_bn_apply per half-step instead of on load in the fused kernel
+    assert float((z0 - z5).abs().max()) <= 2e-5 and abs(ld0 - ld5) <= 1e-6 * max(1.0, abs(ld0))
+    assert abs(loss0 - loss5) <= 1e-6 * max(1.0, abs(loss0))
     z4, ld4, loss4, g4 = run(dw_debug=256)  # the batch-norm bijector's backward pass: its own launch instead of the tile kernel's prologue
     assert torch.equal(z0, z4) and loss0 == loss4
     gmax = max(float(np.abs(v).max()) for v in g0.values())
@@ -477,3 +482,4 @@ def test_default_flags_alternative_launch_sequences_agree():
         assert float(np.abs(g0[name] - g1[name]).max()) <= 5e-4 * scale, name
         assert float(np.abs(g0[name] - g3[name]).max()) <= 5e-4 * scale, name
         assert float(np.abs(g0[name] - g4[name]).max()) <= 5e-4 * scale, name
+        assert float(np.abs(g0[name] - g5[name]).max()) <= 5e-4 * scale, name
