@@ -48,6 +48,13 @@ WORKLOADS = {
                          hp=dict(activation="relu", attn=dict(num_heads=8, kq_dim=10, v_dim=10, out_dim=80, concat=True,
                                                               kq_dim_division=False, residual=False)),
                          inverse=False, fc=False),
+    # the drivers' DEFAULT flags together at inference: dm_self_attn GNN + use_batch_norm=True (training-mode batch moments in f)
+    "default_flags": dict(desc="community_medium, the drivers' default GNN (dm_self_attn) and use_batch_norm=True, forward + log-prob",
+                          dataset="graph_rnn_community_medium", graphs=64,
+                          hp=dict(activation="relu", use_batch_norm=True,
+                                  attn=dict(num_heads=8, kq_dim=10, v_dim=10, out_dim=80, concat=True,
+                                            kq_dim_division=False, residual=False)),
+                          inverse=False, fc=False),
     # train_grevnet_with_data.py:104-117 defaults (10 coupling steps, 3 x 2048 MLPs, D = 200, fully connected
     # topology): too wide for the LDS-resident kernel, runs the layered path's matrix-core GEMM
     "wide_fc": dict(desc="community_medium, fully connected, latent 2048 x 3 layers, D = 200, T = 10 (layered GEMM path)",

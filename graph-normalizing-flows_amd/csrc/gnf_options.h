@@ -15,7 +15,7 @@ namespace gnf {
 enum OptionId {
     OPT_FORCE_SHAPE = 0,     // fused forward workgroup shape <MT><NETS>, e.g. 21; 0 = by batch size
     OPT_FUSED_VARIANT,       // fused forward kernel: A/B bits (0 = shipped behaviour): 1 no thin-chunk form, 4 attention front-end as
-                             // its own launch, 64 no closing round of small workgroups in the large-batch kernel
+                             // its own launch, 8 batch-norm bijectors as their own pass per half-step, 64 no closing round of small workgroups in the large-batch kernel
     OPT_FLOW_NO_OOP,         // out-of-place flows: always copy first, then walk in place (A/B of the fused first step)
     OPT_ATTN_EDGE_TILED,     // attention forward: always the edge-tiled kernel
     OPT_ATTN_ROWS,           // attention forward: always the rows kernel

@@ -183,7 +183,8 @@ int gnf_abi_version(void);
 /* ABI v6: developer options (kernel-generation A/B switches and launch-shape overrides that tools/ and the parity tests
  * use to reach every code path).  value 0 = automatic.  Names (18): force_shape (<MT><NETS>, e.g. 21; 40 / 30 / 20 / 10:
  * the large-batch kernel with that many row tiles per workgroup at most), fused_variant (bits: 1 no thin-chunk form,
- * 4 attention front-end as its own launch instead of the fused kernel's prologue, 64 no closing round of small
+ * 4 attention front-end as its own launch instead of the fused kernel's prologue, 8 batch-norm bijectors as a pass of
+ * their own per half-step instead of on load in that prologue, 64 no closing round of small
  * workgroups), flow_no_oop (out-of-place flows copy first instead of running the first half-step out of place),
  * attn_edge_tiled, attn_rows, gemm_no_buf, gemm_no_splitk, dw_grouped, dw_wide_units, dw_wide_lds, dw_no_streamk,
  * dw_no_buf, dw_debug (bits: 1 print the dW plan, 2 / 4 / 8 / 16 timing ablations, 32 dagg through a GEMM launch, 64

@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 tag=${1:-r3z}
 cd $R
-for w in config2_fc config2_attn config4 config5 wide_fc config2_train default_flags_train; do
+for w in config2_fc config2_attn default_flags config4 config5 wide_fc config2_train default_flags_train; do
   timeout 300 python bench.py --workload $w --no-cpu-baseline --no-secondary --latency-steps 0 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_$w.json
 done
 timeout 900 python bench.py 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_config2_default_run.json

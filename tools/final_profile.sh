@@ -13,7 +13,7 @@ for w in config2_train default_flags_train; do
   python $R/tools/kstats.py $R/gpurun_out/kt_${tag}_$w 24 > $R/gpurun_out/kt_${tag}_$w.txt
 done
 cd $R
-for w in config2_fc config2_attn config4 config5 wide_fc config2_train default_flags_train; do
+for w in config2_fc config2_attn default_flags config4 config5 wide_fc config2_train default_flags_train; do
   timeout 300 python bench.py --workload $w --no-cpu-baseline --no-secondary --latency-steps 0 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_$w.json
 done
 timeout 600 python bench.py 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_config2_default_run.json
