@@ -46,7 +46,7 @@ def test_make_batch_shards_cover_the_global_batch():
 
 
 def test_workload_table():
-    assert set(bench.WORKLOADS) == {"config2", "config2_fc", "config2_attn", "config4", "config5", "wide_fc", "config2_train", "default_flags_train"}
+    assert set(bench.WORKLOADS) == {"config2", "config2_fc", "config2_attn", "config4", "config5", "wide_fc", "config2_train", "default_flags", "default_flags_train"}
     assert bench.WORKLOADS["config5"]["hp"] == dict(D=256, T=16)
     assert bench.WORKLOADS["config4"]["inverse"] is True
 
