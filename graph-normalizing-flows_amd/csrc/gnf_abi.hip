@@ -495,7 +495,8 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
     double* const gpart = partials + 2 * (int64_t)(T > 0 ? T : 1) * p.partial_stride;
     int32_t nsq[2] = {0, 0};
     int32_t bn_pre = 0;  // partial rows the previous half-step's kernel left for the next bijector's moments (0: none)
-    bool bn_on_load = false;  // forward: the bijectors are applied by the half-step kernels themselves (decided at the first half-step)
+    bool bn_on_load = false;  // the bijectors are applied by the half-step kernels themselves (decided at the walk's first half-step)
+    const GnfBatchNorm* inv_pending = nullptr;  // inverse pass: the bijector the next half-step of the walk applies on load
     const bool sq_ok = direction == GNF_FORWARD && !flow->bns && T > 0 && 2 * ((n + 15) / 16) <= kMaxGaussBlocks;
     if (n > 0) {
         if (direction == GNF_FORWARD) {
@@ -566,14 +567,25 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
                                 partials + used, &np_, nullptr, csr->n_edges};
                     mark_first(hs, half);
                     mark_attn(hs, half, i);
+                    // gnn.py:356-358, 369-371: bn.forward (moving statistics) on the conditioning half AFTER the half-step - a
+                    // pass of its own, or (fused attention instance) left for the next half-step of the walk, which rewrites
+                    // exactly that half, to apply where it reads the old value
+                    if (flow->bns && i == T - 1 && half == 1) bn_on_load = fused_bn_on_load_ok(hs);
+                    if (bn_on_load) hs.bnu_inv = inv_pending;
                     rc = run_half(hs, scratch, st);
                     if (rc) return rc;
                     // partial slots are reused: the inverse pass has no log-det (gnn.py:343-373)
-                    if (flow->bns) {  // gnn.py:356-358, 369-371: bn.forward on the conditioning half afterwards
+                    if (flow->bns && bn_on_load) {
+                        inv_pending = &flow->bns[half * T + i];
+                    } else if (flow->bns) {
                         rc = launch_bn_denormalize(&flow->bns[half * T + i], half == 0 ? half0 : half1, ld, n, H, st);
                         if (rc) return rc;
                     }
                 }
+            }
+            if (inv_pending) {  // the walk's last half-step (i = 0, half = 0): its conditioning half is columns [0, H)
+                rc = launch_bn_denormalize(inv_pending, half0, ld, n, H, st);
+                if (rc) return rc;
             }
         }
     }

@@ -78,6 +78,9 @@ struct HalfStep {
     double* bnc_logdet = nullptr;
     float* bnc_const = nullptr;
     const float* bnu_const = nullptr;
+    // inverse pass, the same idea: the bijector behind the PREVIOUS half-step of the walk, applied where this one reads the
+    // half it rewrites (moving statistics: no moments to gather), or NULL
+    const GnfBatchNorm* bnu_inv = nullptr;
 };
 // may a forward flow with batch-norm bijectors hand them to the half-step kernels this way? (the first half-step decides)
 bool fused_bn_on_load_ok(const HalfStep& hs);

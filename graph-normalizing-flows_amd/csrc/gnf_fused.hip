@@ -323,6 +323,14 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
         if (a.bnu_const) {  // the previous bijector's (scale, shift), for the coupling stage below
             const int HPb = (H + 15) & ~15;
             for (int i = tid; i < 2 * H; i += kFusedThreads) bn_lds[2 * HPb + (i < H ? i : HPb + (i - H))] = a.bnu_const[i];
+        } else if (a.bnu_inv[0]) {  // inverse pass: beta | gamma | sqrt(moving variance + eps) | moving mean
+            const int HPb = (H + 15) & ~15;
+            for (int i = tid; i < H; i += kFusedThreads) {
+                bn_lds[i] = a.bnu_inv[1][i];
+                bn_lds[HPb + i] = a.bnu_inv[0][i];
+                bn_lds[2 * HPb + i] = sqrtf(a.bnu_inv[3][i] + a.bnu_inv_eps);
+                bn_lds[3 * HPb + i] = a.bnu_inv[2][i];
+            }
         }
 #pragma unroll
         for (int q = 0; q < kBiasRegsF; ++q) {
@@ -515,6 +523,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
                 float xv = a.x_upd_src[(int64_t)r * a.ld + f];
                 if constexpr (FRONT) {
                     if (a.bnu_const) xv = xv * bn_lds[2 * HPb + f] + bn_lds[3 * HPb + f];  // the previous half-step's bijector, deferred
+                    else if (a.bnu_inv[0]) xv = (xv - bn_lds[f]) / bn_lds[HPb + f] * bn_lds[2 * HPb + f] + bn_lds[3 * HPb + f];
                 }
                 const float xn = a.inverse ? (xv - tv) * expf(-sv) : xv * expf(sv) + tv;
                 a.x_upd[(int64_t)r * a.ld + f] = xn;
@@ -692,7 +701,7 @@ static int launch_shape(const FusedArgs& a, unsigned grid, size_t lds, hipStream
 
 static bool front_fold_ok(const HalfStep& hs, FrontArgs* fa);
 bool fused_bn_on_load_ok(const HalfStep& hs) {
-    if (!hs.s_net->attn || hs.direction != GNF_FORWARD || hs.H > 128 || !fused_supported(hs)) return false;
+    if (!hs.s_net->attn || hs.H > 128 || !fused_supported(hs)) return false;
     if (opt(OPT_FUSED_VARIANT) & 8) return false;  // (A/B: k_bn_apply's own launch per half-step)
     int MT, NETS;
     choose_shape(hs, &MT, &NETS);
@@ -823,9 +832,20 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
     a.stash_mask = nullptr;
     a.stash_mld = 0;
     a.bnu_const = nullptr;
+    a.bnu_inv[0] = a.bnu_inv[1] = a.bnu_inv[2] = a.bnu_inv[3] = nullptr;
+    a.bnu_inv_eps = 0.f;
     FrontArgs fa;
     memset(&fa, 0, sizeof(fa));
     const bool fold = s->attn && MT == 1 && NETS == 2 && !choose_big(hs) && front_fold_ok(hs, &fa);
+    if (hs.bnu_inv) {
+        if (!fold || hs.direction != GNF_INVERSE) {
+            set_error("internal: batch norm on load (inverse) handed to a half-step that does not run the fused attention instance");
+            return GNF_EINVAL;
+        }
+        a.bnu_inv[0] = hs.bnu_inv->gamma, a.bnu_inv[1] = hs.bnu_inv->beta;
+        a.bnu_inv[2] = hs.bnu_inv->moving_mean, a.bnu_inv[3] = hs.bnu_inv->moving_variance;
+        a.bnu_inv_eps = hs.bnu_inv->epsilon;
+    }
     if (hs.bnc) {  // the bijector on load (the caller asked fused_bn_on_load_ok first)
         if (!fold || hs.direction != GNF_FORWARD) {
             set_error("internal: batch norm on load handed to a half-step that does not run the fused attention instance");

@@ -67,6 +67,11 @@ struct FusedArgs {
     // bijector in front of the PREVIOUS half-step - that half-step read its conditioning rows raw and normalised them on
     // the fly; they are the half THIS half-step rewrites, so the coupling applies the pair to the old value first (NULL: none)
     const float* bnu_const;
+    // inverse pass: gamma, beta, moving mean, moving variance of the bijector BEHIND the previous half-step of the walk
+    // (bn.forward on its conditioning half, gnn.py:356-358,369-371 = the half this half-step rewrites), applied to the
+    // old value on load with k_bn_denorm's own expression (NULL: none)
+    const float* bnu_inv[4];
+    float bnu_inv_eps;
 };
 
 
