@@ -2032,11 +2032,11 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
         return GNF_EWORKSPACE;
     }
     if (merged) aux = nullptr;
-    // attention nets on the merged walk: Wo of every net as transposed fragments, once per call (k_pack_wot) - the tile
+    // attention nets: Wo of every net as transposed fragments, once per call (k_pack_wot) - the tile
     // kernel then forms dagg = dnew Wo^T itself (its last table row) and the GEMM launch in front of the edge kernels
     // goes (7.7 us per half-step on the config-2 batch).  dw_debug bit 32 keeps the GEMM (A/B).
     bool wot_packed = false;
-    if (merged && flow->s_nets[0].attn && n_nets_each <= 32 && !(opt(OPT_DW_DEBUG) & 32)) {
+    if (flow->s_nets[0].attn && n_nets_each <= 32 && !(opt(OPT_DW_DEBUG) & 32)) {
         PackWot pw;
         memset(&pw, 0, sizeof(pw));
         for (int k = 0; k < n_nets_each; ++k) {
@@ -2279,6 +2279,13 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 continue;
             }
             // ---- recompute + coupling + dP chain -------------------------------------------------------------
+            bool nm_have_dagg = false;
+            const float* nm_wct[2] = {nullptr, nullptr};
+            if (attn && wot_packed && !(opt(OPT_DW_DEBUG) & 64)) {
+                const int ni = flow->weight_sharing ? half : half * T + i;
+                nm_wct[0] = wsf + p.wct + (size_t)ni * p.wct_each;
+                nm_wct[1] = wsf + p.wct + (size_t)(n_nets_each + ni) * p.wct_each;
+            }
             if (fused && mstashed) {  // (attention nets, or the auxiliary-stream scheme by option: the stash without the merged launch)
                 float* slot = flow->mlp_stash + (size_t)(2 * i + half) * msl.slot;
                 for (int q = 0; q < 2; ++q)
@@ -2294,6 +2301,11 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 if (rc) return rc;
                 for (int q = 0; q < 2; ++q) ba.st_in[q] = slot + msl.st + (size_t)q * msl.st_each;
                 ba.mask_in = reinterpret_cast<const unsigned long long*>(slot + msl.mask);
+                if (attn && wot_packed) {  // (as on the merged walk)
+                    const int ni = flow->weight_sharing ? half : half * T + i;
+                    const float* wot[2] = {wsf + p.wot + (size_t)ni * p.wot_each, wsf + p.wot + (size_t)(n_nets_each + ni) * p.wot_each};
+                    nm_have_dagg = bwd_args_add_dagg_row(&ba, wot, o.dagg, p.C, p.NV, nets[0]->attn->concat ? H : 0);
+                }
                 rc = launch_half_bwd_fused_stashed(ba, mt, tiles, lds, st);
             } else if (fused) {
                 const float* h0c[2] = {o.h0[0], o.h0[1]};
@@ -2318,7 +2330,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 const AttnBnFold bnf{z + co, ld, bq ? bq->gamma : nullptr, bq ? bq->beta : nullptr,
                                      reinterpret_cast<double*>(wsf + p.bnpart), &bn_pre};
                 bn_pre = 0;
-                rc = attention_backward(nets, o, g + co, bq ? &bnf : nullptr, x_cond);
+                rc = attention_backward(nets, o, g + co, bq ? &bnf : nullptr, x_cond, nm_have_dagg, nm_wct[0] ? nm_wct : nullptr);
             } else {
                 rc = launch_aggregate_bwd(p, csr_t, flow->gnn, wsf + p.invdeg, o.dh0[0], o.dh0[1], g + co, D, st);
             }
