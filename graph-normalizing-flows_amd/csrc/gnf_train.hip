@@ -815,23 +815,6 @@ struct GroupedReduceT {
 using GroupedReduce = GroupedReduceT<kMaxGroup>;
 using GroupedReduceS = GroupedReduceT<kMergedGroup>;
 // element e of job j (the weight gradient first, then the bias gradient)
-template <class GR>
-__device__ __forceinline__ void reduce_element(const GR& g, const int j, const int64_t e) {
-    const ReduceJob job = g.job[j];
-    const int64_t nw = g.nw[j];
-    const int nb = g.nb[j];
-    const int nchunk = g.chunks[j];
-    if (e < nw) {
-        float s = 0.f;
-        for (int c = 0; c < nchunk; ++c) s += job.wslab[(int64_t)c * nw + e];
-        job.gw[e] = g.accumulate ? job.gw[e] + s : s;
-    } else if (e < nw + nb) {
-        const int i = (int)(e - nw);
-        float s = 0.f;
-        for (int c = 0; c < nchunk; ++c) s += job.bslab[(int64_t)c * nb + i];
-        job.gb[i] = g.accumulate ? job.gb[i] + s : s;
-    }
-}
 // All jobs of a reduce as ONE index space, strided over `nthr` threads (this one is thread `t`): every item (four
 // consecutive weight-gradient elements, or one element where a job cannot be read as float4) sums its slabs with up to
 // eight chunk loads in flight, and a thread's items are independent of each other.  (The first version walked job after
@@ -903,8 +886,11 @@ __device__ __forceinline__ void reduce_jobs_strided(const GR& g, const int nj, c
     }
 }
 
-__global__ __launch_bounds__(256) void k_reduce_grouped(const GroupedReduce g) {
-    reduce_element(g, blockIdx.y, (int64_t)blockIdx.x * 256 + threadIdx.x);
+// (one axis over every job's elements, 16 bytes per thread and eight slabs in flight - reduce_jobs_strided, as the merged
+// launch's tile workgroups do it; the per-element form, one 4-byte load per slab in a dependent loop, took 21.7 us per
+// half-step on the 3 200-node batches of the drivers' default loop)
+__global__ __launch_bounds__(256) void k_reduce_grouped(const GroupedReduce g, int nj) {
+    reduce_jobs_strided(g, nj, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
 }
 
 // g[N, D] <- z[N, D]: dL/dz of L = 1/2 sum z^2 + const - logdet
@@ -1535,7 +1521,9 @@ static int run_weight_gemms(const DwLaunch& L, hipStream_t st) {
 
 static int run_weight_reduce(const DwLaunch& L, hipStream_t st) {
     if (L.direct) return GNF_OK;
-    hipLaunchKernelGGL(k_reduce_grouped, dim3((unsigned)((L.maxred + 255) / 256), (unsigned)L.nj), dim3(256), 0, st, L.gr);
+    int64_t blocks = ((L.maxred + 3) / 4 * L.nj + 255) / 256;  // about one 16-byte quad per thread
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(k_reduce_grouped, dim3((unsigned)blocks), dim3(256), 0, st, L.gr, (int)L.nj);
     GNF_LAUNCH_CHECK("k_reduce_grouped");
     return GNF_OK;
 }
@@ -1557,7 +1545,7 @@ static int launch_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJo
 // (profiles/r2u_train_timeline.txt).  Here ONE launch carries, software-pipelined,
 //   workgroups [0, n_bwd)        the backward kernel of half-step k            (half_bwd_body, one 16-node tile each)
 //   workgroups [n_bwd, n_bwd+n_dw) the dW GEMMs of half-step k-1                 (dw_wide_body; its operands are complete)
-//   all workgroups behind n_bwd  the fixed-order slab reduce of half-step k-2  (reduce_element; slab sets alternate)
+//   all workgroups behind n_bwd  the fixed-order slab reduce of half-step k-2  (reduce_jobs_strided; slab sets alternate)
 // so the walk needs no second stream, no events, and the kernel boundary is the only synchronisation.  Every
 // workgroup asks for the backward kernel's LDS footprint (> 80 KB), i.e. one workgroup per CU.
 template <int MT, bool STASHED>
