@@ -2,7 +2,8 @@
 """bench.py - GRevNet forward + log-det throughput on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+    (N>1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, or - when no
+    launcher set WORLD_SIZE - bench.py starts its N ranks itself: self_launch())
 
 One "step" = one pass of the hot path over one batch: GRevNet.f (gnn.py:304-341) + the log-prob
 reductions (run_grevnet.py:290-302) on a synthetic community_medium batch, inputs (node features,
@@ -263,6 +264,61 @@ def cpu_baseline(dicts, params, budget_s=15.0, min_iters=3, warm=1):
                       f"[{' '.join(sweep)}] -> {best_thr} threads; os.cpu_count()={os.cpu_count()}"}, res
 
 
+def self_launch(n, argv, backend):
+    """`python bench.py --gpus N ...` with no launcher in front (WORLD_SIZE unset): start the N ranks ourselves - one child
+    process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment exactly as torch.distributed.run would
+    set them, rendezvous on 127.0.0.1 and a free port.  Rank 0 owns stdout (the ONE JSON line); the other ranks' stdout
+    goes to stderr; stderr is shared.  Returns the exit code: 0 only if every rank exited 0; the first failing rank's
+    code otherwise (the remaining ranks are terminated - they would sit in a collective for ever).  With fewer than N
+    devices a JSON line with an `error` field is printed instead of hanging in init_process_group."""
+    import socket
+    import subprocess
+    one_device = os.environ.get("GNF_BENCH_ONE_DEVICE") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    err = None
+    if have < (1 if one_device else n):
+        err = f"bench.py --gpus {n}: {have} HIP device(s) visible, {1 if one_device else n} needed"
+    elif one_device and backend == "nccl":
+        err = "GNF_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and RCCL refuses two ranks of one device: add --dist-backend gloo"
+    if err:
+        print(json.dumps({"error": err, "n_gpus": n, "devices_visible": have}), flush=True)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GNF_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    deadline = time.time() + float(os.environ.get("GNF_BENCH_LAUNCH_TIMEOUT_S", "3000"))
+    rc, live = 0, set(range(n))
+    while live and rc == 0:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is not None:
+                live.discard(r)
+                if code != 0:
+                    print(f"[bench.py launcher] rank {r} exited with code {code}", file=sys.stderr, flush=True)
+                    rc = code if code > 0 else 1
+        if time.time() > deadline:
+            print("[bench.py launcher] timed out waiting for the ranks", file=sys.stderr, flush=True)
+            rc = 124
+        if live and rc == 0:
+            time.sleep(0.05)
+    for r in live:                      # (exactly the processes started above, by handle)
+        procs[r].terminate()
+    for r in live:
+        try:
+            procs[r].wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -286,9 +342,11 @@ def main():
                     help="run the N > 1 code path (process group + collectives) even with one rank")
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed regions of --steps steps each, back to back: the line reports the median one (+ spread)")
-    ap.add_argument("--all-workloads", action="store_true",
-                    help="also run the other forward workloads (config4, config5, config2_attn) as child processes and "
-                         "attach their headline fields as secondary_workloads (one command reproduces DESIGN.md's table)")
+    ap.add_argument("--no-secondary-workloads", action="store_true",
+                    help="the default config2 run on one GPU also runs config4, config5, config2_attn and default_flags as child "
+                         "processes (3 timed regions each) and attaches their headline fields as secondary_workloads - the "
+                         "at-scale roofline fractions in the same driver-timed line; this flag (or --no-secondary) turns that off")
+    ap.add_argument("--secondary-steps", type=int, default=0, help="steps per timed region of the secondary workloads (0: --steps, capped at 40)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + GNF_BENCH_ONE_DEVICE=1 runs several ranks on ONE GPU to exercise the N>1 logic")
     args = ap.parse_args()
@@ -298,13 +356,15 @@ def main():
     HP.update(WORKLOAD["hp"])
     inverse = WORKLOAD["inverse"]
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by itself (no launcher in front): this process becomes the launcher of its N ranks
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], args.dist_backend))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        args.gpus = world
+    args.gpus = world          # under a launcher the launcher's world size is the truth
+    if os.environ.get("GNF_BENCH_TEST_FAIL_RANK") == str(rank) and world > 1:      # tests: a rank that dies before the rendezvous
+        raise SystemExit(7)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     if os.environ.get("GNF_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
@@ -752,30 +812,44 @@ def main():
         allsh = [torch.zeros_like(shard) for _ in range(world)]
         dist.all_gather(allsh, shard)
         nodes_r, edges_r = [int(t[0]) for t in allsh], [int(t[1]) for t in allsh]
+        out["nccl_ranks_seen"] = dist.get_world_size()      # what the process group itself says after init
+        out["dist_backend"] = dist.get_backend()
+        out["launcher"] = "bench.py itself (one child process per GPU)" if os.environ.get("GNF_BENCH_SELF_LAUNCHED") else "external (torch.distributed.run)"
         out["config"]["nodes_per_rank"] = nodes_r
         out["config"]["edges_per_rank"] = edges_r
         out["config"]["shard_imbalance_max_over_mean"] = {"nodes": round(max(nodes_r) * world / max(1, sum(nodes_r)), 4),
                                                            "edges": round(max(edges_r) * world / max(1, sum(edges_r)), 4)}
-    if rank == 0 and not multi and args.all_workloads:
+    if (rank == 0 and not multi and args.workload == "config2" and not args.layered and not args.no_secondary
+            and not args.no_secondary_workloads and not args.sync_each_step):
         import subprocess
-        sec = {}
-        for wl in ("config4", "config5", "config2_attn"):
-            if wl == args.workload:
-                continue
-            cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", str(args.steps), "--warmup", str(args.warmup),
+        sec, t_sec = {}, time.perf_counter()
+        ksteps = args.secondary_steps or min(args.steps, 40)
+        torch.cuda.synchronize()
+        for wl in ("config4", "config5", "config2_attn", "default_flags"):
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", str(ksteps), "--warmup", str(min(args.warmup, 10)),
                    "--repeats", "3", "--no-cpu-baseline", "--no-secondary", "--latency-steps", "0"]
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            if r.returncode == 0 and lines:
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                err = None if (r.returncode == 0 and lines) else (r.stderr or r.stdout)[-400:]
+            except subprocess.TimeoutExpired:
+                err, lines = "timed out after 600 s", []
+            if err is None:
                 d = json.loads(lines[-1])
-                sec[wl] = {"value": d["value"], "ms_per_step": d["ms_per_step"], "spread": d["spread"],
+                sec[wl] = {"value": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "spread": d["spread"],
                            "frac": d["roofline"]["frac"], "kernel_us": d["roofline"]["kernel_us"],
                            "launches_per_step": d["roofline"]["launches_per_step"], "traffic": d["roofline"]["traffic"],
-                           "nodes": d["config"]["nodes_total"], "workload": d["config"]["workload"],
-                           "round_trip_max_abs_err": d.get("round_trip_max_abs_err")}
+                           "algorithmic_flops_per_launch": d["roofline"]["algorithmic_flops_per_launch"],
+                           "algorithmic_bytes_per_launch": d["roofline"]["algorithmic_bytes_per_launch"],
+                           "kernel_a": d.get("kernel_a"),
+                           "nodes": d["config"]["nodes_total"], "edges": d["config"]["edges_total"], "workload": d["config"]["workload"],
+                           "log_prob_xs_per_node": d.get("log_prob_xs_per_node"),
+                           "round_trip_max_abs_err": d.get("round_trip_max_abs_err"),
+                           "consistency": d.get("consistency")}
             else:
-                sec[wl] = {"error": (r.stderr or r.stdout)[-400:]}
+                sec[wl] = {"error": err}
         out["secondary_workloads"] = sec
+        out["secondary_workloads_wall_s"] = round(time.perf_counter() - t_sec, 1)
     out["consistency"] = line_consistency_errors(out)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -1,8 +1,14 @@
 """bench.py pieces that run without a GPU: the algorithmic work model, the weight
 generator, batch construction + sharding, and the workload table."""
+import json
+import os
+import sys
+
 import numpy as np
 
 import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_algorithmic_work_matches_survey_worked_example():
@@ -76,3 +82,15 @@ def test_line_consistency_checks():
                 assert bench.line_consistency_errors(d) == [], (f, bench.line_consistency_errors(d))
                 seen += 1
     assert seen >= 1
+
+
+def test_bench_gpus_n_without_devices_prints_an_error_line_and_fails():
+    """`python bench.py --gpus 2` with no launcher and fewer than 2 devices: ONE JSON line with an `error` field and a
+    non-zero exit code (not a hang in init_process_group, not a traceback)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and "error" in d and d["devices_visible"] == 0

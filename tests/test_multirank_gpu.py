@@ -56,6 +56,35 @@ def test_bench_n_ranks_on_one_device_match_one_rank_over_the_same_batch(nranks):
     assert one["steps_landed_on_host"] == 6
 
 
+@pytest.mark.timeout(1200)
+def test_bench_gpus_2_launches_its_own_ranks():
+    """The driver's command shape for N > 1 is `python bench.py --gpus N --steps K --warmup W` with NO launcher in front:
+    bench.py starts its N ranks itself (bench.self_launch).  On the one-GPU box the two ranks share cuda:0 and talk over
+    gloo; everything else is the default line (no flags switching legs off)."""
+    env = dict(os.environ, GNF_BENCH_ONE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--dist-backend", "gloo"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1000, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["nccl_ranks_seen"] == 2 and d["dist_backend"] == "gloo"
+    assert d["launcher"].startswith("bench.py itself")
+    assert d["steps"] == 6 and d["warmup"] == 2 and d["steps_landed_on_host"] == 6
+    assert len(d["config"]["nodes_per_rank"]) == 2 and sum(d["config"]["nodes_per_rank"]) == d["config"]["nodes_total"]
+    assert d["consistency"] == []
+    one = _bench(1, 128)
+    assert one["config"]["nodes_total"] == d["config"]["nodes_total"]
+    assert abs(d["log_prob_xs_per_node"] - one["log_prob_xs_per_node"]) <= 1e-9
+    # a rank that dies takes the launch down with a non-zero exit code instead of leaving its peer in a collective
+    r = subprocess.run(cmd, env=dict(env, GNF_BENCH_TEST_FAIL_RANK="1"), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")], (r.returncode, r.stdout[-500:])
+    # RCCL cannot put two ranks on one device: refused up front with an `error` line, not a hang
+    r = subprocess.run(cmd[:-2], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0 and "error" in json.loads(r.stdout.splitlines()[-1])
+
+
 @pytest.mark.timeout(900)
 def test_trainer_step_all_reduce_two_ranks_match_one_process():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_train_check.py")], capture_output=True, text=True,
