@@ -1,9 +1,11 @@
 #!/bin/bash
 # PMC passes for one bench workload under one GNF_OPTIONS setting (run on the GPU box):
-#   tools/pmc_shape.sh <tag> <workload> [GNF_OPTIONS]
+#   tools/pmc_shape.sh <tag> <workload> [GNF_OPTIONS] [kernel-name substrings, comma separated]
 # -> gpurun_out/pmc_<tag>/{kernel_stats.txt, pmc_means.txt}
+# The counter means are printed for the launch's dominant kernel and for every kernel whose name contains one of the
+# substrings of the 4th argument (e.g. "k_aggregate,k_half_bwd_dw"), each with its rocprofv3 average duration.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-tag=$1; wl=$2; export GNF_OPTIONS=$3
+tag=$1; wl=$2; export GNF_OPTIONS=$3; also=$4
 out=$R/gpurun_out/pmc_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
@@ -22,16 +24,28 @@ python - <<PY > $out/pmc_means.txt
 import csv, glob, collections
 rows = list(csv.DictReader(open(glob.glob("$out/trace/**/*kernel_stats.csv", recursive=True)[0])))
 dom = max(rows, key=lambda r: float(r["TotalDurationNs"]))["Name"]
+names = [dom] + [r["Name"] for r in rows if r["Name"] != dom and any(s and s in r["Name"] for s in "$also".split(","))]
+avg = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in rows}
+calls = {r["Name"]: int(r["Calls"]) for r in rows}
 print("# workload $wl  GNF_OPTIONS=$3  kernel sources stamp (bench.kernel_source_stamp):", open("$out/source_stamp.txt").read().strip())
-print("# dominant kernel:", dom[:100])
-print("# PMC passes (separate runs, --pmc only with --kernel-trace): mean per dispatch of the dominant kernel")
-for f in sorted(glob.glob("$out/p*/**/*counter_collection.csv", recursive=True)):
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if r["Kernel_Name"] == dom:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
-        print(f"{sum(v)/len(v):18.1f}  n={len(v):4d}  {k}")
+print("# PMC passes (separate runs, --pmc only with --kernel-trace): mean per dispatch; FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 prints them")
+print("# (HBM-side bytes per launch = FETCH_SIZE x 1024 x 2 [gfx950 correction, MI355X_MICROARCH.md] + WRITE_SIZE x 1024)")
+files = sorted(glob.glob("$out/p*/**/*counter_collection.csv", recursive=True))
+data = [list(csv.DictReader(open(f))) for f in files]
+for k, name in enumerate(names):
+    print(f"# {'dominant kernel' if k == 0 else 'kernel'}: {name[:110]}  (kernel-trace pass: {calls[name]} calls, average {avg[name]:.2f} us)")
+    got = {}
+    for rws in data:
+        agg = collections.defaultdict(list)
+        for r in rws:
+            if r["Kernel_Name"] == name:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for c, v in agg.items():
+            got[c] = sum(v) / len(v)
+            print(f"{sum(v)/len(v):18.1f}  n={len(v):4d}  {c}")
+    if "FETCH_SIZE" in got and "WRITE_SIZE" in got:
+        b = got["FETCH_SIZE"] * 1024 * 2 + got["WRITE_SIZE"] * 1024
+        print(f"#   -> HBM-side traffic {b / 1e6:.2f} MB per launch = {b / avg[name] / 1e3:.1f} GB/s over the kernel-trace average")
 PY
 $B --steps 50 --warmup 10 > $out/bench.json 2> $out/bench.err
 cat $out/kernel_stats.txt $out/pmc_means.txt; tail -1 $out/bench.json
