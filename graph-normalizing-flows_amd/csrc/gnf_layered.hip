@@ -18,11 +18,26 @@ namespace gnf {
 // Kernel A: CSR segmented reduce of neighbour rows (gnn.py:103-104,117-118,151-156).
 // A group of G lanes (G = power of two <= 64) owns one receiver row; lanes run along the feature axis
 // VEC floats each, so every neighbour row is one coalesced read (16 B per lane when VEC = 4) and a
-// wave covers 64/G rows.  Four neighbour rows are in flight per lane; the adds stay in edge order.
+// wave covers 64/G rows.  Eight neighbour rows are in flight per lane; the adds stay in edge order.
 //   mode 0: out[r, f] = eps * x[r, f] + agg        (AggThenMLPBlock)
 //   mode 1: out[r, f] = x[r, f]; out[r, H+f] = agg (ConcatThenMLPBlock)
 //   mode 2: out[r, f] = agg                        (aggregator alone)
+//
+// Hub rows.  A row's loop is a chain of dependent round trips (8 neighbour rows each, ~0.6 us under load): the ego
+// hub of a config-5 graph (in-degree up to 194) took 25 of them, and the launch ended when the last graph's hub did
+// (17.3 us on that batch against 10.3 with every row cut to 8 edges; tools/probes/agg_probe.hip).  The grid is
+// therefore [front | regular]: front workgroup i, dispatched first, scans the rowptr slice of rows [256 i, 256 i + 256)
+// and takes the first kAggFrontRows rows of more than kAggLong edges there - each row's edges split into contiguous
+// segments over the workgroup's lane groups (a group adds its segment up in edge order, 8 rows in flight), the
+// partial sums added up in group order: a fixed order, but not the sequential one (such a row differs from the
+// sequential sum in rounding only).  A regular wave that meets a long row reads the same slice and skips the rows a
+// front workgroup has.  A slice with more than kAggDense long rows (complete graphs: nothing to gain) is left alone.
+// Config-5 batch, H = 128: 17.3 -> 12.5 us alone; H = 32: 12.3 -> 6.1 us; batches without long rows: unchanged.
 // ------------------------------------------------------------------------------------------------
+static constexpr int kAggLong = 32;
+static constexpr int kAggFrontRows = 4;
+static constexpr int kAggDense = 16;
+
 template <int VEC>
 struct VecT;
 template <>
@@ -35,27 +50,22 @@ struct VecT<4> {
 };
 
 template <int VEC>
-__global__ __launch_bounds__(256) void k_aggregate(const int32_t* __restrict__ rowptr,
-                                                   const int32_t* __restrict__ col, int64_t n_nodes,
-                                                   const float* __restrict__ x, int64_t ldx, int H,
-                                                   int mean, int mode, float eps,
-                                                   float* __restrict__ out, int64_t ldo, int G) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_aggregate(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n_nodes, const float* __restrict__ x,
+    int64_t ldx, int H, int mean, int mode, float eps, float* __restrict__ out, int64_t ldo, int G, int n_front) {
     typedef typename VecT<VEC>::type V;
-    // XCD-aware bijective block remap (block b runs on XCD b % 8): consecutive row blocks - the nodes
-    // of one graph and their neighbours - share one XCD's L2 instead of being sprayed over all eight.
-    const int64_t nwg = gridDim.x, bid = blockIdx.x;
-    const int64_t xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
-    const int64_t blk = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    const int64_t gid = (blk * 256 + threadIdx.x) / G;  // row
-    const int gl = threadIdx.x & (G - 1);
-    if (gid >= n_nodes) return;
-    const int64_t r = gid;
-    const int beg = rowptr[r], end = rowptr[r + 1];
-    const float cnt = (float)((end - beg) > 1 ? (end - beg) : 1);  // unsorted_segment_mean: max(count, 1)
-    for (int f = gl * VEC; f < H; f += G * VEC) {
+    __shared__ __attribute__((aligned(16))) V part[kAggFrontRows * 256];  // front: [row][lane group][lane]
+    __shared__ int s_rp[257];
+    __shared__ unsigned long long s_mask[4];
+    __shared__ int s_list[kAggFrontRows];
+    const int t = threadIdx.x;
+    const int rows_wg = 256 / G;  // (divides 256: a regular workgroup's rows lie in one slice)
+    const int gq = t / G, gl = t & (G - 1);
+    // a lane group's sum over edges [beg, end) of feature slice f, in edge order, 8 neighbour rows in flight
+    auto seg_sum = [&](int beg, int end, int f) {
         V acc = V(0.f);
         int e = beg;
-        for (; e + 8 <= end; e += 8) {  // 8 neighbour rows in flight per lane
+        for (; e + 8 <= end; e += 8) {
             int ci[8];
             V vv[8];
 #pragma unroll
@@ -76,7 +86,10 @@ __global__ __launch_bounds__(256) void k_aggregate(const int32_t* __restrict__ r
             for (int q = 0; q < 7; ++q)
                 if (e + q < end) acc += vv[q];
         }
-        if (mean) acc = acc / cnt;
+        return acc;
+    };
+    auto finish = [&](int64_t r, int f, V acc, int deg) {
+        if (mean) acc = acc / (float)(deg > 1 ? deg : 1);  // unsorted_segment_mean: max(count, 1)
         if (mode == 0) {
             const V xs = *reinterpret_cast<const V*>(x + r * ldx + f);
             *reinterpret_cast<V*>(out + r * ldo + f) = eps * xs + acc;
@@ -85,6 +98,79 @@ __global__ __launch_bounds__(256) void k_aggregate(const int32_t* __restrict__ r
             *reinterpret_cast<V*>(out + r * ldo + H + f) = acc;
         } else {
             *reinterpret_cast<V*>(out + r * ldo + f) = acc;
+        }
+    };
+    auto clampi = [&](int64_t i) { return rowptr[i < n_nodes ? i : n_nodes]; };
+
+    if ((int)blockIdx.x >= n_front) {
+        // ---- regular workgroup.  XCD-aware bijective block remap (block b runs on XCD b % 8): consecutive row blocks -
+        // the nodes of one graph and their neighbours - share one XCD's L2 instead of being sprayed over all eight.
+        const int64_t nwg = gridDim.x - n_front, bid = blockIdx.x - n_front;
+        const int64_t xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
+        const int64_t blk = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+        const int64_t r = blk * rows_wg + gq;
+        const bool live = r < n_nodes;
+        int beg = 0, end = 0;
+        if (live) {
+            beg = rowptr[r];
+            end = rowptr[r + 1];
+        }
+        bool taken = false;
+        if (__ballot(end - beg > kAggLong)) {  // (wave-uniform, rare) does a front workgroup have the row?
+            const int64_t sbase = (blk * rows_wg) & ~(int64_t)255;
+            const int lane = t & 63;
+            unsigned long long m[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m[k] = __ballot(clampi(sbase + 64 * k + lane + 1) - clampi(sbase + 64 * k + lane) > kAggLong);
+            const int total = __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]);
+            if (live && end - beg > kAggLong && total <= kAggDense) {
+                const int tl = (int)(r - sbase), w = tl >> 6;
+                int rank = __popcll((w == 0 ? m[0] : w == 1 ? m[1] : w == 2 ? m[2] : m[3]) & ((1ull << (tl & 63)) - 1ull));
+                rank += (w > 0 ? __popcll(m[0]) : 0) + (w > 1 ? __popcll(m[1]) : 0) + (w > 2 ? __popcll(m[2]) : 0);
+                taken = rank < kAggFrontRows;
+            }
+        }
+        if (!live || taken) return;
+        for (int f = gl * VEC; f < H; f += G * VEC) finish(r, f, seg_sum(beg, end, f), end - beg);
+        return;
+    }
+
+    // ---- front workgroup: the hub rows of one 256-row slice --------------------------------------------------------
+    const int64_t sbase = (int64_t)blockIdx.x * 256;
+    s_rp[t] = clampi(sbase + t);
+    if (t == 0) s_rp[256] = clampi(sbase + 256);
+    __syncthreads();
+    const bool is_long = s_rp[t + 1] - s_rp[t] > kAggLong;
+    const unsigned long long bal = __ballot(is_long);
+    if ((t & 63) == 0) s_mask[t >> 6] = bal;
+    __syncthreads();
+    const int c0 = __popcll(s_mask[0]), c1 = __popcll(s_mask[1]), c2 = __popcll(s_mask[2]), c3 = __popcll(s_mask[3]);
+    const int total = c0 + c1 + c2 + c3;
+    if (total == 0 || total > kAggDense) return;
+    if (is_long) {
+        const int w = t >> 6;
+        const int rank = (w > 0 ? c0 : 0) + (w > 1 ? c1 : 0) + (w > 2 ? c2 : 0) + __popcll(s_mask[w] & ((1ull << (t & 63)) - 1ull));
+        if (rank < kAggFrontRows) s_list[rank] = t;
+    }
+    __syncthreads();
+    const int nl = total < kAggFrontRows ? total : kAggFrontRows;
+    for (int f0 = 0; f0 < H; f0 += G * VEC) {
+        const int f = f0 + gl * VEC;
+        const bool livef = f < H;
+        if (f0 > 0) __syncthreads();  // (the previous slice's partial sums have been read)
+        for (int i = 0; i < nl; ++i) {
+            const int tl = s_list[i];
+            const int b2 = s_rp[tl], e2 = s_rp[tl + 1];
+            const int seg = (e2 - b2 + rows_wg - 1) / rows_wg;
+            const int sb = b2 + gq * seg < e2 ? b2 + gq * seg : e2, se = sb + seg < e2 ? sb + seg : e2;
+            part[(i * rows_wg + gq) * G + gl] = livef ? seg_sum(sb, se, f) : V(0.f);
+        }
+        __syncthreads();
+        if (gq < nl && livef) {  // lane group i adds up row i's partial sums in group order
+            const int tl = s_list[gq];
+            V acc = part[(gq * rows_wg) * G + gl];
+            for (int g = 1; g < rows_wg; ++g) acc += part[(gq * rows_wg + g) * G + gl];
+            finish(sbase + tl, f, acc, s_rp[tl + 1] - s_rp[tl]);
         }
     }
 }
@@ -98,13 +184,14 @@ int launch_aggregate(const int32_t* rowptr, const int32_t* col, int64_t n_nodes,
     const int per_row = vec4 ? H / 4 : H;  // lanes a row can use
     int G = 1;
     while (G < per_row && G < 64) G <<= 1;
-    const int64_t blocks = (n_nodes * G + 255) / 256;
+    const int64_t n_front = (n_nodes + 255) / 256;
+    const int64_t blocks = (n_nodes * G + 255) / 256 + n_front;
     if (vec4)
         hipLaunchKernelGGL(k_aggregate<4>, dim3((unsigned)blocks), dim3(256), 0, st, rowptr, col, n_nodes, x,
-                           ldx, H, mean, mode, eps, out, ldo, G);
+                           ldx, H, mean, mode, eps, out, ldo, G, (int)n_front);
     else
         hipLaunchKernelGGL(k_aggregate<1>, dim3((unsigned)blocks), dim3(256), 0, st, rowptr, col, n_nodes, x,
-                           ldx, H, mean, mode, eps, out, ldo, G);
+                           ldx, H, mean, mode, eps, out, ldo, G, (int)n_front);
     GNF_LAUNCH_CHECK("k_aggregate");
     return GNF_OK;
 }
