@@ -20,7 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gnf_amd import gnn                                              # noqa: E402
 from gnf_amd.flow import sample                                      # noqa: E402
-from gnf_amd.train import get_learning_rate                          # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from driver_utils import get_learning_rate                           # noqa: E402
 from gnf_amd.grevnet_synthetic_data import DATASETS_MAP              # noqa: E402
 from gnf_amd.train import GRevNetTrainer                             # noqa: E402
 

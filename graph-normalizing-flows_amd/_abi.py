@@ -16,7 +16,7 @@ GNF_ACT_RELU, GNF_ACT_LEAKY_RELU = 0, 1
 GNF_FORWARD, GNF_INVERSE = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GNF_LIB_PATH: developer override to A/B kernel variants (tools/build_variants.sh); still a HIP build
+# GNF_LIB_PATH: developer override (a library built from another checkout, for A/B runs); still a HIP build
 LIB_PATH = os.environ.get("GNF_LIB_PATH") or os.path.join(_HERE, "libgnf_hip.so")
 
 

@@ -14,9 +14,7 @@ static thread_local char g_err[512] = "";
 std::atomic<int64_t> g_options[OPT_COUNT];  // zero-initialised: every option "auto"
 
 static const char* const kOptionNames[OPT_COUNT] = {
-    "force_shape",   "fused_variant", "flow_no_oop",   "attn_edge_tiled", "attn_rows",    "gemm_no_buf",  "gemm_no_splitk",
-    "dw_grouped",    "dw_wide_units", "dw_wide_lds",   "dw_no_streamk",   "dw_no_buf",    "dw_debug",     "bwd_generic",
-    "dw_unmerged",   "no_mlp_stash",  "attn_bwd_rows", "attn_bwd_split"};
+    "force_shape", "attn_kernel", "attn_bwd_rows", "bwd_generic", "dw_grouped", "dw_wide_units"};
 
 static int option_index(const char* name) {
     if (!name) return -1;
@@ -419,7 +417,7 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
     // conditioning half in place, so such flows copy first too.
     bool first_oop = false;
     if (x_src && n > 0) {
-        if (T > 0 && ld_src == ld && !(direction == GNF_FORWARD && flow->bns) && !opt(OPT_FLOW_NO_OOP)) {
+        if (T > 0 && ld_src == ld && !(direction == GNF_FORWARD && flow->bns)) {
             const int h0_ = direction == GNF_FORWARD ? 0 : 1, i0_ = direction == GNF_FORWARD ? 0 : T - 1;
             HalfStep probe{csr->rowptr, csr->col, n, x, x, ld, H, direction, flow->gnn,
                            pick(flow, flow->s_nets, h0_, i0_), pick(flow, flow->t_nets, h0_, i0_), nullptr, nullptr,
@@ -432,11 +430,11 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
         }
     }
     // attention nets on a sparse batch: the weights of every net go into fragment order ONCE per call (one small launch)
-    // and the one-launch front-end of gnf_attn_front.hip runs per half-step (developer options attn_edge_tiled /
-    // attn_rows keep the two-launch kernels)
+    // and the one-launch front-end of gnf_attn_front.hip runs per half-step (the attn_kernel option keeps the two-launch
+    // kernels)
     const float* attn_pack = nullptr;
     if (n > 0 && n_nets > 0 && flow->s_nets[0].attn && csr->n_edges > 0 && csr->n_edges < 24 * n &&
-        !opt(OPT_ATTN_EDGE_TILED) && !opt(OPT_ATTN_ROWS) && attn_front_fused_ok(flow->s_nets[0].attn, H)) {
+        !opt(OPT_ATTN_KERNEL) && attn_front_fused_ok(flow->s_nets[0].attn, H)) {
         const GnfAttn* all[2 * 64];
         if (2 * n_nets <= 128) {
             for (int q = 0; q < n_nets; ++q) {
@@ -517,7 +515,18 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
                     mark_attn(hs, half, i);
                     if (mstash) hs.mlp_stash = mstash + (size_t)(2 * i + half) * mstash_slot;
                     const int idx = 2 * i + half;
-                    if (flow->bns && idx == 0) bn_on_load = !flow->bn_allreduce && fused_bn_on_load_ok(hs);
+                    if (flow->bns && idx == 0) {
+                        // decided once, for every half-step of the walk: ALL net pairs must fit the attention instance (a
+                        // C-ABI caller's nets may differ from pair to pair when weight_sharing = 0), else the separate passes
+                        bn_on_load = !flow->bn_allreduce;
+                        for (int i2 = 0; i2 < T && bn_on_load; ++i2)
+                            for (int h2 = 0; h2 < 2 && bn_on_load; ++h2) {
+                                HalfStep probe = hs;
+                                probe.s_net = pick(flow, flow->s_nets, h2, i2), probe.t_net = pick(flow, flow->t_nets, h2, i2);
+                                mark_attn(probe, h2, i2);
+                                bn_on_load = fused_bn_on_load_ok(probe);
+                            }
+                    }
                     double* const bn_rows_in = partials + ((idx & 1) && bn_on_load ? p.bn_offset2 : p.bn_offset);
                     double* const bn_rows_out = partials + (!(idx & 1) && bn_on_load ? p.bn_offset2 : p.bn_offset);
                     if (flow->bns && !bn_on_load) {

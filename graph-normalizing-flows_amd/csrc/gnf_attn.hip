@@ -458,22 +458,11 @@ __device__ __forceinline__ void attn_fwd_thread(const AttnArgs& a, const float* 
     }
 }
 
-#ifdef GNF_ATTN_TRACE  // developer build: cycle stamps of workgroup 0 / thread 0 at the phase boundaries
-__device__ unsigned long long g_attn_trace[16];
-#define GNF_ATRACE(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_attn_trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
-extern "C" int gnf_debug_read_attn_trace(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_trace), sizeof(unsigned long long) * 16);
-}
-#else
-#define GNF_ATRACE(i)
-#endif
-
 // ROWS: receiver rows per workgroup (lanes ROWS .. 63 of every head's wave idle): 64, or 32 while 64-row tiles would be
 // fewer workgroups than the chip has CUs (the drivers' default batch: 3200 nodes = 50 tiles per net)
 template <int KQM, int VDM, int ROWS = 64>
 __global__ __launch_bounds__(512) void k_attn_fwd_rows(const AttnArgs a, int win_cap) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    GNF_ATRACE(0);
     const int net = blockIdx.y;
     const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd, C = a.C, H = a.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -506,7 +495,6 @@ __global__ __launch_bounds__(512) void k_attn_fwd_rows(const AttnArgs a, int win
         }
     }
     __syncthreads();
-    GNF_ATRACE(1);
     const float* qkv = a.qkv[net];
     bool cols_in_lds = false;
     const int lo = stage_window(a.col, s_rp, ROWS, s_hdr, win_cap, tid, 512, [&](int lo_, int cnt) {
@@ -521,9 +509,7 @@ __global__ __launch_bounds__(512) void k_attn_fwd_rows(const AttnArgs a, int win
                 return qkv[(int64_t)(lo_ + rr) * P + (c < nq ? c : nq + c)];
             });
     }, s_col, kRowsColCap, &cols_in_lds);
-    GNF_ATRACE(2);
     __syncthreads();
-    GNF_ATRACE(3);
     const int* cols = cols_in_lds ? s_col : a.col;
     const int col_base = cols_in_lds ? s_rp[0] : 0;
     constexpr int PAR = ROWS == 32 ? 2 : 1;  // 32-row tiles: the wave's other 32 lanes take half of every row's edges
@@ -541,9 +527,7 @@ __global__ __launch_bounds__(512) void k_attn_fwd_rows(const AttnArgs a, int win
                                                   even && (reinterpret_cast<uintptr_t>(qkv) & 7) == 0, agg_s + row_l * (NV + 1), par,
                                                   a.mz_out[net]);
     }
-    GNF_ATRACE(4);
     __syncthreads();
-    GNF_ATRACE(5);
     if (a.agg_out[net])  // the attended values stay for the backward pass (coalesced rows)
         for (int i = tid; i < ROWS * NV; i += 512) {
             const int rl = i / NV, c = i - rl * NV;
@@ -575,7 +559,6 @@ __global__ __launch_bounds__(512) void k_attn_fwd_rows(const AttnArgs a, int win
         if (a.concat)
             for (int f = wave; f < H; f += 8) h0[(int64_t)r * a.in0 + f] = a.x[(int64_t)r * a.ldx + f];
     }
-    GNF_ATRACE(6);
 }
 
 size_t attn_scratch_floats(const GnfAttn* at, int64_t n_nodes, int32_t in0) {
@@ -655,8 +638,8 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
     else
         hipLaunchKernelGGL((k_attn_proj<0, 0, 0>), pgrid, dim3(256), proj_lds, st, a);
     GNF_LAUNCH_CHECK("k_attn_proj");
-    const bool old_attn = opt(OPT_ATTN_EDGE_TILED) != 0;  // developer A/B switches (gnf_set_option)
-    const bool rows_always = opt(OPT_ATTN_ROWS) != 0;
+    const bool old_attn = opt(OPT_ATTN_KERNEL) == 2;  // shape forcing for the parity tests (gnf_set_option): 1 rows kernel, 2 edge-tiled kernel
+    const bool rows_always = opt(OPT_ATTN_KERNEL) == 1;
     // sparse batches (mean in-degree under ~24: the config-2 batch has 12) are 8 % faster through the edge-tiled kernel;
     // the rows kernel wins by 4.5 x on the complete graphs of the drivers' default dataset (degree 100)
     const bool sparse = !rows_always && n_edges > 0 && n_edges < 24 * n;

@@ -1172,7 +1172,7 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
                     reinterpret_cast<const void*>(k_attn_bwd_edges<10, 10, 32, 32>), reinterpret_cast<const void*>(k_attn_bwd_edges<32, 32, 32, 32>),
                     reinterpret_cast<const void*>(k_attn_bwd_edges<10, 10, 32, 64>), reinterpret_cast<const void*>(k_attn_bwd_edges<32, 32, 32, 64>)};
                 for (const void* k : ks) GNF_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
-            // Tile sizes.  Two launches (dense batches; option attn_bwd_split): 32-row tiles on sparse batches (default-flags
+            // Tile sizes.  Two launches (dense batches): 32-row tiles on sparse batches (default-flags
             // training step on the config-2 batch: 4.44 (64) / 4.24 (32) / 4.74 ms (16: the window staging per workgroup
             // takes over)) and on any batch whose 64-row tiles would be fewer workgroups than the chip has CUs (the drivers'
             // default batch, 32 complete 100-node graphs: 10.25 -> 9.9 ms per iteration of examples/run_grevnet.py).
@@ -1182,7 +1182,7 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
             int rows = (sparse || 2 * ((n + 63) / 64) < 256) ? 32 : 64;
             const int64_t force = opt(OPT_ATTN_BWD_ROWS);
             if (force == 64 || force == 32 || force == 16) rows = (int)force;
-            const bool one_launch = sparse && !opt(OPT_ATTN_BWD_SPLIT) && rows != 16;
+            const bool one_launch = sparse && rows != 16;
             const bool small = a.kq <= 10 && a.v <= 10;
             if (one_launch) {
                 const int64_t t32 = (n + 31) / 32, t64 = (n + 63) / 64;
@@ -1198,7 +1198,7 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
                 const dim3 egrid((unsigned)(2 * ts + 2 * tr));
                 auto go1 = [&](auto rs_c, auto rr_c) {
                     constexpr int RS = decltype(rs_c)::value, RR = decltype(rr_c)::value;
-                    if (a.nh == 8 && a.kq == 10 && a.v == 10 && RS == 32 && RR == 64 && !(opt(OPT_DW_DEBUG) & 128))  // (dw_debug bit 128: the run-time geometry instance, A/B)
+                    if (a.nh == 8 && a.kq == 10 && a.v == 10 && RS == 32 && RR == 64)
                         hipLaunchKernelGGL((k_attn_bwd_edges<10, 10, RS, RR, true>), egrid, dim3(512), (size_t)kRowsLdsBudget, st, a, capr, capw, ts);
                     else if (small)
                         hipLaunchKernelGGL((k_attn_bwd_edges<10, 10, RS, RR>), egrid, dim3(512), (size_t)kRowsLdsBudget, st, a, capr, capw, ts);
@@ -1275,7 +1275,7 @@ dx_pass:
         const int Pp = (P + 15) & ~15, Hp = (H + 15) & ~15;
         const size_t lds_m = ((size_t)2 * kDxmRows * (Pp + 4) + (size_t)2 * kDxmRows * (Hp + 4) + (size_t)2 * kDxmRows * H) * sizeof(float);
         const int64_t blocks_m = (n + kDxmRows - 1) / kDxmRows;
-        if (d.wct[0] && d.wct[1] && lds_m <= 64 * 1024 && !opt(OPT_ATTN_BWD_SPLIT)) {
+        if (d.wct[0] && d.wct[1] && lds_m <= 64 * 1024) {
             d.bn_y = nullptr, d.bn_ld = 0, d.bn_gamma = d.bn_beta = nullptr, d.bn_part = nullptr;
             if (bn && bn->n_parts) *bn->n_parts = 0;
             if (bn && bn->part && blocks_m <= kBnPartRowsMax) {
@@ -1295,7 +1295,7 @@ dx_pass:
         if (bn->n_parts) *bn->n_parts = (int32_t)dx_blocks;
     }
     const size_t lds_x2 = (2 * ((size_t)H * (P + 1) + (size_t)kDxRows * P) + (size_t)2 * kDxRows * H) * sizeof(float);
-    if (kDxRows * H <= 256 && H * P <= 256 * kDx2Loads && lds_x2 <= 64 * 1024 && !opt(OPT_ATTN_BWD_SPLIT)) {
+    if (kDxRows * H <= 256 && H * P <= 256 * kDx2Loads && lds_x2 <= 64 * 1024) {
         if (d.nq == 80 && d.v == 10)  // the reference's head geometry (run_grevnet.py:74-76)
             hipLaunchKernelGGL((k_attn_bwd_dx2<80, 10>), dim3((unsigned)dx_blocks), dim3(256), lds_x2, st, d);
         else

@@ -21,7 +21,6 @@
 // fragment is one coalesced 16-byte load per lane, exactly like the MLP weights of the fused half-step kernel.
 // When a.qkv != NULL (training forward: GnfFlow.attn_stash) the tile also writes q|k|v of its OWN rows, in the
 // layout and with the arithmetic (same MFMA k-order) the backward kernels expect.
-#define GNF_ATTN_FRONT_TU 1
 #include "gnf_attn_front_dev.h"
 
 namespace gnf {

@@ -85,24 +85,6 @@ static __host__ __device__ inline FrontLds front_lds(const FrontDims& d) {
     return L;
 }
 
-#if defined(GNF_ATTN_TRACE) && defined(GNF_ATTN_FRONT_TU)  // developer build of gnf_attn_front.hip: cycle stamps of workgroup 0 / thread 0 at the phase boundaries
-__device__ unsigned long long g_front_trace[32];
-#define FR_STAMP(i)                                                                                           \
-    do {                                                                                                      \
-        if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 32) g_front_trace[i] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-extern "C" int gnf_debug_read_front_trace(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_front_trace), sizeof(unsigned long long) * 32);
-}
-#elif defined(GNF_FOLD_TRACE) && !defined(GNF_ATTN_FRONT_TU)  // developer build of gnf_fused.hip: the same stamps inside k_half_fused's attention instance
-#define FR_STAMP(i)                                                                                           \
-    do {                                                                                                      \
-        if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 32) g_fold_trace[i] = __builtin_amdgcn_s_memtime();  \
-    } while (0)
-#else
-#define FR_STAMP(i)
-#endif
-
 // HOIST: the [Wq | Wv] fragments of the wave's projection (PW/16 <= 6 column tiles x Hp/16 <= 2 k-groups: the
 // reference's head geometry at H <= 32) stay in registers for the whole kernel instead of being re-read per chunk.
 // KQM / VDM: register widths of a thread's k / q / v rows (kq <= KQM, v <= VDM); EU: edges whose rows are in flight.
@@ -140,8 +122,6 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
     const float* wk_p = wqv_p + (size_t)Hp * PW;
     const float* wo_p = wk_p + (size_t)Hp * nqp;
     const int voff = lane * 4;  // this lane's float4 inside a 256-float fragment block
-
-    FR_STAMP(0);
     auto b_frag = [&](const float* packed, int nts, int g, int nt) -> f32x4 {
         return *reinterpret_cast<const f32x4*>(packed + ((size_t)(g * nts + nt) * 64) * 4 + voff);
     };
@@ -242,7 +222,6 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
     }
     if (tid <= kFrRows) rp_l[tid] = rp_reg;
     __syncthreads();
-    FR_STAMP(1);
 
     // K order inside a group of 16 is permuted identically on both operands (k = 16 g + 4 (lane >> 4) + q), so an A
     // fragment is one 16-byte LDS read and a B fragment one 16-byte global read.
@@ -309,7 +288,6 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
             }
         }
     }
-    FR_STAMP(2);
     const int seg_beg = rp_l[0], seg_end = rp_l[kFrRows];
     constexpr int kHoistNT = 6, kHoistKG = 2;
     f32x4 bqv[HOIST ? kHoistNT : 1][HOIST ? kHoistKG : 1];
@@ -379,8 +357,6 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
     for (int w0 = win_lo; w0 <= win_hi; w0 += kFrWin) {
         const int nw = win_hi + 1 - w0 < kFrWin ? win_hi + 1 - w0 : kFrWin;  // window nodes of this pass
         if (chunk_ > 0) __syncthreads();  // the previous pass's buffers are free
-        FR_STAMP(3 + 5 * chunk_);
-        FR_STAMP(4 + 5 * chunk_);
         // ---- C2: the window's x rows (contiguous rows: coalesced) ------------------------------------------------------
         {
             const int f4n = Hp >> 2;
@@ -412,7 +388,6 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
             }
         }
         __syncthreads();
-        FR_STAMP(5 + 5 * chunk_);
         // ---- C3: q | v of the window's nodes: wave wn of each net takes M-tiles wn and wn + 4 (16 nodes each) -----------
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -468,7 +443,6 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
             }
         }
         __syncthreads();
-        FR_STAMP(6 + 5 * chunk_);
         // ---- C4: this thread's share of the row's edges whose sender lies in the pass's window part, EU at a time (their
         // q | v rows are independent LDS reads; only the softmax recurrence is sequential) -----------------------------------
         if (att) {
@@ -533,7 +507,6 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
                 }
             }
         }
-        FR_STAMP(7 + 5 * chunk_);
         ++chunk_;
     }
     // ---- merge the two halves of every row (online-softmax merge with the partner lane) -----------------------------------
@@ -587,9 +560,7 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
         }
     }
     __syncthreads();
-    FR_STAMP(28);
     before_out();
-    FR_STAMP(30);
     if (a.agg_out[net])
         for (int i = tn; i < kFrRows * NV; i += 256) {
             const int rl = i / NV, c = i - rl * NV;
@@ -642,7 +613,6 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
                 }
             }
         }
-        FR_STAMP(31);
         if (a.concat) {
             if constexpr (TO_LDS) {
                 float* hl = net == 0 ? h0_lds0 : h0_lds1;
@@ -663,7 +633,6 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
             }
         }
     }
-    FR_STAMP(29);
 }
 
 }  // namespace gnf

@@ -144,7 +144,7 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st);
 struct FusedArgs;
 bool big_supported(const GnfMlp* s, int32_t H);
 int big_cu_count();  // multiProcessorCount of the current device (cached per device)
-int big_plan(int64_t n_nodes, int cus, int cap, int variant, int32_t* seg_n, int32_t* seg_sz);  // -> workgroups; runs of (count, row tiles)
+int big_plan(int64_t n_nodes, int cus, int cap, int32_t* seg_n, int32_t* seg_sz);  // -> workgroups; runs of (count, row tiles)
 int launch_half_big(FusedArgs& a, int64_t n_nodes, int cap, hipStream_t st, int* n_wg_out);
 // coupling epilogue from global s / t [N, H] buffers (writes hs.partials, *hs.n_partials)
 int launch_coupling(const float* s, const float* t, const HalfStep& hs, const float* xres, hipStream_t st);
@@ -201,7 +201,7 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
 size_t attn_wct_floats(const GnfAttn* at, int32_t H);
 
 
-// thin y = act(x W + b) through the split-K generic GEMM (gnf_train.hip); 1 = not thin, the caller runs its own kernel
+// y = act(x W + b) through the generic GEMM (gnf_train.hip; thin launches split over the reduction); GNF_OK or a GNF_E* code
 int launch_linear_splitk(const float* const* x, int64_t ldx, const float* const* W, const float* const* b, float* const* y,
                          int64_t ldy, int nj, int64_t n, int32_t I, int32_t O, int act, float alpha, int apply_act,
                          float* const* sk, size_t sk_floats, hipStream_t st);

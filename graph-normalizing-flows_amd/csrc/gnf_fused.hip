@@ -110,44 +110,9 @@ int launch_pack_mlp(const GnfMlp* m, float* packed, hipStream_t st) {
     return GNF_OK;
 }
 
-#ifdef GNF_TRACE  // developer build only: per-wave cycle stamps of workgroup 0
-#define GNF_TRACE_GLOBALS 1
-__device__ unsigned long long g_trace[8][16];
-__device__ unsigned long long g_stage[8][40];  // per-stage stamps of the traced layer
-__device__ int g_trace_layer = 1;
-#define GNF_STAMP(slot)                                                                  \
-    do {                                                                                 \
-        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)                                  \
-            g_trace[threadIdx.x >> 6][slot] = __builtin_amdgcn_s_memtime();              \
-    } while (0)
-#define GNF_PSTAMP(idx)                                                                  \
-    do {                                                                                 \
-        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)                                  \
-            g_stage[threadIdx.x >> 6][30 + (idx)] = __builtin_amdgcn_s_memtime();        \
-    } while (0)
-#define GNF_STAGE_STAMP(idx)                                                             \
-    do {                                                                                 \
-        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && trace_on && (idx) < 40)        \
-            g_stage[threadIdx.x >> 6][idx] = __builtin_amdgcn_s_memtime();               \
-    } while (0)
-#endif
 
 }  // namespace gnf
 #include "gnf_fused_dev.h"
-#ifdef GNF_FOLD_TRACE  // developer build (tools/probe_fold_trace.py): cycle stamps of workgroup 0 / thread 0 of the attention instance
-namespace gnf {
-__device__ unsigned long long g_fold_trace[64];
-}
-extern "C" int gnf_debug_read_fold_trace(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gnf::g_fold_trace), sizeof(unsigned long long) * 64);
-}
-#define GNF_FOLD_STAMP(i)                                                                                  \
-    do {                                                                                                   \
-        if (FRONT && blockIdx.x == 0 && threadIdx.x == 0) g_fold_trace[i] = __builtin_amdgcn_s_memtime();  \
-    } while (0)
-#else
-#define GNF_FOLD_STAMP(i)
-#endif
 #include "gnf_attn_front_dev.h"
 namespace gnf {
 
@@ -252,11 +217,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
         }
         for (++j; j < a.K; ++j) {
             const int ont_ = __builtin_amdgcn_readfirstlane(tab[8 * j + 1]);
-#ifdef GNF_ARGS_CHUNKS
-            if (wl < ont_) return chunk_from_args(j, wl);
-#else
             if (wl < ont_) return chunk_from_tab(j, wl);
-#endif
         }
         WChunk n = c;
         n.layer = a.K;
@@ -270,13 +231,12 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
         if (j0 >= a.K) cur.layer = a.K;  // (cannot happen: the last layer has >= 1 tile; wave 0 runs it)
     }
 
-    GNF_STAMP(0);
     // ---- weights of the first chunk start streaming before anything else -----------------------
     f32x4 b_pre[kPF][4];
     // thin-chunk form (gnf_fused_dev.h) of a one-tile chunk: everywhere in the inference instances; the stash instance
     // only in the LAST layer (a hidden layer's epilogue there also leaves the act' ballots, which the thin form does not do).
     // The prefetch of a chunk packs its registers for the form that will consume it: both sides ask thin_for(layer).
-    auto thin_for = [&](int layer) { return MT == 1 && !(a.variant & 1) && (!STASH || layer == a.K - 1); };
+    auto thin_for = [&](int layer) { return MT == 1 && (!STASH || layer == a.K - 1); };
     int* s_rowptr = tab + GNF_MAX_LAYERS * 8;
     int* s_col = s_rowptr + kRowptrPad;
     // STASH only: the act' ballots.  With the attention prologue they sit right behind the activation buffers, inside the
@@ -339,12 +299,9 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
         }
         for (int i = tid + kBiasRegsF * kFusedThreads; i < bias_all_f; i += kFusedThreads)
             bias_lds[i] = i < a.bias_tot ? a.bias[0][i] : a.bias[1][i - a.bias_tot];
-        GNF_FOLD_STAMP(32);
         __syncthreads();
-        GNF_FOLD_STAMP(33);
     } else {
     prefetch_chunk(cur, WPN, voff, b_pre, thin_for(cur.layer));
-    GNF_PSTAMP(0);
     // ---- every independent global read of the prologue is ISSUED before any is consumed: rowptr of
     // the tile, the biases (<= 8 floats per thread in registers), the layer table - one memory round
     // trip instead of three back-to-back ones ----------------------------------------------------------
@@ -379,7 +336,6 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
             row[7] = (int)(unsigned)(p1 >> 32);
         }
     }
-    GNF_PSTAMP(1);
     if (tid <= TM) s_rowptr[tid] = rp_reg;
 #pragma unroll
     for (int q = 0; q < kBiasRegs; ++q) {
@@ -389,9 +345,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
     for (int i = tid + kBiasRegs * kFusedThreads; i < bias_all; i += kFusedThreads)  // very wide nets only
         bias_lds[i] = i < a.bias_tot ? bsrc0[i] : bsrc1[i - a.bias_tot];
     // ---- A: aggregate + combine into the layer-0 input of each net (tile_aggregate, gnf_fused_dev.h) ----
-    GNF_PSTAMP(2);
     __syncthreads();
-    GNF_PSTAMP(3);
     if (a.h0[0] != nullptr) {
         // attention GNNs: the layer-0 input of each net was produced by the attention front-end
         const int in0p = a.ipg[0] * 16;
@@ -422,18 +376,12 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
         tile_aggregate<TM, kFusedThreads, kColCap>(ta, s_rowptr, s_col, buf(0, 0), NETS == 2 ? buf(1, 0) : nullptr, LS,
                                                    STASH ? a.stash_h0 : nullptr, tid);
     }  // message-passing prologue
-    GNF_STAMP(1);
     __syncthreads();
-    GNF_STAMP(2);
     }  // !FRONT
 
     // ---- B: K layers ------------------------------------------------------------------------------
     int pp = 0;
-#ifdef GNF_ABL_NOLAYERS
-    for (int j = 0; j < 0; ++j) {
-#else
     for (int j = 0; j < a.K; ++j) {
-#endif
         const float* in_lds = buf(nl, pp);
         float* out_lds = buf(nl, pp ^ 1);
         const float slope = (j == a.K - 1) ? 1.f : (a.act == GNF_ACT_RELU ? 0.f : a.alpha);
@@ -478,10 +426,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
             }
         }
         pp ^= 1;
-        GNF_STAMP(3 + 2 * j);
         __syncthreads();
-        GNF_STAMP(4 + 2 * j);
-        GNF_FOLD_STAMP(34 + j);
     }
 
     if constexpr (STASH) {  // (every layer's barrier has passed: the words are complete)
@@ -568,18 +513,8 @@ __global__ __launch_bounds__(kFusedThreads) void k_half_fused(const FusedArgs a,
             }
         }
     }
-    GNF_STAMP(15);
-    GNF_FOLD_STAMP(48);
 }
 
-#ifdef GNF_TRACE
-extern "C" int gnf_debug_read_trace(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 8 * 16);
-}
-extern "C" int gnf_debug_read_stages(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stage), sizeof(unsigned long long) * 8 * 40);
-}
-#endif
 
 // ------------------------------------------------------------------------------------------------
 static int max_padded_width(const GnfMlp* m) {
@@ -702,7 +637,6 @@ static int launch_shape(const FusedArgs& a, unsigned grid, size_t lds, hipStream
 static bool front_fold_ok(const HalfStep& hs, FrontArgs* fa);
 bool fused_bn_on_load_ok(const HalfStep& hs) {
     if (!hs.s_net->attn || hs.H > 128 || !fused_supported(hs)) return false;
-    if (opt(OPT_FUSED_VARIANT) & 8) return false;  // (A/B: k_bn_apply's own launch per half-step)
     int MT, NETS;
     choose_shape(hs, &MT, &NETS);
     FrontArgs fa;
@@ -722,17 +656,17 @@ static size_t fused_front_lds_bytes(const GnfMlp* m, const FrontDims& d) {
 // May the attention front-end run as the fused kernel's prologue (k_half_fused<1, 2, false, true>)?  The sparse-batch
 // front-end with the reference's head geometry (its register-resident instance), widths that need no zero padding in
 // the layer-0 rows, and the two areas in 160 KB; the training forward (q | k | v, the attended values and h0 also go to the
-// stash) with the drivers' default geometry only.  gnf_set_option("fused_variant", 4) keeps the two launches (A/B).
+// stash) with the drivers' default geometry only.
 static bool front_fold_ok(const HalfStep& hs, FrontArgs* fa) {
     const GnfMlp *s = hs.s_net, *t = hs.t_net;
     const GnfAttn *a0 = s->attn, *a1 = t->attn;
-    if (!a0 || !a1 || (opt(OPT_FUSED_VARIANT) & 4)) return false;
+    if (!a0 || !a1) return false;
     if (!hs.attn_packed[0] || !hs.attn_packed[1]) return false;
     if (!(hs.n_edges > 0 && hs.n_edges < 24 * hs.n_nodes) || !attn_front_fused_ok(a0, hs.H)) return false;
     if (a1->num_heads != a0->num_heads || a1->kq_dim != a0->kq_dim || a1->v_dim != a0->v_dim || a1->out_dim != a0->out_dim ||
         a1->concat != a0->concat || a1->kq_dim_division != a0->kq_dim_division)
         return false;  // (launch_attn_front reports it)
-    if (a0->layer_norm || opt(OPT_ATTN_EDGE_TILED) || opt(OPT_ATTN_ROWS)) return false;
+    if (a0->layer_norm || opt(OPT_ATTN_KERNEL)) return false;
     const FrontDims d = front_dims(hs.H, a0->num_heads, a0->kq_dim, a0->v_dim, a0->out_dim);
     if (!((d.PW >> 4) <= 6 && (d.Hp >> 4) <= 2 && d.kq == 10 && d.vd == 10)) return false;
     const int in0 = s->dims[0];
@@ -811,7 +745,6 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
     a.col = hs.col;
     a.x_cond = hs.x_cond;
     a.x_upd = hs.x_upd;
-    a.variant = (int32_t)opt(OPT_FUSED_VARIANT);
     memset(a.big_seg_n, 0, sizeof(a.big_seg_n));
     memset(a.big_seg_sz, 0, sizeof(a.big_seg_sz));
     a.x_upd_src = hs.x_upd_src ? hs.x_upd_src : hs.x_upd;

@@ -44,28 +44,11 @@ static constexpr int kBigTM = 16 * kBigMT;
 static constexpr int kBigLS = 260;       // LDS row stride (floats): 256 + 4, rows 16-byte aligned and spread over banks
 static constexpr int kBigMaxW = 256;     // widest padded layer input / hidden width
 static constexpr int kBigMaxH = 128;     // widest padded output (s stays in 8 * 4 accumulator registers of its wave)
-#ifndef GNF_BIG_RBW
-#define GNF_BIG_RBW 2  // weight k-groups in the register ring of the widest shapes (one less in flight; 3 measured equal)
-#endif
-#ifndef GNF_BIG_RB2
-#define GNF_BIG_RB2 (2 * GNF_BIG_RBW)  // the same for workgroups of 1 or 2 row tiles (their k-groups are half as long)
-#endif
+static constexpr int kBigRBW = 2;            // weight k-groups in the register ring of the widest shapes (one less in flight; 3 measured equal)
+static constexpr int kBigRB2 = 2 * kBigRBW;  // the same for workgroups of 1 or 2 row tiles (their k-groups are half as long)
 
 static inline int pad16(int v) { return (v + 15) & ~15; }
 
-#ifdef GNF_BIG_TRACE  // developer build only (tools/probe_big_trace.py): s_memtime stamps of every wave of two workgroups
-__device__ unsigned long long g_big_trace[2][8][64];
-__device__ unsigned int g_big_hwid[2][8];
-__device__ int g_big_trace_blocks[2] = {0, 256};
-__device__ unsigned long long g_big_span[8192][5];  // per block: start, end (s_memtime: a per-CU clock), HW_ID | XCC_ID << 16 (wave 0),
-                                                    // start, end in s_memrealtime ticks (100 MHz, one clock for the chip)
-#define GNF_BSTAMP(slot)                                                                              \
-    do {                                                                                              \
-        if (trace_slot >= 0 && (threadIdx.x & 63) == 0) g_big_trace[trace_slot][threadIdx.x >> 6][slot] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-#else
-#define GNF_BSTAMP(slot)
-#endif
 
 // a wave's share of one layer (all wave-uniform)
 struct BChunk {
@@ -336,16 +319,6 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
     const int tid = threadIdx.x;
     const int H = a.H, K = a.K;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-#ifdef GNF_BIG_TRACE
-    const int trace_slot = (int)blockIdx.x == g_big_trace_blocks[0] ? 0 : ((int)blockIdx.x == g_big_trace_blocks[1] ? 1 : -1);
-    if (trace_slot >= 0 && lane == 0) g_big_hwid[trace_slot][wave] = (__builtin_amdgcn_s_getreg(4 | (15 << 11)) & 0xffffu) | (__builtin_amdgcn_s_getreg(20 | (3 << 11)) << 16);  // HW_ID[15:0] | XCC_ID << 16
-    if (tid == 0 && blockIdx.x < 8192) {
-        g_big_span[blockIdx.x][0] = __builtin_amdgcn_s_memtime();
-        g_big_span[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();
-        g_big_span[blockIdx.x][2] = (__builtin_amdgcn_s_getreg(4 | (15 << 11)) & 0xffffu) | (__builtin_amdgcn_s_getreg(20 | (3 << 11)) << 16);
-    }
-#endif
-    GNF_BSTAMP(0);
     __builtin_amdgcn_s_setprio(3);  // (see big_chunk)
 
     // this wave's share of a layer: column tiles {w, w+4, w+8, w+12} x every row tile when the layer has at least 3 column
@@ -458,9 +431,7 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
             a.cond_copy[(int64_t)(row0 + rl) * a.ld + f] = a.x_cond[(int64_t)(row0 + rl) * a.ld + f];
         }
     }
-    GNF_BSTAMP(2);
     __syncthreads();
-    GNF_BSTAMP(3);
 
     // ---- B: s-net, then t-net ------------------------------------------------------------------------------
     f32x4 s_keep[kBigMT][2];
@@ -474,7 +445,6 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
             BChunk nx = cur;
             if (has_next) nx = last ? chunk_from_tab(0, 1) : chunk_from_tab(j + 1, net);
             const bool pre_next = has_next && nx.active;
-            GNF_BSTAMP(4 + 6 * (net * K + j) + 0);
             if (cur.active) {
                 if (!have_pre) big_prefetch(cur, lane, b_nx);
 #define GNF_BIG_RUN(NV_, RB_, MW_) \
@@ -483,15 +453,15 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
                     big_chunk_thin(act, cur, nx, pre_next, lane, b_nx, last, slope_hidden, s_keep, net == 1, hp);
                 else if (cur.nv == 4) {
                     if (cur.mw == kBigMT)  // (the shape almost all of a large batch's work runs in: no row-tile branches)
-                        big_chunk<4, GNF_BIG_RBW, kBigMT, true>(act, cur, nx, pre_next, lane, b_nx, last, slope_hidden, s_keep,
+                        big_chunk<4, kBigRBW, kBigMT, true>(act, cur, nx, pre_next, lane, b_nx, last, slope_hidden, s_keep,
                                                                 net == 1, hp);
                     else if (cur.mw == 3)  // (its own instance: a 3-tile workgroup in the 4-tile one took a 4-tile workgroup's time)
-                        big_chunk<4, GNF_BIG_RBW, 3, true>(act, cur, nx, pre_next, lane, b_nx, last, slope_hidden, s_keep,
+                        big_chunk<4, kBigRBW, 3, true>(act, cur, nx, pre_next, lane, b_nx, last, slope_hidden, s_keep,
                                                            net == 1, hp);
                     else
-                        GNF_BIG_RUN(4, GNF_BIG_RB2, 2);
+                        GNF_BIG_RUN(4, kBigRB2, 2);
                 } else if (cur.nv == 3) {  // (the less common widths: one instance each, to keep the code small)
-                    GNF_BIG_RUN(3, GNF_BIG_RBW, kBigMT);
+                    GNF_BIG_RUN(3, kBigRBW, kBigMT);
                 } else if (cur.nv == 2) {
                     GNF_BIG_RUN(2, 3, kBigMT);
                 } else {
@@ -507,14 +477,10 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
                     __syncthreads();  // (the barrier in front of the s | t rows, big_layer_end)
                 }
             }
-            GNF_BSTAMP(4 + 6 * (net * K + j) + 5);
             if (last && net == 0) {
                 __syncthreads();  // every wave is done with the s-net's last hidden rows
-                GNF_BSTAMP(4 + 6 * (net * K + j) + 2);
                 load_h0(a.h0[1]);
-                GNF_BSTAMP(4 + 6 * (net * K + j) + 3);
                 __syncthreads();
-                GNF_BSTAMP(4 + 6 * (net * K + j) + 4);
             }
             if (has_next) {
                 have_pre = pre_next;
@@ -526,7 +492,6 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
     // ---- C: coupling update from the s | t rows in LDS, rows of x coalesced (16 bytes per lane where the widths allow,
     // four requests per thread before the first use); this lane's fp64 shares of sum(s) and sum(x_new^2) ----
     __syncthreads();
-    GNF_BSTAMP(60);
     double local = 0.0, local2 = 0.0;
     {
         auto one = [&](float xv, float xr, float sv, float tv, float& xn) {
@@ -599,7 +564,6 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
             }
         }
     }
-    GNF_BSTAMP(61);
     for (int off = 32; off > 0; off >>= 1) {
         local += __shfl_down(local, off, 64);
         local2 += __shfl_down(local2, off, 64);
@@ -618,29 +582,8 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
         a.partials[wg] = tot;
         if (a.sq_partials) a.sq_partials[wg] = tot2;
     }
-    GNF_BSTAMP(63);
-#ifdef GNF_BIG_TRACE
-    if (tid == 0 && blockIdx.x < 8192) {
-        g_big_span[blockIdx.x][1] = __builtin_amdgcn_s_memtime();
-        g_big_span[blockIdx.x][4] = __builtin_amdgcn_s_memrealtime();
-    }
-#endif
 }
 
-#ifdef GNF_BIG_TRACE
-extern "C" int gnf_debug_big_trace(unsigned long long* out, unsigned int* hwid, int b0, int b1) {
-    if (b0 >= 0) {  // set the two traced blocks for the next launches
-        int v[2] = {b0, b1};
-        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_big_trace_blocks), v, sizeof(v));
-    }
-    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_trace), sizeof(unsigned long long) * 2 * 8 * 64);
-    if (rc) return rc;
-    return (int)hipMemcpyFromSymbol(hwid, HIP_SYMBOL(g_big_hwid), sizeof(unsigned int) * 2 * 8);
-}
-extern "C" int gnf_debug_big_spans(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_span), sizeof(unsigned long long) * 8192 * 5);
-}
-#endif
 
 // ------------------------------------------------------------------------------------------------
 static size_t big_lds_bytes(int bias_tot) {
@@ -670,7 +613,7 @@ bool big_supported(const GnfMlp* s, int32_t H) {
 //     of phase by themselves.  Measured and dropped (tools/ab_shapes.sh, CHANGELOG.md): an even deal over ALL rounds
 //     (642 vs 555 us on config 4 while 3-tile workgroups still ran the 4-tile instance) and an opening of cap-tile +
 //     half-tile workgroups (the half-size one, served second, takes as long as its partner).
-int big_plan(int64_t n_nodes, int cus, int cap, int variant, int32_t* seg_n, int32_t* seg_sz) {
+int big_plan(int64_t n_nodes, int cus, int cap, int32_t* seg_n, int32_t* seg_sz) {
     for (int k = 0; k < 6; ++k) seg_n[k] = 0, seg_sz[k] = 1;
     const int64_t g = (n_nodes + 15) / 16;
     if (g <= (int64_t)cap * 2 * cus) {
@@ -695,7 +638,7 @@ int big_plan(int64_t n_nodes, int cus, int cap, int variant, int32_t* seg_n, int
     // weights as a 4-tile one, and a CU takes them at 15 - 20 bytes per clock whatever the depth of the register ring:
     // 115 k cycles alone, 180 k beside another, against 315 k / 475 k for 4-tile ones) - they keep every CU busy to the end.
     const int64_t per_round = (int64_t)cap * 2 * cus;
-    const int64_t full = cap == kBigMT && !(variant & 64) ? g / per_round : 0, left = g - full * per_round;
+    const int64_t full = cap == kBigMT ? g / per_round : 0, left = g - full * per_round;
     if (full > 0 && left > 0 && (left <= 3 * (int64_t)cus || left > 4 * (int64_t)cus)) {
         int k = 0;
         seg_n[k] = (int32_t)(full * 2 * cus), seg_sz[k] = cap, ++k;
@@ -724,7 +667,7 @@ int big_cu_count() {
 }
 
 int launch_half_big(FusedArgs& a, int64_t n_nodes, int cap, hipStream_t st, int* n_wg_out) {
-    const int n_wg = big_plan(n_nodes, big_cu_count(), cap, a.variant, a.big_seg_n, a.big_seg_sz);
+    const int n_wg = big_plan(n_nodes, big_cu_count(), cap, a.big_seg_n, a.big_seg_sz);
     a.n_tiles = n_wg;
     const size_t lds = big_lds_bytes(a.bias_tot);  // <= 66.7 KB + 2 * 8 * 256 * 4: two workgroups per CU
     GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_big),

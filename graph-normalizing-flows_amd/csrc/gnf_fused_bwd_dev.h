@@ -339,9 +339,6 @@ __device__ __forceinline__ void half_bwd_body(const BwdArgs& a, const int bid, c
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 float* dump = reinterpret_cast<float*>(ptr_of(row, 12 + 2 * q));
-#ifdef GNF_ABL_NODUMP  // timing ablation only (wrong gradients): what the dW operand dumps cost
-                dump = nullptr;
-#endif
                 if (dump == nullptr) continue;
                 tile_dump<TM, kBwdThreads, true>(buf(q, pp), LS, dump, dld, width, row0, a.n_nodes, tid);
             }

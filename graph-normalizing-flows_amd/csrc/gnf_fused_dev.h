@@ -8,15 +8,8 @@ namespace gnf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef GNF_STAMP  // the trace hooks exist in developer builds of gnf_fused.hip only
-#define GNF_STAMP(slot)
-#define GNF_STAGE_STAMP(idx)
-#define GNF_PSTAMP(idx)
-#endif
 
-#ifndef GNF_PF
-#define GNF_PF 2  // k-groups of weights in flight ahead of the one being multiplied
-#endif
+static constexpr int kFusedPF = 2;  // k-groups of weights in flight ahead of the one being multiplied
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -50,7 +43,6 @@ struct FusedArgs {
     int32_t bias_tot;  // floats of bias per net in LDS
     int32_t mean, concat, act, inverse;
     int32_t residual;  // attention block with residual: s, t += x_cond (gnn.py:547-548)
-    int32_t variant;   // developer A/B bits (gnf_set_option("fused_variant", ...)); 0 = shipped behaviour
     // k_half_big: the launch is a sequence of runs of big_seg_n[k] workgroups that own big_seg_sz[k] row tiles of 16 nodes each
     int32_t big_seg_n[6], big_seg_sz[6];
     float eps, alpha;
@@ -78,12 +70,8 @@ struct FusedArgs {
 // B fragments come through a buffer descriptor: base = this (net, layer)'s packed weights (SGPRs),
 // soffset = wave-uniform byte offset of the 1 KiB fragment block, voffset = lane * 16.  No per-load
 // 64-bit VALU address arithmetic and a single constant address VGPR.
-#ifdef GNF_ABL_NOLOAD  // ablation: B operand from registers, no weight traffic
-#define GNF_LOAD_B(RSRC, VOFF, SOFF) (f32x4{1.f, 2.f, 3.f, 4.f} * (float)(SOFF))
-#else
 #define GNF_LOAD_B(RSRC, VOFF, SOFF) \
     __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RSRC, VOFF, SOFF, 0))
-#endif
 
 // A wave's unit of work: NV (<= 4) column tiles {nt0, nt0+ts, ...} of one layer.  All wave-uniform.
 struct WChunk {
@@ -97,7 +85,7 @@ struct WChunk {
     int ont;   // column tiles of the layer
 };
 
-static constexpr int kPF = GNF_PF;
+static constexpr int kPF = kFusedPF;
 
 // Issue the loads of the first kPF stages of chunk c into b_pre (4 tile slots; slots >= c.nv repeat the
 // last valid tile).  Called one round BEFORE the previous chunk ends - and before the prologue for
@@ -203,10 +191,6 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
     constexpr int R = PF + 1;  // register ring: PF stages in flight + the one being consumed
     const int lrow = lane & 15, lgrp = lane >> 4;
     const int ipg = c.ipg, nt0 = c.nt0;
-#ifdef GNF_TRACE_GLOBALS  // set by gnf_fused.hip in -DGNF_TRACE builds (the stamps live there)
-    const bool trace_on = c.layer == g_trace_layer;
-#endif
-    GNF_STAGE_STAMP(0);
     f32x4 acc[MT][NV];
 #pragma unroll
     for (int b = 0; b < NV; ++b) {
@@ -235,16 +219,10 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
 #pragma unroll
         for (int b = 0; b < NV; ++b) b_ring[u][b] = b_pre[u][b];
     }
-#ifndef GNF_ABL_NOMFMA
 #define GNF_MFMA_STAGE(U)                                                                          \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int b = 0; b < NV; ++b)   \
         _Pragma("unroll") for (int m = 0; m < MT; ++m) acc[m][b] =                                 \
             __builtin_amdgcn_mfma_f32_16x16x4f32(a_ring[U][m][q], b_ring[U][b][q], acc[m][b], 0, 0, 0);
-#else  // ablation: keep every load alive, issue no MFMA
-#define GNF_MFMA_STAGE(U)                                                                          \
-    _Pragma("unroll") for (int b = 0; b < NV; ++b) asm volatile("" ::"v"(b_ring[U][b]));           \
-    _Pragma("unroll") for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(a_ring[U][m]));
-#endif
     // One round = R stages; a stage = the 4*NV*MT MFMAs of k-group kg with the loads of k-group kg+PF
     // (NV buffer loads, MT LDS reads) issued in their shadow: an MFMA occupies the matrix pipe for 32
     // cycles but the wave's issue slot for ~4, so a load placed after an MFMA costs nothing, while
@@ -253,9 +231,6 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
     // other, not interleaved).  sched_group_barrier spells the interleave, sched_barrier(0) closes
     // the stage (left alone, hipcc sinks every load of a round to its end and waits vmcnt(0) at the
     // top of the next one); there is NO branch inside a round (it would also force vmcnt(0)).
-#ifdef GNF_NO_INTERLEAVE
-#define GNF_INTERLEAVE()
-#else
 #define GNF_INTERLEAVE()                                                                           \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  /* 1 MFMA */                               \
     __builtin_amdgcn_sched_group_barrier(0x100, MT, 0); /* the LDS reads of the next A fragments */ \
@@ -265,7 +240,6 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT, 0);                                    \
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                         \
     }
-#endif
 #define GNF_ROUND(KG0)                                                                             \
     _Pragma("unroll") for (int u = 0; u < R; ++u) {                                                \
         const int kg = (KG0) + u;                                                                  \
@@ -276,7 +250,6 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
             GNF_LOAD_B(rsrc, voff, wtile[b] + kn * kstride);                                       \
         GNF_MFMA_STAGE(u)                                                                          \
         GNF_INTERLEAVE()                                                                           \
-        GNF_STAGE_STAMP(2 + kg);                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
     int kg0 = 0;
@@ -305,7 +278,6 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
 #undef GNF_ROUND
 #undef GNF_INTERLEAVE
 #undef GNF_MFMA_STAGE
-    GNF_STAGE_STAMP(38);
     // accumulator layout: col = lane&15, row = 4*(lane>>4) + r.  slope: 1 on the last (linear) layer,
     // alpha (leaky) or 0 (relu) otherwise: max(v, slope*v) is branch-free for all three.
 #pragma unroll
@@ -406,15 +378,10 @@ __device__ __forceinline__ void tile_gather(const TileAgg& t, const int* __restr
                                             float* __restrict__ h0_out, int tid) {
     const int seg_beg = s_rowptr[0];
     const int seg_len = s_rowptr[TM] - seg_beg;
-#ifdef GNF_NO_STAGE_CSR
-    const bool staged = false;
-#else
     const bool staged = seg_len <= COLCAP;  // workgroup-uniform
-#endif
     // sum of x_cond[nbr, f] over the incoming edges [beg, end) of one node, in edge order
     auto gather = [&](int beg, int end, const float* xf, auto colat) -> float {
         float s = 0.f;
-#ifndef GNF_ABL_NOAGG
         int e = beg;
         for (; e + 8 <= end; e += 8) {  // 8 independent row reads in flight
             int ci[8];
@@ -437,7 +404,6 @@ __device__ __forceinline__ void tile_gather(const TileAgg& t, const int* __restr
             for (int q = 0; q < 7; ++q)
                 if (e + q < end) s += vv[q];
         }
-#endif
         return s;
     };
     const int H = t.H, in0p = t.in0p;
@@ -481,12 +447,9 @@ __device__ __forceinline__ void tile_aggregate(const TileAgg& t, const int* __re
                                                float* __restrict__ h0_out, int tid) {
     const int seg_beg = s_rowptr[0];
     const int seg_len = s_rowptr[TM] - seg_beg;
-#ifndef GNF_NO_STAGE_CSR
     if (seg_len <= COLCAP)
         for (int i = tid; i < seg_len; i += NTHR) s_col[i] = t.col[seg_beg + i];
-#endif
     __syncthreads();
-    GNF_PSTAMP(4);
     tile_gather<TM, NTHR, COLCAP>(t, s_rowptr, s_col, buf0, buf1, LS, h0_out, tid);
 }
 

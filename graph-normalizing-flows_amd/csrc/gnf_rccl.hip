@@ -46,14 +46,28 @@ static RcclApi g_rccl;
 static std::once_flag g_rccl_once;
 static char g_rccl_load_error[256] = "";
 
+static char g_rccl_loaded_from[128] = "";
+
 static void load_rccl() {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-    for (const char* nm : names) {
-        g_rccl.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-        if (g_rccl.handle) break;
-    }
+    // a copy the process already holds (PyTorch ships one) first: two RCCLs in one process would each own a set of
+    // communicators and device buffers; only then load one, privately (RTLD_LOCAL: its symbols stay out of the global scope)
+    char errs[200] = "";
+    for (int pass = 0; pass < 2 && !g_rccl.handle; ++pass)
+        for (const char* nm : names) {
+            g_rccl.handle = dlopen(nm, pass == 0 ? (RTLD_NOW | RTLD_NOLOAD) : (RTLD_NOW | RTLD_LOCAL));
+            if (g_rccl.handle) {
+                snprintf(g_rccl_loaded_from, sizeof(g_rccl_loaded_from), "%s (%s)", nm, pass == 0 ? "already in the process" : "loaded here");
+                break;
+            }
+            if (pass == 1) {
+                const char* e = dlerror();
+                const size_t used = strlen(errs);
+                if (used + 4 < sizeof(errs)) snprintf(errs + used, sizeof(errs) - used, "%s%s", used ? "; " : "", e ? e : nm);
+            }
+        }
     if (!g_rccl.handle) {
-        snprintf(g_rccl_load_error, sizeof(g_rccl_load_error), "librccl.so not found (dlopen: %s)", dlerror());
+        snprintf(g_rccl_load_error, sizeof(g_rccl_load_error), "librccl.so not found (dlopen: %s)", errs);
         return;
     }
     g_rccl.get_unique_id = (fn_get_unique_id)dlsym(g_rccl.handle, "ncclGetUniqueId");
@@ -61,8 +75,15 @@ static void load_rccl() {
     g_rccl.comm_destroy = (fn_comm_destroy)dlsym(g_rccl.handle, "ncclCommDestroy");
     g_rccl.all_reduce = (fn_all_reduce)dlsym(g_rccl.handle, "ncclAllReduce");
     g_rccl.get_error_string = (fn_get_error_string)dlsym(g_rccl.handle, "ncclGetErrorString");
-    if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce) {
-        snprintf(g_rccl_load_error, sizeof(g_rccl_load_error), "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce");
+    typedef int (*fn_get_version)(int*);
+    const fn_get_version get_version = (fn_get_version)dlsym(g_rccl.handle, "ncclGetVersion");
+    int version = 0;
+    if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce || !get_version ||
+        get_version(&version) != 0 || version < 20000) {  // (the restated declarations above are NCCL 2.x's)
+        snprintf(g_rccl_load_error, sizeof(g_rccl_load_error),
+                 "%s lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce / ncclGetVersion >= 2.0 (version %d)",
+                 g_rccl_loaded_from, version);
+        dlclose(g_rccl.handle);
         g_rccl.handle = nullptr;
     }
 }

@@ -29,20 +29,6 @@ namespace gnf {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-#ifdef GNF_DW_TRACE  // developer build: s_memtime ticks of workgroup 0 / thread 0, summed per phase
-__device__ unsigned long long g_dw_trace[8];
-#define GNF_DWT(i, t0) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); g_dw_trace[i] += t1_ - t0; t0 = t1_; } } while (0)
-extern "C" int gnf_debug_read_dw_trace(unsigned long long* out, int reset) {
-    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dw_trace), sizeof(unsigned long long) * 8);
-    if (reset) {
-        unsigned long long z[8] = {0};
-        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dw_trace), z, sizeof(z));
-    }
-    return rc;
-}
-#else
-#define GNF_DWT(i, t0)
-#endif
 
 static constexpr int TGM = 128, TGN = 64, TGK = 32;
 static constexpr int kGemmThreads = 512;
@@ -201,12 +187,8 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
     }
     __syncthreads();
     for (int64_t k0 = kbeg; k0 < kend; k0 += TGK) {
-#ifdef GNF_DW_TRACE
-        unsigned long long tt = __builtin_amdgcn_s_memtime();
-#endif
         const bool more = k0 + TGK < kend;
         if (more) fetch(k0 + TGK);  // in flight behind this step's MFMAs
-        GNF_DWT(0, tt);
         const float* As = As2 + cur * kAs;
         const float* Bs = Bs2 + cur * kBs;
         if (EPI == EPI_SLAB && BK == OPND_MC) {
@@ -248,18 +230,12 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
                     for (int m = 0; m < 2; ++m)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][q], b[n][q], acc[m][n], 0, 0, 0);
         }
-        GNF_DWT(2, tt);
         if (more) {
             tile_stash<AR, AC, 2>(As2 + (cur ^ 1) * kAs, tid, av);
             tile_stash<BR, BC, 1>(Bs2 + (cur ^ 1) * kBs, tid, bvr);
         }
-        GNF_DWT(3, tt);
         __syncthreads();
-        GNF_DWT(4, tt);
         cur ^= 1;
-#ifdef GNF_DW_TRACE
-        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_dw_trace[7] += 1;
-#endif
     }
     // accumulator layout: col = lane & 15, row = 4 * (lane >> 4) + r
     float* __restrict__ Cp = job.C;
@@ -304,9 +280,8 @@ __global__ __launch_bounds__(kGemmThreads) void k_gemm(GemmJob j0, GemmJob j1, G
 }
 
 // may the operands of a GEMM go through the buffer path? (32-bit byte offsets; a KC operand's reduction length in whole
-// float4s; gemm_no_buf: developer A/B option)
+// float4s)
 static bool gemm_buf_ok(int ak, int bk, int64_t a_rows, int64_t lda, int64_t b_rows, int64_t ldb, int64_t K) {
-    if (opt(OPT_GEMM_NO_BUF)) return false;
     if ((a_rows + 256) * lda * 4 >= ((int64_t)1 << 31) || (b_rows + 256) * ldb * 4 >= ((int64_t)1 << 31)) return false;
     if ((ak == OPND_KC || bk == OPND_KC) && K % 4 != 0) return false;
     return true;
@@ -363,11 +338,7 @@ static constexpr int kWidePieces = 4 * kWideQ;
 static constexpr int kWideLd = WGM + 4;
 static constexpr int kWideStage = 2 * WGK * kWideLd;  // floats: A tile then B tile
 static constexpr size_t kWideLdsMin = (size_t)2 * kWideStage * sizeof(float);
-// cache policy of the operand loads (A/B switch; streaming / non-temporal hints measured no different from the default)
-#ifndef GNF_DW_LOAD_POLICY
-#define GNF_DW_LOAD_POLICY 0
-#endif
-static constexpr int kWideLoadPolicy = GNF_DW_LOAD_POLICY;
+static constexpr int kWideLoadPolicy = 0;  // cache policy of the operand loads (streaming / non-temporal hints measured no different from the default)
 
 template <int G>
 struct WideGemmT {
@@ -474,9 +445,6 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <bool BUF, class WG>
 __device__ __forceinline__ void dw_wide_body(const WG& g, const int vblock, const int vgrid) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
-#ifdef GNF_DW_TRACE
-    unsigned long long tt0 = __builtin_amdgcn_s_memtime();
-#endif
     // a workgroup takes unit vblock (a chunk of one of the costliest tiles; those are cut equal) and then, strided,
     // its share of the cheap units that follow them in the list
     for (int it = 0;; ++it) {
@@ -588,15 +556,11 @@ __device__ __forceinline__ void dw_wide_body(const WG& g, const int vblock, cons
         if (BUF || kbeg + WGK < kend) fetch_any(kbeg + WGK);  // stays in flight into step 0
     }
     lds_barrier();
-    GNF_DWT(5, tt0);
     // The K loop exists once per block shape (dispatch OUTSIDE the loop: with the switch inside, the accumulators
     // crossed it in VGPRs and were copied to and from the AGPRs the MFMAs use on every step - 128 moves per step).
     auto k_loop = [&](auto mtw_c, auto ntw_c) {
         constexpr int MTW = decltype(mtw_c)::value, NTW = decltype(ntw_c)::value;
         for (int64_t k0 = kbeg; k0 < kend; k0 += WGK) {
-#ifdef GNF_DW_TRACE
-            unsigned long long tt = __builtin_amdgcn_s_memtime();
-#endif
             const float* As = wl + cur * kWideStage;
             const float* Bs = As + WGK * kWideLd;
             float* nstage = wl + (cur ^ 1) * kWideStage;
@@ -605,7 +569,6 @@ __device__ __forceinline__ void dw_wide_body(const WG& g, const int vblock, cons
                 if (k0 + WGK < kend) stash_all(nstage);
                 if (k0 + 2 * WGK < kend) fetch_any(k0 + 2 * WGK);
             }
-            GNF_DWT(0, tt);
             const int voa = va + (int)(k0 + 2 * WGK - kbeg) * (int)lda * 4, vob = vb + (int)(k0 + 2 * WGK - kbeg) * (int)ldb * 4;
             auto piece = [&](int i) {
                 if (!BUF) return;
@@ -620,13 +583,8 @@ __device__ __forceinline__ void dw_wide_body(const WG& g, const int vblock, cons
 #pragma unroll
                 for (int i = 0; i < kWidePieces; ++i) piece(i);
             }
-            GNF_DWT(2, tt);
             lds_barrier();
-            GNF_DWT(4, tt);
             cur ^= 1;
-#ifdef GNF_DW_TRACE
-            if (vblock == 0 && threadIdx.x == 0) g_dw_trace[7] += 1;
-#endif
         }
     };
     // partial blocks round up to 1 / 2 / 4 tiles (the stages are zero filled beyond M, N)
@@ -647,9 +605,6 @@ __device__ __forceinline__ void dw_wide_body(const WG& g, const int vblock, cons
         default: k_loop(I0{}, I0{}); break;
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs have left the pipe before acc is read
-#ifdef GNF_DW_TRACE
-    tt0 = __builtin_amdgcn_s_memtime();
-#endif
     // accumulator layout: col = lane & 15, row = 4 * (lane >> 4) + r
     float* __restrict__ Cp = job.C + (int64_t)chunk * M * N;
 #pragma unroll
@@ -694,10 +649,6 @@ __device__ __forceinline__ void dw_wide_body(const WG& g, const int vblock, cons
             }
         }
     }
-#ifdef GNF_DW_TRACE
-    __builtin_amdgcn_s_waitcnt(0);
-    GNF_DWT(6, tt0);
-#endif
     }  // items of this workgroup
 }
 
@@ -741,8 +692,7 @@ static int launch_gemm(const GemmJob* jobs, int nj, const GemmShape& sh, hipStre
     if (sh.M == 0 || sh.N == 0) return GNF_OK;
     {
         const int64_t tiles = (int64_t)((sh.N + TGN - 1) / TGN) * ((sh.M + TGM - 1) / TGM) * nj;
-        const bool no_split = opt(OPT_GEMM_NO_SPLITK) != 0;  // developer A/B option
-        if (sk && sk[0] && sk[nj - 1] && !no_split && EPI != EPI_SLAB && sh.chunks == 1 && tiles < 96 && sh.K >= 512) {
+        if (sk && sk[0] && sk[nj - 1] && EPI != EPI_SLAB && sh.chunks == 1 && tiles < 96 && sh.K >= 512) {
             int64_t chunks = 256 / tiles;
             if (chunks > 16) chunks = 16;
             if (chunks > sh.K / 128) chunks = sh.K / 128;
@@ -1242,7 +1192,7 @@ struct DwPolicy {
 // dW workgroup - hence the strict cap.  Without enough idle CUs to finish in the backward kernel's time, the grouped
 // kernel's many short workgroups spread the contention evenly instead.
 static DwPolicy dw_policy(const GnfMlp* net, int64_t bwd_tiles, size_t bwd_lds) {
-    const int64_t env_g = opt(OPT_DW_GROUPED), env_u = opt(OPT_DW_WIDE_UNITS), env_l = opt(OPT_DW_WIDE_LDS);  // developer A/B options
+    const int64_t env_g = opt(OPT_DW_GROUPED), env_u = opt(OPT_DW_WIDE_UNITS);  // shape forcing for the parity tests (gnf_set_option)
     DwPolicy pol{0, kWideLdsMin, 0.0};
     if (env_g) return pol;
     if (bwd_tiles > 0 && bwd_tiles <= 192 && bwd_lds > 80 * 1024) {
@@ -1260,7 +1210,6 @@ static DwPolicy dw_policy(const GnfMlp* net, int64_t bwd_tiles, size_t bwd_lds) 
         pol.budget_us = 1.4 * (2.0 * 2.0 * 16.0 * macs * 2.0) / (614e9 * 0.6) * 1e6 + 10.0;
     }
     if (env_u > 0) pol.max_units = (int)env_u, pol.budget_us = 1e30;
-    if (env_l > 0 && (size_t)env_l >= kWideLdsMin) pol.lds = (size_t)env_l;
     return pol;
 }
 
@@ -1379,10 +1328,9 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
         // ---- stream-K for the costliest jobs: equal runs of k-steps across tile boundaries instead of whole chunks ----
         // (24 tiles on 64 workgroups is 2.67 workgroups per tile: cut in whole chunks that is 2 per tile = 48 busy
         // workgroups with 43 steps each; as one axis of 24 x 85 steps it is 64 workgroups with 32 steps each)
-        const bool no_sk = opt(OPT_DW_NO_STREAMK) != 0;  // developer A/B option
         const int sk_steps = (int)((p.n + WGK - 1) / WGK);
         int sk_q = 0, sk_grid = 0, sk_cmax = 0;
-        if (!no_sk && c_heavy > 0 && heavy_tiles > 0 && heavy_tiles <= pol.max_units && sk_steps >= 8) {
+        if (c_heavy > 0 && heavy_tiles > 0 && heavy_tiles <= pol.max_units && sk_steps >= 8) {
             sk_grid = pol.max_units;
             const int64_t total_steps = (int64_t)heavy_tiles * sk_steps;
             sk_q = (int)((total_steps + sk_grid - 1) / sk_grid);
@@ -1409,17 +1357,6 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
             }
         }
         if (grid == 0 || est_us > pol.budget_us) wide = false;
-        if (opt(OPT_DW_DEBUG) & 1) {
-            static std::atomic<int> shown_ctr{0};
-            const int shown = shown_ctr.fetch_add(1) + 1;
-            if (shown <= 2)
-                fprintf(stderr, "[gnf dW] n=%lld max_units=%d heavy_tiles=%d (cost %d/16) light_tiles=%d c_heavy=%d c_light=%d grid=%d "
-                        "est %.1f us budget %.1f us lds %zu -> %s\n", (long long)p.n, pol.max_units, heavy_tiles, cmax, light_tiles,
-                        c_heavy, c_light, grid, est_us, pol.budget_us, pol.lds, wide ? "wide" : "grouped");
-            if (shown <= 2 && sk_q > 0)
-                fprintf(stderr, "[gnf dW] stream-K: %d steps per tile, runs of %d steps, %d workgroups, up to %d pieces per tile\n",
-                        sk_steps, sk_q, sk_grid, sk_cmax);
-        }
         int sk_jobs = 0;
         for (int q = 0; q < nj && wide; ++q) {
             const int e = order[q];
@@ -1470,7 +1407,7 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
         // buffer path: byte offsets inside a chunk (+ the two tiles fetched past its end) stay below 2^31.  Rows need
         // not be 16-byte aligned: buffer_load_dwordx4 only asks for dword alignment (the attention projections have
         // 170-float rows)
-        bool buf = opt(OPT_DW_NO_BUF) == 0;
+        bool buf = true;
         for (int e = 0; e < nj; ++e)
             buf = buf && (max_kchunk + 4 * WGK) * (jobs[e].lda > jobs[e].ldb ? jobs[e].lda : jobs[e].ldb) * 4 < ((int64_t)1 << 31);
         L->buf = buf;
@@ -1602,13 +1539,8 @@ static int launch_half_bwd_dw(const BwdArgs* bwd, int64_t bwd_tiles, size_t bwd_
     memset(&g, 0, sizeof(g));
     memset(&r, 0, sizeof(r));
     int n_dw = 0, r_nj = 0;
-    // developer option dw_debug, bits beyond 1 (plan print): timing ablations of this launch - 2 = the reduce in a launch
-    // of its own, 4 = no dW GEMMs, 8 = no backward tiles (4 and 8 give wrong gradients; CHANGELOG.md section 10 has the numbers)
-    const int64_t dbg = opt(OPT_DW_DEBUG);
-    if (dw && !(dbg & 4)) narrow_wide(dw->wg, &g), n_dw = dw->units;
-    if (red && !red->direct && !(dbg & 2)) narrow_reduce(red->gr, red->nj, &r), r_nj = red->nj;
-    if (red && (dbg & 2)) { const int rc_ = run_weight_reduce(*red, st); if (rc_) return rc_; }
-    if (dbg & 8) bwd = nullptr;
+    if (dw) narrow_wide(dw->wg, &g), n_dw = dw->units;
+    if (red && !red->direct) narrow_reduce(red->gr, red->nj, &r), r_nj = red->nj;
     const int n_bwd = bwd ? (int)bwd_tiles : 0;
     int grid = n_bwd + n_dw;
     if (r_nj > 0 && grid == n_bwd) grid += 64;  // reduce only: some workgroups to carry it
@@ -1629,7 +1561,7 @@ static int launch_half_bwd_dw(const BwdArgs* bwd, int64_t bwd_tiles, size_t bwd_
 
 // the backward half of the merged-launch / stash conditions (the forward half: fused_stash_shape)
 static bool merged_walk_ok(const GnfFlow* flow, int64_t n, int64_t* tiles_out, size_t* lds_out) {
-    if (opt(OPT_DW_UNMERGED) || opt(OPT_BWD_GENERIC) || opt(OPT_DW_GROUPED)) return false;
+    if (opt(OPT_BWD_GENERIC) || opt(OPT_DW_GROUPED)) return false;
     if (flow->s_nets[0].attn && 2 * (flow->s_nets[0].num_layers + 4) > kMergedGroup) return false;
     const int n_nets = flow->weight_sharing ? 2 : 2 * flow->num_timesteps;
     for (int q = 0; q < n_nets; ++q)
@@ -1644,7 +1576,7 @@ static bool merged_walk_ok(const GnfFlow* flow, int64_t n, int64_t* tiles_out, s
 
 bool mlp_stash_supported(const GnfFlow* flow, int64_t n, int32_t H) {
     (void)H;
-    if (opt(OPT_NO_MLP_STASH) || opt(OPT_BWD_GENERIC) || n <= 0 || !flow->s_nets || !flow->t_nets) return false;
+    if (opt(OPT_BWD_GENERIC) || n <= 0 || !flow->s_nets || !flow->t_nets) return false;
     const int n_nets = flow->weight_sharing ? 2 : 2 * flow->num_timesteps;
     for (int q = 0; q < n_nets; ++q)
         if (!fused_stash_shape(&flow->s_nets[q], &flow->t_nets[q], n) || !fused_bwd_supported(&flow->s_nets[q], &flow->t_nets[q]))
@@ -2022,9 +1954,9 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     if (merged) aux = nullptr;
     // attention nets: Wo of every net as transposed fragments, once per call (k_pack_wot) - the tile
     // kernel then forms dagg = dnew Wo^T itself (its last table row) and the GEMM launch in front of the edge kernels
-    // goes (7.7 us per half-step on the config-2 batch).  dw_debug bit 32 keeps the GEMM (A/B).
+    // goes (7.7 us per half-step on the config-2 batch).
     bool wot_packed = false;
-    if (flow->s_nets[0].attn && n_nets_each <= 32 && !(opt(OPT_DW_DEBUG) & 32)) {
+    if (flow->s_nets[0].attn && n_nets_each <= 32) {
         PackWot pw;
         memset(&pw, 0, sizeof(pw));
         for (int k = 0; k < n_nets_each; ++k) {
@@ -2102,7 +2034,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     bool have_fold = false;  // the previous half-step left its dL/dh0 rows for this one's prologue to scatter
     // the previous half-step's batch-norm bijector, left for this half-step's tile kernel to undo where it reads the
     // half it updates (BwdArgs.bn_part): merged walk, partial sums left by the attention backward's last kernel, no
-    // cross-rank moments; dw_debug bit 256 keeps k_bn_bwd_apply's own launch (A/B)
+    // cross-rank moments
     struct PendingBn {
         const GnfBatchNorm* bn = nullptr;
         const GnfBatchNorm* gbn = nullptr;
@@ -2124,7 +2056,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             const bool acc = flow->weight_sharing && used[half];
             used[half] = true;
             const int co = half == 0 ? 0 : H, uo = half == 0 ? H : 0;
-            const bool no_fused = opt(OPT_BWD_GENERIC) != 0;  // developer A/B option
+            const bool no_fused = opt(OPT_BWD_GENERIC) != 0;  // (shape forcing for the parity tests)
             const bool attn = nets[0]->attn != nullptr;
             const bool fused = !no_fused && fused_bwd_supported(nets[0], nets[1]);
             const int set = step % p.n_sets;
@@ -2206,16 +2138,13 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                     const int ni = flow->weight_sharing ? half : half * T + i;
                     const float* wot[2] = {wsf + p.wot + (size_t)ni * p.wot_each, wsf + p.wot + (size_t)(n_nets_each + ni) * p.wot_each};
                     have_dagg = bwd_args_add_dagg_row(&ba, wot, o.dagg, p.C, p.NV, nets[0]->attn->concat ? H : 0);
-                    if (!(opt(OPT_DW_DEBUG) & 64)) {  // (dw_debug bit 64: the scalar form of dL/dx_cond, A/B)
-                        wct[0] = wsf + p.wct + (size_t)ni * p.wct_each;
-                        wct[1] = wsf + p.wct + (size_t)(n_nets_each + ni) * p.wct_each;
-                    }
+                    wct[0] = wsf + p.wct + (size_t)ni * p.wct_each;
+                    wct[1] = wsf + p.wct + (size_t)(n_nets_each + ni) * p.wct_each;
                 }
                 if (mstashed) {
                     const float* slot = flow->mlp_stash + (size_t)(2 * i + half) * msl.slot;
                     for (int q = 0; q < 2; ++q) ba.st_in[q] = slot + msl.st + (size_t)q * msl.st_each;
-                    // dw_debug bit 16: no act' masks (timing ablation, wrong gradients)
-                    ba.mask_in = (opt(OPT_DW_DEBUG) & 16) ? nullptr : reinterpret_cast<const unsigned long long*>(slot + msl.mask);
+                    ba.mask_in = reinterpret_cast<const unsigned long long*>(slot + msl.mask);
                 }
                 const int prev = (step + 1) & 1, cur = step & 1;   // pend[prev]: half-step k-1, pend[cur]: k-2
                 rc = launch_half_bwd_dw(&ba, tiles, lds, step >= 1 && pend_ok[prev] ? &pend[prev] : nullptr,
@@ -2227,7 +2156,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 const bool last = step == 2 * T - 1;
                 const int cus = big_cu_count();
                 int room = last ? cus : cus - (int)tiles;   // CUs the backward tiles of the NEXT launch leave
-                if (const int64_t force = opt(OPT_DW_WIDE_UNITS)) room = force < room ? (int)force : room;  // developer A/B option
+                if (const int64_t force = opt(OPT_DW_WIDE_UNITS)) room = force < room ? (int)force : room;  // (shape forcing for the parity tests)
                 const DwPolicy pol{room, lds, 1e30};
                 rc = plan_weight_grads(p, pol, jobs, nj, acc, wsf, cur, &pend[cur]);
                 if (rc) return rc;
@@ -2255,7 +2184,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 ++step;
                 if (flow->bns) {
                     const bool more = !(i == 0 && half == 0);
-                    if (more && attn && bn_pre > 0 && !flow->bn_allreduce && H <= 128 && !folded && !(opt(OPT_DW_DEBUG) & 256)) {
+                    if (more && attn && bn_pre > 0 && !flow->bn_allreduce && H <= 128 && !folded) {
                         pend_bn.bn = &flow->bns[half * T + i], pend_bn.gbn = &grad->bns[half * T + i];
                         pend_bn.nparts = bn_pre, pend_bn.co = co;
                     } else {
@@ -2269,7 +2198,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
             // ---- recompute + coupling + dP chain -------------------------------------------------------------
             bool nm_have_dagg = false;
             const float* nm_wct[2] = {nullptr, nullptr};
-            if (attn && wot_packed && !(opt(OPT_DW_DEBUG) & 64)) {
+            if (attn && wot_packed) {
                 const int ni = flow->weight_sharing ? half : half * T + i;
                 nm_wct[0] = wsf + p.wct + (size_t)ni * p.wct_each;
                 nm_wct[1] = wsf + p.wct + (size_t)(n_nets_each + ni) * p.wct_each;

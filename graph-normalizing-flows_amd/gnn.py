@@ -591,12 +591,12 @@ class GRevNet:
         self._cache = None
 
     def _flow(self, hdim, device):
-        fast = (str(device), hdim, bool(self.fused), self._bn_sync_world(), _EPOCH[0])
+        fast = (str(device), hdim, bool(self.fused), self._bn_sync_key(), _EPOCH[0])
         if self._cache is not None and self._cache_fast == fast:
             return self._cache[1]
         flow = self._flow_slow(hdim, device)
         # building may itself have touched containers (first connect, device move): key on the epoch AFTER it
-        self._cache_fast = (str(device), hdim, bool(self.fused), self._bn_sync_world(), _EPOCH[0])
+        self._cache_fast = (str(device), hdim, bool(self.fused), self._bn_sync_key(), _EPOCH[0])
         return flow
 
     def _flow_slow(self, hdim, device):
@@ -612,7 +612,8 @@ class GRevNet:
         bn_list = [b.ensure_built(hdim, device) for half in self.bns for b in half] if self.use_batch_norm else []
         sync = self._bn_sync_world() if bn_list else 0
         key = (str(device), hdim, bool(self.fused), tuple(m.version for m in s_mlps + t_mlps),
-               tuple(b.attn_version() for b in blocks), tuple(b.version for b in bn_list), sync)
+               tuple(b.attn_version() for b in blocks), tuple(b.version for b in bn_list), sync,
+               self._bn_sync_key() if bn_list else 0)
         if self._cache is not None and self._cache[0] == key:
             return self._cache[1]
         n = len(s_mlps)
@@ -679,11 +680,19 @@ class GRevNet:
         if not (self.use_batch_norm and self.sync_batch_norm):
             return 1
         if self.bn_rccl_comm is not None:
-            return self.bn_rccl_comm.n_ranks + 1000   # (cache key only: distinct from any torch.distributed world size)
+            if not self.bn_rccl_comm.handle:   # (a cached GnfFlow would hold the dangling ncclComm_t)
+                raise _abi.GnfError("sync_batch_norm: bn_rccl_comm has been destroyed")
+            return self.bn_rccl_comm.n_ranks + 1000   # (distinct from any torch.distributed world size)
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
             return 1
         return dist.get_world_size(self.bn_process_group)
+
+    def _bn_sync_key(self):
+        """Cache key of the cross-rank moments: the world size AND the communicator's identity - a flow built on one
+        native communicator must not be reused after that one was destroyed or swapped for another of the same size."""
+        comm = self.bn_rccl_comm
+        return (self._bn_sync_world(), comm.handle if comm is not None and self.use_batch_norm and self.sync_batch_norm else 0)
 
     def _run(self, graph, direction, sums_out=None):
         lib = _abi.lib()
@@ -705,7 +714,8 @@ class GRevNet:
             raise ValueError("sync_batch_norm: a rank with an empty shard cannot take part in the cross-rank moments "
                              "(every rank must make the same sequence of all-reduce calls)")
         csr = csr_of(graph)
-        ws_bytes = lib.gnf_workspace_bytes(n, d, C.byref(flow))
+        with torch.cuda.device(dev):   # (the planners read the CURRENT device's CU count: size and launch on the same one)
+            ws_bytes = lib.gnf_workspace_bytes(n, d, C.byref(flow))
         ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
         sums = None
         if direction == _abi.GNF_FORWARD:

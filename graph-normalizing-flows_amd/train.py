@@ -10,8 +10,9 @@ views into it, in snt.Linear's own [in, out] layout), the gradient, and Adam's t
 the same layout: the optimiser is one elementwise launch over the whole model, and the data-parallel
 gradient exchange is one flat all-reduce (RCCL over xGMI), not one collective per variable.
 
-The drivers' default learning-rate schedule, `exponential_decay` (run_grevnet.py:341-347), is a host function here;
-any other schedule is the caller's business (`step(graph, learning_rate=...)`).
+The drivers' default learning-rate decay (tf.train.exponential_decay, run_grevnet.py:341-347) is one line of
+`current_learning_rate`; any other schedule is the caller's business (`step(graph, learning_rate=...)`; the
+--use_lr_schedule function and checkpoint / resume live in examples/driver_utils.py: out of this path's scope).
 """
 import ctypes as C
 import math
@@ -22,27 +23,6 @@ from . import _abi
 from .gnn import _touch as _gnn_touch
 from .flow import LN_2PI
 from .graphs import csr_of
-
-
-def exponential_decay(learning_rate, global_step, decay_steps, decay_rate, staircase=False):
-    """tf.train.exponential_decay as the drivers call it (run_grevnet.py:341-347)."""
-    p = global_step / float(decay_steps)
-    if staircase:
-        p = math.floor(p)
-    return learning_rate * decay_rate ** p
-
-
-def get_learning_rate(timestep, max_lr, ramp_up=1000, hold_steady=2000, const_multiple=3):
-    """The drivers' --use_lr_schedule (utils.py:93-105, called at run_grevnet.py:444): linear warm-up to max_lr over
-    `ramp_up` steps, max_lr up to and including step `hold_steady`, then max_lr * min(1, const_multiple) /
-    sqrt(steps past hold_steady).  The warm-up test comes first, so with ramp_up > hold_steady the ramp runs to its end
-    and the decay starts from there."""
-    if timestep < ramp_up:
-        return max_lr * timestep / ramp_up
-    if timestep <= hold_steady:
-        return max_lr
-    inv = 1.0 / math.sqrt(timestep - hold_steady)
-    return max_lr * min(inv, const_multiple * inv)
 
 
 class _StepTerms(dict):
@@ -297,7 +277,9 @@ class GRevNetTrainer:
         # the backward pass reads instead of recomputing it (memory for time: 2T slots; stash_attention=False keeps
         # the fully reversible, recompute-everything walk)
         fwd_flow = net._flow(d // 2, dev)
-        stash_bytes = lib.gnf_attn_stash_bytes(n, d, C.byref(fwd_flow)) if self.stash_attention else 0
+        with torch.cuda.device(dev):   # (the planners behind these sizes read the CURRENT device's CU count)
+            stash_bytes = lib.gnf_attn_stash_bytes(n, d, C.byref(fwd_flow)) if self.stash_attention else 0
+            mlp_bytes = lib.gnf_mlp_stash_bytes(n, d, C.byref(fwd_flow)) if self.stash_mlp_rows else 0
         if stash_bytes:
             if self._stash is None or self._stash.numel() < stash_bytes or self._stash.device != dev:
                 self._stash = torch.empty(stash_bytes, dtype=torch.uint8, device=dev)
@@ -305,7 +287,6 @@ class GRevNetTrainer:
         # message-passing nets on small batches: the same trade for the MLP rows (layer-0 inputs, hidden activations,
         # s and t of every half-step - what TensorFlow keeps for tf.gradients anyway): the backward kernels skip their
         # recompute half.  gnf_mlp_stash_bytes is 0 where the library would not use a stash.
-        mlp_bytes = lib.gnf_mlp_stash_bytes(n, d, C.byref(fwd_flow)) if self.stash_mlp_rows else 0
         if mlp_bytes:
             if self._mlp_stash is None or self._mlp_stash.numel() < mlp_bytes or self._mlp_stash.device != dev:
                 self._mlp_stash = torch.empty(mlp_bytes, dtype=torch.uint8, device=dev)
@@ -342,8 +323,8 @@ class GRevNetTrainer:
 
     # ---- apply_gradients -----------------------------------------------------------------------
     def current_learning_rate(self):
-        if self.use_lr_decay:
-            return exponential_decay(self.lr, self.global_step, self.lr_decay_steps, self.lr_decay_rate)
+        if self.use_lr_decay:   # tf.train.exponential_decay(lr, global_step, decay_steps, decay_rate), run_grevnet.py:341-347
+            return self.lr * self.lr_decay_rate ** (self.global_step / float(self.lr_decay_steps))
         return self.lr
 
     def apply_gradients(self, learning_rate=None):
@@ -376,40 +357,6 @@ class GRevNetTrainer:
             if self._bns:          # gamma_constraint projection (gnn.py:261-262) + UPDATE_OPS (run_grevnet.py:360), one launch
                 _abi.check(lib.gnf_bn_post_step_f32(C.byref(flow), h, self._bns[0].momentum, st), "gnf_bn_post_step_f32")
         self.global_step = t
-
-    # ---- checkpoint / resume (the drivers use tf.train.Saver, run_grevnet.py:379, 449-453) ---------------------
-    def state_dict(self):
-        """Everything a resumed run needs: parameters, Adam moments, step counter, batch-norm moving statistics."""
-        if self.theta is None:
-            raise _abi.GnfError("state_dict(): run a step (or loss_and_grads) first so that the variables exist")
-        return {"theta": self.theta.detach().cpu(), "m": self.m.detach().cpu(), "v": self.v.detach().cpu(),
-                "global_step": self.global_step,
-                "bn_moving": [(b.moving_mean.detach().cpu(), b.moving_variance.detach().cpu()) for b in self._bns]}
-
-    def load_state_dict(self, state):
-        if self.theta is None:
-            raise _abi.GnfError("load_state_dict(): connect the trainer first (run loss_and_grads on a batch)")
-        if state["theta"].numel() != self.theta.numel():
-            raise ValueError(f"checkpoint has {state['theta'].numel()} parameters, the flow has {self.theta.numel()}")
-        self.theta.copy_(state["theta"])
-        self.m.copy_(state["m"])
-        self.v.copy_(state["v"])
-        self.global_step = int(state["global_step"])
-        for b, (mm, mv) in zip(self._bns, state["bn_moving"]):
-            b.moving_mean.copy_(mm)
-            b.moving_variance.copy_(mv)
-        lib = _abi.lib()
-        dev = self.theta.device
-        with torch.cuda.device(dev):            # the matrix-core weight copies follow the restored parameters
-            flow = self.net._flow(self.net.mlps("s")[0].layer_sizes[-1], dev)
-            if self.net.fused:
-                _abi.check(lib.gnf_pack_flow(C.byref(flow), _abi.stream_ptr(dev)), "gnf_pack_flow")
-
-    def save_checkpoint(self, path):
-        torch.save(self.state_dict(), path)
-
-    def load_checkpoint(self, path):
-        self.load_state_dict(torch.load(path, map_location="cpu"))
 
     def all_reduce_gradients(self, group=None):
         """Data parallelism: total_loss is a SUM over nodes (run_grevnet.py:295), so the gradient of the global

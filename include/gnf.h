@@ -180,18 +180,15 @@ typedef struct GnfFlow {
 } GnfFlow;
 
 int gnf_abi_version(void);
-/* ABI v6: developer options (kernel-generation A/B switches and launch-shape overrides that tools/ and the parity tests
- * use to reach every code path).  value 0 = automatic.  Names (18): force_shape (<MT><NETS>, e.g. 21; 40 / 30 / 20 / 10:
- * the large-batch kernel with that many row tiles per workgroup at most), fused_variant (bits: 1 no thin-chunk form,
- * 4 attention front-end as its own launch instead of the fused kernel's prologue, 8 batch-norm bijectors as a pass of
- * their own per half-step instead of on load in that prologue, 64 no closing round of small
- * workgroups), flow_no_oop (out-of-place flows copy first instead of running the first half-step out of place),
- * attn_edge_tiled, attn_rows, gemm_no_buf, gemm_no_splitk, dw_grouped, dw_wide_units, dw_wide_lds, dw_no_streamk,
- * dw_no_buf, dw_debug (bits: 1 print the dW plan, 2 / 4 / 8 / 16 timing ablations, 32 dagg through a GEMM launch, 64
- * scalar dL/dx_cond kernel, 128 run-time head geometry in the attention backward, 256 the batch-norm bijector's
- * backward pass as its own launch), bwd_generic, dw_unmerged, no_mlp_stash, attn_bwd_rows, attn_bwd_split (the
- * training walk: DESIGN.md section 10).  Process-wide, relaxed atomics: takes effect for calls made after it returns.
- * Unknown name: GNF_EINVAL.  Nothing in the reference corresponds to these. */
+/* Launch-shape forcing (ABI v6; the list was cut from 18 A/B switches to these 6 in round 4).  The library picks its kernel
+ * instances by batch size; the parity tests force them on small batches through these named integers.  value 0 =
+ * automatic.  force_shape: fused forward workgroup shape <MT><NETS>, e.g. 21; 40 / 30 / 20 / 10: the large-batch kernel
+ * with that many row tiles per workgroup at most.  attn_kernel: 1 the attention rows kernels, 2 the edge-tiled kernel
+ * (either keeps the front-end out of the fused kernel's prologue).  attn_bwd_rows: 64 / 32 / 16 / 3264 rows per workgroup
+ * of the attention rows / edge kernels.  bwd_generic: the backward pass through the generic GEMM path.  dw_grouped: weight
+ * gradients through the grouped kernel.  dw_wide_units: the wide weight-gradient kernel with that many workgroups at most.
+ * Process-wide, relaxed atomics: takes effect for calls made after it returns.  Unknown name: GNF_EINVAL.  Nothing in the
+ * reference corresponds to these. */
 int gnf_set_option(const char* name, int64_t value);
 int64_t gnf_get_option(const char* name);
 /* Bytes of GnfFlow.attn_stash for n_nodes nodes of width D (0 when the flow's nets have no attention front-end). */

@@ -426,60 +426,3 @@ def test_config4_closing_rounds_of_the_large_batch_kernel_bitwise_vs_32_row_shap
     assert torch.equal(x.nodes, x_ref.nodes), closing
     assert abs(float(ld) - float(ld_ref)) <= 1e-9 * max(1.0, abs(float(ld_ref)))
     assert float((back.nodes - graph.nodes).abs().max()) <= 5e-5
-
-
-def test_default_flags_alternative_launch_sequences_agree():
-    """Two places where round 3 removed a launch keep the old sequence behind a developer option; both sequences must
-    give the same numbers on the bench batch with the drivers' default flags:
-      * inference / training forward: the attention front-end as the fused kernel's prologue vs its own launch
-        (fused_variant bit 4) - same arithmetic in the same order: z bitwise;
-      * forward: the batch-norm bijectors applied where the fused kernel reads the rows vs k_bn_apply's own pass per
-        half-step (fused_variant bit 8): z to 2e-5, log-det and loss to 1e-6;
-      * training walk: dagg = dnew Wo^T as the last row of the backward tile kernel vs the GEMM launch in front of the
-        edge kernels (dw_debug bit 32), and dL/dx_cond += dqkv [Wq | Wk | Wv]^T on the matrix cores vs the scalar kernel
-        (dw_debug bit 64), and the batch-norm bijector's backward pass folded into the next tile kernel vs its own launch
-        (dw_debug bit 256) - different summation trees: every gradient tensor to 5e-4 of its scale (the float32 CPU autograd of the oracle is 1e-2 off on its worst tensor)."""
-    from gnf_amd import _abi
-    from gnf_amd.train import GRevNetTrainer
-    g_cpu, p, hp = _bench_batch("default_flags_train")
-    x, s_, r_ = g_cpu.nodes.numpy(), g_cpu.senders.numpy(), g_cpu.receivers.numpy()
-    graph = graph_from_arrays(g_cpu.n_node.numpy(), g_cpu.n_edge.numpy(), s_, r_, x, DEV)
-
-    def run(**opts):
-        for k, v in opts.items():
-            _abi.set_option(k, v)
-        try:
-            net = make_product_grevnet(hp, p)
-            z, ld = net(graph, inverse=True)
-            tr = GRevNetTrainer(net)
-            out = tr.loss_and_grads(graph)
-            torch.cuda.synchronize()
-            return z.nodes.clone(), float(ld), float(out["total_loss"]), {k: v.copy() for k, v in _named(tr.named_gradients(), hp)}
-        finally:
-            for k in opts:
-                _abi.set_option(k, 0)
-
-    def _named(grads, hp_):
-        return list(_grad_tensors(grads, hp_))
-
-    z0, ld0, loss0, g0 = run()
-    z1, ld1, loss1, g1 = run(fused_variant=4)
-    assert torch.equal(z0, z1) and ld0 == ld1
-    assert abs(loss0 - loss1) <= 1e-9 * max(1.0, abs(loss0))
-    z2, ld2, loss2, g2 = run(dw_debug=32)
-    assert torch.equal(z0, z2) and loss0 == loss2
-    z3, ld3, loss3, g3 = run(dw_debug=64)   # dL/dx_cond += dqkv Wcat^T: the scalar kernel instead of the matrix-core one
-    assert torch.equal(z0, z3) and loss0 == loss3
-    z5, ld5, loss5, g5 = run(fused_variant=8)  # the bijector's forward pass: k_bn_apply per half-step instead of on load in the fused kernel
-    assert float((z0 - z5).abs().max()) <= 2e-5 and abs(ld0 - ld5) <= 1e-6 * max(1.0, abs(ld0))
-    assert abs(loss0 - loss5) <= 1e-6 * max(1.0, abs(loss0))
-    z4, ld4, loss4, g4 = run(dw_debug=256)  # the batch-norm bijector's backward pass: its own launch instead of the tile kernel's prologue
-    assert torch.equal(z0, z4) and loss0 == loss4
-    gmax = max(float(np.abs(v).max()) for v in g0.values())
-    for name in g0:
-        scale = max(float(np.abs(g0[name]).max()), 1e-3 * gmax)
-        assert float(np.abs(g0[name] - g2[name]).max()) <= 5e-4 * scale, name
-        assert float(np.abs(g0[name] - g1[name]).max()) <= 5e-4 * scale, name
-        assert float(np.abs(g0[name] - g3[name]).max()) <= 5e-4 * scale, name
-        assert float(np.abs(g0[name] - g4[name]).max()) <= 5e-4 * scale, name
-        assert float(np.abs(g0[name] - g5[name]).max()) <= 5e-4 * scale, name

@@ -68,22 +68,19 @@ def test_forward_and_inverse_replay_bitwise(community_medium, fused):
         assert torch.equal(back_c, b_e), name
 
 
-@pytest.mark.parametrize("unmerged", [0, 1], ids=["merged_launch", "forked_dw_stream"])
-def test_backward_replay_bitwise(community_medium, unmerged):
-    """The training step under capture: the default walk (one launch per half-step carrying the previous half-step's
-    weight-gradient GEMMs) and the round-1 scheme (dW GEMMs forked to the auxiliary stream with per-call events)."""
-    from gnf_amd import _abi
-    _abi.set_option("dw_unmerged", unmerged)
-    try:
-        _backward_replay(community_medium)
-    finally:
-        _abi.set_option("dw_unmerged", 0)
+@pytest.mark.parametrize("graphs", [48, 90], ids=["merged_launch", "forked_dw_stream"])
+def test_backward_replay_bitwise(community_medium, graphs):
+    """The training step under capture: the walk of batches of up to 192 tiles (one launch per half-step carrying the
+    previous half-step's weight-gradient GEMMs) and the one larger batches take (dW GEMMs forked to the auxiliary stream
+    with per-call events)."""
+    _backward_replay(community_medium, graphs)
 
 
-def _backward_replay(community_medium):
+def _backward_replay(community_medium, graphs):
     from gnf_amd.graphs import csr_of
     from gnf_amd.train import GRevNetTrainer
-    graph, x2, p = _config2(community_medium, graphs=48, seed=7)
+    graph, x2, p = _config2(community_medium, graphs=graphs, seed=7)
+    assert (graph.nodes.shape[0] > 192 * 16) == (graphs > 48)   # 192 tiles: where the merged launch ends
     net = make_product_grevnet(HP, p)
     tr = GRevNetTrainer(net)
     assert tr.overlap_weight_grads

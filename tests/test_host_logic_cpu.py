@@ -277,25 +277,6 @@ def test_check_graphs_tuple_rejects_cross_graph_edges_and_bad_counts():
         check_graphs_tuple(short)
 
 
-def test_get_learning_rate_schedule():
-    """--use_lr_schedule (utils.py:93-105): warm-up, plateau, 1 / sqrt decay scaled by min(1, const_multiple); values
-    worked out by hand from the reference's formula."""
-    import math
-    from gnf_amd.train import get_learning_rate as lr
-    assert lr(0, 0.01) == 0.0
-    assert lr(500, 0.01) == pytest.approx(0.005)
-    assert lr(999, 0.01) == pytest.approx(0.00999)
-    assert lr(1000, 0.01) == 0.01 and lr(2000, 0.01) == 0.01                 # plateau includes hold_steady itself
-    assert lr(2001, 0.01) == pytest.approx(0.01)                             # sqrt(1) = 1, min(1, 3) = 1
-    assert lr(2004, 0.01) == pytest.approx(0.005)
-    assert lr(2100, 0.01) == pytest.approx(0.001)
-    assert lr(2004, 0.01, const_multiple=0.5) == pytest.approx(0.0025)       # min(1 / 2, 0.5 / 2)
-    # ramp_up beyond hold_steady: the ramp finishes first, then the decay counts from hold_steady
-    assert lr(2500, 0.01, ramp_up=3000, hold_steady=2000) == pytest.approx(0.01 * 2500 / 3000)
-    assert lr(3000, 0.01, ramp_up=3000, hold_steady=2000) == pytest.approx(0.01 / math.sqrt(1000))
-    assert lr(10, 0.3, ramp_up=4, hold_steady=6) == pytest.approx(0.15)
-
-
 def test_chunk_readers_open_their_first_file_in_the_constructor(tmp_path):
     """file_ind exists before the first batch, an empty directory and an oversized graph fail at construction, and the
     short last batch of the last file is handed out (documented difference to train_grevnet_with_data.py:183-234)."""

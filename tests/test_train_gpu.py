@@ -390,37 +390,40 @@ def test_layer_norm_parameters_train(community_medium):
     assert np.abs(blk.attn_params["ln_beta"].cpu().numpy()).max() > 0.0
 
 
-@pytest.mark.parametrize("rows,split", [(16, 0), (32, 0), (64, 0), (3264, 0), (32, 1), (64, 1)],
-                         ids=["16", "32", "64", "32s64r", "32-two-launches", "64-two-launches"])
-def test_attention_backward_row_tile_sizes(community_medium, rows, split):
+@pytest.mark.parametrize("rows,dense", [(16, 0), (32, 0), (64, 0), (3264, 0), (32, 1), (64, 1)],
+                         ids=["16", "32", "64", "32s64r", "32-dense-two-launches", "64-dense-two-launches"])
+def test_attention_backward_row_tile_sizes(community_medium, rows, dense):
     """The attention backward's edge passes exist for 64-, 32- and 16-row tiles, k_attn_fwd_rows for 64 and 32 (the library
-    picks by batch size and mean degree; the developer option attn_bwd_rows forces one; 32-row tiles split every row's
+    picks by batch size and mean degree; the option attn_bwd_rows forces one; 32-row tiles split every row's
     edges over two lanes), and on sparse batches as ONE launch (k_attn_bwd_edges: sender tiles, which then carry the
     receivers' softmax statistics and delta in their LDS window, and receiver tiles; 3264 = 32-row sender / 64-row
-    receiver tiles) or as two (attn_bwd_split=1, what dense batches take; 16-row tiles always; also the older
-    k_attn_bwd_dx): the same loss and gradients through each.  attn_rows=1 keeps the sparse batch on the rows kernels in
-    the forward pass too."""
+    receiver tiles) or as two (what dense batches - here complete graphs - take; 16-row tiles always): the same loss and
+    gradients through each.  attn_kernel=1 keeps the sparse batch on the rows kernels in the forward pass too."""
     from gnf_amd import _abi
+    from gnf_amd.datasets import senders_receivers
     from gnf_amd.train import GRevNetTrainer
     attn = dict(num_heads=4, kq_dim=6, v_dim=5, out_dim=12, concat=True, kq_dim_division=True, residual=False)
     hp = dict(D=12, latent=32, K=2, T=2, agg="mean", combine="agg", epsilon=0.0, activation="relu",
               weight_sharing=False, attn=attn)
-    nn, ne, s, r = _batch(community_medium, [3, 50, 77, 12, 100])
+    if dense:
+        nn = np.array([30, 41, 26, 64, 35], np.int32)
+        s, r, ne = senders_receivers(nn)
+        assert len(s) >= 24 * int(nn.sum())
+    else:
+        nn, ne, s, r = _batch(community_medium, [3, 50, 77, 12, 100])
     n = int(nn.sum())
     x = np.random.default_rng(8).standard_normal((n, 12)).astype(np.float32)
     p = O.make_attn_grevnet_params(13, 6, 32, 2, 2, final_scale=0.3, **attn)
     ref = O.loss_and_grads(s, r, n, x, p, 2, activation="relu")
     _abi.set_option("attn_bwd_rows", rows)
-    _abi.set_option("attn_bwd_split", split)
-    _abi.set_option("attn_rows", 1)
+    _abi.set_option("attn_kernel", 1)
     try:
         tr = GRevNetTrainer(make_product_grevnet(hp, p))
         out = tr.loss_and_grads(graph_from_arrays(nn, ne, s, r, x, DEV))
         torch.cuda.synchronize()
     finally:
         _abi.set_option("attn_bwd_rows", 0)
-        _abi.set_option("attn_bwd_split", 0)
-        _abi.set_option("attn_rows", 0)
+        _abi.set_option("attn_kernel", 0)
     assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
     for (name, a), (_, b) in zip(_flat_attn(tr.named_gradients(), False), _flat_attn(ref["grads"], False)):
         assert np.abs(a - b).max() <= 5e-4 * np.abs(b).max() + 1e-5, name
@@ -458,17 +461,17 @@ def test_attention_backward_window_wider_than_lds():
     x = rng.standard_normal((n, 8)).astype(np.float32)
     p = O.make_attn_grevnet_params(5, 4, 16, 2, 1, final_scale=0.3, **attn)
     ref = O.loss_and_grads(s, r, n, x, p, 1, activation="relu")
-    for split in (0, 1):
-        _abi.set_option("attn_bwd_split", split)
+    for rows in (0, 16):   # 0: the one-launch form; 16-row tiles: two launches
+        _abi.set_option("attn_bwd_rows", rows)
         try:
             tr = GRevNetTrainer(make_product_grevnet(hp, p))
             out = tr.loss_and_grads(graph_from_arrays(nn, ne, s, r, x, DEV))
             torch.cuda.synchronize()
         finally:
-            _abi.set_option("attn_bwd_split", 0)
+            _abi.set_option("attn_bwd_rows", 0)
         assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
         for (name, a), (_, b) in zip(_flat_attn(tr.named_gradients(), False), _flat_attn(ref["grads"], False)):
-            assert np.abs(a - b).max() <= 5e-4 * np.abs(b).max() + 1e-5, (split, name)
+            assert np.abs(a - b).max() <= 5e-4 * np.abs(b).max() + 1e-5, (rows, name)
 
 
 def test_attention_backward_statistics_from_the_edge_tiled_forward():
@@ -687,20 +690,16 @@ DW_MODES = [   # (gnf_set_option values, dw_modes_check.py flags)
     ({}, ""),                                                     # what the library picks by itself (this batch: the merged launch)
     ({}, "ws"),                                                   # ... with weight sharing: the in-launch reduce accumulates
     ({"dw_wide_units": 8}, ""),                                   # merged launch, few dW workgroups: cheap units ride behind, strided
-    ({"dw_no_streamk": 1}, ""),                                   # ... whole chunks instead of stream-K runs
     ({"dw_wide_units": 13}, "ws"),                                # ... stream-K with an odd workgroup count
-    ({"no_mlp_stash": 1}, "ws"),                                  # merged launch recomputing the MLP rows (no stash)
-    ({"dw_no_buf": 1}, ""),                                       # ... a plan the merged launch cannot carry runs on its own
-    ({"dw_unmerged": 1}, ""),                                     # round-1 scheme: dW GEMMs on the auxiliary stream
-    ({"dw_unmerged": 1, "dw_grouped": 1}, ""),                    # the 128 x 64 grouped kernel
-    ({"dw_unmerged": 1, "dw_wide_units": 8}, ""),
-    ({"dw_unmerged": 1, "dw_wide_units": 200}, "ws"),             # many node chunks per job + accumulating reduce
-    ({"dw_unmerged": 1, "dw_wide_units": 24, "dw_no_buf": 1}, ""),  # bounds-checked generic tile fetch
-    ({"dw_unmerged": 1, "dw_wide_units": 40}, "ws,serial"),       # no auxiliary stream
-    ({"dw_unmerged": 1, "dw_wide_units": 24, "dw_no_streamk": 1}, ""),
-    ({"dw_unmerged": 1, "dw_wide_units": 13}, "ws"),
-    ({"bwd_generic": 1}, ""),                                     # generic (GEMM) backward: buffer-descriptor tile fetch
-    ({"bwd_generic": 1, "gemm_no_buf": 1}, "ws"),                 # ... through the bounds-checked fetch
+    ({}, "ws,nostash"),                                           # merged launch recomputing the MLP rows (no stash)
+    ({}, "big"),                                                  # more than 192 tiles: dW GEMMs on the auxiliary stream
+    ({"dw_grouped": 1}, ""),                                      # the 128 x 64 grouped kernel
+    ({"dw_wide_units": 8}, "big"),
+    ({"dw_wide_units": 200}, "ws,big"),                           # many node chunks per job + accumulating reduce
+    ({"dw_wide_units": 40}, "ws,serial,big"),                     # no auxiliary stream
+    ({"dw_wide_units": 13}, "ws,big"),
+    ({"bwd_generic": 1}, ""),                                     # generic (GEMM) backward
+    ({"bwd_generic": 1}, "ws"),
 ]
 
 
@@ -772,33 +771,6 @@ def test_batch_norm_allreduce_hook_contract(grid_small):
         net(graph, inverse=True)
     flow.bn_allreduce = _abi.BN_ALLREDUCE_FN()       # back to NULL
     flow.bn_sync_buf = None
-
-
-def test_checkpoint_resume_reproduces_the_run(grid_small, tmp_path):
-    """save_checkpoint after 3 steps, load into a freshly built trainer: parameters, Adam moments, step counter and
-    batch-norm moving statistics come back, and the next step is bitwise the same as in the uninterrupted run."""
-    from gnf_amd.train import GRevNetTrainer
-    hp = dict(D=8, latent=32, K=3, T=2, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu",
-              weight_sharing=False)
-    nn, ne, s, r = _batch(grid_small, list(range(12)))
-    n = int(nn.sum())
-    x = np.random.default_rng(0).standard_normal((n, 8)).astype(np.float32)
-    p = O.make_grevnet_params(4, 4, 32, 3, 2, final_scale=0.3)
-    p["bn"] = O.make_bn_params(5, 4, 2)
-    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
-    a = GRevNetTrainer(make_product_grevnet(hp, p), lr=1e-3)
-    for _ in range(3):
-        a.step(graph)
-    a.save_checkpoint(str(tmp_path / "ckpt.pt"))
-    la = float(a.step(graph)["total_loss"])
-    b = GRevNetTrainer(make_product_grevnet(hp, p), lr=1e-3)
-    b.loss_and_grads(graph)                       # connect (creates the variables), then restore
-    b.load_checkpoint(str(tmp_path / "ckpt.pt"))
-    assert b.global_step == 3
-    lb = float(b.step(graph)["total_loss"])
-    assert la == lb
-    torch.testing.assert_close(a.theta, b.theta, rtol=0, atol=0)
-    torch.testing.assert_close(a.net.bns[1][0].moving_variance, b.net.bns[1][0].moving_variance, rtol=0, atol=0)
 
 
 def test_set_params_after_training_started_reseats_the_arena(grid_small):

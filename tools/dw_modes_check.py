@@ -1,6 +1,8 @@
 """Gradient parity of one mid-size batch under whatever dW launch shape the library options force (GNF_OPTIONS=
 "dw_grouped=1,..." -> gnf_set_option through the binding; a script so that tests/test_train_gpu.py can run every
-shape in its own process).  argv[1]: comma list of "ws" (weight sharing), "serial" (no auxiliary dW stream).  Ragged layer widths exercise partial 128 x 128 tiles, thin strips (1 x 8 / 8 x 1 wave layouts),
+shape in its own process).  argv[1]: comma list of "ws" (weight sharing), "serial" (no auxiliary dW stream), "nostash"
+(the backward walk recomputes the MLP rows), "big" (3 300 nodes: more than 192 tiles, the walk whose dW GEMMs go to the
+auxiliary stream).  Ragged layer widths exercise partial 128 x 128 tiles, thin strips (1 x 8 / 8 x 1 wave layouts),
 several node chunks per job and cheap units riding behind the costly ones; weight sharing exercises the
 accumulating reduce.  Prints 'dw-modes-ok' on success."""
 import os, sys
@@ -15,7 +17,7 @@ from gnf_amd.datasets import senders_receivers
 flags = sys.argv[1].split(",") if len(sys.argv) > 1 else []
 ws = "ws" in flags
 rng = np.random.default_rng(5)
-n_node = rng.integers(9, 17, size=72).astype(np.int32)          # ~900 nodes: 4 node chunks in the plan
+n_node = rng.integers(9, 17, size=264 if "big" in flags else 72).astype(np.int32)   # ~900 nodes: 4 node chunks in the plan
 s, r, ne = senders_receivers(n_node)
 n = int(n_node.sum())
 D, L, K, T = 48, 200, 3, 2                                      # widths 24 -> 200 -> 200 -> 24
@@ -26,6 +28,8 @@ ref = O.loss_and_grads(s, r, n, x, p, T, weight_sharing=ws, **kw)
 net = make_product_grevnet(dict(D=D, latent=L, K=K, T=T, weight_sharing=ws, **kw), p)
 tr = GRevNetTrainer(net)
 tr.overlap_weight_grads = "serial" not in flags
+tr.stash_mlp_rows = "nostash" not in flags
+assert ("big" in flags) == (n > 192 * 16)
 out = tr.loss_and_grads(graph_from_arrays(n_node, ne, s, r, x, "cuda:0"))
 torch.cuda.synchronize()
 assert abs(float(out["loss_per_node"]) - ref["total_loss"] / n) <= 1e-4
