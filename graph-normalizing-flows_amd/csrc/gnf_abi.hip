@@ -452,6 +452,18 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
         hs.attn_packed[0] = attn_pack + (size_t)q * p.attn_pack_per_net;
         hs.attn_packed[1] = attn_pack + (size_t)(n_nets + q) * p.attn_pack_per_net;
     };
+    // split row tiles of the large-batch kernel (message-passing nets, batches of more than two row tiles per CU): their
+    // flags are zeroed once per call, every half-step launch gets a value of its own
+    int32_t split_epoch = 0;
+    if (n_nets > 0 && !flow->s_nets[0].attn && n > (int64_t)32 * big_cu_count()) {
+        const int in0_ = flow->s_nets[0].dims[0];
+        int lmax_ = 1;
+        for (int j = 1; j < flow->s_nets[0].num_layers; ++j) lmax_ = lmax_ > flow->s_nets[0].dims[j] ? lmax_ : flow->s_nets[0].dims[j];
+        if (big_split_offset(n, in0_) + big_split_floats() <= (size_t)n * (size_t)(in0_ + kLayeredActBufs * lmax_ + 2 * H)) {
+            GNF_HIP_TRY(hipMemsetAsync(scratch + big_split_offset(n, in0_), 0, kBigSplitMax * sizeof(int), st));
+            split_epoch = 1;
+        }
+    }
     bool first = true;
     auto mark_first = [&](HalfStep& hs, int half) {
         if (!first) return;
@@ -513,6 +525,7 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
                                 stash ? stash + (size_t)(2 * i + half) * stash_slot : nullptr, csr->n_edges};
                     mark_first(hs, half);
                     mark_attn(hs, half, i);
+                    if (split_epoch) hs.split_epoch = split_epoch++;
                     if (mstash) hs.mlp_stash = mstash + (size_t)(2 * i + half) * mstash_slot;
                     const int idx = 2 * i + half;
                     if (flow->bns && idx == 0) {
@@ -576,6 +589,7 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
                                 partials + used, &np_, nullptr, csr->n_edges};
                     mark_first(hs, half);
                     mark_attn(hs, half, i);
+                    if (split_epoch) hs.split_epoch = split_epoch++;
                     // gnn.py:356-358, 369-371: bn.forward (moving statistics) on the conditioning half AFTER the half-step - a
                     // pass of its own, or (fused attention instance) left for the next half-step of the walk, which rewrites
                     // exactly that half, to apply where it reads the old value

@@ -57,6 +57,9 @@ struct HalfStep {
     float* cond_copy = nullptr;
     // attention nets: fragment-order copies of this half-step's two attention blocks (launch_attn_pack), or NULL
     const float* attn_packed[2] = {nullptr, nullptr};
+    // large-batch kernel, split row tiles (gnf_fused_big.hip): > 0 = the caller zeroed big_split_flags(scratch, ...) at the
+    // start of its call and hands every half-step launch a value of its own (1, 2, ...); 0 = no split tiles
+    int32_t split_epoch = 0;
     // training forward: this half-step's slot of GnfFlow.mlp_stash (mlp_stash_layout), or NULL
     float* mlp_stash = nullptr;
     // forward, the flow's last two half-steps (their outputs are z): room for one fp64 partial of sum(x_upd_new^2) per
@@ -144,7 +147,12 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st);
 struct FusedArgs;
 bool big_supported(const GnfMlp* s, int32_t H);
 int big_cu_count();  // multiProcessorCount of the current device (cached per device)
-int big_plan(int64_t n_nodes, int cus, int cap, int32_t* seg_n, int32_t* seg_sz);  // -> workgroups; runs of (count, row tiles)
+// split row tiles of the large-batch kernel: [kBigSplitMax flags | kBigSplitMax x 16 x 128 floats of s rows] behind the layer-0
+// rows at the head of the half-step scratch (message-passing nets; room = the layered path's activation buffers)
+static constexpr int kBigSplitMax = 128;
+inline size_t big_split_offset(int64_t n_nodes, int in0) { return ((size_t)n_nodes * (size_t)in0 + 63) / 64 * 64; }
+inline size_t big_split_floats() { return (size_t)kBigSplitMax + (size_t)kBigSplitMax * 16 * 128; }
+int big_plan(int64_t n_nodes, int cus, int cap, int32_t* seg_n, int32_t* seg_sz, int32_t* seg_kind = nullptr, int32_t* xg0 = nullptr);  // -> workgroups; runs of (count, row tiles)
 int launch_half_big(FusedArgs& a, int64_t n_nodes, int cap, hipStream_t st, int* n_wg_out);
 // coupling epilogue from global s / t [N, H] buffers (writes hs.partials, *hs.n_partials)
 int launch_coupling(const float* s, const float* t, const HalfStep& hs, const float* xres, hipStream_t st);

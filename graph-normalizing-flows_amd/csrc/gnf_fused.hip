@@ -747,6 +747,8 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
     a.x_upd = hs.x_upd;
     memset(a.big_seg_n, 0, sizeof(a.big_seg_n));
     memset(a.big_seg_sz, 0, sizeof(a.big_seg_sz));
+    memset(a.big_seg_kind, 0, sizeof(a.big_seg_kind));
+    a.big_xg0 = 0, a.big_epoch = 0, a.big_split_s = nullptr, a.big_split_flag = nullptr;
     a.x_upd_src = hs.x_upd_src ? hs.x_upd_src : hs.x_upd;
     a.cond_copy = hs.cond_copy;
     a.partials = hs.partials;
@@ -841,6 +843,16 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
                                   a.in0, st);
             if (rc) return rc;
             a.h0[0] = a.h0[1] = scratch;
+            // split row tiles: flags and s rows behind the layer-0 rows (the caller zeroed the flags: split_epoch > 0)
+            int lmax = 1;
+            for (int j = 1; j < s->num_layers; ++j) lmax = lmax > s->dims[j] ? lmax : s->dims[j];
+            const size_t off = big_split_offset(hs.n_nodes, a.in0);
+            const size_t room = (size_t)hs.n_nodes * (size_t)(a.in0 + kLayeredActBufs * lmax + 2 * hs.H);
+            if (hs.split_epoch > 0 && big_cu_count() / 2 <= kBigSplitMax && off + big_split_floats() <= room) {
+                a.big_split_flag = reinterpret_cast<int*>(scratch + off);
+                a.big_split_s = scratch + off + kBigSplitMax;
+                a.big_epoch = hs.split_epoch;
+            }
         }
         int n_wg = 0;
         rc = launch_half_big(a, hs.n_nodes, big, st, &n_wg);

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
     // workgroup = block (dispatch order = row order: nothing here gathers, so which XCD a row tile lands on does not
     // matter); its row tiles from the launch's run table (big_plan)
     const int wg = blockIdx.x;
-    int mt = 1, row0 = 0;
+    int mt = 1, row0 = 0, kind = 0, wrun = 0;
     {
         int w = wg, g0 = 0;
 #pragma unroll
@@ -306,6 +306,8 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
             const int nk = a.big_seg_n[k], sk = a.big_seg_sz[k];
             if (w >= 0 && w < nk) {
                 mt = sk;
+                kind = a.big_seg_kind[k];
+                wrun = w;
                 g0 += w * sk;
                 w = -1;
             } else if (w >= 0) {
@@ -316,6 +318,13 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
         row0 = 16 * g0;
     }
     const int rows = a.n_nodes - row0 < 16 * mt ? a.n_nodes - row0 : 16 * mt;   // live rows (> 0)
+    // split row tile (kind 1: this workgroup runs its s-net; kind 2: its t-net and the coupling): LDS row tile `mt`, right
+    // behind the workgroup's own row tiles (which are whole 16-row tiles whenever a launch has split tiles)
+    const int xrow0 = 16 * (a.big_xg0 + wrun);
+    const int rows_x = kind == 0 ? 0 : (a.n_nodes - xrow0 < 16 ? a.n_nodes - xrow0 : 16);
+    const int mt_s = mt + (kind == 1 ? 1 : 0), mt_t = mt + (kind == 2 ? 1 : 0);
+    auto grow = [&](int rl) { return rl < 16 * mt ? row0 + rl : xrow0 + (rl - 16 * mt); };  // LDS row -> node
+    auto row_live = [&](int rl) { return rl < 16 * mt ? rl < rows : rl - 16 * mt < rows_x; };
     const int tid = threadIdx.x;
     const int H = a.H, K = a.K;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -324,16 +333,18 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
     // this wave's share of a layer: column tiles {w, w+4, w+8, w+12} x every row tile when the layer has at least 3 column
     // tiles; a thinner layer spreads its column tiles over the first cg = ont waves of each group and the row tiles over
     // the 4 / cg groups (the 256 -> 32 output layer: 2 column tiles x 2 halves of the rows)
-    auto assign = [&](BChunk& c) {  // (shifts and masks only: this runs on the scalar unit in front of every layer)
+    // mtn: row tiles of this net; mlay: row tiles the split over the wave groups is laid out for - the same for both nets in
+    // the LAST layer, whose waves keep s in registers from the s-net's pass to the t-net's (a split tile makes mt_s != mt_t)
+    auto assign = [&](BChunk& c, const int mtn, const int mlay) {  // (shifts and masks only: this runs on the scalar unit in front of every layer)
         const int ont = c.ont;
         const int cgl = ont >= 3 ? 2 : (ont <= 1 ? 0 : 1);  // log2 of the waves a group has: 4, 1, 2
         const int gl = 2 - cgl;                             // log2 of the groups: 1, 4, 2
-        const int per = (mt + (1 << gl) - 1) >> gl;         // row tiles per wave group: <= 2 when there are 2 or 4 groups
+        const int per = (mlay + (1 << gl) - 1) >> gl;       // row tiles per wave group: <= 2 when there are 2 or 4 groups
         const int g = wave >> cgl;
         c.col0 = wave & ((1 << cgl) - 1);
         c.nv = c.col0 < ont ? (ont - c.col0 + kBigWaves - 1) >> 2 : 0;
         c.m0 = g * per;
-        const int left = mt - c.m0;
+        const int left = mtn - c.m0;
         c.mw = left < 0 ? 0 : (left < per ? left : per);
         c.thin = cgl < 2;
         c.active = (c.nv > 0 && c.mw > 0) ? 1 : 0;
@@ -345,7 +356,7 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
         c.wbase = a.wp[net][j];
         c.wbytes = (unsigned)c.ipg * (unsigned)c.ont * 1024u;
         c.bias = bias_lds + net * a.bias_tot + a.boff[j];
-        assign(c);
+        assign(c, net ? mt_t : mt_s, j == K - 1 ? mt + (kind ? 1 : 0) : (net ? mt_t : mt_s));
         return c;
     };
     auto chunk_from_tab = [&](int j, int net) -> BChunk {
@@ -359,7 +370,7 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
         c.wbase = reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
         c.wbytes = (unsigned)c.ipg * (unsigned)c.ont * 1024u;
         c.bias = bias_lds + net * a.bias_tot + boff;
-        assign(c);
+        assign(c, net ? mt_t : mt_s, j == K - 1 ? mt + (kind ? 1 : 0) : (net ? mt_t : mt_s));
         return c;
     };
 
@@ -391,10 +402,10 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
 
     // layer-0 input of one net from global rows [n, in0] (the aggregation kernel's or the attention front-end's output):
     // eight 16-byte reads per thread requested before the first is stored (a 64 x 128 tile is exactly eight per thread)
-    auto load_h0 = [&](const float* __restrict__ src) {
+    auto load_h0 = [&](const float* __restrict__ src, const int mtn) {
         const int in0p = a.ipg[0] * 16;
         if ((a.in0 & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-            const int q4 = in0p >> 2, total = 16 * mt * q4;
+            const int q4 = in0p >> 2, total = 16 * mtn * q4;
 #pragma unroll 1
             for (int base = tid; base < total; base += 8 * kBigThreads) {
                 f32x4 v[8];
@@ -402,8 +413,8 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
                 for (int g = 0; g < 8; ++g) {
                     const int idx = base + g * kBigThreads;
                     const int rl = idx / q4, c = (idx - rl * q4) * 4;
-                    const bool live = idx < total && rl < rows && c < a.in0;
-                    v[g] = live ? *reinterpret_cast<const f32x4*>(src + (int64_t)(row0 + rl) * a.in0 + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const bool live = idx < total && row_live(rl) && c < a.in0;
+                    v[g] = live ? *reinterpret_cast<const f32x4*>(src + (int64_t)grow(rl) * a.in0 + c) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
@@ -414,21 +425,21 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
             }
         } else {
 #pragma unroll 1
-            for (int idx = tid; idx < 16 * mt * in0p; idx += kBigThreads) {
+            for (int idx = tid; idx < 16 * mtn * in0p; idx += kBigThreads) {
                 const int rl = idx / in0p, c = idx - rl * in0p;
-                act[rl * kBigLS + c] = (rl < rows && c < a.in0) ? src[(int64_t)(row0 + rl) * a.in0 + c] : 0.f;
+                act[rl * kBigLS + c] = (row_live(rl) && c < a.in0) ? src[(int64_t)grow(rl) * a.in0 + c] : 0.f;
             }
         }
     };
 
     // ---- A: the s-net's layer-0 input (see the header); an out-of-place first half-step also copies its conditioning
     // rows on the way ------------------------------------------------------------------------------------------
-    load_h0(a.h0[0]);
-    if (a.cond_copy) {
+    load_h0(a.h0[0], mt_s);
+    if (a.cond_copy) {  // (a split tile's rows: by the workgroup that couples it)
 #pragma unroll 1
-        for (int i = tid; i < rows * H; i += kBigThreads) {
+        for (int i = tid; i < (rows + (kind == 2 ? rows_x : 0)) * H; i += kBigThreads) {
             const int rl = i / H, f = i - rl * H;
-            a.cond_copy[(int64_t)(row0 + rl) * a.ld + f] = a.x_cond[(int64_t)(row0 + rl) * a.ld + f];
+            a.cond_copy[(int64_t)grow(rl) * a.ld + f] = a.x_cond[(int64_t)grow(rl) * a.ld + f];
         }
     }
     __syncthreads();
@@ -478,8 +489,25 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
                 }
             }
             if (last && net == 0) {
+                if (kind == 1 && cur.active) {  // the split tile's s rows: to its partner, through memory the whole device sees
+                    float* sx = a.big_split_s + (size_t)wrun * 16 * hp + (lane & 15) * hp + 16 * cur.col0 + 4 * (lane >> 4);
+#pragma unroll
+                    for (int m = 0; m < kBigMT; ++m)
+                        if (m < cur.mw && cur.m0 + m == mt) {
+#pragma unroll
+                            for (int b = 0; b < 2; ++b)
+                                if (b < cur.nv) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r)
+                                        __hip_atomic_store(sx + 16 * kBigWaves * b + r, s_keep[m][b][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                        }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                }
                 __syncthreads();  // every wave is done with the s-net's last hidden rows
-                load_h0(a.h0[1]);
+                if (kind == 1 && tid == 0)
+                    __hip_atomic_store(a.big_split_flag + wrun, a.big_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                load_h0(a.h0[1], mt_t);
                 __syncthreads();
             }
             if (has_next) {
@@ -492,6 +520,28 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
     // ---- C: coupling update from the s | t rows in LDS, rows of x coalesced (16 bytes per lane where the widths allow,
     // four requests per thread before the first use); this lane's fp64 shares of sum(s) and sum(x_new^2) ----
     __syncthreads();
+    bool lost = false;  // (the partner's s rows never came: the partial sums turn into NaN instead of the launch hanging)
+    if (kind == 2) {
+        // the split tile's s rows from the workgroup that ran its s-net (dispatched before this one, and long done with the
+        // s-net by the time this one is through both of its nets): wait for its flag, copy the rows beside t
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(a.big_split_flag + wrun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.big_epoch && ++spins < (1 << 20))
+                __builtin_amdgcn_s_sleep(32);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            red[15] = spins >= (1 << 20) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        lost = red[15] != 0.0;
+        const float* sx = a.big_split_s + (size_t)wrun * 16 * hp;
+#pragma unroll 1
+        for (int i = tid; i < 16 * hp; i += kBigThreads) {
+            const int r = i / hp, c = i - r * hp;
+            act[(16 * mt + r) * kBigLS + c] = __hip_atomic_load(sx + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+    const int rows_c = rows + (kind == 2 ? rows_x : 0);  // rows this workgroup couples (LDS rows 0 .. rows_c - 1)
     double local = 0.0, local2 = 0.0;
     {
         auto one = [&](float xv, float xr, float sv, float tv, float& xn) {
@@ -504,7 +554,7 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
                         ((reinterpret_cast<uintptr_t>(a.x_upd_src) | reinterpret_cast<uintptr_t>(a.x_upd) |
                           reinterpret_cast<uintptr_t>(a.x_cond)) & 15) == 0;
         if (v4) {
-            const int q4 = H >> 2, total = rows * q4;
+            const int q4 = H >> 2, total = rows_c * q4;
 #pragma unroll 1
             for (int base = tid; base < total; base += 4 * kBigThreads) {
                 f32x4 xv[4], xr[4];
@@ -514,7 +564,7 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
                     const int idx = base + g * kBigThreads;
                     const int i = idx < total ? idx : total - 1;
                     const int rl = i / q4, f = (i - rl * q4) * 4;
-                    off[g] = (int)((row0 + rl) * a.ld) + f;  // < 2^31: choose_big checked n_nodes * ld
+                    off[g] = (int)(grow(rl) * a.ld) + f;  // < 2^31: choose_big checked n_nodes * ld
                     xv[g] = *reinterpret_cast<const f32x4*>(a.x_upd_src + off[g]);
                     xr[g] = a.residual ? *reinterpret_cast<const f32x4*>(a.x_cond + off[g]) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
@@ -537,7 +587,7 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
                 }
             }
         } else {
-            const int total = rows * H;
+            const int total = rows_c * H;
 #pragma unroll 1
             for (int base = tid; base < total; base += 4 * kBigThreads) {  // four independent elements in flight
                 float xv[4], xr[4];
@@ -547,7 +597,7 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
                     const int idx = base + g * kBigThreads;
                     const int i = idx < total ? idx : total - 1;
                     const int rl = i / H, f = i - rl * H;
-                    off[g] = (int)((row0 + rl) * a.ld) + f;
+                    off[g] = (int)(grow(rl) * a.ld) + f;
                     xv[g] = a.x_upd_src[off[g]];
                     xr[g] = a.residual ? a.x_cond[off[g]] : 0.f;
                 }
@@ -579,6 +629,7 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
             tot += red[w];
             tot2 += red[kBigWaves + w];
         }
+        if (lost) tot = tot2 = __builtin_nan("");
         a.partials[wg] = tot;
         if (a.sq_partials) a.sq_partials[wg] = tot2;
     }
@@ -613,13 +664,33 @@ bool big_supported(const GnfMlp* s, int32_t H) {
 //     of phase by themselves.  Measured and dropped (tools/ab_shapes.sh, CHANGELOG.md): an even deal over ALL rounds
 //     (642 vs 555 us on config 4 while 3-tile workgroups still ran the 4-tile instance) and an opening of cap-tile +
 //     half-tile workgroups (the half-size one, served second, takes as long as its partner).
-int big_plan(int64_t n_nodes, int cus, int cap, int32_t* seg_n, int32_t* seg_sz) {
+int big_plan(int64_t n_nodes, int cus, int cap, int32_t* seg_n, int32_t* seg_sz, int32_t* seg_kind, int32_t* xg0) {
     for (int k = 0; k < 6; ++k) seg_n[k] = 0, seg_sz[k] = 1;
+    if (seg_kind)
+        for (int k = 0; k < 6; ++k) seg_kind[k] = 0;
+    if (xg0) *xg0 = 0;
     const int64_t g = (n_nodes + 15) / 16;
     if (g <= (int64_t)cap * 2 * cus) {
         const int64_t w = g < 2 * (int64_t)cus ? g : 2 * (int64_t)cus;
         const int base = (int)(g / w);
         const int64_t rem = g % w;
+        // Split row tiles (seg_kind != NULL: the caller has scratch and flags for them).  With every slot of the chip
+        // taken, the deal leaves a top layer of e row tiles - one more for e of the CUs, and the launch ends when those
+        // CUs do: 8 row tiles against the 7.2 a CU gets on average on the config-5 batch (1 842 row tiles on 256 CUs).
+        // When that layer covers at most half of the CUs, each of its tiles goes to TWO workgroups on different CUs -
+        // one runs its s-net, the other its t-net and the coupling - and the longest CU carries half a row tile more
+        // than the shortest instead of a whole one.  The split tiles are the batch's LAST e row tiles; a workgroup
+        // holds its own row tiles plus the split one (base + 1 <= cap LDS slots).
+        const int64_t e = rem <= cus ? rem : rem - cus;
+        if (seg_kind && xg0 && w == 2 * (int64_t)cus && e > 0 && 2 * e <= cus && base + 1 <= cap && base >= 1) {
+            int k = 0;
+            if (rem > cus) seg_n[k] = cus, seg_sz[k] = base + 1, ++k;   // every CU's first workgroup
+            seg_n[k] = (int32_t)e, seg_sz[k] = base, seg_kind[k] = 1, ++k;  // + the s-net of split tile xg0 + w
+            seg_n[k] = (int32_t)e, seg_sz[k] = base, seg_kind[k] = 2, ++k;  // + its t-net (dispatched after its partner)
+            seg_n[k] = (int32_t)((rem > cus ? cus : w) - 2 * e), seg_sz[k] = base;
+            *xg0 = (int32_t)(g - e);
+            return (int)w;
+        }
         int k = 0;
         if (rem) seg_n[k] = (int32_t)rem, seg_sz[k] = base + 1, ++k;
         seg_n[k] = (int32_t)(w - rem), seg_sz[k] = base;
@@ -667,7 +738,8 @@ int big_cu_count() {
 }
 
 int launch_half_big(FusedArgs& a, int64_t n_nodes, int cap, hipStream_t st, int* n_wg_out) {
-    const int n_wg = big_plan(n_nodes, big_cu_count(), cap, a.big_seg_n, a.big_seg_sz);
+    const bool split = a.big_split_flag && a.big_split_s && a.big_epoch > 0;
+    const int n_wg = big_plan(n_nodes, big_cu_count(), cap, a.big_seg_n, a.big_seg_sz, split ? a.big_seg_kind : nullptr, split ? &a.big_xg0 : nullptr);
     a.n_tiles = n_wg;
     const size_t lds = big_lds_bytes(a.bias_tot);  // <= 66.7 KB + 2 * 8 * 256 * 4: two workgroups per CU
     GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_big),

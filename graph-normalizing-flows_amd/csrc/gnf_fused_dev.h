@@ -45,6 +45,15 @@ struct FusedArgs {
     int32_t residual;  // attention block with residual: s, t += x_cond (gnn.py:547-548)
     // k_half_big: the launch is a sequence of runs of big_seg_n[k] workgroups that own big_seg_sz[k] row tiles of 16 nodes each
     int32_t big_seg_n[6], big_seg_sz[6];
+    // ... and big_seg_kind[k]: 0 = those row tiles and nothing else; 1 / 2 = workgroup w of the run also runs the s-net / the
+    // t-net of SPLIT row tile big_xg0 + w (a row tile whose two nets go to two workgroups on different CUs: the launch's time
+    // then moves in half row tiles per CU, gnf_fused_big.hip).  The kind-1 workgroup leaves the tile's s rows in
+    // big_split_s[w] ([16][hp] floats) and sets big_split_flag[w] = big_epoch; the kind-2 workgroup waits for it and couples.
+    int32_t big_seg_kind[6];
+    int32_t big_xg0;
+    int32_t big_epoch;
+    float* big_split_s;
+    int* big_split_flag;
     float eps, alpha;
     // training forward (STASH instance only): every row the backward pass would otherwise recompute goes to the
     // half-step's slot of GnfFlow.mlp_stash - the layer-0 input, each hidden activation of both nets, s and t

@@ -101,11 +101,13 @@ __device__ __forceinline__ void tile_stash(float* __restrict__ lds, int tid, con
 // below compiles to ~450 instructions with vmcnt(0) waits inside its scalar tails).  Columns past the valid width are
 // NOT zeroed by the range check: for an MC operand they are output columns that are never stored; for a KC operand
 // they are the reduction tail, and the lane's offset is pushed out of range instead (needs K % 4 == 0).
-template <int AK, int BK, int EPI, bool BUF = false>
+template <int AK, int BK, int EPI, bool BUF = false, int TN = TGN>
 __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& sh, const int bx, const int by,
                                           const int chunk) {
     constexpr int AR = AK == OPND_KC ? TGM : TGK, AC = AK == OPND_KC ? TGK : TGM;  // LDS tile rows x cols
-    constexpr int BR = BK == OPND_KC ? TGN : TGK, BC = BK == OPND_KC ? TGK : TGN;
+    constexpr int BR = BK == OPND_KC ? TN : TGK, BC = BK == OPND_KC ? TGK : TN;
+    constexpr int NW = TN / 32;  // 16-column MFMA tiles per wave: 2 (64-column tile) or 4 (128)
+    constexpr int UB = TN / 64;  // float4 per thread of a B tile
     // two LDS stages: the next k-tile is written into the other stage behind this one's MFMAs - ONE barrier per step and
     // nothing waits for a stage to drain (with a single stage every step stalled twice; at a few hundred rows there is
     // one workgroup per CU and nothing else to fill those stalls)
@@ -113,20 +115,20 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
     __shared__ __attribute__((aligned(16))) float As2[2 * kAs];
     __shared__ __attribute__((aligned(16))) float Bs2[2 * kBs];
     const int64_t m0 = (int64_t)by * TGM;
-    const int n0 = bx * TGN;
+    const int n0 = bx * TN;
     const int64_t kbeg = (int64_t)chunk * sh.kchunk;
     const int64_t kend = (EPI == EPI_SLAB) ? (kbeg + sh.kchunk < sh.K ? kbeg + sh.kchunk : sh.K) : sh.K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, lgrp = lane >> 4;
-    const int wm = (wave & 3) * 32, wn = (wave >> 2) * 32;
+    const int wm = (wave & 3) * 32, wn = (wave >> 2) * (TN / 2);
     const bool avec = (sh.lda % 4 == 0) && (reinterpret_cast<uintptr_t>(job.A) % 16 == 0);
     const bool bvec = (sh.ldb % 4 == 0) && (reinterpret_cast<uintptr_t>(job.B) % 16 == 0);
 
-    f32x4_t acc[2][2];
+    f32x4_t acc[2][NW];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < NW; ++b) {
             float bv = 0.f;
             if (EPI == EPI_BIAS_ACT) {
                 const int gc = n0 + wn + 16 * b + lrow;
@@ -136,7 +138,7 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
         }
     float colsum = 0.f;  // EPI_SLAB: sum over this chunk's k of B[k][n0 + tid]
 
-    f32x4_t av[2], bvr[1];
+    f32x4_t av[2], bvr[UB];
     // buffer path: descriptors over [tile's first row .. operand's last valid row], per-thread byte offsets of its float4s
     constexpr int AC4 = AC / 4, BC4 = BC / 4;
     const int64_t a_rows = AK == OPND_KC ? sh.M - m0 : kend - kbeg, b_rows = BK == OPND_KC ? (int64_t)sh.N - n0 : kend - kbeg;
@@ -148,7 +150,7 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
         const_cast<float*>(b_base), 0, BUF && b_rows > 0 ? (int)((b_rows * sh.ldb - (BK == OPND_KC ? 0 : n0)) * 4) : 0, 0x00020000);
     const int ar = tid / AC4, ac = (tid % AC4) * 4, br = tid / BC4, bc = (tid % BC4) * 4;
     const int va0 = (ar * (int)sh.lda + ac) * 4, va1 = ((ar + kGemmThreads / AC4) * (int)sh.lda + ac) * 4;
-    const int vb0 = (br * (int)sh.ldb + bc) * 4;
+    const int vb0 = (br * (int)sh.ldb + bc) * 4, vb1 = ((br + kGemmThreads / BC4) * (int)sh.ldb + bc) * 4;
     constexpr int kOut = 0x7fffffff;  // beyond any descriptor: the load returns zeros
     auto fetch = [&](int64_t k0) {
         if (BUF) {
@@ -165,8 +167,10 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
             if (BK == OPND_KC) {
                 const bool in = k0 + bc < kend;
                 bvr[0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rb, in ? vb0 + (int)k0 * 4 : kOut, 0, 0));
+                if (UB > 1) bvr[UB - 1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rb, in ? vb1 + (int)k0 * 4 : kOut, 0, 0));
             } else {
                 bvr[0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rb, vb0 + (int)(k0 - kbeg) * (int)sh.ldb * 4, 0, 0));
+                if (UB > 1) bvr[UB - 1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rb, vb1 + (int)(k0 - kbeg) * (int)sh.ldb * 4, 0, 0));
             }
             return;
         }
@@ -175,15 +179,15 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
         else
             tile_fetch<AR, AC, 2>(job.A + k0 * sh.lda + m0, sh.lda, kend - k0, sh.M - m0, avec, tid, av);
         if (BK == OPND_KC)
-            tile_fetch<BR, BC, 1>(job.B + (int64_t)n0 * sh.ldb + k0, sh.ldb, sh.N - n0, kend - k0, bvec, tid, bvr);
+            tile_fetch<BR, BC, UB>(job.B + (int64_t)n0 * sh.ldb + k0, sh.ldb, sh.N - n0, kend - k0, bvec, tid, bvr);
         else
-            tile_fetch<BR, BC, 1>(job.B + k0 * sh.ldb + n0, sh.ldb, kend - k0, sh.N - n0, bvec, tid, bvr);
+            tile_fetch<BR, BC, UB>(job.B + k0 * sh.ldb + n0, sh.ldb, kend - k0, sh.N - n0, bvec, tid, bvr);
     };
     int cur = 0;
     if (kbeg < kend) {
         fetch(kbeg);
         tile_stash<AR, AC, 2>(As2, tid, av);
-        tile_stash<BR, BC, 1>(Bs2, tid, bvr);
+        tile_stash<BR, BC, UB>(Bs2, tid, bvr);
     }
     __syncthreads();
     for (int64_t k0 = kbeg; k0 < kend; k0 += TGK) {
@@ -192,14 +196,14 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
         const float* As = As2 + cur * kAs;
         const float* Bs = Bs2 + cur * kBs;
         if (EPI == EPI_SLAB && BK == OPND_MC) {
-            if (by == 0 && tid < TGN) {
+            if (by == 0 && tid < TN) {
 #pragma unroll 8
                 for (int k = 0; k < TGK; ++k) colsum += Bs[k * (BC + 4) + tid];
             }
         }
 #pragma unroll
         for (int kg = 0; kg < TGK / 16; ++kg) {
-            float a[2][4], b[2][4];
+            float a[2][4], b[NW][4];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 if (AK == OPND_KC) {
@@ -212,7 +216,7 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
                 }
             }
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int n = 0; n < NW; ++n) {
                 if (BK == OPND_KC) {
                     const f32x4_t t = *reinterpret_cast<const f32x4_t*>(Bs + (wn + 16 * n + lrow) * (BC + 4) + 16 * kg + 4 * lgrp);
 #pragma unroll
@@ -225,14 +229,14 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                for (int n = 0; n < NW; ++n)
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][q], b[n][q], acc[m][n], 0, 0, 0);
         }
         if (more) {
             tile_stash<AR, AC, 2>(As2 + (cur ^ 1) * kAs, tid, av);
-            tile_stash<BR, BC, 1>(Bs2 + (cur ^ 1) * kBs, tid, bvr);
+            tile_stash<BR, BC, UB>(Bs2 + (cur ^ 1) * kBs, tid, bvr);
         }
         __syncthreads();
         cur ^= 1;
@@ -243,7 +247,7 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < NW; ++b) {
             const int gc = n0 + wn + 16 * b + lrow;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -263,7 +267,7 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
                 }
             }
         }
-    if (EPI == EPI_SLAB && job.aux_out && by == 0 && tid < TGN && n0 + tid < sh.N)
+    if (EPI == EPI_SLAB && job.aux_out && by == 0 && tid < TN && n0 + tid < sh.N)
         job.aux_out[(int64_t)chunk * sh.N + n0 + tid] = colsum;
 }
 
@@ -272,11 +276,11 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
 // 1600 cycles per step; wide_fc 10.4 -> 10.8 ms, the 2048-wide trainer 12.0 -> 13.0 ms per iteration.  Removed in round 3
 // with its developer option; DESIGN.md's changelog has the numbers.)
 
-template <int AK, int BK, int EPI, bool BUF>
+template <int AK, int BK, int EPI, bool BUF, int TN = TGN>
 __global__ __launch_bounds__(kGemmThreads) void k_gemm(GemmJob j0, GemmJob j1, GemmShape sh) {
     const int jz = blockIdx.z / sh.chunks, chunk = blockIdx.z - jz * sh.chunks;
     const GemmJob job = jz ? j1 : j0;
-    gemm_tile<AK, BK, EPI, BUF>(job, sh, blockIdx.x, blockIdx.y, chunk);
+    gemm_tile<AK, BK, EPI, BUF, TN>(job, sh, blockIdx.x, blockIdx.y, chunk);
 }
 
 // may the operands of a GEMM go through the buffer path? (32-bit byte offsets; a KC operand's reduction length in whole
@@ -692,8 +696,8 @@ static int launch_gemm(const GemmJob* jobs, int nj, const GemmShape& sh, hipStre
     if (sh.M == 0 || sh.N == 0) return GNF_OK;
     {
         const int64_t tiles = (int64_t)((sh.N + TGN - 1) / TGN) * ((sh.M + TGM - 1) / TGM) * nj;
-        if (sk && sk[0] && sk[nj - 1] && EPI != EPI_SLAB && sh.chunks == 1 && tiles < 96 && sh.K >= 512) {
-            int64_t chunks = 256 / tiles;
+        if (sk && sk[0] && sk[nj - 1] && EPI != EPI_SLAB && sh.chunks == 1 && tiles < 192 && sh.K >= 512) {
+            int64_t chunks = 2 * (int64_t)big_cu_count() / tiles;  // two 54 KB workgroups fit a CU
             if (chunks > 16) chunks = 16;
             if (chunks > sh.K / 128) chunks = sh.K / 128;
             while (chunks > 1 && (size_t)chunks * sh.M * sh.N > sk_floats) --chunks;
@@ -720,8 +724,15 @@ static int launch_gemm(const GemmJob* jobs, int nj, const GemmShape& sh, hipStre
             }
         }
     }
-    dim3 grid((unsigned)((sh.N + TGN - 1) / TGN), (unsigned)((sh.M + TGM - 1) / TGM), (unsigned)(nj * sh.chunks));
     const bool buf = gemm_buf_ok(AK, BK, AK == OPND_KC ? sh.M : sh.K, sh.lda, BK == OPND_KC ? (int64_t)sh.N : sh.K, sh.ldb, sh.K);
+    // 128 x 128 tiles once they fill every CU's two slots (2 x 73.7 KB of LDS)
+    if (buf && EPI != EPI_SLAB && (int64_t)((sh.N + 127) / 128) * ((sh.M + TGM - 1) / TGM) * nj * sh.chunks >= 2 * (int64_t)big_cu_count()) {
+        dim3 grid2((unsigned)((sh.N + 127) / 128), (unsigned)((sh.M + TGM - 1) / TGM), (unsigned)(nj * sh.chunks));
+        hipLaunchKernelGGL((k_gemm<AK, BK, EPI, true, 128>), grid2, dim3(kGemmThreads), 0, st, jobs[0], jobs[nj - 1], sh);
+        GNF_LAUNCH_CHECK("k_gemm (128-column tiles)");
+        return GNF_OK;
+    }
+    dim3 grid((unsigned)((sh.N + TGN - 1) / TGN), (unsigned)((sh.M + TGM - 1) / TGM), (unsigned)(nj * sh.chunks));
     if (buf)
         hipLaunchKernelGGL((k_gemm<AK, BK, EPI, true>), grid, dim3(kGemmThreads), 0, st, jobs[0], jobs[nj - 1], sh);
     else

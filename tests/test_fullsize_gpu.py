@@ -469,3 +469,39 @@ def test_config4_closing_rounds_of_the_large_batch_kernel_bitwise_vs_32_row_shap
     assert torch.equal(x.nodes, x_ref.nodes), closing
     assert abs(float(ld) - float(ld_ref)) <= 1e-9 * max(1.0, abs(float(ld_ref)))
     assert float((back.nodes - graph.nodes).abs().max()) <= 5e-5
+
+
+@pytest.mark.parametrize("graphs,layout", [(24, "1 + half | 1"), (43, "2 | 1 + half | 1"), (53, "2 + half | 2"), (70, "3 | 2 + half | 2"),
+                                           (80, "3 + half | 3"), (97, "4 | 3 + half | 3")])
+def test_config4_split_row_tiles_of_the_large_batch_kernel_bitwise_vs_32_row_shape(graphs, layout):
+    """Batches of up to one pass of the chip whose even deal leaves a top layer of row tiles on at most half of the CUs:
+    each of those tiles is SPLIT - one workgroup runs its s-net and hands the s rows over through device memory, another
+    (on another CU) its t-net and the coupling (gnf_fused_big.hip, big_plan).  Same arithmetic per row: forward and inverse
+    must equal the 32-row both-nets shape bitwise, in every layout (1 - 3 own row tiles per split workgroup, with and
+    without a full first layer of workgroups, a partial last row tile among the split ones)."""
+    from gnf_amd import _abi
+    g_cpu, p, hp = _bench_batch("config4", graphs)
+    nn = g_cpu.n_node.numpy()
+    n = int(nn.sum())
+    tiles, cus = (n + 15) // 16, torch.cuda.get_device_properties(0).multi_processor_count
+    rem = tiles % (2 * cus)
+    e = rem if rem <= cus else rem - cus
+    if not (2 * cus < tiles <= 8 * cus and 0 < e <= cus // 2):
+        pytest.skip("this device's CU count gives the batch no split tiles")
+    net = make_product_grevnet(hp, p)
+    graph = graph_from_arrays(nn, g_cpu.n_edge.numpy(), g_cpu.senders.numpy(), g_cpu.receivers.numpy(), g_cpu.nodes.numpy(), DEV)
+    try:
+        _abi.set_option("force_shape", 22)
+        z_ref, ld_ref = net(graph, inverse=True)
+        x_ref = net(graph, inverse=False)
+        _abi.set_option("force_shape", 40)
+        z, ld = net(graph, inverse=True)
+        x = net(graph, inverse=False)
+        z2, ld2 = net(graph, inverse=True)          # the flags of the first call do not leak into the next
+    finally:
+        _abi.set_option("force_shape", 0)
+    torch.cuda.synchronize()
+    assert torch.equal(z.nodes, z_ref.nodes), layout
+    assert torch.equal(x.nodes, x_ref.nodes), layout
+    assert torch.equal(z2.nodes, z.nodes) and float(ld2) == float(ld), layout
+    assert abs(float(ld) - float(ld_ref)) <= 1e-9 * max(1.0, abs(float(ld_ref)))
