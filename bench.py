@@ -80,14 +80,14 @@ PEAK_HBM_GBS = 8000.0
 
 
 def kernel_source_stamp():
-    """sha256 over the sources of the dominant kernels (k_half_fused, with the attention front-end as its prologue, and
-    k_half_big: gnf_fused.hip + gnf_fused_dev.h + gnf_attn_front_dev.h + gnf_fused_big.hip): what the PMC passes under
-    profiles/ were taken on.  (There is no .git on the GPU box, so the
+    """sha256 over the sources of the dominant kernels (k_half_fused, with the attention front-end as its prologue,
+    k_half_big and kernel A: gnf_fused.hip + gnf_fused_dev.h + gnf_attn_front_dev.h + gnf_fused_big.hip + gnf_layered.hip):
+    what the PMC passes under profiles/ were taken on.  (There is no .git on the GPU box, so the
     stamp is content-based.)"""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "graph-normalizing-flows_amd", "csrc")
-    for name in ("gnf_fused.hip", "gnf_fused_dev.h", "gnf_attn_front_dev.h", "gnf_fused_big.hip"):
+    for name in ("gnf_fused.hip", "gnf_fused_dev.h", "gnf_attn_front_dev.h", "gnf_fused_big.hip", "gnf_layered.hip"):
         h.update(name.encode())
         h.update(open(os.path.join(csrc, name), "rb").read())
     return h.hexdigest()[:16]
@@ -733,8 +733,21 @@ def main():
     kernel_a = {"kernel": "k_aggregate<4> (gnf_aggregate_f32)", "us": round(agg_us, 2),
                 "algorithmic_bytes": agg_bytes, "achieved_gbs": round(agg_bytes / agg_us / 1e3, 1),
                 "peak_gbs": PEAK_HBM_GBS, "frac": round(agg_bytes / agg_us / 1e3 / PEAK_HBM_GBS, 4),
-                "note": "launch-latency-bound at this batch size (a few us); 2.9 TB/s algorithmic on 77k-308k node "
-                        "batches (tools/probe_agg.py, profiles/)"}
+                "traffic": None, "traffic_gbs": None,
+                "note": "HIP events around gnf_aggregate_f32 alone, back to back (the launch inside a flow sees the previous "
+                        "kernel's rows come back through memory: the rocprofv3 average next to `traffic`); launch-latency-bound "
+                        "on small batches (a few us); 2.9 TB/s algorithmic on 77k-308k node batches (tools/probe_agg.py, profiles/)"}
+    try:   # counter evidence of kernel A inside this workload's flow, when a PMC pass of this build exists (k_half_big workloads)
+        pm_a = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        ka = next((v for k, v in pm_a.get("workloads", {}).get(args.workload, {}).get("kernels", {}).items() if k.startswith("k_aggregate")), None)
+        if ka and pm_a.get("source_stamp") == kernel_source_stamp():
+            kernel_a["traffic"] = round(ka["traffic_bytes_per_launch"])
+            kernel_a["traffic_gbs"] = round(ka["hbm_gbs_over_rocprof_avg"], 1)
+            kernel_a["traffic_note"] = (f"rocprofv3 --pmc FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE of k_aggregate inside the flow, "
+                                        f"mean per launch; / its rocprofv3 average of {ka['rocprof_avg_us']} us = HBM-side GB/s "
+                                        f"(profiles/pmc_traffic.json, tag {pm_a['workloads'][args.workload].get('tag')}, kernel sources = this build)")
+    except (OSError, ValueError, KeyError):
+        pass
 
     flops, abytes = algorithmic_half_step(n_local, e_local, HP)
     # HBM-side bytes per launch come from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950

@@ -1,20 +1,25 @@
 #!/bin/bash
-# Round-end evidence run (on the GPU box): the PMC / kernel-stat passes of the forward workloads, kernel stats of the
-# training workloads, one un-profiled bench line per workload.   tools/final_profile.sh <tag>
+# Round-end evidence (on the GPU box), two phases because bench.py quotes counter traffic only from a
+# profiles/pmc_traffic.json that was taken on the build's own kernel sources:
+#   tools/final_profile.sh pmc <tag>    PMC / kernel-stat passes (tools/pmc_shape.sh) of the forward workloads (kernel A
+#                                       reported next to the dominant kernel), the training workloads and the wide layers
+#     -> here: for w in ...; do python tools/summarize_profile.py --pmc-shape gpurun_out/pmc_<tag>_$w $w; done; commit
+#   tools/final_profile.sh bench <tag>  one un-profiled bench line per workload + the driver-shaped default run
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-tag=${1:-r3z}
+phase=${1:-pmc}; tag=${2:-r4z}
 cd $R
-for w in config2 config4 config5 config2_attn; do
-  timeout 600 bash tools/pmc_shape.sh ${tag}_$w $w > gpurun_out/pmc_${tag}_$w.log 2>&1
-done
-cd /tmp && export TMPDIR=/tmp
-for w in config2_train default_flags_train; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kt_${tag}_$w -o kt -- python $R/bench.py --workload $w --steps 40 --warmup 10 --no-cpu-baseline --no-secondary --latency-steps 0 > $R/gpurun_out/kt_${tag}_$w.log 2>&1
-  python $R/tools/kstats.py $R/gpurun_out/kt_${tag}_$w 24 > $R/gpurun_out/kt_${tag}_$w.txt
-done
-cd $R
-for w in config2_fc config2_attn default_flags config4 config5 wide_fc config2_train default_flags_train; do
-  timeout 300 python bench.py --workload $w --no-cpu-baseline --no-secondary --latency-steps 0 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_$w.json
-done
-timeout 600 python bench.py 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_config2_default_run.json
+if [ "$phase" = pmc ]; then
+  for w in config2 config4 config5 config2_attn default_flags; do
+    timeout 600 bash tools/pmc_shape.sh ${tag}_$w $w "" k_aggregate > gpurun_out/pmc_${tag}_$w.log 2>&1
+  done
+  for w in config2_train default_flags_train; do
+    timeout 600 bash tools/pmc_shape.sh ${tag}_$w $w "" k_half_fused,k_half_bwd,k_reduce,k_attn,k_adam > gpurun_out/pmc_${tag}_$w.log 2>&1
+  done
+  timeout 600 bash tools/pmc_shape.sh ${tag}_wide_fc wide_fc "" k_gemm,k_splitk,k_aggregate,k_coupling > gpurun_out/pmc_${tag}_wide_fc.log 2>&1
+else
+  for w in config2_fc config2_attn default_flags config4 config5 wide_fc config2_train default_flags_train; do
+    timeout 300 python bench.py --workload $w --no-cpu-baseline --no-secondary --latency-steps 0 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_$w.json
+  done
+  ( time timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 ) 2> gpurun_out/${tag}_bench_config2_default_run.time | tail -1 > gpurun_out/${tag}_bench_config2_default_run.json
+fi
 ls gpurun_out | grep $tag

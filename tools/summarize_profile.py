@@ -30,19 +30,42 @@ def merge_traffic(path, stamp, workload, entry):
 
 
 def merge_pmc_shape(src, workload, dst):
-    """A tools/pmc_shape.sh output directory (gpurun_out/pmc_<tag>) -> profiles/<tag>_rocprof_summary.txt + its entry."""
+    """A tools/pmc_shape.sh output directory (gpurun_out/pmc_<tag>) -> profiles/<tag>_rocprof_summary.txt + its entry
+    (the launch's dominant kernel, and under "kernels" every other kernel the run was asked to report - kernel A, the
+    training kernels - with its own counter traffic and rocprofv3 average)."""
     import re
     tag = os.path.basename(os.path.normpath(src))[len("pmc_"):]
     txt = open(os.path.join(src, "pmc_means.txt")).read()
     stamp = re.search(r"stamp \(bench.kernel_source_stamp\): (\w+)", txt).group(1)
-    vals = {m.group(2): float(m.group(1)) for m in re.finditer(r"^\s*([\d.]+)\s+n=\s*\d+\s+(\w+)$", txt, re.M)}
-    kern = re.search(r"# dominant kernel: (.*)", txt).group(1).strip()
-    f, w = vals["FETCH_SIZE"] * 1024 * 2, vals["WRITE_SIZE"] * 1024
-    merge_traffic(os.path.join(dst, "pmc_traffic.json"), stamp, workload,
-                  {"tag": tag, "kernel": kern, "fetch_bytes_per_launch": f, "write_bytes_per_launch": w,
-                   "traffic_bytes_per_launch": f + w, "l2_hit_rate": vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]),
-                   "mfma_busy_cycles_per_launch": vals["SQ_VALU_MFMA_BUSY_CYCLES"],
-                   "grbm_gui_active_sum_over_8_xcds": vals["GRBM_GUI_ACTIVE"]})
+    sections = []   # (name, average us, {counter: mean})
+    for line in txt.split("\n"):
+        m = re.match(r"# (?:dominant )?kernel: (.*?)\s+\(kernel-trace pass: (\d+) calls, average ([\d.]+) us\)", line)
+        if m:
+            sections.append((m.group(1).strip(), float(m.group(3)), {}))
+            continue
+        m = re.match(r"^\s*([\d.]+)\s+n=\s*\d+\s+(\w+)$", line)
+        if m and sections:
+            sections[-1][2][m.group(2)] = float(m.group(1))
+
+    def entry(name, avg_us, vals):
+        f, w = vals["FETCH_SIZE"] * 1024 * 2, vals["WRITE_SIZE"] * 1024
+        e = {"kernel": name, "rocprof_avg_us": avg_us, "fetch_bytes_per_launch": f, "write_bytes_per_launch": w,
+             "traffic_bytes_per_launch": f + w, "hbm_gbs_over_rocprof_avg": (f + w) / avg_us / 1e3}
+        if "TCC_HIT_sum" in vals:
+            e["l2_hit_rate"] = vals["TCC_HIT_sum"] / max(1.0, vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"])
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in vals:
+            e["mfma_busy_cycles_per_launch"] = vals["SQ_VALU_MFMA_BUSY_CYCLES"]
+        if "GRBM_GUI_ACTIVE" in vals:
+            e["grbm_gui_active_sum_over_8_xcds"] = vals["GRBM_GUI_ACTIVE"]
+        return e
+    dom = entry(*sections[0])
+    dom["tag"] = tag
+    dom["kernels"] = {}
+    for name, avg_us, vals in sections[1:]:
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            short = re.sub(r"^(void )?gnf::", "", name).split("(")[0]
+            dom["kernels"][short] = entry(name, avg_us, vals)
+    merge_traffic(os.path.join(dst, "pmc_traffic.json"), stamp, workload, dom)
     lines = [f"# tools/pmc_shape.sh {tag} {workload}: rocprofv3 --kernel-trace --stats of bench.py --workload {workload} --steps 20 "
              "--warmup 5 --no-cpu-baseline --no-secondary --latency-steps 0 --prewarm-ms 0, then one --pmc pass per counter group",
              open(os.path.join(src, "kernel_stats.txt")).read(), txt,
