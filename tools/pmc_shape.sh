@@ -48,4 +48,5 @@ for k, name in enumerate(names):
         print(f"#   -> HBM-side traffic {b / 1e6:.2f} MB per launch = {b / avg[name] / 1e3:.1f} GB/s over the kernel-trace average")
 PY
 $B --steps 50 --warmup 10 > $out/bench.json 2> $out/bench.err
+rm -rf $out/trace $out/p[0-9] $out/p[0-9].log   # (the raw csv files: tens of MB per workload; gpurun merges 64 MiB back at most)
 cat $out/kernel_stats.txt $out/pmc_means.txt; tail -1 $out/bench.json
