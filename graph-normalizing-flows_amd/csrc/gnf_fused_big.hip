@@ -288,6 +288,8 @@ __device__ __forceinline__ void big_chunk_thin(float* __restrict__ act, const BC
     big_layer_end<1, MW>(act, c, lane, acc, last, slope, s_keep, couple, hp);
 }
 
+// SPLIT: the launch has split row tiles (big_seg_kind != 0 somewhere); the plain instance carries none of that code
+template <bool SPLIT>
 __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_half_big(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* act = smem;
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
             const int nk = a.big_seg_n[k], sk = a.big_seg_sz[k];
             if (w >= 0 && w < nk) {
                 mt = sk;
-                kind = a.big_seg_kind[k];
+                kind = SPLIT ? a.big_seg_kind[k] : 0;
                 wrun = w;
                 g0 += w * sk;
                 w = -1;
@@ -742,9 +744,16 @@ int launch_half_big(FusedArgs& a, int64_t n_nodes, int cap, hipStream_t st, int*
     const int n_wg = big_plan(n_nodes, big_cu_count(), cap, a.big_seg_n, a.big_seg_sz, split ? a.big_seg_kind : nullptr, split ? &a.big_xg0 : nullptr);
     a.n_tiles = n_wg;
     const size_t lds = big_lds_bytes(a.bias_tot);  // <= 66.7 KB + 2 * 8 * 256 * 4: two workgroups per CU
-    GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_big),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024)));  // (K = 8 layers of 256: 83.3 KB)
-    hipLaunchKernelGGL(k_half_big, dim3((unsigned)n_wg), dim3(kBigThreads), lds, st, a);
+    GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_big<false>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024));  // (K = 8 layers of 256: 83.3 KB)
+                        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_half_big<true>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024)));
+    bool any_split = false;
+    for (int k = 0; k < 6; ++k) any_split = any_split || (a.big_seg_n[k] > 0 && a.big_seg_kind[k] != 0);
+    if (any_split)
+        hipLaunchKernelGGL(k_half_big<true>, dim3((unsigned)n_wg), dim3(kBigThreads), lds, st, a);
+    else
+        hipLaunchKernelGGL(k_half_big<false>, dim3((unsigned)n_wg), dim3(kBigThreads), lds, st, a);
     GNF_LAUNCH_CHECK("k_half_big");
     *n_wg_out = n_wg;
     return GNF_OK;
