@@ -59,8 +59,8 @@ def test_workload_table():
 
 def test_line_consistency_checks():
     """kernel_us x launches_per_step <= ms_per_step (round 2's attention line had 78.8 us x 16 = 1.26 ms against a 0.866 ms
-    step: its kernel-timing leg ran a path the step does not), on synthetic lines and on every round-3 line committed
-    under profiles/."""
+    step: its kernel-timing leg ran a path the step does not), on synthetic lines and on every round-3 / round-4 line
+    committed under profiles/ (the default line's secondary workloads included)."""
     import glob
     import json
     import os
@@ -75,13 +75,15 @@ def test_line_consistency_checks():
     assert any("kernel_us" in e for e in bench.line_consistency_errors(bad))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     seen = 0
-    for f in sorted(glob.glob(os.path.join(root, "profiles", "r3*"))):
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "r3*")) + glob.glob(os.path.join(root, "profiles", "r4*"))):
         for line in open(f, errors="replace"):
             if line.startswith('{"metric"'):
                 d = json.loads(line)
                 assert bench.line_consistency_errors(d) == [], (f, bench.line_consistency_errors(d))
+                for wl, e in (d.get("secondary_workloads") or {}).items():
+                    assert e.get("consistency") == [], (f, wl, e.get("consistency"))
                 seen += 1
-    assert seen >= 1
+    assert seen >= 10
 
 
 def test_bench_gpus_n_without_devices_prints_an_error_line_and_fails():
