@@ -81,7 +81,7 @@ def test_line_consistency_checks():
                 d = json.loads(line)
                 assert bench.line_consistency_errors(d) == [], (f, bench.line_consistency_errors(d))
                 for wl, e in (d.get("secondary_workloads") or {}).items():
-                    assert e.get("consistency") == [], (f, wl, e.get("consistency"))
+                    assert e.get("consistency") in ([], None), (f, wl, e.get("consistency"))   # (None: round-3 lines had no per-child check)
                 seen += 1
     assert seen >= 10
 
