@@ -303,6 +303,80 @@ def test_aggregate_kernel_alone(community_medium, agg, h):
     np.testing.assert_allclose(out.cpu().numpy(), want, atol=1e-5, rtol=1e-5)
 
 
+def _hub_graphs(seed):
+    """Graphs that exercise kernel A's hub-row path (gnf_layered.hip): hubs of 40 - 400 in-edges, a slice of 256 rows with
+    more long rows than a front workgroup takes (the rest stay with the regular waves), a complete graph (a DENSE slice: more
+    than 16 long rows, left alone), a long row in the batch's last, partial slice, duplicate edges."""
+    rng = np.random.default_rng(seed)
+    sizes, S, R = [], [], []
+    def graph(n, hubs):
+        s = list(range(n)) + [int(v) for v in rng.integers(0, n, 2 * n)]
+        r = list(range(n)) + [int(v) for v in rng.integers(0, n, 2 * n)]
+        for hub, deg in hubs:
+            src = rng.integers(0, n, deg)
+            s += [int(v) for v in src]
+            r += [hub] * deg
+        sizes.append(n), S.append(np.array(s, np.int32)), R.append(np.array(r, np.int32))
+    graph(300, [(0, 400), (7, 41)])                                   # one hub far beyond a chunk, one just over the line
+    graph(200, [(i, 33 + 5 * i) for i in range(9)])                   # 9 long rows in one slice: the front takes the first 4
+    n_c = 40                                                          # complete graph: every row has 40 > 32 edges
+    sizes.append(n_c), S.append(np.repeat(np.arange(n_c, dtype=np.int32), n_c)), R.append(np.tile(np.arange(n_c, dtype=np.int32), n_c))
+    graph(75, [(74, 120)])                                            # the batch's last row is a hub
+    nn = np.array(sizes, np.int32)
+    ne = np.array([len(v) for v in S], np.int32)
+    off = np.concatenate([[0], np.cumsum(nn)[:-1]]).astype(np.int32)
+    return nn, ne, np.concatenate([v + o for v, o in zip(S, off)]), np.concatenate([v + o for v, o in zip(R, off)])
+
+
+@pytest.mark.parametrize("agg", ["sum", "mean"])
+@pytest.mark.parametrize("h", [3, 8, 32, 128, 300])
+def test_aggregate_kernel_hub_rows(agg, h):
+    """Rows of more than 32 edges: front workgroups, edges split over the lane groups, partial sums in group order
+    (every lane width: scalar lanes for H = 3, 2 .. 64 lanes per row, several feature slices per lane for H = 300)."""
+    from gnf_amd import _abi
+    from gnf_amd.graphs import csr_of
+    nn, ne, s, r = _hub_graphs(h)
+    n = int(nn.sum())
+    x = np.random.default_rng(h).standard_normal((n, h)).astype(np.float32)
+    g = graph_from_arrays(nn, ne, s, r, x, DEV)
+    csr = csr_of(g)
+    out = torch.full((n, h), float("nan"), device=DEV)
+    _abi.check(_abi.lib().gnf_aggregate_f32(C.byref(csr.desc), _abi.ptr(g.nodes), h, h,
+                                            _abi.GNF_AGG_MEAN if agg == "mean" else _abi.GNF_AGG_SUM,
+                                            _abi.ptr(out), h, _abi.stream_ptr()), "gnf_aggregate_f32")
+    deg = np.bincount(r, minlength=n).astype(np.float64)
+    want = np.zeros((n, h))
+    np.add.at(want, r, x.astype(np.float64)[s])
+    if agg == "mean":
+        want = want / np.maximum(deg, 1.0)[:, None]
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any()                                     # every row written exactly by someone
+    np.testing.assert_allclose(got, want, atol=3e-5 * (1.0 if agg == "mean" else 20.0), rtol=1e-5)
+    out2 = torch.empty_like(out)                                       # deterministic: a second launch is bitwise the first
+    _abi.check(_abi.lib().gnf_aggregate_f32(C.byref(csr.desc), _abi.ptr(g.nodes), h, h,
+                                            _abi.GNF_AGG_MEAN if agg == "mean" else _abi.GNF_AGG_SUM,
+                                            _abi.ptr(out2), h, _abi.stream_ptr()), "gnf_aggregate_f32")
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("combine", ["agg", "concat"])
+def test_gnn_module_on_hub_graphs(combine):
+    """The eps * x + agg and [x || agg] forms of kernel A (what the large-batch kernel and the layered path read) on the
+    hub graphs, through a make_gnn_fn() product with layers too wide for the fused kernels (the layered path)."""
+    from gnf_amd import gnn
+    nn, ne, s, r = _hub_graphs(11)
+    n = int(nn.sum())
+    x = np.random.default_rng(5).standard_normal((n, 12)).astype(np.float32)
+    in0 = 24 if combine == "concat" else 12
+    layers = O.make_mlp_params(np.random.default_rng(6), in0, 1100, 12, 2)
+    mk = partial(gnn.make_mlp_model, 1100, 12, 2, gnn.leaky_relu)
+    mod = gnn.avg_concat_then_mlp_gnn(mk) if combine == "concat" else gnn.avg_then_mlp_gnn(mk, 0.5)
+    mod._node_block._mlp.set_params(layers)
+    out = mod(graph_from_arrays(nn, ne, s, r, x, DEV))
+    want = O.Fp64Dense(s, r, n, agg="mean", combine=combine, epsilon=0.5).gnn(x.astype(np.float64), layers)
+    np.testing.assert_allclose(out.nodes.cpu().numpy(), want, atol=2e-4, rtol=2e-4)
+
+
 def test_gnn_module_call_alone(grid_small):
     """A make_gnn_fn() product called like the reference calls it: module(GraphsTuple) -> GraphsTuple."""
     from gnf_amd import gnn
