@@ -527,7 +527,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
         rebuild = {"ms_per_step": round(1e3 * dt / nreb, 4), "value": round(n_global * HP["T"] * nreb / dt, 1),
-                   "note": "gnf_build_csr (5 small kernels) + torch allocations inside every step"}
+                   "note": "gnf_build_csr (one launch: a workgroup per graph) + torch allocations inside every step"}
 
     # ---- secondary figure: the PCIe-inclusive rate.  The C ABI takes device pointers, but the reference's drivers
     # hand every batch over as host arrays (feed_dict of a GraphsTuple, run_grevnet.py:440-447): here the batch's

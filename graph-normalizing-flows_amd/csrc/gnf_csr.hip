@@ -3,16 +3,18 @@
 // builds at train_grevnet_with_data.py:265-271 and graph_data.py:122).
 //
 // Batched graphs are block-diagonal: every edge of graph g lies in one contiguous slice of the edge
-// list and touches only g's nodes.  One workgroup per graph therefore sorts locally, in LDS:
-//   count : edge-parallel LDS-atomic histogram of the receivers            -> deg[node]
-//   scan  : one workgroup, chunked exclusive scan                          -> rowptr
-//   fill  : edge-parallel placement with an LDS-atomic cursor per receiver (order inside a row is
-//           arbitrary at this point), then one thread per node sorts its row by ORIGINAL EDGE INDEX
-//           (insertion sort; rows are short) and writes col[] = senders[edge].  Sorting by edge
-//           index makes the result identical to a stable sort by receiver, i.e. neighbours appear
-//           in original edge order, which fixes the fp32 summation order of the aggregation.
-// Graphs too large for the LDS budget (more than kCapE edges or kCapN nodes) take a slower
-// scan-based path (one thread per receiver walks the edge slice in order).
+// list and touches only g's nodes.  One workgroup per graph therefore does everything locally, in LDS, in ONE launch:
+//   offsets : sums of n_node / n_edge over the graphs in front of it        -> n0, e0
+//   count   : edge-parallel LDS-atomic histogram of the receivers
+//   scan    : exclusive scan of the counts                                  -> rowptr[n0 + i] = e0 + prefix
+//   place   : edge-parallel placement with an LDS-atomic cursor per receiver (order inside a row is
+//             arbitrary at this point)
+//   rank    : one wave per row counts, per entry, the row's smaller edge ids: its slot in EDGE ORDER.  Sorting by edge
+//             index makes the result identical to a stable sort by receiver, i.e. neighbours appear in original edge
+//             order, which fixes the fp32 summation order of the aggregation
+//   gather  : col[] = senders[edge], every entry of the graph in one sweep.
+// Graphs too large for the LDS budget (more than kCapE edges or kCapN nodes) take a slower path inside the same
+// workgroup (global counts, one thread per receiver walks the edge slice in order).
 #include "gnf_common.h"
 
 namespace gnf {
@@ -22,121 +24,97 @@ static constexpr int kEdgeTile = 2048;
 static constexpr int kCapE = 16384;  // edges per graph handled in LDS (64 KB of edge ids)
 static constexpr int kCapN = 2048;   // nodes per graph handled in LDS
 
-// out[0] = 0, out[i+1] = sum_{j<=i} in[j]; single workgroup, chunked.
-__device__ void block_exclusive_scan(const int32_t* __restrict__ in, int32_t* __restrict__ out,
-                                     int64_t n, int32_t* sh /*kCsrBlock+1*/) {
-    const int64_t chunk = (n + kCsrBlock - 1) / kCsrBlock;
-    const int64_t beg = (int64_t)threadIdx.x * chunk;
-    int64_t end = beg + chunk;
-    if (end > n) end = n;
-    int32_t local = 0;
-    for (int64_t i = beg; i < end; ++i) local += in[i];
-    sh[threadIdx.x + 1] = local;
-    if (threadIdx.x == 0) sh[0] = 0;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        for (int i = 1; i <= kCsrBlock; ++i) sh[i] += sh[i - 1];
-    __syncthreads();
-    int32_t run = sh[threadIdx.x];
-    if (threadIdx.x == 0) out[0] = 0;
-    for (int64_t i = beg; i < end; ++i) {
-        run += in[i];
-        out[i + 1] = run;
-    }
-}
-
-__global__ __launch_bounds__(kCsrBlock) void k_graph_offsets(const int32_t* __restrict__ n_node,
-                                                             const int32_t* __restrict__ n_edge,
-                                                             int64_t n_graphs,
-                                                             int32_t* __restrict__ node_off,
-                                                             int32_t* __restrict__ edge_off) {
-    __shared__ int32_t sh[kCsrBlock + 1];
-    block_exclusive_scan(n_node, node_off, n_graphs, sh);
-    __syncthreads();
-    block_exclusive_scan(n_edge, edge_off, n_graphs, sh);
-}
-
-// ---- count: deg[node] = number of incoming edges ------------------------------------------------
-__global__ __launch_bounds__(kCsrBlock) void k_csr_count(const int32_t* __restrict__ receivers,
-                                                         const int32_t* __restrict__ node_off,
-                                                         const int32_t* __restrict__ edge_off,
-                                                         int32_t* __restrict__ deg) {
-    __shared__ int32_t cnt[kCapN];
-    const int g = blockIdx.x;
-    const int n0 = node_off[g], n1 = node_off[g + 1];
-    const int e0 = edge_off[g], e1 = edge_off[g + 1];
-    const int ng = n1 - n0;
-    if (ng <= kCapN) {
-        for (int i = threadIdx.x; i < ng; i += kCsrBlock) cnt[i] = 0;
-        __syncthreads();
-        for (int e = e0 + threadIdx.x; e < e1; e += kCsrBlock) atomicAdd(&cnt[receivers[e] - n0], 1);
-        __syncthreads();
-        for (int i = threadIdx.x; i < ng; i += kCsrBlock) deg[n0 + i] = cnt[i];
-    } else {  // very large graph: global atomics (deg zeroed by the caller-side memset kernel below)
-        for (int e = e0 + threadIdx.x; e < e1; e += kCsrBlock) atomicAdd(&deg[receivers[e]], 1);
-    }
-}
-
-__global__ __launch_bounds__(kCsrBlock) void k_zero_i32(int32_t* __restrict__ p, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * kCsrBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kCsrBlock)
-        p[i] = 0;
-}
-
-__global__ __launch_bounds__(kCsrBlock) void k_rowptr_scan(const int32_t* __restrict__ deg,
-                                                           int32_t* __restrict__ rowptr, int64_t n) {
-    __shared__ int32_t sh[kCsrBlock + 1];
-    block_exclusive_scan(deg, rowptr, n, sh);
-}
-
-// ---- fill ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kCsrBlock) void k_csr_fill(const int32_t* __restrict__ senders,
-                                                        const int32_t* __restrict__ receivers,
-                                                        const int32_t* __restrict__ node_off,
-                                                        const int32_t* __restrict__ edge_off,
-                                                        const int32_t* __restrict__ rowptr,
-                                                        int32_t* __restrict__ col) {
+// ---- one workgroup per graph: offsets, count, scan, placement, rank, gather ---------------------------------------
+// Everything a graph's rows need is local to the graph: rowptr[n0 + i] = e0 + (edges of the graph with a receiver
+// below i), because the graphs before it own exactly the e0 edges in front of its slice - no scan over the batch's nodes.
+// (Round 4: this kernel replaces five launches - graph offsets, zero, count, a one-workgroup scan over all nodes, fill -
+// whose fill also paid a global round trip per ROW for the senders: 46 us of launches on the config-2 batch.)
+__global__ __launch_bounds__(kCsrBlock) void k_csr_graph(const int32_t* __restrict__ senders,
+                                                         const int32_t* __restrict__ receivers,
+                                                         const int32_t* __restrict__ n_node,
+                                                         const int32_t* __restrict__ n_edge, int64_t n_nodes,
+                                                         int32_t* __restrict__ deg_ws,
+                                                         int32_t* __restrict__ rowptr, int32_t* __restrict__ col) {
     extern __shared__ __attribute__((aligned(16))) int32_t sm[];
-    const int g = blockIdx.x;
-    const int n0 = node_off[g], n1 = node_off[g + 1];
-    const int e0 = edge_off[g], e1 = edge_off[g + 1];
-    const int ng = n1 - n0, eg = e1 - e0;
-    if (eg == 0) return;
+    __shared__ int32_t red[2][kCsrBlock / 64];
+    __shared__ int32_t scan_sh[kCsrBlock + 1];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    // this graph's first node / edge: sums over the graphs in front of it
+    int sn = 0, se = 0;
+    for (int j = tid; j < g; j += kCsrBlock) sn += n_node[j], se += n_edge[j];
+    for (int off = 32; off > 0; off >>= 1) sn += __shfl_down(sn, off, 64), se += __shfl_down(se, off, 64);
+    if (lane == 0) red[0][wave] = sn, red[1][wave] = se;
+    __syncthreads();
+    int n0 = 0, e0 = 0;
+    for (int w = 0; w < kCsrBlock / 64; ++w) n0 += red[0][w], e0 += red[1][w];
+    const int ng = n_node[g], eg = n_edge[g];
+    if (g == 0 && tid == 0) rowptr[0] = 0;
     if (ng <= kCapN && eg <= kCapE) {
-        int32_t* rp = sm;                  // [ng + 1] row starts relative to the graph's first row
-        int32_t* cur = sm + kCapN + 1;     // [ng] placement cursors
-        int32_t* eid = cur + kCapN;        // [eg] edge ids (relative to e0), grouped by receiver
-        const int base = rowptr[n0];
-        for (int i = threadIdx.x; i <= ng; i += kCsrBlock) rp[i] = rowptr[n0 + i] - base;
-        for (int i = threadIdx.x; i < ng; i += kCsrBlock) cur[i] = 0;
+        int32_t* rp = sm;                  // [ng + 1] row starts relative to the graph's first edge
+        int32_t* cur = sm + kCapN + 1;     // [ng] counts, then placement cursors
+        int32_t* eid = cur + kCapN;        // [eg] edge ids (relative to e0), grouped by receiver, any order inside a row
+        int32_t* srt = eid + kCapE;        // [eg] the same in edge order
+        for (int i = tid; i < ng; i += kCsrBlock) cur[i] = 0;
         __syncthreads();
         for (int eb = 0; eb < eg; eb += 8 * kCsrBlock) {  // eight receiver loads in flight per thread, then the atomics
             int rr[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int e = eb + u * kCsrBlock + threadIdx.x;
+                const int e = eb + u * kCsrBlock + tid;
+                rr[u] = e < eg ? receivers[e0 + e] - n0 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (rr[u] >= 0) atomicAdd(&cur[rr[u]], 1);
+        }
+        __syncthreads();
+        {   // exclusive scan of the counts (each thread a contiguous run of rows), rowptr, cursors back to zero
+            const int chunk = (ng + kCsrBlock - 1) / kCsrBlock;
+            const int beg = tid * chunk, end = beg + chunk < ng ? beg + chunk : ng;
+            int local = 0;
+            for (int i = beg; i < end; ++i) local += cur[i];
+            scan_sh[tid + 1] = local;
+            if (tid == 0) scan_sh[0] = 0;
+            __syncthreads();
+            if (tid == 0)
+                for (int i = 1; i <= kCsrBlock; ++i) scan_sh[i] += scan_sh[i - 1];
+            __syncthreads();
+            int run = scan_sh[tid];
+            for (int i = beg; i < end; ++i) {
+                rp[i] = run;
+                rowptr[n0 + i] = e0 + run;
+                run += cur[i];
+                cur[i] = 0;
+            }
+            if (tid == 0) rp[ng] = eg, rowptr[n0 + ng] = e0 + eg;  // (= the next graph's first entry: the same value)
+        }
+        __syncthreads();
+        for (int eb = 0; eb < eg; eb += 8 * kCsrBlock) {
+            int rr[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = eb + u * kCsrBlock + tid;
                 rr[u] = e < eg ? receivers[e0 + e] - n0 : -1;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (rr[u] >= 0) {
                     const int pos = atomicAdd(&cur[rr[u]], 1);
-                    eid[rp[rr[u]] + pos] = eb + u * kCsrBlock + threadIdx.x;
+                    eid[rp[rr[u]] + pos] = eb + u * kCsrBlock + tid;
                 }
         }
         __syncthreads();
         // the atomics above put a row's edges in any order: restore edge order by RANK - one wave per row, a lane per
-        // entry counts the row's smaller edge ids (every lane reads the same LDS word: a broadcast) and writes its sender
-        // straight to its final slot.  (One thread insertion-sorting a whole row took 231 us on the complete 100-node
-        // graphs of the drivers' default dataset: 100 rows of 100 entries per workgroup.)
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        // entry counts the row's smaller edge ids (every lane reads the same LDS word: a broadcast); sorting by edge index
+        // makes the result identical to a stable sort by receiver
         for (int i = wave; i < ng; i += kCsrBlock / 64) {
             const int beg = rp[i], d = rp[i + 1] - beg;
             for (int a = lane; a < d; a += 64) {
                 const int key = eid[beg + a];
-                const int snd = senders[e0 + key];  // in flight while the rank is counted
                 int rank = 0;
                 int b = 0;
-                for (; b + 16 <= d; b += 16) {  // sixteen LDS reads in flight (one at a time: ~100 cycles each, 133 us)
+                for (; b + 16 <= d; b += 16) {  // sixteen LDS reads in flight
                     int v[16];
 #pragma unroll
                     for (int u = 0; u < 16; ++u) v[u] = eid[beg + b + u];
@@ -144,24 +122,54 @@ __global__ __launch_bounds__(kCsrBlock) void k_csr_fill(const int32_t* __restric
                     for (int u = 0; u < 16; ++u) rank += v[u] < key ? 1 : 0;
                 }
                 for (; b < d; ++b) rank += eid[beg + b] < key ? 1 : 0;
-                col[base + beg + rank] = snd;
+                srt[beg + rank] = key;
             }
         }
+        __syncthreads();
+        for (int j = tid; j < eg; j += kCsrBlock) col[e0 + j] = senders[e0 + srt[j]];  // every sender in one sweep
     } else {
-        // slow path: one thread per receiver walks the graph's edge slice in order (tiles staged in LDS)
+        // a graph too large for LDS (rare): counts through global atomics into the workspace, a scan over its rows, then
+        // one thread per receiver walks the graph's edge slice in order (tiles staged in LDS) - all by this workgroup
+        int32_t* deg = deg_ws + n0;
+        for (int i = tid; i < ng; i += kCsrBlock) deg[i] = 0;
+        __threadfence_block();
+        __syncthreads();
+        for (int e = tid; e < eg; e += kCsrBlock) atomicAdd(&deg[receivers[e0 + e] - n0], 1);
+        __threadfence_block();
+        __syncthreads();
+        {
+            const int chunk = (ng + kCsrBlock - 1) / kCsrBlock;
+            const int beg = tid * chunk, end = beg + chunk < ng ? beg + chunk : ng;
+            int local = 0;
+            for (int i = beg; i < end; ++i) local += __hip_atomic_load(&deg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            scan_sh[tid + 1] = local;
+            if (tid == 0) scan_sh[0] = 0;
+            __syncthreads();
+            if (tid == 0)
+                for (int i = 1; i <= kCsrBlock; ++i) scan_sh[i] += scan_sh[i - 1];
+            __syncthreads();
+            int run = scan_sh[tid];
+            for (int i = beg; i < end; ++i) {
+                rowptr[n0 + i] = e0 + run;
+                run += __hip_atomic_load(&deg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid == 0) rowptr[n0 + ng] = e0 + eg;
+        }
+        __threadfence_block();
+        __syncthreads();
         int32_t* s_recv = sm;
         int32_t* s_send = sm + kEdgeTile;
-        for (int nb = n0; nb < n1; nb += kCsrBlock) {
-            const int node = nb + threadIdx.x;
-            const bool live = node < n1;
-            const int cursor = live ? rowptr[node] : 0;
+        for (int nb = 0; nb < ng; nb += kCsrBlock) {
+            const int node = nb + tid;
+            const bool live = node < ng;
+            const int cursor = live ? rowptr[n0 + node] : 0;
             int count = 0;
-            for (int eb = e0; eb < e1; eb += kEdgeTile) {
-                const int m = (e1 - eb) < kEdgeTile ? (e1 - eb) : kEdgeTile;
+            for (int eb = 0; eb < eg; eb += kEdgeTile) {
+                const int m = (eg - eb) < kEdgeTile ? (eg - eb) : kEdgeTile;
                 __syncthreads();
-                for (int i = threadIdx.x; i < m; i += kCsrBlock) {
-                    s_recv[i] = receivers[eb + i];
-                    s_send[i] = senders[eb + i];
+                for (int i = tid; i < m; i += kCsrBlock) {
+                    s_recv[i] = receivers[e0 + eb + i] - n0;
+                    s_send[i] = senders[e0 + eb + i];
                 }
                 __syncthreads();
                 if (live)
@@ -170,9 +178,10 @@ __global__ __launch_bounds__(kCsrBlock) void k_csr_fill(const int32_t* __restric
             }
         }
     }
+    (void)n_nodes;
 }
 
-static constexpr size_t kFillLds = (size_t)(2 * kCapN + 1 + kCapE) * sizeof(int32_t);
+static constexpr size_t kFillLds = (size_t)(2 * kCapN + 1 + 2 * kCapE) * sizeof(int32_t);  // 147.5 KB: one workgroup per CU
 
 }  // namespace gnf
 
@@ -204,32 +213,16 @@ int gnf_build_csr(const int32_t* senders, const int32_t* receivers, const int32_
         return GNF_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    int32_t* node_off = (int32_t*)ws;
-    int32_t* edge_off = node_off + (n_graphs + 1);
-    int32_t* deg = edge_off + (n_graphs + 1);
-    hipLaunchKernelGGL(k_graph_offsets, dim3(1), dim3(kCsrBlock), 0, st, n_node, n_edge, n_graphs,
-                       node_off, edge_off);
-    GNF_LAUNCH_CHECK("k_graph_offsets");
-    if (n_nodes > 0) {
-        int64_t zb = (n_nodes + kCsrBlock - 1) / kCsrBlock;
-        if (zb > 1024) zb = 1024;
-        hipLaunchKernelGGL(k_zero_i32, dim3((unsigned)zb), dim3(kCsrBlock), 0, st, deg, n_nodes);
-        GNF_LAUNCH_CHECK("k_zero_i32");
+    int32_t* deg = (int32_t*)ws + 2 * (n_graphs + 1);  // (only graphs too large for LDS count through it)
+    if (n_graphs == 0 || n_nodes == 0) {  // no rows: rowptr = [0 .. 0]
+        GNF_HIP_TRY(hipMemsetAsync(rowptr, 0, (size_t)(n_nodes + 1) * sizeof(int32_t), st));
+        return GNF_OK;
     }
-    if (n_graphs > 0) {
-        hipLaunchKernelGGL(k_csr_count, dim3((unsigned)n_graphs), dim3(kCsrBlock), 0, st, receivers,
-                           node_off, edge_off, deg);
-        GNF_LAUNCH_CHECK("k_csr_count");
-    }
-    hipLaunchKernelGGL(k_rowptr_scan, dim3(1), dim3(kCsrBlock), 0, st, deg, rowptr, n_nodes);
-    GNF_LAUNCH_CHECK("k_rowptr_scan");
-    if (n_graphs > 0 && n_edges > 0) {
-        GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_csr_fill),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFillLds)));
-        hipLaunchKernelGGL(k_csr_fill, dim3((unsigned)n_graphs), dim3(kCsrBlock), kFillLds, st, senders,
-                           receivers, node_off, edge_off, rowptr, col);
-        GNF_LAUNCH_CHECK("k_csr_fill");
-    }
+    GNF_ONCE_PER_DEVICE(GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_csr_graph),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFillLds)));
+    hipLaunchKernelGGL(k_csr_graph, dim3((unsigned)n_graphs), dim3(kCsrBlock), kFillLds, st, senders, receivers, n_node, n_edge,
+                       n_nodes, deg, rowptr, col);
+    GNF_LAUNCH_CHECK("k_csr_graph");
     return GNF_OK;
 }
 
