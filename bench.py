@@ -751,7 +751,7 @@ def main():
 
     flops, abytes = algorithmic_half_step(n_local, e_local, HP)
     # HBM-side bytes per launch come from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
-    # correction + WRITE_SIZE; tools/profile.sh + tools/summarize_profile.py): PMC counters cannot be
+    # correction + WRITE_SIZE; tools/pmc_shape.sh + tools/summarize_profile.py): PMC counters cannot be
     # collected from inside this process.  Only quoted for the workload they were measured on.
     traffic, traffic_note = None, "no PMC pass recorded for this workload"
     try:
@@ -765,7 +765,7 @@ def main():
                                 f"kernel sources {pm.get('source_stamp')} = this build)")
             else:
                 traffic_note = (f"profiles/pmc_traffic.json was taken on kernel sources {pm.get('source_stamp')}, this build is "
-                                f"{kernel_source_stamp()}: not quoted (re-run tools/profile.sh / tools/pmc_shape.sh)")
+                                f"{kernel_source_stamp()}: not quoted (re-run tools/final_profile.sh pmc)")
     except (OSError, ValueError, KeyError):
         pass
     achieved_tflops = flops / (kernel_us * 1e-6) / 1e12

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Turn a tools/profile.sh output directory (gpurun_out/prof_<tag>) into the small text files that
-are committed under profiles/: per-kernel stats of the --kernel-trace --stats run, mean PMC counters of
-the dominant kernel per pass, and the HBM traffic per launch with the gfx950 FETCH_SIZE correction
-(MI355X_MICROARCH.md section HBM: FETCH_SIZE under-reports a wide coalesced read stream by exactly 2x;
-WRITE_SIZE uncalibrated, taken as is; both are in KiB)."""
+"""Turn a tools/pmc_shape.sh output directory (gpurun_out/pmc_<tag>) into the small text file that is committed
+under profiles/ (<tag>_rocprof_summary.txt: per-kernel stats of the --kernel-trace --stats run, mean PMC counters per
+dispatch of the dominant kernel and of every other kernel the run reported) and into the workload's entry of
+profiles/pmc_traffic.json: HBM traffic per launch with the gfx950 FETCH_SIZE correction (MI355X_MICROARCH.md section
+HBM: FETCH_SIZE under-reports a wide coalesced read stream by exactly 2x; WRITE_SIZE uncalibrated, taken as is; both
+are in KiB).
+    python tools/summarize_profile.py --pmc-shape gpurun_out/pmc_<tag> <workload> [profiles]"""
 import collections
 import csv
 import glob
@@ -13,7 +15,7 @@ import sys
 
 
 TRAFFIC_NOTE = ("HBM-side bytes per launch of each workload's dominant kernel: rocprofv3 --pmc FETCH_SIZE x 1024 x 2 (gfx950 "
-                "correction, MI355X_MICROARCH.md) + WRITE_SIZE x 1024, separate passes (tools/profile.sh, tools/pmc_shape.sh); "
+                "correction, MI355X_MICROARCH.md) + WRITE_SIZE x 1024, separate passes (tools/pmc_shape.sh); "
                 "bench.py quotes an entry only when source_stamp is the build's")
 
 
@@ -74,61 +76,8 @@ def merge_pmc_shape(src, workload, dst):
     open(os.path.join(dst, f"{tag}_rocprof_summary.txt"), "w").write("\n".join(lines) + "\n")
 
 
-def main(src, tag, dst):
-    os.makedirs(dst, exist_ok=True)
-    lines = []
-    ks = os.path.join(src, "trace", "kt_kernel_stats.csv")
-    rows = list(csv.DictReader(open(ks)))
-    lines.append(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-secondary --latency-steps 0   ({tag})")
-    lines.append(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'min_us':>9} {'max_us':>9} {'pct':>6}  kernel")
-    for r in rows:
-        lines.append(f"{int(r['Calls']):7d} {float(r['TotalDurationNs'])/1e3:12.1f} {float(r['AverageNs'])/1e3:10.3f} "
-                     f"{float(r['MinNs'])/1e3:9.3f} {float(r['MaxNs'])/1e3:9.3f} {float(r['Percentage']):6.2f}  {r['Name'][:110]}")
-    dom = max(rows, key=lambda r: float(r["TotalDurationNs"]))["Name"]
-    lines.append("")
-    lines.append(f"# PMC passes (separate runs, --pmc only with --kernel-trace): mean per dispatch of the dominant kernel")
-    lines.append(f"# dominant kernel: {dom}")
-    pmc = {}
-    for f in sorted(glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv"))):
-        agg = collections.defaultdict(list)
-        for r in csv.DictReader(open(f)):
-            if r["Kernel_Name"] == dom:
-                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        for k, v in agg.items():
-            pmc[k] = sum(v) / len(v)
-            lines.append(f"{pmc[k]:18.1f}  n={len(v):4d}  {k}")
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-    import bench
-    stamp_file = os.path.join(src, "source_stamp.txt")   # written on the GPU box by tools/profile.sh
-    stamp = open(stamp_file).read().strip() if os.path.exists(stamp_file) else bench.kernel_source_stamp()
-    out = {"tag": tag, "kernel": dom, "source_stamp": stamp}
-    lines.append(f"# kernel sources stamp (bench.kernel_source_stamp): {out['source_stamp']}")
-    if "FETCH_SIZE" in pmc:
-        out["fetch_bytes_per_launch"] = pmc["FETCH_SIZE"] * 1024 * 2      # gfx950 correction x2
-        out["write_bytes_per_launch"] = pmc.get("WRITE_SIZE", 0.0) * 1024
-        out["traffic_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
-        lines.append("")
-        lines.append(f"# HBM-side traffic per launch = FETCH_SIZE*1024*2 (gfx950 correction) + WRITE_SIZE*1024 = "
-                     f"{out['traffic_bytes_per_launch']/1e6:.2f} MB")
-    if "TCC_HIT_sum" in pmc:
-        out["l2_hit_rate"] = pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])
-        lines.append(f"# L2 hit rate = {out['l2_hit_rate']:.4f}")
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in pmc and "SQ_WAVE_CYCLES" in pmc:
-        lines.append(f"# SQ_WAIT_ANY/SQ_WAVE_CYCLES = {pmc['SQ_WAIT_ANY']/pmc['SQ_WAVE_CYCLES']:.3f}, "
-                     f"SQ_WAIT_INST_ANY/SQ_WAVE_CYCLES = {pmc['SQ_WAIT_INST_ANY']/pmc['SQ_WAVE_CYCLES']:.3f}, "
-                     f"SQ_ACTIVE_INST_ANY/SQ_WAVE_CYCLES = {pmc['SQ_ACTIVE_INST_ANY']/pmc['SQ_WAVE_CYCLES']:.3f}")
-    open(os.path.join(dst, f"{tag}_rocprof_summary.txt"), "w").write("\n".join(lines) + "\n")
-    merge_traffic(os.path.join(dst, "pmc_traffic.json"), out.pop("source_stamp"), "config2", out)
-    bj = os.path.join(src, "bench.json")
-    if os.path.exists(bj):
-        txt = [l for l in open(bj) if l.startswith("{")]
-        if txt:
-            open(os.path.join(dst, f"{tag}_bench.json"), "w").write(txt[-1])
-    print("\n".join(lines))
-
-
-if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--pmc-shape":
+if __name__ == "__main__":
     # summarize_profile.py --pmc-shape gpurun_out/pmc_<tag> <workload> [profiles]
+    if len(sys.argv) < 4 or sys.argv[1] != "--pmc-shape":
+        raise SystemExit(__doc__)
     merge_pmc_shape(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "profiles")
-elif __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "profiles")
