@@ -672,54 +672,55 @@ int big_plan(int64_t n_nodes, int cus, int cap, int32_t* seg_n, int32_t* seg_sz,
         for (int k = 0; k < 6; ++k) seg_kind[k] = 0;
     if (xg0) *xg0 = 0;
     const int64_t g = (n_nodes + 15) / 16;
-    if (g <= (int64_t)cap * 2 * cus) {
-        const int64_t w = g < 2 * (int64_t)cus ? g : 2 * (int64_t)cus;
-        const int base = (int)(g / w);
-        const int64_t rem = g % w;
-        // Split row tiles (seg_kind != NULL: the caller has scratch and flags for them).  With every slot of the chip
-        // taken, the deal leaves a top layer of e row tiles - one more for e of the CUs, and the launch ends when those
-        // CUs do: 8 row tiles against the 7.2 a CU gets on average on the config-5 batch (1 842 row tiles on 256 CUs).
-        // When that layer covers at most half of the CUs, each of its tiles goes to TWO workgroups on different CUs -
-        // one runs its s-net, the other its t-net and the coupling - and the longest CU carries half a row tile more
-        // than the shortest instead of a whole one.  The split tiles are the batch's LAST e row tiles; a workgroup
-        // holds its own row tiles plus the split one (base + 1 <= cap LDS slots).
-        const int64_t e = rem <= cus ? rem : rem - cus;
-        if (seg_kind && xg0 && w == 2 * (int64_t)cus && e > 0 && 2 * e <= cus && base + 1 <= cap && base >= 1) {
-            int k = 0;
-            if (rem > cus) seg_n[k] = cus, seg_sz[k] = base + 1, ++k;   // every CU's first workgroup
-            seg_n[k] = (int32_t)e, seg_sz[k] = base, seg_kind[k] = 1, ++k;  // + the s-net of split tile xg0 + w
-            seg_n[k] = (int32_t)e, seg_sz[k] = base, seg_kind[k] = 2, ++k;  // + its t-net (dispatched after its partner)
-            seg_n[k] = (int32_t)((rem > cus ? cus : w) - 2 * e), seg_sz[k] = base;
+    // The batch's LAST `tiles` row tiles, dealt evenly over w workgroups (sizes differing by one row tile, the larger ones
+    // first in dispatch order), as runs k, k + 1, ...  w = 2 cus: a pair per CU (the first cus workgroups are the CUs' first
+    // slots); w = cus: one workgroup per CU.
+    // Split row tiles (seg_kind != NULL: the caller has scratch and flags for them).  The deal leaves a top layer of e row
+    // tiles - one more for e of the CUs, and the launch ends when those CUs do: 8 row tiles against the 7.2 a CU gets on
+    // average on the config-5 batch (1 842 row tiles on 256 CUs).  When that layer covers at most half of the CUs, each of
+    // its tiles goes to TWO workgroups on different CUs - one runs its s-net, the other its t-net and the coupling - and
+    // the longest CU carries half a row tile more than the shortest instead of a whole one.  The split tiles are the
+    // batch's LAST e row tiles; a workgroup holds its own row tiles plus the split one (base + 1 <= cap LDS slots).
+    auto deal = [&](int k, int64_t tiles, int64_t w) {
+        const int base = (int)(tiles / w);
+        const int64_t rem = tiles % w;
+        const int64_t layer = w > cus ? cus : w;                  // workgroups per layer of the deal
+        const int64_t e = rem <= layer ? rem : rem - layer;       // the partially filled top layer
+        if (seg_kind && xg0 && w >= cus && e > 0 && 2 * e <= cus && base + 1 <= cap && base >= 1) {
+            if (rem > layer) seg_n[k] = (int32_t)layer, seg_sz[k] = base + 1, ++k;   // every CU's first workgroup
+            seg_n[k] = (int32_t)e, seg_sz[k] = base, seg_kind[k] = 1, ++k;          // + the s-net of split tile xg0 + w
+            seg_n[k] = (int32_t)e, seg_sz[k] = base, seg_kind[k] = 2, ++k;          // + its t-net (dispatched after its partner)
+            seg_n[k] = (int32_t)((rem > layer ? w - layer : w) - 2 * e), seg_sz[k] = base;
             *xg0 = (int32_t)(g - e);
-            return (int)w;
+            return;
         }
-        int k = 0;
         if (rem) seg_n[k] = (int32_t)rem, seg_sz[k] = base + 1, ++k;
         seg_n[k] = (int32_t)(w - rem), seg_sz[k] = base;
+    };
+    if (g <= (int64_t)cap * 2 * cus) {  // up to one pass of the chip: every slot gets one workgroup
+        const int64_t w = g < 2 * (int64_t)cus ? g : 2 * (int64_t)cus;
+        deal(0, g, w);
         return (int)w;
     }
     // Larger batches: whole double rounds of cap-tile workgroups (a pair per CU each), then ONE closing round laid out by
-    // what is left per CU (t = left / cus row tiles; the larger workgroups first in dispatch order - a CU's two slots
-    // free half a period apart, so every CU gets one of each size):
-    //     t <= 3        : an even deal over 2 cus workgroups (1-tile workgroups only when t <= 2, else 2 and 1 row tiles)
-    //     t <= 4        : cap-tile workgroups, one per CU          (pairs of 2-tile ones measured 3 % slower)
+    // what is left per CU (t = left / cus row tiles):
+    //     t <= 1        : 1-tile workgroups
+    //     t <= 4        : ONE workgroup of 1 - 4 row tiles per CU (round 4: a lone 3-tile workgroup ends sooner than a pair
+    //                     of a 2-tile and a 1-tile one, which stream the weights twice - config 4: 523.9 -> 514.0 us)
     //     else          : an even deal over 2 cus workgroups: 3 + 2, 3 + 3, 4 + 3 row tiles per CU
+    // - each with its top layer split when it covers at most half of the CUs.
     // A closing round of whole cap-tile workgroups handed out one by one would run on a part of the CUs only - for
     // as long as a full pair where two of them share a CU (config 4, 19 row tiles per CU: 23 % of the CUs idle for the
-    // last quarter of the launch; 520 us with the closing round of 2 + 1 row tiles against 531; 34 k nodes 259 us
-    // against 326).  The small workgroups are not efficient themselves (a 1-tile workgroup streams the same 1.7 MB of
-    // weights as a 4-tile one, and a CU takes them at 15 - 20 bytes per clock whatever the depth of the register ring:
-    // 115 k cycles alone, 180 k beside another, against 315 k / 475 k for 4-tile ones) - they keep every CU busy to the end.
+    // last quarter of the launch).  Small workgroups are not efficient themselves (a 1-tile workgroup streams the same
+    // 1.7 MB of weights as a 4-tile one, and a CU takes them at 15 - 20 bytes per clock whatever the depth of the register
+    // ring: 115 k cycles alone, 180 k beside another, against 315 k / 475 k for 4-tile ones) - they keep every CU busy to
+    // the end.
     const int64_t per_round = (int64_t)cap * 2 * cus;
     const int64_t full = cap == kBigMT ? g / per_round : 0, left = g - full * per_round;
-    if (full > 0 && left > 0 && (left <= 3 * (int64_t)cus || left > 4 * (int64_t)cus)) {
-        int k = 0;
-        seg_n[k] = (int32_t)(full * 2 * cus), seg_sz[k] = cap, ++k;
-        const int64_t w = left < 2 * (int64_t)cus ? left : 2 * (int64_t)cus;
-        const int base = (int)(left / w);
-        const int64_t rem = left % w;
-        if (rem) seg_n[k] = (int32_t)rem, seg_sz[k] = base + 1, ++k;
-        seg_n[k] = (int32_t)(w - rem), seg_sz[k] = base;
+    if (full > 0 && left > 0) {
+        seg_n[0] = (int32_t)(full * 2 * cus), seg_sz[0] = cap;
+        const int64_t w = left <= cus ? left : (left <= (int64_t)cap * cus ? (int64_t)cus : 2 * (int64_t)cus);
+        deal(1, left, w);
         return (int)(full * 2 * cus + w);
     }
     seg_n[0] = (int32_t)((g + cap - 1) / cap);

@@ -440,7 +440,9 @@ def test_config4_256_graphs_inverse_worst_graphs_vs_oracle():
 
 
 @pytest.mark.parametrize("graphs,closing", [(112, "1-tile workgroups"), (144, "2 + 1 row tiles"), (160, "one 4-tile workgroup per CU"),
-                                            (176, "3 + 3 / 3 + 2 row tiles"), (192, "4 + 3 / 3 + 3 row tiles"), (224, "two double rounds + 1-tile workgroups")])
+                                            (176, "3 + 3 / 3 + 2 row tiles"), (192, "4 + 3 / 3 + 3 row tiles"), (224, "two double rounds + 1-tile workgroups"),
+                                            (236, "one 2- / 1-tile workgroup per CU"), (244, "one 2-tile workgroup per CU, top layer split"),
+                                            (256, "one 3- / 2-tile workgroup per CU")])
 def test_config4_closing_rounds_of_the_large_batch_kernel_bitwise_vs_32_row_shape(graphs, closing):
     """The large-batch kernel's launch plan (gnf_fused_big.hip, big_plan): whole double rounds of 4-tile workgroups, then a
     closing round whose layout depends on the row tiles left per CU.  Config-4 batches that land in each layout: the
