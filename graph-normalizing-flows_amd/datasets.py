@@ -281,6 +281,7 @@ class _ChunkBatches:
     def _cut(self, path):
         emb, n_node = _read_embedding_chunk(path)
         row_end = np.concatenate([[0], np.cumsum(n_node)])
+        self.n_node = n_node      # the chunk just opened, like the reference readers' self.n_node = d[1] (:157, 172)
         return emb, n_node, row_end, self._plan(n_node)
 
     def _generate(self):

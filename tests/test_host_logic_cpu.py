@@ -302,4 +302,6 @@ def test_chunk_readers_open_their_first_file_in_the_constructor(tmp_path):
     with pytest.raises(ValueError):                                          # found when that chunk is opened
         late.train_batch()
     fx = D.GrevnetDatasetFixed(str(tmp_path), 2, sort_files=True)
-    assert fx.file_ind == 0 and fx.train_batch()[1].tolist() == [10, 20] and fx.train_batch()[1].tolist() == [30, 4]
+    assert fx.file_ind == 0 and fx.n_node.tolist() == [10, 20, 5]             # the open chunk's sizes (reference: self.n_node = d[1])
+    assert fx.train_batch()[1].tolist() == [10, 20] and fx.train_batch()[1].tolist() == [30, 4]
+    assert fx.n_node.tolist() == [30, 4]
