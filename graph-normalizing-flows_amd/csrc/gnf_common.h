@@ -214,6 +214,10 @@ int launch_linear_splitk(const float* const* x, int64_t ldx, const float* const*
                          int64_t ldy, int nj, int64_t n, int32_t I, int32_t O, int act, float alpha, int apply_act,
                          float* const* sk, size_t sk_floats, hipStream_t st);
 
+// wide y = act(x W_j + b_j) of a pair of nets from their packed weights (gnf_linear_big.hip); 1 = not its case
+int launch_linear_big(const GnfMlp* const* nets, int nj, int j, const float* const* x, int64_t ldx, float* const* y, int64_t ldy,
+                      int64_t n, int act, float alpha, int apply_act, hipStream_t st);
+
 // batch-norm bijector (gnf_bn.hip)
 int validate_bn(const GnfBatchNorm* bn, int direction, const char* what, int q);
 // cross-rank moments (GnfFlow.bn_allreduce): fold the per-workgroup partials into flow->bn_sync_buf (and, when

@@ -430,8 +430,11 @@ static int run_mlps(const GnfMlp* const* nets, int nj, const float* const* h0, i
                 xin[q] = in[q], wq[q] = nets[q]->W[j], bq[q] = nets[q]->b[j], yq[q] = dst[q];
                 if (last && j >= 1) sk[q] = (j & 1) ? bufB[q] : bufA[q];
             }
-            const int rc = launch_linear_splitk(xin, ldin, wq, bq, yq, lddst, nj, n, I, O, g.activation, g.alpha,
-                                                last ? 0 : 1, sk, (size_t)n * (size_t)ldbuf, st);
+            // wide layers of a pair of nets with packed weights: the large-batch kernel's inner loop (gnf_linear_big.hip)
+            int rc = launch_linear_big(nets, nj, j, xin, ldin, yq, lddst, n, g.activation, g.alpha, last ? 0 : 1, st);
+            if (rc == 1)
+                rc = launch_linear_splitk(xin, ldin, wq, bq, yq, lddst, nj, n, I, O, g.activation, g.alpha, last ? 0 : 1, sk,
+                                          (size_t)n * (size_t)ldbuf, st);
             if (rc) return rc;
             in[0] = dst[0];
             in[1] = dst[1];

@@ -1,0 +1,256 @@
+// Wide linear layers of the layered path (gfx950 / MI355X): y = act(x W + b) for layers the LDS-resident fused kernels
+// cannot hold (the data driver's default MLP, train_grevnet_with_data.py:104-117: 2048 x 3), with the large-batch fused
+// kernel's inner loop (gnf_fused_big.hip) instead of the generic GEMM tile:
+//
+//   * the WEIGHTS come straight from L2 into registers in MFMA fragment order (the packed copy every MLP has for the fused
+//     kernels, gnf_fused.hip: Wp[kg][nt][lane][q]) - one coalesced 1 KiB load per wave and column tile, no trip through
+//     LDS, no barrier on the weight stream.  The generic tile fetched raw W[k][n] rows into LDS and read its B fragments
+//     back with four 4-byte LDS reads per column tile and k-group, behind a barrier per 32-wide k-step;
+//   * a workgroup is 4 waves (one per SIMD) and owns 64 rows x 256 columns: wave w holds column tiles {w, w + 4, w + 8, w + 12}
+//     x the four row tiles = 16 accumulators, 4 weight loads + 4 LDS reads per 64 MFMAs, accumulators transposed (a lane
+//     holds four consecutive columns of a row: 16-byte stores);
+//   * the ACTIVATION rows pass through one [64][260] LDS buffer in chunks of 256 columns (16 k-groups), the next chunk in
+//     registers while the current one is multiplied; 66.7 KB of LDS = two workgroups per CU, each filling the other's
+//     chunk boundaries and epilogue;
+//   * every accumulator sees bias, then its k-groups and the four MFMAs inside a k-group in the generic tile's order:
+//     bitwise the same sums.
+// gnn.py:159-180 (snt.nets.MLP: MatMul + Add, activation between layers).
+#include "gnf_common.h"
+#include "gnf_fused_dev.h"
+
+namespace gnf {
+
+static constexpr int kLbThreads = 256;
+static constexpr int kLbRows = 64;
+static constexpr int kLbLS = 276;      // LDS row stride (floats): 256 + one k-group a wave may read past a chunk's end + 4
+static constexpr int kLbChunk = 256;   // activation columns per LDS chunk
+static constexpr int kLbCols = 256;    // output columns per workgroup
+
+struct LinBigArgs {
+    const float* x[2];
+    float* y[2];
+    const float* wp[2];    // packed weights of the layer
+    const float* bias[2];  // its padded bias row
+    int64_t ldx, ldy;
+    int32_t n, I, O;
+    int32_t ipg, ont;      // padded input width / 16, padded output width / 16
+    int32_t col_blocks;    // 256-column blocks
+    int32_t act, apply_act;
+    float alpha;
+    // the row tiles (16 rows) of a panel are dealt out over wg_per_panel workgroups: the first wg_rem of them own wg_base + 1
+    int32_t wg_per_panel, wg_base, wg_rem;
+};
+
+#define GNF_LB_LOAD_B(RSRC, VOFF, SOFF) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RSRC, VOFF, SOFF, 0))
+
+// MW: row tiles of the workgroup (2 .. 4; the instance has accumulators and stage registers for exactly those)
+template <int MW>
+__device__ __forceinline__ void lin_big_body(const LinBigArgs& a, float* __restrict__ act, const int cb, const int net, const int row0) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    const int ct0 = 16 * cb + wave;  // this wave's first column tile; the others + 4, + 8, + 12
+    int nv = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) nv += (ct0 + 4 * b < a.ont && 4 * b + wave < 16) ? 1 : 0;
+    const float* __restrict__ x = a.x[net];
+    const float* __restrict__ bias = a.bias[net];
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp[net]), 0, (int)((unsigned)a.ipg * (unsigned)a.ont * 1024u), 0x00020000);
+    const int voff = lane * 16;
+    const int kstride = a.ont * 1024;
+    int wtile[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) wtile[b] = (ct0 + (b < nv ? 4 * b : 0)) * 1024;
+
+    f32x4 acc[MW][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 16 * (ct0 + (b < nv ? 4 * b : 0)) + 4 * lgrp);
+#pragma unroll
+        for (int m = 0; m < MW; ++m) acc[m][b] = bv;
+    }
+
+    // activation chunk: 16 MW rows x 256 columns = 4 MW float4 per thread (thread t: column 4 (t & 63), rows (t >> 6) + 4 q)
+    const bool vec = (a.ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    f32x4 stage[4 * MW];
+    auto fetch = [&](int c0) {
+        const int c = c0 + 4 * (tid & 63);
+#pragma unroll
+        for (int q = 0; q < 4 * MW; ++q) {
+            const int r = row0 + (tid >> 6) + 4 * q;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < a.n && c < a.I) {
+                const float* p = x + (int64_t)r * a.ldx + c;
+                if (vec && c + 3 < a.I) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+                    v[0] = p[0];
+                    if (c + 1 < a.I) v[1] = p[1];
+                    if (c + 2 < a.I) v[2] = p[2];
+                    if (c + 3 < a.I) v[3] = p[3];
+                }
+            }
+            stage[q] = v;
+        }
+    };
+    auto put = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4 * MW; ++q)
+            *reinterpret_cast<f32x4*>(act + ((tid >> 6) + 4 * q) * kLbLS + 4 * (tid & 63)) = stage[q];
+    };
+
+    // weight ring: two named slots (indexed dynamically the compiler keeps both in one array, cannot tell which loads a
+    // k-group waits for and drains the queue - the prefetch included - in front of every k-group)
+    f32x4 b0[4], b1[4];
+    if (nv > 0) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) b0[b] = GNF_LB_LOAD_B(rsrc, voff, wtile[b]);
+    }
+    fetch(0);
+    const int n_chunks = (a.ipg * 16 + kLbChunk - 1) / kLbChunk;
+    const float* arow = act + lrow * kLbLS + 4 * lgrp;
+    // one k-group: request the NEXT one's weights into NXT, multiply with CUR row tile by row tile, each row tile's A
+    // fragment refilled for the next k-group right behind the last MFMA that reads it (past a chunk's end that read takes
+    // the row's padding: the next chunk's first k-group is read again after the barrier).  Issue order pinned as in
+    // gnf_fused_big.hip: loads behind MFMAs, never bunched in front of them.  A k-group past the layer's last reads zeros
+    // from both sides (the buffer's range check; the chunk's zero-filled columns): an odd count is rounded up.
+#define GNF_LB_MBLOCK(M, CUR, KL)                                                                              \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int b = 0; b < 4; ++b)                \
+        acc[M][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(CUR[b][q], af[M][q], acc[M][b], 0, 0, 0);             \
+    af[M] = *reinterpret_cast<const f32x4*>(arow + 16 * (M) * kLbLS + 16 * ((KL) + 1));
+#define GNF_LB_STEP(CUR, NXT, KL)                                                                              \
+    {                                                                                                          \
+        _Pragma("unroll") for (int b = 0; b < 4; ++b) NXT[b] = GNF_LB_LOAD_B(rsrc, voff, wtile[b] + (kg0 + (KL) + 1) * kstride); \
+        GNF_LB_MBLOCK(0, CUR, KL)                                                                              \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
+        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                                                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 15, 0);                                                    \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                     \
+        _Pragma("unroll") for (int m_ = 1; m_ < MW; ++m_) {                                                     \
+            GNF_LB_MBLOCK(m_, CUR, KL)                                                                         \
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                                                \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
+        }                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }
+    __builtin_amdgcn_s_setprio(3);
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        __syncthreads();  // (the previous chunk has been read)
+        put();
+        __syncthreads();
+        if (ch + 1 < n_chunks) fetch((ch + 1) * kLbChunk);  // in flight behind this chunk's MFMAs
+        const int kg0 = ch * (kLbChunk / 16);
+        const int kgn = a.ipg - kg0 < kLbChunk / 16 ? a.ipg - kg0 : kLbChunk / 16;
+        if (nv > 0) {
+            f32x4 af[MW];
+#pragma unroll
+            for (int m = 0; m < MW; ++m) af[m] = *reinterpret_cast<const f32x4*>(arow + 16 * m * kLbLS);
+            __builtin_amdgcn_s_setprio(0);  // (the MFMA stream yields issue slots to the co-resident workgroup's latency-bound phases)
+            for (int kl = 0; kl < kgn; kl += 2) {
+                GNF_LB_STEP(b0, b1, kl)
+                GNF_LB_STEP(b1, b0, kl + 1)
+            }
+            __builtin_amdgcn_s_setprio(3);
+        }
+    }
+#undef GNF_LB_MBLOCK
+#undef GNF_LB_STEP
+    // epilogue: lane l holds out[row = 16 m + (l & 15)][16 ct + 4 (l >> 4) + r]
+    const float slope = a.act == GNF_ACT_RELU ? 0.f : a.alpha;
+    float* __restrict__ y = a.y[net];
+    const bool yvec = (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        if (b >= nv) continue;
+        const int c = 16 * (ct0 + 4 * b) + 4 * lgrp;
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            const int r = row0 + 16 * m + lrow;
+            if (r >= a.n || c >= a.O) continue;
+            f32x4 v = acc[m][b];
+            if (a.apply_act) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], slope * v[q]);
+            }
+            float* p = y + (int64_t)r * a.ldy + c;
+            if (yvec && c + 3 < a.O) {
+                *reinterpret_cast<f32x4*>(p) = v;
+            } else {
+                p[0] = v[0];
+                if (c + 1 < a.O) p[1] = v[1];
+                if (c + 2 < a.O) p[2] = v[2];
+                if (c + 3 < a.O) p[3] = v[3];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kLbThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linear_big(const LinBigArgs a) {
+    __shared__ __attribute__((aligned(16))) float act[kLbRows * kLbLS];
+    // block -> (panel = column block x net, workgroup of the panel), XCD-aware: block b runs on XCD b % 8, and a 256-column
+    // weight panel (2 MB at 2048 inputs) has to stay in that XCD's 4 MB L2 for every workgroup that uses it - so each XCD gets
+    // a CONTIGUOUS range of the (panel-major) order and works its panels off one after the other.
+    const int64_t nwg = gridDim.x, bid = blockIdx.x;
+    const int64_t xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
+    const int64_t L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int panel = (int)(L / a.wg_per_panel), w = (int)(L - (int64_t)panel * a.wg_per_panel);
+    const int cb = panel >> 1, net = panel & 1;
+    const int mt = a.wg_base + (w < a.wg_rem ? 1 : 0);
+    const int rt0 = w < a.wg_rem ? w * (a.wg_base + 1) : a.wg_rem * (a.wg_base + 1) + (w - a.wg_rem) * a.wg_base;
+    if (mt >= 4)
+        lin_big_body<4>(a, act, cb, net, 16 * rt0);
+    else if (mt == 3)
+        lin_big_body<3>(a, act, cb, net, 16 * rt0);
+    else
+        lin_big_body<2>(a, act, cb, net, 16 * rt0);  // (a 1-tile workgroup multiplies a row tile of zeros beside its own)
+}
+
+static inline int lb_pad16(int v) { return (v + 15) & ~15; }
+
+// y[q] = act(x[q] W_j + b_j) of nets[q] (nj = 1 or 2 nets with identical shapes), layer j, from the nets' packed weights.
+// 1 = not this kernel's case (no packed copy, a narrow output, a launch that would not fill the chip): the caller runs the
+// generic tile.
+int launch_linear_big(const GnfMlp* const* nets, int nj, int j, const float* const* x, int64_t ldx, float* const* y, int64_t ldy,
+                      int64_t n, int act, float alpha, int apply_act, hipStream_t st) {
+    const GnfMlp* m = nets[0];
+    const int I = m->dims[j], O = m->dims[j + 1];
+    // (a short reduction - the 100 -> 2048 first layer - is all prologue and epilogue here: 45 us against the generic tile's 24)
+    if (nj != 2 || !nets[0]->packed || !nets[1]->packed || O < 256 || I < 512 || n > (int64_t)INT32_MAX - 64) return 1;
+    const int ipg = lb_pad16(I) / 16, ont = lb_pad16(O) / 16;
+    const int col_blocks = (ont * 16 + kLbCols - 1) / kLbCols;
+    // Row tiles per workgroup.  With whole 64-row workgroups the data driver's batch is 43 x 16 = 688 workgroups on 512
+    // slots: 2.7 per CU, some CU takes 3 (0.90 of whatever a pair reaches).  Instead every slot gets the same NUMBER of
+    // workgroups (R rounds) and the panels' row tiles are dealt evenly over them, 2 - 4 row tiles each, the larger ones first:
+    // 170 row tiles per panel = 42 x 3 + 22 x 2 there, (3 + 3) and (3 + 2) row tiles per slot.
+    const int64_t n_rt = (n + 15) / 16, panels = (int64_t)col_blocks * 2, slots = 2 * (int64_t)big_cu_count();
+    const int64_t units = n_rt * panels;
+    if (units < 2 * slots) return 1;                                   // would not fill the chip with 2-tile workgroups
+    const int64_t rounds = (units + 4 * slots - 1) / (4 * slots);
+    int64_t wpp = (rounds * slots + panels - 1) / panels;                 // workgroups per panel
+    if (wpp * 4 < n_rt) wpp = (n_rt + 3) / 4;
+    if (wpp > n_rt) wpp = n_rt;
+    const int wg_base = (int)(n_rt / wpp), wg_rem = (int)(n_rt % wpp);
+    if (wg_base + (wg_rem ? 1 : 0) > 4 || wg_base < 1) return 1;
+    int64_t woff = 0, wtot = 0, boff = 0;
+    for (int i = 0; i < m->num_layers; ++i) {
+        const int64_t w = (int64_t)lb_pad16(m->dims[i]) * lb_pad16(m->dims[i + 1]);
+        if (i < j) woff += w, boff += lb_pad16(m->dims[i + 1]);
+        wtot += w;
+    }
+    if ((int64_t)ipg * ont * 1024 >= ((int64_t)1 << 31)) return 1;  // (32-bit buffer offsets)
+    LinBigArgs a;
+    for (int q = 0; q < 2; ++q) {
+        a.x[q] = x[q], a.y[q] = y[q];
+        a.wp[q] = nets[q]->packed + woff;
+        a.bias[q] = nets[q]->packed + wtot + boff;
+    }
+    a.ldx = ldx, a.ldy = ldy;
+    a.n = (int32_t)n, a.I = I, a.O = O, a.ipg = ipg, a.ont = ont, a.col_blocks = col_blocks;
+    a.act = act, a.apply_act = apply_act, a.alpha = alpha;
+    a.wg_per_panel = (int32_t)wpp, a.wg_base = wg_base, a.wg_rem = wg_rem;
+    hipLaunchKernelGGL(k_linear_big, dim3((unsigned)(wpp * panels)), dim3(kLbThreads), 0, st, a);
+    GNF_LAUNCH_CHECK("k_linear_big");
+    return GNF_OK;
+}
+
+}  // namespace gnf

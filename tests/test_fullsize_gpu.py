@@ -117,6 +117,45 @@ def test_config2_full_batch_vs_fp64_oracle(fused):
     assert rt <= SLACK * c["rt_err32"] + FLOOR, (rt, c["rt_err32"])
 
 
+def test_wide_layers_on_the_bench_batch_vs_fp64_oracle():
+    """Layers wider than the fused kernels hold (latent 1536, K = 3: the layered path) on the config-2 batch: the wide hidden
+    layer of both nets runs through k_linear_big (gnf_linear_big.hip: packed weights straight from L2, workgroups of 2 - 4
+    row tiles dealt evenly over the CU slots), the others through the generic tile - forward, log-prob and inverse vs the
+    float64 oracle, and the generic tile alone (one net at a time is not k_linear_big's case) bitwise."""
+    g_cpu, p0, hp0 = _bench_batch()
+    hp = dict(hp0, latent=1536, K=3, T=1)
+    p = O.make_grevnet_params(31, hp["D"] // 2, hp["latent"], hp["K"], hp["T"], final_scale=0.25)
+    x = g_cpu.nodes.numpy()
+    s, r = g_cpu.senders.numpy(), g_cpu.receivers.numpy()
+    n = x.shape[0]
+    assert ((n + 15) // 16) * 2 * (1536 // 256) >= 4 * torch.cuda.get_device_properties(0).multi_processor_count
+    c = _conditioning(hp, s, r, n, x, p)
+    ref = c["ref"]
+    net = make_product_grevnet(hp, p)
+    from gnf_amd.flow import log_prob_terms
+    graph = graph_from_arrays(g_cpu.n_node.numpy(), g_cpu.n_edge.numpy(), s, r, x, DEV)
+    out = log_prob_terms(net, graph)
+    torch.cuda.synchronize()
+    for key in ("log_prob_xs_per_node", "log_prob_zs_per_node", "log_det_jacobian_per_node"):
+        assert abs(float(out[key]) - ref[key]) <= 1e-4, key
+    z = out["z_graph"].nodes.cpu().double()
+    z_err = float((z - ref["z"]).abs().max())
+    assert z_err <= SLACK * c["z_err32"] + FLOOR, (z_err, c["z_err32"])
+    back = net(out["z_graph"], inverse=False).nodes
+    assert float((back - graph.nodes).abs().max()) <= SLACK * c["rt_err32"] + FLOOR
+    # the same module through gnf_gnn_apply_f32 (ONE net per call: the generic tile) must give the bits k_linear_big gave:
+    # s of the first half-step, recovered from z = x1 * exp(s) + t ... is not separable - compare the GNN module outputs
+    from gnf_amd import gnn
+    from functools import partial
+    mod = gnn.avg_then_mlp_gnn(partial(gnn.make_mlp_model, hp["latent"], hp["D"] // 2, hp["K"], gnn.leaky_relu), hp["epsilon"])
+    mod._node_block._mlp.set_params(p["s"][0][0])
+    h = hp["D"] // 2
+    alone = mod(graph.replace(nodes=graph.nodes[:, :h].contiguous())).nodes.cpu().double()
+    o64 = c["o64"]
+    want = o64.gnn(o64.to_t(x[:, :h]), c["p64"]["s"][0][0])
+    assert float((alone - want).abs().max()) <= 2e-4
+
+
 def test_config3_512_graphs_vs_oracle_and_8_shards(community_medium):
     """community_medium batch = 512 (bench.py --gpus 8 global batch: 64 graphs per rank), on ONE device:
     the whole batch vs the oracle, then the 8 shards 8 ranks would run."""
