@@ -28,7 +28,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HP = dict(D=64, latent=256, K=5, T=8, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu",
           weight_sharing=False)
@@ -61,6 +60,28 @@ WORKLOADS = {
     "wide_fc": dict(desc="community_medium, fully connected, latent 2048 x 3 layers, D = 200, T = 10 (layered GEMM path)",
                     dataset="graph_rnn_community_medium", graphs=64, hp=dict(D=200, latent=2048, K=3, T=10),
                     inverse=False, fc=True),
+    # train_grevnet_with_data.py's LITERAL defaults (:40-46, 100-117, 303-310): dm_attn with ONE head, kq = v = 64, C = 64,
+    # kq_dim_division, concat; relu MLPs 2048 x 3 (bias_init_stddev 0.3); D = 200; 10 coupling layers; use_batch_norm=True;
+    # complete graphs (transform_example).  Forward + log-prob (training-mode batch moments in f)
+    "data_default_flags": dict(desc="community_medium, fully connected, the DATA driver's default flags: dm_attn (1 head, kq=v=64, C=64, "
+                                    "kq_dim_division) + batch norm around relu MLPs 2048 x 3, D = 200, T = 10",
+                               dataset="graph_rnn_community_medium", graphs=64,
+                               hp=dict(D=200, latent=2048, K=3, T=10, activation="relu", use_batch_norm=True, bias_init_stddev=0.3,
+                                       attn=dict(num_heads=1, kq_dim=64, v_dim=64, out_dim=64, concat=True,
+                                                 kq_dim_division=True, residual=False)),
+                               inverse=False, fc=True),
+    # ... and one iteration of that driver's training loop per step (train_grevnet_with_data.py:380,478-554)
+    "data_default_flags_train": dict(desc="community_medium, fully connected, TRAINING step with the DATA driver's default flags: dm_attn "
+                                          "(1 head, kq=v=64, C=64) + batch norm around relu MLPs 2048 x 3, D = 200, T = 10",
+                                     dataset="graph_rnn_community_medium", graphs=64,
+                                     hp=dict(D=200, latent=2048, K=3, T=10, activation="relu", use_batch_norm=True, bias_init_stddev=0.3,
+                                             attn=dict(num_heads=1, kq_dim=64, v_dim=64, out_dim=64, concat=True,
+                                                       kq_dim_division=True, residual=False)),
+                                     inverse=False, fc=True, train=True),
+    # the same trainer step with the message-passing GNN in place of the attention block (the wide MLPs' backward alone)
+    "wide_fc_train": dict(desc="community_medium, fully connected, TRAINING step, latent 2048 x 3 layers, D = 200, T = 10 (avg_then_mlp)",
+                          dataset="graph_rnn_community_medium", graphs=64, hp=dict(D=200, latent=2048, K=3, T=10),
+                          inverse=False, fc=True, train=True),
     # one training iteration of run_grevnet.py:440-447 per step: forward + reversible backward + Adam + re-pack
     "config2_train": dict(desc="community_medium, TRAINING step (fwd + reversible backward + Adam)",
                           dataset="graph_rnn_community_medium", graphs=64, hp={}, inverse=False, fc=False, train=True),
@@ -79,15 +100,33 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 
 PEAK_HBM_GBS = 8000.0
 
 
-def kernel_source_stamp():
-    """sha256 over the sources of the dominant kernels (k_half_fused, with the attention front-end as its prologue,
-    k_half_big and kernel A: gnf_fused.hip + gnf_fused_dev.h + gnf_attn_front_dev.h + gnf_fused_big.hip + gnf_layered.hip):
-    what the PMC passes under profiles/ were taken on.  (There is no .git on the GPU box, so the
-    stamp is content-based.)"""
+# Sources of the kernels each workload's launches live in: what a PMC pass under profiles/ is evidence FOR.  An entry of
+# profiles/pmc_traffic.json is quoted only while the sha256 over its workload's set is the build's (there is no .git on the
+# GPU box, so the stamp is content-based).
+_SRC_FUSED = ("gnf_fused.hip", "gnf_fused_dev.h", "gnf_attn_front_dev.h")
+_SRC_BIG = ("gnf_fused_big.hip", "gnf_fused_dev.h", "gnf_layered.hip")
+_SRC_WIDE = ("gnf_linear_big.hip", "gnf_train.hip", "gnf_layered.hip", "gnf_fused_dev.h")
+_SRC_ATTN = ("gnf_attn.hip", "gnf_attn_dev.h", "gnf_bn.hip")
+_SRC_BWD = ("gnf_train.hip", "gnf_fused_bwd.hip", "gnf_fused_bwd_dev.h", "gnf_optim.hip")
+_SRC_ATTN_BWD = ("gnf_attn_bwd.hip", "gnf_bn_bwd.hip")
+WORKLOAD_SOURCES = {
+    "config2": _SRC_FUSED, "config2_fc": _SRC_FUSED, "config2_attn": _SRC_FUSED, "default_flags": _SRC_FUSED,
+    "config4": _SRC_BIG, "config5": _SRC_BIG,
+    "wide_fc": _SRC_WIDE,
+    "data_default_flags": _SRC_WIDE + _SRC_ATTN,
+    "config2_train": _SRC_FUSED + _SRC_BWD,
+    "default_flags_train": _SRC_FUSED + _SRC_BWD + _SRC_ATTN_BWD,
+    "wide_fc_train": _SRC_WIDE + _SRC_BWD,
+    "data_default_flags_train": _SRC_WIDE + _SRC_ATTN + _SRC_BWD + _SRC_ATTN_BWD,
+}
+
+
+def kernel_source_stamp(workload="config2"):
+    """sha256 (16 hex digits) over the kernel sources of `workload` (WORKLOAD_SOURCES)."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "graph-normalizing-flows_amd", "csrc")
-    for name in ("gnf_fused.hip", "gnf_fused_dev.h", "gnf_attn_front_dev.h", "gnf_fused_big.hip", "gnf_layered.hip"):
+    for name in sorted(set(WORKLOAD_SOURCES[workload])):
         h.update(name.encode())
         h.update(open(os.path.join(csrc, name), "rb").read())
     return h.hexdigest()[:16]
@@ -387,7 +426,7 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    from helpers import make_product_grevnet
+    from gnf_amd.factories import make_product_grevnet
     from gnf_amd import _abi
     from gnf_amd.flow import forward_shard_sums, log_prob_from_sums
     from gnf_amd.graphs import csr_of, data_dicts_to_graphs_tuple
@@ -740,7 +779,7 @@ def main():
     try:   # counter evidence of kernel A inside this workload's flow, when a PMC pass of this build exists (k_half_big workloads)
         pm_a = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         ka = next((v for k, v in pm_a.get("workloads", {}).get(args.workload, {}).get("kernels", {}).items() if k.startswith("k_aggregate")), None)
-        if ka and pm_a.get("source_stamp") == kernel_source_stamp():
+        if ka and pm_a["workloads"][args.workload].get("source_stamp") == kernel_source_stamp(args.workload):
             kernel_a["traffic"] = round(ka["traffic_bytes_per_launch"])
             kernel_a["traffic_gbs"] = round(ka["hbm_gbs_over_rocprof_avg"], 1)
             kernel_a["traffic_note"] = (f"rocprofv3 --pmc FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE of k_aggregate inside the flow, "
@@ -758,14 +797,14 @@ def main():
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         ent = pm.get("workloads", {}).get(args.workload)
         if ent and net.fused:
-            if pm.get("source_stamp") == kernel_source_stamp():
+            if ent.get("source_stamp") == kernel_source_stamp(args.workload):
                 traffic = round(ent["traffic_bytes_per_launch"])
                 traffic_note = (f"HBM-side bytes per launch of {ent.get('kernel')} from profiles/pmc_traffic.json "
                                 f"(rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE passes, tag {ent.get('tag')}, "
-                                f"kernel sources {pm.get('source_stamp')} = this build)")
+                                f"kernel sources {ent.get('source_stamp')} = this build's {', '.join(sorted(set(WORKLOAD_SOURCES[args.workload])))})")
             else:
-                traffic_note = (f"profiles/pmc_traffic.json was taken on kernel sources {pm.get('source_stamp')}, this build is "
-                                f"{kernel_source_stamp()}: not quoted (re-run tools/final_profile.sh pmc)")
+                traffic_note = (f"profiles/pmc_traffic.json's entry was taken on kernel sources {ent.get('source_stamp')}, this build's "
+                                f"{args.workload} sources are {kernel_source_stamp(args.workload)}: not quoted (re-run tools/final_profile.sh pmc)")
     except (OSError, ValueError, KeyError):
         pass
     achieved_tflops = flops / (kernel_us * 1e-6) / 1e12

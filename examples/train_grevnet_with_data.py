@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The data-backed trainer's loop (/root/reference/train_grevnet_with_data.py:145-271, 336-416, 520-545) on the
-MI355X kernels: node-embedding chunks on disk -> batches of complete graphs (transform_example) -> GRevNet with the
-wide relu MLPs of that driver (latent 2048 x 3 layers, D = 200, 10 coupling layers, batch norm) -> Adam; then the
+MI355X kernels: node-embedding chunks on disk -> batches of complete graphs (transform_example) -> GRevNet with that
+driver's default GNN (dm_attn: one head, kq = v = 64, C = 64, kq_dim_division; :40-46, 303-310) around its wide relu
+MLPs (latent 2048 x 3 layers, D = 200, 10 coupling layers, batch norm) -> Adam (beta2 0.999, constant lr); then the
 sampling pipeline z ~ N(0, I) -> grevnet(., inverse=False) -> pred_adj(scaled_hacky_sigmoid_l2) -> threshold 0.5.
 
 There is no trained encoder here (run_gnn.py is out of scope), so --make_chunks writes embedding chunks whose
@@ -54,18 +55,23 @@ def main():
     ap.add_argument("--bias_init_stddev", type=float, default=0.3)
     ap.add_argument("--no_batch_norm", action="store_true")
     ap.add_argument("--weight_sharing", action="store_true")
-    ap.add_argument("--attn_type", default="avg_then_mlp", choices=["avg_then_mlp", "dm_attn"])
+    # the reference's defaults (train_grevnet_with_data.py:40-46): dm_attn, one head, kq = v = 64, C = 64
+    # ("avg_then_mlp" is not a choice of the reference's ATTN_MAP; kept here as the message-passing alternative)
+    ap.add_argument("--attn_type", default="dm_attn", choices=["dm_attn", "avg_then_mlp"])
     ap.add_argument("--use_layer_norm", action="store_true")
-    ap.add_argument("--attn_kq_dim", type=int, default=10)
-    ap.add_argument("--attn_v_dim", type=int, default=10)
-    ap.add_argument("--attn_num_heads", type=int, default=8)
-    ap.add_argument("--attn_concat_heads_output_dim", type=int, default=80)
+    ap.add_argument("--attn_kq_dim", type=int, default=64)
+    ap.add_argument("--attn_v_dim", type=int, default=64)
+    ap.add_argument("--attn_num_heads", type=int, default=1)
+    ap.add_argument("--attn_concat_heads_output_dim", type=int, default=64)
     ap.add_argument("--train_batch_size", type=int, default=32)
     ap.add_argument("--train_epochs", type=int, default=20)
     ap.add_argument("--num_train_iters", type=int, default=60)
     ap.add_argument("--log_every_n_steps", type=int, default=10)
     ap.add_argument("--sample_size", type=int, default=8)
-    ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--lr", type=float, default=1e-4)          # lr_type 'constant' (train_grevnet_with_data.py:75-78)
+    ap.add_argument("--adam_beta1", type=float, default=0.9)
+    ap.add_argument("--adam_beta2", type=float, default=0.999)  # (:86; run_grevnet.py's default is 0.9)
+    ap.add_argument("--adam_epsilon", type=float, default=1e-8)
     ap.add_argument("--clip_gradient_by_value", action="store_true")
     ap.add_argument("--clip_gradient_by_norm", action="store_true")
     ap.add_argument("--clip_gradient_norm", type=float, default=10.0)
@@ -98,7 +104,8 @@ def main():
     }[F.attn_type]
     grevnet = gnn.GRevNet(make_gnn_fn, F.num_coupling_layers, F.node_embedding_dim,
                           use_batch_norm=not F.no_batch_norm, weight_sharing=F.weight_sharing)
-    trainer = GRevNetTrainer(grevnet, lr=F.lr, clip_gradient_by_value=F.clip_gradient_by_value,
+    trainer = GRevNetTrainer(grevnet, lr=F.lr, adam_beta1=F.adam_beta1, adam_beta2=F.adam_beta2, adam_epsilon=F.adam_epsilon,
+                             use_lr_decay=False, clip_gradient_by_value=F.clip_gradient_by_value,
                              clip_gradient_by_norm=F.clip_gradient_by_norm, clip_gradient_norm=F.clip_gradient_norm)
     t0 = time.perf_counter()
     for iteration in range(F.num_train_iters + 1):

@@ -18,9 +18,6 @@
 
 namespace gnf {
 
-static constexpr int kAttnMaxKq = 256;  // bounds keep the LDS tile small; the kernels loop at run time
-static constexpr int kAttnMaxV = 256;
-
 struct AttnArgs {
     const float* Wq[2];
     const float* Wk[2];
@@ -341,10 +338,10 @@ __global__ __launch_bounds__(512) void k_attn_agg(const AttnArgs a, int RB) {
 }
 
 int validate_attn(const GnfAttn* at, const GnfMlp* mlp, int32_t H, const char* what) {
-    if (at->num_heads < 1 || at->num_heads > 64 || at->kq_dim < 1 || at->kq_dim > kAttnMaxKq ||
-        at->v_dim < 1 || at->v_dim > kAttnMaxV || at->out_dim < 1) {
-        set_error("%s: attention dims heads=%d kq=%d v=%d out=%d outside (1..64, 1..%d, 1..%d, >=1)", what,
-                  at->num_heads, at->kq_dim, at->v_dim, at->out_dim, kAttnMaxKq, kAttnMaxV);
+    if (at->num_heads < 1 || at->num_heads > kAttnMaxHeads || at->kq_dim < 1 || at->v_dim < 1 || at->out_dim < 1 ||
+        (int64_t)at->num_heads * at->kq_dim > kAttnMaxWidth || (int64_t)at->num_heads * at->v_dim > kAttnMaxWidth) {
+        set_error("%s: attention dims heads=%d kq=%d v=%d out=%d outside heads in 1..%d, heads*kq <= %d, heads*v <= %d, out >= 1",
+                  what, at->num_heads, at->kq_dim, at->v_dim, at->out_dim, kAttnMaxHeads, kAttnMaxWidth, kAttnMaxWidth);
         return GNF_ESHAPE;
     }
     if (!at->Wq || !at->Wk || !at->Wv || !at->Wo) {

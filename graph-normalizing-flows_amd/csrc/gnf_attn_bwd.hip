@@ -1134,9 +1134,10 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
     a.scale = a0->kq_dim_division ? 1.f / sqrtf((float)a0->kq_dim) : 1.f;
     const int NV = a.nh * a.v, nq = a.nh * a.kq, P = 2 * nq + a.v;
     const int wmax = nq > NV ? nq : NV;
-    if (wmax > 256 || a.nh > 64) {
-        set_error("attention backward supports heads*kq_dim, heads*v_dim <= 256 and heads <= 64");
-        return GNF_EUNSUPPORTED;
+    if (wmax > kAttnMaxWidth || a.nh > kAttnMaxHeads) {  // (validate_attn's limit: the entry point has rejected this already)
+        set_error("attention backward: heads=%d kq=%d v=%d outside heads <= %d, heads*kq <= %d, heads*v <= %d", a.nh, a.kq,
+                  a.v, kAttnMaxHeads, kAttnMaxWidth, kAttnMaxWidth);
+        return GNF_ESHAPE;
     }
     const size_t fixed = attn_bwd_fixed_bytes(nq, NV, a.nh);
     const int cap_r = (int)((kWinBudget - fixed) / ((size_t)(nq + a.v + 1) * sizeof(float)));   // window rows, receiver pass

@@ -214,6 +214,11 @@ int launch_linear_splitk(const float* const* x, int64_t ldx, const float* const*
                          int64_t ldy, int nj, int64_t n, int32_t I, int32_t O, int act, float alpha, int apply_act,
                          float* const* sk, size_t sk_floats, hipStream_t st);
 
+// which layers the wide-layer kernel takes: y = x W reads Wp of a layer with a long reduction and a wide output; the
+// backward dX = dY W^T reads WpT where the roles are swapped.  gnf_pack_flow keeps exactly these copies of a net that is
+// too wide for the fused kernels in step with its weights.
+inline bool linear_big_fwd_layer(int I, int O) { return I >= 512 && O >= 256; }
+inline bool linear_big_bwd_layer(int I, int O) { return O >= 512 && I >= 256; }
 // wide y = act(x W_j + b_j) of a pair of nets from their packed weights (gnf_linear_big.hip); 1 = not its case
 int launch_linear_big(const GnfMlp* const* nets, int nj, int j, const float* const* x, int64_t ldx, float* const* y, int64_t ldy,
                       int64_t n, int act, float alpha, int apply_act, hipStream_t st);
@@ -234,7 +239,10 @@ int launch_bn_backward(const GnfFlow* flow, const GnfBatchNorm* bn, const GnfBat
 
 int validate_mlp(const GnfMlp* m, const char* what);
 int validate_flow_call(const GnfCsr* csr, const GnfFlow* flow, int64_t ld, int32_t D, const char* what);
-// attention front-end (gnf_attn.hip)
+// attention front-end (gnf_attn.hip).  THE limit of the head geometry (include/gnf.h, GnfAttn): heads <= 64,
+// heads * kq <= 256, heads * v <= 256 - validate_attn enforces it for the forward / inverse AND the backward entry points
+static constexpr int kAttnMaxHeads = 64;
+static constexpr int kAttnMaxWidth = 256;
 int validate_attn(const GnfAttn* at, const GnfMlp* mlp, int32_t H, const char* what);
 size_t attn_scratch_floats(const GnfAttn* at, int64_t n_nodes, int32_t in0);
 // need_qkv: the caller reads the per-node q | k | v block of `scratch` afterwards (backward pass, attention stash)

@@ -60,12 +60,13 @@ __device__ __forceinline__ void lin_big_body(const LinBigArgs& a, float* __restr
     const int kstride = a.ont * 1024;
     int wtile[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) wtile[b] = (ct0 + (b < nv ? 4 * b : 0)) * 1024;
+    for (int b = 0; b < 4; ++b) wtile[b] = (nv > 0 ? ct0 + (b < nv ? 4 * b : 0) : 0) * 1024;
 
     f32x4 acc[MW][4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 16 * (ct0 + (b < nv ? 4 * b : 0)) + 4 * lgrp);
+        // (a wave without a live column tile - padded O not a multiple of 256 - reads tile 0's bias, not past the row)
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 16 * (nv > 0 ? ct0 + (b < nv ? 4 * b : 0) : 0) + 4 * lgrp);
 #pragma unroll
         for (int m = 0; m < MW; ++m) acc[m][b] = bv;
     }
@@ -215,7 +216,7 @@ int launch_linear_big(const GnfMlp* const* nets, int nj, int j, const float* con
     const GnfMlp* m = nets[0];
     const int I = m->dims[j], O = m->dims[j + 1];
     // (a short reduction - the 100 -> 2048 first layer - is all prologue and epilogue here: 45 us against the generic tile's 24)
-    if (nj != 2 || !nets[0]->packed || !nets[1]->packed || O < 256 || I < 512 || n > (int64_t)INT32_MAX - 64) return 1;
+    if (nj != 2 || !nets[0]->packed || !nets[1]->packed || !linear_big_fwd_layer(I, O) || n > (int64_t)INT32_MAX - 64) return 1;
     const int ipg = lb_pad16(I) / 16, ont = lb_pad16(O) / 16;
     const int col_blocks = (ont * 16 + kLbCols - 1) / kLbCols;
     // Row tiles per workgroup.  With whole 64-row workgroups the data driver's batch is 43 x 16 = 688 workgroups on 512

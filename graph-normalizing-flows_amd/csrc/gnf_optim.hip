@@ -54,12 +54,16 @@ __global__ __launch_bounds__(256) void k_pack_multi(const PackBatch pb) {
                     if (ko + q < d.O) t4[q] = row[q];
             }
         }
+        // (wout / wtout == NULL: that copy of the layer has no reader - wide nets, see pack_flow)
         if (((reinterpret_cast<uintptr_t>(d.wout) | reinterpret_cast<uintptr_t>(d.wtout)) & 15) == 0) {
-            *reinterpret_cast<float4*>(d.wout + i) = make_float4(w4[0], w4[1], w4[2], w4[3]);
-            *reinterpret_cast<float4*>(d.wtout + i) = make_float4(t4[0], t4[1], t4[2], t4[3]);
+            if (d.wout) *reinterpret_cast<float4*>(d.wout + i) = make_float4(w4[0], w4[1], w4[2], w4[3]);
+            if (d.wtout) *reinterpret_cast<float4*>(d.wtout + i) = make_float4(t4[0], t4[1], t4[2], t4[3]);
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) d.wout[i + q] = w4[q], d.wtout[i + q] = t4[q];
+            for (int q = 0; q < 4; ++q) {
+                if (d.wout) d.wout[i + q] = w4[q];
+                if (d.wtout) d.wtout[i + q] = t4[q];
+            }
         }
     } else if (i < nw + 4 * ((d.Op + 3) / 4)) {
         for (int q = 0; q < 4; ++q) {
@@ -88,9 +92,11 @@ static int pack_flow(const GnfFlow* flow, hipStream_t st) {
         for (int q = 0; q < n_nets; ++q) {
             const GnfMlp* m = kind ? &flow->t_nets[q] : &flow->s_nets[q];
             if (!m->packed) continue;
-            // layers too wide for LDS never run the fused kernels: nothing reads their fragment-order copy (at the
-            // data-backed trainer's 2048-wide layers the re-pack was 1.1 ms per step and 1.5 GB)
-            if (!fused_fits_lds(m) && !fused_bwd_fits_lds(m)) continue;
+            // nets too wide for LDS never run the fused kernels: of their fragment-order copies only what the wide-layer
+            // kernel of the layered path reads (gnf_linear_big.hip: Wp of the layers linear_big_fwd_layer names, WpT of
+            // the ones linear_big_bwd_layer names, and the bias rows) follows the weights - the full re-pack of the
+            // data-backed trainer's 2048-wide nets was 1.1 ms per step and 1.5 GB
+            const bool wide_only = !fused_fits_lds(m) && !fused_bwd_fits_lds(m);
             int64_t woff = 0, boff = 0;
             for (int j = 0; j < m->num_layers; ++j) boff += (int64_t)pad16i(m->dims[j]) * pad16i(m->dims[j + 1]);
             int64_t toff = boff;
@@ -98,9 +104,14 @@ static int pack_flow(const GnfFlow* flow, hipStream_t st) {
             for (int j = 0; j < m->num_layers; ++j) {
                 const int I = m->dims[j], O = m->dims[j + 1], Ip = pad16i(I), Op = pad16i(O);
                 float* pk = const_cast<float*>(m->packed);
-                pb.d[cnt++] = PackDesc{m->W[j], m->b[j], pk + woff, pk + boff, pk + toff + woff, I, O, Ip, Op};
-                const int64_t tot = (int64_t)Ip * Op + Op;
-                maxtot = maxtot > tot ? maxtot : tot;
+                const bool need_w = !wide_only || linear_big_fwd_layer(I, O);
+                const bool need_wt = !wide_only || linear_big_bwd_layer(I, O);
+                if (need_w || need_wt) {
+                    pb.d[cnt++] = PackDesc{m->W[j], m->b[j], need_w ? pk + woff : nullptr, pk + boff,
+                                           need_wt ? pk + toff + woff : nullptr, I, O, Ip, Op};
+                    const int64_t tot = (int64_t)Ip * Op + Op;
+                    maxtot = maxtot > tot ? maxtot : tot;
+                }
                 woff += (int64_t)Ip * Op;
                 boff += Op;
                 if (cnt == kPackBatch) {

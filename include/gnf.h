@@ -79,9 +79,13 @@ typedef struct GnfCsr {
  * + ln_beta with the biased per-row variance; ln_gamma / ln_beta have the MLP's output width. */
 #define GNF_LN_EPS 1e-5f
 typedef struct GnfAttn {
-    int32_t num_heads;       /* 1..64 */
-    int32_t kq_dim;          /* 1..32 */
-    int32_t v_dim;           /* 1..32 */
+    /* ONE limit, checked by every entry point that takes the block (forward, inverse, backward): num_heads in 1..64 and
+     * num_heads * kq_dim <= 256 and num_heads * v_dim <= 256 (GNF_ESHAPE otherwise).  Inside it every geometry runs; the
+     * drivers' defaults have kernels of their own (run_grevnet.py:74-77: 8 heads, kq = v = 10, C = 80;
+     * train_grevnet_with_data.py:40-46: 1 head, kq = v = 64, C = 64). */
+    int32_t num_heads;
+    int32_t kq_dim;
+    int32_t v_dim;
     int32_t out_dim;         /* concat_heads_output_dim */
     int32_t concat;          /* attn_concat */
     int32_t kq_dim_division; /* divide logits by sqrt(kq_dim) */

@@ -174,8 +174,65 @@ def main_bn():
           f"logdet={res['log_det_jacobian']:.4f} -> {os.path.getsize(path)} B")
 
 
+def main_data_driver():
+    """The DATA driver's default GNN and flags (train_grevnet_with_data.py:40-46, 100-117, 303-310, 336-343): dm_attn with
+    ONE head, kq = v = 64, C = 64, kq_dim_division=True, concat, around a relu MLP; use_batch_norm=True; complete graphs
+    incl. self loops in transform_example's edge order (utils.py:164-183).  Widths other than the head geometry are cut
+    down (D = 40, latent 48, T = 2) so that the fixture stays small; the literal widths run in tests/test_data_driver_gpu.py."""
+    name, d, latent, k, t = "attn_data_driver_defaults", 40, 48, 3, 2
+    akw = dict(num_heads=1, kq_dim=64, v_dim=64, out_dim=64, concat=True, kq_dim_division=True, residual=False)
+    n_node = load("grid_small")[0][[6, 2, 9, 0]]
+    s_l, r_l = [], []
+    for n_ in n_node:                                   # sender-major ordered pairs of every graph, global ids
+        off = int(sum(len(np.unique(a)) for a in s_l))
+        a = np.repeat(np.arange(n_, dtype=np.int32), n_) + off
+        b = np.tile(np.arange(n_, dtype=np.int32), n_) + off
+        s_l.append(a)
+        r_l.append(b)
+    s, r = np.concatenate(s_l), np.concatenate(r_l)
+    nn, ne = n_node.astype(np.int32), (n_node.astype(np.int64) ** 2).astype(np.int32)
+    n = int(nn.sum())
+    rng = np.random.default_rng(12345)
+    x = (rng.standard_normal((n, d)) * 1.3 + 0.2).astype(np.float32)
+    p = O.make_attn_grevnet_params(2028, d // 2, latent, k, t, final_scale=0.4, **akw)
+    p["bn"] = O.make_bn_params(2029, d // 2, t)
+    o64 = O.Fp64Dense(s, r, n, activation="relu")
+    res = o64.log_prob(x, p, t)
+    o32 = O.Fp32Gather(s, r, n, activation="relu")
+    r32 = o32.log_prob(o32.to_t(x), o32.prep_params(p), t)
+    assert abs(res["log_prob_xs_per_node"] - r32["log_prob_xs_per_node"]) < 2e-5, name
+    assert np.abs(r32["z"].numpy() - res["z"]).max() < 5e-5, name
+    xr = o64.g(res["z"], p, t)                          # (moving statistics: not x)
+    blob = dict(n_node=nn, n_edge=ne, senders=s, receivers=r, x=x, D=d, latent=latent, K=k, T=t,
+                agg="mean", combine="agg", epsilon=0.0, activation="relu", weight_sharing=False, gnn="dm_self_attn",
+                use_batch_norm=True, z=res["z"], logdet=res["log_det_jacobian"], log_prob_zs=res["log_prob_zs"],
+                log_prob_xs=res["log_prob_xs"], log_prob_xs_per_node=res["log_prob_xs_per_node"],
+                x_roundtrip=xr, **{"attn_" + kk: vv for kk, vv in akw.items()})
+    for kind in ("s", "t"):
+        for half in range(2):
+            for i, net in enumerate(p[kind][half]):
+                for key in O.attn_weight_keys(net["attn"]):
+                    blob[f"a_{kind}_{half}_{i}_{key}"] = net["attn"][key]
+                for j, (w, b) in enumerate(net["mlp"]):
+                    blob[f"w_{kind}_{half}_{i}_{j}"] = w
+                    blob[f"b_{kind}_{half}_{i}_{j}"] = b
+    for half in range(2):
+        for i in range(t):
+            for key in ("gamma", "beta", "moving_mean", "moving_variance"):
+                blob[f"bn_{half}_{i}_{key}"] = p["bn"][half][i][key]
+            m, v = o64.last_bn_moments[(half, i)]
+            blob[f"bn_{half}_{i}_batch_mean"] = m
+            blob[f"bn_{half}_{i}_batch_variance"] = v
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **blob)
+    print(f"{name}: N={n} E={len(s)} per-node log-prob={res['log_prob_xs_per_node']:.6f} "
+          f"logdet={res['log_det_jacobian']:.4f} -> {os.path.getsize(path)} B")
+
+
 if __name__ == "__main__":
     main()
     main_attn()
+    if not ONLY or "attn_data_driver_defaults" in ONLY:
+        main_data_driver()
     if not ONLY or "bn_small_community" in ONLY:
         main_bn()

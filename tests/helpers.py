@@ -7,6 +7,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDEN_CASES = ["cfg1_grid_small_d2", "cfg1_grid_small_d8", "cfg2_small_community", "sum_concat_relu_shared"]
 ATTN_GOLDEN_CASES = ["attn_cfg1_grid_small", "attn_small_community_noconcat_div", "attn_layer_norm_residual"]
 BN_GOLDEN_CASES = ["bn_small_community"]
+DATA_DRIVER_GOLDEN_CASES = ["attn_data_driver_defaults"]   # dm_attn 1 head kq = v = 64 + batch norm on complete graphs
 ATTN_KEYS = ("num_heads", "kq_dim", "v_dim", "out_dim", "concat", "kq_dim_division", "residual")
 
 
@@ -55,26 +56,9 @@ def load_golden(name):
 
 
 def make_product_grevnet(hp, params):
-    """Build the product GRevNet through the reference-shaped factories (run_grevnet.py:154-180).
-    hp: dict with D, latent, K, T, agg, combine, epsilon, activation, weight_sharing."""
-    from functools import partial
-    from gnf_amd import gnn
-    act = gnn.leaky_relu if hp["activation"] == "leaky_relu" else gnn.relu
-    mk_mlp = partial(gnn.make_mlp_model, hp["latent"], hp["D"] / 2, hp["K"], act, 0.01, 0.1)
-    if hp.get("attn"):                      # run_grevnet.py:199-211 make_dm_self_attn_gnn
-        a = hp["attn"]
-        mk = partial(gnn.dm_self_attn_gnn, kq_dim=a["kq_dim"], v_dim=a["v_dim"], make_mlp_fn=mk_mlp,
-                     num_heads=a["num_heads"], concat_heads_output_dim=a["out_dim"], concat=a["concat"],
-                     residual=a["residual"], layer_norm=a.get("layer_norm", False), kq_dim_division=a["kq_dim_division"])
-    elif hp["combine"] == "concat":
-        mk = partial(gnn.sum_concat_then_mlp_gnn if hp["agg"] == "sum" else gnn.avg_concat_then_mlp_gnn, mk_mlp)
-    else:
-        mk = partial(gnn.sum_then_mlp_gnn if hp["agg"] == "sum" else gnn.avg_then_mlp_gnn, mk_mlp, hp["epsilon"])
-    net = gnn.GRevNet(mk, hp["T"], hp["D"], use_batch_norm=bool(params is not None and params.get("bn")),
-                      weight_sharing=hp["weight_sharing"])
-    if params is not None:
-        net.set_params(params)
-    return net
+    """The drivers' factory wiring (run_grevnet.py:154-211) lives in the package: gnf_amd.factories."""
+    from gnf_amd.factories import make_product_grevnet as mk
+    return mk(hp, params)
 
 
 def graph_from_arrays(n_node, n_edge, senders, receivers, x, device="cpu"):

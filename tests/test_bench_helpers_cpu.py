@@ -52,9 +52,35 @@ def test_make_batch_shards_cover_the_global_batch():
 
 
 def test_workload_table():
-    assert set(bench.WORKLOADS) == {"config2", "config2_fc", "config2_attn", "config4", "config5", "wide_fc", "config2_train", "default_flags", "default_flags_train"}
+    assert set(bench.WORKLOADS) == {"config2", "config2_fc", "config2_attn", "config4", "config5", "wide_fc", "config2_train", "default_flags",
+                                    "default_flags_train", "data_default_flags", "data_default_flags_train", "wide_fc_train"}
+    assert set(bench.WORKLOAD_SOURCES) == set(bench.WORKLOADS)
+    # the data driver's literal defaults (train_grevnet_with_data.py:40-46, 100-117)
+    hp = bench.WORKLOADS["data_default_flags"]["hp"]
+    assert (hp["D"], hp["latent"], hp["K"], hp["T"], hp["use_batch_norm"], hp["activation"]) == (200, 2048, 3, 10, True, "relu")
+    assert hp["attn"] == dict(num_heads=1, kq_dim=64, v_dim=64, out_dim=64, concat=True, kq_dim_division=True, residual=False)
+    assert bench.WORKLOADS["data_default_flags"]["fc"] and bench.WORKLOADS["data_default_flags_train"]["train"]
     assert bench.WORKLOADS["config5"]["hp"] == dict(D=256, T=16)
     assert bench.WORKLOADS["config4"]["inverse"] is True
+
+
+def test_every_pmc_traffic_entry_names_its_kernel_sources():
+    """profiles/pmc_traffic.json: each workload's entry carries the list of kernel sources it is evidence for (the
+    workload's set in bench.WORKLOAD_SOURCES, every one an existing file of csrc/) and the stamp over them; the training /
+    wide-layer workloads' sets contain the files their dominant kernels live in."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert "source_stamp" not in d                       # (round 4's single stamp over five forward files is gone)
+    csrc = os.path.join(ROOT, "graph-normalizing-flows_amd", "csrc")
+    for wl, e in d["workloads"].items():
+        assert e["sources"] == sorted(set(bench.WORKLOAD_SOURCES[wl])), wl
+        assert len(e["source_stamp"]) == 16 and all(os.path.exists(os.path.join(csrc, f)) for f in e["sources"]), wl
+    assert {"gnf_linear_big.hip", "gnf_train.hip"} <= set(bench.WORKLOAD_SOURCES["wide_fc"])
+    for wl in bench.WORKLOADS:
+        if wl.endswith("_train"):
+            assert {"gnf_train.hip", "gnf_fused_bwd.hip", "gnf_fused_bwd_dev.h"} <= set(bench.WORKLOAD_SOURCES[wl]), wl
+        if "default_flags_train" in wl:
+            assert {"gnf_attn_bwd.hip", "gnf_bn_bwd.hip"} <= set(bench.WORKLOAD_SOURCES[wl]), wl
+        assert len(bench.kernel_source_stamp(wl)) == 16
 
 
 def test_line_consistency_checks():

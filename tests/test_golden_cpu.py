@@ -4,10 +4,10 @@ import numpy as np
 import pytest
 
 from oracle import gnf_oracle as O
-from helpers import ATTN_GOLDEN_CASES, BN_GOLDEN_CASES, GOLDEN_CASES, load_golden
+from helpers import ATTN_GOLDEN_CASES, BN_GOLDEN_CASES, DATA_DRIVER_GOLDEN_CASES, GOLDEN_CASES, load_golden
 
 # attention and batch-norm fixtures run through the same checks
-GOLDEN_CASES = GOLDEN_CASES + ATTN_GOLDEN_CASES + BN_GOLDEN_CASES
+GOLDEN_CASES = GOLDEN_CASES + ATTN_GOLDEN_CASES + BN_GOLDEN_CASES + DATA_DRIVER_GOLDEN_CASES
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)

@@ -305,3 +305,16 @@ def test_chunk_readers_open_their_first_file_in_the_constructor(tmp_path):
     assert fx.file_ind == 0 and fx.n_node.tolist() == [10, 20, 5]             # the open chunk's sizes (reference: self.n_node = d[1])
     assert fx.train_batch()[1].tolist() == [10, 20] and fx.train_batch()[1].tolist() == [30, 4]
     assert fx.n_node.tolist() == [30, 4]
+
+
+def test_example_driver_defaults_are_the_reference_flags():
+    """examples/train_grevnet_with_data.py's argument defaults = train_grevnet_with_data.py:40-46, 86, 100-117."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "train_grevnet_with_data.py")).read()
+    want = {"attn_type": '"dm_attn"', "attn_kq_dim": "64", "attn_v_dim": "64", "attn_num_heads": "1",
+            "attn_concat_heads_output_dim": "64", "node_embedding_dim": "200", "latent_dim": "2048", "num_layers": "3",
+            "num_coupling_layers": "10", "bias_init_stddev": "0.3", "adam_beta2": "0.999", "train_batch_size": "32"}
+    for flag, val in want.items():
+        m = re.search(r'add_argument\("--%s",[^\n]*default=([^,)\s]+)' % flag, src)
+        assert m and m.group(1) == val, (flag, m and m.group(1))

@@ -807,3 +807,39 @@ def test_pred_adj_rejects_a_launch_bound_below_the_largest_graph():
     g = graph_from_arrays([5, 7], [0, 0], np.zeros(0, np.int32), np.zeros(0, np.int32), z, DEV)
     with pytest.raises(ValueError, match="below the largest graph"):
         pred_adj(g, max_nodes_per_graph=6)
+
+
+def test_wide_nets_packed_copies_follow_the_weights(community_medium):
+    """Nets too wide for the fused kernels (1280-wide hidden layers) on a batch large enough for k_linear_big: that kernel
+    reads the PACKED copy of the middle layer, the backward pass and Adam the raw W.  After optimiser steps the forward
+    through the packed copy must equal the forward through the raw weights (net.fused = False: generic tile), and a step
+    taken from the updated weights must see them (the loss of step 3 is the loss the raw weights give)."""
+    from gnf_amd.flow import log_prob_terms
+    from gnf_amd.train import GRevNetTrainer
+    hp = dict(D=24, latent=1280, K=3, T=1, agg="mean", combine="agg", epsilon=1.0, activation="relu", weight_sharing=False)
+    nn, ne, s, r = _batch(community_medium, list(range(64)))
+    n = int(nn.sum())
+    assert n >= 1650                               # (launch_linear_big wants two row-tile units per CU slot)
+    x = (np.random.default_rng(5).standard_normal((n, 24)) * 0.7).astype(np.float32)
+    p = O.make_grevnet_params(31, 12, 1280, 3, 1, final_scale=0.3)
+    net = make_product_grevnet(hp, p)
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    before = float(log_prob_terms(net, graph)["log_prob_xs_per_node"])
+    tr = GRevNetTrainer(net, lr=2e-3, use_lr_decay=False)
+    for _ in range(2):
+        tr.step(graph)
+    packed = log_prob_terms(net, graph)
+    z_packed = packed["z_graph"].nodes.cpu().numpy()
+    lp_packed = float(packed["log_prob_xs_per_node"])
+    assert abs(lp_packed - before) > 1e-2, "the two steps did not move the model: the test would prove nothing"
+    loss3 = float(tr.step(graph)["loss_per_node"])            # forward of step 3 = the forward after two updates
+    assert abs(loss3 + lp_packed) <= 1e-5 * max(1.0, abs(lp_packed))
+    # ... and the same weights through the raw-W kernels: restore step 2's state first
+    net2 = make_product_grevnet(hp, p)
+    tr2 = GRevNetTrainer(net2, lr=2e-3, use_lr_decay=False)
+    for _ in range(2):
+        tr2.step(graph)
+    net2.fused = False
+    raw = log_prob_terms(net2, graph)
+    assert abs(float(raw["log_prob_xs_per_node"]) - lp_packed) <= 2e-5 * max(1.0, abs(lp_packed))
+    np.testing.assert_allclose(raw["z_graph"].nodes.cpu().numpy(), z_packed, atol=2e-4, rtol=2e-4)

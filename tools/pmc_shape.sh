@@ -11,7 +11,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --workload $wl --no-cpu-baseline --no-secondary --latency-steps 0 --prewarm-ms 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o kt -- $B --steps 20 --warmup 5 > $out/bench_under_rocprof.log 2>&1
-python -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.kernel_source_stamp())" > $out/source_stamp.txt
+python -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.kernel_source_stamp('$wl'), ' '.join(sorted(set(bench.WORKLOAD_SOURCES['$wl']))))" > $out/source_stamp.txt
 python $R/tools/kstats.py $out/trace 6 > $out/kernel_stats.txt
 i=0
 for p in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT" \
@@ -27,7 +27,8 @@ dom = max(rows, key=lambda r: float(r["TotalDurationNs"]))["Name"]
 names = [dom] + [r["Name"] for r in rows if r["Name"] != dom and any(s and s in r["Name"] for s in "$also".split(","))]
 avg = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in rows}
 calls = {r["Name"]: int(r["Calls"]) for r in rows}
-print("# workload $wl  GNF_OPTIONS=$3  kernel sources stamp (bench.kernel_source_stamp):", open("$out/source_stamp.txt").read().strip())
+st = open("$out/source_stamp.txt").read().split()
+print("# workload $wl  GNF_OPTIONS=$3  kernel sources stamp (bench.kernel_source_stamp):", st[0], " sources:", ",".join(st[1:]))
 print("# PMC passes (separate runs, --pmc only with --kernel-trace): mean per dispatch; FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 prints them")
 print("# (HBM-side bytes per launch = FETCH_SIZE x 1024 x 2 [gfx950 correction, MI355X_MICROARCH.md] + WRITE_SIZE x 1024)")
 files = sorted(glob.glob("$out/p*/**/*counter_collection.csv", recursive=True))

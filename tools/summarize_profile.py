@@ -15,18 +15,21 @@ import sys
 
 
 TRAFFIC_NOTE = ("HBM-side bytes per launch of each workload's dominant kernel: rocprofv3 --pmc FETCH_SIZE x 1024 x 2 (gfx950 "
-                "correction, MI355X_MICROARCH.md) + WRITE_SIZE x 1024, separate passes (tools/pmc_shape.sh); "
-                "bench.py quotes an entry only when source_stamp is the build's")
+                "correction, MI355X_MICROARCH.md) + WRITE_SIZE x 1024, separate passes (tools/pmc_shape.sh); every entry names the "
+                "kernel sources it was taken on (sources) and their sha256 (source_stamp = bench.kernel_source_stamp(workload)); "
+                "bench.py quotes an entry only while that stamp is the build's")
 
 
-def merge_traffic(path, stamp, workload, entry):
-    """profiles/pmc_traffic.json = {source_stamp, workloads: {name: entry}}; entries taken on other kernel sources go."""
+def merge_traffic(path, stamp, sources, workload, entry):
+    """profiles/pmc_traffic.json = {note, workloads: {name: entry}}; an entry carries the stamp and the list of the kernel
+    sources of ITS workload (bench.WORKLOAD_SOURCES), so evidence for one workload survives edits to another's kernels."""
     try:
         cur = json.load(open(path))
     except (OSError, ValueError):
         cur = {}
-    if cur.get("source_stamp") != stamp:
-        cur = {"source_stamp": stamp, "note": TRAFFIC_NOTE, "workloads": {}}
+    cur.pop("source_stamp", None)
+    cur["note"] = TRAFFIC_NOTE
+    entry["source_stamp"], entry["sources"] = stamp, sources
     cur.setdefault("workloads", {})[workload] = entry
     json.dump(cur, open(path, "w"), indent=1)
 
@@ -38,7 +41,8 @@ def merge_pmc_shape(src, workload, dst):
     import re
     tag = os.path.basename(os.path.normpath(src))[len("pmc_"):]
     txt = open(os.path.join(src, "pmc_means.txt")).read()
-    stamp = re.search(r"stamp \(bench.kernel_source_stamp\): (\w+)", txt).group(1)
+    m = re.search(r"stamp \(bench.kernel_source_stamp\): (\w+)\s+sources: (\S+)", txt)
+    stamp, sources = m.group(1), m.group(2).split(",")
     sections = []   # (name, average us, {counter: mean})
     for line in txt.split("\n"):
         m = re.match(r"# (?:dominant )?kernel: (.*?)\s+\(kernel-trace pass: (\d+) calls, average ([\d.]+) us\)", line)
@@ -67,7 +71,7 @@ def merge_pmc_shape(src, workload, dst):
         if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
             short = re.sub(r"^(void )?gnf::", "", name).split("(")[0]
             dom["kernels"][short] = entry(name, avg_us, vals)
-    merge_traffic(os.path.join(dst, "pmc_traffic.json"), stamp, workload, dom)
+    merge_traffic(os.path.join(dst, "pmc_traffic.json"), stamp, sources, workload, dom)
     lines = [f"# tools/pmc_shape.sh {tag} {workload}: rocprofv3 --kernel-trace --stats of bench.py --workload {workload} --steps 20 "
              "--warmup 5 --no-cpu-baseline --no-secondary --latency-steps 0 --prewarm-ms 0, then one --pmc pass per counter group",
              open(os.path.join(src, "kernel_stats.txt")).read(), txt,
