@@ -106,9 +106,9 @@ PEAK_HBM_GBS = 8000.0
 _SRC_FUSED = ("gnf_fused.hip", "gnf_fused_dev.h", "gnf_attn_front_dev.h")
 _SRC_BIG = ("gnf_fused_big.hip", "gnf_fused_dev.h", "gnf_layered.hip")
 _SRC_WIDE = ("gnf_linear_big.hip", "gnf_train.hip", "gnf_layered.hip", "gnf_fused_dev.h")
-_SRC_ATTN = ("gnf_attn.hip", "gnf_attn_dev.h", "gnf_bn.hip")
+_SRC_ATTN = ("gnf_attn.hip", "gnf_attn_dev.h", "gnf_attn_core.hip", "gnf_bn.hip")
 _SRC_BWD = ("gnf_train.hip", "gnf_fused_bwd.hip", "gnf_fused_bwd_dev.h", "gnf_optim.hip")
-_SRC_ATTN_BWD = ("gnf_attn_bwd.hip", "gnf_bn_bwd.hip")
+_SRC_ATTN_BWD = ("gnf_attn_bwd.hip", "gnf_attn_core_bwd.hip", "gnf_bn_bwd.hip")
 WORKLOAD_SOURCES = {
     "config2": _SRC_FUSED, "config2_fc": _SRC_FUSED, "config2_attn": _SRC_FUSED, "default_flags": _SRC_FUSED,
     "config4": _SRC_BIG, "config5": _SRC_BIG,

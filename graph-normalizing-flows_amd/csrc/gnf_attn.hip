@@ -618,29 +618,29 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
     a.concat = a0->concat ? 1 : 0;
     a.in0 = in0;
     a.scale = a0->kq_dim_division ? 1.f / sqrtf((float)a0->kq_dim) : 1.f;
-    const size_t proj_lds = ((size_t)H * P + (size_t)kProjRows * H) * sizeof(float);
-    if (proj_lds > 160 * 1024) {
-        set_error("attention projection needs %zu bytes of LDS (H=%d x %zu projected columns): unsupported", proj_lds, H, P);
-        return GNF_EUNSUPPORTED;
-    }
-    GNF_ONCE_PER_DEVICE(
-        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_proj<0, 0, 0>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_proj<8, 10, 10>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
     const bool ref_default = a.nh == 8 && a.kq == 10 && a.v == 10;  // run_grevnet.py:74-76
-    const dim3 pgrid((unsigned)((n + kProjRows - 1) / kProjRows), nets);
-    if (ref_default)
+    const size_t proj_lds = ((size_t)H * P + (size_t)kProjRows * H) * sizeof(float);
+    // The projection.  The drivers' default head geometry at small H keeps its folded vector-unit instance (the weights
+    // fit the LDS many times over: run_grevnet.py:74-76); every other geometry - first of all the data driver's one head of
+    // 64 / 64 at H = 100, where that kernel took 38.6 us per half-step - multiplies on the matrix cores.
+    if (ref_default && proj_lds <= 64 * 1024) {
+        GNF_ONCE_PER_DEVICE(
+            GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_proj<8, 10, 10>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+        const dim3 pgrid((unsigned)((n + kProjRows - 1) / kProjRows), nets);
         hipLaunchKernelGGL((k_attn_proj<8, 10, 10>), pgrid, dim3(256), proj_lds, st, a);
-    else
-        hipLaunchKernelGGL((k_attn_proj<0, 0, 0>), pgrid, dim3(256), proj_lds, st, a);
-    GNF_LAUNCH_CHECK("k_attn_proj");
-    const bool old_attn = opt(OPT_ATTN_KERNEL) == 2;  // shape forcing for the parity tests (gnf_set_option): 1 rows kernel, 2 edge-tiled kernel
-    const bool rows_always = opt(OPT_ATTN_KERNEL) == 1;
+        GNF_LAUNCH_CHECK("k_attn_proj");
+    } else {
+        const int rc = launch_attn_proj_mfma(at, nets, n, x, ldx, H, a.qkv, st);
+        if (rc) return rc;
+    }
+    const bool old_attn = opt(OPT_ATTN_KERNEL) == 2;  // shape forcing for the parity tests (gnf_set_option): 1 rows kernel, 2 edge-tiled kernel,
+    const bool rows_always = opt(OPT_ATTN_KERNEL) == 1;   // 3 the matrix-core attention core
+    const bool core_always = opt(OPT_ATTN_KERNEL) == 3;
     // sparse batches (mean in-degree under ~24: the config-2 batch has 12) are 8 % faster through the edge-tiled kernel;
     // the rows kernel wins by 4.5 x on the complete graphs of the drivers' default dataset (degree 100)
     const bool sparse = !rows_always && n_edges > 0 && n_edges < 24 * n;
-    if (!old_attn && !sparse && a.nh <= kRowsMaxHeads && a.kq <= 32 && a.v <= 32) {
+    if (!old_attn && !core_always && !sparse && a.nh <= kRowsMaxHeads && a.kq <= 32 && a.v <= 32) {
         const int NV = a.nh * a.v, nq = a.nh * a.kq;
         const size_t fixed = (size_t)(kRowsTile + 1 + 3 + kRowsColCap) * sizeof(int) +
                              ((size_t)NV * a.C + (size_t)kRowsTile * (NV + 1)) * sizeof(float);
@@ -675,6 +675,27 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
     }
     int RB = 512 / (a.nh * kEL);  // (row, head) groups of kEL lanes
     if (RB < 1) RB = 1;
+    {
+        // Heads wider than the thread-per-(row, head) kernels' registers (kq or v above 32: the DATA driver's default is one
+        // head of 64 / 64, train_grevnet_with_data.py:40-46) - or a geometry whose edge tile does not fit the LDS - take the
+        // matrix-core attention core (gnf_attn_core.hip), then new = agg Wo on the generic GEMM tile into h0's columns.
+        const size_t tile_lds = ((size_t)RB * a.nh * a.v + (size_t)kEdgeCap * (a.nh * a.kq + a.v) + (size_t)RB * a.nh * a.kq +
+                                 (size_t)kEdgeCap * a.nh + 2 * (size_t)RB * a.nh + (size_t)a.nh * a.v * a.C + (size_t)RB * H) * sizeof(float) +
+                                (size_t)(RB + 1 + kEdgeCap) * sizeof(int);
+        if (core_always || (!old_attn && (a.kq > 32 || a.v > 32)) || tile_lds > 160 * 1024) {
+            const int NV = a.nh * a.v;
+            float* agg_def = scratch + 2 * (size_t)n * (P + (size_t)in0);   // attn_scratch_floats' layout
+            float* aggs[2] = {a.agg_out[0] ? a.agg_out[0] : agg_def, a.agg_out[1] ? a.agg_out[1] : agg_def + (size_t)(nets > 1 ? 1 : 0) * n * NV};
+            const float* qk[2] = {a.qkv[0], a.qkv[1]};
+            float* mzs[2] = {a.mz_out[0], a.mz_out[1]};
+            int rc = launch_attn_core(a0, nets, rowptr, col, n, x, ldx, H, in0, qk, aggs, mzs, a.h0, st);
+            if (rc) return rc;
+            const float* as_[2] = {aggs[0], aggs[1]};
+            const float* nob[2] = {nullptr, nullptr};
+            float* ys[2] = {a.h0[0] + (a.concat ? H : 0), a.h0[1] + (a.concat ? H : 0)};
+            return launch_linear_splitk(as_, (int64_t)NV, a.Wo, nob, ys, (int64_t)in0, nets, n, NV, a.C, GNF_ACT_RELU, 0.f, 0, nullptr, 0, st);
+        }
+    }
     int threads = RB * a.nh * kEL;  // nh <= 64 -> at most 512 when RB == 1
     threads = (threads + 63) / 64 * 64;
     if (threads < kEdgeCap) threads = kEdgeCap;  // the col tile is staged one edge per thread

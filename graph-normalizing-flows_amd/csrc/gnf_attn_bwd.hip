@@ -1237,6 +1237,11 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
         }
     }
     {
+    // wide heads (the data driver's one head of 64 / 64, train_grevnet_with_data.py:40-46): both passes on the matrix cores
+    // (gnf_attn_core_bwd.hip), from the statistics and attended values the forward pass left
+    const int rc_core = launch_attn_core_backward(a0, n, rowptr, col, rowptr_t, col_t, qkv, dagg, agg, stats, dqkv, st);
+    if (rc_core == GNF_OK) goto dx_pass;
+    if (rc_core != 1) return rc_core;
     const dim3 grid((unsigned)((n + kRB - 1) / kRB), 2);
     const int FU = wmax <= 64 ? 1 : (wmax <= 128 ? 2 : 4);
     const size_t lds = kWinBudget;

@@ -205,11 +205,17 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
                          // wct != NULL: [Wq | Wk | Wv]^T of the two blocks as packed MFMA fragments (attn_wct_floats each,
                          // k_pack_wot): dL/dx_cond += dqkv Wcat^T runs on the matrix cores (k_attn_bwd_dx_mfma)
                          const float* const* wct = nullptr);
+// both passes of the attention backward on the matrix cores for heads wider than the per-(row, head) thread kernels hold
+// (gnf_attn_core_bwd.hip); needs the forward's agg / stats; 1 = not its geometry
+int launch_attn_core_backward(const GnfAttn* a0, int64_t n, const int32_t* rowptr, const int32_t* col, const int32_t* rowptr_t,
+                              const int32_t* col_t, const float* const* qkv, const float* const* dagg, const float* const* agg,
+                              float* const* stats, float* const* dqkv, hipStream_t st);
 // [Wq | Wk | Wv]^T ([P, H], P = 2 heads kq + v) as fragments: Bp[kg][nt][lane][q] = Wcat[16 nt + (lane & 15)][16 kg + 4 (lane >> 4) + q]
 size_t attn_wct_floats(const GnfAttn* at, int32_t H);
 
 
 // y = act(x W + b) through the generic GEMM (gnf_train.hip; thin launches split over the reduction); GNF_OK or a GNF_E* code
+// (b[q] == NULL: no bias)
 int launch_linear_splitk(const float* const* x, int64_t ldx, const float* const* W, const float* const* b, float* const* y,
                          int64_t ldy, int nj, int64_t n, int32_t I, int32_t O, int act, float alpha, int apply_act,
                          float* const* sk, size_t sk_floats, hipStream_t st);
@@ -250,8 +256,19 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
                       int32_t H, const GnfAttn* const* at, int nets, int32_t in0, float* scratch,
                       float* const* h0_out, hipStream_t st, int64_t n_edges = 0, bool need_qkv = true,
                       const float* const* packed = nullptr, float* const* agg_out = nullptr, float* const* mz_out = nullptr);
+// Scratch contract: q | k | v of net q at scratch + q n P.  With agg_out == NULL the kernels that need the attended values
+// in memory (gnf_attn_core.hip) put them at scratch + 2 n (P + in0) - attn_scratch_floats' layout, which every caller that
+// passes NULL provides (plan_workspace); a caller that passes only the q | k | v block (the backward recompute) passes agg_out.
 // agg_out / mz_out (training): per net [N, heads*v] attended values and [N, 3*heads] softmax statistics (running max at [h],
 // denominator at [heads + h]; the third block is scratch of the backward pass), kept for launch_attn_backward
+// matrix-core attention core for wide heads (gnf_attn_core.hip): qkv[q] -> agg[q] ([N, heads v], normalised), mz[q]
+// (nullable), and h0[q][:, 0:H) = x for concat blocks; the output projection is the caller's next launch
+int launch_attn_core(const GnfAttn* a0, int nets, const int32_t* rowptr, const int32_t* col, int64_t n, const float* x, int64_t ldx,
+                     int32_t H, int32_t in0, const float* const* qkv, float* const* agg, float* const* mz, float* const* h0,
+                     hipStream_t st);
+// q | k | v = x [Wq | Wk | Wv] of 1 or 2 nets on the matrix cores, any widths (gnf_attn_core.hip); qkv[q]: [N, P]
+int launch_attn_proj_mfma(const GnfAttn* const* at, int nets, int64_t n, const float* x, int64_t ldx, int32_t H, float* const* qkv,
+                          hipStream_t st);
 // one-launch front-end for sparse batches (gnf_attn_front.hip), weights pre-packed into fragment order once per flow call
 bool attn_front_fused_ok(const GnfAttn* at, int32_t H);
 size_t attn_pack_floats(const GnfAttn* at, int32_t H);

@@ -16,8 +16,8 @@ namespace gnf {
 enum OptionId {
     OPT_FORCE_SHAPE = 0,     // fused forward workgroup shape <MT><NETS>, e.g. 21; 40 / 30 / 20 / 10: the large-batch kernel with that many
                              // row tiles per workgroup at most; 0 = by batch size
-    OPT_ATTN_KERNEL,         // attention forward: 1 always the rows kernel, 2 always the edge-tiled kernel (either keeps the front-end
-                             // out of the fused kernel's prologue); 0 = by batch
+    OPT_ATTN_KERNEL,         // attention forward: 1 always the rows kernel, 2 always the edge-tiled kernel, 3 always the matrix-core
+                             // attention core (each keeps the front-end out of the fused kernel's prologue); 0 = by batch / geometry
     OPT_ATTN_BWD_ROWS,       // attention rows kernels: 64 / 32 (backward also 16 and 3264) rows per workgroup; 0 = by batch size / mean degree
     OPT_BWD_GENERIC,         // backward pass through the generic GEMM path even where the fused kernel fits
     OPT_DW_GROUPED,          // weight gradients: always the grouped kernel (on the auxiliary stream, not inside the backward launch)

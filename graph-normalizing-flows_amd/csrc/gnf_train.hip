@@ -132,7 +132,7 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
             float bv = 0.f;
             if (EPI == EPI_BIAS_ACT) {
                 const int gc = n0 + wn + 16 * b + lrow;
-                bv = gc < sh.N ? job.aux[gc] : 0.f;
+                bv = (job.aux && gc < sh.N) ? job.aux[gc] : 0.f;  // (aux == NULL: no bias - the attention projections)
             }
             acc[m][b] = f32x4_t{bv, bv, bv, bv};
         }
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(GemmJob j0, GemmJob j1,
     float v = 0.f;
     for (int c = 0; c < chunks; ++c) v += slab[(int64_t)c * mn + e];
     if (EPI == EPI_BIAS_ACT) {
-        v += job.aux[n];
+        if (job.aux) v += job.aux[n];
         if (sh.apply_act) v = (sh.act == GNF_ACT_RELU) ? fmaxf(v, 0.f) : fmaxf(v, sh.alpha * v);
     } else if (EPI == EPI_MASK) {
         if (job.aux) {

@@ -6,8 +6,8 @@ widths are not), through the fused-where-possible and the layered path; a golden
 kq / v value on either side of every boundary the attention dispatch has (10 | 16 | 32 | 33 | 64 | 65, heads 1 / 2 / 9).
 
 Tolerances: the per-node log-prob bar (1e-4) is absolute; z and g(z) 3e-4; a gradient tensor is compared with
-atol = 5e-4 * max|g| of that tensor (+ 1e-5 + 1e-6 of the flow's gradient scale) - the literal-width case states 2e-3 (its
-GEMMs reduce over 2048 terms and thousands of nodes in fp32 against float64)."""
+atol = 5e-4 * max|g| of that tensor (+ 1e-5 + 1e-6 of the flow's gradient scale); the literal-width case derives its bound
+from the same autograd run in float32 on the CPU (relu kinks: see the test)."""
 import numpy as np
 import pytest
 import torch
@@ -60,6 +60,19 @@ def _check_all_grads(got, ref, scale):
         worst = max(worst, err / max(float(np.abs(b).max()), 1e-30))
         assert err <= tol, f"{name}: max err {err:.3e} > {tol:.3e} (max|g| {np.abs(b).max():.3e})"
     return worst
+
+
+def _grad_errors(got, ref):
+    """Per tensor: max |a - b| / max |b| and ||a - b||_2 / ||b||_2 (tensors that are zero by cancellation judged against the
+    flow's overall gradient scale)."""
+    gmax = max(float(np.abs(b).max()) for _, b in _flat_all(ref))
+    out = []
+    for (name, a), (_, b) in zip(_flat_all(got), _flat_all(ref)):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        scale = max(float(np.abs(b).max()), 1e-3 * gmax)
+        l2 = max(float(np.linalg.norm(b)), 1e-3 * gmax * np.sqrt(b.size))
+        out.append((name, float(np.abs(a - b).max()) / scale, float(np.linalg.norm(a - b)) / l2))
+    return out
 
 
 def _hp(d, latent, k, t, attn, ws=False):
@@ -134,7 +147,19 @@ def test_data_driver_defaults_at_the_literal_widths(community_medium, fused):
     torch.cuda.synchronize()
     assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
     np.testing.assert_allclose(out["reconstruction"].cpu().numpy(), x, atol=3e-4, rtol=3e-4)
-    _check_all_grads(tr.named_gradients(), ref["grads"], 2e-3)
+    # 3.5 M relu pre-activations per net: some lie within fp32 rounding of the kink and take the other side than in float64,
+    # which moves a whole term of a gradient column (tests/test_fullsize_gpu.py states the same for the run_grevnet.py
+    # defaults).  The bound is derived: the SAME autograd in float32 on the CPU shows what single precision costs on these
+    # inputs; the device has to stay within SLACK of that run's worst tensor in the maximum norm and in the 2-norm, and
+    # inside 2e-3 in the 2-norm whatever the CPU run does.
+    r32 = O.loss_and_grads(s, r, n, x, p, t, activation="relu", dtype=torch.float32)
+    e32 = _grad_errors(r32["grads"], ref["grads"])
+    errs = _grad_errors(tr.named_gradients(), ref["grads"])
+    worst_max, worst_l2 = max(errs, key=lambda e: e[1]), max(errs, key=lambda e: e[2])
+    print(f"literal widths: worst tensor {worst_max[0]} {worst_max[1]:.2e} (max norm), {worst_l2[0]} {worst_l2[2]:.2e} (2-norm); "
+          f"float32 CPU autograd {max(e[1] for e in e32):.2e} / {max(e[2] for e in e32):.2e}")
+    assert worst_max[1] <= 6.0 * max(e[1] for e in e32) + 1e-4, (worst_max, max(e[1] for e in e32))
+    assert worst_l2[2] <= min(6.0 * max(e[2] for e in e32) + 1e-5, 2e-3), (worst_l2, max(e[2] for e in e32))
 
 
 # one kq / v value on either side of every boundary of the attention dispatch: the per-(row, head) thread kernels' register
