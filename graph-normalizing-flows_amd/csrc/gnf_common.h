@@ -102,6 +102,9 @@ MlpStashLayout mlp_stash_layout(const GnfMlp* net, int64_t n, int32_t H);
 bool fused_stash_shape(const GnfMlp* s, const GnfMlp* t, int64_t n);   // forward side (gnf_fused.hip)
 // both sides: message-passing nets on the fused forward kernel's (1,2) shape AND the merged backward launch
 bool mlp_stash_supported(const GnfFlow* flow, int64_t n, int32_t H);   // gnf_train.hip
+// ... its second mode: nets on the layered forward / generic backward path (too wide for the fused kernels): the forward's
+// layer outputs and s, t go straight into the slot, the backward skips its recompute of both MLPs
+bool layered_stash_mode(const GnfFlow* flow, int64_t n, int32_t H);
 bool fused_supports_oop(const HalfStep& hs);
 // floats of one half-step's slot in GnfFlow.attn_stash ( = attn_scratch_floats: [2][n][P] q|k|v, [2][n][in0] h0,
 // [2][n][heads*v] attended values, [2][n][3*heads] softmax statistics)
@@ -228,6 +231,10 @@ inline bool linear_big_bwd_layer(int I, int O) { return O >= 512 && I >= 256; }
 // wide y = act(x W_j + b_j) of a pair of nets from their packed weights (gnf_linear_big.hip); 1 = not its case
 int launch_linear_big(const GnfMlp* const* nets, int nj, int j, const float* const* x, int64_t ldx, float* const* y, int64_t ldy,
                       int64_t n, int act, float alpha, int apply_act, hipStream_t st);
+
+// dX[q] = (dY[q] W_j^T) * act'(h[q]) of a pair of nets from their transposed packed fragments (h == NULL: no mask); 1 = not its case
+int launch_linear_big_dx(const GnfMlp* const* nets, int nj, int j, const float* const* dy, int64_t lddy, float* const* dx, int64_t lddx,
+                         const float* const* h, int64_t ldh, int64_t n, int act, float alpha, hipStream_t st);
 
 // batch-norm bijector (gnf_bn.hip)
 int validate_bn(const GnfBatchNorm* bn, int direction, const char* what, int q);

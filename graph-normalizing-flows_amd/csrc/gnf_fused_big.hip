@@ -522,7 +522,9 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
     // ---- C: coupling update from the s | t rows in LDS, rows of x coalesced (16 bytes per lane where the widths allow,
     // four requests per thread before the first use); this lane's fp64 shares of sum(s) and sum(x_new^2) ----
     __syncthreads();
-    bool lost = false;  // (the partner's s rows never came: the partial sums turn into NaN instead of the launch hanging)
+    // the partner's s rows never came: the tile's rows of x_upd AND the partial sums turn into NaN instead of the launch
+    // hanging - loud in both directions (GRevNet.g returns nodes only, gnn.py:343-373: a sampling pass has no scalar to poison)
+    bool lost = false;
     if (kind == 2) {
         // the split tile's s rows from the workgroup that ran its s-net (dispatched before this one, and long done with the
         // s-net by the time this one is through both of its nets): wait for its flag, copy the rows beside t
@@ -539,7 +541,8 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
 #pragma unroll 1
         for (int i = tid; i < 16 * hp; i += kBigThreads) {
             const int r = i / hp, c = i - r * hp;
-            act[(16 * mt + r) * kBigLS + c] = __hip_atomic_load(sx + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float sv = __hip_atomic_load(sx + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            act[(16 * mt + r) * kBigLS + c] = lost ? __builtin_nanf("") : sv;   // (x exp(NaN) + t = NaN: the rows are written as NaN)
         }
         __syncthreads();
     }

@@ -451,9 +451,11 @@ int launch_finalize(const double* a, int64_t na, const double* b, int64_t nb, do
 // ------------------------------------------------------------------------------------------------
 // nets[0..nj): MLPs with identical layer shapes (nj = 2: the s- and t-net of a half-step), each with its
 // own input h0[q], ping-pong buffers bufA[q] / bufB[q] (row stride ldbuf) and output outp[q].
+// keep (nullable): keep[q * GNF_MAX_LAYERS + j] = where layer j's output of net q goes instead of the ping-pong buffers
+// (j < K - 1: the training forward's stash of the hidden activations, row stride ldbuf)
 static int run_mlps(const GnfMlp* const* nets, int nj, const float* const* h0, int64_t ld0, float* const* bufA,
                     float* const* bufB, int64_t ldbuf, float* const* outp, int64_t ldout, int64_t n,
-                    const GnfGnnSpec& g, hipStream_t st) {
+                    const GnfGnnSpec& g, hipStream_t st, float* const* keep = nullptr) {
     const GnfMlp* m = nets[0];
     const float* in[2] = {h0[0], h0[nj - 1]};
     int64_t ldin = ld0;
@@ -462,7 +464,7 @@ static int run_mlps(const GnfMlp* const* nets, int nj, const float* const* h0, i
         float* dst[2];
         for (int q = 0; q < 2; ++q) {
             const int qq = q < nj ? q : nj - 1;
-            dst[q] = last ? outp[qq] : ((j & 1) ? bufB[qq] : bufA[qq]);
+            dst[q] = last ? outp[qq] : (keep ? keep[qq * GNF_MAX_LAYERS + j] : ((j & 1) ? bufB[qq] : bufA[qq]));
         }
         const int64_t lddst = last ? ldout : ldbuf;
         const int I = m->dims[j], O = m->dims[j + 1];
@@ -636,6 +638,19 @@ int launch_half_layered(const HalfStep& hs, float* scratch, hipStream_t st) {
     float* bufB[2] = {bufA[0] + n * lmax, bufA[1] + n * lmax};
     float* sbuf = bufA[0] + n * lmax * kLayeredActBufs;
     float* tbuf = sbuf + n * H;
+    // training forward with the MLP-row stash in its layered mode (layered_stash_mode, gnf_train.hip): the layer-0 rows of a
+    // message-passing net, every hidden activation and s, t are written straight into the half-step's slot
+    float* keep[2 * GNF_MAX_LAYERS];
+    const bool stash = hs.mlp_stash != nullptr && hs.direction == GNF_FORWARD;
+    if (stash) {
+        const MlpStashLayout L = mlp_stash_layout(hs.s_net, n, H);
+        if (!hs.s_net->attn) h0 = hs.mlp_stash + L.h0;
+        for (int q = 0; q < 2; ++q)
+            for (int j = 0; j + 1 < hs.s_net->num_layers; ++j)
+                keep[q * GNF_MAX_LAYERS + j] = hs.mlp_stash + L.act + ((size_t)q * (hs.s_net->num_layers - 1) + j) * L.act_each;
+        sbuf = hs.mlp_stash + L.st;
+        tbuf = sbuf + L.st_each;
+    }
     const float* h0s = h0;
     const float* h0t = h0;
     int rc;
@@ -653,7 +668,7 @@ int launch_half_layered(const HalfStep& hs, float* scratch, hipStream_t st) {
         const GnfMlp* nets[2] = {hs.s_net, hs.t_net};
         const float* h0p[2] = {h0s, h0t};
         float* outs[2] = {sbuf, tbuf};
-        rc = run_mlps(nets, 2, h0p, in0, bufA, bufB, lmax, outs, H, n, hs.gnn, st);
+        rc = run_mlps(nets, 2, h0p, in0, bufA, bufB, lmax, outs, H, n, hs.gnn, st, stash ? keep : nullptr);
     }
     if (rc) return rc;
     const bool res = hs.s_net->attn && hs.s_net->attn->residual;

@@ -29,8 +29,10 @@ static constexpr int kLbCols = 256;    // output columns per workgroup
 struct LinBigArgs {
     const float* x[2];
     float* y[2];
-    const float* wp[2];    // packed weights of the layer
-    const float* bias[2];  // its padded bias row
+    const float* wp[2];    // packed weights of the layer (the transposed copy for the backward product)
+    const float* bias[2];  // its padded bias row, or NULL (backward: no bias)
+    const float* aux[2];   // NULL, or [n, O] rows (leading dimension ldaux) whose sign picks act' for every output element:
+    int64_t ldaux;         //   y = (x W^T) * act'(aux) - the backward pass's dP_{j-1} = (dP_j W_j^T) * act'(h_j)
     int64_t ldx, ldy;
     int32_t n, I, O;
     int32_t ipg, ont;      // padded input width / 16, padded output width / 16
@@ -54,6 +56,7 @@ __device__ __forceinline__ void lin_big_body(const LinBigArgs& a, float* __restr
     for (int b = 0; b < 4; ++b) nv += (ct0 + 4 * b < a.ont && 4 * b + wave < 16) ? 1 : 0;
     const float* __restrict__ x = a.x[net];
     const float* __restrict__ bias = a.bias[net];
+    const float* __restrict__ aux = a.aux[net];
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp[net]), 0, (int)((unsigned)a.ipg * (unsigned)a.ont * 1024u), 0x00020000);
     const int voff = lane * 16;
@@ -66,7 +69,8 @@ __device__ __forceinline__ void lin_big_body(const LinBigArgs& a, float* __restr
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         // (a wave without a live column tile - padded O not a multiple of 256 - reads tile 0's bias, not past the row)
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 16 * (nv > 0 ? ct0 + (b < nv ? 4 * b : 0) : 0) + 4 * lgrp);
+        const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + 16 * (nv > 0 ? ct0 + (b < nv ? 4 * b : 0) : 0) + 4 * lgrp)
+                              : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < MW; ++m) acc[m][b] = bv;
     }
@@ -169,7 +173,12 @@ __device__ __forceinline__ void lin_big_body(const LinBigArgs& a, float* __restr
             const int r = row0 + 16 * m + lrow;
             if (r >= a.n || c >= a.O) continue;
             f32x4 v = acc[m][b];
-            if (a.apply_act) {
+            if (aux) {  // act'(pre) read off the stored activation: h > 0 <=> pre > 0 (the generic tile's EPI_MASK)
+                const float* pa = aux + (int64_t)r * a.ldaux + c;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (c + q < a.O) v[q] = pa[q] > 0.f ? v[q] : v[q] * slope;
+            } else if (a.apply_act) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], slope * v[q]);
             }
@@ -208,15 +217,19 @@ __global__ __launch_bounds__(kLbThreads) __attribute__((amdgpu_waves_per_eu(2, 2
 
 static inline int lb_pad16(int v) { return (v + 15) & ~15; }
 
-// y[q] = act(x[q] W_j + b_j) of nets[q] (nj = 1 or 2 nets with identical shapes), layer j, from the nets' packed weights.
-// 1 = not this kernel's case (no packed copy, a narrow output, a launch that would not fill the chip): the caller runs the
-// generic tile.
-int launch_linear_big(const GnfMlp* const* nets, int nj, int j, const float* const* x, int64_t ldx, float* const* y, int64_t ldy,
-                      int64_t n, int act, float alpha, int apply_act, hipStream_t st) {
+// y[q] = act(x[q] W_j + b_j) of nets[q] (nj = 1 or 2 nets with identical shapes), layer j, from the nets' packed weights;
+// transposed = true: y[q] = (x[q] W_j^T) * act'(aux[q]) from the transposed packed copy (the backward pass's dX product; aux ==
+// NULL: no mask).  1 = not this kernel's case (no packed copy, a narrow output, a launch that would not fill the chip): the
+// caller runs the generic tile.
+static int launch_linear_big_impl(const GnfMlp* const* nets, int nj, int j, bool transposed, const float* const* x, int64_t ldx,
+                                  float* const* y, int64_t ldy, const float* const* aux, int64_t ldaux, int64_t n, int act, float alpha,
+                                  int apply_act, hipStream_t st) {
     const GnfMlp* m = nets[0];
-    const int I = m->dims[j], O = m->dims[j + 1];
+    // I / O: reduction length and output width of THIS product
+    const int I = transposed ? m->dims[j + 1] : m->dims[j], O = transposed ? m->dims[j] : m->dims[j + 1];
     // (a short reduction - the 100 -> 2048 first layer - is all prologue and epilogue here: 45 us against the generic tile's 24)
-    if (nj != 2 || !nets[0]->packed || !nets[1]->packed || !linear_big_fwd_layer(I, O) || n > (int64_t)INT32_MAX - 64) return 1;
+    const bool mine = transposed ? linear_big_bwd_layer(m->dims[j], m->dims[j + 1]) : linear_big_fwd_layer(m->dims[j], m->dims[j + 1]);
+    if (nj != 2 || !nets[0]->packed || !nets[1]->packed || !mine || n > (int64_t)INT32_MAX - 64) return 1;
     const int ipg = lb_pad16(I) / 16, ont = lb_pad16(O) / 16;
     const int col_blocks = (ont * 16 + kLbCols - 1) / kLbCols;
     // Row tiles per workgroup.  With whole 64-row workgroups the data driver's batch is 43 x 16 = 688 workgroups on 512
@@ -232,19 +245,23 @@ int launch_linear_big(const GnfMlp* const* nets, int nj, int j, const float* con
     if (wpp > n_rt) wpp = n_rt;
     const int wg_base = (int)(n_rt / wpp), wg_rem = (int)(n_rt % wpp);
     if (wg_base + (wg_rem ? 1 : 0) > 4 || wg_base < 1) return 1;
-    int64_t woff = 0, wtot = 0, boff = 0;
+    int64_t woff = 0, wtot = 0, boff = 0, btot = 0;
     for (int i = 0; i < m->num_layers; ++i) {
         const int64_t w = (int64_t)lb_pad16(m->dims[i]) * lb_pad16(m->dims[i + 1]);
         if (i < j) woff += w, boff += lb_pad16(m->dims[i + 1]);
         wtot += w;
+        btot += lb_pad16(m->dims[i + 1]);
     }
     if ((int64_t)ipg * ont * 1024 >= ((int64_t)1 << 31)) return 1;  // (32-bit buffer offsets)
     LinBigArgs a;
     for (int q = 0; q < 2; ++q) {
         a.x[q] = x[q], a.y[q] = y[q];
-        a.wp[q] = nets[q]->packed + woff;
-        a.bias[q] = nets[q]->packed + wtot + boff;
+        // packed layout (gnf_fused.hip): [Wp_0 .. Wp_{K-1} | bias rows | WpT_0 .. WpT_{K-1}], WpT_j = the fragments of W_j^T
+        a.wp[q] = nets[q]->packed + (transposed ? wtot + btot : 0) + woff;
+        a.bias[q] = transposed ? nullptr : nets[q]->packed + wtot + boff;
+        a.aux[q] = aux ? aux[q] : nullptr;
     }
+    a.ldaux = ldaux;
     a.ldx = ldx, a.ldy = ldy;
     a.n = (int32_t)n, a.I = I, a.O = O, a.ipg = ipg, a.ont = ont, a.col_blocks = col_blocks;
     a.act = act, a.apply_act = apply_act, a.alpha = alpha;
@@ -252,6 +269,17 @@ int launch_linear_big(const GnfMlp* const* nets, int nj, int j, const float* con
     hipLaunchKernelGGL(k_linear_big, dim3((unsigned)(wpp * panels)), dim3(kLbThreads), 0, st, a);
     GNF_LAUNCH_CHECK("k_linear_big");
     return GNF_OK;
+}
+
+int launch_linear_big(const GnfMlp* const* nets, int nj, int j, const float* const* x, int64_t ldx, float* const* y, int64_t ldy,
+                      int64_t n, int act, float alpha, int apply_act, hipStream_t st) {
+    return launch_linear_big_impl(nets, nj, j, false, x, ldx, y, ldy, nullptr, 0, n, act, alpha, apply_act, st);
+}
+
+// dX[q] = (dY[q] W_j^T) * act'(h[q]) (h == NULL: no mask) from the transposed fragments every packed MLP carries
+int launch_linear_big_dx(const GnfMlp* const* nets, int nj, int j, const float* const* dy, int64_t lddy, float* const* dx, int64_t lddx,
+                         const float* const* h, int64_t ldh, int64_t n, int act, float alpha, hipStream_t st) {
+    return launch_linear_big_impl(nets, nj, j, true, dy, lddy, dx, lddx, h, ldh, n, act, alpha, 0, st);
 }
 
 }  // namespace gnf

@@ -1220,6 +1220,15 @@ static DwPolicy dw_policy(const GnfMlp* net, int64_t bwd_tiles, size_t bwd_lds) 
         // the alternative (grouped kernel sharing every CU) stretches the backward kernel by ~1.3 x
         pol.budget_us = 1.4 * (2.0 * 2.0 * 16.0 * macs * 2.0) / (614e9 * 0.6) * 1e6 + 10.0;
     }
+    if (bwd_tiles == 0) {
+        // generic backward (nets too wide for the fused kernels: the data driver's 2048 x 3 MLPs): a hidden layer's dW is
+        // hundreds of full 128 x 128 tiles over the whole node axis - the wide kernel with ONE chunk per tile (the slab IS
+        // the gradient: no reduce pass) where three workgroups per CU hold them all, against the grouped kernel's 128 x 64
+        // tiles + slabs + reduce: wide_fc_train 34.2 -> 29.8 ms per step (measured with dw_wide_units = 640 .. 4096)
+        int lmax = 1;
+        for (int j = 1; j < net->num_layers; ++j) lmax = lmax > net->dims[j] ? lmax : net->dims[j];
+        if (lmax >= 512) pol.max_units = 3 * big_cu_count(), pol.budget_us = 1e30;
+    }
     if (env_u > 0) pol.max_units = (int)env_u, pol.budget_us = 1e30;
     return pol;
 }
@@ -1248,6 +1257,7 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
     memset(&gr, 0, sizeof(gr));
     L->nj = nj;
     L->lds = pol.lds;
+    L->direct = false;
     ws += (size_t)slab_set * p.slab_stride;
     int maxM = 1, maxN = 1;
     int64_t maxred = 1;
@@ -1368,6 +1378,9 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
             }
         }
         if (grid == 0 || est_us > pol.budget_us) wide = false;
+        // the costliest tiles in ONE chunk each and nothing to accumulate into: the cheap jobs take one chunk too, so that
+        // every slab is its gradient and the reduce launch goes (a thin tile over the whole node axis is no longer than a full one)
+        if (wide && sk_q == 0 && c_heavy == 1 && !accumulate) c_light = 1;
         int sk_jobs = 0;
         for (int q = 0; q < nj && wide; ++q) {
             const int e = order[q];
@@ -1398,6 +1411,13 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
         }
         if (wide) {
             for (int e = 0; e < nj; ++e) gr.chunks[e] = cj[e];
+            // every job in ONE chunk and nothing to add to: the slabs are the gradients themselves, no reduce launch
+            bool one = !accumulate && sk_q == 0;
+            for (int e = 0; e < nj; ++e) one = one && cj[e] == 1;
+            if (one) {
+                for (int q = 0; q < nj; ++q) wg.job[q].C = jobs[order[q]].gw, wg.job[q].aux_out = jobs[order[q]].gb;
+                L->direct = true;
+            }
             wg.unit_base[nj] = units;
             wg.K = p.n, wg.njobs = nj;
             if (sk_q > 0) {
@@ -1409,10 +1429,11 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
             }
         }
     }
+    const bool wide_direct = wide && L->direct;
     L->wide = wide;
     L->units = units;
     L->maxred = maxred;
-    L->direct = false;
+    L->direct = wide_direct;
     L->buf = false;
     if (wide) {
         // buffer path: byte offsets inside a chunk (+ the two tiles fetched past its end) stay below 2^31.  Rows need
@@ -1585,8 +1606,29 @@ static bool merged_walk_ok(const GnfFlow* flow, int64_t n, int64_t* tiles_out, s
     return tiles == (n + 15) / 16 && tiles <= kMergedMaxTiles;
 }
 
+// The stash's second mode: nets whose forward runs the LAYERED path (too wide for the fused kernels - the data driver's
+// 2048 x 3 MLPs - or unpacked) and whose backward is the generic GEMM path.  There the backward walk recomputed every
+// hidden layer of both nets per half-step (a quarter of a training step's flops at that width); with the stash the forward's
+// layer outputs and s, t go straight into the half-step's slot (same layout, no act' ballots used) and the recompute loop of
+// mlp_backward_generic is skipped.  Memory for time, like the fused mode: 2 T slots of (in0 + 2 (K - 1) lmax + 2 H) n floats
+// (1.8 GB for the data driver's defaults on a 2 718-node batch), bounded at 48 GB.
+bool layered_stash_mode(const GnfFlow* flow, int64_t n, int32_t H) {
+    if (n <= 0 || !flow->s_nets || !flow->t_nets || flow->num_timesteps < 1) return false;
+    const int n_nets = flow->weight_sharing ? 2 : 2 * flow->num_timesteps;
+    for (int q = 0; q < n_nets; ++q) {
+        const GnfMlp *s = &flow->s_nets[q], *t = &flow->t_nets[q];
+        if (s->num_layers != t->num_layers || s->num_layers < 2) return false;
+        for (int j = 0; j <= s->num_layers; ++j)
+            if (s->dims[j] != t->dims[j]) return false;
+        const bool fwd_fused = s->packed && t->packed && fused_fits_lds(s);   // (fused_supported's rule)
+        if (fwd_fused || fused_bwd_supported(s, t) || (s->attn && s->attn->layer_norm)) return false;
+    }
+    const size_t bytes = (size_t)2 * flow->num_timesteps * mlp_stash_layout(&flow->s_nets[0], n, H).slot * sizeof(float);
+    return bytes <= ((size_t)48 << 30);
+}
+
 bool mlp_stash_supported(const GnfFlow* flow, int64_t n, int32_t H) {
-    (void)H;
+    if (layered_stash_mode(flow, n, H)) return true;
     if (opt(OPT_BWD_GENERIC) || n <= 0 || !flow->s_nets || !flow->t_nets) return false;
     const int n_nets = flow->weight_sharing ? 2 : 2 * flow->num_timesteps;
     for (int q = 0; q < n_nets; ++q)
@@ -1727,14 +1769,15 @@ __global__ __launch_bounds__(256) void k_layer_norm_grad(const LnGradArgs a) {
     *dst = a.accumulate ? *dst + s : s;
 }
 
+// have_rows: o.hin / o.stb already hold every layer input and s, t (the forward's stash, layered_stash_mode): no recompute
 static int mlp_backward_generic(const BwdPlan& p, const BwdOperands& o, const GnfGnnSpec& gnn, const GnfMlp* const* nets,
                                 const GnfMlp* const* grads, bool acc, const float* x_cond, float* y_upd, int64_t ld,
-                                float* g_upd, int64_t ldg, float* ws, hipStream_t st) {
+                                float* g_upd, int64_t ldg, float* ws, hipStream_t st, bool have_rows = false) {
     const int64_t n = p.n;
     const int K = p.K, H = p.H;
     int rc;
     float* const sk[2] = {ws + p.splitk, ws + p.splitk + p.splitk_each};
-    for (int j = 0; j < K; ++j) {  // recompute the two MLPs, keeping every layer output
+    for (int j = have_rows ? K : 0; j < K; ++j) {  // recompute the two MLPs, keeping every layer output
         const int I = nets[0]->dims[j], O = nets[0]->dims[j + 1];
         const bool last = j == K - 1;
         GemmJob jobs[2];
@@ -1747,6 +1790,13 @@ static int mlp_backward_generic(const BwdPlan& p, const BwdOperands& o, const Gn
         sh.ldc = last ? H : p.lmax;
         sh.M = n, sh.K = I, sh.N = O, sh.chunks = 1, sh.kchunk = TGK;
         sh.act = gnn.activation, sh.alpha = gnn.alpha, sh.apply_act = last ? 0 : 1;
+        {   // wide layers of packed nets: the large-batch kernel's inner loop, exactly as the forward pass ran them (run_mlps)
+            const float* xin[2] = {jobs[0].A, jobs[1].A};
+            float* yq[2] = {jobs[0].C, jobs[1].C};
+            rc = launch_linear_big(nets, 2, j, xin, sh.lda, yq, sh.ldc, n, gnn.activation, gnn.alpha, last ? 0 : 1, st);
+            if (rc == GNF_OK) continue;
+            if (rc != 1) return rc;
+        }
         rc = launch_gemm<OPND_KC, OPND_MC, EPI_BIAS_ACT>(jobs, 2, sh, st, sk, p.splitk_each);
         if (rc) return rc;
     }
@@ -1811,6 +1861,14 @@ static int mlp_backward_generic(const BwdPlan& p, const BwdOperands& o, const Gn
         sh.ldaux = p.lmax;
         sh.M = n, sh.K = O, sh.N = I, sh.chunks = 1, sh.kchunk = TGK;
         sh.act = gnn.activation, sh.alpha = gnn.alpha;
+        {   // dX of a wide layer: k_linear_big on the transposed fragments (the packed copy's W^T half)
+            const float* dy[2] = {jobs[0].A, jobs[1].A};
+            float* dx[2] = {jobs[0].C, jobs[1].C};
+            const float* hm[2] = {jobs[0].aux, jobs[1].aux};
+            rc = launch_linear_big_dx(nets, 2, j, dy, sh.lda, dx, sh.ldc, j == 0 ? nullptr : hm, sh.ldaux, n, gnn.activation, gnn.alpha, st);
+            if (rc == GNF_OK) continue;
+            if (rc != 1) return rc;
+        }
         rc = launch_gemm<OPND_KC, OPND_KC, EPI_MASK>(jobs, 2, sh, st, sk, p.splitk_each);
         if (rc) return rc;
     }
@@ -1957,6 +2015,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     // the training forward left every half-step's MLP rows in GnfFlow.mlp_stash: no recompute (ABI v8)
     const bool mstashed = flow->mlp_stash != nullptr && mlp_stash_supported(flow, n, D / 2);
     const MlpStashLayout msl = mstashed ? mlp_stash_layout(&flow->s_nets[0], n, D / 2) : MlpStashLayout{};
+    const bool layered = mstashed && layered_stash_mode(flow, n, D / 2);
     if (mstashed && flow->mlp_stash_bytes < (size_t)2 * T * msl.slot * sizeof(float)) {
         set_error("gnf_grevnet_backward_f32: mlp_stash %zu < %zu bytes", flow->mlp_stash_bytes,
                   (size_t)2 * T * msl.slot * sizeof(float));
@@ -2099,7 +2158,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 }
                 // (the conditioning half as the dW GEMMs of Wq / Wk / Wv read it, o.xc, is copied by the attention
                 // backward's last kernel: launch_attn_backward)
-            } else if (!fused) {
+            } else if (!fused && !(mstashed && layered)) {   // (layered stash: the forward's layer-0 rows are in the slot)
                 rc = launch_aggregate(csr->rowptr, csr->col, n, x_cond, ld, H, flow->gnn.agg == GNF_AGG_MEAN,
                                       flow->gnn.combine == GNF_COMBINE_CONCAT ? 1 : 0, flow->gnn.epsilon, o.h0[0], p.in0, st);
                 if (rc) return rc;
@@ -2241,7 +2300,16 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                                            g + uo, D, H, o.h0[0], attn ? h0c : nullptr, o.hin, p.lmax, o.dPs, p.lmax,
                                            o.gst, o.dh0, st);
             } else {
-                rc = mlp_backward_generic(p, o, flow->gnn, nets, grads, acc, x_cond, z + uo, ld, g + uo, D, wsf, st);
+                const bool rows = mstashed && layered;
+                if (rows) {  // the forward's layered path left every layer input and s, t in the half-step's slot
+                    float* slot = flow->mlp_stash + (size_t)(2 * i + half) * msl.slot;
+                    for (int q = 0; q < 2; ++q) {
+                        if (!attn) o.h0[q] = slot + msl.h0, o.hin[q * p.K] = o.h0[q];
+                        for (int j = 1; j < p.K; ++j) o.hin[q * p.K + j] = slot + msl.act + ((size_t)q * (p.K - 1) + (j - 1)) * msl.act_each;
+                        o.stb[q] = slot + msl.st + (size_t)q * msl.st_each;
+                    }
+                }
+                rc = mlp_backward_generic(p, o, flow->gnn, nets, grads, acc, x_cond, z + uo, ld, g + uo, D, wsf, st, rows);
             }
             if (rc) return rc;
             // message passing: the weight gradients only read what the fused kernel has just written, so their stream

@@ -177,8 +177,10 @@ typedef struct GnfFlow {
      * activations, their sign bits and s, t of both nets in mlp_stash (what TensorFlow keeps for tf.gradients anyway), and
      * gnf_grevnet_backward_f32 - called next with the SAME flow, graph and the z that forward produced - skips the
      * recompute half of its fused kernel and feeds the weight-gradient GEMMs from the stash.  gnf_mlp_stash_bytes()
-     * sizes it and returns 0 where the library would not use one (batches of more than 256 16-node tiles, layers too
-     * wide for the fused kernels, attention blocks that end in LayerNorm): pass NULL then. */
+     * sizes it and returns 0 where the library would not use one (batches of more than one 16-node tile per CU on the fused
+     * kernels, attention blocks that end in LayerNorm): pass NULL then.  Nets too wide for the fused kernels (the data
+     * driver's 2048 x 3 MLPs) use it too since round 5: their layered forward writes every hidden activation and s, t
+     * into the slot and the backward pass skips its recompute of both MLPs (up to 48 GB). */
     float* mlp_stash;
     size_t mlp_stash_bytes;
 } GnfFlow;

@@ -843,3 +843,68 @@ def test_wide_nets_packed_copies_follow_the_weights(community_medium):
     raw = log_prob_terms(net2, graph)
     assert abs(float(raw["log_prob_xs_per_node"]) - lp_packed) <= 2e-5 * max(1.0, abs(lp_packed))
     np.testing.assert_allclose(raw["z_graph"].nodes.cpu().numpy(), z_packed, atol=2e-4, rtol=2e-4)
+
+
+@pytest.mark.parametrize("gnn_kind", ["avg_then_mlp", "dm_attn_bn"])
+def test_layered_mlp_row_stash_matches_the_recomputing_walk(community_medium, gnn_kind):
+    """Nets too wide for the fused kernels (layered forward, generic backward): with GnfFlow.mlp_stash the forward's hidden
+    activations and s, t go straight into the stash and the backward pass skips its recompute of both MLPs
+    (layered_stash_mode).  The library offers the stash for such a flow, the gradients agree with the fully reversible walk to
+    rounding (the recompute starts from the RECONSTRUCTED inputs, the stash holds the forward's own rows) and with the
+    oracle, and a plain forward afterwards does not touch the stash."""
+    import ctypes as C
+    from gnf_amd import _abi
+    from gnf_amd.flow import log_prob_terms
+    from gnf_amd.train import GRevNetTrainer
+    d, latent, k, t = 24, 1280, 3, 2
+    attn = dict(num_heads=1, kq_dim=64, v_dim=64, out_dim=64, concat=True, kq_dim_division=True, residual=False) if gnn_kind == "dm_attn_bn" else None
+    hp = dict(D=d, latent=latent, K=k, T=t, agg="mean", combine="agg", epsilon=1.0, activation="relu", weight_sharing=False)
+    if attn:
+        hp["attn"] = attn
+    nn, ne, s, r = _batch(community_medium, list(range(64)))
+    n = int(nn.sum())
+    x = (np.random.default_rng(8).standard_normal((n, d)) * 0.7).astype(np.float32)
+    if attn:
+        p = O.make_attn_grevnet_params(41, d // 2, latent, k, t, final_scale=0.3, **attn)
+        p["bn"] = O.make_bn_params(42, d // 2, t)
+    else:
+        p = O.make_grevnet_params(41, d // 2, latent, k, t, final_scale=0.3)
+    ref = O.loss_and_grads(s, r, n, x, p, t, activation="relu")
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    got = {}
+    for stash in (True, False):
+        net = make_product_grevnet(hp, p)
+        tr = GRevNetTrainer(net)
+        tr.stash_mlp_rows = stash
+        out = tr.loss_and_grads(graph)
+        torch.cuda.synchronize()
+        assert (tr._mlp_stash is not None) == stash
+        if stash:
+            flow = net._flow(d // 2, torch.device(DEV))
+            in0 = d // 2 + (64 if attn else 0)
+            want = 2 * t * 4 * sum((v + 63) // 64 * 64 for v in (n * in0, n * latent, n * latent, n * latent, n * latent, n * (d // 2), n * (d // 2)))
+            assert _abi.lib().gnf_mlp_stash_bytes(n, d, C.byref(flow)) >= want   # (+ the fused mode's ballot words)
+        assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
+        np.testing.assert_allclose(out["reconstruction"].cpu().numpy(), x, atol=3e-4, rtol=3e-4)
+        got[stash] = tr.named_gradients()
+        before = tr._mlp_stash.clone() if stash else None
+        log_prob_terms(net, graph)                  # a plain forward: flow.mlp_stash is NULL again
+        torch.cuda.synchronize()
+        if stash:
+            assert torch.equal(before, tr._mlp_stash)
+
+    def flat(gr):
+        for kind in ("s", "t"):
+            for net_ in gr[kind][0] + gr[kind][1]:
+                mlp = net_["mlp"] if isinstance(net_, dict) else net_
+                if isinstance(net_, dict):
+                    for key in ("wq", "wk", "wv", "wo"):
+                        yield net_["attn"][key]
+                for (w, b) in mlp:
+                    yield w
+                    yield b
+    gmax = max(float(np.abs(b).max()) for b in flat(ref["grads"]))
+    for a, b, c in zip(flat(got[True]), flat(got[False]), flat(ref["grads"])):
+        scale = max(float(np.abs(c).max()), 1e-3 * gmax)
+        assert float(np.abs(a - b).max()) <= 2e-3 * scale          # stash vs recompute: relu kinks of the reconstruction aside
+        assert float(np.linalg.norm(a - c)) <= 2e-3 * max(float(np.linalg.norm(c)), 1e-3 * gmax * np.sqrt(c.size))
