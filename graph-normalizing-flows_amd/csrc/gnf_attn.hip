@@ -619,6 +619,25 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
     a.in0 = in0;
     a.scale = a0->kq_dim_division ? 1.f / sqrtf((float)a0->kq_dim) : 1.f;
     const bool ref_default = a.nh == 8 && a.kq == 10 && a.v == 10;  // run_grevnet.py:74-76
+    const bool old_attn = opt(OPT_ATTN_KERNEL) == 2;  // shape forcing for the parity tests (gnf_set_option): 1 rows kernel, 2 edge-tiled kernel,
+    const bool rows_always = opt(OPT_ATTN_KERNEL) == 1;   // 3 the matrix-core attention core
+    const bool core_always = opt(OPT_ATTN_KERNEL) == 3;
+    // sparse batches (mean in-degree under ~24: the config-2 batch has 12) are 8 % faster through the edge-tiled kernel;
+    // the rows kernel wins by 4.5 x on the complete graphs of the drivers' default dataset (degree 100)
+    const bool sparse = !rows_always && n_edges > 0 && n_edges < 24 * n;
+    // which kernel behind the projection: the thread-per-(row, head) rows kernel (dense batches, heads <= 8, kq, v <= 32, its
+    // window in LDS), the matrix-core attention core (wider heads, or an edge tile that does not fit the LDS), else the
+    // edge-tiled kernel
+    int RB = 512 / (a.nh * kEL);  // (row, head) groups of kEL lanes of the edge-tiled kernel
+    if (RB < 1) RB = 1;
+    const size_t rows_fixed = (size_t)(kRowsTile + 1 + 3 + kRowsColCap) * sizeof(int) +
+                              ((size_t)a.nh * a.v * a.C + (size_t)kRowsTile * (a.nh * a.v + 1)) * sizeof(float);
+    const bool use_rows = !old_attn && !core_always && !sparse && a.nh <= kRowsMaxHeads && a.kq <= 32 && a.v <= 32 &&
+                          rows_fixed + 64 * (size_t)(a.nh * a.kq + a.v + 2) * sizeof(float) <= (size_t)kRowsLdsBudget;
+    const size_t tile_lds = ((size_t)RB * a.nh * a.v + (size_t)kEdgeCap * (a.nh * a.kq + a.v) + (size_t)RB * a.nh * a.kq +
+                             (size_t)kEdgeCap * a.nh + 2 * (size_t)RB * a.nh + (size_t)a.nh * a.v * a.C + (size_t)RB * H) * sizeof(float) +
+                            (size_t)(RB + 1 + kEdgeCap) * sizeof(int);
+    const bool use_core = !use_rows && (core_always || (!old_attn && (a.kq > 32 || a.v > 32)) || tile_lds > 160 * 1024);
     const size_t proj_lds = ((size_t)H * P + (size_t)kProjRows * H) * sizeof(float);
     // The projection.  The drivers' default head geometry at small H keeps its folded vector-unit instance (the weights
     // fit the LDS many times over: run_grevnet.py:74-76); every other geometry - first of all the data driver's one head of
@@ -631,20 +650,14 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
         hipLaunchKernelGGL((k_attn_proj<8, 10, 10>), pgrid, dim3(256), proj_lds, st, a);
         GNF_LAUNCH_CHECK("k_attn_proj");
     } else {
-        const int rc = launch_attn_proj_mfma(at, nets, n, x, ldx, H, a.qkv, st);
+        // (the core kernel's concat half of h0 rides along here, from the registers that hold the rows)
+        const int rc = launch_attn_proj_mfma(at, nets, n, x, ldx, H, a.qkv, st, use_core && a.concat ? a.h0 : nullptr, in0);
         if (rc) return rc;
     }
-    const bool old_attn = opt(OPT_ATTN_KERNEL) == 2;  // shape forcing for the parity tests (gnf_set_option): 1 rows kernel, 2 edge-tiled kernel,
-    const bool rows_always = opt(OPT_ATTN_KERNEL) == 1;   // 3 the matrix-core attention core
-    const bool core_always = opt(OPT_ATTN_KERNEL) == 3;
-    // sparse batches (mean in-degree under ~24: the config-2 batch has 12) are 8 % faster through the edge-tiled kernel;
-    // the rows kernel wins by 4.5 x on the complete graphs of the drivers' default dataset (degree 100)
-    const bool sparse = !rows_always && n_edges > 0 && n_edges < 24 * n;
-    if (!old_attn && !core_always && !sparse && a.nh <= kRowsMaxHeads && a.kq <= 32 && a.v <= 32) {
+    if (use_rows) {
         const int NV = a.nh * a.v, nq = a.nh * a.kq;
-        const size_t fixed = (size_t)(kRowsTile + 1 + 3 + kRowsColCap) * sizeof(int) +
-                             ((size_t)NV * a.C + (size_t)kRowsTile * (NV + 1)) * sizeof(float);
-        if (fixed + 64 * (size_t)(nq + a.v + 2) * sizeof(float) <= (size_t)kRowsLdsBudget) {
+        const size_t fixed = rows_fixed;
+        {
             const int cap = (int)((kRowsLdsBudget - fixed) / ((size_t)(nq + a.v + 2) * sizeof(float)));
             GNF_ONCE_PER_DEVICE(
                 const void* ks[4] = {reinterpret_cast<const void*>(k_attn_fwd_rows<10, 10, 64>),
@@ -673,16 +686,17 @@ int launch_attn_front(const int32_t* rowptr, const int32_t* col, int64_t n, cons
             return GNF_OK;
         }
     }
-    int RB = 512 / (a.nh * kEL);  // (row, head) groups of kEL lanes
-    if (RB < 1) RB = 1;
     {
         // Heads wider than the thread-per-(row, head) kernels' registers (kq or v above 32: the DATA driver's default is one
         // head of 64 / 64, train_grevnet_with_data.py:40-46) - or a geometry whose edge tile does not fit the LDS - take the
         // matrix-core attention core (gnf_attn_core.hip), then new = agg Wo on the generic GEMM tile into h0's columns.
-        const size_t tile_lds = ((size_t)RB * a.nh * a.v + (size_t)kEdgeCap * (a.nh * a.kq + a.v) + (size_t)RB * a.nh * a.kq +
-                                 (size_t)kEdgeCap * a.nh + 2 * (size_t)RB * a.nh + (size_t)a.nh * a.v * a.C + (size_t)RB * H) * sizeof(float) +
-                                (size_t)(RB + 1 + kEdgeCap) * sizeof(int);
-        if (core_always || (!old_attn && (a.kq > 32 || a.v > 32)) || tile_lds > 160 * 1024) {
+        if (use_core) {
+            if (a.concat && ref_default && proj_lds <= 64 * 1024) {   // (the folded projection instance does not write h0's concat half)
+                for (int q = 0; q < nets; ++q) {
+                    const int rc0 = launch_copy_rows(x, ldx, a.h0[q], in0, n, H, st);
+                    if (rc0) return rc0;
+                }
+            }
             const int NV = a.nh * a.v;
             float* agg_def = scratch + 2 * (size_t)n * (P + (size_t)in0);   // attn_scratch_floats' layout
             float* aggs[2] = {a.agg_out[0] ? a.agg_out[0] : agg_def, a.agg_out[1] ? a.agg_out[1] : agg_def + (size_t)(nets > 1 ? 1 : 0) * n * NV};

@@ -17,10 +17,9 @@
 //     the O^T = V^T P^T product: no trip through LDS between the two GEMMs;
 //   * empty receivers give agg = 0 (gnn.py:403); the running max / denominator go to `mz` for the backward pass.
 // Around it (launch_attn_core): the q | k | v projection (k_attn_proj, or the generic GEMM tile where Wq | Wk | Wv do not
-// fit the LDS) in front, the output projection new = agg Wo (generic GEMM tile) behind; the kernel itself copies the
-// node's own features into h0 when the block concatenates them (gnn.py:542-543).
-#include "gnf_attn_dev.h"
-#include "gnf_fused_dev.h"
+// fit the LDS) in front - it also copies the node's own features into h0 when the block concatenates them (gnn.py:542-543),
+// from the registers that hold them anyway - and the output projection new = agg Wo (generic GEMM tile) behind.
+#include "gnf_attn_core_dev.h"
 
 namespace gnf {
 
@@ -49,6 +48,8 @@ __global__ __launch_bounds__(256) void k_attn_core(const AttnCoreArgs a) {
     unsigned* mult = reinterpret_cast<unsigned*>(vt_lds + 16 * VT * VS);   // [64][MW] pairs of 16-bit counts
     int* s_rp = reinterpret_cast<int*>(mult + kCoreRows * MW);             // [65]
     int* s_hdr = s_rp + kCoreRows + 1;                                     // lo, hi, overflow
+    int* s_col = s_hdr + 3;                                                // [kCap] the tile's slice of col
+    constexpr int kCap = core_col_cap<KG>();
     const int net = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, lgrp = lane >> 4;
@@ -60,70 +61,33 @@ __global__ __launch_bounds__(256) void k_attn_core(const AttnCoreArgs a) {
         s_rp[tid] = a.rowptr[r < a.n ? r : a.n];
     }
     if (tid == 0) s_hdr[0] = 0x7fffffff, s_hdr[1] = -1, s_hdr[2] = 0;
-    if (a.concat) {  // h0[r, 0:H) = x[r, :]  (the MLP behind reads [x || new], gnn.py:542-543)
-        float* __restrict__ h0 = a.h0[net];
-        const int total = kCoreRows * a.H;
-        for (int base = 0; base < total; base += 256 * 8) {
-            float reg[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + tid + 256 * u;
-                const int rl = i / a.H, f = i - rl * a.H;
-                reg[u] = (i < total && row0 + rl < a.n) ? a.x[(int64_t)(row0 + rl) * a.ldx + f] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + tid + 256 * u;
-                const int rl = i / a.H, f = i - rl * a.H;
-                if (i < total && row0 + rl < a.n) h0[(int64_t)(row0 + rl) * a.in0 + f] = reg[u];
-            }
-        }
-    }
-    __syncthreads();
-    const int e0 = s_rp[0], e1 = s_rp[kCoreRows];
-    {   // sender window of the tile: min / max over its slice of col (eight loads in flight per thread)
-        int lo = 0x7fffffff, hi = -1;
-        for (int base = e0; base < e1; base += 256 * 8) {
-            int reg[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = base + tid + 256 * u;
-                reg[u] = a.col[e < e1 ? e : e1 - 1];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                lo = reg[u] < lo ? reg[u] : lo;
-                hi = reg[u] > hi ? reg[u] : hi;
-            }
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            const int l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
-            lo = l2 < lo ? l2 : lo;
-            hi = h2 > hi ? h2 : hi;
-        }
-        if (lane == 0 && e1 > e0) {
-            atomicMin(&s_hdr[0], lo);
-            atomicMax(&s_hdr[1], hi);
-        }
-    }
-    __syncthreads();
-    const int win_lo = s_hdr[0], win_n = s_hdr[1] >= s_hdr[0] ? s_hdr[1] - s_hdr[0] + 1 : 0;
-    const int n_chunks = (win_n + CH - 1) / CH;
-    // 16-byte staging loads: every q / v segment of a row starts on a multiple of four floats of a 16-byte aligned array
-    const bool vec4 = ((kq | vd | P) & 3) == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0;
-    const int r = row0 + 16 * wave + lrow;  // this lane's receiver
-    const int my_row = 16 * wave + lrow;
-
-    for (int h = 0; h < nh; ++h) {
-        // the receiver's k row as the logits' second operand: k-slot g of the q-th MFMA of k-group kg = component 16 kg + 4 g + q
-        f32x4 kB[KG];
+    // the receiver's k row as the logits' second operand (k-slot g of the q-th MFMA of k-group kg = component 16 kg + 4 g + q):
+    // head 0's is requested here, in the shadow of the rowptr / col round trips, head h + 1's behind head h's last chunk
+    const int r = row0 + 16 * (tid >> 6) + (tid & 15);  // this lane's receiver
+    f32x4 kB[KG];
+    auto load_k = [&](int h) {
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int j = 16 * kg + 4 * lgrp + q;
-                kB[kg][q] = (r < a.n && j < kq) ? qkv[(int64_t)r * P + nq + h * kq + j] : 0.f;
+                const int j = 16 * kg + 4 * ((tid & 63) >> 4) + q;
+                kB[kg][q] = (r < a.n && j < a.kq) ? qkv[(int64_t)r * (2 * a.nh * a.kq + a.v) + a.nh * a.kq + h * a.kq + j] : 0.f;
             }
+    };
+    load_k(0);
+    __syncthreads();
+    core_window_scan(a.col, s_rp[0], s_rp[kCoreRows], s_hdr, tid, lane, s_col, kCap);
+    __syncthreads();
+    const bool col_kept = s_rp[kCoreRows] - s_rp[0] <= kCap;
+    const int32_t* cols = col_kept ? s_col : a.col;
+    const int col_base = col_kept ? s_rp[0] : 0;
+    const int win_lo = s_hdr[0], win_n = s_hdr[1] >= s_hdr[0] ? s_hdr[1] - s_hdr[0] + 1 : 0;
+    const int n_chunks = (win_n + CH - 1) / CH;
+    // 16-byte staging loads: every q / v segment of a row starts on a multiple of four floats of a 16-byte aligned array
+    const bool vec4 = ((kq | vd | P) & 3) == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0;
+    const int my_row = 16 * wave + lrow;
+
+    for (int h = 0; h < nh; ++h) {
         float m_run = -INFINITY, z_run = 0.f;
         f32x4 O[VT];
 #pragma unroll
@@ -207,24 +171,7 @@ __global__ __launch_bounds__(256) void k_attn_core(const AttnCoreArgs a) {
                 }
             }
             __syncthreads();
-            if (restage_shared) {  // the tile's edges into the multiplicity table: four threads per receiver row
-                const int rl = tid >> 2, sub = tid & 3;
-                const int beg = s_rp[rl], end = s_rp[rl + 1];
-                for (int e = beg + sub; e < end; e += 16) {
-                    int sreg[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) sreg[u] = a.col[e + 4 * u < end ? e + 4 * u : end - 1];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int s = sreg[u] - win_lo - c0;
-                        if (e + 4 * u < end && s >= 0 && s < CH) {
-                            const unsigned sh = 16u * (unsigned)(s & 1);
-                            const unsigned old = atomicAdd(&mult[rl * MW + (s >> 1)], 1u << sh);
-                            if (((old >> sh) & 0xffffu) == 0xffffu) s_hdr[2] = 1;  // an edge repeated 65536 times: not representable
-                        }
-                    }
-                }
-            }
+            if (restage_shared) core_scatter_mult<CH>(mult, s_rp, cols, col_base, win_lo, c0, s_hdr, tid);
             __syncthreads();
             // ---- S^T tiles of the chunk: sender rows x this wave's 16 receivers ------------------------------------------
             f32x4 S[ST];
@@ -311,6 +258,7 @@ __global__ __launch_bounds__(256) void k_attn_core(const AttnCoreArgs a) {
                 mz[nh + h] = z_run > 0.f ? z_run : 1.f;
             }
         }
+        if (h + 1 < nh) load_k(h + 1);
     }
 }
 
@@ -325,6 +273,8 @@ struct AttnProjArgs {
     const float* Wk[2];
     const float* Wv[2];
     float* qkv[2];
+    float* h0[2];          // NULL, or the MLP's layer-0 rows [N, in0] of a concat block: h0[r, 0:H) = x[r, :] rides along (gnn.py:542-543)
+    int32_t in0;
     const float* x;
     int64_t ldx;
     int32_t n, H, nq, v;
@@ -403,6 +353,15 @@ __global__ __launch_bounds__(256) void k_attn_proj_mfma(const AttnProjArgs a) {
             for (int u = 0; u < 2; ++u) {
                 const int i = tid + 256 * u;
                 *reinterpret_cast<f32x4*>(xs + (i >> 4) * kPjKS + 4 * (i & 15)) = xr[u];
+                if (cp == 0 && a.h0[net]) {   // the block's own features into its MLP's input rows, from the registers that hold them
+                    const int rl = i >> 4, c = 4 * (i & 15), r = row0 + rl;
+                    if (r < a.n) {
+                        float* ph = a.h0[net] + (int64_t)r * a.in0 + k0 + c;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (c + q < kn) ph[q] = xr[u][q];
+                    }
+                }
             }
             __syncthreads();
 #pragma unroll
@@ -446,13 +405,15 @@ __global__ __launch_bounds__(256) void k_attn_proj_mfma(const AttnProjArgs a) {
 }
 
 int launch_attn_proj_mfma(const GnfAttn* const* at, int nets, int64_t n, const float* x, int64_t ldx, int32_t H, float* const* qkv,
-                          hipStream_t st) {
+                          hipStream_t st, float* const* h0_concat, int32_t in0) {
     if (n == 0) return GNF_OK;
     AttnProjArgs a;
     for (int q = 0; q < 2; ++q) {
         const GnfAttn* t = at[q < nets ? q : 0];
         a.Wq[q] = t->Wq, a.Wk[q] = t->Wk, a.Wv[q] = t->Wv, a.qkv[q] = qkv[q < nets ? q : 0];
+        a.h0[q] = h0_concat ? h0_concat[q < nets ? q : 0] : nullptr;
     }
+    a.in0 = in0;
     a.x = x, a.ldx = ldx, a.n = (int32_t)n, a.H = H, a.nq = at[0]->num_heads * at[0]->kq_dim, a.v = at[0]->v_dim;
     hipLaunchKernelGGL(k_attn_proj_mfma, dim3((unsigned)((n + kPjRows - 1) / kPjRows), (unsigned)nets), dim3(256), 0, st, a);
     GNF_LAUNCH_CHECK("k_attn_proj_mfma");
@@ -466,7 +427,7 @@ template <int KG, int VT, int ST>
 static size_t core_lds_bytes() {
     constexpr int CH = 16 * ST;
     return ((size_t)CH * (16 * KG + 4) + (size_t)16 * VT * (CH + 4)) * sizeof(float) + (size_t)kCoreRows * (CH / 2 + 1) * sizeof(unsigned) +
-           (size_t)(kCoreRows + 1 + 3) * sizeof(int);
+           (size_t)(kCoreRows + 1 + 3 + core_col_cap<KG>()) * sizeof(int);
 }
 
 // qkv[q]: the projections of net q ([N, P]); writes agg[q] ([N, nh v], normalised), mz[q] (nullable) and, for concat

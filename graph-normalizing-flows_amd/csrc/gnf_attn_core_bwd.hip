@@ -14,8 +14,7 @@
 // owns ONE node of the tile, lane & 15, and four nodes of the other side per 16-node tile), the other side's rows sit
 // TRANSPOSED in LDS ([component][node]) so that the two accumulating products read 16-byte first operands along the node
 // axis and the two logit-side products four 4-byte ones; P and dS never leave the registers.
-#include "gnf_attn_dev.h"
-#include "gnf_fused_dev.h"
+#include "gnf_attn_core_dev.h"
 
 namespace gnf {
 
@@ -33,124 +32,6 @@ struct AttnCoreBwdArgs {
 
 static constexpr int kCbRows = 64;
 
-// sender / receiver window of the tile's edges: min / max of its slice of col -> s_hdr[0], s_hdr[1] (caller: barriers around)
-__device__ __forceinline__ void core_window_scan(const int32_t* __restrict__ col, int e0, int e1, int* s_hdr, int tid, int lane) {
-    int lo = 0x7fffffff, hi = -1;
-    for (int base = e0; base < e1; base += 256 * 8) {
-        int reg[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = base + tid + 256 * u;
-            reg[u] = col[e < e1 ? e : e1 - 1];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            lo = reg[u] < lo ? reg[u] : lo;
-            hi = reg[u] > hi ? reg[u] : hi;
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        const int l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
-        lo = l2 < lo ? l2 : lo;
-        hi = h2 > hi ? h2 : hi;
-    }
-    if (lane == 0 && e1 > e0) {
-        atomicMin(&s_hdr[0], lo);
-        atomicMax(&s_hdr[1], hi);
-    }
-}
-
-// the tile's edges into the [64][MW] table of 16-bit multiplicities: four threads per tile row (table cleared, barriers by the caller)
-template <int CH>
-__device__ __forceinline__ void core_scatter_mult(unsigned* mult, const int* s_rp, const int32_t* __restrict__ col, int win_lo, int c0,
-                                                  int* s_hdr, int tid) {
-    constexpr int MW = CH / 2 + 1;
-    const int rl = tid >> 2, sub = tid & 3;
-    const int beg = s_rp[rl], end = s_rp[rl + 1];
-    for (int e = beg + sub; e < end; e += 16) {
-        int sreg[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) sreg[u] = col[e + 4 * u < end ? e + 4 * u : end - 1];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int s = sreg[u] - win_lo - c0;
-            if (e + 4 * u < end && s >= 0 && s < CH) {
-                const unsigned sh = 16u * (unsigned)(s & 1);
-                const unsigned old = atomicAdd(&mult[rl * MW + (s >> 1)], 1u << sh);
-                if (((old >> sh) & 0xffffu) == 0xffffu) s_hdr[2] = 1;  // an edge repeated 65536 times: not representable
-            }
-        }
-    }
-}
-
-// rows [row_lo, row_lo + cn) x columns [0, width) of a row-major array (row pitch `pitch`; src = its first column) ->
-// TRANSPOSED LDS slab dst[j][s] (j < 16 WT, s < CH; row stride CH + 4), zero beyond width / cn; every load before the first store
-template <int WT, int CH>
-__device__ __forceinline__ void core_stage_t(float* __restrict__ dst, const float* __restrict__ src, int64_t pitch, int width, int row_lo,
-                                             int cn, int tid, bool vec4) {
-    constexpr int VS = CH + 4;
-    if (vec4) {
-        constexpr int W4 = 4 * WT, PER = CH * W4 / 256;
-        f32x4 reg[PER];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int i = tid + 256 * u, s = i / W4, j = 4 * (i % W4);
-            reg[u] = (s < cn && j < width) ? *reinterpret_cast<const f32x4*>(src + (int64_t)(row_lo + s) * pitch + j) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int i = tid + 256 * u, s = i / W4, j = 4 * (i % W4);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) dst[(j + c) * VS + s] = reg[u][c];
-        }
-    } else {
-        constexpr int W = 16 * WT, PER = CH * W / 256;
-        for (int b = 0; b < PER; b += 8) {
-            float reg[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = tid + 256 * (b + u), s = i / W, j = i % W;
-                reg[u] = (s < cn && j < width) ? src[(int64_t)(row_lo + s) * pitch + j] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = tid + 256 * (b + u);
-                dst[(i % W) * VS + (i / W)] = reg[u];
-            }
-        }
-    }
-}
-
-// one 16-node tile of "other side" logits-type product: D[m = other node 16 t + ..][n = own node] = sum_j X[other][j] B[j]
-// with X^T in LDS (xt[j][node]) read as four 4-byte first operands per k-group and B the own node's row in registers
-template <int NG>
-__device__ __forceinline__ f32x4 core_dot_tile(const float* __restrict__ xt, int VS, int t, int lrow, int lgrp, int width, const f32x4 (&B)[NG]) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        if (16 * g < width) {
-            const float* p = xt + (16 * g + 4 * lgrp) * VS + 16 * t + lrow;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p[q * VS], B[g][q], acc, 0, 0, 0);
-        }
-    }
-    return acc;
-}
-
-// acc[g] += X^T[16 g + ..][nodes of tile t] * w  (the accumulating products: 16-byte first operands along the node axis)
-template <int NG>
-__device__ __forceinline__ void core_acc_tile(const float* __restrict__ xt, int VS, int t, int lrow, int lgrp, int width, const f32x4& w,
-                                              f32x4 (&acc)[NG]) {
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        if (16 * g < width) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(xt + (16 * g + lrow) * VS + 16 * t + 4 * lgrp);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], w[q], acc[g], 0, 0, 0);
-        }
-    }
-}
-
 // ---- receiver side ------------------------------------------------------------------------------------------------------
 template <int KG, int VT, int ST>
 __global__ __launch_bounds__(256) void k_attn_core_bwd_recv(const AttnCoreBwdArgs a) {
@@ -161,6 +42,8 @@ __global__ __launch_bounds__(256) void k_attn_core_bwd_recv(const AttnCoreBwdArg
     unsigned* mult = reinterpret_cast<unsigned*>(vt + 16 * VT * VS);       // [64][MW]
     int* s_rp = reinterpret_cast<int*>(mult + kCbRows * MW);
     int* s_hdr = s_rp + kCbRows + 1;
+    int* s_col = s_hdr + 3;                                                // [kCap] the tile's slice of col
+    constexpr int kCap = core_col_cap<KG>();
     const int net = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 15, lgrp = lane >> 4;
     const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
@@ -172,8 +55,11 @@ __global__ __launch_bounds__(256) void k_attn_core_bwd_recv(const AttnCoreBwdArg
     }
     if (tid == 0) s_hdr[0] = 0x7fffffff, s_hdr[1] = -1, s_hdr[2] = 0;
     __syncthreads();
-    core_window_scan(a.col, s_rp[0], s_rp[kCbRows], s_hdr, tid, lane);
+    core_window_scan(a.col, s_rp[0], s_rp[kCbRows], s_hdr, tid, lane, s_col, kCap);
     __syncthreads();
+    const bool col_kept = s_rp[kCbRows] - s_rp[0] <= kCap;
+    const int32_t* cols = col_kept ? s_col : a.col;
+    const int col_base = col_kept ? s_rp[0] : 0;
     const int win_lo = s_hdr[0], win_n = s_hdr[1] >= s_hdr[0] ? s_hdr[1] - s_hdr[0] + 1 : 0;
     const int n_chunks = (win_n + CH - 1) / CH;
     const bool vec4 = ((kq | vd | P) & 3) == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0;
@@ -217,7 +103,7 @@ __global__ __launch_bounds__(256) void k_attn_core_bwd_recv(const AttnCoreBwdArg
                 for (int i = tid; i < kCbRows * MW; i += 256) mult[i] = 0u;
             }
             __syncthreads();
-            if (restage_shared) core_scatter_mult<CH>(mult, s_rp, a.col, win_lo, c0, s_hdr, tid);
+            if (restage_shared) core_scatter_mult<CH>(mult, s_rp, cols, col_base, win_lo, c0, s_hdr, tid);
             __syncthreads();
 #pragma unroll
             for (int t = 0; t < ST; ++t) {
@@ -262,6 +148,8 @@ __global__ __launch_bounds__(256) void k_attn_core_bwd_send(const AttnCoreBwdArg
     unsigned* mult = reinterpret_cast<unsigned*>(stl + 3 * CH);            // [64][MW]
     int* s_rp = reinterpret_cast<int*>(mult + kCbRows * MW);
     int* s_hdr = s_rp + kCbRows + 1;
+    int* s_col = s_hdr + 3;                                                // [kCap] the tile's slice of col
+    constexpr int kCap = core_col_cap<KG>();
     const int net = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 15, lgrp = lane >> 4;
     const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
@@ -274,8 +162,11 @@ __global__ __launch_bounds__(256) void k_attn_core_bwd_send(const AttnCoreBwdArg
     }
     if (tid == 0) s_hdr[0] = 0x7fffffff, s_hdr[1] = -1, s_hdr[2] = 0;
     __syncthreads();
-    core_window_scan(a.col, s_rp[0], s_rp[kCbRows], s_hdr, tid, lane);
+    core_window_scan(a.col, s_rp[0], s_rp[kCbRows], s_hdr, tid, lane, s_col, kCap);
     __syncthreads();
+    const bool col_kept = s_rp[kCbRows] - s_rp[0] <= kCap;
+    const int32_t* cols = col_kept ? s_col : a.col;
+    const int col_base = col_kept ? s_rp[0] : 0;
     const int win_lo = s_hdr[0], win_n = s_hdr[1] >= s_hdr[0] ? s_hdr[1] - s_hdr[0] + 1 : 0;
     const int n_chunks = (win_n + CH - 1) / CH;
     const bool vec4k = ((kq | P) & 3) == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0;
@@ -319,7 +210,7 @@ __global__ __launch_bounds__(256) void k_attn_core_bwd_send(const AttnCoreBwdArg
             if (restage_shared)
                 for (int i = tid; i < kCbRows * MW; i += 256) mult[i] = 0u;
             __syncthreads();
-            if (restage_shared) core_scatter_mult<CH>(mult, s_rp, a.col, win_lo, c0, s_hdr, tid);
+            if (restage_shared) core_scatter_mult<CH>(mult, s_rp, cols, col_base, win_lo, c0, s_hdr, tid);
             __syncthreads();
 #pragma unroll
             for (int t = 0; t < ST; ++t) {
@@ -371,7 +262,7 @@ template <int KG, int VT, int ST>
 static size_t core_bwd_lds_bytes() {
     constexpr int CH = 16 * ST;
     return ((size_t)16 * (KG + VT) * (CH + 4) + 3 * (size_t)CH) * sizeof(float) + (size_t)kCbRows * (CH / 2 + 1) * sizeof(unsigned) +
-           (size_t)(kCbRows + 1 + 3) * sizeof(int);
+           (size_t)(kCbRows + 1 + 3 + core_col_cap<KG>()) * sizeof(int);
 }
 
 // dq | dk | dv of both nets from dagg, the forward's q | k | v, attended values and statistics (stats' third block is

@@ -226,7 +226,7 @@ int launch_linear_splitk(const float* const* x, int64_t ldx, const float* const*
 // which layers the wide-layer kernel takes: y = x W reads Wp of a layer with a long reduction and a wide output; the
 // backward dX = dY W^T reads WpT where the roles are swapped.  gnf_pack_flow keeps exactly these copies of a net that is
 // too wide for the fused kernels in step with its weights.
-inline bool linear_big_fwd_layer(int I, int O) { return I >= 512 && O >= 256; }
+inline bool linear_big_fwd_layer(int I, int O) { return I >= 64 && O >= 256; }
 inline bool linear_big_bwd_layer(int I, int O) { return O >= 512 && I >= 256; }
 // wide y = act(x W_j + b_j) of a pair of nets from their packed weights (gnf_linear_big.hip); 1 = not its case
 int launch_linear_big(const GnfMlp* const* nets, int nj, int j, const float* const* x, int64_t ldx, float* const* y, int64_t ldy,
@@ -274,8 +274,9 @@ int launch_attn_core(const GnfAttn* a0, int nets, const int32_t* rowptr, const i
                      int32_t H, int32_t in0, const float* const* qkv, float* const* agg, float* const* mz, float* const* h0,
                      hipStream_t st);
 // q | k | v = x [Wq | Wk | Wv] of 1 or 2 nets on the matrix cores, any widths (gnf_attn_core.hip); qkv[q]: [N, P]
+// h0_concat != NULL: h0_concat[q][r, 0:H) = x[r, :] rides along (the concat half of a block's layer-0 rows, row stride in0)
 int launch_attn_proj_mfma(const GnfAttn* const* at, int nets, int64_t n, const float* x, int64_t ldx, int32_t H, float* const* qkv,
-                          hipStream_t st);
+                          hipStream_t st, float* const* h0_concat = nullptr, int32_t in0 = 0);
 // one-launch front-end for sparse batches (gnf_attn_front.hip), weights pre-packed into fragment order once per flow call
 bool attn_front_fused_ok(const GnfAttn* at, int32_t H);
 size_t attn_pack_floats(const GnfAttn* at, int32_t H);
