@@ -848,6 +848,15 @@ def main():
         "kernel_a": kernel_a,
     }
 
+    if trainer is not None:
+        # one trainer step = forward + dL/dx chain + weight gradients: 3 x the forward's algorithmic flops (what tf.gradients
+        # executes; the reversible walk's recompute, where a stash does not replace it, is NOT counted as useful work)
+        t_tf = 3.0 * flops * 2 * HP["T"] / (ms_per_step * 1e-3) / 1e12
+        out["train_roofline"] = {"bound": "mfma", "achieved": round(t_tf, 3), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(t_tf / PEAK_FP32_MATRIX_TFLOPS, 4),
+                                 "algorithmic_flops_per_step": 3 * flops * 2 * HP["T"],
+                                 "note": "3 x the forward's algorithmic flops per step (forward, dX chain, dW) / ms_per_step: the whole "
+                                         "step incl. Adam, the re-pack and every small launch; `roofline` above is the forward flow alone"}
     if inverse:   # round-trip check f(g(z)) = z on the device (size-independent property)
         zg = net(graph, inverse=False)
         back, _ = net(zg, inverse=True)
@@ -877,7 +886,7 @@ def main():
         sec, t_sec = {}, time.perf_counter()
         ksteps = args.secondary_steps or min(args.steps, 40)
         torch.cuda.synchronize()
-        for wl in ("config4", "config5", "config2_attn", "default_flags"):
+        for wl in ("config4", "config5", "config2_attn", "default_flags", "data_default_flags"):
             cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", str(ksteps), "--warmup", str(min(args.warmup, 10)),
                    "--repeats", "3", "--no-cpu-baseline", "--no-secondary", "--latency-steps", "0"]
             try:
