@@ -226,7 +226,9 @@ int launch_linear_splitk(const float* const* x, int64_t ldx, const float* const*
 // which layers the wide-layer kernel takes: y = x W reads Wp of a layer with a long reduction and a wide output; the
 // backward dX = dY W^T reads WpT where the roles are swapped.  gnf_pack_flow keeps exactly these copies of a net that is
 // too wide for the fused kernels in step with its weights.
-inline bool linear_big_fwd_layer(int I, int O) { return I >= 64 && O >= 256; }
+// (short reductions - the 100 / 164 -> 2048 first layer - measured level with the generic tile through k_linear_big as well,
+// 51 vs 49.5 us in round 5: they stay on the generic tile, which keeps this kernel's profile one shape)
+inline bool linear_big_fwd_layer(int I, int O) { return I >= 512 && O >= 256; }
 inline bool linear_big_bwd_layer(int I, int O) { return O >= 512 && I >= 256; }
 // wide y = act(x W_j + b_j) of a pair of nets from their packed weights (gnf_linear_big.hip); 1 = not its case
 int launch_linear_big(const GnfMlp* const* nets, int nj, int j, const float* const* x, int64_t ldx, float* const* y, int64_t ldy,
