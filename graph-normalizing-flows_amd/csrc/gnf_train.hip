@@ -244,6 +244,23 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
     // accumulator layout: col = lane & 15, row = 4 * (lane >> 4) + r
     float* __restrict__ Cp = job.C;
     if (EPI == EPI_SLAB) Cp += (int64_t)chunk * sh.M * sh.N;
+    // EPI_MASK: the stored activations that pick act' - ALL of a lane's 8 NW values requested before the first is used (read
+    // inside the store loop they were one dependent memory round trip per element: the 100 -> 2048 dX product of the data
+    // driver's last layer took 223 us for 2.2 GFLOP)
+    [[maybe_unused]] float hmask[2][NW][4];
+    if (EPI == EPI_MASK && job.aux) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int b = 0; b < NW; ++b) {
+                const int gc = n0 + wn + 16 * b + lrow;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t gr = m0 + wm + 16 * m + 4 * lgrp + r;
+                    hmask[m][b][r] = (gr < sh.M && gc < sh.N) ? job.aux[gr * sh.ldaux + gc] : 0.f;
+                }
+            }
+    }
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -258,9 +275,8 @@ __device__ __forceinline__ void gemm_tile(const GemmJob& job, const GemmShape& s
                         if (sh.apply_act) v = (sh.act == GNF_ACT_RELU) ? fmaxf(v, 0.f) : fmaxf(v, sh.alpha * v);
                     } else if (EPI == EPI_MASK) {
                         if (job.aux) {  // act'(pre) read off the stored activation: h > 0 <=> pre > 0
-                            const float h = job.aux[gr * sh.ldaux + gc];
                             const float slope = (sh.act == GNF_ACT_RELU) ? 0.f : sh.alpha;
-                            v = h > 0.f ? v : v * slope;
+                            v = hmask[m][b][r] > 0.f ? v : v * slope;
                         }
                     }
                     Cp[gr * sh.ldc + gc] = v;
@@ -1192,6 +1208,7 @@ struct DwPolicy {
     int max_units;
     size_t lds;
     double budget_us;
+    bool big_tiles_only = false;  // only the jobs with the most tiles count as "costliest" (see dw_policy, generic backward)
 };
 
 // The fused backward kernel of the NEXT half-step runs beside this half-step's dW GEMMs (one 16-node tile per
@@ -1227,7 +1244,12 @@ static DwPolicy dw_policy(const GnfMlp* net, int64_t bwd_tiles, size_t bwd_lds) 
         // tiles + slabs + reduce: wide_fc_train 34.2 -> 29.8 ms per step (measured with dw_wide_units = 640 .. 4096)
         int lmax = 1;
         for (int j = 1; j < net->num_layers; ++j) lmax = lmax > net->dims[j] ? lmax : net->dims[j];
-        if (lmax >= 512) pol.max_units = 3 * big_cu_count(), pol.budget_us = 1e30;
+        // ONE workgroup per CU, each taking its share of the hidden layers' 2 x 256 full tiles by stride (one chunk per tile:
+        // the slab is the gradient) with the thin first / last layers' tiles cut into pieces that ride behind through slabs of
+        // their own.  The count hardly matters (measured 128 .. 512 workgroups: 29.56 .. 29.90 ms per wide_fc_train step,
+        // best at one per CU): the step is bound by the matrix cores under these kernels' efficiencies, and one workgroup per
+        // CU leaves the other LDS slot of every CU to the main stream's kernels
+        if (lmax >= 512) pol.max_units = big_cu_count(), pol.budget_us = 1e30, pol.big_tiles_only = true;
     }
     if (env_u > 0) pol.max_units = (int)env_u, pol.budget_us = 1e30;
     return pol;
@@ -1317,12 +1339,26 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
         // The costliest jobs (the hidden-layer matrices) give the launch its grid: the smallest per-workgroup work T (in
         // rows of a full tile) whose cut of THEM fits max_units; candidates n / k.  Cheaper jobs (thin first / last
         // layers, attention projections) are cut into about as many units as there are workgroups and ride behind.
+        if (pol.big_tiles_only) {  // a job with under a quarter of the largest job's tiles is not among the costliest
+            int tmax = 1;
+            for (int e = 0; e < nj; ++e) tmax = tmax > tiles_of[e] ? tmax : tiles_of[e];
+            for (int e = 0; e < nj; ++e)
+                if (4 * tiles_of[e] < tmax && cost[e] > 1) cost[e] -= 1;
+            for (int a = 1; a < nj; ++a) {  // (re-sort: costliest first, stable)
+                const int v = order[a];
+                int b = a - 1;
+                while (b >= 0 && cost[order[b]] < cost[v]) order[b + 1] = order[b], --b;
+                order[b + 1] = v;
+            }
+        }
         const int cmax = nj > 0 ? cost[order[0]] : 16;
         int heavy_tiles = 0, light_tiles = 0;
         for (int e = 0; e < nj; ++e) (cost[e] == cmax ? heavy_tiles : light_tiles) += tiles_of[e];
         int c_heavy = 0;
         for (int k = p.chunks; k >= 1; --k)
             if ((int64_t)k * heavy_tiles <= pol.max_units) { c_heavy = k; break; }
+        // (generic backward of wide nets: more whole tiles than workgroups is fine - one chunk each, taken by stride)
+        if (c_heavy == 0 && pol.big_tiles_only && heavy_tiles > 0) c_heavy = 1;
         int grid = 0, c_light = 1;
         double est_us = 1e30;
         if (c_heavy > 0) {
@@ -1330,6 +1366,7 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
             kc = (kc + WGK - 1) / WGK * WGK;
             c_heavy = (int)((p.n + kc - 1) / kc);
             grid = c_heavy * heavy_tiles;
+            if (grid > pol.max_units) grid = pol.max_units;
             bool light_own = false;  // room for the cheap units as workgroups of their own?
             if (light_tiles > 0) {
                 light_own = grid + light_tiles <= pol.max_units;
@@ -1378,9 +1415,6 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
             }
         }
         if (grid == 0 || est_us > pol.budget_us) wide = false;
-        // the costliest tiles in ONE chunk each and nothing to accumulate into: the cheap jobs take one chunk too, so that
-        // every slab is its gradient and the reduce launch goes (a thin tile over the whole node axis is no longer than a full one)
-        if (wide && sk_q == 0 && c_heavy == 1 && !accumulate) c_light = 1;
         int sk_jobs = 0;
         for (int q = 0; q < nj && wide; ++q) {
             const int e = order[q];
@@ -1411,13 +1445,20 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
         }
         if (wide) {
             for (int e = 0; e < nj; ++e) gr.chunks[e] = cj[e];
-            // every job in ONE chunk and nothing to add to: the slabs are the gradients themselves, no reduce launch
-            bool one = !accumulate && sk_q == 0;
-            for (int e = 0; e < nj; ++e) one = one && cj[e] == 1;
-            if (one) {
-                for (int q = 0; q < nj; ++q) wg.job[q].C = jobs[order[q]].gw, wg.job[q].aux_out = jobs[order[q]].gb;
-                L->direct = true;
+            // a job in ONE chunk with nothing to add to: its slab is the gradient itself - written in place, nothing for the
+            // reduce launch to do for it (every job so: no reduce launch)
+            bool all_one = !accumulate && sk_q == 0;
+            for (int q = 0; q < nj && !accumulate; ++q) {
+                const int e = order[q];
+                const bool sk_job = sk_q > 0 && cost[e] == cmax;
+                if (cj[e] == 1 && !sk_job) {
+                    wg.job[q].C = jobs[e].gw, wg.job[q].aux_out = jobs[e].gb;
+                    gr.nw[e] = 0, gr.nb[e] = 0;
+                } else {
+                    all_one = false;
+                }
             }
+            if (all_one) L->direct = true;
             wg.unit_base[nj] = units;
             wg.K = p.n, wg.njobs = nj;
             if (sk_q > 0) {
