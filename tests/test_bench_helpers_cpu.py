@@ -90,7 +90,7 @@ def test_every_pmc_traffic_entry_names_its_kernel_sources():
 def test_line_consistency_checks():
     """kernel_us x launches_per_step <= ms_per_step (round 2's attention line had 78.8 us x 16 = 1.26 ms against a 0.866 ms
     step: its kernel-timing leg ran a path the step does not), on synthetic lines and on every round-3 / round-4 line
-    committed under profiles/ (the default line's secondary workloads included)."""
+    committed under profiles/ (the default line's secondary workloads included); a round-5 training line also carries train_roofline."""
     import glob
     import json
     import os
@@ -105,15 +105,20 @@ def test_line_consistency_checks():
     assert any("kernel_us" in e for e in bench.line_consistency_errors(bad))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     seen = 0
-    for f in sorted(glob.glob(os.path.join(root, "profiles", "r3*")) + glob.glob(os.path.join(root, "profiles", "r4*"))):
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "r3*")) + glob.glob(os.path.join(root, "profiles", "r4*")) +
+                    glob.glob(os.path.join(root, "profiles", "r5*"))):
         for line in open(f, errors="replace"):
             if line.startswith('{"metric"'):
                 d = json.loads(line)
                 assert bench.line_consistency_errors(d) == [], (f, bench.line_consistency_errors(d))
                 for wl, e in (d.get("secondary_workloads") or {}).items():
                     assert e.get("consistency") in ([], None), (f, wl, e.get("consistency"))   # (None: round-3 lines had no per-child check)
+                if "_train" in d["config"]["workload"].split(":")[0] and os.path.basename(f).startswith("r5"):
+                    tr = d["train_roofline"]
+                    assert abs(tr["frac"] - tr["achieved"] / tr["peak"]) <= 2e-3
+                    assert abs(tr["achieved"] - tr["algorithmic_flops_per_step"] / (d["ms_per_step"] * 1e-3) / 1e12) <= 2e-3 * tr["achieved"]
                 seen += 1
-    assert seen >= 10
+    assert seen >= 20
 
 
 def test_bench_gpus_n_without_devices_prints_an_error_line_and_fails():
