@@ -837,8 +837,12 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
         a.bn_part = nullptr;
         if (!s->attn) {
             // message-passing GNNs: the layer-0 input rows of both nets (eps * x + agg | [x || agg], gnn.py:108-109,123)
-            // from the standalone aggregation kernel - same edge order, same fma as the fused kernels' gather - into the
-            // head of the scratch; the large-batch kernel reads them like an attention front-end's output
+            // from the standalone aggregation kernel into the head of the scratch; the large-batch kernel reads them like an
+            // attention front-end's output.  Rows of up to 32 edges are summed in edge order with the fused kernels' fma
+            // (bitwise their gather); a longer row (an ego hub) is added up as contiguous segments in a fixed order
+            // (gnf_layered.hip), which differs from the sequential sum - and from what the fused inverse / backward kernels
+            // recompute for that row - in rounding only (the round-trip and gradient pins of tests/test_fullsize_gpu.py,
+            // config 5, cover batches whose hub rows cross this boundary)
             rc = launch_aggregate(hs.rowptr, hs.col, hs.n_nodes, hs.x_cond, hs.ld, hs.H, a.mean, a.concat ? 1 : 0, a.eps, scratch,
                                   a.in0, st);
             if (rc) return rc;
