@@ -378,6 +378,11 @@ struct WideGemmT {
     // the slabs that tile does not reach, so the reduce can add chunks[j] slabs everywhere.  Jobs 0 .. sk_jobs-1.
     int32_t sk_q, sk_steps, sk_tiles, sk_jobs;
     int32_t sk_light_base;  // first unit of the jobs cut the uniform way (they ride behind, strided)
+    // > 0: the first xcd_jobs jobs are whole-tile jobs (one chunk per tile) of a launch with a multiple of 8 workgroups, and
+    // workgroup b runs on XCD b % 8: a job's tile grid is then dealt to the XCDs as 2 x 4 BLOCKS (gx / 2 columns x gy / 4 rows
+    // of tiles each) instead of every eighth tile, so that an XCD's L2 holds gy / 4 A panels and gx / 2 B panels instead of
+    // all gy A panels (PMC, wide_fc_train: 516 MB fetched per launch for ~100 MB of operands, L2 hit rate 0.67)
+    int32_t xcd_jobs;
 };
 using WideGemm = WideGemmT<kMaxGroup>;
 // what fits next to the backward kernel's arguments in one launch (4 KB of kernel arguments)
@@ -505,8 +510,16 @@ __device__ __forceinline__ void dw_wide_body(const WG& g, const int vblock, cons
         kend = kbeg + g.kchunk[j] < g.K ? kbeg + g.kchunk[j] : g.K;
     }
     const int gxj = g.gx[j];
-    const int bx = lt % gxj, by = lt / gxj;
+    int bx = lt % gxj, by = lt / gxj;
     const int M = g.M[j], N = g.N[j];
+    if (j < g.xcd_jobs) {
+        const int gyj = (M + WGM - 1) / WGM;
+        if ((gxj & 1) == 0 && (gyj & 3) == 0) {  // tile lt of the job runs on XCD lt % 8 (unit_base and the grid are multiples of 8)
+            const int xcd = lt & 7, slot = lt >> 3, bw = gxj >> 1, bh = gyj >> 2;   // block width / height in tiles
+            bx = (xcd & 1) * bw + slot % bw;
+            by = (xcd >> 1) * bh + slot / bw;
+        }
+    }
     const int64_t lda = g.lda[j], ldb = g.ldb[j];
     const GemmJob job = g.job[j];
     const int m0 = by * WGM, n0 = bx * WGN;
@@ -1459,6 +1472,13 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
                 }
             }
             if (all_one) L->direct = true;
+            if (pol.big_tiles_only && sk_q == 0) {  // XCD blocks for the leading whole-tile jobs (see WideGemmT.xcd_jobs)
+                int xj = 0;
+                while (xj < nj && cost[order[xj]] == cmax && cj[order[xj]] == 1 && tiles_of[order[xj]] % 8 == 0 &&
+                       wg.unit_base[xj] % 8 == 0)
+                    ++xj;
+                wg.xcd_jobs = (grid % 8 == 0) ? xj : 0;
+            }
             wg.unit_base[nj] = units;
             wg.K = p.n, wg.njobs = nj;
             if (sk_q > 0) {
@@ -1592,6 +1612,7 @@ static void narrow_wide(const WideGemm& w, WideGemmS* o) {
     o->K = w.K, o->njobs = w.njobs;
     o->sk_q = w.sk_q, o->sk_steps = w.sk_steps, o->sk_tiles = w.sk_tiles, o->sk_jobs = w.sk_jobs;
     o->sk_light_base = w.sk_light_base;
+    o->xcd_jobs = 0;
 }
 static void narrow_reduce(const GroupedReduce& r, int nj, GroupedReduceS* o) {
     memset(o, 0, sizeof(*o));

@@ -908,3 +908,41 @@ def test_layered_mlp_row_stash_matches_the_recomputing_walk(community_medium, gn
         scale = max(float(np.abs(c).max()), 1e-3 * gmax)
         assert float(np.abs(a - b).max()) <= 2e-3 * scale          # stash vs recompute: relu kinks of the reconstruction aside
         assert float(np.linalg.norm(a - c)) <= 2e-3 * max(float(np.linalg.norm(c)), 1e-3 * gmax * np.sqrt(c.size))
+
+
+def test_checkpoint_restore_of_a_wide_net_repacks_what_the_wide_kernels_read(community_medium, tmp_path):
+    """examples/driver_utils.py save_checkpoint / load_checkpoint (the drivers' tf.train.Saver, run_grevnet.py:379,449-453) on a
+    net too wide for the fused kernels: after the restore the forward through the packed middle layer (k_linear_big) equals
+    the forward of the trainer that wrote the checkpoint, and the forward through the raw weights (gnf_pack_flow
+    used to skip such nets, a restored model ran on its INITIAL middle layer)."""
+    import os
+    import sys
+    from gnf_amd.flow import log_prob_terms
+    from gnf_amd.train import GRevNetTrainer
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import driver_utils as DU
+    hp = dict(D=24, latent=1280, K=3, T=1, agg="mean", combine="agg", epsilon=1.0, activation="relu", weight_sharing=False)
+    nn, ne, s, r = _batch(community_medium, list(range(64)))
+    n = int(nn.sum())
+    x = (np.random.default_rng(6).standard_normal((n, 24)) * 0.7).astype(np.float32)
+    p = O.make_grevnet_params(51, 12, 1280, 3, 1, final_scale=0.3)
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    net = make_product_grevnet(hp, p)
+    tr = GRevNetTrainer(net, lr=2e-3, use_lr_decay=False)
+    for _ in range(3):
+        tr.step(graph)
+    want = float(log_prob_terms(net, graph)["log_prob_xs_per_node"])
+    path = str(tmp_path / "ckpt.pt")
+    DU.save_checkpoint(tr, path)
+    net2 = make_product_grevnet(hp, p)                  # a fresh model with the INITIAL weights
+    tr2 = GRevNetTrainer(net2, lr=2e-3, use_lr_decay=False)
+    tr2.loss_and_grads(graph)                           # connects the variables (the restore needs them to exist)
+    first = float(log_prob_terms(net2, graph)["log_prob_xs_per_node"])
+    assert abs(first - want) > 1e-2
+    DU.load_checkpoint(tr2, path)
+    assert tr2.global_step == 3
+    got = float(log_prob_terms(net2, graph)["log_prob_xs_per_node"])
+    assert abs(got - want) <= 1e-6 * max(1.0, abs(want))
+    net2.fused = False
+    raw = float(log_prob_terms(net2, graph)["log_prob_xs_per_node"])
+    assert abs(raw - want) <= 2e-5 * max(1.0, abs(want))
