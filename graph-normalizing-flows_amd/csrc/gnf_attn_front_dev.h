@@ -161,16 +161,18 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
             const int c = tid % H, g = tid / H;
             if (g < G) {
                 double s_ = 0.0, q_ = 0.0;
-                for (int b0 = g; b0 < a.bn_nparts; b0 += 8 * G) {  // eight partial pairs in flight per thread
-                    double ps[8], pq[8];
+                // sixteen partial pairs in flight per thread: the 170 rows of a config-2 batch over 16 thread groups are ONE
+                // round trip (eight: two dependent ones, 2 k cycles of this prologue); the additions keep their order
+                for (int b0 = g; b0 < a.bn_nparts; b0 += 16 * G) {
+                    double ps[16], pq[16];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
+                    for (int k = 0; k < 16; ++k) {
                         const int b = b0 + k * G < a.bn_nparts ? b0 + k * G : g;
                         ps[k] = a.bn_part[((int64_t)b * H + c) * 2 + 0];
                         pq[k] = a.bn_part[((int64_t)b * H + c) * 2 + 1];
                     }
 #pragma unroll
-                    for (int k = 0; k < 8; ++k)
+                    for (int k = 0; k < 16; ++k)
                         if (b0 + k * G < a.bn_nparts) s_ += ps[k], q_ += pq[k];
                 }
                 red[(g * H + c) * 2 + 0] = s_;
