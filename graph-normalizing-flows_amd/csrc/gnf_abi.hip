@@ -146,7 +146,8 @@ WorkspacePlan plan_workspace(int64_t n_nodes, int32_t H, const GnfMlp* net, int3
     p.attn_pack_offset = p.base_floats + attn_scratch_floats(net ? net->attn : nullptr, n_nodes, in0);
     p.attn_pack_per_net = net ? (attn_pack_floats(net->attn, H) + 63) / 64 * 64 : 0;
     // (every net of the call: at most 2 per half-step and kind; weight sharing needs fewer)
-    p.scratch_floats = p.attn_pack_offset + p.attn_pack_per_net * (size_t)(4 * (n_halfsteps > 0 ? n_halfsteps : 1));
+    p.attn_tile_offset = p.attn_pack_offset + p.attn_pack_per_net * (size_t)(4 * (n_halfsteps > 0 ? n_halfsteps : 1));
+    p.scratch_floats = p.attn_tile_offset + (net && net->attn ? ((size_t)2 * ((n_nodes + 15) / 16) + 63) / 64 * 64 : 0);
     p.total_bytes = p.partial_bytes + p.scratch_floats * sizeof(float);
     return p;
 }
@@ -433,6 +434,7 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
     // and the one-launch front-end of gnf_attn_front.hip runs per half-step (the attn_kernel option keeps the two-launch
     // kernels)
     const float* attn_pack = nullptr;
+    const int32_t* attn_tiles = nullptr;
     if (n > 0 && n_nets > 0 && flow->s_nets[0].attn && csr->n_edges > 0 && csr->n_edges < 24 * n &&
         !opt(OPT_ATTN_KERNEL) && attn_front_fused_ok(flow->s_nets[0].attn, H)) {
         const GnfAttn* all[2 * 64];
@@ -444,6 +446,10 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
             rc = launch_attn_pack(all, 2 * n_nets, H, scratch + p.attn_pack_offset, st);
             if (rc) return rc;
             attn_pack = scratch + p.attn_pack_offset;
+            // ... and every tile's sender window, once for the 2 T half-steps of the call
+            rc = launch_attn_tiles(csr->rowptr, csr->col, n, reinterpret_cast<int32_t*>(scratch + p.attn_tile_offset), st);
+            if (rc) return rc;
+            attn_tiles = reinterpret_cast<const int32_t*>(scratch + p.attn_tile_offset);
         }
     }
     auto mark_attn = [&](HalfStep& hs, int half, int i) {
@@ -451,6 +457,7 @@ int gnf_grevnet_from_f32(const GnfCsr* csr, const GnfFlow* flow, const float* x_
         const int q = flow->weight_sharing ? half : half * T + i;
         hs.attn_packed[0] = attn_pack + (size_t)q * p.attn_pack_per_net;
         hs.attn_packed[1] = attn_pack + (size_t)(n_nets + q) * p.attn_pack_per_net;
+        hs.attn_tiles = attn_tiles;
     };
     // split row tiles of the large-batch kernel (message-passing nets, batches of more than two row tiles per CU): their
     // flags are zeroed once per call, every half-step launch gets a value of its own

@@ -97,6 +97,44 @@ int launch_attn_pack(const GnfAttn* const* at, int count, int32_t H, float* out,
     return GNF_OK;
 }
 
+// Sender window (lo, hi) of every 16-row tile: min / max of the tile's slice of col; an empty tile gets (0x7fffffff, -1).
+// One wave per tile.  Launched once per flow call (FrontArgs.tiles): the topology is the same for all 2 T half-steps.
+__global__ __launch_bounds__(256) void k_attn_tiles(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int n_nodes,
+                                                    int n_tiles, int32_t* __restrict__ out) {
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile >= n_tiles) return;
+    const int r0 = tile * kFrRows, r1 = r0 + kFrRows < n_nodes ? r0 + kFrRows : n_nodes;
+    const int e0 = rowptr[r0], e1 = rowptr[r1];
+    int lo = 0x7fffffff, hi = -1;
+    for (int base = e0; base < e1; base += 64 * 8) {
+        int reg[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = base + lane + 64 * u;
+            reg[u] = col[e < e1 ? e : e1 - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            lo = reg[u] < lo ? reg[u] : lo;
+            hi = reg[u] > hi ? reg[u] : hi;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const int l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if (lane == 0) out[2 * tile] = lo, out[2 * tile + 1] = hi;
+}
+
+int launch_attn_tiles(const int32_t* rowptr, const int32_t* col, int64_t n, int32_t* out, hipStream_t st) {
+    if (n <= 0) return GNF_OK;
+    const int n_tiles = (int)((n + kFrRows - 1) / kFrRows);
+    hipLaunchKernelGGL(k_attn_tiles, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, st, rowptr, col, (int)n, n_tiles, out);
+    GNF_LAUNCH_CHECK("k_attn_tiles");
+    return GNF_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 template <bool HOIST, int KQM, int VDM, int EU, bool EXACT, bool FIXED = false>
 __global__ __launch_bounds__(kFrThreads) void k_attn_front(const FrontArgs a) {
@@ -133,6 +171,8 @@ int launch_attn_front_fused(const int32_t* rowptr, const int32_t* col, int64_t n
         a.mz_out[q] = mz_out ? mz_out[s] : nullptr;
     }
     a.rowptr = rowptr, a.col = col, a.x = x, a.ldx = ldx;
+    a.tiles = nullptr;   // (the standalone launches scan their col slice themselves)
+    a.bn_part = nullptr;
     a.n_nodes = (int32_t)n;
     a.concat = a0->concat ? 1 : 0;
     a.in0 = in0;

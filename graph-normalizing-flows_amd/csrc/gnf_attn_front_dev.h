@@ -61,6 +61,11 @@ struct FrontArgs {
     float* bn_const_out;  // [2][H]: scale | shift
     int32_t bn_nparts;
     float bn_eps;
+    // NULL, or [tiles][2]: the sender window (lo, hi) of every 16-row tile of the batch (k_attn_tiles, once per flow call: the
+    // topology is the same for all 2 T half-steps).  With it the tile's col slice and its window's x rows are requested right
+    // behind the first round trip (rowptr | own rows | this pair) and arrive behind the k projection, instead of two further
+    // dependent round trips (col -> window -> rows): round-5 phase stamps 3.2 k + 1.1 k cycles of the 27.6 k front-end
+    const int32_t* tiles;
 };
 
 // LDS carve (floats); strides + 4 keep rows 16-byte aligned and spread rows over banks
@@ -143,6 +148,9 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
         const int r = row0 + tid;
         rp_reg = a.rowptr[r < a.n_nodes ? r : a.n_nodes];
     }
+    const bool have_tab = a.tiles != nullptr;  // (workgroup-uniform)
+    int tab_reg = 0;
+    if (have_tab && tid >= 32 && tid < 34) tab_reg = a.tiles[2 * (row0 / kFrRows) + (tid - 32)];
     {
         constexpr int kB = 4;  // 16 rows x Hp <= 128 floats = 2048 = 512 threads x 4
         float reg[kB];
@@ -223,7 +231,36 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
         }
     }
     if (tid <= kFrRows) rp_l[tid] = rp_reg;
+    if (have_tab && tid >= 32 && tid < 34) hdr_l[tid - 32] = tab_reg;
     __syncthreads();
+    // With the window table: the tile's col slice and the x rows of the first window pass are requested HERE and land behind
+    // the k projection below (one batch each; longer slices / wider rows keep the loops further down)
+    const bool pre_x = have_tab && kFrWin * (Hp >> 2) <= 2 * kFrThreads;
+    int pre_col[4] = {0, 0, 0, 0};
+    f32x4 pre_v4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (have_tab) {
+        const int sb = rp_l[0], sl = rp_l[kFrRows] - sb;
+        if (sl <= kFrColCap) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = tid + u * kFrThreads;
+                pre_col[u] = a.col[sb + (i < sl ? i : 0)];
+            }
+        }
+        if (pre_x) {
+            const int w0 = hdr_l[0], nw = hdr_l[1] + 1 - w0 < kFrWin ? hdr_l[1] + 1 - w0 : kFrWin, f4n = Hp >> 2;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = tid + u * kFrThreads;
+                const int e = i / f4n, f = (i - e * f4n) * 4;
+                const float* src = a.x + (int64_t)(w0 + (e < nw ? e : 0)) * a.ldx;   // (an empty tile: nw <= 0, row w0 = 0x7fffffff is never read:
+                if (nw > 0) {                                                        //  guarded)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pre_v4[u][q] = src[f + q < H ? f + q : 0];
+                }
+            }
+        }
+    }
 
     // K order inside a group of 16 is permuted identically on both operands (k = 16 g + 4 (lane >> 4) + q), so an A
     // fragment is one 16-byte LDS read and a B fragment one 16-byte global read.
@@ -314,7 +351,37 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
     // ---- the tile's col slice into LDS, its sender window [lo, hi] ----------------------------------------------------
     const int seg_len = seg_end - seg_beg;
     const bool col_staged = seg_len <= kFrColCap;
-    {
+    if (have_tab) {
+        // the prefetched col slice and window rows into LDS (the rows normalised like the own rows when a bijector rides along)
+        if (col_staged) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = tid + u * kFrThreads;
+                if (i < seg_len) col_l[i] = pre_col[u];
+            }
+            for (int i = tid + 4 * kFrThreads; i < seg_len; i += kFrThreads) col_l[i] = a.col[seg_beg + i];  // (slices of more than 2048 edges: never staged)
+        }
+        if (pre_x) {
+            const int w0 = hdr_l[0], nw = hdr_l[1] + 1 - w0 < kFrWin ? hdr_l[1] + 1 - w0 : kFrWin, f4n = Hp >> 2;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = tid + u * kFrThreads;
+                const int e = i / f4n, f = (i - e * f4n) * 4;
+                if (e >= kFrWin) continue;
+                f32x4 v = pre_v4[u];
+                if (TO_LDS && bn_lds != nullptr && a.bn_part != nullptr) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (f + q < H) v[q] = v[q] * bn_lds[f + q] + bn_lds[Hp + f + q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (!(e < nw && f + q < H)) v[q] = 0.f;
+                *reinterpret_cast<f32x4*>(xs_e + e * L.ldx + f) = v;
+            }
+        }
+        __syncthreads();  // (also: k_r is complete)
+    } else {
         if (tid == 0) {
             hdr_l[0] = 0x7fffffff;
             hdr_l[1] = -1;
@@ -351,7 +418,7 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
 #pragma unroll
     for (int j = 0; j < KQM; ++j) kreg[j] = (att && (EXACT || j < kq)) ? k_r[t_rl * L.ldk + t_h * kq + j] : 0.f;
     const int t_beg = rp_l[t_rl], t_end = att ? rp_l[t_rl + 1] : t_beg;
-    __syncthreads();
+    if (!have_tab) __syncthreads();
     const int win_lo = hdr_l[0], win_hi = hdr_l[1];  // empty tile: hi = -1 < lo
     int chunk_ = 0;
     (void)chunk_;
@@ -360,7 +427,7 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
         const int nw = win_hi + 1 - w0 < kFrWin ? win_hi + 1 - w0 : kFrWin;  // window nodes of this pass
         if (chunk_ > 0) __syncthreads();  // the previous pass's buffers are free
         // ---- C2: the window's x rows (contiguous rows: coalesced) ------------------------------------------------------
-        {
+        if (!(pre_x && chunk_ == 0)) {   // (the first pass's rows are in LDS already when the window table gave their range up front)
             const int f4n = Hp >> 2;
             for (int base = 0; base < kFrWin * f4n; base += 2 * kFrThreads) {  // two slots per thread in flight
                 f32x4 v4[2];
@@ -389,7 +456,7 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
                 }
             }
         }
-        __syncthreads();
+        if (!(pre_x && chunk_ == 0)) __syncthreads();
         // ---- C3: q | v of the window's nodes: wave wn of each net takes M-tiles wn and wn + 4 (16 nodes each) -----------
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {

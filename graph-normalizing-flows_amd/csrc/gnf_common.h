@@ -57,6 +57,8 @@ struct HalfStep {
     float* cond_copy = nullptr;
     // attention nets: fragment-order copies of this half-step's two attention blocks (launch_attn_pack), or NULL
     const float* attn_packed[2] = {nullptr, nullptr};
+    // ... and the sender window (lo, hi) of every 16-row tile of the batch (launch_attn_tiles, once per flow call), or NULL
+    const int32_t* attn_tiles = nullptr;
     // large-batch kernel, split row tiles (gnf_fused_big.hip): > 0 = the caller zeroed big_split_flags(scratch, ...) at the
     // start of its call and hands every half-step launch a value of its own (1, 2, ...); 0 = no split tiles
     int32_t split_epoch = 0;
@@ -133,6 +135,7 @@ struct WorkspacePlan {
     size_t bn_const_offset;  // ... and the (scale, shift) pairs of every bijector of the call: n_halfsteps x [2][H] floats
     size_t attn_pack_offset; // floats: fragment-order attention weights of every net of the call, behind the attention region
     size_t attn_pack_per_net;
+    size_t attn_tile_offset; // floats: [tiles][2] ints, the attention front-end's per-tile sender windows (behind the packed weights)
     size_t scratch_floats;   // layered path activations (+ attention front-end region at its end)
     size_t base_floats;      // offset of the attention region inside the scratch
     size_t total_bytes;
@@ -283,6 +286,8 @@ int launch_attn_proj_mfma(const GnfAttn* const* at, int nets, int64_t n, const f
 bool attn_front_fused_ok(const GnfAttn* at, int32_t H);
 size_t attn_pack_floats(const GnfAttn* at, int32_t H);
 int launch_attn_pack(const GnfAttn* const* at, int count, int32_t H, float* out, hipStream_t st);
+// out[tiles][2]: sender window (lo, hi) of every 16-row tile (an empty tile: 0x7fffffff, -1)
+int launch_attn_tiles(const int32_t* rowptr, const int32_t* col, int64_t n, int32_t* out, hipStream_t st);
 int launch_attn_front_fused(const int32_t* rowptr, const int32_t* col, int64_t n, const float* x, int64_t ldx, int32_t H,
                             const GnfAttn* const* at, int nets, int32_t in0, const float* const* packed,
                             float* const* qkv_out, float* const* h0_out, hipStream_t st, float* const* agg_out = nullptr,

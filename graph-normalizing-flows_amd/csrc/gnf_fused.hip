@@ -694,6 +694,7 @@ static bool front_fold_ok(const HalfStep& hs, FrontArgs* fa) {
         fa->mz_out[0] = fa->agg_out[1] + n * NV, fa->mz_out[1] = fa->mz_out[0] + n * 3 * a0->num_heads;
     }
     fa->rowptr = hs.rowptr, fa->col = hs.col, fa->x = hs.x_cond, fa->ldx = hs.ld;
+    fa->tiles = hs.attn_tiles;
     fa->n_nodes = (int32_t)hs.n_nodes;
     fa->concat = a0->concat ? 1 : 0;
     fa->in0 = in0;
