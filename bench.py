@@ -462,6 +462,11 @@ def main():
     if WORKLOAD.get("train"):
         from gnf_amd.train import GRevNetTrainer
         trainer = GRevNetTrainer(net, lr=1e-5, use_lr_decay=False)
+    # Training workloads step on ONE fixed batch of noise: a wide flow memorises it and the likelihood grows without bound
+    # (finite through 300 steps of the data driver's nets, NaN somewhere past that - measured).  Every timed region
+    # therefore starts from the same initial variables and optimiser state (restored OUTSIDE the timed region, the
+    # checkpoint helpers of examples/driver_utils.py), and the line's log-prob is the one after exactly K steps from there.
+    state0 = None
 
     def step(i):
         if trainer is not None:   # gradient all-reduce (one flat RCCL all-reduce) when sharded
@@ -495,6 +500,11 @@ def main():
             work.wait()
             host[j].copy_(t, non_blocking=True)
 
+    if trainer is not None:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "examples"))
+        from driver_utils import load_trainer_state, trainer_state
+        trainer.loss_and_grads(graph)        # (connects the variables)
+        state0 = trainer_state(trainer)
     prewarm_steps = 0
     if args.prewarm_ms > 0:
         t_pre = time.perf_counter()
@@ -514,6 +524,8 @@ def main():
     def timed_region():
         """EXACTLY args.steps steps between barrier + synchronize on both sides; MAX over ranks.  Every step of a region
         writes the same host rows (args.warmup + i): the rows are results, not a log."""
+        if state0 is not None:
+            load_trainer_state(trainer, state0)
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
@@ -857,6 +869,8 @@ def main():
                                  "algorithmic_flops_per_step": 3 * flops * 2 * HP["T"],
                                  "note": "3 x the forward's algorithmic flops per step (forward, dX chain, dW) / ms_per_step: the whole "
                                          "step incl. Adam, the re-pack and every small launch; `roofline` above is the forward flow alone"}
+        out["train_state"] = ("variables and optimiser state restored to the initial ones before every timed region (outside it): "
+                              "log_prob_xs_per_node is the value after exactly `steps` steps on the one fixed batch")
     if inverse:   # round-trip check f(g(z)) = z on the device (size-independent property)
         zg = net(graph, inverse=False)
         back, _ = net(zg, inverse=True)

@@ -160,8 +160,17 @@ inline size_t big_split_offset(int64_t n_nodes, int in0) { return ((size_t)n_nod
 inline size_t big_split_floats() { return (size_t)kBigSplitMax + (size_t)kBigSplitMax * 16 * 128; }
 int big_plan(int64_t n_nodes, int cus, int cap, int32_t* seg_n, int32_t* seg_sz, int32_t* seg_kind = nullptr, int32_t* xg0 = nullptr);  // -> workgroups; runs of (count, row tiles)
 int launch_half_big(FusedArgs& a, int64_t n_nodes, int cap, hipStream_t st, int* n_wg_out);
+// s, t as the last layer's partial products (launch_linear_big_fused): n_slab dense [N, H] slabs `stride` floats apart
+// behind the s / t pointers, + the layer's bias; s_out / t_out (nullable): where the summed rows are also written (the
+// training forward's stash).  n_slab == 0: s, t are the finished rows.
+struct SlabSrc {
+    int32_t n_slab;
+    int64_t stride;
+    const float *bias_s, *bias_t;
+    float *s_out, *t_out;
+};
 // coupling epilogue from global s / t [N, H] buffers (writes hs.partials, *hs.n_partials)
-int launch_coupling(const float* s, const float* t, const HalfStep& hs, const float* xres, hipStream_t st);
+int launch_coupling(const float* s, const float* t, const HalfStep& hs, const float* xres, hipStream_t st, const SlabSrc* slabs = nullptr);
 int launch_half_layered(const HalfStep& hs, float* scratch, hipStream_t st);
 int launch_attn_pair(const HalfStep& hs, float* scratch, float** h0_pair, hipStream_t st);
 int launch_gnn_layered(const int32_t* rowptr, const int32_t* col, int64_t n_nodes, const float* x,
@@ -236,7 +245,16 @@ inline bool linear_big_bwd_layer(int I, int O) { return O >= 512 && I >= 256; }
 // wide y = act(x W_j + b_j) of a pair of nets from their packed weights (gnf_linear_big.hip); 1 = not its case
 int launch_linear_big(const GnfMlp* const* nets, int nj, int j, const float* const* x, int64_t ldx, float* const* y, int64_t ldy,
                       int64_t n, int act, float alpha, int apply_act, hipStream_t st);
-
+// layers j and j + 1 = the last in one launch (the thin last layer out of the wide one's accumulators): slab[q] receives
+// *n_slabs = linear_big_fused_slabs(O_j) dense partial [n, O_{j+1}] products whose sum + b_{j+1} is the net's output;
+// y[q] == NULL: layer j's own output is not kept.  1 = not its case
+static constexpr int kLinearBigFusedMaxOut = 128;
+inline bool linear_big_fused_last(const GnfMlp* m, int j) {
+    return j >= 1 && j == m->num_layers - 1 && m->dims[j + 1] <= kLinearBigFusedMaxOut && linear_big_fwd_layer(m->dims[j - 1], m->dims[j]);
+}
+int launch_linear_big_fused(const GnfMlp* const* nets, int nj, int j, const float* const* x, int64_t ldx, float* const* y, int64_t ldy,
+                            float* const* slab, int32_t* n_slabs, int64_t n, int act, float alpha, hipStream_t st);
+int linear_big_fused_slabs(int O);
 // dX[q] = (dY[q] W_j^T) * act'(h[q]) of a pair of nets from their transposed packed fragments (h == NULL: no mask); 1 = not its case
 int launch_linear_big_dx(const GnfMlp* const* nets, int nj, int j, const float* const* dy, int64_t lddy, float* const* dx, int64_t lddx,
                          const float* const* h, int64_t ldh, int64_t n, int act, float alpha, hipStream_t st);

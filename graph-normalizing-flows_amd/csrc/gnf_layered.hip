@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void k_coupling(const float* __restrict__ s,
                                                   float* __restrict__ x_upd, int64_t ld,
                                                   int64_t n_nodes, int H, int inverse,
                                                   double* __restrict__ partials,
-                                                  const float* __restrict__ xres) {
+                                                  const float* __restrict__ xres, const SlabSrc sl) {
     __shared__ double sh[4];
     const int64_t total = n_nodes * H;
     const int64_t per_block = ((total + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
@@ -289,7 +289,15 @@ __global__ __launch_bounds__(256) void k_coupling(const float* __restrict__ s,
     for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
         const int64_t r = i / H;
         const int f = (int)(i - r * H);
-        float sv = s[r * lds_ + f], tv = t[r * lds_ + f];
+        float sv, tv;
+        if (sl.n_slab) {  // s, t = the last layer's bias + its partial products (launch_linear_big_fused), added in slab order
+            sv = sl.bias_s[f], tv = sl.bias_t[f];
+#pragma unroll 8
+            for (int k = 0; k < sl.n_slab; ++k) sv += s[k * sl.stride + r * lds_ + f], tv += t[k * sl.stride + r * lds_ + f];
+            if (sl.s_out) sl.s_out[r * lds_ + f] = sv, sl.t_out[r * lds_ + f] = tv;
+        } else {
+            sv = s[r * lds_ + f], tv = t[r * lds_ + f];
+        }
         if (xres) {  // attention block with residual (gnn.py:547-548): both nets' outputs += x_cond
             const float xr = xres[r * ld + f];
             sv += xr;
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(256) void k_coupling(const float* __restrict__ s,
 __global__ __launch_bounds__(256) void k_coupling_rows(const float* __restrict__ s, const float* __restrict__ t, int64_t lds_,
                                                        float* __restrict__ x_upd, int64_t ld, int64_t n_nodes, int H, int rows,
                                                        double* __restrict__ partials, const float* __restrict__ xres,
-                                                       double* __restrict__ bn_part) {
+                                                       double* __restrict__ bn_part, const SlabSrc sl) {
     __shared__ double sh[4];
     __shared__ double cs[2][256];
     const int tid = threadIdx.x;
@@ -326,6 +334,24 @@ __global__ __launch_bounds__(256) void k_coupling_rows(const float* __restrict__
                 const int64_t rr = r + u * lanes < r1 ? r + u * lanes : r;
                 sv[u] = s[rr * lds_ + c], tv[u] = t[rr * lds_ + c], xv[u] = x_upd[rr * ld + c];
                 xr[u] = xres ? xres[rr * ld + c] : 0.f;
+            }
+            if (sl.n_slab) {  // (see k_coupling)
+                const float bs = sl.bias_s[c], bt = sl.bias_t[c];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sv[u] += bs, tv[u] += bt;
+#pragma unroll 4
+                for (int k = 1; k < sl.n_slab; ++k) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int64_t rr = r + u * lanes < r1 ? r + u * lanes : r;
+                        sv[u] += s[k * sl.stride + rr * lds_ + c], tv[u] += t[k * sl.stride + rr * lds_ + c];
+                    }
+                }
+                if (sl.s_out) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (r + u * lanes < r1) sl.s_out[(r + u * lanes) * lds_ + c] = sv[u], sl.t_out[(r + u * lanes) * lds_ + c] = tv[u];
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -455,12 +481,31 @@ int launch_finalize(const double* a, int64_t na, const double* b, int64_t nb, do
 // (j < K - 1: the training forward's stash of the hidden activations, row stride ldbuf)
 static int run_mlps(const GnfMlp* const* nets, int nj, const float* const* h0, int64_t ld0, float* const* bufA,
                     float* const* bufB, int64_t ldbuf, float* const* outp, int64_t ldout, int64_t n,
-                    const GnfGnnSpec& g, hipStream_t st, float* const* keep = nullptr) {
+                    const GnfGnnSpec& g, hipStream_t st, float* const* keep = nullptr, SlabSrc* fuse = nullptr) {
     const GnfMlp* m = nets[0];
     const float* in[2] = {h0[0], h0[nj - 1]};
     int64_t ldin = ld0;
+    if (fuse) fuse->n_slab = 0;
     for (int j = 0; j < m->num_layers; ++j) {
         const bool last = (j == m->num_layers - 1);
+        if (fuse && nj == 2 && j + 2 == m->num_layers && linear_big_fused_last(m, j + 1) &&
+            (int64_t)linear_big_fused_slabs(m->dims[j + 1]) * m->dims[j + 2] <= ldbuf) {
+            // the wide layer in front of a thin last one takes it along (gnf_linear_big.hip): the partial products land in
+            // the ping-pong buffer this layer's output would have taken, the caller's coupling kernel adds them up
+            float* yq[2];
+            float* sq[2];
+            for (int q = 0; q < 2; ++q) yq[q] = keep ? keep[q * GNF_MAX_LAYERS + j] : nullptr, sq[q] = (j & 1) ? bufB[q] : bufA[q];
+            int32_t ns = 0;
+            const int rc = launch_linear_big_fused(nets, 2, j, in, ldin, yq, ldbuf, sq, &ns, n, g.activation, g.alpha, st);
+            if (rc == GNF_OK) {
+                fuse->n_slab = ns;
+                fuse->stride = n * (int64_t)m->dims[j + 2];
+                fuse->bias_s = nets[0]->b[j + 1], fuse->bias_t = nets[1]->b[j + 1];
+                fuse->s_out = sq[0], fuse->t_out = sq[1];  // (callers read: the slabs' bases)
+                return GNF_OK;
+            }
+            if (rc != 1) return rc;
+        }
         float* dst[2];
         for (int q = 0; q < 2; ++q) {
             const int qq = q < nj ? q : nj - 1;
@@ -653,6 +698,8 @@ int launch_half_layered(const HalfStep& hs, float* scratch, hipStream_t st) {
     }
     const float* h0s = h0;
     const float* h0t = h0;
+    SlabSrc fuse;
+    memset(&fuse, 0, sizeof(fuse));
     int rc;
     if (hs.s_net->attn) {
         float* h0_pair[2];
@@ -668,10 +715,16 @@ int launch_half_layered(const HalfStep& hs, float* scratch, hipStream_t st) {
         const GnfMlp* nets[2] = {hs.s_net, hs.t_net};
         const float* h0p[2] = {h0s, h0t};
         float* outs[2] = {sbuf, tbuf};
-        rc = run_mlps(nets, 2, h0p, in0, bufA, bufB, lmax, outs, H, n, hs.gnn, st, stash ? keep : nullptr);
+        const bool ln = hs.s_net->attn && hs.s_net->attn->layer_norm;  // (normalises finished rows in place)
+        rc = run_mlps(nets, 2, h0p, in0, bufA, bufB, lmax, outs, H, n, hs.gnn, st, stash ? keep : nullptr, ln ? nullptr : &fuse);
     }
     if (rc) return rc;
     const bool res = hs.s_net->attn && hs.s_net->attn->residual;
+    if (fuse.n_slab) {
+        const float *ss = fuse.s_out, *ts = fuse.t_out;
+        fuse.s_out = stash ? sbuf : nullptr, fuse.t_out = stash ? tbuf : nullptr;
+        return launch_coupling(ss, ts, hs, res ? hs.x_cond : nullptr, st, &fuse);
+    }
     if (hs.s_net->attn && hs.s_net->attn->layer_norm) {
         rc = launch_half_layer_norm(hs, sbuf, tbuf, res ? hs.x_cond : nullptr, st);
         if (rc) return rc;
@@ -706,15 +759,18 @@ int launch_attn_pair(const HalfStep& hs, float* scratch, float** h0_pair, hipStr
                              /*need_qkv=*/keep, hs.attn_packed, keep ? agg_out : nullptr, keep ? mz_out : nullptr);
 }
 
-int launch_coupling(const float* sbuf, const float* tbuf, const HalfStep& hs, const float* xres, hipStream_t st) {
+int launch_coupling(const float* sbuf, const float* tbuf, const HalfStep& hs, const float* xres, hipStream_t st, const SlabSrc* slabs) {
     const int64_t n = hs.n_nodes;
     const int H = hs.H;
+    SlabSrc sl;
+    memset(&sl, 0, sizeof(sl));
+    if (slabs) sl = *slabs;
     if (hs.bn_part && hs.n_bn && hs.direction == GNF_FORWARD && H <= 256 && n > 0) {
         // (16 rows per workgroup: (n + 15) / 16 partial rows - the caller sized both partial buffers for exactly that)
         const int rows = 16;
         const int64_t blocks = (n + rows - 1) / rows;
         hipLaunchKernelGGL(k_coupling_rows, dim3((unsigned)blocks), dim3(256), 0, st, sbuf, tbuf, (int64_t)H, hs.x_upd, hs.ld, n, H,
-                           rows, hs.partials, xres, hs.bn_part);
+                           rows, hs.partials, xres, hs.bn_part, sl);
         GNF_LAUNCH_CHECK("k_coupling_rows");
         *hs.n_partials = (int32_t)blocks;
         *hs.n_bn = (int32_t)blocks;
@@ -725,7 +781,7 @@ int launch_coupling(const float* sbuf, const float* tbuf, const HalfStep& hs, co
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_coupling, dim3((unsigned)blocks), dim3(256), 0, st, sbuf, tbuf, (int64_t)H,
-                       hs.x_upd, hs.ld, n, H, hs.direction == GNF_INVERSE ? 1 : 0, hs.partials, xres);
+                       hs.x_upd, hs.ld, n, H, hs.direction == GNF_INVERSE ? 1 : 0, hs.partials, xres, sl);
     GNF_LAUNCH_CHECK("k_coupling");
     *hs.n_partials = (int32_t)blocks;
     return GNF_OK;

@@ -41,7 +41,17 @@ struct LinBigArgs {
     float alpha;
     // the row tiles (16 rows) of a panel are dealt out over wg_per_panel workgroups: the first wg_rem of them own wg_base + 1
     int32_t wg_per_panel, wg_base, wg_rem;
+    // the thin LAST layer behind this one, multiplied out of the accumulators (wp2 != NULL): a workgroup's 256 activated
+    // output columns are 16 k-groups of the next layer's reduction, its partial [rows, O2] product goes to slab[net] +
+    // cb * slab_stride and the consumer adds the col_blocks slabs and the bias (k_coupling / k_coupling_rows)
+    const float* wp2[2];
+    float* slab[2];
+    int64_t slab_stride;
+    int32_t O2, ont2;
+    int32_t store_y;       // 0: nobody reads this layer's own output (inference): not written
 };
+
+static constexpr int kLbFuseTiles = kLinearBigFusedMaxOut / 16;  // widest fused next layer: 128 columns
 
 #define GNF_LB_LOAD_B(RSRC, VOFF, SOFF) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RSRC, VOFF, SOFF, 0))
 
@@ -171,9 +181,9 @@ __device__ __forceinline__ void lin_big_body(const LinBigArgs& a, float* __restr
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
             const int r = row0 + 16 * m + lrow;
-            if (r >= a.n || c >= a.O) continue;
             f32x4 v = acc[m][b];
             if (aux) {  // act'(pre) read off the stored activation: h > 0 <=> pre > 0 (the generic tile's EPI_MASK)
+                if (r >= a.n || c >= a.O) continue;
                 const float* pa = aux + (int64_t)r * a.ldaux + c;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -181,7 +191,9 @@ __device__ __forceinline__ void lin_big_body(const LinBigArgs& a, float* __restr
             } else if (a.apply_act) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], slope * v[q]);
+                acc[m][b] = v;
             }
+            if (r >= a.n || c >= a.O || !a.store_y) continue;
             float* p = y + (int64_t)r * a.ldy + c;
             if (yvec && c + 3 < a.O) {
                 *reinterpret_cast<f32x4*>(p) = v;
@@ -191,6 +203,48 @@ __device__ __forceinline__ void lin_big_body(const LinBigArgs& a, float* __restr
                 if (c + 2 < a.O) p[2] = v[2];
                 if (c + 3 < a.O) p[3] = v[3];
             }
+        }
+    }
+    if (a.wp2[net] == nullptr) return;
+    // The next (last, thin) layer on the accumulators: a lane's four consecutive columns of a row are the B operand of
+    // y2^T[16 t + .][row] += W2^T fragment x h^T, k-group = this wave's column tile (padded columns: zero activations x zero
+    // weight rows).  Row tile by row tile: the four waves' partial [16, O2] tiles meet in LDS (the activation buffer is free
+    // now), are added in wave order and written to this column block's slab.
+    const __amdgpu_buffer_rsrc_t rsrc2 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp2[net]), 0, (int)((unsigned)a.ont * (unsigned)a.ont2 * 1024u), 0x00020000);
+    const int PS = 16 * a.ont2 + 4;
+    float* __restrict__ part = act + wave * 16 * PS;
+    float* __restrict__ slab = a.slab[net] + (int64_t)cb * a.slab_stride;
+#pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        f32x4 y2[kLbFuseTiles];
+#pragma unroll
+        for (int t = 0; t < kLbFuseTiles; ++t) y2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b >= nv) continue;
+            f32x4 w2[kLbFuseTiles];
+#pragma unroll
+            for (int t = 0; t < kLbFuseTiles; ++t)
+                if (t < a.ont2) w2[t] = GNF_LB_LOAD_B(rsrc2, voff, ((ct0 + 4 * b) * a.ont2 + t) * 1024);
+#pragma unroll
+            for (int t = 0; t < kLbFuseTiles; ++t)
+                if (t < a.ont2) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) y2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[t][q], acc[m][b][q], y2[t], 0, 0, 0);
+                }
+        }
+        __syncthreads();  // (the last chunk / the previous row tile's partial tiles have been read)
+#pragma unroll
+        for (int t = 0; t < kLbFuseTiles; ++t)
+            if (t < a.ont2) *reinterpret_cast<f32x4*>(part + lrow * PS + 16 * t + 4 * lgrp) = y2[t];
+        __syncthreads();
+        for (int i = tid; i < 16 * a.O2; i += kLbThreads) {
+            const int r = i / a.O2, c = i - r * a.O2;
+            const int64_t gr = row0 + 16 * m + r;
+            if (gr >= a.n) continue;
+            const float* p = act + r * PS + c;
+            slab[gr * a.O2 + c] = ((p[0] + p[16 * PS]) + p[32 * PS]) + p[48 * PS];
         }
     }
 }
@@ -223,7 +277,7 @@ static inline int lb_pad16(int v) { return (v + 15) & ~15; }
 // caller runs the generic tile.
 static int launch_linear_big_impl(const GnfMlp* const* nets, int nj, int j, bool transposed, const float* const* x, int64_t ldx,
                                   float* const* y, int64_t ldy, const float* const* aux, int64_t ldaux, int64_t n, int act, float alpha,
-                                  int apply_act, hipStream_t st) {
+                                  int apply_act, hipStream_t st, float* const* slab = nullptr, int32_t* n_slabs = nullptr) {
     const GnfMlp* m = nets[0];
     // I / O: reduction length and output width of THIS product
     const int I = transposed ? m->dims[j + 1] : m->dims[j], O = transposed ? m->dims[j] : m->dims[j + 1];
@@ -266,6 +320,16 @@ static int launch_linear_big_impl(const GnfMlp* const* nets, int nj, int j, bool
     a.n = (int32_t)n, a.I = I, a.O = O, a.ipg = ipg, a.ont = ont, a.col_blocks = col_blocks;
     a.act = act, a.apply_act = apply_act, a.alpha = alpha;
     a.wg_per_panel = (int32_t)wpp, a.wg_base = wg_base, a.wg_rem = wg_rem;
+    a.wp2[0] = a.wp2[1] = nullptr, a.slab[0] = a.slab[1] = nullptr;
+    a.slab_stride = 0, a.O2 = a.ont2 = 0, a.store_y = 1;
+    if (slab) {  // layer j + 1 (the last one) out of this layer's accumulators
+        if (transposed || !apply_act || j + 2 != m->num_layers || !linear_big_fused_last(m, j + 1)) return 1;
+        const int O2 = m->dims[j + 2];
+        for (int q = 0; q < 2; ++q) a.wp2[q] = nets[q]->packed + woff + (int64_t)lb_pad16(I) * lb_pad16(O), a.slab[q] = slab[q];
+        a.slab_stride = n * O2, a.O2 = O2, a.ont2 = lb_pad16(O2) / 16;
+        a.store_y = y[0] != nullptr;
+        *n_slabs = col_blocks;
+    }
     hipLaunchKernelGGL(k_linear_big, dim3((unsigned)(wpp * panels)), dim3(kLbThreads), 0, st, a);
     GNF_LAUNCH_CHECK("k_linear_big");
     return GNF_OK;
@@ -275,6 +339,16 @@ int launch_linear_big(const GnfMlp* const* nets, int nj, int j, const float* con
                       int64_t n, int act, float alpha, int apply_act, hipStream_t st) {
     return launch_linear_big_impl(nets, nj, j, false, x, ldx, y, ldy, nullptr, 0, n, act, alpha, apply_act, st);
 }
+
+// Layers j and j + 1 (the thin last layer) of nets[0..2) in one launch: slab[q] receives *n_slabs partial [n, O_{j+1}] products
+// (dense, one after the other) whose sum + b_{j+1} is the net's output; y[q] == NULL: layer j's own output is not kept.
+// slab[q] has to hold lb_fused_slabs(O_j) * n * O_{j+1} floats.  1 = not this kernel's case.
+int launch_linear_big_fused(const GnfMlp* const* nets, int nj, int j, const float* const* x, int64_t ldx, float* const* y, int64_t ldy,
+                            float* const* slab, int32_t* n_slabs, int64_t n, int act, float alpha, hipStream_t st) {
+    return launch_linear_big_impl(nets, nj, j, false, x, ldx, y, ldy, nullptr, 0, n, act, alpha, 1, st, slab, n_slabs);
+}
+
+int linear_big_fused_slabs(int O) { return (lb_pad16(O) + kLbCols - 1) / kLbCols; }
 
 // dX[q] = (dY[q] W_j^T) * act'(h[q]) (h == NULL: no mask) from the transposed fragments every packed MLP carries
 int launch_linear_big_dx(const GnfMlp* const* nets, int nj, int j, const float* const* dy, int64_t lddy, float* const* dx, int64_t lddx,

@@ -910,6 +910,43 @@ def test_layered_mlp_row_stash_matches_the_recomputing_walk(community_medium, gn
         assert float(np.linalg.norm(a - c)) <= 2e-3 * max(float(np.linalg.norm(c)), 1e-3 * gmax * np.sqrt(c.size))
 
 
+@pytest.mark.parametrize("d,latent,act", [(14, 1280, "leaky_relu"), (200, 1040, "relu"), (256, 1280, "relu")],
+                         ids=["H7_leaky", "H100_ragged_hidden", "H128_widest"])
+def test_wide_layer_takes_the_thin_last_layer_along(community_medium, d, latent, act):
+    """Layered forward of nets too wide for the fused kernels: the wide layer in front of the thin last one multiplies it out
+    of its accumulators (k_linear_big's second epilogue, launch_linear_big_fused) and the coupling kernel adds the column
+    blocks' partial products and the bias.  Output widths that are no multiple of 4 or 16, a hidden width that is no
+    multiple of 256 (a column block with dead waves) and the widest last layer it takes (128): forward against the oracle,
+    the inverse through the same kernels, every gradient (stash mode: the coupling kernel also writes s, t into the slot)."""
+    from gnf_amd.flow import log_prob_terms
+    from gnf_amd.train import GRevNetTrainer
+    t = 2
+    hp = dict(D=d, latent=latent, K=3, T=t, agg="mean", combine="agg", epsilon=1.0, activation=act, weight_sharing=False)
+    nn, ne, s, r = _batch(community_medium, list(range(64)))
+    n = int(nn.sum())
+    x = (np.random.default_rng(9).standard_normal((n, d)) * 0.7).astype(np.float32)
+    p = O.make_grevnet_params(51, d // 2, latent, 3, t, final_scale=0.3)
+    ref = O.loss_and_grads(s, r, n, x, p, t, activation=act)
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    net = make_product_grevnet(hp, p)
+    terms = log_prob_terms(net, graph)
+    assert abs(float(terms["log_prob_xs_per_node"]) + ref["total_loss"] / n) <= 1e-4 * max(1.0, abs(ref["total_loss"] / n))
+    z = terms["z_graph"]
+    back = net(z, inverse=False)
+    np.testing.assert_allclose(back.nodes.cpu().numpy(), x, atol=3e-4, rtol=3e-4)
+    for stash in (True, False):
+        tr = GRevNetTrainer(make_product_grevnet(hp, p))
+        tr.stash_mlp_rows = stash
+        out = tr.loss_and_grads(graph)
+        torch.cuda.synchronize()
+        assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
+        gmax = max(float(np.abs(b).max()) for _, b in _flat(ref["grads"], False))
+        for (name, a), (_, c) in zip(_flat(tr.named_gradients(), False), _flat(ref["grads"], False)):
+            # (2-norm per tensor: single elements next to a relu kink of the reconstruction may land on the other side)
+            bound = 2e-3 * max(float(np.linalg.norm(c)), 1e-3 * gmax * np.sqrt(c.size))
+            assert float(np.linalg.norm(a - c)) <= bound, name
+
+
 def test_checkpoint_restore_of_a_wide_net_repacks_what_the_wide_kernels_read(community_medium, tmp_path):
     """examples/driver_utils.py save_checkpoint / load_checkpoint (the drivers' tf.train.Saver, run_grevnet.py:379,449-453) on a
     net too wide for the fused kernels: after the restore the forward through the packed middle layer (k_linear_big) equals
