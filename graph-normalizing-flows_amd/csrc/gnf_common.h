@@ -242,6 +242,9 @@ int launch_linear_splitk(const float* const* x, int64_t ldx, const float* const*
 // 51 vs 49.5 us in round 5: they stay on the generic tile, which keeps this kernel's profile one shape)
 inline bool linear_big_fwd_layer(int I, int O) { return I >= 512 && O >= 256; }
 inline bool linear_big_bwd_layer(int I, int O) { return O >= 512 && I >= 256; }
+// ... and a short reduction into a wide layer (the first layer of such a net) runs k_linear_short off Wp (whole reduction in
+// registers: at most 13 k-groups; activation rows loaded as 16-byte operand fragments: widths in whole float4s)
+inline bool linear_short_fwd_layer(int I, int O) { return I <= 208 && (I & 3) == 0 && O >= 256; }
 // wide y = act(x W_j + b_j) of a pair of nets from their packed weights (gnf_linear_big.hip); 1 = not its case
 int launch_linear_big(const GnfMlp* const* nets, int nj, int j, const float* const* x, int64_t ldx, float* const* y, int64_t ldy,
                       int64_t n, int act, float alpha, int apply_act, hipStream_t st);
@@ -252,6 +255,8 @@ static constexpr int kLinearBigFusedMaxOut = 128;
 inline bool linear_big_fused_last(const GnfMlp* m, int j) {
     return j >= 1 && j == m->num_layers - 1 && m->dims[j + 1] <= kLinearBigFusedMaxOut && linear_big_fwd_layer(m->dims[j - 1], m->dims[j]);
 }
+int launch_linear_short(const GnfMlp* const* nets, int nj, int j, const float* const* x, int64_t ldx, float* const* y, int64_t ldy,
+                        int64_t n, int act, float alpha, int apply_act, hipStream_t st);
 int launch_linear_big_fused(const GnfMlp* const* nets, int nj, int j, const float* const* x, int64_t ldx, float* const* y, int64_t ldy,
                             float* const* slab, int32_t* n_slabs, int64_t n, int act, float alpha, hipStream_t st);
 int linear_big_fused_slabs(int O);

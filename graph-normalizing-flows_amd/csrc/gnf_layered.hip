@@ -527,6 +527,7 @@ static int run_mlps(const GnfMlp* const* nets, int nj, const float* const* h0, i
             }
             // wide layers of a pair of nets with packed weights: the large-batch kernel's inner loop (gnf_linear_big.hip)
             int rc = launch_linear_big(nets, nj, j, xin, ldin, yq, lddst, n, g.activation, g.alpha, last ? 0 : 1, st);
+            if (rc == 1) rc = launch_linear_short(nets, nj, j, xin, ldin, yq, lddst, n, g.activation, g.alpha, last ? 0 : 1, st);
             if (rc == 1)
                 rc = launch_linear_splitk(xin, ldin, wq, bq, yq, lddst, nj, n, I, O, g.activation, g.alpha, last ? 0 : 1, sk,
                                           (size_t)n * (size_t)ldbuf, st);

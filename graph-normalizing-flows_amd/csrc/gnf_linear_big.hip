@@ -51,6 +51,7 @@ struct LinBigArgs {
     int32_t store_y;       // 0: nobody reads this layer's own output (inference): not written
 };
 
+static constexpr int kLinShortRowTiles = 4;  // k_linear_short: a round of workgroups is at most 4 x this many row tiles long
 static constexpr int kLbFuseTiles = kLinearBigFusedMaxOut / 16;  // widest fused next layer: 128 columns
 
 #define GNF_LB_LOAD_B(RSRC, VOFF, SOFF) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RSRC, VOFF, SOFF, 0))
@@ -349,6 +350,171 @@ int launch_linear_big_fused(const GnfMlp* const* nets, int nj, int j, const floa
 }
 
 int linear_big_fused_slabs(int O) { return (lb_pad16(O) + kLbCols - 1) / kLbCols; }
+
+// ---- short reductions into wide layers (the first layer of a wide net: 100 / 164 -> 2048) ----------------------------------
+// The other extreme of the same product: the reduction is a handful of k-groups and the OUTPUT is what costs (44 MB per
+// half-step on the data driver's batch).  Per 128 x 128 tile the generic kernel spent its time in prologue, barriers and
+// epilogue (36 us for 2.2 GFLOP on wide_fc, 48.5 us for 3.7 GFLOP on the data driver's nets); here nothing is staged at all:
+//   * a wave keeps the WHOLE reduction of its NB column tiles in registers (KG x NB fragments, loaded once per workgroup),
+//   * the activation rows come straight from global memory in operand order - with transposed accumulators the operand of
+//     lane (row r, group g) for k-group kg is the 16 bytes x[r][16 kg + 4 g ..], one dwordx4 load, no LDS, no barrier -
+//     the next row tile's fragments in flight behind this one's MFMAs,
+//   * a lane stores four consecutive columns of its row.
+// The four waves of a workgroup share the row loads through L1 and differ in their column tiles.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct LinShortArgs {
+    const float* x[2];
+    float* y[2];
+    const float* wp[2];
+    const float* bias[2];
+    int64_t ldx, ldy;
+    int32_t n, I, O, ipg, ont;
+    // a panel's row tiles are dealt over wg_per_panel workgroups, the first wg_rem of them take wg_base + 1 (k_linear_big's deal)
+    int32_t wg_per_panel, wg_base, wg_rem;
+    int32_t act, apply_act;
+    float alpha;
+};
+
+template <int KG, int NB>
+__global__ __launch_bounds__(kLbThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_linear_short(const LinShortArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    // block -> (panel = column block x net, row chunk): panel-major per XCD as in k_linear_big (the panel's fragments stay in one L2)
+    const int64_t nwg = gridDim.x, bid = blockIdx.x;
+    const int64_t xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
+    const int64_t L = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int panel = (int)(L / a.wg_per_panel), chunk = (int)(L - (int64_t)panel * a.wg_per_panel);
+    const int cb = panel >> 1, net = panel & 1;
+    const int ct0 = 4 * NB * cb + wave;  // column tiles ct0, + 4, ...
+    int nv = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) nv += ct0 + 4 * b < a.ont ? 1 : 0;
+    if (nv == 0) return;  // (no barrier in this kernel)
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp[net]), 0, (int)((unsigned)a.ipg * (unsigned)a.ont * 1024u), 0x00020000);
+    f32x4 w[KG][NB];
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)  // (k-groups past the layer's: the buffer's range check returns zeros)
+            w[kg][b] = GNF_LB_LOAD_B(rw, lane * 16, (kg * a.ont + ct0 + (b < nv ? 4 * b : 0)) * 1024);
+    f32x4 bv[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) bv[b] = *reinterpret_cast<const f32x4*>(a.bias[net] + 16 * (ct0 + (b < nv ? 4 * b : 0)) + 4 * lgrp);
+    const float* __restrict__ x = a.x[net];
+    float* __restrict__ y = a.y[net];
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)((int64_t)a.n * a.ldx * 4), 0x00020000);
+    constexpr int kOut = 0x7fffffff;
+    const int rt0 = chunk < a.wg_rem ? chunk * (a.wg_base + 1) : a.wg_rem * (a.wg_base + 1) + (chunk - a.wg_rem) * a.wg_base;
+    const int rt1 = rt0 + a.wg_base + (chunk < a.wg_rem ? 1 : 0);
+    // this lane's fragment of k-group kg starts 64 kg + 16 lgrp bytes into its row; only the layer's LAST k-group can be cut
+    // by the layer's width (whole float4s: a lane's fragment is inside or outside), those lanes read nothing
+    // (KG >= the layer's k-groups, all of them unrolled without a branch: a group past the layer's reads zeros on both sides)
+    const int i4 = 4 * a.I - 16 * lgrp;  // fragment of k-group kg inside the row <=> 64 kg < i4
+    auto row_off = [&](int rt) {
+        const int r = 16 * rt + lrow;
+        return rt < rt1 && r < a.n ? r * (int)a.ldx * 4 + 16 * lgrp : kOut;
+    };
+    const float slope = !a.apply_act ? 1.f : a.act == GNF_ACT_RELU ? 0.f : a.alpha;  // (max(v, 1 v) = v: no activation)
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)((int64_t)a.n * a.ldy * 4), 0x00020000);
+    f32x4 xf[KG];
+    {
+        const int ro = row_off(rt0);
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) xf[kg] = GNF_LB_LOAD_B(rx, 64 * kg < i4 ? ro : kOut, 64 * kg);
+        // (NB stores that write nothing: the loop is then entered with the same sequence of outstanding operations it is
+        // re-entered with - the wait counts in front of the MFMAs are the minimum over both ways in)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, ry, kOut, 16 * b, 0);
+    }
+    for (int rt = rt0; rt < rt1; ++rt) {
+        const int rn = row_off(rt + 1);  // the next row tile's fragments are requested behind the MFMAs that read this one's
+        f32x4 acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = bv[b];
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[kg][b][q], xf[kg][q], acc[b], 0, 0, 0);
+            xf[kg] = GNF_LB_LOAD_B(rx, 64 * kg < i4 ? rn : kOut, 64 * kg);
+            // (issue order pinned: the refill right behind the MFMAs that read the fragment - left alone the scheduler sinks
+            // all refills behind the tile's last MFMA and every row tile waits out a full load latency)
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NB, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // Stores through a buffer descriptor, every one of them issued on every path (rows past the batch, dead column tiles:
+        // offset out of range, nothing written).  With the stores inside branches the compiler has to assume the path WITHOUT
+        // them when it counts what is outstanding behind a fragment load, and its s_waitcnt vmcnt (loads and stores share the
+        // in-order counter on gfx9) then waits for the previous row tile's stores to be acknowledged in the middle of the MFMAs.
+        const int so = 16 * rt + lrow < a.n ? (16 * rt + lrow) * (int)a.ldy * 4 : kOut;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int c = 16 * (ct0 + 4 * b) + 4 * lgrp;
+            f32x4 v = acc[b];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], slope * v[q]);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, (so != kOut && b < nv && c < a.O) ? so + 4 * c : kOut, 0, 0);
+        }
+    }
+}
+
+// y[q] = act(x[q] W_j + b_j) for a short reduction into a wide layer; 1 = not this kernel's case
+int launch_linear_short(const GnfMlp* const* nets, int nj, int j, const float* const* x, int64_t ldx, float* const* y, int64_t ldy,
+                        int64_t n, int act, float alpha, int apply_act, hipStream_t st) {
+    const GnfMlp* m = nets[0];
+    const int I = m->dims[j], O = m->dims[j + 1];
+    // (operand fragments and output pieces are whole, aligned float4s; 32-bit buffer offsets)
+    if (nj != 2 || !nets[0]->packed || !nets[1]->packed || !linear_short_fwd_layer(I, O) || (ldx & 3) || (ldy & 3) || (O & 3) ||
+        ((reinterpret_cast<uintptr_t>(x[0]) | reinterpret_cast<uintptr_t>(x[1]) | reinterpret_cast<uintptr_t>(y[0]) |
+          reinterpret_cast<uintptr_t>(y[1])) & 15) ||
+        n * ldx * 4 >= ((int64_t)1 << 31) || n * ldy * 4 >= ((int64_t)1 << 31))
+        return 1;
+    const int ipg = lb_pad16(I) / 16, ont = lb_pad16(O) / 16;
+    const bool narrow = ipg > 8;              // longer reductions: two column tiles per wave (the fragments have to fit the registers)
+    const int cols = narrow ? 128 : 256;
+    const int col_blocks = (ont * 16 + cols - 1) / cols;
+    const int64_t n_rt = (n + 15) / 16, panels = (int64_t)col_blocks * 2;
+    if (n_rt * panels < 2 * (int64_t)big_cu_count()) return 1;
+    int64_t woff = 0, wtot = 0, boff = 0;
+    for (int i = 0; i < m->num_layers; ++i) {
+        const int64_t w = (int64_t)lb_pad16(m->dims[i]) * lb_pad16(m->dims[i + 1]);
+        if (i < j) woff += w, boff += lb_pad16(m->dims[i + 1]);
+        wtot += w;
+    }
+    LinShortArgs a;
+    for (int q = 0; q < 2; ++q) {
+        a.x[q] = x[q], a.y[q] = y[q];
+        a.wp[q] = nets[q]->packed + woff;
+        a.bias[q] = nets[q]->packed + wtot + boff;
+    }
+    a.ldx = ldx, a.ldy = ldy;
+    a.n = (int32_t)n, a.I = I, a.O = O, a.ipg = ipg, a.ont = ont;
+    // every CU slot (two workgroups per CU by registers) gets ONE workgroup per round with its share of the panel's row tiles
+    // (fixed chunks of 4 row tiles were 688 workgroups on 512 slots: two rounds for 1.34 rounds of work); rounds grow with the
+    // batch so that a workgroup's walk stays short enough to leave the dispatcher something to balance
+    const int64_t slots = 2 * (int64_t)big_cu_count();
+    const int64_t rounds = (n_rt * panels + kLinShortRowTiles * 4 * slots - 1) / (kLinShortRowTiles * 4 * slots);
+    int64_t wpp = (rounds * slots + panels - 1) / panels;
+    if (wpp > n_rt) wpp = n_rt;
+    a.wg_per_panel = (int32_t)wpp, a.wg_base = (int32_t)(n_rt / wpp), a.wg_rem = (int32_t)(n_rt % wpp);
+    a.act = act, a.apply_act = apply_act, a.alpha = alpha;
+    const dim3 grid((unsigned)(panels * wpp));
+    if (ipg <= 7)
+        hipLaunchKernelGGL((k_linear_short<7, 4>), grid, dim3(kLbThreads), 0, st, a);
+    else if (ipg == 8)
+        hipLaunchKernelGGL((k_linear_short<8, 4>), grid, dim3(kLbThreads), 0, st, a);
+    else if (ipg <= 11)
+        hipLaunchKernelGGL((k_linear_short<11, 2>), grid, dim3(kLbThreads), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_linear_short<13, 2>), grid, dim3(kLbThreads), 0, st, a);
+    GNF_LAUNCH_CHECK("k_linear_short");
+    return GNF_OK;
+}
 
 // dX[q] = (dY[q] W_j^T) * act'(h[q]) (h == NULL: no mask) from the transposed fragments every packed MLP carries
 int launch_linear_big_dx(const GnfMlp* const* nets, int nj, int j, const float* const* dy, int64_t lddy, float* const* dx, int64_t lddx,

@@ -94,7 +94,7 @@ static int pack_flow(const GnfFlow* flow, hipStream_t st) {
             if (!m->packed) continue;
             // nets too wide for LDS never run the fused kernels: of their fragment-order copies only what the wide-layer
             // kernel of the layered path reads (gnf_linear_big.hip: Wp of the layers linear_big_fwd_layer names and of a
-            // thin last layer it multiplies out of its accumulators - linear_big_fused_last -, WpT of the ones
+            // thin last layer it multiplies out of its accumulators - linear_big_fused_last -, Wp of a short reduction into a wide layer - linear_short_fwd_layer -, WpT of the ones
             // linear_big_bwd_layer names, and the bias rows) follows the weights - the full re-pack of the
             // data-backed trainer's 2048-wide nets was 1.1 ms per step and 1.5 GB
             const bool wide_only = !fused_fits_lds(m) && !fused_bwd_fits_lds(m);
@@ -105,7 +105,7 @@ static int pack_flow(const GnfFlow* flow, hipStream_t st) {
             for (int j = 0; j < m->num_layers; ++j) {
                 const int I = m->dims[j], O = m->dims[j + 1], Ip = pad16i(I), Op = pad16i(O);
                 float* pk = const_cast<float*>(m->packed);
-                const bool need_w = !wide_only || linear_big_fwd_layer(I, O) || linear_big_fused_last(m, j);
+                const bool need_w = !wide_only || linear_big_fwd_layer(I, O) || linear_big_fused_last(m, j) || linear_short_fwd_layer(I, O);
                 const bool need_wt = !wide_only || linear_big_bwd_layer(I, O);
                 if (need_w || need_wt) {
                     pb.d[cnt++] = PackDesc{m->W[j], m->b[j], need_w ? pk + woff : nullptr, pk + boff,

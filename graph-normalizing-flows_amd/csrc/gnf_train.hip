@@ -1856,6 +1856,7 @@ static int mlp_backward_generic(const BwdPlan& p, const BwdOperands& o, const Gn
             const float* xin[2] = {jobs[0].A, jobs[1].A};
             float* yq[2] = {jobs[0].C, jobs[1].C};
             rc = launch_linear_big(nets, 2, j, xin, sh.lda, yq, sh.ldc, n, gnn.activation, gnn.alpha, last ? 0 : 1, st);
+            if (rc == 1) rc = launch_linear_short(nets, 2, j, xin, sh.lda, yq, sh.ldc, n, gnn.activation, gnn.alpha, last ? 0 : 1, st);
             if (rc == GNF_OK) continue;
             if (rc != 1) return rc;
         }

@@ -910,23 +910,28 @@ def test_layered_mlp_row_stash_matches_the_recomputing_walk(community_medium, gn
         assert float(np.linalg.norm(a - c)) <= 2e-3 * max(float(np.linalg.norm(c)), 1e-3 * gmax * np.sqrt(c.size))
 
 
-@pytest.mark.parametrize("d,latent,act", [(14, 1280, "leaky_relu"), (200, 1040, "relu"), (256, 1280, "relu")],
-                         ids=["H7_leaky", "H100_ragged_hidden", "H128_widest"])
-def test_wide_layer_takes_the_thin_last_layer_along(community_medium, d, latent, act):
+@pytest.mark.parametrize("d,latent,act,combine", [(14, 1280, "leaky_relu", "agg"), (200, 1040, "relu", "agg"), (256, 1280, "relu", "agg"),
+                                                  (200, 1280, "leaky_relu", "concat")],
+                         ids=["H7_leaky", "H100_ragged_hidden", "H128_widest", "H100_concat_in200"])
+def test_wide_layer_takes_the_thin_last_layer_along(community_medium, d, latent, act, combine):
     """Layered forward of nets too wide for the fused kernels: the wide layer in front of the thin last one multiplies it out
     of its accumulators (k_linear_big's second epilogue, launch_linear_big_fused) and the coupling kernel adds the column
     blocks' partial products and the bias.  Output widths that are no multiple of 4 or 16, a hidden width that is no
     multiple of 256 (a column block with dead waves) and the widest last layer it takes (128): forward against the oracle,
-    the inverse through the same kernels, every gradient (stash mode: the coupling kernel also writes s, t into the slot)."""
+    the inverse through the same kernels, every gradient (stash mode: the coupling kernel also writes s, t into the slot).
+    The first layer of these nets is the short-reduction kernel's (k_linear_short: 100 -> 1040 with a column block of dead waves,
+    128 -> 1280 = 8 k-groups exactly, 200 -> 1280 = the widest reduction it holds in registers; 7 -> 1280 is not whole float4s
+    and stays on the generic tile)."""
     from gnf_amd.flow import log_prob_terms
     from gnf_amd.train import GRevNetTrainer
     t = 2
-    hp = dict(D=d, latent=latent, K=3, T=t, agg="mean", combine="agg", epsilon=1.0, activation=act, weight_sharing=False)
+    hp = dict(D=d, latent=latent, K=3, T=t, agg="mean", combine=combine, epsilon=0.0 if combine == "concat" else 1.0, activation=act,
+              weight_sharing=False)
     nn, ne, s, r = _batch(community_medium, list(range(64)))
     n = int(nn.sum())
     x = (np.random.default_rng(9).standard_normal((n, d)) * 0.7).astype(np.float32)
-    p = O.make_grevnet_params(51, d // 2, latent, 3, t, final_scale=0.3)
-    ref = O.loss_and_grads(s, r, n, x, p, t, activation=act)
+    p = O.make_grevnet_params(51, d // 2, latent, 3, t, combine=combine, final_scale=0.3)
+    ref = O.loss_and_grads(s, r, n, x, p, t, activation=act, combine=combine, epsilon=hp["epsilon"])
     graph = graph_from_arrays(nn, ne, s, r, x, DEV)
     net = make_product_grevnet(hp, p)
     terms = log_prob_terms(net, graph)
