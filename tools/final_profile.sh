@@ -17,11 +17,11 @@ if [ "$phase" = pmc ]; then
   for w in config2_train default_flags_train; do
     want $w && timeout 600 bash tools/pmc_shape.sh ${tag}_$w $w "" k_half_fused,k_half_bwd,k_reduce,k_attn,k_adam > gpurun_out/pmc_${tag}_$w.log 2>&1
   done
-  want wide_fc && timeout 600 bash tools/pmc_shape.sh ${tag}_wide_fc wide_fc "" k_gemm,k_splitk,k_aggregate,k_coupling > gpurun_out/pmc_${tag}_wide_fc.log 2>&1
+  want wide_fc && timeout 600 bash tools/pmc_shape.sh ${tag}_wide_fc wide_fc "" k_linear_short,k_gemm,k_splitk,k_aggregate,k_coupling > gpurun_out/pmc_${tag}_wide_fc.log 2>&1
   # the data driver's literal defaults (train_grevnet_with_data.py:40-46, 100-117): forward and one trainer step; the wide MLPs' trainer step alone
-  want data_default_flags && timeout 600 bash tools/pmc_shape.sh ${tag}_data_default_flags data_default_flags "" k_attn,k_gemm,k_bn,k_coupling,k_splitk > gpurun_out/pmc_${tag}_data_default_flags.log 2>&1
+  want data_default_flags && timeout 600 bash tools/pmc_shape.sh ${tag}_data_default_flags data_default_flags "" k_linear_short,k_attn,k_gemm,k_bn,k_coupling,k_splitk > gpurun_out/pmc_${tag}_data_default_flags.log 2>&1
   for w in data_default_flags_train wide_fc_train; do
-    want $w && timeout 900 bash tools/pmc_shape.sh ${tag}_$w $w "" k_gemm,k_attn,k_adam,k_pack,k_bn,k_coupling,k_aggregate > gpurun_out/pmc_${tag}_$w.log 2>&1
+    want $w && timeout 900 bash tools/pmc_shape.sh ${tag}_$w $w "" k_linear_short,k_gemm,k_attn,k_adam,k_pack,k_bn,k_coupling,k_aggregate > gpurun_out/pmc_${tag}_$w.log 2>&1
   done
 else
   for w in config2_fc config2_attn default_flags config4 config5 wide_fc config2_train default_flags_train data_default_flags data_default_flags_train wide_fc_train; do
