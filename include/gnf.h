@@ -310,7 +310,10 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                              gnf_stream_t aux_stream);
 
 /* Re-pack EVERY net of a flow (W/b -> `packed`, nets with packed == NULL skipped) in a handful of
- * launches; call after an optimiser step.  Nothing in the reference (weight pre-pack). */
+ * launches; call after an optimiser step.  Nothing in the reference (weight pre-pack).
+ * Nets too wide for the LDS-resident kernels (they run layer by layer): only what those kernels read of `packed` follows the
+ * weights - the wide layers' fragments in both orientations, the fragments of a short first layer and of a thin last layer,
+ * and every bias row; the other regions of such a net's `packed` are read by nothing. */
 int gnf_pack_flow(const GnfFlow* flow, gnf_stream_t stream);
 
 /* ABI v6: what follows the optimiser step for the batch-norm bijectors of a flow, all 2T of them in one launch:
