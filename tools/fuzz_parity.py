@@ -161,16 +161,168 @@ def run_case(idx, seed, verbose=False):
         return "ok (activation-kink coincidence, passes perturbed)" if res == "ok" else res
 
 
+def _run_wide_case(idx, seed, verbose=False):
+    """--wide: nets too wide for the fused kernels on batches of a few thousand nodes - the layered path's kernels
+    (k_linear_short, k_linear_big with and without the thin last layer in its epilogue, split-K tiles, the slab-adding coupling
+    kernels, the MLP-row stash in its layered mode) with random widths: hidden widths that are no multiple of 16 or 256,
+    input widths on both sides of every dispatch rule, 2 - 4 layers, batch norm, the data driver's attention block."""
+    from gnf_amd.flow import log_prob_terms
+    from gnf_amd.train import GRevNetTrainer
+    rng = np.random.default_rng([seed, idx, 77])
+    d = int(rng.choice([8, 14, 24, 52, 100, 128, 200, 256, 328, 400]))
+    latent = int(rng.choice([512, 528, 640, 1000, 1040, 1100, 1280, 1536]))
+    hp = dict(D=d, latent=latent, K=int(rng.integers(2, 5)), T=int(rng.integers(1, 3)), agg="mean",
+              combine=str(rng.choice(["agg", "concat"])), epsilon=float(rng.choice([0.0, 1.0])),
+              activation=str(rng.choice(["relu", "leaky_relu"])), weight_sharing=False)
+    attn = None
+    if rng.random() < 0.35:
+        w = int(rng.choice([16, 32, 64]))
+        attn = dict(num_heads=1, kq_dim=w, v_dim=w, out_dim=int(rng.choice([16, 40, 64])), concat=True, kq_dim_division=True,
+                    residual=False)
+        hp.update(attn=attn, activation="relu", combine="agg", epsilon=0.0)
+    use_bn = rng.random() < 0.5
+    if os.environ.get("FUZZ_BN"):        # (diagnosis: the same case with one thing changed)
+        use_bn = os.environ["FUZZ_BN"] == "1"
+    if os.environ.get("FUZZ_ACT"):
+        hp["activation"] = os.environ["FUZZ_ACT"]
+    if os.environ.get("FUZZ_K"):
+        hp["K"] = int(os.environ["FUZZ_K"])
+    if os.environ.get("FUZZ_LATENT"):
+        hp["latent"] = latent = int(os.environ["FUZZ_LATENT"])
+    sizes, tot = [], 0
+    target = int(rng.integers(1700, 3400))
+    while tot < target:
+        m = int(rng.integers(6, 60))
+        sizes.append(m)
+        tot += m
+    s_l, r_l, ne, off = [], [], [], 0
+    for m in sizes:
+        if attn or rng.random() < 0.5:   # complete graphs with self loops (the data driver's topology)
+            a, b = np.repeat(np.arange(m), m), np.tile(np.arange(m), m)
+        else:                             # symmetric ring + a few random edges
+            i = np.arange(m)
+            a = np.concatenate([i, (i + 1) % m, rng.integers(0, m, size=m)])
+            b = np.concatenate([(i + 1) % m, i, rng.integers(0, m, size=m)])
+        s_l.append(a + off), r_l.append(b + off), ne.append(len(a))
+        off += m
+    nn, ne = np.asarray(sizes, np.int32), np.asarray(ne, np.int32)
+    s, r = np.concatenate(s_l).astype(np.int32), np.concatenate(r_l).astype(np.int32)
+    n, t = int(nn.sum()), hp["T"]
+    x = (rng.standard_normal((n, d)) * 0.7).astype(np.float32)
+    if os.environ.get("FUZZ_PERTURB"):
+        x = (x + 1e-3 * np.random.default_rng(int(os.environ["FUZZ_PERTURB"])).standard_normal(x.shape)).astype(np.float32)
+    if attn:
+        p = O.make_attn_grevnet_params(idx, d // 2, latent, hp["K"], t, final_scale=0.3, **attn)
+    else:
+        p = O.make_grevnet_params(idx, d // 2, latent, hp["K"], t, combine=hp["combine"], final_scale=0.3)
+    if use_bn:
+        p["bn"] = O.make_bn_params(idx + 7, d // 2, t)
+    kw = dict(agg="mean", combine=hp["combine"], epsilon=hp["epsilon"], activation=hp["activation"])
+    desc = f"wide case {idx}: {hp} bn={use_bn} n={n} graphs={len(sizes)} E={len(s)}"
+    if verbose:
+        print(desc, flush=True)
+    ref = O.loss_and_grads(s, r, n, x, p, t, False, **kw)
+    if not np.isfinite(ref["total_loss"]) or np.abs(ref["z"]).max() > 1e3:
+        return "skipped (oracle overflow)"
+    graph = graph_from_arrays(nn, ne, s, r, x, "cuda:0")
+    net = make_product_grevnet(hp, p)
+    out = log_prob_terms(net, graph)
+    z = out["z_graph"].nodes.cpu().numpy()
+    tol = 5e-4 * max(1.0, float(np.abs(ref["z"]).max()))
+    assert np.abs(z - ref["z"]).max() <= tol, f"{desc}\n z max err {np.abs(z - ref['z']).max():.3e}"
+    lp_ref = -ref["total_loss"] / n
+    assert abs(float(out["log_prob_xs_per_node"]) - lp_ref) <= 2e-4 * max(1.0, abs(lp_ref)), \
+        f"{desc}\n log-prob {float(out['log_prob_xs_per_node'])} vs {lp_ref}"
+    if not use_bn:   # g(f(x)) = x through the same kernels (the bijectors' moving statistics aside)
+        back = net(out["z_graph"], inverse=False).nodes.cpu().numpy()
+        assert np.abs(back - x).max() <= 5e-4 * max(1.0, float(np.abs(x).max())), f"{desc}\n round trip {np.abs(back - x).max():.3e}"
+    flat = []
+
+    def scan(b, path):
+        if isinstance(b, dict):
+            for k in b:
+                scan(b[k], path + "." + k)
+        elif isinstance(b, (list, tuple)) and not isinstance(b, np.ndarray):
+            for i, v in enumerate(b):
+                scan(v, f"{path}[{i}]")
+        else:
+            flat.append((path, b))
+    scan(ref["grads"], "")
+    gmax = max(float(np.abs(b).max()) for _, b in flat)
+    # Bound per tensor, in the 2-norm: 6 x what the SAME autograd costs in float32 on the CPU on these inputs (relu kinks: a
+    # pre-activation within single-precision rounding of 0 takes the other branch of act' than the float64 run), at least 2e-3
+    r32 = O.loss_and_grads(s, r, n, x, p, t, False, dtype=torch.float32, **kw)
+    f32 = []
+    flat64, flat[:] = list(flat), []
+    scan(r32["grads"], "")
+    f32, flat = list(flat), flat64
+    floor = lambda c: max(float(np.linalg.norm(c)), 1e-3 * gmax * np.sqrt(c.size))   # noqa: E731
+    rel32 = max(float(np.linalg.norm(np.asarray(a) - c)) / floor(c) for (_, a), (_, c) in zip(f32, flat))
+    rel_bound = max(2e-3, 6.0 * rel32)
+    failed = []
+    for stash in (True, False):
+        tr = GRevNetTrainer(make_product_grevnet(hp, p))
+        tr.stash_mlp_rows = stash
+        bw = tr.loss_and_grads(graph)
+        torch.cuda.synchronize()
+        assert abs(float(bw["total_loss"]) - ref["total_loss"]) <= 2e-4 * max(n, abs(ref["total_loss"])), f"{desc}\n stash={stash}: loss"
+        got = tr.named_gradients()
+
+        def pick(a, path):
+            for tok in path.replace("]", "").replace("[", ".").split(".")[1:]:
+                a = a[int(tok)] if tok.isdigit() else a[tok]
+            return np.asarray(a)
+        recon = float((bw["reconstruction"] - graph.nodes).abs().max())
+        errs = []
+        for path, c in flat:
+            try:
+                a = pick(got, path)
+            except (KeyError, IndexError, TypeError):
+                continue
+            errs.append((float(np.linalg.norm(a - c)) / floor(c), path))
+        errs.sort(reverse=True)
+        if verbose:
+            print(f"  stash={stash}: reconstruction max err {recon:.2e}; worst tensors (2-norm, relative): "
+                  + ", ".join(f"{p_} {e:.1e}" for e, p_ in errs[:6]) + f"; float32 CPU autograd worst {rel32:.1e}", flush=True)
+        if errs[0][0] > rel_bound:
+            failed.append(f"{desc}\n stash={stash}: grad{errs[0][1]} 2-norm err {errs[0][0]:.3e} relative > {rel_bound:.3e} (float32 CPU autograd: {rel32:.2e})")
+    assert not failed, "\n".join(failed)
+    return "ok"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--only", type=int, default=None)
+    ap.add_argument("--wide", action="store_true", help="the layered path's kernels: nets too wide for the fused kernels on batches of thousands of nodes")
     args = ap.parse_args()
     idxs = [args.only] if args.only is not None else range(args.cases)
     counts = {}
+    def wide(i, seed, verbose):
+        """One flipped relu costs ~1e-3 of a bias gradient's norm on these batches (a column sum of ~2 000 random-sign terms),
+        and the float32 CPU autograd shows flips of its own (1e-3 .. 3e-3) on about half of the inputs: a case that misses the
+        bound is re-run on up to three slightly perturbed inputs and passes when one of them has no flip on the device (every
+        tensor at ~3e-5 then); a defect does not go away under a 1e-3 perturbation."""
+        try:
+            return _run_wide_case(i, seed, verbose)
+        except AssertionError as e:
+            if ": grad" not in str(e):
+                raise
+            first = str(e)
+        for k in (1, 2, 3):
+            os.environ["FUZZ_PERTURB"] = str(k)
+            try:
+                if _run_wide_case(i, seed, verbose) == "ok":
+                    return "ok (activation-kink coincidence, passes perturbed)"
+            except AssertionError as e:
+                if ": grad" not in str(e):
+                    raise
+            finally:
+                os.environ.pop("FUZZ_PERTURB", None)
+        raise AssertionError(first)
     for i in idxs:
-        res = run_case(i, args.seed, verbose=args.only is not None)
+        res = (wide if args.wide else run_case)(i, args.seed, verbose=args.only is not None or args.wide)
         counts[res] = counts.get(res, 0) + 1
     print("fuzz parity:", counts)
 
