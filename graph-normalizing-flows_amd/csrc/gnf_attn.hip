@@ -338,10 +338,11 @@ __global__ __launch_bounds__(512) void k_attn_agg(const AttnArgs a, int RB) {
 }
 
 int validate_attn(const GnfAttn* at, const GnfMlp* mlp, int32_t H, const char* what) {
-    if (at->num_heads < 1 || at->num_heads > kAttnMaxHeads || at->kq_dim < 1 || at->v_dim < 1 || at->out_dim < 1 ||
-        (int64_t)at->num_heads * at->kq_dim > kAttnMaxWidth || (int64_t)at->num_heads * at->v_dim > kAttnMaxWidth) {
-        set_error("%s: attention dims heads=%d kq=%d v=%d out=%d outside heads in 1..%d, heads*kq <= %d, heads*v <= %d, out >= 1",
-                  what, at->num_heads, at->kq_dim, at->v_dim, at->out_dim, kAttnMaxHeads, kAttnMaxWidth, kAttnMaxWidth);
+    if (at->out_dim < 1 || !attn_geometry_ok(at->num_heads, at->kq_dim, at->v_dim, H)) {
+        set_error("%s: attention dims heads=%d kq=%d v=%d out=%d on H=%d outside heads in 1..%d, heads*kq <= %d, heads*v <= %d, "
+                  "pad16(2 heads kq + v) + pad16(H) + H <= %d, out >= 1",
+                  what, at->num_heads, at->kq_dim, at->v_dim, at->out_dim, H, kAttnMaxHeads, kAttnMaxWidth, kAttnMaxWidth,
+                  kAttnMaxRowFloats);
         return GNF_ESHAPE;
     }
     if (!at->Wq || !at->Wk || !at->Wv || !at->Wo) {

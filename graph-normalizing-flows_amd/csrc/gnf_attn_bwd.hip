@@ -1134,21 +1134,30 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
     a.scale = a0->kq_dim_division ? 1.f / sqrtf((float)a0->kq_dim) : 1.f;
     const int NV = a.nh * a.v, nq = a.nh * a.kq, P = 2 * nq + a.v;
     const int wmax = nq > NV ? nq : NV;
-    if (wmax > kAttnMaxWidth || a.nh > kAttnMaxHeads) {  // (validate_attn's limit: the entry point has rejected this already)
-        set_error("attention backward: heads=%d kq=%d v=%d outside heads <= %d, heads*kq <= %d, heads*v <= %d", a.nh, a.kq,
-                  a.v, kAttnMaxHeads, kAttnMaxWidth, kAttnMaxWidth);
+    if (wmax > kAttnMaxWidth || a.nh > kAttnMaxHeads || !attn_geometry_ok(a.nh, a.kq, a.v, H)) {  // (validate_attn's limit: the entry point has rejected this already)
+        set_error("attention backward: heads=%d kq=%d v=%d on H=%d outside heads <= %d, heads*kq <= %d, heads*v <= %d, "
+                  "pad16(2 heads kq + v) + pad16(H) + H <= %d", a.nh, a.kq, a.v, H, kAttnMaxHeads, kAttnMaxWidth, kAttnMaxWidth,
+                  kAttnMaxRowFloats);
         return GNF_ESHAPE;
     }
     const size_t fixed = attn_bwd_fixed_bytes(nq, NV, a.nh);
     const int cap_r = (int)((kWinBudget - fixed) / ((size_t)(nq + a.v + 1) * sizeof(float)));   // window rows, receiver pass
     const int cap_s = (int)((kWinBudget - fixed) / ((size_t)(nq + NV + 1) * sizeof(float)));    // window rows, sender pass
+    // dL/dx_cond: the matrix-core form (the caller's packed [Wq | Wk | Wv]^T; fits every geometry inside the limit by the
+    // limit's last clause), else both nets' whole weights in LDS
     const size_t lds_x = ((size_t)H * (P + 1) + (size_t)kDxRows * P + (size_t)2 * kDxRows * H) * sizeof(float);
-    if (lds_x > 160 * 1024 || cap_s < 1) {
-        set_error("attention backward: head geometry needs more LDS than a CU has");
+    const size_t lds_m = ((size_t)2 * kDxmRows * (((P + 15) & ~15) + 4) + (size_t)2 * kDxmRows * (((H + 15) & ~15) + 4) +
+                          (size_t)2 * kDxmRows * H) * sizeof(float);
+    const bool dx_mfma = wct && wct[0] && wct[1] && lds_m <= 160 * 1024;
+    if ((!dx_mfma && lds_x > 160 * 1024) || cap_s < 1) {
+        set_error("attention backward: heads=%d kq=%d v=%d on H=%d without the packed [Wq | Wk | Wv]^T needs more LDS than a CU has",
+                  a.nh, a.kq, a.v, H);
         return GNF_EUNSUPPORTED;
     }
     GNF_ONCE_PER_DEVICE(
         GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dx),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dx_mfma),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         const void* ks[6] = {reinterpret_cast<const void*>(k_attn_bwd_recv<1>), reinterpret_cast<const void*>(k_attn_bwd_recv<2>),
                              reinterpret_cast<const void*>(k_attn_bwd_recv<4>), reinterpret_cast<const void*>(k_attn_bwd_send<1>),
@@ -1278,10 +1287,8 @@ dx_pass:
     d.xc_src = xc_src, d.xc_ld = xc_ld, d.xc_dst = xc_dst;
     d.wct[0] = wct ? wct[0] : nullptr, d.wct[1] = wct ? wct[1] : nullptr;
     {   // the matrix-core form when the caller has the packed weights
-        const int Pp = (P + 15) & ~15, Hp = (H + 15) & ~15;
-        const size_t lds_m = ((size_t)2 * kDxmRows * (Pp + 4) + (size_t)2 * kDxmRows * (Hp + 4) + (size_t)2 * kDxmRows * H) * sizeof(float);
         const int64_t blocks_m = (n + kDxmRows - 1) / kDxmRows;
-        if (d.wct[0] && d.wct[1] && lds_m <= 64 * 1024) {
+        if (dx_mfma) {
             d.bn_y = nullptr, d.bn_ld = 0, d.bn_gamma = d.bn_beta = nullptr, d.bn_part = nullptr;
             if (bn && bn->n_parts) *bn->n_parts = 0;
             if (bn && bn->part && blocks_m <= kBnPartRowsMax) {

@@ -280,10 +280,18 @@ int launch_bn_backward(const GnfFlow* flow, const GnfBatchNorm* bn, const GnfBat
 
 int validate_mlp(const GnfMlp* m, const char* what);
 int validate_flow_call(const GnfCsr* csr, const GnfFlow* flow, int64_t ld, int32_t D, const char* what);
-// attention front-end (gnf_attn.hip).  THE limit of the head geometry (include/gnf.h, GnfAttn): heads <= 64,
-// heads * kq <= 256, heads * v <= 256 - validate_attn enforces it for the forward / inverse AND the backward entry points
+// attention front-end (gnf_attn.hip).  THE limit of the block's geometry (include/gnf.h, GnfAttn): heads <= 64,
+// heads * kq <= 256, heads * v <= 256, and pad16(2 heads kq + v) + pad16(H) + H <= 1272 (the backward pass's dL/dx_cond
+// product keeps sixteen rows of both nets' projections, products and operands in one CU's LDS, k_attn_bwd_dx_mfma) -
+// validate_attn enforces all of it for the forward / inverse AND the backward entry points
 static constexpr int kAttnMaxHeads = 64;
 static constexpr int kAttnMaxWidth = 256;
+static constexpr int kAttnMaxRowFloats = 1272;
+inline bool attn_geometry_ok(int heads, int kq, int v, int H) {
+    const int64_t nq = (int64_t)heads * kq, nv = (int64_t)heads * v, P = 2 * nq + v;
+    return heads >= 1 && heads <= kAttnMaxHeads && kq >= 1 && v >= 1 && nq <= kAttnMaxWidth && nv <= kAttnMaxWidth &&
+           ((P + 15) & ~(int64_t)15) + ((H + 15) & ~15) + H <= kAttnMaxRowFloats;
+}
 int validate_attn(const GnfAttn* at, const GnfMlp* mlp, int32_t H, const char* what);
 size_t attn_scratch_floats(const GnfAttn* at, int64_t n_nodes, int32_t in0);
 // need_qkv: the caller reads the per-node q | k | v block of `scratch` afterwards (backward pass, attention stash)

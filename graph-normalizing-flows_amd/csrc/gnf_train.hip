@@ -2089,23 +2089,26 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
     // kernel then forms dagg = dnew Wo^T itself (its last table row) and the GEMM launch in front of the edge kernels
     // goes (7.7 us per half-step on the config-2 batch).
     bool wot_packed = false;
-    if (flow->s_nets[0].attn && n_nets_each <= 32) {
-        PackWot pw;
-        memset(&pw, 0, sizeof(pw));
-        for (int k = 0; k < n_nets_each; ++k) {
-            for (int q = 0; q < 2; ++q) {
-                const GnfAttn* at = q ? flow->t_nets[k].attn : flow->s_nets[k].attn;
-                const int ix = q * n_nets_each + k;
-                pw.wo[ix] = at->Wo, pw.wq[ix] = at->Wq, pw.wk[ix] = at->Wk, pw.wv[ix] = at->Wv;
-                pw.out[ix] = wsf + p.wot + (size_t)ix * p.wot_each;
-                pw.out_ct[ix] = wsf + p.wct + (size_t)ix * p.wct_each;
+    if (flow->s_nets[0].attn) {
+        for (int k0 = 0; k0 < n_nets_each; k0 += 32) {  // (64 pointers per array in the kernel's arguments: 32 nets of each kind a launch)
+            const int cnt = n_nets_each - k0 < 32 ? n_nets_each - k0 : 32;
+            PackWot pw;
+            memset(&pw, 0, sizeof(pw));
+            for (int k = 0; k < cnt; ++k) {
+                for (int q = 0; q < 2; ++q) {
+                    const GnfAttn* at = q ? flow->t_nets[k0 + k].attn : flow->s_nets[k0 + k].attn;
+                    const int slot = q * cnt + k, ix = q * n_nets_each + k0 + k;
+                    pw.wo[slot] = at->Wo, pw.wq[slot] = at->Wq, pw.wk[slot] = at->Wk, pw.wv[slot] = at->Wv;
+                    pw.out[slot] = wsf + p.wot + (size_t)ix * p.wot_each;
+                    pw.out_ct[slot] = wsf + p.wct + (size_t)ix * p.wct_each;
+                }
             }
+            pw.NV = p.NV, pw.C = p.C, pw.NVp = (p.NV + 15) & ~15, pw.Cp = (p.C + 15) & ~15;
+            pw.H = p.H, pw.nq = p.nh * p.kq, pw.vd = p.vd, pw.Pp = (p.P + 15) & ~15, pw.Hp = (p.H + 15) & ~15;
+            const int pack_elems = pw.NVp * pw.Cp > pw.Pp * pw.Hp ? pw.NVp * pw.Cp : pw.Pp * pw.Hp;
+            hipLaunchKernelGGL(k_pack_wot, dim3((unsigned)((pack_elems + 255) / 256), (unsigned)(2 * cnt)), dim3(256), 0, st, pw);
+            GNF_LAUNCH_CHECK("k_pack_wot");
         }
-        pw.NV = p.NV, pw.C = p.C, pw.NVp = (p.NV + 15) & ~15, pw.Cp = (p.C + 15) & ~15;
-        pw.H = p.H, pw.nq = p.nh * p.kq, pw.vd = p.vd, pw.Pp = (p.P + 15) & ~15, pw.Hp = (p.H + 15) & ~15;
-        const int pack_elems = pw.NVp * pw.Cp > pw.Pp * pw.Hp ? pw.NVp * pw.Cp : pw.Pp * pw.Hp;
-        hipLaunchKernelGGL(k_pack_wot, dim3((unsigned)((pack_elems + 255) / 256), (unsigned)(2 * n_nets_each)), dim3(256), 0, st, pw);
-        GNF_LAUNCH_CHECK("k_pack_wot");
         wot_packed = true;
     }
     const bool reuse_sets = 2 * T > p.n_sets;

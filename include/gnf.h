@@ -80,7 +80,9 @@ typedef struct GnfCsr {
 #define GNF_LN_EPS 1e-5f
 typedef struct GnfAttn {
     /* ONE limit, checked by every entry point that takes the block (forward, inverse, backward): num_heads in 1..64 and
-     * num_heads * kq_dim <= 256 and num_heads * v_dim <= 256 (GNF_ESHAPE otherwise).  Inside it every geometry runs; the
+     * num_heads * kq_dim <= 256 and num_heads * v_dim <= 256 and, with H = D / 2 the width of the conditioning half,
+     * pad16(2 * num_heads * kq_dim + v_dim) + pad16(H) + H <= 1272 (sixteen rows of the backward pass's dL/dx_cond product in
+     * one CU's LDS; the drivers' geometries: H <= 544 / H <= 536) - GNF_ESHAPE otherwise.  Inside it every geometry runs; the
      * drivers' defaults have kernels of their own (run_grevnet.py:74-77: 8 heads, kq = v = 10, C = 80;
      * train_grevnet_with_data.py:40-46: 1 head, kq = v = 64, C = 64). */
     int32_t num_heads;

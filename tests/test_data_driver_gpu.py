@@ -170,11 +170,15 @@ BOUNDARY_SHAPES = [
     (1, 10, 10, 12, 24), (1, 16, 16, 16, 24), (1, 32, 32, 24, 24), (1, 33, 32, 24, 24), (1, 32, 33, 24, 24),
     (1, 64, 64, 64, 24), (1, 65, 64, 32, 24), (1, 64, 65, 32, 24), (2, 64, 16, 40, 24), (2, 33, 64, 40, 24),
     (9, 8, 8, 30, 24), (4, 64, 64, 48, 24), (1, 256, 256, 64, 24), (3, 40, 70, 50, 16),
+    # the limit's last clause, pad16(2 heads kq + v) + pad16(H) + H <= 1272 (sixteen rows of the backward pass's dL/dx_cond
+    # product in one CU's LDS): a wide feature half at the data driver's head (found by tools/fuzz_parity.py --wide: the
+    # backward pass used to reject H = 200 at kq = v = 64 while the forward ran it), and the clause's edge for two geometries
+    (1, 64, 64, 16, 400), (4, 64, 64, 48, 688), (1, 256, 256, 64, 496),
 ]
 
 
 @pytest.mark.parametrize("dense", [True, False], ids=["complete_graphs", "dataset_topology"])
-@pytest.mark.parametrize("shape", BOUNDARY_SHAPES, ids=[f"h{s[0]}_kq{s[1]}_v{s[2]}_C{s[3]}" for s in BOUNDARY_SHAPES])
+@pytest.mark.parametrize("shape", BOUNDARY_SHAPES, ids=[f"h{s[0]}_kq{s[1]}_v{s[2]}_C{s[3]}" + (f"_D{s[4]}" if s[4] > 24 else "") for s in BOUNDARY_SHAPES])
 def test_attention_head_geometry_boundaries(community_medium, shape, dense):
     """Forward, inverse and gradients for head geometries around every dispatch boundary, on complete graphs (mean
     degree ~40: the rows / matrix-core kernels) and on the dataset's sparse topology (the edge-tiled / front-end kernels)."""
@@ -202,19 +206,42 @@ def test_attention_head_geometry_boundaries(community_medium, shape, dense):
 
 
 def test_head_geometry_beyond_the_abi_limit_is_rejected(grid_small):
-    """include/gnf.h states ONE limit (heads <= 64, heads * kq <= 256, heads * v <= 256); forward and backward reject
-    anything beyond it with GNF_ESHAPE instead of running an untested shape."""
+    """include/gnf.h states ONE limit (heads <= 64, heads * kq <= 256, heads * v <= 256, pad16(2 heads kq + v) + pad16(H) + H
+    <= 1272); forward and backward reject anything beyond it with GNF_ESHAPE instead of running an untested shape - the
+    feature-width clause one element past the two edges test_attention_head_geometry_boundaries runs."""
     from gnf_amd import _abi
     from gnf_amd.flow import log_prob_terms
     nn, ne, s, r = _complete_batch(grid_small[0][[6]])
     n = int(nn.sum())
-    x = np.zeros((n, 8), np.float32)
-    for nh, kq, vd in ((1, 257, 8), (1, 8, 257), (5, 52, 8), (65, 2, 2)):
+    for nh, kq, vd, d in ((1, 257, 8, 8), (1, 8, 257, 8), (5, 52, 8, 8), (65, 2, 2, 8), (1, 256, 256, 498), (4, 64, 64, 690)):
+        x = np.zeros((n, d), np.float32)
         attn = dict(num_heads=nh, kq_dim=kq, v_dim=vd, out_dim=8, concat=True, kq_dim_division=True, residual=False)
-        p = O.make_attn_grevnet_params(1, 4, 16, 2, 1, final_scale=0.3, **attn)
-        net = make_product_grevnet(_hp(8, 16, 2, 1, attn), p)
+        p = O.make_attn_grevnet_params(1, d // 2, 16, 2, 1, final_scale=0.3, **attn)
+        net = make_product_grevnet(_hp(d, 16, 2, 1, attn), p)
         with pytest.raises(_abi.GnfError, match="heads"):
             log_prob_terms(net, graph_from_arrays(nn, ne, s, r, x, DEV))
+
+
+def test_more_than_32_timesteps_pack_their_attention_weights_in_batches(grid_small):
+    """T = 33 without weight sharing: 33 s-nets and 33 t-nets.  The backward pass packs Wo^T and [Wq | Wk | Wv]^T of every net
+    once per call, 32 nets of either kind per launch (the kernel's argument block holds 64 pointers per array); flows deeper
+    than 32 steps used to skip the pack and take the kernels that read the raw weights.  Every gradient against the oracle."""
+    from gnf_amd.train import GRevNetTrainer
+    d, latent, k, t = 8, 16, 2, 33
+    attn = dict(num_heads=2, kq_dim=4, v_dim=4, out_dim=6, concat=True, kq_dim_division=True, residual=False)
+    nn, ne, s, r = _complete_batch(grid_small[0][[6, 0, 7]])
+    n = int(nn.sum())
+    rng = np.random.default_rng(33)
+    x = (rng.standard_normal((n, d)) * 0.8).astype(np.float32)
+    p = O.make_attn_grevnet_params(34, d // 2, latent, k, t, final_scale=0.1, **attn)
+    net = make_product_grevnet(_hp(d, latent, k, t, attn), p)
+    graph, _ = _forward_inverse_vs_oracle(net, nn, ne, s, r, x, p, t, rng)
+    ref = O.loss_and_grads(s, r, n, x, p, t, activation="relu")
+    tr = GRevNetTrainer(net)
+    out = tr.loss_and_grads(graph)
+    torch.cuda.synchronize()
+    assert abs(float(out["total_loss"]) - ref["total_loss"]) <= 1e-4 * n
+    _check_all_grads(tr.named_gradients(), ref["grads"], 5e-4)
 
 
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "layered"])

@@ -161,7 +161,7 @@ def run_case(idx, seed, verbose=False):
         return "ok (activation-kink coincidence, passes perturbed)" if res == "ok" else res
 
 
-def _run_wide_case(idx, seed, verbose=False):
+def _run_wide_case(idx, seed, verbose=False, big=False):
     """--wide: nets too wide for the fused kernels on batches of a few thousand nodes - the layered path's kernels
     (k_linear_short, k_linear_big with and without the thin last layer in its epilogue, split-K tiles, the slab-adding coupling
     kernels, the MLP-row stash in its layered mode) with random widths: hidden widths that are no multiple of 16 or 256,
@@ -171,6 +171,9 @@ def _run_wide_case(idx, seed, verbose=False):
     rng = np.random.default_rng([seed, idx, 77])
     d = int(rng.choice([8, 14, 24, 52, 100, 128, 200, 256, 328, 400]))
     latent = int(rng.choice([512, 528, 640, 1000, 1040, 1100, 1280, 1536]))
+    if big:   # --big: nets the fused kernels hold, on batches large enough for their large-batch forms (k_half_big, split row tiles, kernel A)
+        d = int(rng.choice([8, 14, 24, 64, 100, 128, 256]))
+        latent = int(rng.choice([32, 64, 100, 128, 200, 256]))
     hp = dict(D=d, latent=latent, K=int(rng.integers(2, 5)), T=int(rng.integers(1, 3)), agg="mean",
               combine=str(rng.choice(["agg", "concat"])), epsilon=float(rng.choice([0.0, 1.0])),
               activation=str(rng.choice(["relu", "leaky_relu"])), weight_sharing=False)
@@ -179,6 +182,9 @@ def _run_wide_case(idx, seed, verbose=False):
         w = int(rng.choice([16, 32, 64]))
         attn = dict(num_heads=1, kq_dim=w, v_dim=w, out_dim=int(rng.choice([16, 40, 64])), concat=True, kq_dim_division=True,
                     residual=False)
+        if big:   # the drivers' head shapes and their neighbours
+            w = int(rng.choice([4, 10, 16, 32]))
+            attn.update(num_heads=int(rng.choice([1, 2, 8])), kq_dim=w, v_dim=int(rng.choice([w, 10])), out_dim=int(rng.choice([8, 20, 80])))
         hp.update(attn=attn, activation="relu", combine="agg", epsilon=0.0)
     use_bn = rng.random() < 0.5
     if os.environ.get("FUZZ_BN"):        # (diagnosis: the same case with one thing changed)
@@ -190,14 +196,14 @@ def _run_wide_case(idx, seed, verbose=False):
     if os.environ.get("FUZZ_LATENT"):
         hp["latent"] = latent = int(os.environ["FUZZ_LATENT"])
     sizes, tot = [], 0
-    target = int(rng.integers(1700, 3400))
+    target = int(rng.integers(4000, 12000)) if big else int(rng.integers(1700, 3400))
     while tot < target:
-        m = int(rng.integers(6, 60))
+        m = int(rng.integers(6, 60)) if not big or rng.random() < 0.8 else int(rng.integers(100, 400))
         sizes.append(m)
         tot += m
     s_l, r_l, ne, off = [], [], [], 0
     for m in sizes:
-        if attn or rng.random() < 0.5:   # complete graphs with self loops (the data driver's topology)
+        if m < 100 and (attn or rng.random() < 0.5):   # complete graphs with self loops (the data driver's topology)
             a, b = np.repeat(np.arange(m), m), np.tile(np.arange(m), m)
         else:                             # symmetric ring + a few random edges
             i = np.arange(m)
@@ -296,6 +302,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--only", type=int, default=None)
     ap.add_argument("--wide", action="store_true", help="the layered path's kernels: nets too wide for the fused kernels on batches of thousands of nodes")
+    ap.add_argument("--big", action="store_true", help="the fused kernels' large-batch forms: nets they hold on batches of 4 000 - 12 000 nodes")
     args = ap.parse_args()
     idxs = [args.only] if args.only is not None else range(args.cases)
     counts = {}
@@ -305,7 +312,7 @@ def main():
         bound is re-run on up to three slightly perturbed inputs and passes when one of them has no flip on the device (every
         tensor at ~3e-5 then); a defect does not go away under a 1e-3 perturbation."""
         try:
-            return _run_wide_case(i, seed, verbose)
+            return _run_wide_case(i, seed, verbose, args.big)
         except AssertionError as e:
             if ": grad" not in str(e):
                 raise
@@ -313,7 +320,7 @@ def main():
         for k in (1, 2, 3):
             os.environ["FUZZ_PERTURB"] = str(k)
             try:
-                if _run_wide_case(i, seed, verbose) == "ok":
+                if _run_wide_case(i, seed, verbose, args.big) == "ok":
                     return "ok (activation-kink coincidence, passes perturbed)"
             except AssertionError as e:
                 if ": grad" not in str(e):
@@ -322,7 +329,7 @@ def main():
                 os.environ.pop("FUZZ_PERTURB", None)
         raise AssertionError(first)
     for i in idxs:
-        res = (wide if args.wide else run_case)(i, args.seed, verbose=args.only is not None or args.wide)
+        res = (wide if args.wide or args.big else run_case)(i, args.seed, verbose=args.only is not None or args.wide or args.big)
         counts[res] = counts.get(res, 0) + 1
     print("fuzz parity:", counts)
 
