@@ -174,9 +174,9 @@ def _run_wide_case(idx, seed, verbose=False, big=False):
     if big:   # --big: nets the fused kernels hold, on batches large enough for their large-batch forms (k_half_big, split row tiles, kernel A)
         d = int(rng.choice([8, 14, 24, 64, 100, 128, 256]))
         latent = int(rng.choice([32, 64, 100, 128, 200, 256]))
-    hp = dict(D=d, latent=latent, K=int(rng.integers(2, 5)), T=int(rng.integers(1, 3)), agg="mean",
+    hp = dict(D=d, latent=latent, K=int(rng.integers(2, 5)), T=int(rng.integers(1, 3)), agg=str(rng.choice(["mean", "mean", "sum"])),
               combine=str(rng.choice(["agg", "concat"])), epsilon=float(rng.choice([0.0, 1.0])),
-              activation=str(rng.choice(["relu", "leaky_relu"])), weight_sharing=False)
+              activation=str(rng.choice(["relu", "leaky_relu"])), weight_sharing=bool(rng.random() < 0.2))
     attn = None
     if rng.random() < 0.35:
         w = int(rng.choice([16, 32, 64]))
@@ -185,7 +185,9 @@ def _run_wide_case(idx, seed, verbose=False, big=False):
         if big:   # the drivers' head shapes and their neighbours
             w = int(rng.choice([4, 10, 16, 32]))
             attn.update(num_heads=int(rng.choice([1, 2, 8])), kq_dim=w, v_dim=int(rng.choice([w, 10])), out_dim=int(rng.choice([8, 20, 80])))
-        hp.update(attn=attn, activation="relu", combine="agg", epsilon=0.0)
+        if rng.random() < 0.3:          # --attn_layer_norm (gnn.py:550-552), with or without the residual
+            attn.update(layer_norm=True, residual=bool(rng.integers(0, 2)))
+        hp.update(attn=attn, activation="relu", agg="mean", combine="agg", epsilon=0.0)
     use_bn = rng.random() < 0.5
     if os.environ.get("FUZZ_BN"):        # (diagnosis: the same case with one thing changed)
         use_bn = os.environ["FUZZ_BN"] == "1"
@@ -217,17 +219,19 @@ def _run_wide_case(idx, seed, verbose=False, big=False):
     x = (rng.standard_normal((n, d)) * 0.7).astype(np.float32)
     if os.environ.get("FUZZ_PERTURB"):
         x = (x + 1e-3 * np.random.default_rng(int(os.environ["FUZZ_PERTURB"])).standard_normal(x.shape)).astype(np.float32)
+    ws = hp["weight_sharing"]
+    fs = 0.3 if hp["agg"] == "mean" else 0.02   # (sum over tens of neighbours: keep |s| moderate)
     if attn:
-        p = O.make_attn_grevnet_params(idx, d // 2, latent, hp["K"], t, final_scale=0.3, **attn)
+        p = O.make_attn_grevnet_params(idx, d // 2, latent, hp["K"], t, weight_sharing=ws, final_scale=0.3, **attn)
     else:
-        p = O.make_grevnet_params(idx, d // 2, latent, hp["K"], t, combine=hp["combine"], final_scale=0.3)
+        p = O.make_grevnet_params(idx, d // 2, latent, hp["K"], t, combine=hp["combine"], weight_sharing=ws, final_scale=fs)
     if use_bn:
         p["bn"] = O.make_bn_params(idx + 7, d // 2, t)
-    kw = dict(agg="mean", combine=hp["combine"], epsilon=hp["epsilon"], activation=hp["activation"])
+    kw = dict(agg=hp["agg"], combine=hp["combine"], epsilon=hp["epsilon"], activation=hp["activation"])
     desc = f"wide case {idx}: {hp} bn={use_bn} n={n} graphs={len(sizes)} E={len(s)}"
     if verbose:
         print(desc, flush=True)
-    ref = O.loss_and_grads(s, r, n, x, p, t, False, **kw)
+    ref = O.loss_and_grads(s, r, n, x, p, t, ws, **kw)
     if not np.isfinite(ref["total_loss"]) or np.abs(ref["z"]).max() > 1e3:
         return "skipped (oracle overflow)"
     graph = graph_from_arrays(nn, ne, s, r, x, "cuda:0")
@@ -257,7 +261,7 @@ def _run_wide_case(idx, seed, verbose=False, big=False):
     gmax = max(float(np.abs(b).max()) for _, b in flat)
     # Bound per tensor, in the 2-norm: 6 x what the SAME autograd costs in float32 on the CPU on these inputs (relu kinks: a
     # pre-activation within single-precision rounding of 0 takes the other branch of act' than the float64 run), at least 2e-3
-    r32 = O.loss_and_grads(s, r, n, x, p, t, False, dtype=torch.float32, **kw)
+    r32 = O.loss_and_grads(s, r, n, x, p, t, ws, dtype=torch.float32, **kw)
     f32 = []
     flat64, flat[:] = list(flat), []
     scan(r32["grads"], "")
