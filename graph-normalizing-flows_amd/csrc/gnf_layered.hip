@@ -273,39 +273,54 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh) {
     return tot;  // valid on thread 0
 }
 
+// V4: every row is whole, aligned float4s (H, ld, every pointer): a thread takes four consecutive features of a row per step -
+// a quarter of the loads, index divisions and stores (with the last layer's slabs a scalar element is 2 x n_slab + 2 loads:
+// 9.8 us per half-step on the 2 718 x 100 wide_fc batch)
+template <bool V4>
 __global__ __launch_bounds__(256) void k_coupling(const float* __restrict__ s,
                                                   const float* __restrict__ t, int64_t lds_,
                                                   float* __restrict__ x_upd, int64_t ld,
                                                   int64_t n_nodes, int H, int inverse,
                                                   double* __restrict__ partials,
                                                   const float* __restrict__ xres, const SlabSrc sl) {
+    typedef float vf __attribute__((ext_vector_type(V4 ? 4 : 1)));
+    constexpr int W = V4 ? 4 : 1;
     __shared__ double sh[4];
-    const int64_t total = n_nodes * H;
+    const int Hw = H / W;
+    const int64_t total = n_nodes * Hw;
     const int64_t per_block = ((total + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
     const int64_t beg = (int64_t)blockIdx.x * per_block;
     int64_t end = beg + per_block;
     if (end > total) end = total;
     double local = 0.0;
+    auto ldv = [](const float* p) { return *reinterpret_cast<const vf*>(p); };
     for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
-        const int64_t r = i / H;
-        const int f = (int)(i - r * H);
-        float sv, tv;
+        const int64_t r = i / Hw;
+        const int f = (int)(i - r * Hw) * W;
+        vf sv, tv;
         if (sl.n_slab) {  // s, t = the last layer's bias + its partial products (launch_linear_big_fused), added in slab order
-            sv = sl.bias_s[f], tv = sl.bias_t[f];
+            sv = ldv(sl.bias_s + f), tv = ldv(sl.bias_t + f);
 #pragma unroll 8
-            for (int k = 0; k < sl.n_slab; ++k) sv += s[k * sl.stride + r * lds_ + f], tv += t[k * sl.stride + r * lds_ + f];
-            if (sl.s_out) sl.s_out[r * lds_ + f] = sv, sl.t_out[r * lds_ + f] = tv;
+            for (int k = 0; k < sl.n_slab; ++k) sv += ldv(s + k * sl.stride + r * lds_ + f), tv += ldv(t + k * sl.stride + r * lds_ + f);
+            if (sl.s_out) *reinterpret_cast<vf*>(sl.s_out + r * lds_ + f) = sv, *reinterpret_cast<vf*>(sl.t_out + r * lds_ + f) = tv;
         } else {
-            sv = s[r * lds_ + f], tv = t[r * lds_ + f];
+            sv = ldv(s + r * lds_ + f), tv = ldv(t + r * lds_ + f);
         }
         if (xres) {  // attention block with residual (gnn.py:547-548): both nets' outputs += x_cond
-            const float xr = xres[r * ld + f];
+            const vf xr = ldv(xres + r * ld + f);
             sv += xr;
             tv += xr;
         }
-        const float xv = x_upd[r * ld + f];
-        x_upd[r * ld + f] = inverse ? (xv - tv) * expf(-sv) : xv * expf(sv) + tv;
-        local += (double)sv;
+        const vf xv = ldv(x_upd + r * ld + f);
+        vf y;
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            const float se = V4 ? sv[q] : sv[0], te = V4 ? tv[q] : tv[0], xe = V4 ? xv[q] : xv[0];
+            const float ye = inverse ? (xe - te) * expf(-se) : xe * expf(se) + te;
+            if (V4) y[q] = ye; else y[0] = ye;
+            local += (double)se;
+        }
+        *reinterpret_cast<vf*>(x_upd + r * ld + f) = y;
     }
     const double tot = block_sum_256(local, sh);
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
@@ -781,8 +796,16 @@ int launch_coupling(const float* sbuf, const float* tbuf, const HalfStep& hs, co
     const int64_t cap = coupling_blocks_max(n);
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_coupling, dim3((unsigned)blocks), dim3(256), 0, st, sbuf, tbuf, (int64_t)H,
-                       hs.x_upd, hs.ld, n, H, hs.direction == GNF_INVERSE ? 1 : 0, hs.partials, xres, sl);
+    uintptr_t al = reinterpret_cast<uintptr_t>(sbuf) | reinterpret_cast<uintptr_t>(tbuf) | reinterpret_cast<uintptr_t>(hs.x_upd) |
+                   reinterpret_cast<uintptr_t>(xres) | reinterpret_cast<uintptr_t>(sl.bias_s) | reinterpret_cast<uintptr_t>(sl.bias_t) |
+                   reinterpret_cast<uintptr_t>(sl.s_out) | reinterpret_cast<uintptr_t>(sl.t_out);
+    const bool v4 = (H & 3) == 0 && (hs.ld & 3) == 0 && (sl.stride & 3) == 0 && (al & 15) == 0;
+    if (v4)
+        hipLaunchKernelGGL(k_coupling<true>, dim3((unsigned)blocks), dim3(256), 0, st, sbuf, tbuf, (int64_t)H,
+                           hs.x_upd, hs.ld, n, H, hs.direction == GNF_INVERSE ? 1 : 0, hs.partials, xres, sl);
+    else
+        hipLaunchKernelGGL(k_coupling<false>, dim3((unsigned)blocks), dim3(256), 0, st, sbuf, tbuf, (int64_t)H,
+                           hs.x_upd, hs.ld, n, H, hs.direction == GNF_INVERSE ? 1 : 0, hs.partials, xres, sl);
     GNF_LAUNCH_CHECK("k_coupling");
     *hs.n_partials = (int32_t)blocks;
     return GNF_OK;
