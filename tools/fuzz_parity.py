@@ -195,10 +195,24 @@ def _run_wide_case(idx, seed, verbose=False, big=False):
         hp["activation"] = os.environ["FUZZ_ACT"]
     if os.environ.get("FUZZ_K"):
         hp["K"] = int(os.environ["FUZZ_K"])
+    if os.environ.get("FUZZ_T"):
+        hp["T"] = int(os.environ["FUZZ_T"])
+    if os.environ.get("FUZZ_D"):
+        hp["D"] = d = int(os.environ["FUZZ_D"])
+    if os.environ.get("FUZZ_ATTN"):      # "heads,kq,v,C" or "0"
+        if os.environ["FUZZ_ATTN"] == "0":
+            attn = None
+            hp.pop("attn", None)
+        else:
+            nh_, kq_, v_, c_ = (int(v) for v in os.environ["FUZZ_ATTN"].split(","))
+            attn = dict(num_heads=nh_, kq_dim=kq_, v_dim=v_, out_dim=c_, concat=True, kq_dim_division=True, residual=False)
+            hp.update(attn=attn, activation="relu", agg="mean", combine="agg", epsilon=0.0)
     if os.environ.get("FUZZ_LATENT"):
         hp["latent"] = latent = int(os.environ["FUZZ_LATENT"])
     sizes, tot = [], 0
     target = int(rng.integers(4000, 12000)) if big else int(rng.integers(1700, 3400))
+    if os.environ.get("FUZZ_NODES"):
+        target = int(os.environ["FUZZ_NODES"])
     while tot < target:
         m = int(rng.integers(6, 60)) if not big or rng.random() < 0.8 else int(rng.integers(100, 400))
         sizes.append(m)
