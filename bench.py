@@ -465,7 +465,7 @@ def main():
     # Training workloads step on ONE fixed batch of noise: a wide flow memorises it and the likelihood grows without bound
     # (finite through 300 steps of the data driver's nets, NaN somewhere past that - measured).  Every timed region
     # therefore starts from the same initial variables and optimiser state (restored OUTSIDE the timed region, the
-    # checkpoint helpers of examples/driver_utils.py), and the line's log-prob is the one after exactly K steps from there.
+    # gnf_amd.train.trainer_state / load_trainer_state), and the line's log-prob is the one after exactly K steps from there.
     state0 = None
 
     def step(i):
@@ -501,8 +501,7 @@ def main():
             host[j].copy_(t, non_blocking=True)
 
     if trainer is not None:
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "examples"))
-        from driver_utils import load_trainer_state, trainer_state
+        from gnf_amd.train import load_trainer_state, trainer_state
         trainer.loss_and_grads(graph)        # (connects the variables)
         state0 = trainer_state(trainer)
     prewarm_steps = 0
@@ -764,41 +763,43 @@ def main():
     kernel_us = 1e3 * float(np.median([a.elapsed_time(b) for a, b in evs])) / (2 * HP["T"]) if evs else float("nan")
     # ---- kernel A alone (gnf_aggregate_f32: the CSR segment-reduce the north_star asks HBM evidence for;
     # on the hot path it is fused into the half-step kernel's prologue) ------------------------------
-    agg_out = torch.empty(n_local, h, dtype=torch.float32, device=dev)
-    xin = graph.nodes[:, :h]
+    kernel_a = None      # (attention GNNs replace the aggregation: a workload that never launches k_aggregate reports none)
+    if not HP.get("attn"):
+        agg_out = torch.empty(n_local, h, dtype=torch.float32, device=dev)
+        xin = graph.nodes[:, :h]
 
-    def run_agg():
-        _abi.check(lib.gnf_aggregate_f32(C.byref(csr.desc), _abi.ptr(xin), xin.stride(0), h,
-                                         _abi.GNF_AGG_MEAN if HP["agg"] == "mean" else _abi.GNF_AGG_SUM,
-                                         _abi.ptr(agg_out), h, st), "gnf_aggregate_f32")
-    for _ in range(5):
-        run_agg()
-    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ea.record()
-    for _ in range(50):
-        run_agg()
-    eb.record()
-    torch.cuda.synchronize()
-    agg_us = 1e3 * ea.elapsed_time(eb) / 50
-    agg_bytes = 8 * n_local * h + 4 * e_local + 4 * n_local
-    kernel_a = {"kernel": "k_aggregate<4> (gnf_aggregate_f32)", "us": round(agg_us, 2),
-                "algorithmic_bytes": agg_bytes, "achieved_gbs": round(agg_bytes / agg_us / 1e3, 1),
-                "peak_gbs": PEAK_HBM_GBS, "frac": round(agg_bytes / agg_us / 1e3 / PEAK_HBM_GBS, 4),
-                "traffic": None, "traffic_gbs": None,
-                "note": "HIP events around gnf_aggregate_f32 alone, back to back (the launch inside a flow sees the previous "
-                        "kernel's rows come back through memory: the rocprofv3 average next to `traffic`); launch-latency-bound "
-                        "on small batches (a few us); 2.9 TB/s algorithmic on 77k-308k node batches (tools/probe_agg.py, profiles/)"}
-    try:   # counter evidence of kernel A inside this workload's flow, when a PMC pass of this build exists (k_half_big workloads)
-        pm_a = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        ka = next((v for k, v in pm_a.get("workloads", {}).get(args.workload, {}).get("kernels", {}).items() if k.startswith("k_aggregate")), None)
-        if ka and pm_a["workloads"][args.workload].get("source_stamp") == kernel_source_stamp(args.workload):
-            kernel_a["traffic"] = round(ka["traffic_bytes_per_launch"])
-            kernel_a["traffic_gbs"] = round(ka["hbm_gbs_over_rocprof_avg"], 1)
-            kernel_a["traffic_note"] = (f"rocprofv3 --pmc FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE of k_aggregate inside the flow, "
-                                        f"mean per launch; / its rocprofv3 average of {ka['rocprof_avg_us']} us = HBM-side GB/s "
-                                        f"(profiles/pmc_traffic.json, tag {pm_a['workloads'][args.workload].get('tag')}, kernel sources = this build)")
-    except (OSError, ValueError, KeyError):
-        pass
+        def run_agg():
+            _abi.check(lib.gnf_aggregate_f32(C.byref(csr.desc), _abi.ptr(xin), xin.stride(0), h,
+                                             _abi.GNF_AGG_MEAN if HP["agg"] == "mean" else _abi.GNF_AGG_SUM,
+                                             _abi.ptr(agg_out), h, st), "gnf_aggregate_f32")
+        for _ in range(5):
+            run_agg()
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record()
+        for _ in range(50):
+            run_agg()
+        eb.record()
+        torch.cuda.synchronize()
+        agg_us = 1e3 * ea.elapsed_time(eb) / 50
+        agg_bytes = 8 * n_local * h + 4 * e_local + 4 * n_local
+        kernel_a = {"kernel": "k_aggregate<4> (gnf_aggregate_f32)", "us": round(agg_us, 2),
+                    "algorithmic_bytes": agg_bytes, "achieved_gbs": round(agg_bytes / agg_us / 1e3, 1),
+                    "peak_gbs": PEAK_HBM_GBS, "frac": round(agg_bytes / agg_us / 1e3 / PEAK_HBM_GBS, 4),
+                    "traffic": None, "traffic_gbs": None,
+                    "note": "HIP events around gnf_aggregate_f32 alone, back to back (the launch inside a flow sees the previous "
+                            "kernel's rows come back through memory: the rocprofv3 average next to `traffic`); launch-latency-bound "
+                            "on small batches (a few us); 2.9 TB/s algorithmic on 77k-308k node batches (tools/probe_agg.py, profiles/)"}
+        try:   # counter evidence of kernel A inside this workload's flow, when a PMC pass of this build exists (k_half_big workloads)
+            pm_a = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            ka = next((v for k, v in pm_a.get("workloads", {}).get(args.workload, {}).get("kernels", {}).items() if k.startswith("k_aggregate")), None)
+            if ka and pm_a["workloads"][args.workload].get("source_stamp") == kernel_source_stamp(args.workload):
+                kernel_a["traffic"] = round(ka["traffic_bytes_per_launch"])
+                kernel_a["traffic_gbs"] = round(ka["hbm_gbs_over_rocprof_avg"], 1)
+                kernel_a["traffic_note"] = (f"rocprofv3 --pmc FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE of k_aggregate inside the flow, "
+                                            f"mean per launch; / its rocprofv3 average of {ka['rocprof_avg_us']} us = HBM-side GB/s "
+                                            f"(profiles/pmc_traffic.json, tag {pm_a['workloads'][args.workload].get('tag')}, kernel sources = this build)")
+        except (OSError, ValueError, KeyError):
+            pass
 
     flops, abytes = algorithmic_half_step(n_local, e_local, HP)
     # HBM-side bytes per launch come from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950

@@ -12,7 +12,11 @@ gradient exchange is one flat all-reduce (RCCL over xGMI), not one collective pe
 
 The drivers' default learning-rate decay (tf.train.exponential_decay, run_grevnet.py:341-347) is one line of
 `current_learning_rate`; any other schedule is the caller's business (`step(graph, learning_rate=...)`; the
---use_lr_schedule function and checkpoint / resume live in examples/driver_utils.py: out of this path's scope).
+--use_lr_schedule function lives in examples/driver_utils.py: out of this path's scope).
+
+The trainer's state (what tf.train.Saver checkpoints for the drivers, run_grevnet.py:379,449-453: variables, Adam slots,
+global_step, the bijectors' moving statistics) is `trainer_state` / `load_trainer_state` / `save_checkpoint` /
+`load_checkpoint` below; bench.py restores it before every timed region of a training workload.
 """
 import ctypes as C
 import math
@@ -90,6 +94,12 @@ class GRevNetTrainer:
         self._arena_epoch = -1
         self._aux = None         # second HIP stream: the weight-gradient GEMMs overlap the backward walk
         self.overlap_weight_grads = True     # False: no auxiliary stream for the weight-gradient GEMMs
+        # the MLP-row stash is memory for time (wide nets: 2T slots of every hidden activation - about 20 GB for 30 k nodes
+        # at the data driver's defaults): it is taken only while it fits this budget; beyond it the walk recomputes.
+        # None = at most `mlp_stash_free_fraction` of the memory the device has free when the stash is first needed.
+        self.mlp_stash_max_bytes = None
+        self.mlp_stash_free_fraction = 0.5
+        self.mlp_stash_declined = None       # (bytes asked, reason) of the last stash that was NOT taken
 
     # ---- parameter arena ---------------------------------------------------------------------
     def _ensure_arena(self, hdim, device):
@@ -287,15 +297,33 @@ class GRevNetTrainer:
         # message-passing nets on small batches: the same trade for the MLP rows (layer-0 inputs, hidden activations,
         # s and t of every half-step - what TensorFlow keeps for tf.gradients anyway): the backward kernels skip their
         # recompute half.  gnf_mlp_stash_bytes is 0 where the library would not use a stash.
+        if mlp_bytes and not self._ensure_mlp_stash(mlp_bytes, dev):
+            mlp_bytes = 0          # (GnfFlow.mlp_stash = NULL: the backward walk recomputes the MLP rows)
         if mlp_bytes:
-            if self._mlp_stash is None or self._mlp_stash.numel() < mlp_bytes or self._mlp_stash.device != dev:
-                self._mlp_stash = torch.empty(mlp_bytes, dtype=torch.uint8, device=dev)
             fwd_flow.mlp_stash, fwd_flow.mlp_stash_bytes = self._mlp_stash.data_ptr(), mlp_bytes
         try:
             return self._loss_and_grads(graph, n, d, dev)
         finally:   # plain forward calls of the same net must not write into (or rely on) the stashes
             fwd_flow.attn_stash, fwd_flow.attn_stash_bytes = None, 0
             fwd_flow.mlp_stash, fwd_flow.mlp_stash_bytes = None, 0
+
+    def _ensure_mlp_stash(self, mlp_bytes, dev):
+        """Make self._mlp_stash hold `mlp_bytes` on `dev` if the budget allows; False = train without the stash."""
+        if self._mlp_stash is not None and self._mlp_stash.numel() >= mlp_bytes and self._mlp_stash.device == dev:
+            return True
+        self._mlp_stash = None     # (a smaller one is released before the larger one is asked for)
+        free, _total = torch.cuda.mem_get_info(dev)
+        free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)   # the caching allocator's idle blocks
+        ok, why = mlp_stash_within_budget(mlp_bytes, free, self.mlp_stash_max_bytes, self.mlp_stash_free_fraction)
+        if ok:
+            try:
+                self._mlp_stash = torch.empty(mlp_bytes, dtype=torch.uint8, device=dev)
+                self.mlp_stash_declined = None
+                return True
+            except torch.OutOfMemoryError:
+                why = "allocation failed (device out of memory)"
+        self.mlp_stash_declined = (int(mlp_bytes), why)
+        return False
 
     def _loss_and_grads(self, graph, n, d, dev):
         lib = _abi.lib()
@@ -377,3 +405,54 @@ class GRevNetTrainer:
             self.all_reduce_gradients()
         self.apply_gradients(learning_rate)
         return out
+
+
+def mlp_stash_within_budget(stash_bytes, free_bytes, max_bytes=None, free_fraction=0.5):
+    """The trainer's rule for taking the MLP-row stash (pure arithmetic: tests/test_host_logic_cpu.py): within the caller's
+    cap when there is one, else within `free_fraction` of the device memory currently free (the backward workspace, the
+    attention stash and the next batch have to fit beside it).  Returns (ok, reason)."""
+    if max_bytes is not None:
+        if stash_bytes > max_bytes:
+            return False, f"{stash_bytes} bytes > mlp_stash_max_bytes = {max_bytes}"
+        return True, ""
+    if stash_bytes > free_fraction * free_bytes:
+        return False, f"{stash_bytes} bytes > {free_fraction:g} x {free_bytes} bytes free on the device"
+    return True, ""
+
+
+# ---- the trainer's state: what the drivers checkpoint through tf.train.Saver (run_grevnet.py:379, 449-453) --------------
+def trainer_state(tr):
+    """Everything a resumed run needs: parameters, Adam moments, step counter, batch-norm moving statistics (host copies)."""
+    if tr.theta is None:
+        raise RuntimeError("run a step (or loss_and_grads) first so that the variables exist")
+    return {"theta": tr.theta.detach().cpu(), "m": tr.m.detach().cpu(), "v": tr.v.detach().cpu(),
+            "global_step": tr.global_step,
+            "bn_moving": [(b.moving_mean.detach().cpu(), b.moving_variance.detach().cpu()) for b in tr._bns]}
+
+
+def load_trainer_state(tr, state):
+    """Restore `trainer_state`'s dict into a connected trainer; the matrix-core weight copies follow (gnf_pack_flow)."""
+    if tr.theta is None:
+        raise RuntimeError("connect the trainer first (run loss_and_grads on a batch)")
+    if state["theta"].numel() != tr.theta.numel():
+        raise ValueError(f"checkpoint has {state['theta'].numel()} parameters, the flow has {tr.theta.numel()}")
+    tr.theta.copy_(state["theta"])
+    tr.m.copy_(state["m"])
+    tr.v.copy_(state["v"])
+    tr.global_step = int(state["global_step"])
+    for b, (mm, mv) in zip(tr._bns, state["bn_moving"]):
+        b.moving_mean.copy_(mm)
+        b.moving_variance.copy_(mv)
+    dev = tr.theta.device
+    with torch.cuda.device(dev):
+        flow = tr.net._flow(tr.net.mlps("s")[0].layer_sizes[-1], dev)
+        if tr.net.fused:
+            _abi.check(_abi.lib().gnf_pack_flow(C.byref(flow), _abi.stream_ptr(dev)), "gnf_pack_flow")
+
+
+def save_checkpoint(tr, path):
+    torch.save(trainer_state(tr), path)
+
+
+def load_checkpoint(tr, path):
+    load_trainer_state(tr, torch.load(path, map_location="cpu"))

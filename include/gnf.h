@@ -26,8 +26,13 @@
  *     coupling halves are the column ranges [0, D/2) and [D/2, D), so tf.split / tf.concat
  *     (gnn.py:306,340,344,373) are zero-copy views.
  *   - the graph is given as CSR sorted by RECEIVER: for node r, col[rowptr[r] .. rowptr[r+1]) are
- *     the SENDERS of its incoming edges in original edge order (stable), which is the summation
- *     order of tf.unsorted_segment_sum on the reference's edge list.
+ *     the SENDERS of its incoming edges in original edge order (stable) - the order in which
+ *     tf.unsorted_segment_sum (CPU) adds a receiver's edges up on the reference's edge list.
+ *     Summation order actually taken: the fused kernels' in-kernel gathers add every row up sequentially in that
+ *     order; the stand-alone aggregation kernel (gnf_aggregate_f32, and the launch in front of the large-batch
+ *     kernel) does so for rows of up to 32 edges, and adds a longer row up as contiguous edge segments whose
+ *     partial sums are combined in a FIXED segment order (gnf_layered.hip: deterministic and bitwise reproducible,
+ *     but not the sequential sum - it differs from it in rounding only).
  */
 #ifndef GNF_H
 #define GNF_H
