@@ -151,6 +151,29 @@ def line_consistency_errors(d):
     return errs
 
 
+def secondary_entry(d):
+    """What the default run keeps of a child workload's line (secondary_workloads[wl]); training children also carry
+    train_roofline's fraction / flops and the counter traffic of the trainer step's dominant kernel."""
+    e = {"value": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "spread": d["spread"],
+         "frac": d["roofline"]["frac"], "kernel_us": d["roofline"]["kernel_us"],
+         "launches_per_step": d["roofline"]["launches_per_step"], "traffic": d["roofline"]["traffic"],
+         "algorithmic_flops_per_launch": d["roofline"]["algorithmic_flops_per_launch"],
+         "algorithmic_bytes_per_launch": d["roofline"]["algorithmic_bytes_per_launch"],
+         "nodes": d["config"]["nodes_total"], "edges": d["config"]["edges_total"], "workload": d["config"]["workload"],
+         "log_prob_xs_per_node": d.get("log_prob_xs_per_node"),
+         "round_trip_max_abs_err": d.get("round_trip_max_abs_err"),
+         "consistency": d.get("consistency")}
+    if d.get("kernel_a") is not None:          # (absent where the flow never launches k_aggregate: attention GNNs)
+        e["kernel_a"] = d["kernel_a"]
+    tr = d.get("train_roofline")
+    if tr:
+        e["train_roofline"] = {k: tr.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "algorithmic_flops_per_step",
+                                                      "traffic", "traffic_kernel")}
+        e["train_frac"] = tr["frac"]
+        e["frac_note"] = "`frac` / `kernel_us` are the forward flow alone inside the trainer step; `train_frac` is the whole step"
+    return e
+
+
 def percentiles(ms):
     a = np.sort(np.asarray(ms, np.float64))
     return {"p50_ms": round(float(np.percentile(a, 50)), 4), "p95_ms": round(float(np.percentile(a, 95)), 4),
@@ -805,13 +828,14 @@ def main():
     # HBM-side bytes per launch come from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
     # correction + WRITE_SIZE; tools/pmc_shape.sh + tools/summarize_profile.py): PMC counters cannot be
     # collected from inside this process.  Only quoted for the workload they were measured on.
-    traffic, traffic_note = None, "no PMC pass recorded for this workload"
+    traffic, traffic_note, traffic_kernel = None, "no PMC pass recorded for this workload", None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         ent = pm.get("workloads", {}).get(args.workload)
         if ent and net.fused:
             if ent.get("source_stamp") == kernel_source_stamp(args.workload):
                 traffic = round(ent["traffic_bytes_per_launch"])
+                traffic_kernel = ent.get("kernel")
                 traffic_note = (f"HBM-side bytes per launch of {ent.get('kernel')} from profiles/pmc_traffic.json "
                                 f"(rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE passes, tag {ent.get('tag')}, "
                                 f"kernel sources {ent.get('source_stamp')} = this build's {', '.join(sorted(set(WORKLOAD_SOURCES[args.workload])))})")
@@ -868,6 +892,7 @@ def main():
         out["train_roofline"] = {"bound": "mfma", "achieved": round(t_tf, 3), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                                  "frac": round(t_tf / PEAK_FP32_MATRIX_TFLOPS, 4),
                                  "algorithmic_flops_per_step": 3 * flops * 2 * HP["T"],
+                                 "traffic": traffic, "traffic_kernel": traffic_kernel,
                                  "note": "3 x the forward's algorithmic flops per step (forward, dX chain, dW) / ms_per_step: the whole "
                                          "step incl. Adam, the re-pack and every small launch; `roofline` above is the forward flow alone"}
         out["train_state"] = ("variables and optimiser state restored to the initial ones before every timed region (outside it): "
@@ -901,9 +926,16 @@ def main():
         sec, t_sec = {}, time.perf_counter()
         ksteps = args.secondary_steps or min(args.steps, 40)
         torch.cuda.synchronize()
-        for wl in ("config4", "config5", "config2_attn", "default_flags", "data_default_flags"):
-            cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", str(ksteps), "--warmup", str(min(args.warmup, 10)),
+        # forward workloads at --secondary-steps; the two trainer workloads (run_grevnet.py:344-377,440-447 on the config-2 batch;
+        # train_grevnet_with_data.py:380,478-554 with that driver's literal defaults) with their own step caps: the
+        # whole default run has to stay within a minute or so
+        children = [(wl, ksteps) for wl in ("config4", "config5", "config2_attn", "default_flags", "data_default_flags")]
+        children += [("config2_train", min(ksteps, 20)), ("data_default_flags_train", min(ksteps, 6))]
+        for wl, wsteps in children:
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", str(wsteps), "--warmup", str(min(args.warmup, 10 if wsteps > 6 else 2)),
                    "--repeats", "3", "--no-cpu-baseline", "--no-secondary", "--latency-steps", "0"]
+            if wl == "data_default_flags_train":
+                cmd += ["--prewarm-ms", "100"]
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -911,17 +943,7 @@ def main():
             except subprocess.TimeoutExpired:
                 err, lines = "timed out after 600 s", []
             if err is None:
-                d = json.loads(lines[-1])
-                sec[wl] = {"value": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "spread": d["spread"],
-                           "frac": d["roofline"]["frac"], "kernel_us": d["roofline"]["kernel_us"],
-                           "launches_per_step": d["roofline"]["launches_per_step"], "traffic": d["roofline"]["traffic"],
-                           "algorithmic_flops_per_launch": d["roofline"]["algorithmic_flops_per_launch"],
-                           "algorithmic_bytes_per_launch": d["roofline"]["algorithmic_bytes_per_launch"],
-                           "kernel_a": d.get("kernel_a"),
-                           "nodes": d["config"]["nodes_total"], "edges": d["config"]["edges_total"], "workload": d["config"]["workload"],
-                           "log_prob_xs_per_node": d.get("log_prob_xs_per_node"),
-                           "round_trip_max_abs_err": d.get("round_trip_max_abs_err"),
-                           "consistency": d.get("consistency")}
+                sec[wl] = secondary_entry(json.loads(lines[-1]))
             else:
                 sec[wl] = {"error": err}
         out["secondary_workloads"] = sec

@@ -608,7 +608,10 @@ static int choose_big(const HalfStep& hs) {
     if (!big_supported(s, hs.H) || hs.mlp_stash) return 0;
     if (hs.n_nodes * hs.ld >= (int64_t(1) << 31)) return 0;  // (its coupling loop indexes the rows with 32-bit offsets)
     if (s->attn && s->attn->layer_norm) return 0;  // (whole rows of s and t before the coupling: one-net-per-workgroup shape)
-    if (const int64_t force = opt(OPT_FORCE_SHAPE)) return (force % 10 == 0 && force >= 10 && force <= 40) ? (int)(force / 10) : 0;
+    if (const int64_t force = opt(OPT_FORCE_SHAPE)) {
+        if (force == kForceBigLostPartner) return 4;  // (fault injection for the tests: launch_half_fused withholds the hand-over flag)
+        return (force % 10 == 0 && force >= 10 && force <= 40) ? (int)(force / 10) : 0;
+    }
     const int64_t g = (hs.n_nodes + 15) / 16, c = big_cu_count();
     if (g <= 2 * c) return 0;  // one tile per CU or less: the 16- / 32-row both-nets shapes
     const double old_q = (double)((g + 2 * c - 1) / (2 * c));
@@ -749,7 +752,7 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
     memset(a.big_seg_n, 0, sizeof(a.big_seg_n));
     memset(a.big_seg_sz, 0, sizeof(a.big_seg_sz));
     memset(a.big_seg_kind, 0, sizeof(a.big_seg_kind));
-    a.big_xg0 = 0, a.big_epoch = 0, a.big_split_s = nullptr, a.big_split_flag = nullptr;
+    a.big_xg0 = 0, a.big_epoch = 0, a.big_epoch_set = 0, a.big_split_s = nullptr, a.big_split_flag = nullptr;
     a.x_upd_src = hs.x_upd_src ? hs.x_upd_src : hs.x_upd;
     a.cond_copy = hs.cond_copy;
     a.partials = hs.partials;
@@ -857,6 +860,10 @@ int launch_half_fused(const HalfStep& hs, float* scratch, hipStream_t st) {
                 a.big_split_flag = reinterpret_cast<int*>(scratch + off);
                 a.big_split_s = scratch + off + kBigSplitMax;
                 a.big_epoch = hs.split_epoch;
+                // force_shape = 49: the s-net workgroups of split tiles publish a value the t-net workgroups do not wait for -
+                // every split tile's partner is "lost" (the only way to execute that branch: in a healthy launch the flag is
+                // there half a launch before anybody looks at it)
+                a.big_epoch_set = opt(OPT_FORCE_SHAPE) == kForceBigLostPartner ? -hs.split_epoch : hs.split_epoch;
             }
         }
         int n_wg = 0;

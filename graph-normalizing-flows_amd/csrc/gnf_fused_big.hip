@@ -508,7 +508,7 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
                 }
                 __syncthreads();  // every wave is done with the s-net's last hidden rows
                 if (kind == 1 && tid == 0)
-                    __hip_atomic_store(a.big_split_flag + wrun, a.big_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.big_split_flag + wrun, a.big_epoch_set, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 load_h0(a.h0[1], mt_t);
                 __syncthreads();
             }

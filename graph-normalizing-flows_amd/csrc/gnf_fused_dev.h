@@ -52,6 +52,7 @@ struct FusedArgs {
     int32_t big_seg_kind[6];
     int32_t big_xg0;
     int32_t big_epoch;
+    int32_t big_epoch_set;  // what the kind-1 workgroup stores: big_epoch (anything else only under the tests' fault injection)
     float* big_split_s;
     int* big_split_flag;
     float eps, alpha;

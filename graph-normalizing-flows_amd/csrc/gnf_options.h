@@ -15,7 +15,8 @@ namespace gnf {
 
 enum OptionId {
     OPT_FORCE_SHAPE = 0,     // fused forward workgroup shape <MT><NETS>, e.g. 21; 40 / 30 / 20 / 10: the large-batch kernel with that many
-                             // row tiles per workgroup at most; 0 = by batch size
+                             // row tiles per workgroup at most; 49: that kernel (cap 4) with the split tiles' hand-over flag withheld -
+                             // fault injection, every split tile takes the lost-partner branch (NaN rows, NaN partial sums); 0 = by batch size
     OPT_ATTN_KERNEL,         // attention forward: 1 always the rows kernel, 2 always the edge-tiled kernel, 3 always the matrix-core
                              // attention core (each keeps the front-end out of the fused kernel's prologue); 0 = by batch / geometry
     OPT_ATTN_BWD_ROWS,       // attention rows kernels: 64 / 32 (backward also 16 and 3264) rows per workgroup; 0 = by batch size / mean degree
@@ -25,6 +26,7 @@ enum OptionId {
     OPT_COUNT
 };
 
+static constexpr int64_t kForceBigLostPartner = 49;
 extern std::atomic<int64_t> g_options[OPT_COUNT];
 inline int64_t opt(OptionId id) { return g_options[id].load(std::memory_order_relaxed); }
 

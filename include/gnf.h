@@ -196,7 +196,8 @@ int gnf_abi_version(void);
 /* Launch-shape forcing (ABI v6; the list was cut from 18 A/B switches to these 6 in round 4).  The library picks its kernel
  * instances by batch size; the parity tests force them on small batches through these named integers.  value 0 =
  * automatic.  force_shape: fused forward workgroup shape <MT><NETS>, e.g. 21; 40 / 30 / 20 / 10: the large-batch kernel
- * with that many row tiles per workgroup at most.  attn_kernel: 1 the attention rows kernels, 2 the edge-tiled kernel
+ * with that many row tiles per workgroup at most (49: cap 4 with the split row tiles' hand-over flag withheld - fault
+ * injection for the lost-partner branch, tests only).  attn_kernel: 1 the attention rows kernels, 2 the edge-tiled kernel
  * (either keeps the front-end out of the fused kernel's prologue).  attn_bwd_rows: 64 / 32 / 16 / 3264 rows per workgroup
  * of the attention rows / edge kernels.  bwd_generic: the backward pass through the generic GEMM path.  dw_grouped: weight
  * gradients through the grouped kernel.  dw_wide_units: the wide weight-gradient kernel with that many workgroups at most.

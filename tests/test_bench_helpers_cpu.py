@@ -131,3 +131,29 @@ def test_bench_gpus_n_without_devices_prints_an_error_line_and_fails():
     assert r.returncode == 2
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and "error" in d and d["devices_visible"] == 0
+
+
+def test_secondary_entry_keeps_the_trainer_fields():
+    """The default run's secondary_workloads: a forward child keeps roofline frac / kernel_us / traffic (and kernel_a only if
+    its flow launches k_aggregate); a training child also carries train_roofline (frac, flops per step, the dominant
+    kernel's counter traffic) - row f4's driver-timed evidence (round 6).  Checked on the committed round-5 lines."""
+    fwd = json.loads(open(os.path.join(ROOT, "profiles", "r5z_bench_config5.json")).read().strip().splitlines()[-1])
+    e = bench.secondary_entry(fwd)
+    assert e["frac"] == fwd["roofline"]["frac"] and e["kernel_a"]["kernel"].startswith("k_aggregate") and "train_frac" not in e
+    trn = json.loads(open(os.path.join(ROOT, "profiles", "r5z_bench_config2_train.json")).read().strip().splitlines()[-1])
+    e = bench.secondary_entry(trn)
+    assert e["train_frac"] == trn["train_roofline"]["frac"] and e["ms_per_step"] == trn["ms_per_step"]
+    assert e["train_roofline"]["algorithmic_flops_per_step"] == trn["train_roofline"]["algorithmic_flops_per_step"]
+    assert abs(e["train_frac"] - e["train_roofline"]["algorithmic_flops_per_step"] / (e["ms_per_step"] * 1e-3) / 1e12 / bench.PEAK_FP32_MATRIX_TFLOPS) < 2e-3
+    attn = dict(fwd, kernel_a=None)           # an attention workload's line (round 6): no kernel_a at all
+    assert "kernel_a" not in bench.secondary_entry(attn)
+    # every committed default-run line of round 6 carries both trainer children
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r6*_bench_config2_default_run.json")):
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        sw = d["secondary_workloads"]
+        for wl in ("config2_train", "data_default_flags_train"):
+            assert "error" not in sw[wl], (f, wl, sw[wl])
+            assert 0.0 < sw[wl]["train_frac"] < 1.0 and sw[wl]["consistency"] == []
+        for wl in ("config2_attn", "default_flags", "data_default_flags"):
+            assert "kernel_a" not in sw[wl], (f, wl)

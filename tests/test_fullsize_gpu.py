@@ -512,6 +512,53 @@ def test_config4_closing_rounds_of_the_large_batch_kernel_bitwise_vs_32_row_shap
     assert float((back.nodes - graph.nodes).abs().max()) <= 5e-5
 
 
+@pytest.mark.timeout(600)
+def test_split_row_tile_whose_partner_is_lost_writes_nan_rows_and_nan_sums():
+    """The t-net workgroup of a SPLIT row tile waits (bounded) for the s rows of the workgroup that ran the tile's s-net
+    (gnf_fused_big.hip).  A partner that never publishes must be loud in BOTH directions - GRevNet.g returns nodes only
+    (gnn.py:343-373: a sampling pass has no scalar to poison), GRevNet.f also its sums - and must not hang the launch.  A
+    healthy launch has the flag half a launch before anybody looks, so the branch runs only under fault injection:
+    force_shape = 49 = the large-batch kernel with the hand-over flag withheld (every split tile loses its partner, each
+    half-step's launch sits out the bounded spin: about a second).  One timestep of the config-4 nets on a batch that has
+    split tiles; afterwards a healthy call on the same workspace is bitwise the reference again (the flags do not leak)."""
+    from gnf_amd import _abi
+    g_cpu, p, hp = _bench_batch("config4", 53)
+    nn = g_cpu.n_node.numpy()
+    n = int(nn.sum())
+    tiles, cus = (n + 15) // 16, torch.cuda.get_device_properties(0).multi_processor_count
+    rem = tiles % (2 * cus)
+    e = rem if rem <= cus else rem - cus
+    if not (2 * cus < tiles <= 8 * cus and 0 < e <= cus // 2):
+        pytest.skip("this device's CU count gives the batch no split tiles")
+    hp1 = dict(hp, T=1)
+    p1 = {k: [[half[0]] for half in p[k]] for k in ("s", "t")}
+    net = make_product_grevnet(hp1, p1)
+    graph = graph_from_arrays(nn, g_cpu.n_edge.numpy(), g_cpu.senders.numpy(), g_cpu.receivers.numpy(), g_cpu.nodes.numpy(), DEV)
+    try:
+        _abi.set_option("force_shape", 40)
+        z_ref, ld_ref = net(graph, inverse=True)
+        x_ref = net(graph, inverse=False)
+        _abi.set_option("force_shape", 49)
+        x_bad = net(graph, inverse=False)             # g: nodes only
+        z_bad, ld_bad = net(graph, inverse=True)      # f: nodes + sums
+        sums_bad = net.last_sums.clone()
+        _abi.set_option("force_shape", 40)
+        z_ok, ld_ok = net(graph, inverse=True)
+        x_ok = net(graph, inverse=False)
+    finally:
+        _abi.set_option("force_shape", 0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(z_ref.nodes).all() and torch.isfinite(x_ref.nodes).all()
+    for bad in (x_bad.nodes, z_bad.nodes):
+        nan_rows = int(torch.isnan(bad).any(dim=1).sum())
+        # at least the e split tiles' own rows (16 each, the batch's last tile may be partial); NaN then spreads through the
+        # second half-step's aggregation - inside a graph only (block-diagonal batch): most graphs stay finite
+        assert nan_rows >= 16 * (e - 1) + 1, (nan_rows, e)
+        assert nan_rows < n, (nan_rows, n)
+    assert torch.isnan(sums_bad[:2]).all() and bool(torch.isnan(ld_bad))
+    assert torch.equal(z_ok.nodes, z_ref.nodes) and torch.equal(x_ok.nodes, x_ref.nodes) and float(ld_ok) == float(ld_ref)
+
+
 @pytest.mark.parametrize("graphs,layout", [(24, "1 + half | 1"), (43, "2 | 1 + half | 1"), (53, "2 + half | 2"), (70, "3 | 2 + half | 2"),
                                            (80, "3 + half | 3"), (97, "4 | 3 + half | 3")])
 def test_config4_split_row_tiles_of_the_large_batch_kernel_bitwise_vs_32_row_shape(graphs, layout):

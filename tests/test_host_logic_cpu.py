@@ -318,3 +318,18 @@ def test_example_driver_defaults_are_the_reference_flags():
     for flag, val in want.items():
         m = re.search(r'add_argument\("--%s",[^\n]*default=([^,)\s]+)' % flag, src)
         assert m and m.group(1) == val, (flag, m and m.group(1))
+
+
+def test_mlp_stash_budget_rule():
+    """train.mlp_stash_within_budget: the MLP-row stash is taken only within the caller's cap or, with no
+    cap, within a fraction of the device memory that is free - a 20 GB stash of a 30 k-node wide-net batch must not turn a
+    step that trains through the recomputing walk into a device OOM."""
+    from gnf_amd.train import mlp_stash_within_budget
+    gb = 1 << 30
+    assert mlp_stash_within_budget(2 * gb, 200 * gb)[0]
+    ok, why = mlp_stash_within_budget(20 * gb, 30 * gb)
+    assert not ok and "free" in why
+    assert mlp_stash_within_budget(20 * gb, 30 * gb, free_fraction=0.9)[0]
+    assert mlp_stash_within_budget(20 * gb, 1 * gb, max_bytes=32 * gb)[0]       # an explicit cap is the caller's decision
+    ok, why = mlp_stash_within_budget(20 * gb, 200 * gb, max_bytes=8 * gb)
+    assert not ok and "mlp_stash_max_bytes" in why

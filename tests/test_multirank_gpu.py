@@ -56,6 +56,30 @@ def test_bench_n_ranks_on_one_device_match_one_rank_over_the_same_batch(nranks):
     assert one["steps_landed_on_host"] == 6
 
 
+@pytest.mark.timeout(2400)
+@pytest.mark.parametrize("workload,graphs_per_rank,tol", [("config2", 16, 1e-9), ("config5", 8, 1e-9), ("default_flags", 16, 1e-6)])
+def test_bench_eight_ranks_on_one_device_match_one_rank(workload, graphs_per_rank, tol):
+    """EIGHT ranks - the rank count BASELINE.json's north_star names (configs 3 and 5) - through bench.py's sharded protocol
+    on the one device of this box (gloo): whole graphs dealt to 8 ranks by the greedy balance, every rank's kernels on its
+    shard, the asynchronous 3 x fp64 all-reduce, the drain.  config5: the large-batch kernel's hyper-parameters (D = 256,
+    T = 16).  default_flags: the drivers' attention GNN + batch-norm bijectors with the batch moments taken over ALL ranks'
+    nodes (GnfFlow.bn_allreduce: one exchange of 2 H + 1 doubles per bijector call, 8 ranks) - the all-reduced moments are
+    fp64 sums grouped by rank, the (scale, shift) pairs derived from them are float32: a last-bit difference there moves the
+    per-node log-prob by parts in 1e-8, hence the looser pin.  What this cannot show: RCCL itself with 8 peers."""
+    extra = ("--workload", workload)
+    one = _bench(1, 8 * graphs_per_rank, extra=extra)
+    many = _bench(8, graphs_per_rank, extra=extra)
+    assert many["n_gpus"] == 8 and many["nccl_ranks_seen"] == 8 and many["dist_backend"] == "gloo"
+    assert many["config"]["nodes_total"] == one["config"]["nodes_total"]
+    assert many["config"]["edges_total"] == one["config"]["edges_total"]
+    assert len(many["config"]["nodes_per_rank"]) == 8 and sum(many["config"]["nodes_per_rank"]) == one["config"]["nodes_total"]
+    imb = many["config"]["shard_imbalance_max_over_mean"]
+    assert imb["nodes"] <= 1.05 and imb["edges"] <= 1.05, imb
+    assert abs(many["log_prob_xs_per_node"] - one["log_prob_xs_per_node"]) <= tol, (many["log_prob_xs_per_node"], one["log_prob_xs_per_node"])
+    assert many["steps_landed_on_host"] == many["steps"] == 6
+    assert many["consistency"] == []
+
+
 @pytest.mark.timeout(1200)
 def test_bench_gpus_2_launches_its_own_ranks():
     """The driver's command shape for N > 1 is `python bench.py --gpus N --steps K --warmup W` with NO launcher in front:
