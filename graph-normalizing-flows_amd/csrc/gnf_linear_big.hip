@@ -209,43 +209,60 @@ __device__ __forceinline__ void lin_big_body(const LinBigArgs& a, float* __restr
     if (a.wp2[net] == nullptr) return;
     // The next (last, thin) layer on the accumulators: a lane's four consecutive columns of a row are the B operand of
     // y2^T[16 t + .][row] += W2^T fragment x h^T, k-group = this wave's column tile (padded columns: zero activations x zero
-    // weight rows).  Row tile by row tile: the four waves' partial [16, O2] tiles meet in LDS (the activation buffer is free
-    // now), are added in wave order and written to this column block's slab.
+    // weight rows).  The fragments of W2 are the same for every row tile: each is loaded ONCE and used for all of them, four
+    // column tiles of the thin layer per pass, the next column tile's fragments in flight behind the MFMAs (round 5 loaded
+    // them per row tile: sixteen dependent trips to L2 per workgroup, 100 k cycles where the MFMAs take 14 k - round 6's time
+    // stamps).  Row tile by row tile the four waves' partial [16, 64] tiles then meet in LDS (the activation buffer is free
+    // now), are added in wave order and written to this column block's slab.  Per output element the same products in the
+    // same order as before.
     const __amdgpu_buffer_rsrc_t rsrc2 =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp2[net]), 0, (int)((unsigned)a.ont * (unsigned)a.ont2 * 1024u), 0x00020000);
-    const int PS = 16 * a.ont2 + 4;
+    constexpr int TH = 4;
+    const int PS = 16 * TH + 4;
     float* __restrict__ part = act + wave * 16 * PS;
     float* __restrict__ slab = a.slab[net] + (int64_t)cb * a.slab_stride;
+#pragma unroll 1
+    for (int t0 = 0; t0 < a.ont2; t0 += TH) {
+        f32x4 y2[MW][TH];
 #pragma unroll
-    for (int m = 0; m < MW; ++m) {
-        f32x4 y2[kLbFuseTiles];
+        for (int m = 0; m < MW; ++m)
 #pragma unroll
-        for (int t = 0; t < kLbFuseTiles; ++t) y2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < TH; ++t) y2[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 wa[TH], wb[TH];
+        // (a column tile past the thin layer's, a dead column tile of this wave: offset out of the descriptor's range - zeros)
+#define GNF_LB_W2(W, B)                                                                                                    \
+    _Pragma("unroll") for (int t = 0; t < TH; ++t) W[t] =                                                                  \
+        GNF_LB_LOAD_B(rsrc2, (B) < nv && t0 + t < a.ont2 ? voff : 0x7fffffff, ((ct0 + 4 * (B)) * a.ont2 + t0 + t) * 1024);
+#define GNF_LB_MM(W, B)                                                                                                    \
+    if ((B) < nv) {                                                                                                        \
+        _Pragma("unroll") for (int m = 0; m < MW; ++m) _Pragma("unroll") for (int t = 0; t < TH; ++t)                       \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                   \
+                y2[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[t][q], acc[m][B][q], y2[m][t], 0, 0, 0);                  \
+    }
+        GNF_LB_W2(wa, 0)
+        GNF_LB_W2(wb, 1)
+        GNF_LB_MM(wa, 0)
+        GNF_LB_W2(wa, 2)
+        GNF_LB_MM(wb, 1)
+        GNF_LB_W2(wb, 3)
+        GNF_LB_MM(wa, 2)
+        GNF_LB_MM(wb, 3)
+#undef GNF_LB_W2
+#undef GNF_LB_MM
+        const int cw = a.O2 - 16 * t0 < 16 * TH ? a.O2 - 16 * t0 : 16 * TH;  // live columns of this pass
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (b >= nv) continue;
-            f32x4 w2[kLbFuseTiles];
+        for (int m = 0; m < MW; ++m) {
+            __syncthreads();  // (the last chunk / the previous partial tiles have been read)
 #pragma unroll
-            for (int t = 0; t < kLbFuseTiles; ++t)
-                if (t < a.ont2) w2[t] = GNF_LB_LOAD_B(rsrc2, voff, ((ct0 + 4 * b) * a.ont2 + t) * 1024);
-#pragma unroll
-            for (int t = 0; t < kLbFuseTiles; ++t)
-                if (t < a.ont2) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) y2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[t][q], acc[m][b][q], y2[t], 0, 0, 0);
-                }
-        }
-        __syncthreads();  // (the last chunk / the previous row tile's partial tiles have been read)
-#pragma unroll
-        for (int t = 0; t < kLbFuseTiles; ++t)
-            if (t < a.ont2) *reinterpret_cast<f32x4*>(part + lrow * PS + 16 * t + 4 * lgrp) = y2[t];
-        __syncthreads();
-        for (int i = tid; i < 16 * a.O2; i += kLbThreads) {
-            const int r = i / a.O2, c = i - r * a.O2;
-            const int64_t gr = row0 + 16 * m + r;
-            if (gr >= a.n) continue;
-            const float* p = act + r * PS + c;
-            slab[gr * a.O2 + c] = ((p[0] + p[16 * PS]) + p[32 * PS]) + p[48 * PS];
+            for (int t = 0; t < TH; ++t) *reinterpret_cast<f32x4*>(part + lrow * PS + 16 * t + 4 * lgrp) = y2[m][t];
+            __syncthreads();
+            for (int i = tid; i < 16 * cw; i += kLbThreads) {
+                const int r = i / cw, c = i - r * cw;
+                const int64_t gr = row0 + 16 * m + r;
+                if (gr >= a.n) continue;
+                const float* p = act + r * PS + c;
+                slab[gr * a.O2 + 16 * t0 + c] = ((p[0] + p[16 * PS]) + p[32 * PS]) + p[48 * PS];
+            }
         }
     }
 }
