@@ -5,15 +5,17 @@
 // and dh0 = dL/dh0 coming back from the MLP:
 //   dnew = dh0[:, off:]           dagg = dnew Wo^T                      dWo = agg^T dnew
 //   dw[e,h] = <dagg[r_e,h,:], v[s_e,:]>      dlogit[e,h] = w[e,h] (dw[e,h] - sum_{e' into r_e} w[e',h] dw[e',h])
-//   dk[r,h,:] = sum_{e into r}  scale dlogit[e,h] q[s_e,h,:]            (receiver side:  k_attn_bwd_recv)
-//   dq[u,h,:] = sum_{e out of u} scale dlogit[e,h] k[r_e,h,:]           (sender side:    k_attn_bwd_send,
+//   dk[r,h,:] = sum_{e into r}  scale dlogit[e,h] q[s_e,h,:]            (receiver side)
+//   dq[u,h,:] = sum_{e out of u} scale dlogit[e,h] k[r_e,h,:]           (sender side,
 //   dv[u,:]   = sum_{e out of u} sum_h w[e,h] dagg[r_e,h,:]              by-sender CSR, no atomics)
 //   dx = dq Wq^T + dk Wk^T + dv Wv^T (+ dh0[:, :H] when the node is concatenated)   (k_attn_bwd_dx)
 //   dWq = x^T dq, dWk = x^T dk, dWv = x^T dv                             (grouped dW GEMM, gnf_train.hip)
 // The sender-side pass needs no edge ids: it recomputes w[e,h] from the per-(receiver, head) softmax max and
-// normaliser the receiver-side pass leaves in `stats`, and reads dagg per receiver.
-// One wave per row, lanes along the feature axis (coalesced row reads, nothing of the edge list staged in
-// LDS); per-(edge, head) scalars through segmented sums in a small per-wave scratch.
+// normaliser the forward pass leaves in `stats`, and reads dagg per receiver.
+// Two kernel families, by head geometry: heads <= 8 with kq, v <= 32 (the drivers' default 8 x 10 / 10) take the
+// thread-per-(row, head) kernels below; everything else inside the ABI's limit takes the matrix-core attention core
+// (gnf_attn_core_bwd.hip).  (Rounds 1 - 5 also carried a lane-per-feature pair, k_attn_bwd_recv / _send<FU>, for wider heads:
+// unreachable since the core kernels took every such geometry in round 5, removed in round 6.)
 #include "gnf_attn_dev.h"
 
 #include <stdlib.h>
@@ -37,361 +39,11 @@ struct AttnBwdArgs {
     float scale;
 };
 
-__device__ __forceinline__ float wave_sum(float x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-    return x;
-}
-__device__ __forceinline__ float wave_max(float x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
-    return x;
-}
-
-static constexpr int kRB = 32;            // rows per workgroup (8 waves x 4 rows)
-static constexpr int kRPW = 4;            // rows a wave handles, one after the other
-static constexpr int kG = 4;              // edges handled together (loads of the group are all in flight at once)
-static constexpr int kWinBudget = 144 * 1024;
-
-// Lanes run along the FEATURE axis (every row read is coalesced); the per-(edge, head) scalars come from
-// segmented sums through a small per-wave LDS scratch:
-//   pq[g][c] = q . k products, pd[g][i] = dagg . v products  ->  lane t = (g, h) sums its head's segment.
-// per-wave scratch (floats): pq [kG][nq] | pd [kG][NV] | hw [kG][nh] | hd [kG][nh] | red [kG][3 nh]
-__host__ __device__ inline int attn_bwd_wave_floats(int nq, int NV, int nh) { return kG * (nq + NV + 5 * nh); }
-// fixed part of the LDS of the two row kernels (bytes): rowptr slice + window header + 8 wave scratches
-__host__ __device__ inline size_t attn_bwd_fixed_bytes(int nq, int NV, int nh) {
-    return (size_t)(kRB + 1 + 3) * sizeof(int) + (size_t)8 * attn_bwd_wave_floats(nq, NV, nh) * sizeof(float);
-}
-
-// Receiver side.  Two sweeps over the row's incoming edges: softmax statistics by the online (running-max)
-// recurrence, then the outputs, each recomputing the logits from the sender rows: any degree, no per-edge
-// storage.  WIN: sender rows (q | v, row stride WS) come from the LDS window.
-template <int FU, bool WIN>
-__device__ __forceinline__ void attn_recv_row(const AttnBwdArgs& a, int net, int r, float* scr, const float* win,
-                                              int win_lo, int WS, int lane) {
-    const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
-    float* pq = scr;
-    float* pd = pq + kG * nq;
-    float* hw = pd + kG * NV;
-    float* hd = hw + kG * nh;
-    float* red = hd + kG * nh;
-    const float* qkv = a.qkv[net];
-    const float* daggr = a.dagg[net] + (int64_t)r * NV;
-    const int beg = a.rowptr[r], end = a.rowptr[r + 1];
-    float kreg[FU], dreg[FU], dk[FU], ag[FU];
-#pragma unroll
-    for (int u = 0; u < FU; ++u) {
-        const int c = lane + 64 * u;
-        kreg[u] = c < nq ? qkv[(int64_t)r * P + nq + c] : 0.f;
-        dreg[u] = c < NV ? daggr[c] : 0.f;
-        dk[u] = 0.f;
-        ag[u] = 0.f;
-    }
-    const int G = 64 / nh < kG ? 64 / nh : kG;  // (edge slot, head) pairs fit one wave
-    const int tg = lane / nh, th = lane - tg * nh;  // this lane's (slot, head) when lane < G * nh
-    const bool head_lane = lane < G * nh;
-    float m_run = -INFINITY, z_run = 0.f, s1_run = 0.f;  // per (slot, head) partials
-    float m_h = 0.f, z_h = 1.f, sw_h = 0.f;               // per head, valid on the head lanes after sweep 1
-    for (int sweep = 1; sweep < 3; ++sweep) {
-        for (int e0 = beg; e0 < end; e0 += G) {
-            float qv[kG][FU], vv[kG][FU];
-#pragma unroll
-            for (int g = 0; g < kG; ++g) {
-                const int e = e0 + g < end ? e0 + g : end - 1;
-                const int s_ = a.col[e];
-#pragma unroll
-                for (int u = 0; u < FU; ++u) {
-                    const int c = lane + 64 * u;
-                    if (WIN) {
-                        const float* row = win + (s_ - win_lo) * WS;
-                        qv[g][u] = (g < G && c < nq) ? row[c] : 0.f;
-                        vv[g][u] = (g < G && c < NV) ? row[nq + c % vd] : 0.f;
-                    } else {
-                        qv[g][u] = (g < G && c < nq) ? qkv[(int64_t)s_ * P + c] : 0.f;
-                        vv[g][u] = (g < G && c < NV) ? qkv[(int64_t)s_ * P + 2 * nq + c % vd] : 0.f;
-                    }
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < kG; ++g)
-#pragma unroll
-                for (int u = 0; u < FU; ++u) {
-                    const int c = lane + 64 * u;
-                    if (g < G && c < nq) pq[g * nq + c] = qv[g][u] * kreg[u];
-                    if (g < G && c < NV) pd[g * NV + c] = dreg[u] * vv[g][u];
-                }
-            __builtin_amdgcn_wave_barrier();
-            float lg = -INFINITY, dw = 0.f;
-            const bool live = head_lane && e0 + tg < end;
-            if (live) {
-                float s0 = 0.f, s1 = 0.f;
-                for (int j = 0; j < kq; ++j) s0 += pq[tg * nq + th * kq + j];
-                for (int j = 0; j < vd; ++j) s1 += pd[tg * NV + th * vd + j];
-                lg = s0 * a.scale;
-                dw = s1;
-            }
-            if (sweep == 1) {
-                if (live) {  // online softmax: rescale the running sums when the maximum moves
-                    const float mn = fmaxf(m_run, lg);
-                    const float sc = expf(m_run - mn), ex = expf(lg - mn);
-                    z_run = z_run * sc + ex;
-                    s1_run = s1_run * sc + ex * dw;
-                    m_run = mn;
-                }
-            } else {
-                if (head_lane) {
-                    const float w = live ? expf(lg - m_h) / z_h : 0.f;
-                    hw[tg * nh + th] = w;
-                    hd[tg * nh + th] = w * (dw - sw_h);
-                }
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int g = 0; g < kG; ++g)
-#pragma unroll
-                    for (int u = 0; u < FU; ++u) {
-                        const int c = lane + 64 * u;
-                        if (g < G && c < nq) dk[u] += hd[g * nh + c / kq] * qv[g][u];
-                        if (g < G && c < NV) ag[u] += hw[g * nh + c / vd] * vv[g][u];
-                    }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (sweep == 1) {  // combine the slot partials per head
-            __builtin_amdgcn_wave_barrier();
-            if (head_lane) {
-                red[tg * nh + th] = m_run;
-                red[G * nh + tg * nh + th] = z_run;
-                red[2 * G * nh + tg * nh + th] = s1_run;
-            }
-            __builtin_amdgcn_wave_barrier();
-            float m = -INFINITY, z = 0.f, s1 = 0.f;
-            if (head_lane) {
-                for (int g = 0; g < G; ++g) m = fmaxf(m, red[g * nh + th]);
-                for (int g = 0; g < G; ++g) {
-                    const float mg = red[g * nh + th];
-                    const float sc = mg == -INFINITY ? 0.f : expf(mg - m);
-                    z += red[G * nh + g * nh + th] * sc;
-                    s1 += red[2 * G * nh + g * nh + th] * sc;
-                }
-            }
-            m_h = m;
-            z_h = end > beg ? z : 1.f;
-            sw_h = end > beg ? s1 / z : 0.f;
-            if (lane < nh) {
-                float* st = a.stats[net] + (int64_t)r * 3 * nh;
-                st[lane] = m_h;
-                st[nh + lane] = z_h;
-                st[2 * nh + lane] = sw_h;
-            }
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < FU; ++u) {
-        const int c = lane + 64 * u;
-        if (c < nq) a.dqkv[net][(int64_t)r * P + nq + c] = dk[u] * a.scale;
-        if (c < NV) a.agg[net][(int64_t)r * NV + c] = ag[u];
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-
-template <int FU>
-__global__ __launch_bounds__(512) void k_attn_bwd_recv(const AttnBwdArgs a, int win_cap) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int net = blockIdx.y;
-    const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * kRB;
-    int* s_rp = reinterpret_cast<int*>(sm);
-    int* s_hdr = s_rp + kRB + 1;
-    float* scr = reinterpret_cast<float*>(s_hdr + 3) + wave * attn_bwd_wave_floats(nq, NV, nh);
-    float* win = reinterpret_cast<float*>(s_hdr + 3) + 8 * attn_bwd_wave_floats(nq, NV, nh);
-    const int WS = nq + vd + 1;
-    if (tid <= kRB) {
-        const int r = row0 + tid;
-        s_rp[tid] = a.rowptr[r < a.n ? r : a.n];
-    }
-    __syncthreads();
-    const float* qkv = a.qkv[net];
-    const int lo = stage_window(a.col, s_rp, kRB, s_hdr, win_cap, tid, 512, [&](int lo_, int cnt) {
-        const int W = nq + vd;  // q at [0, nq), v at [2 nq, 2 nq + vd)
-        for (int base = 0; base < cnt * W; base += 512 * 8) {
-            float reg[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int i0 = base + tid + q * 512;
-                const int i = i0 < cnt * W ? i0 : 0;
-                const int rr = i / W, c = i - rr * W;
-                reg[q] = qkv[(int64_t)(lo_ + rr) * P + (c < nq ? c : nq + c)];
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int i = base + tid + q * 512;
-                if (i < cnt * W) win[(i / W) * WS + (i % W)] = reg[q];
-            }
-        }
-    });
-    for (int rr = 0; rr < kRPW; ++rr) {
-        const int r = row0 + wave * kRPW + rr;
-        if (r >= a.n) break;
-        if (lo >= 0)
-            attn_recv_row<FU, true>(a, net, r, scr, win, lo, WS, lane);
-        else
-            attn_recv_row<FU, false>(a, net, r, scr, win, 0, WS, lane);
-    }
-}
-
-// Sender side: ONE pass over the out-edges; the softmax weight of every edge is rebuilt from the receiver's
-// statistics.  dv is accumulated per (head, component) and folded over the heads at the end.  WIN: the receivers'
-// k | dagg rows (row stride WS) come from the LDS window; their softmax statistics always from global memory.
-template <int FU, bool WIN>
-__device__ __forceinline__ void attn_send_row(const AttnBwdArgs& a, int net, int u_, float* scr, const float* win,
-                                              int win_lo, int WS, int lane) {
-    const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
-    float* pq = scr;
-    float* pd = pq + kG * nq;
-    float* hw = pd + kG * NV;
-    float* hd = hw + kG * nh;
-    const float* qkv = a.qkv[net];
-    const float* dagg = a.dagg[net];
-    const float* stats = a.stats[net];
-    const int beg = a.rowptr_t[u_], end = a.rowptr_t[u_ + 1];
-    float qreg[FU], vreg[FU], dq[FU], dvp[FU];
-#pragma unroll
-    for (int u = 0; u < FU; ++u) {
-        const int c = lane + 64 * u;
-        qreg[u] = c < nq ? qkv[(int64_t)u_ * P + c] : 0.f;
-        vreg[u] = c < NV ? qkv[(int64_t)u_ * P + 2 * nq + c % vd] : 0.f;
-        dq[u] = 0.f;
-        dvp[u] = 0.f;
-    }
-    const int G = 64 / nh < kG ? 64 / nh : kG;
-    const int tg = lane / nh, th = lane - tg * nh;
-    const bool head_lane = lane < G * nh;
-    for (int e0 = beg; e0 < end; e0 += G) {
-        float kv[kG][FU], dv_[kG][FU], st_m = 0.f, st_z = 1.f, st_s = 0.f;
-#pragma unroll
-        for (int g = 0; g < kG; ++g) {
-            const int e = e0 + g < end ? e0 + g : end - 1;
-            const int r = a.col_t[e];
-#pragma unroll
-            for (int u = 0; u < FU; ++u) {
-                const int c = lane + 64 * u;
-                if (WIN) {
-                    const float* row = win + (r - win_lo) * WS;
-                    kv[g][u] = (g < G && c < nq) ? row[c] : 0.f;
-                    dv_[g][u] = (g < G && c < NV) ? row[nq + c] : 0.f;
-                } else {
-                    kv[g][u] = (g < G && c < nq) ? qkv[(int64_t)r * P + nq + c] : 0.f;
-                    dv_[g][u] = (g < G && c < NV) ? dagg[(int64_t)r * NV + c] : 0.f;
-                }
-            }
-            if (head_lane && tg == g) {
-                const float* st = stats + (int64_t)r * 3 * nh;
-                st_m = st[th];
-                st_z = st[nh + th];
-                st_s = st[2 * nh + th];
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < kG; ++g)
-#pragma unroll
-            for (int u = 0; u < FU; ++u) {
-                const int c = lane + 64 * u;
-                if (g < G && c < nq) pq[g * nq + c] = qreg[u] * kv[g][u];
-                if (g < G && c < NV) pd[g * NV + c] = dv_[g][u] * vreg[u];
-            }
-        __builtin_amdgcn_wave_barrier();
-        if (head_lane) {
-            float w = 0.f, dl = 0.f;
-            if (e0 + tg < end) {
-                float s0 = 0.f, s1 = 0.f;
-                for (int j = 0; j < kq; ++j) s0 += pq[tg * nq + th * kq + j];
-                for (int j = 0; j < vd; ++j) s1 += pd[tg * NV + th * vd + j];
-                w = expf(s0 * a.scale - st_m) / st_z;
-                dl = w * (s1 - st_s);
-            }
-            hw[tg * nh + th] = w;
-            hd[tg * nh + th] = dl;
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int g = 0; g < kG; ++g)
-#pragma unroll
-            for (int u = 0; u < FU; ++u) {
-                const int c = lane + 64 * u;
-                if (g < G && c < nq) dq[u] += hd[g * nh + c / kq] * kv[g][u];
-                if (g < G && c < NV) dvp[u] += hw[g * nh + c / vd] * dv_[g][u];
-            }
-        __builtin_amdgcn_wave_barrier();
-    }
-#pragma unroll
-    for (int u = 0; u < FU; ++u) {
-        const int c = lane + 64 * u;
-        if (c < nq) a.dqkv[net][(int64_t)u_ * P + c] = dq[u] * a.scale;
-        if (c < NV) pd[c] = dvp[u];  // fold the heads: dv[j] = sum_h dvp[h * vd + j]
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int j = lane; j < vd; j += 64) {
-        float s = 0.f;
-        for (int h = 0; h < nh; ++h) s += pd[h * vd + j];
-        a.dqkv[net][(int64_t)u_ * P + 2 * nq + j] = s;
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-
-template <int FU>
-__global__ __launch_bounds__(512) void k_attn_bwd_send(const AttnBwdArgs a, int win_cap) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int net = blockIdx.y;
-    const int nh = a.nh, kq = a.kq, vd = a.v, nq = nh * kq, P = 2 * nq + vd, NV = nh * vd;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * kRB;
-    int* s_rp = reinterpret_cast<int*>(sm);
-    int* s_hdr = s_rp + kRB + 1;
-    float* scr = reinterpret_cast<float*>(s_hdr + 3) + wave * attn_bwd_wave_floats(nq, NV, nh);
-    float* win = reinterpret_cast<float*>(s_hdr + 3) + 8 * attn_bwd_wave_floats(nq, NV, nh);
-    const int WS = nq + NV + 1;
-    if (tid <= kRB) {
-        const int r = row0 + tid;
-        s_rp[tid] = a.rowptr_t[r < a.n ? r : a.n];
-    }
-    __syncthreads();
-    const float* qkv = a.qkv[net];
-    const float* dagg = a.dagg[net];
-    const int lo = stage_window(a.col_t, s_rp, kRB, s_hdr, win_cap, tid, 512, [&](int lo_, int cnt) {
-        const int W = nq + NV;  // the receiver's k, then its dagg
-        for (int base = 0; base < cnt * W; base += 512 * 8) {
-            float reg[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int i0 = base + tid + q * 512;
-                const int i = i0 < cnt * W ? i0 : 0;
-                const int rr = i / W, c = i - rr * W;
-                reg[q] = c < nq ? qkv[(int64_t)(lo_ + rr) * P + nq + c] : dagg[(int64_t)(lo_ + rr) * NV + (c - nq)];
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int i = base + tid + q * 512;
-                if (i < cnt * W) win[(i / W) * WS + (i % W)] = reg[q];
-            }
-        }
-    });
-    for (int rr = 0; rr < kRPW; ++rr) {
-        const int u_ = row0 + wave * kRPW + rr;
-        if (u_ >= a.n) break;
-        if (lo >= 0)
-            attn_send_row<FU, true>(a, net, u_, scr, win, lo, WS, lane);
-        else
-            attn_send_row<FU, false>(a, net, u_, scr, win, 0, WS, lane);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // thread = (row, head) versions of the two passes (wave w = head w, lane = row of a 64-row tile; gnf_attn_dev.h):
 // the rows the tile's edges point at sit in the LDS window, the tile's col slice too, and a thread walks its own CSR
 // row with everything in registers - no per-edge LDS scratch, no cross-lane reductions.  These run whenever
-// heads <= 8 and kq, v <= 32; the lane-per-feature kernels above remain for wider heads.  On the drivers' default
-// dataset (complete 100-node graphs) the receiver pass went from 438 to ... us, the sender pass from 288 to ... us.
+// heads <= 8 and kq, v <= 32.
 // ------------------------------------------------------------------------------------------------
 // The forward pass leaves, per (row, head), the softmax statistics (running max m, denominator Z) and the attended values
 // O = sum_e w_e v_e (AttnArgs.agg_out / mz_out): the backward pass never rebuilds them.  With
@@ -1140,16 +792,13 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
                   kAttnMaxRowFloats);
         return GNF_ESHAPE;
     }
-    const size_t fixed = attn_bwd_fixed_bytes(nq, NV, a.nh);
-    const int cap_r = (int)((kWinBudget - fixed) / ((size_t)(nq + a.v + 1) * sizeof(float)));   // window rows, receiver pass
-    const int cap_s = (int)((kWinBudget - fixed) / ((size_t)(nq + NV + 1) * sizeof(float)));    // window rows, sender pass
     // dL/dx_cond: the matrix-core form (the caller's packed [Wq | Wk | Wv]^T; fits every geometry inside the limit by the
     // limit's last clause), else both nets' whole weights in LDS
     const size_t lds_x = ((size_t)H * (P + 1) + (size_t)kDxRows * P + (size_t)2 * kDxRows * H) * sizeof(float);
     const size_t lds_m = ((size_t)2 * kDxmRows * (((P + 15) & ~15) + 4) + (size_t)2 * kDxmRows * (((H + 15) & ~15) + 4) +
                           (size_t)2 * kDxmRows * H) * sizeof(float);
     const bool dx_mfma = wct && wct[0] && wct[1] && lds_m <= 160 * 1024;
-    if ((!dx_mfma && lds_x > 160 * 1024) || cap_s < 1) {
+    if (!dx_mfma && lds_x > 160 * 1024) {
         set_error("attention backward: heads=%d kq=%d v=%d on H=%d without the packed [Wq | Wk | Wv]^T needs more LDS than a CU has",
                   a.nh, a.kq, a.v, H);
         return GNF_EUNSUPPORTED;
@@ -1159,10 +808,7 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         GNF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dx_mfma),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        const void* ks[6] = {reinterpret_cast<const void*>(k_attn_bwd_recv<1>), reinterpret_cast<const void*>(k_attn_bwd_recv<2>),
-                             reinterpret_cast<const void*>(k_attn_bwd_recv<4>), reinterpret_cast<const void*>(k_attn_bwd_send<1>),
-                             reinterpret_cast<const void*>(k_attn_bwd_send<2>), reinterpret_cast<const void*>(k_attn_bwd_send<4>)};
-        for (const void* k : ks) GNF_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+);
     if (a.nh <= kRowsMaxHeads && a.kq <= 32 && a.v <= 32) {
         const size_t fixed_r = (size_t)(kRowsTile + 1 + 3 + kRowsColCap) * sizeof(int);
         const int capr = (int)((kRowsLdsBudget - fixed_r) / ((size_t)(nq + a.v + 2) * sizeof(float)));
@@ -1249,22 +895,13 @@ int launch_attn_backward(const GnfAttn* const* at, int64_t n, int32_t H, int32_t
     // wide heads (the data driver's one head of 64 / 64, train_grevnet_with_data.py:40-46): both passes on the matrix cores
     // (gnf_attn_core_bwd.hip), from the statistics and attended values the forward pass left
     const int rc_core = launch_attn_core_backward(a0, n, rowptr, col, rowptr_t, col_t, qkv, dagg, agg, stats, dqkv, st);
-    if (rc_core == GNF_OK) goto dx_pass;
-    if (rc_core != 1) return rc_core;
-    const dim3 grid((unsigned)((n + kRB - 1) / kRB), 2);
-    const int FU = wmax <= 64 ? 1 : (wmax <= 128 ? 2 : 4);
-    const size_t lds = kWinBudget;
-    if (FU == 1) {
-        hipLaunchKernelGGL(k_attn_bwd_recv<1>, grid, dim3(512), lds, st, a, cap_r);
-        hipLaunchKernelGGL(k_attn_bwd_send<1>, grid, dim3(512), lds, st, a, cap_s);
-    } else if (FU == 2) {
-        hipLaunchKernelGGL(k_attn_bwd_recv<2>, grid, dim3(512), lds, st, a, cap_r);
-        hipLaunchKernelGGL(k_attn_bwd_send<2>, grid, dim3(512), lds, st, a, cap_s);
-    } else {
-        hipLaunchKernelGGL(k_attn_bwd_recv<4>, grid, dim3(512), lds, st, a, cap_r);
-        hipLaunchKernelGGL(k_attn_bwd_send<4>, grid, dim3(512), lds, st, a, cap_s);
+    if (rc_core != GNF_OK) {
+        if (rc_core == 1) {   // (kq or v above 256: outside validate_attn's limit, the entry point has rejected it)
+            set_error("attention backward: heads=%d kq=%d v=%d has no kernel", a.nh, a.kq, a.v);
+            return GNF_EUNSUPPORTED;
+        }
+        return rc_core;
     }
-    GNF_LAUNCH_CHECK("k_attn_bwd_recv / k_attn_bwd_send");
     }
 dx_pass:
     AttnDxArgs d;

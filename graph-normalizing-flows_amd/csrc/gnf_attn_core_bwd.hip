@@ -266,7 +266,11 @@ static size_t core_bwd_lds_bytes() {
 }
 
 // dq | dk | dv of both nets from dagg, the forward's q | k | v, attended values and statistics (stats' third block is
-// written here).  1 = not this path's geometry (the caller runs the lane-per-feature kernels).
+// written here).  Every geometry the thread-per-(row, head) kernels do not take comes here (heads above 8 or kq / v above 32 -
+// many narrow heads too: each head is padded to whole 16-wide k-groups, one head at a time); the probabilities are rebuilt with
+// __expf from the forward's (max, Z) - the rows / edge-tiled forward kernels formed Z with expf, the core forward with __expf:
+// a relative 1e-7 per weight either way, inside the gradient pins of tests/test_data_driver_gpu.py for both.  1 = kq or v above
+// 256 (outside validate_attn's limit: no kernel).
 int launch_attn_core_backward(const GnfAttn* a0, int64_t n, const int32_t* rowptr, const int32_t* col, const int32_t* rowptr_t,
                               const int32_t* col_t, const float* const* qkv, const float* const* dagg, const float* const* agg,
                               float* const* stats, float* const* dqkv, hipStream_t st) {

@@ -240,7 +240,7 @@ __device__ __forceinline__ void attn_front_tile(const FrontArgs& a, float* __res
     f32x4 pre_v4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if (have_tab) {
         const int sb = rp_l[0], sl = rp_l[kFrRows] - sb;
-        if (sl <= kFrColCap) {
+        if (sl > 0 && sl <= kFrColCap) {   // (sl == 0: a tile of isolated receivers - at the batch's end sb == n_edges, one int past col)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = tid + u * kFrThreads;

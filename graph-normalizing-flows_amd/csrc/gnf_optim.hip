@@ -23,7 +23,8 @@ struct PackBatch {
 
 __global__ __launch_bounds__(256) void k_pack_multi(const PackBatch pb) {
     const PackDesc& d = pb.d[blockIdx.y];
-    const int64_t nw = (int64_t)d.Ip * d.Op;
+    // (a layer with no reader of either fragment copy - wout == wtout == NULL - still gets its bias row: nw = 0)
+    const int64_t nw = d.wout || d.wtout ? (int64_t)d.Ip * d.Op : 0;
     // a thread = the four k-consecutive elements of one lane's fragment (i = 4 t .. 4 t + 3): one 16-byte store per copy, and
     // for the transposed copy - whose four elements are consecutive in a row of W - one 16-byte load where rows are aligned
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -107,10 +108,11 @@ static int pack_flow(const GnfFlow* flow, hipStream_t st) {
                 float* pk = const_cast<float*>(m->packed);
                 const bool need_w = !wide_only || linear_big_fwd_layer(I, O) || linear_big_fused_last(m, j) || linear_short_fwd_layer(I, O);
                 const bool need_wt = !wide_only || linear_big_bwd_layer(I, O);
-                if (need_w || need_wt) {
+                {   // every layer's padded bias row follows its bias (include/gnf.h: "every bias row"), the fragment copies
+                    // only where a kernel reads them
                     pb.d[cnt++] = PackDesc{m->W[j], m->b[j], need_w ? pk + woff : nullptr, pk + boff,
                                            need_wt ? pk + toff + woff : nullptr, I, O, Ip, Op};
-                    const int64_t tot = (int64_t)Ip * Op + Op;
+                    const int64_t tot = (need_w || need_wt ? (int64_t)Ip * Op : 0) + Op;
                     maxtot = maxtot > tot ? maxtot : tot;
                 }
                 woff += (int64_t)Ip * Op;

@@ -89,7 +89,9 @@ typedef struct GnfAttn {
      * pad16(2 * num_heads * kq_dim + v_dim) + pad16(H) + H <= 1272 (sixteen rows of the backward pass's dL/dx_cond product in
      * one CU's LDS; the drivers' geometries: H <= 544 / H <= 536) - GNF_ESHAPE otherwise.  Inside it every geometry runs; the
      * drivers' defaults have kernels of their own (run_grevnet.py:74-77: 8 heads, kq = v = 10, C = 80;
-     * train_grevnet_with_data.py:40-46: 1 head, kq = v = 64, C = 64). */
+     * train_grevnet_with_data.py:40-46: 1 head, kq = v = 64, C = 64).  The forward and inverse kernels alone could take
+     * some geometries beyond it; the limit is deliberately the same for all three entry points, so that a flow that evaluates
+     * or samples is also a flow that trains (the reference's DMSelfAttentionMLP has no bound: gnn.py:480-553). */
     int32_t num_heads;
     int32_t kq_dim;
     int32_t v_dim;
@@ -187,7 +189,11 @@ typedef struct GnfFlow {
      * sizes it and returns 0 where the library would not use one (batches of more than one 16-node tile per CU on the fused
      * kernels, attention blocks that end in LayerNorm): pass NULL then.  Nets too wide for the fused kernels (the data
      * driver's 2048 x 3 MLPs) use it too since round 5: their layered forward writes every hidden activation and s, t
-     * into the slot and the backward pass skips its recompute of both MLPs (up to 48 GB). */
+     * into the slot and the backward pass skips its recompute of both MLPs.  The stash is OPTIONAL at every size: it is memory
+     * for time (2T slots of every hidden activation - about 20 GB for a 30 k-node batch of those nets), gnf_mlp_stash_bytes()
+     * reports what it would take (0 beyond 48 GB) and the caller decides whether the device has it; with mlp_stash = NULL the
+     * same flow trains through the recomputing walk.  (The Python trainer takes it within half of the free device memory,
+     * or the caller's cap: train.py, GRevNetTrainer.mlp_stash_max_bytes.) */
     float* mlp_stash;
     size_t mlp_stash_bytes;
 } GnfFlow;

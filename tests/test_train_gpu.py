@@ -845,6 +845,69 @@ def test_wide_nets_packed_copies_follow_the_weights(community_medium):
     np.testing.assert_allclose(raw["z_graph"].nodes.cpu().numpy(), z_packed, atol=2e-4, rtol=2e-4)
 
 
+def test_packed_bias_rows_of_every_layer_follow_an_optimiser_step(community_medium):
+    """gnf_pack_flow (include/gnf.h: "every bias row"): a wide net's last layer 1280 -> 150 (H > 128: not the wide kernel's
+    fused last layer, no short first layer, no wide product in either direction) has NO reader of its fragment copies, so
+    round 5 emitted no descriptor for it - and its padded bias row in `packed` kept the initial values for ever.
+    After two optimiser steps every layer's bias row in `packed` must equal the layer's current bias."""
+    from gnf_amd.train import GRevNetTrainer
+    d, latent = 300, 1280
+    hp = dict(D=d, latent=latent, K=3, T=1, agg="mean", combine="agg", epsilon=1.0, activation="relu", weight_sharing=False)
+    nn, ne, s, r = _batch(community_medium, list(range(64)))
+    n = int(nn.sum())
+    x = (np.random.default_rng(6).standard_normal((n, d)) * 0.7).astype(np.float32)
+    net = make_product_grevnet(hp, O.make_grevnet_params(33, d // 2, latent, 3, 1, final_scale=0.3))
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    tr = GRevNetTrainer(net, lr=2e-3, use_lr_decay=False)
+    b_before = [b.detach().cpu().clone() for (_w, b) in net.mlps("s")[0].params]
+    for _ in range(2):
+        tr.step(graph)
+    torch.cuda.synchronize()
+    packed = net._cache[2][3]                                   # all nets' packed copies, s-nets first
+    pad = lambda v: (v + 15) // 16 * 16                         # noqa: E731
+    dims = [d // 2, latent, latent, d // 2]
+    woff = sum(pad(dims[j]) * pad(dims[j + 1]) for j in range(3))
+    off = woff                                                  # net 0 (s, half 0, step 0): bias rows behind its Wp
+    for j, (_w, b) in enumerate(net.mlps("s")[0].params):
+        row = packed[off:off + pad(dims[j + 1])]
+        assert float((b.cpu() - b_before[j]).abs().max()) > 0, "the steps did not move this bias: the test would prove nothing"
+        assert torch.equal(row[:dims[j + 1]], b), f"layer {j}: packed bias row is stale"
+        assert float(row[dims[j + 1]:].abs().max()) == 0.0 if pad(dims[j + 1]) > dims[j + 1] else True
+        off += pad(dims[j + 1])
+
+
+def test_mlp_row_stash_beyond_its_budget_trains_through_the_recomputing_walk(community_medium):
+    """gnf_mlp_stash_bytes offers the layered stash at any size up to 48 GB and the trainer allocated it
+    unconditionally - a batch that trained through the recomputing walk could now die of a device OOM.  The trainer takes the
+    stash only within its budget (a cap, or half of the free device memory): with a cap below the stash's size the step runs
+    without it (mlp_stash = NULL), says so, and produces the gradients of the recomputing walk bit for bit."""
+    from gnf_amd.train import GRevNetTrainer
+    hp = dict(D=24, latent=1280, K=3, T=1, agg="mean", combine="agg", epsilon=1.0, activation="relu", weight_sharing=False)
+    nn, ne, s, r = _batch(community_medium, list(range(64)))
+    n = int(nn.sum())
+    x = (np.random.default_rng(5).standard_normal((n, 24)) * 0.7).astype(np.float32)
+    p = O.make_grevnet_params(31, 12, 1280, 3, 1, final_scale=0.3)
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    grads = {}
+    for mode in ("capped", "recompute", "stash"):
+        net = make_product_grevnet(hp, p)
+        tr = GRevNetTrainer(net, lr=1e-3, use_lr_decay=False)
+        if mode == "capped":
+            tr.mlp_stash_max_bytes = 1 << 20                    # the stash of this batch is ~100 MB
+        if mode == "recompute":
+            tr.stash_mlp_rows = False
+        tr.loss_and_grads(graph)
+        torch.cuda.synchronize()
+        grads[mode] = tr.grad.clone()
+        if mode == "capped":
+            assert tr._mlp_stash is None and tr.mlp_stash_declined is not None
+            assert tr.mlp_stash_declined[0] > (1 << 20) and "mlp_stash_max_bytes" in tr.mlp_stash_declined[1]
+        if mode == "stash":
+            assert tr._mlp_stash is not None and tr.mlp_stash_declined is None
+    assert torch.equal(grads["capped"], grads["recompute"])
+    assert float((grads["stash"] - grads["recompute"]).abs().max()) <= 2e-3 * float(grads["recompute"].abs().max())
+
+
 @pytest.mark.parametrize("gnn_kind", ["avg_then_mlp", "dm_attn_bn"])
 def test_layered_mlp_row_stash_matches_the_recomputing_walk(community_medium, gnn_kind):
     """Nets too wide for the fused kernels (layered forward, generic backward): with GnfFlow.mlp_stash the forward's hidden
