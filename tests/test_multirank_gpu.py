@@ -77,7 +77,8 @@ def test_bench_eight_ranks_on_one_device_match_one_rank(workload, graphs_per_ran
     assert imb["nodes"] <= 1.05 and imb["edges"] <= 1.05, imb
     assert abs(many["log_prob_xs_per_node"] - one["log_prob_xs_per_node"]) <= tol, (many["log_prob_xs_per_node"], one["log_prob_xs_per_node"])
     assert many["steps_landed_on_host"] == many["steps"] == 6
-    assert many["consistency"] == []
+    # (no `consistency` check here: eight processes share ONE device, a rank's HIP-event interval around its flow call
+    # contains the other ranks' kernels - the timing cross-checks mean something only with a device per rank)
 
 
 @pytest.mark.timeout(1200)
