@@ -218,8 +218,9 @@ __device__ __forceinline__ void lin_big_body(const LinBigArgs& a, float* __restr
     const __amdgpu_buffer_rsrc_t rsrc2 =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp2[net]), 0, (int)((unsigned)a.ont * (unsigned)a.ont2 * 1024u), 0x00020000);
     constexpr int TH = 4;
-    const int PS = 16 * TH + 4;
-    float* __restrict__ part = act + wave * 16 * PS;
+    constexpr int PS = 16 * TH + 4, WS = 16 * MW * PS;   // row stride, floats between two waves' partial tiles
+    static_assert(4 * WS <= kLbRows * kLbLS, "the four waves' partial tiles of every row tile fit the activation buffer");
+    float* __restrict__ part = act + wave * WS;
     float* __restrict__ slab = a.slab[net] + (int64_t)cb * a.slab_stride;
 #pragma unroll 1
     for (int t0 = 0; t0 < a.ont2; t0 += TH) {
@@ -249,19 +250,38 @@ __device__ __forceinline__ void lin_big_body(const LinBigArgs& a, float* __restr
         GNF_LB_MM(wb, 3)
 #undef GNF_LB_W2
 #undef GNF_LB_MM
+        // all row tiles' partial tiles of the four waves meet in LDS at once ([wave][16 MW rows][PS]: 69.6 KB of the buffer's
+        // 70.6) - two barriers per pass, not two per row tile; a thread then adds one row's 16 columns in wave order
         const int cw = a.O2 - 16 * t0 < 16 * TH ? a.O2 - 16 * t0 : 16 * TH;  // live columns of this pass
+        __syncthreads();  // (the last chunk / the previous pass's partial tiles have been read)
 #pragma unroll
-        for (int m = 0; m < MW; ++m) {
-            __syncthreads();  // (the last chunk / the previous partial tiles have been read)
+        for (int m = 0; m < MW; ++m)
 #pragma unroll
-            for (int t = 0; t < TH; ++t) *reinterpret_cast<f32x4*>(part + lrow * PS + 16 * t + 4 * lgrp) = y2[m][t];
-            __syncthreads();
-            for (int i = tid; i < 16 * cw; i += kLbThreads) {
-                const int r = i / cw, c = i - r * cw;
-                const int64_t gr = row0 + 16 * m + r;
-                if (gr >= a.n) continue;
-                const float* p = act + r * PS + c;
-                slab[gr * a.O2 + 16 * t0 + c] = ((p[0] + p[16 * PS]) + p[32 * PS]) + p[48 * PS];
+            for (int t = 0; t < TH; ++t) *reinterpret_cast<f32x4*>(part + (16 * m + lrow) * PS + 16 * t + 4 * lgrp) = y2[m][t];
+        __syncthreads();
+        {
+            const int r = tid >> 2, c0 = 16 * (tid & 3);      // row of the group, first of this thread's 16 columns
+            const int64_t gr = row0 + r;
+            if (r < 16 * MW && gr < a.n && c0 < cw) {
+                const float* p = act + r * PS + c0;
+                float* o = slab + gr * a.O2 + 16 * t0 + c0;
+                const bool v4 = (a.O2 & 3) == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(p + 4 * j), w1 = *reinterpret_cast<const f32x4*>(p + WS + 4 * j);
+                    const f32x4 w2 = *reinterpret_cast<const f32x4*>(p + 2 * WS + 4 * j), w3 = *reinterpret_cast<const f32x4*>(p + 3 * WS + 4 * j);
+                    f32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = ((w0[q] + w1[q]) + w2[q]) + w3[q];
+                    const int c = c0 + 4 * j;
+                    if (v4 && c + 3 < cw) {
+                        *reinterpret_cast<f32x4*>(o + 4 * j) = v;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (c + q < cw) o[4 * j + q] = v[q];
+                    }
+                }
             }
         }
     }
