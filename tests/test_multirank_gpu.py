@@ -66,7 +66,7 @@ def test_bench_eight_ranks_on_one_device_match_one_rank(workload, graphs_per_ran
     nodes (GnfFlow.bn_allreduce: one exchange of 2 H + 1 doubles per bijector call, 8 ranks) - the all-reduced moments are
     fp64 sums grouped by rank, the (scale, shift) pairs derived from them are float32: a last-bit difference there moves the
     per-node log-prob by parts in 1e-8, hence the looser pin.  What this cannot show: RCCL itself with 8 peers."""
-    extra = ("--workload", workload)
+    extra = ("--workload", workload, "--repeats", "1", "--prewarm-ms", "0")   # (one timed region: this is a protocol test)
     one = _bench(1, 8 * graphs_per_rank, extra=extra)
     many = _bench(8, graphs_per_rank, extra=extra)
     assert many["n_gpus"] == 8 and many["nccl_ranks_seen"] == 8 and many["dist_backend"] == "gloo"
