@@ -686,7 +686,9 @@ __device__ __forceinline__ void dw_wide_body(const WG& g, const int vblock, cons
 }
 
 template <bool BUF>
-__global__ __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_dw_wide(const WideGemm g) {
+// (waves_per_eu(2, 3), not (2, 2): with a maximum of two the compiler PADS the register allocation to 169 so that a third wave
+// cannot fit - and then nothing of the main stream's kernels fits beside this one either; its own 140 registers leave them 224)
+__global__ __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_gemm_dw_wide(const WideGemm g) {
     dw_wide_body<BUF>(g, (int)blockIdx.x, (int)gridDim.x);
 }
 
@@ -755,7 +757,9 @@ static int launch_gemm(const GemmJob* jobs, int nj, const GemmShape& sh, hipStre
     }
     const bool buf = gemm_buf_ok(AK, BK, AK == OPND_KC ? sh.M : sh.K, sh.lda, BK == OPND_KC ? (int64_t)sh.N : sh.K, sh.ldb, sh.K);
     // 128 x 128 tiles once they fill every CU's two slots (2 x 73.7 KB of LDS)
-    if (buf && EPI != EPI_SLAB && (int64_t)((sh.N + 127) / 128) * ((sh.M + TGM - 1) / TGM) * nj * sh.chunks >= 2 * (int64_t)big_cu_count()) {
+    // (the masked dX of a wide net's thin last layer keeps the 64-column tile: it runs beside the weight-gradient launch of the
+    // previous half-step, and a 128-column workgroup's 240 registers per SIMD find no room there - round 6's kernel timeline)
+    if (buf && EPI != EPI_SLAB && EPI != EPI_MASK && (int64_t)((sh.N + 127) / 128) * ((sh.M + TGM - 1) / TGM) * nj * sh.chunks >= 2 * (int64_t)big_cu_count()) {
         dim3 grid2((unsigned)((sh.N + 127) / 128), (unsigned)((sh.M + TGM - 1) / TGM), (unsigned)(nj * sh.chunks));
         hipLaunchKernelGGL((k_gemm<AK, BK, EPI, true, 128>), grid2, dim3(kGemmThreads), 0, st, jobs[0], jobs[nj - 1], sh);
         GNF_LAUNCH_CHECK("k_gemm (128-column tiles)");
@@ -1048,7 +1052,13 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net, int n_sets
         for (int j = 0; j < p.K; ++j)
             tiles += (int64_t)((net->dims[j] + TGM - 1) / TGM) * ((net->dims[j + 1] + TGN - 1) / TGN);
         tiles *= 2;
-        const int64_t enough = (1024 + tiles - 1) / (tiles > 0 ? tiles : 1);
+        int64_t enough = (1024 + tiles - 1) / (tiles > 0 ? tiles : 1);
+        // ... except that nets with wide hidden layers AND thin first / last layers need slab room for the thin layers' tiles:
+        // the wide kernel gives every CU one workgroup that takes whole hidden-layer tiles by stride (one chunk each: the slab
+        // is the gradient) and cuts the thin layers' tiles along the node axis so that they ride behind in equal pieces.  With
+        // ONE chunk planned they could not be cut: on the data driver's nets 64 of the 256 workgroups carried a third
+        // full-length tile (time stamps, round 6: 1 216 k cycles against 813 k for the other 192)
+        if (lmax >= 512 && enough < 4) enough = 4;
         if (chunks > enough) chunks = enough;
     }
     if (chunks < 1) chunks = 1;
