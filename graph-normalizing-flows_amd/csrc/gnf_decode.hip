@@ -5,7 +5,8 @@
 // The reference materialises a dense [N, N] matrix and multiplies by a block-diagonal mask; here only
 // the per-graph [n_g, n_g] blocks exist (concatenated, block g at blk_off[g]), which is also what the
 // consumer slices out (train_grevnet_with_data.py:538-540).  One workgroup per (graph, 16-row tile):
-// the tile's rows sit in LDS, every lane walks the columns j of its graph (rows z_j are coalesced reads).
+// the tile's rows sit in LDS, every lane walks the columns j of its graph (rows z_j are coalesced reads).  Rows wider
+// than the LDS tile holds (D > 1024) are read from global memory instead - same order of additions, no bound on D.
 #include "gnf_common.h"
 
 namespace gnf {
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(256) void k_adj_offsets(const int32_t* __restrict__
     }
 }
 
+template <bool LDS_ROWS>
 __global__ __launch_bounds__(256) void k_pred_adj(const float* __restrict__ z, int64_t ld, int D,
                                                   const int64_t* __restrict__ node_off,
                                                   const int64_t* __restrict__ blk_off,
@@ -56,18 +58,21 @@ __global__ __launch_bounds__(256) void k_pred_adj(const float* __restrict__ z, i
     const int i0 = blockIdx.y * kDecTile;
     if (i0 >= ng) return;
     const int rows = ng - i0 < kDecTile ? ng - i0 : kDecTile;
-    for (int i = threadIdx.x; i < rows * D; i += 256) {
-        const int rl = i / D, f = i - rl * D;
-        zi[i] = z[(n0 + i0 + rl) * ld + f];
+    if constexpr (LDS_ROWS) {
+        for (int i = threadIdx.x; i < rows * D; i += 256) {
+            const int rl = i / D, f = i - rl * D;
+            zi[i] = z[(n0 + i0 + rl) * ld + f];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     float* blk = out + blk_off[g];
     for (int idx = threadIdx.x; idx < rows * ng; idx += 256) {
         const int rl = idx / ng, j = idx - rl * ng;
         const float* zj = z + (n0 + j) * ld;
+        const float* zr = LDS_ROWS ? zi + rl * D : z + (n0 + i0 + rl) * ld;
         float d2 = 0.f;
         for (int f = 0; f < D; ++f) {
-            const float df = zi[rl * D + f] - zj[f];
+            const float df = zr[f] - zj[f];
             d2 = fmaf(df, df, d2);
         }
         const float a = 10.f * (1.f - d2 * inv_sqrt_d);
@@ -103,18 +108,19 @@ int gnf_pred_adj_f32(const float* z, int64_t ld, int32_t D, const int32_t* n_nod
         set_error("gnf_pred_adj_f32: workspace %zu < %zu bytes", ws_bytes, gnf_pred_adj_workspace_bytes(n_graphs));
         return GNF_EWORKSPACE;
     }
-    if ((size_t)kDecTile * D * sizeof(float) > 64 * 1024) {
-        set_error("gnf_pred_adj_f32: D=%d too wide for the LDS row tile", D);
-        return GNF_EUNSUPPORTED;
-    }
     hipStream_t st = (hipStream_t)stream;
     int64_t* node_off = (int64_t*)ws;
     hipLaunchKernelGGL(k_adj_offsets, dim3(1), dim3(256), 0, st, n_node, n_graphs, node_off, block_off);
     GNF_LAUNCH_CHECK("k_adj_offsets");
     if (n_graphs == 0 || max_nodes_per_graph == 0) return GNF_OK;
     const unsigned tiles = (unsigned)((max_nodes_per_graph + kDecTile - 1) / kDecTile);
-    hipLaunchKernelGGL(k_pred_adj, dim3((unsigned)n_graphs, tiles), dim3(256), (size_t)kDecTile * D * sizeof(float),
-                       st, z, ld, D, node_off, block_off, out_blocks, 1.f / sqrtf((float)D));
+    const size_t row_tile = (size_t)kDecTile * D * sizeof(float);
+    if (row_tile <= 64 * 1024)
+        hipLaunchKernelGGL(k_pred_adj<true>, dim3((unsigned)n_graphs, tiles), dim3(256), row_tile, st, z, ld, D, node_off,
+                           block_off, out_blocks, 1.f / sqrtf((float)D));
+    else
+        hipLaunchKernelGGL(k_pred_adj<false>, dim3((unsigned)n_graphs, tiles), dim3(256), 0, st, z, ld, D, node_off,
+                           block_off, out_blocks, 1.f / sqrtf((float)D));
     GNF_LAUNCH_CHECK("k_pred_adj");
     return GNF_OK;
 }

@@ -291,8 +291,8 @@ int gnf_gauss_sumsq_f32(const float* z, int64_t n_nodes, int32_t D, int64_t ld, 
  * The reference builds a dense masked [N,N] matrix; only the per-graph [n_g, n_g] blocks are produced
  * here: out_blocks holds them concatenated (sum n_g^2 floats), block g starts at block_off[g]
  * (block_off: device int64[n_graphs + 1], written by this call).  max_nodes_per_graph: any upper
- * bound on n_node (sizes the launch; nothing is read from the host).  D <= 1024 (a tile of sixteen rows in 64 KB of LDS;
- * GNF_EUNSUPPORTED beyond).
+ * bound on n_node (sizes the launch; nothing is read from the host).  Any D (up to 1024 a tile of sixteen rows sits in
+ * LDS, beyond that the rows are read from global memory; same order of additions).
  * ws: gnf_pred_adj_workspace_bytes(n_graphs). */
 size_t gnf_pred_adj_workspace_bytes(int64_t n_graphs);
 int gnf_pred_adj_f32(const float* z, int64_t ld, int32_t D, const int32_t* n_node, int64_t n_graphs,

@@ -585,13 +585,13 @@ def test_attention_module_call_alone_and_isolated_nodes():
 def test_pred_adj_decoder_after_sampling(community_medium):
     """pred_adj(grevnet(sample, inverse=False), scaled_hacky_sigmoid_l2) -> per-graph edge
     probabilities (loss.py:45-53,131-159; train_grevnet_with_data.py:397-416), incl. a 1-node graph and a
-    launch bound (max_nodes_per_graph) larger than any graph."""
+    launch bound (max_nodes_per_graph) larger than any graph; d = 1100: rows wider than the kernel's LDS tile."""
     from gnf_amd.flow import pred_adj, scaled_hacky_sigmoid_l2
     rng = np.random.default_rng(4)
     n_node = np.array([17, 1, 40, 33], np.int32)
     n = int(n_node.sum())
-    for d in (2, 64, 200):
-        z = (rng.standard_normal((n, d)) * 0.7).astype(np.float32)
+    for d in (2, 64, 200, 1100):
+        z = (rng.standard_normal((n, d)) * (0.7 if d < 1000 else 0.12)).astype(np.float32)
         g = graph_from_arrays(n_node, np.zeros(4, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32), z, DEV)
         for cap in (None, 64):
             blocks = pred_adj(g, distance_fn=scaled_hacky_sigmoid_l2, max_nodes_per_graph=cap)
