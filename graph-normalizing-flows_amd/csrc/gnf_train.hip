@@ -383,6 +383,11 @@ struct WideGemmT {
     // of tiles each) instead of every eighth tile, so that an XCD's L2 holds gy / 4 A panels and gx / 2 B panels instead of
     // all gy A panels (PMC, wide_fc_train: 516 MB fetched per launch for ~100 MB of operands, L2 hit rate 0.67)
     int32_t xcd_jobs;
+    // merged training launch, stream-K plans only: the uniformly cut (thin) jobs are NOT taken by the weight-gradient
+    // workgroups behind their runs but by the launch's backward-tile workgroups once their tile and their share of the slab
+    // reduce are done (they end ~11 - 17 us before the launch does: per-workgroup stamps, CHANGELOG round 6) - cut for THEIR
+    // count, one short unit each
+    int32_t light_on_tiles;
 };
 using WideGemm = WideGemmT<kMaxGroup>;
 // what fits next to the backward kernel's arguments in one launch (4 KB of kernel arguments)
@@ -467,12 +472,15 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // M / N read whatever follows in the row; they only reach accumulators that are never stored.  The generic path
 // (any pitch / alignment) keeps the bounds-checked fetch in front of the MFMA block.
 // vblock / vgrid: this workgroup's index among the vgrid workgroups that share the launch's weight-gradient work
+// items [it0, it1) of the workgroup's list: all of them (0, INT_MAX), only its stream-K run (0, 2), or only its share of the
+// uniformly cut jobs (2, INT_MAX) - see WideGemmT.light_on_tiles
 template <bool BUF, class WG>
-__device__ __forceinline__ void dw_wide_body(const WG& g, const int vblock, const int vgrid) {
+__device__ __forceinline__ void dw_wide_body(const WG& g, const int vblock, const int vgrid, const int it0 = 0,
+                                             const int it1 = 0x7fffffff) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
     // a workgroup takes unit vblock (a chunk of one of the costliest tiles; those are cut equal) and then, strided,
     // its share of the cheap units that follow them in the list
-    for (int it = 0;; ++it) {
+    for (int it = it0; it < it1; ++it) {
     int j = 0, lt, chunk, zero_from = 0, zero_to = 0;
     int64_t kbeg, kend;
     if (g.sk_q > 0 && it < 2) {  // stream-K: this workgroup's run [a, b) of the costliest jobs' step axis
@@ -984,6 +992,7 @@ __global__ __launch_bounds__(256) void k_aggregate_bwd(const int32_t* __restrict
 // ---- workspace ---------------------------------------------------------------------------------
 struct BwdPlan {
     int K, in0, lmax, H, chunks;
+    int slab_chunks;  // slabs there is room for per job (>= chunks: thin jobs of a merged walk are cut finer, see plan_weight_grads)
     int64_t n, kchunk;
     int64_t wsum, osum;  // floats of dW / db slabs per chunk, both nets, attention weights included
     // attention geometry (0 when the nets are message-passing GNNs)
@@ -1011,6 +1020,7 @@ static inline size_t al64(size_t v) { return (v + 63) / 64 * 64; }  // keep ever
 // per half-step, i.e. no wait on the main stream at all, changed nothing in the step time (2.41 vs 2.38 ms), and a
 // captured-graph replay of the whole step is 2 % faster than eager launches: the gaps belong to the cross-queue
 // dependency itself, not to the host or to the wait packets.  The generic code below still takes any set count.)
+static constexpr int kTileLightChunks = 24;  // most pieces a thin job is cut into for the tile workgroups of a merged launch
 static constexpr int kMergedMaxTiles = 192;  // backward tiles of a launch that still leaves CUs for the dW GEMMs
 static constexpr int kLnBwdRows = 64;  // rows per workgroup of the layer-norm backward kernel
 static constexpr int kBwdMaxSets = 64;
@@ -1068,14 +1078,17 @@ static BwdPlan plan_backward(int64_t n, int32_t D, const GnfMlp* net, int n_sets
     chunks = n > 0 ? (n + kchunk - 1) / kchunk : 1;
     p.chunks = (int)chunks;
     p.kchunk = kchunk;
+    // merged walk (few tiles, nets the fused kernels hold): room for one short unit of the thin jobs per tile workgroup
+    p.slab_chunks = p.chunks;
+    if ((n + 15) / 16 <= kMergedMaxTiles && lmax < 512 && p.slab_chunks < kTileLightChunks) p.slab_chunks = kTileLightChunks;
     const size_t nk1 = (size_t)(p.K > 1 ? p.K - 1 : 0);
     size_t off = 0;
     p.g = off, off += al64((size_t)n * D);
     p.invdeg = off, off += al64((size_t)n);
     p.bnpart = off, off += al64(((size_t)kBnPartRowsMax + 1) * (size_t)p.H * 4);  // fp64 pairs of the batch-norm backward (+ one row: this rank's sums under cross-rank moments)
     p.st = off, off += 2 * al64((size_t)n * p.H);
-    p.wslab = off, off += al64((size_t)chunks * p.wsum);
-    p.bslab = off, off += al64((size_t)chunks * p.osum);
+    p.wslab = off, off += al64((size_t)p.slab_chunks * p.wsum);
+    p.bslab = off, off += al64((size_t)p.slab_chunks * p.osum);
     p.slab_stride = off - p.wslab;
     p.slab_sets = (n + 15) / 16 <= kMergedMaxTiles ? 2 : 1;
     off += (size_t)(p.slab_sets - 1) * p.slab_stride;
@@ -1232,6 +1245,8 @@ struct DwPolicy {
     size_t lds;
     double budget_us;
     bool big_tiles_only = false;  // only the jobs with the most tiles count as "costliest" (see dw_policy, generic backward)
+    int tile_wgs = 0;  // > 0: the launch that carries this plan has that many backward-tile workgroups with time to spare
+                       // (merged walk with the MLP-row stash): a stream-K plan hands them the thin jobs (WideGemmT.light_on_tiles)
 };
 
 // The fused backward kernel of the NEXT half-step runs beside this half-step's dW GEMMs (one 16-node tile per
@@ -1309,8 +1324,8 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
     int64_t woff = 0, boff = 0;
     for (int e = 0; e < nj; ++e) {
         const WGJob& j = jobs[e];
-        float* wsl = ws + p.wslab + (size_t)p.chunks * woff;
-        float* bsl = j.gb ? ws + p.bslab + (size_t)p.chunks * boff : nullptr;
+        float* wsl = ws + p.wslab + (size_t)p.slab_chunks * woff;
+        float* bsl = j.gb ? ws + p.bslab + (size_t)p.slab_chunks * boff : nullptr;
         gg.job[e] = GemmJob{j.A, j.B, wsl, nullptr, bsl};
         gg.lda[e] = j.lda;
         gg.ldb[e] = j.ldb;
@@ -1411,6 +1426,7 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
         // workgroups with 43 steps each; as one axis of 24 x 85 steps it is 64 workgroups with 32 steps each)
         const int sk_steps = (int)((p.n + WGK - 1) / WGK);
         int sk_q = 0, sk_grid = 0, sk_cmax = 0;
+        bool sk_on_tiles = false;
         if (c_heavy > 0 && heavy_tiles > 0 && heavy_tiles <= pol.max_units && sk_steps >= 8) {
             sk_grid = pol.max_units;
             const int64_t total_steps = (int64_t)heavy_tiles * sk_steps;
@@ -1423,14 +1439,20 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
             }
             const double sk_us = (double)cmax / 16.0 * sk_q * 2.0 + 2 * 4.0 + 2.0;
             double light_us = 0.0;
-            int cl = light_tiles > 0 ? sk_grid / light_tiles : 1;
-            cl = cl < 1 ? 1 : (cl > p.chunks ? p.chunks : cl);
+            // (the thin jobs go to the tile workgroups of the carrying launch where it has them: cut for their count)
+            const bool on_tiles = pol.tile_wgs > 0 && light_tiles > 0;
+                        // (0.6 / 0.8 / 1.0 / 1.2 units per tile workgroup: 1.874 / 1.862 / 1.858 / 1.903 ms per config2_train step)
+            int cl = light_tiles > 0 ? (on_tiles ? pol.tile_wgs : sk_grid) / light_tiles : 1;
+            const int cl_max = on_tiles ? p.slab_chunks : p.chunks;
+            cl = cl < 1 ? 1 : (cl > cl_max ? cl_max : cl);
             for (int e = 0; e < nj; ++e)
                 if (cost[e] != cmax)
                     light_us += tiles_of[e] * cl * ((double)cost[e] / 16.0 * (double)p.n / cl / 32.0 * 2.1 + 4.0);
-            const double sk_est = sk_us + light_us / sk_grid;
+            const double sk_est = on_tiles ? sk_us : sk_us + light_us / sk_grid;
+            sk_on_tiles = on_tiles;
             if (sk_q > sk_steps || sk_cmax > p.chunks || sk_est >= est_us) {
                 sk_q = 0;  // not better than whole chunks (or the slabs were not planned for that many pieces)
+                sk_on_tiles = false;
             } else {
                 est_us = sk_est;
                 c_light = cl;
@@ -1494,6 +1516,7 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
             if (sk_q > 0) {
                 wg.sk_q = sk_q, wg.sk_steps = sk_steps, wg.sk_tiles = heavy_tiles, wg.sk_jobs = sk_jobs;
                 wg.sk_light_base = wg.unit_base[sk_jobs];
+                wg.light_on_tiles = sk_on_tiles ? 1 : 0;
                 units = grid;
             } else {
                 units = grid < units ? grid : units;  // workgroups; units past the grid are picked up by stride
@@ -1592,6 +1615,7 @@ template <int MT, bool STASHED>
 __global__ __launch_bounds__(kBwdThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_half_bwd_dw(const BwdArgs a, const WideGemmS g, const GroupedReduceS r, const int n_bwd, const int n_dw, const int r_nj) {
     const int bid = (int)blockIdx.x;
+    int vb = -1, vg = 1, it0 = 0, it1 = 0x7fffffff;  // this workgroup's place in the weight-gradient work (vb < 0: none)
     if (bid < n_bwd) {
         half_bwd_body<MT, STASHED>(a, bid, n_bwd);
         // the tiles finish before the dW workgroups do (with the MLP-row stash after about 60 % of their time): the slab
@@ -1599,12 +1623,22 @@ void k_half_bwd_dw(const BwdArgs a, const WideGemmS g, const GroupedReduceS r, c
         // (recomputing tiles are the longer side: there the reduce stays with the dW workgroups - 2.18 vs 2.29 ms per step)
         if (STASHED && r_nj > 0)
             reduce_jobs_strided(r, r_nj, (int64_t)bid * kBwdThreads + threadIdx.x, (int64_t)n_bwd * kBwdThreads);
-        return;
+        if (!STASHED || !g.light_on_tiles) return;
+        __syncthreads();  // (the tile's last rows have left the LDS buffers the operand stages overlay)
+        // (units are dealt from the LAST tile workgroup down: where there are fewer units than workgroups, the ones left
+        // without are the first ones - whose threads carry the second round of the strided reduce above)
+        vb = n_bwd - 1 - bid, vg = n_bwd, it0 = 2;
+    } else {
+        const int v = bid - n_bwd;
+        if (v < n_dw) {
+            vb = v, vg = n_dw;
+            if (STASHED && g.light_on_tiles && n_bwd > 0) it1 = 2;
+        }
     }
-    const int v = bid - n_bwd;
-    if (v < n_dw) dw_wide_body<true>(g, v, n_dw);
-    if (r_nj > 0 && (!STASHED || n_bwd == 0))
-        reduce_jobs_strided(r, r_nj, (int64_t)v * kBwdThreads + threadIdx.x, (int64_t)((int)gridDim.x - n_bwd) * kBwdThreads);
+    if (vb >= 0) dw_wide_body<true>(g, vb, vg, it0, it1);
+    if (bid >= n_bwd && r_nj > 0 && (!STASHED || n_bwd == 0))
+        reduce_jobs_strided(r, r_nj, (int64_t)(bid - n_bwd) * kBwdThreads + threadIdx.x,
+                            (int64_t)((int)gridDim.x - n_bwd) * kBwdThreads);
 }
 static_assert(kBwdThreads == kWideThreads, "the merged launch runs both bodies with one workgroup size");
 static_assert(sizeof(BwdArgs) + sizeof(WideGemmS) + sizeof(GroupedReduceS) + 16 <= 4096, "kernel arguments exceed 4 KB");
@@ -1623,6 +1657,7 @@ static void narrow_wide(const WideGemm& w, WideGemmS* o) {
     o->sk_q = w.sk_q, o->sk_steps = w.sk_steps, o->sk_tiles = w.sk_tiles, o->sk_jobs = w.sk_jobs;
     o->sk_light_base = w.sk_light_base;
     o->xcd_jobs = 0;
+    o->light_on_tiles = w.light_on_tiles;
 }
 static void narrow_reduce(const GroupedReduce& r, int nj, GroupedReduceS* o) {
     memset(o, 0, sizeof(*o));
@@ -2303,7 +2338,8 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 const int cus = big_cu_count();
                 int room = last ? cus : cus - (int)tiles;   // CUs the backward tiles of the NEXT launch leave
                 if (const int64_t force = opt(OPT_DW_WIDE_UNITS)) room = force < room ? (int)force : room;  // (shape forcing for the parity tests)
-                const DwPolicy pol{room, lds, 1e30};
+                DwPolicy pol{room, lds, 1e30};
+                if (mstashed && !last) pol.tile_wgs = (int)tiles;  // (the launch that carries this plan walks the next half-step)
                 rc = plan_weight_grads(p, pol, jobs, nj, acc, wsf, cur, &pend[cur]);
                 if (rc) return rc;
                 pend_ok[cur] = pend[cur].wide && pend[cur].buf && nj <= kMergedGroup;
