@@ -2,6 +2,7 @@
 // kernels: the per-wave MLP chunk loop on the exact-fp32 matrix cores with weights streamed from L2 in
 // packed fragment order.  See gnf_fused.hip for the design notes.
 #pragma once
+#include <type_traits>
 #include "gnf_common.h"
 
 namespace gnf {
@@ -129,6 +130,14 @@ __device__ __forceinline__ void prefetch_chunk(const WChunk& c, int ts, int voff
             const int tb = b < c.nv ? b : c.nv - 1;
             b_pre[u][b] = GNF_LOAD_B(rsrc, voff, (kn * c.ont + c.nt0 + ts * tb) * 1024);
         }
+    }
+}
+
+template <int N, class F>
+__device__ __forceinline__ void epi_static_for(F&& f) {  // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+    if constexpr (N > 0) {
+        epi_static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
     }
 }
 
@@ -290,34 +299,55 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
 #undef GNF_MFMA_STAGE
     // accumulator layout: col = lane&15, row = 4*(lane>>4) + r.  slope: 1 on the last (linear) layer,
     // alpha (leaky) or 0 (relu) otherwise: max(v, slope*v) is branch-free for all three.
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int b = 0; b < NV; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
+    // EPI_EX: the chunk's MT * NV * 4 mask words travel through ONE register pair - lane e holds the word of accumulator
+    // element e = 4 (NV m + b) + r.  Mode 0 drops each ballot into its lane (v_writelane) and the first lanes store their
+    // words at the end; mode 1 has those lanes fetch the words up front and every element reads its word back as a scalar
+    // pair, which IS the lane mask of the select.  (One exec-masked 8-byte store, or one broadcast read + 64-bit shift,
+    // per element cost the training forward 0.85 us per hidden layer: stamps, CHANGELOG round 6.)
+    [[maybe_unused]] int mlo = 0, mhi = 0;
+    [[maybe_unused]] int my_word = 0;
+    if constexpr (EPI == EPI_EX) {
+        const int e = lane < MT * NV * 4 ? lane : 0;
+        const int em = e / (4 * NV), eb = (e >> 2) % NV, er = e & 3;
+        my_word = (4 * em + er) * ea.mld + nt0 + ts * eb;
+        if (ea.mode != 0) {
+            unsigned long long w = ~0ull;
+            if (ea.mask != nullptr && lane < MT * NV * 4) w = ea.mask[my_word];
+            mlo = (int)(unsigned)w, mhi = (int)(unsigned)(w >> 32);
+        }
+    }
+    epi_static_for<MT * NV * 4>([&](auto e_c) {
+                constexpr int e = decltype(e_c)::value;
+                constexpr int m = e / (4 * NV), b = (e >> 2) % NV, r = e & 3;
                 const float v = acc[m][b][r];
                 const int rl = 16 * m + 4 * lgrp + r, col = 16 * (nt0 + ts * b) + lrow;
                 if (EPI == EPI_PLAIN) {
                     out_lds[rl * LS + col] = fmaxf(v, slope * v);
                 } else {
-                    const int word = (4 * m + r) * ea.mld + nt0 + ts * b;
                     float o;
                     if (ea.mode == 0) {
                         o = fmaxf(v, slope * v);
-                        if (ea.mask) {
-                            const unsigned long long bal = __ballot(o > 0.f);
-                            if (lane == 0) ea.mask[word] = bal;
-                        }
+                        const unsigned long long bal = __ballot(o > 0.f);
+                        // (gfx940+: a VALU that reads an SGPR another VALU has just written needs two wait states; the compiler
+                        // inserts them for its own instructions, not in front of inline assembly)
+                        asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+                                     : "+v"(mlo), "+v"(mhi)
+                                     : "s"((int)(unsigned)bal), "s"((int)(unsigned)(bal >> 32)), "n"(e));
                     } else {
-                        const bool keep = ea.mask == nullptr || ((ea.mask[word] >> lane) & 1ull);
-                        o = keep ? v : v * ea.act_slope;
+                        const unsigned long long keep = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(mhi, e) << 32) |
+                                                        (unsigned)__builtin_amdgcn_readlane(mlo, e);
+                        const float vs = v * ea.act_slope;
+                        asm volatile("s_nop 1\n\tv_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(o) : "v"(vs), "v"(v), "s"(keep));
                     }
                     out_lds[rl * LS + col] = o;
                     if (ea.dump && ea.row0 + rl < ea.n_nodes && col < ea.width)
                         ea.dump[(int64_t)(ea.row0 + rl) * ea.dld + col] = o;
                 }
-            }
+            });
+    if constexpr (EPI == EPI_EX) {
+        if (ea.mode == 0 && ea.mask != nullptr && lane < MT * NV * 4)
+            ea.mask[my_word] = ((unsigned long long)(unsigned)mhi << 32) | (unsigned)mlo;
+    }
 }
 
 
