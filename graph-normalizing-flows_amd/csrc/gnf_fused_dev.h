@@ -316,14 +316,24 @@ __device__ __forceinline__ void mlp_chunk(const float* __restrict__ in_lds, int 
             mlo = (int)(unsigned)w, mhi = (int)(unsigned)(w >> 32);
         }
     }
+    if constexpr (EPI == EPI_PLAIN) {  // (the inference kernels' epilogue, as it has always been)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int b = 0; b < NV; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[m][b][r];
+                    const int rl = 16 * m + 4 * lgrp + r, col = 16 * (nt0 + ts * b) + lrow;
+                    out_lds[rl * LS + col] = fmaxf(v, slope * v);
+                }
+    } else
     epi_static_for<MT * NV * 4>([&](auto e_c) {
                 constexpr int e = decltype(e_c)::value;
                 constexpr int m = e / (4 * NV), b = (e >> 2) % NV, r = e & 3;
                 const float v = acc[m][b][r];
                 const int rl = 16 * m + 4 * lgrp + r, col = 16 * (nt0 + ts * b) + lrow;
-                if (EPI == EPI_PLAIN) {
-                    out_lds[rl * LS + col] = fmaxf(v, slope * v);
-                } else {
+                {
                     float o;
                     if (ea.mode == 0) {
                         o = fmaxf(v, slope * v);
