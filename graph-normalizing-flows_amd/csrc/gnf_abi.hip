@@ -14,7 +14,7 @@ static thread_local char g_err[512] = "";
 std::atomic<int64_t> g_options[OPT_COUNT];  // zero-initialised: every option "auto"
 
 static const char* const kOptionNames[OPT_COUNT] = {
-    "force_shape", "attn_kernel", "attn_bwd_rows", "bwd_generic", "dw_grouped", "dw_wide_units"};
+    "force_shape", "attn_kernel", "attn_bwd_rows", "bwd_generic", "dw_grouped", "dw_wide_units", "dw_thin_on_dw"};
 
 static int option_index(const char* name) {
     if (!name) return -1;

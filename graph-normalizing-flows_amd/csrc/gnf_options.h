@@ -23,6 +23,7 @@ enum OptionId {
     OPT_BWD_GENERIC,         // backward pass through the generic GEMM path even where the fused kernel fits
     OPT_DW_GROUPED,          // weight gradients: always the grouped kernel (on the auxiliary stream, not inside the backward launch)
     OPT_DW_WIDE_UNITS,       // weight gradients: wide kernel with this many workgroups at most
+    OPT_DW_THIN_ON_DW,       // merged backward + dW launch: 1 = the thin layers' units stay with the dW workgroups (not the tile workgroups)
     OPT_COUNT
 };
 

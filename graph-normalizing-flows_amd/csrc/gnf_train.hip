@@ -2339,7 +2339,7 @@ int gnf_grevnet_backward_f32(const GnfCsr* csr, const GnfCsr* csr_t, const GnfFl
                 int room = last ? cus : cus - (int)tiles;   // CUs the backward tiles of the NEXT launch leave
                 if (const int64_t force = opt(OPT_DW_WIDE_UNITS)) room = force < room ? (int)force : room;  // (shape forcing for the parity tests)
                 DwPolicy pol{room, lds, 1e30};
-                if (mstashed && !last) pol.tile_wgs = (int)tiles;  // (the launch that carries this plan walks the next half-step)
+                if (mstashed && !last && !opt(OPT_DW_THIN_ON_DW)) pol.tile_wgs = (int)tiles;  // (the launch that carries this plan walks the next half-step)
                 rc = plan_weight_grads(p, pol, jobs, nj, acc, wsf, cur, &pend[cur]);
                 if (rc) return rc;
                 pend_ok[cur] = pend[cur].wide && pend[cur].buf && nj <= kMergedGroup;

@@ -199,7 +199,7 @@ typedef struct GnfFlow {
 } GnfFlow;
 
 int gnf_abi_version(void);
-/* Launch-shape forcing (ABI v6; the list was cut from 18 A/B switches to these 6 in round 4).  The library picks its kernel
+/* Launch-shape forcing (ABI v6; the list was cut from 18 A/B switches to 6 in round 4, a 7th came in round 6).  The library picks its kernel
  * instances by batch size; the parity tests force them on small batches through these named integers.  value 0 =
  * automatic.  force_shape: fused forward workgroup shape <MT><NETS>, e.g. 21; 40 / 30 / 20 / 10: the large-batch kernel
  * with that many row tiles per workgroup at most (49: cap 4 with the split row tiles' hand-over flag withheld - fault
@@ -207,6 +207,8 @@ int gnf_abi_version(void);
  * (either keeps the front-end out of the fused kernel's prologue).  attn_bwd_rows: 64 / 32 / 16 / 3264 rows per workgroup
  * of the attention rows / edge kernels.  bwd_generic: the backward pass through the generic GEMM path.  dw_grouped: weight
  * gradients through the grouped kernel.  dw_wide_units: the wide weight-gradient kernel with that many workgroups at most.
+ * dw_thin_on_dw: 1 = in the merged backward + weight-gradient launch of a training step with the MLP-row stash, the thin first /
+ * last layers' units stay with the weight-gradient workgroups instead of the backward-tile workgroups (the round-5 dealing).
  * Process-wide, relaxed atomics: takes effect for calls made after it returns.  Unknown name: GNF_EINVAL.  Nothing in the
  * reference corresponds to these. */
 int gnf_set_option(const char* name, int64_t value);

@@ -154,6 +154,48 @@ def test_mlp_row_stash_matches_the_recomputing_walk(community_medium, flavour):
     assert abs(res[True][1] - res[False][1]) <= 1e-9 * abs(res[False][1])      # the same forward arithmetic
 
 
+@pytest.mark.parametrize("gnn_kind", ["avg_then_mlp", "dm_self_attn"])
+@pytest.mark.parametrize("graphs", [10, 30, 52, 73])
+def test_merged_launch_thin_units_over_batch_sizes(community_medium, graphs, gnn_kind):
+    """The merged backward + dW launch of the stash walk hands the thin layers' weight-gradient units to its backward-tile
+    workgroups (WideGemmT.light_on_tiles, round 6): about 25 / 75 / 130 / 185 tiles beside 224 / 160 / 96 / 64 dW
+    workgroups, thin jobs cut for the tile count.  Reference: the same walk with the units left on the dW workgroups
+    (option dw_thin_on_dw, the round-5 dealing, pinned to the oracle by the tests above) - same stash, same activations,
+    only the cut of the node axis of the thin layers' sums differs: gradients equal to rounding."""
+    from gnf_amd import _abi
+    from gnf_amd.train import GRevNetTrainer
+    rng = np.random.default_rng(graphs)
+    nn, ne, s, r = _batch(community_medium, rng.choice(168, size=graphs, replace=False))
+    n = int(nn.sum())
+    assert (n + 15) // 16 <= 192
+    if gnn_kind == "dm_self_attn":
+        attn = dict(num_heads=8, kq_dim=10, v_dim=10, out_dim=80, concat=True, kq_dim_division=True, residual=False)
+        hp = dict(D=64, latent=256, K=5, T=2, agg="mean", combine="agg", epsilon=0.0, activation="relu", weight_sharing=False,
+                  attn=attn)
+        p = O.make_attn_grevnet_params(7, 32, 256, 5, 2, weight_sharing=False, final_scale=0.3, **attn)
+    else:
+        hp = dict(D=64, latent=256, K=5, T=2, agg="mean", combine="agg", epsilon=1.0, activation="leaky_relu", weight_sharing=False)
+        p = O.make_grevnet_params(7, 32, 256, 5, 2, final_scale=0.3)
+    x = rng.standard_normal((n, 64)).astype(np.float32)
+    graph = graph_from_arrays(nn, ne, s, r, x, DEV)
+    res = {}
+    try:
+        for on_dw in (0, 1):
+            _abi.set_option("dw_thin_on_dw", on_dw)
+            tr = GRevNetTrainer(make_product_grevnet(hp, p))
+            out = tr.loss_and_grads(graph)
+            torch.cuda.synchronize()
+            assert tr._mlp_stash is not None
+            np.testing.assert_allclose(out["reconstruction"].cpu().numpy(), x, atol=3e-4, rtol=3e-4)
+            res[on_dw] = (tr.grad.detach().cpu().numpy().copy(), float(out["total_loss"]))
+    finally:
+        _abi.set_option("dw_thin_on_dw", 0)
+    assert np.isfinite(res[0][0]).all()
+    scale = float(np.abs(res[1][0]).max())
+    assert float(np.abs(res[0][0] - res[1][0]).max()) <= 1e-5 * scale
+    assert res[0][1] == res[1][1]
+
+
 def test_mlp_row_stash_is_not_offered_where_it_would_not_be_used(community_medium, grid_small):
     """gnf_mlp_stash_bytes: 0 for batches of more than 256 16-node tiles and for blocks that end in snt.LayerNorm (their
     half-steps run one net per workgroup); attention nets without it do get one."""
