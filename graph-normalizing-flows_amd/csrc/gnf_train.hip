@@ -848,9 +848,10 @@ __device__ __forceinline__ T sum_slabs(const float* __restrict__ slab, const int
 __host__ __device__ inline bool reduce_job_vec_ok(const ReduceJob& job, int64_t nw) {
     return (nw & 3) == 0 && ((reinterpret_cast<uintptr_t>(job.wslab) | reinterpret_cast<uintptr_t>(job.gw)) & 15) == 0;
 }
-// fills GroupedReduceT.qpre / singles for the first nj jobs (call after the last change to job / nw / nb)
+// fills GroupedReduceT.qpre / singles for the first nj jobs (call after the last change to job / nw / nb); false: the index
+// space does not fit 31 bits (more than 8.6 G weight-gradient elements in one launch)
 template <class GR>
-static void reduce_index_space(GR* g, int nj) {
+static bool reduce_index_space(GR* g, int nj) {
     constexpr int G = (int)(sizeof(g->chunks) / sizeof(g->chunks[0]));
     int64_t quads = 0, singles = 0;
     for (int j = 0; j < G; ++j) {
@@ -864,6 +865,7 @@ static void reduce_index_space(GR* g, int nj) {
     }
     g->qpre[G] = (int32_t)quads;
     g->singles = (int32_t)singles;
+    return quads <= INT32_MAX && singles <= INT32_MAX;
 }
 template <class GR>
 __device__ __forceinline__ void reduce_jobs_strided(const GR& g, const int nj, const int64_t t, const int64_t nthr) {
@@ -1544,7 +1546,10 @@ static int plan_weight_grads(const BwdPlan& p, const DwPolicy& pol, const WGJob*
     const bool wide_direct = wide && L->direct;
     L->wide = wide;
     L->units = units;
-    reduce_index_space(&gr, nj);
+    if (!reduce_index_space(&gr, nj)) {
+        set_error("weight gradients: %d jobs with more than 2^31 reduce items in one launch", nj);
+        return GNF_EUNSUPPORTED;
+    }
     L->maxred = maxred;
     L->direct = wide_direct;
     L->buf = false;
@@ -1685,7 +1690,7 @@ static void narrow_reduce(const GroupedReduce& r, int nj, GroupedReduceS* o) {
         o->nw[q] = r.nw[q], o->nb[q] = r.nb[q], o->chunks[q] = r.chunks[q];
     }
     o->accumulate = r.accumulate;
-    reduce_index_space(o, nj < kMergedGroup ? nj : kMergedGroup);
+    (void)reduce_index_space(o, nj < kMergedGroup ? nj : kMergedGroup);  // (a subset of a plan that fitted)
 }
 
 // bwd: the half-step to walk (NULL: none - the tail of the pipeline); dw: GEMMs to run beside it (NULL: none);
